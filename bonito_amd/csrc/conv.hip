@@ -1,0 +1,190 @@
+// 1-D convolution front-end for gfx950 (replaces cuDNN behind bonito.nn.Convolution,
+// /root/reference bonito/nn.py:222-241, with BatchNorm already folded as nn.py:447-454 does).
+//
+// Activations between convolutions are kept CHANNEL-MINOR ([N][L][C] fp16). With that layout the
+// im2col row of output position t -- all (k, c) taps -- is ONE contiguous run of K*Cin halves
+// starting at input position t*stride - pad, so the convolution is an implicit GEMM whose B
+// fragments are plain 16-byte LDS reads with no gather:
+//     out[t][f] = sum_{kk < K*Cin} Wp[f][kk] * in_flat[(t*stride - pad)*Cin + kk]
+// Wp is the conv weight re-packed [Cout][k*Cin + c] and zero-padded to a multiple of 32.
+//
+//  * bh_k_conv_first : Cin == 1 (raw signal, [N][L] fp16) on the VALU, writes channel-minor.
+//  * bh_k_conv_igemm : Cin % 8 == 0 on MFMA 16x16x32 f16; W is the A operand so a lane owns 4
+//    consecutive output features of one position (8-byte packed stores, lane-local epilogue).
+//    The output may be written NTC ([N][T][C]) or TNC ([T][N][C], what the LSTM stack consumes;
+//    this folds nn.Permute([2,0,1]), nn.py:331-338, into the store).
+#include "common.h"
+#include "kernels.h"
+
+namespace bh {
+
+// ---------------------------------------------------------------------------------------------
+struct ConvFirstArgs {
+    const half_t* sig;  // [N][Lin]
+    const float* w;     // [Cout][K]
+    const float* bias;  // [Cout]
+    half_t* out;
+    int N, Lin, Lout, Cout, K, stride, pad, act;
+    float clamp_lo, clamp_hi;
+    long os_n, os_t;
+};
+
+__global__ __launch_bounds__(256) void conv_first_kernel(ConvFirstArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* wl = (float*)smem;           // [Cout][K]
+    float* bl = wl + p.Cout * p.K;      // [Cout]
+    float* sl = bl + p.Cout;            // signal span of this workgroup, zero padded
+    const int n = blockIdx.y;
+    const int tb = blockIdx.x * 256;
+    const int span = 255 * p.stride + p.K;
+    const half_t* s = p.sig + (long)n * p.Lin;
+    for (int i = threadIdx.x; i < p.Cout * p.K; i += 256) wl[i] = p.w[i];
+    for (int i = threadIdx.x; i < p.Cout; i += 256) bl[i] = p.bias ? p.bias[i] : 0.0f;
+    for (int i = threadIdx.x; i < span; i += 256) {
+        int pos = tb * p.stride - p.pad + i;
+        sl[i] = (pos >= 0 && pos < p.Lin) ? (float)s[pos] : 0.0f;
+    }
+    __syncthreads();
+    const int t = tb + threadIdx.x;
+    if (t >= p.Lout) return;
+    const float* x = sl + threadIdx.x * p.stride;
+    half_t* dst = p.out + (long)n * p.os_n + (long)t * p.os_t;
+    for (int c0 = 0; c0 < p.Cout; c0 += 8) {
+        half8_t o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float* wr = wl + (c0 + j) * p.K;
+            float a = bl[c0 + j];
+            for (int k = 0; k < p.K; ++k) a = fmaf(wr[k], x[k], a);
+            a = apply_act_rt(a, p.act);
+            a = fminf(fmaxf(a, p.clamp_lo), p.clamp_hi);
+            o[j] = (half_t)a;
+        }
+        *(half8_t*)(dst + c0) = o;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+struct ConvArgs {
+    const half_t* in;   // [N][Lin][Cin]
+    const half_t* wpk;  // [Cout16][Kp]
+    const float* bias;  // [Cout]
+    half_t* out;
+    int N, Lin, Lout, Cin, Cout, K, stride, pad, act;
+    int Kp;             // padded K*Cin (multiple of 32)
+    float clamp_lo, clamp_hi;
+    long os_n, os_t;
+};
+
+template <int NTT>  // position tiles (of 16) per wave
+__global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    half_t* xin = (half_t*)smem;
+    constexpr int PW = NTT * 16;
+    constexpr int PB = 4 * PW;  // positions per workgroup
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 15, kg = lane >> 4;
+    const int n = blockIdx.y;
+    const int t0 = blockIdx.x * PB;
+
+    // ---- stage the contiguous input span (zero outside [0, Lin)) -----------------------------
+    const int span_pos = (PB - 1) * p.stride + p.K;
+    const int span_halves = span_pos * p.Cin + 32 + 8;  // tail read by the zero-padded K columns
+    const int p_start = t0 * p.stride - p.pad;
+    const half_t* src = p.in + (long)n * p.Lin * p.Cin;
+    for (int e = tid * 8; e < span_halves; e += 256 * 8) {
+        int pos = p_start + e / p.Cin;
+        uint4_t v = {0, 0, 0, 0};
+        if (pos >= 0 && pos < p.Lin && e < span_pos * p.Cin)
+            v = *(const uint4_t*)(src + (long)pos * p.Cin + (e % p.Cin));
+        *(uint4_t*)(xin + e) = v;
+    }
+    __syncthreads();
+
+    const int nks = p.Kp >> 5;
+    const int nft = (p.Cout + 15) >> 4;
+    int boff[NTT];
+#pragma unroll
+    for (int tt = 0; tt < NTT; ++tt)
+        boff[tt] = (wave * PW + tt * 16 + r) * p.stride * p.Cin + kg * 8;
+
+    for (int ft = 0; ft < nft; ++ft) {
+        float4_t acc[NTT];
+#pragma unroll
+        for (int tt = 0; tt < NTT; ++tt) acc[tt] = float4_t{0.f, 0.f, 0.f, 0.f};
+        const half_t* wrow = p.wpk + (long)(ft * 16 + r) * p.Kp + kg * 8;
+        for (int ks = 0; ks < nks; ++ks) {
+            half8_t a = *(const half8_t*)(wrow + ks * 32);
+#pragma unroll
+            for (int tt = 0; tt < NTT; ++tt) {
+                half8_t b = *(const half8_t*)(xin + boff[tt] + ks * 32);
+                acc[tt] = mfma16(a, b, acc[tt]);
+            }
+        }
+        const int f = ft * 16 + kg * 4;
+        if (f < p.Cout) {
+            float bv[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) bv[g] = (p.bias && f + g < p.Cout) ? p.bias[f + g] : 0.0f;
+#pragma unroll
+            for (int tt = 0; tt < NTT; ++tt) {
+                int t = t0 + wave * PW + tt * 16 + r;
+                if (t >= p.Lout) continue;
+                half4_t o;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    float x = apply_act_rt(acc[tt][g] + bv[g], p.act);
+                    x = fminf(fmaxf(x, p.clamp_lo), p.clamp_hi);
+                    o[g] = (half_t)x;
+                }
+                half_t* dst = p.out + (long)n * p.os_n + (long)t * p.os_t + f;
+                if (f + 4 <= p.Cout) *(half4_t*)dst = o;
+                else
+                    for (int g = 0; g < 4; ++g)
+                        if (f + g < p.Cout) dst[g] = o[g];
+            }
+        }
+    }
+}
+
+}  // namespace bh
+
+int bh_k_conv_first(const void* signal, const float* w, const float* bias, void* out, int N, int Lin,
+                    int Lout, int Cout, int K, int stride, int pad, int act, float clamp_lo,
+                    float clamp_hi, long os_n, long os_t, hipStream_t stream) {
+    using namespace bh;
+    BH_REQUIRE(K <= 32 && Cout % 8 == 0, "conv_first: need K<=32 and Cout%%8==0 (K=%d Cout=%d)", K, Cout);
+    BH_REQUIRE(os_t % 8 == 0 && os_n % 8 == 0, "conv_first: output strides must be multiples of 8");
+    ConvFirstArgs a{(const half_t*)signal, w, bias, (half_t*)out, N, Lin, Lout, Cout, K, stride, pad,
+                    act, clamp_lo, clamp_hi, os_n, os_t};
+    size_t lds = (size_t)(Cout * K + Cout + 255 * stride + K) * sizeof(float);
+    hipLaunchKernelGGL(conv_first_kernel, dim3((Lout + 255) / 256, N), dim3(256), lds, stream, a);
+    BH_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+int bh_k_conv_igemm(const void* in, const void* wpk, const float* bias, void* out, int N, int Lin,
+                    int Lout, int Cin, int Cout, int K, int stride, int pad, int act, float clamp_lo,
+                    float clamp_hi, long os_n, long os_t, hipStream_t stream) {
+    using namespace bh;
+    BH_REQUIRE(Cin % 8 == 0 && Cout % 4 == 0, "conv_igemm: need Cin%%8==0, Cout%%4==0 (Cin=%d Cout=%d)", Cin, Cout);
+    BH_REQUIRE(os_t % 4 == 0 && os_n % 4 == 0, "conv_igemm: output strides must be multiples of 4");
+    ConvArgs a{(const half_t*)in, (const half_t*)wpk, bias, (half_t*)out, N, Lin, Lout, Cin, Cout, K,
+               stride, pad, act, ((K * Cin + 31) / 32) * 32, clamp_lo, clamp_hi, os_n, os_t};
+    auto lds_for = [&](int pw) { return (size_t)(((4 * pw - 1) * stride + K) * Cin + 40) * 2 + 16; };
+    int pw = 64;
+    while (pw > 16 && lds_for(pw) > 64 * 1024) pw >>= 1;
+    size_t lds = lds_for(pw);
+    BH_REQUIRE(lds <= 160 * 1024, "conv_igemm: input span does not fit LDS (%zu bytes)", lds);
+    dim3 grid((Lout + 4 * pw - 1) / (4 * pw), N);
+    if (lds > 64 * 1024) {
+        const void* fn = pw == 64 ? (const void*)conv_igemm_kernel<4>
+                         : pw == 32 ? (const void*)conv_igemm_kernel<2> : (const void*)conv_igemm_kernel<1>;
+        BH_CHECK_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    }
+    if (pw == 64) hipLaunchKernelGGL(conv_igemm_kernel<4>, grid, dim3(256), lds, stream, a);
+    else if (pw == 32) hipLaunchKernelGGL(conv_igemm_kernel<2>, grid, dim3(256), lds, stream, a);
+    else hipLaunchKernelGGL(conv_igemm_kernel<1>, grid, dim3(256), lds, stream, a);
+    BH_CHECK_HIP(hipGetLastError());
+    return 0;
+}

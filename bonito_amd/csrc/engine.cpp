@@ -1,0 +1,489 @@
+// Host side of libbonito_hip.so: error plumbing, weight packing, the encoder engine (a linear chain
+// of layers executed as hand-written HIP kernels on one stream) and the thin extern "C" shells
+// declared in include/bonito_hip.h.
+//
+// The engine is the MI355X replacement for what the reference obtains from
+// koi.lstm.update_graph + cuDNN/cuBLAS under SeqdistModel.forward
+// (/root/reference bonito/crf/model.py:193-194,240-246): it owns fp16 copies of the weights,
+// all activation workspace (sized once for max_batch x max_chunk; HBM is 288 GB so nothing is
+// re-allocated per batch) and runs conv -> [permute folded] -> LSTM x L -> LinearCRFEncoder
+// [-> clamp folded] writing NTC fp16 scores straight into the caller's buffer.
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <cmath>
+#include <string>
+#include <vector>
+
+#include "../../include/bonito_hip.h"
+#include "common.h"
+#include "kernels.h"
+
+// ------------------------------------------------------------------------------------------------
+static thread_local char g_err[1024] = "";
+void bh_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+extern "C" const char* bh_last_error(void) { return g_err; }
+extern "C" int bh_abi_version(void) { return BH_ABI_VERSION; }
+extern "C" int bh_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+        bh_set_error("hipGetDeviceCount failed");
+        return -1;
+    }
+    return n;
+}
+
+// ------------------------------------------------------------------------------------------------
+// fp32 -> fp16 bits, round-to-nearest-even (host)
+static inline uint16_t f2h(float f) {
+    _Float16 h = (_Float16)f;
+    uint16_t u;
+    memcpy(&u, &h, 2);
+    return u;
+}
+
+extern "C" size_t bh_conv1d_packed_halves(int Cin, int Cout, int K) {
+    size_t kp = ((size_t)K * Cin + 31) / 32 * 32;
+    size_t c16 = ((size_t)Cout + 15) / 16 * 16;
+    return kp * c16;
+}
+// torch conv weight [Cout][Cin][K] -> [Cout16][Kp], column index = k*Cin + c (channel-minor taps)
+extern "C" int bh_conv1d_pack(const float* w, int Cin, int Cout, int K, uint16_t* packed) {
+    BH_REQUIRE(w && packed && Cin > 0 && Cout > 0 && K > 0, "conv1d_pack: bad arguments");
+    size_t kp = ((size_t)K * Cin + 31) / 32 * 32;
+    size_t c16 = ((size_t)Cout + 15) / 16 * 16;
+    memset(packed, 0, kp * c16 * 2);
+    for (int f = 0; f < Cout; ++f)
+        for (int c = 0; c < Cin; ++c)
+            for (int k = 0; k < K; ++k)
+                packed[(size_t)f * kp + (size_t)k * Cin + c] = f2h(w[((size_t)f * Cin + c) * K + k]);
+    return 0;
+}
+// W_hh [4H][H] (torch gate order i,f,g,o) -> [slice][gate][kstep][lane][8]: the A fragment of
+// mfma 16x16x32 for rows gate*H + slice*16 + (lane&15), k = kstep*32 + (lane>>4)*8 + j.
+extern "C" int bh_lstm_pack_whh(const float* whh, int H, uint16_t* packed) {
+    BH_REQUIRE(whh && packed && H % 32 == 0 && H > 0, "lstm_pack_whh: H must be a positive multiple of 32");
+    const int nks = H / 32, nsl = H / 16;
+    for (int s = 0; s < nsl; ++s)
+        for (int g = 0; g < 4; ++g)
+            for (int ks = 0; ks < nks; ++ks)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int j = 0; j < 8; ++j) {
+                        int row = g * H + s * 16 + (lane & 15);
+                        int col = ks * 32 + (lane >> 4) * 8 + j;
+                        packed[((((size_t)s * 4 + g) * nks + ks) * 64 + lane) * 8 + j] =
+                            f2h(whh[(size_t)row * H + col]);
+                    }
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+namespace {
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    int alloc(size_t n) {
+        bytes = n;
+        if (n == 0) return 0;
+        BH_CHECK_HIP(hipMalloc(&p, n));
+        return 0;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+    }
+};
+
+static int upload(DevBuf& b, const void* host, size_t bytes) {
+    if (b.alloc(bytes)) return -1;
+    BH_CHECK_HIP(hipMemcpy(b.p, host, bytes, hipMemcpyHostToDevice));
+    return 0;
+}
+static int upload_f16(DevBuf& b, const float* w, size_t n) {
+    std::vector<uint16_t> h(n);
+    for (size_t i = 0; i < n; ++i) h[i] = f2h(w[i]);
+    return upload(b, h.data(), n * 2);
+}
+static int upload_f32(DevBuf& b, const float* w, size_t n) { return upload(b, w, n * 4); }
+
+struct Layer {
+    bh_layer_t d;        // descriptor (host pointers are not kept)
+    DevBuf w0, w1, w2, w3, w4, w5, b0, b1;
+    bool fused_clamp = false;   // a following CLAMP was folded into this layer
+    float clamp_lo = -INFINITY, clamp_hi = INFINITY;
+};
+
+enum Layout { L_SIGNAL, L_NLC, L_TNC };
+
+static inline int pad16(int n) { return (n + 15) / 16 * 16; }
+static inline int conv_out_len(int L, int K, int stride, int pad) { return (L + 2 * pad - K) / stride + 1; }
+
+}  // namespace
+
+struct bh_encoder {
+    int device = 0;
+    int max_batch = 0, max_chunk = 0;
+    int n_cus = 0;
+    std::vector<Layer> layers;
+    DevBuf act[2], gates, sig, err;
+    int out_features = 0;
+    ~bh_encoder() {
+        for (auto& l : layers) {
+            l.w0.release(); l.w1.release(); l.w2.release(); l.w3.release();
+            l.w4.release(); l.w5.release(); l.b0.release(); l.b1.release();
+        }
+        act[0].release(); act[1].release(); gates.release(); sig.release(); err.release();
+    }
+};
+
+namespace {
+
+// Walk the chain for chunks of L samples and batch N (padded): returns T, C, and optionally the
+// largest activation / gate buffer needed.
+static int walk(const bh_encoder* e, int N, int L, int* T_out, int* C_out, size_t* act_bytes, size_t* gate_bytes) {
+    long len = L;
+    int C = 1;
+    size_t amax = 0, gmax = 0;
+    for (const auto& l : e->layers) {
+        switch (l.d.kind) {
+            case BH_LAYER_CONV:
+                len = conv_out_len((int)len, l.d.winlen, l.d.stride, l.d.padding);
+                BH_REQUIRE(len > 0, "encoder: chunk of %d samples is too short for the convolution stack", L);
+                C = l.d.out_size;
+                amax = std::max(amax, (size_t)N * len * C * 2);
+                break;
+            case BH_LAYER_LSTM:
+                C = l.d.out_size;
+                amax = std::max(amax, (size_t)N * len * C * 2);
+                gmax = std::max(gmax, (size_t)N * len * 4 * C * 2);
+                break;
+            case BH_LAYER_LINEAR_CRF:
+                C = l.d.out_size;
+                break;
+            case BH_LAYER_CLAMP:
+                break;
+            default:
+                BH_REQUIRE(false, "encoder: layer kind %d is not supported by this build", l.d.kind);
+        }
+    }
+    *T_out = (int)len;
+    *C_out = C;
+    if (act_bytes) *act_bytes = amax;
+    if (gate_bytes) *gate_bytes = gmax;
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int bh_encoder_create(const bh_layer_t* layers, int n_layers, int device, int max_batch,
+                                 int max_chunk, bh_encoder_t** out) {
+    BH_REQUIRE(layers && n_layers > 0 && out, "encoder_create: bad arguments");
+    BH_REQUIRE(max_batch > 0 && max_chunk > 0, "encoder_create: max_batch/max_chunk must be positive");
+    int ndev = 0;
+    BH_CHECK_HIP(hipGetDeviceCount(&ndev));
+    BH_REQUIRE(ndev > 0, "encoder_create: no HIP device visible -- the MI355X engine has no CPU fallback");
+    BH_REQUIRE(device >= 0 && device < ndev, "encoder_create: device %d out of range (%d visible)", device, ndev);
+    int prev = 0;
+    BH_CHECK_HIP(hipGetDevice(&prev));
+    BH_CHECK_HIP(hipSetDevice(device));
+    auto* e = new bh_encoder();
+    e->device = device;
+    e->max_batch = max_batch;
+    e->max_chunk = max_chunk;
+    int rc = 0;
+    auto fail = [&](int code) {
+        delete e;
+        (void)hipSetDevice(prev);
+        return code;
+    };
+    if (hipDeviceGetAttribute(&e->n_cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) {
+        bh_set_error("encoder_create: cannot query CU count");
+        return fail(-1);
+    }
+    e->layers.resize(n_layers);
+    for (int i = 0; i < n_layers; ++i) {
+        Layer& L = e->layers[i];
+        L.d = layers[i];
+        const bh_layer_t& d = layers[i];
+        switch (d.kind) {
+            case BH_LAYER_CONV: {
+                if (!(d.w0 && d.in_size > 0 && d.out_size > 0 && d.winlen > 0 && d.stride > 0)) {
+                    bh_set_error("encoder_create: layer %d: malformed convolution", i);
+                    return fail(-2);
+                }
+                if (d.groups > 1) { bh_set_error("encoder_create: layer %d: grouped conv not supported here", i); return fail(-2); }
+                if (d.in_size == 1) {
+                    rc = upload_f32(L.w0, d.w0, (size_t)d.out_size * d.winlen);
+                } else {
+                    std::vector<uint16_t> pk(bh_conv1d_packed_halves(d.in_size, d.out_size, d.winlen));
+                    rc = bh_conv1d_pack(d.w0, d.in_size, d.out_size, d.winlen, pk.data());
+                    if (!rc) rc = upload(L.w0, pk.data(), pk.size() * 2);
+                }
+                if (!rc && d.b0) rc = upload_f32(L.b0, d.b0, d.out_size);
+                break;
+            }
+            case BH_LAYER_LSTM: {
+                const int H = d.out_size, I = d.in_size;
+                if (!(d.w0 && d.w1 && H > 0 && I > 0)) { bh_set_error("encoder_create: layer %d: malformed lstm", i); return fail(-2); }
+                if (H % 32 != 0 || H > 512 || I % 8 != 0) {
+                    bh_set_error("encoder_create: layer %d: lstm needs hidden %% 32 == 0, hidden <= 512, insize %% 8 == 0 (got %d, %d)", i, H, I);
+                    return fail(-2);
+                }
+                rc = upload_f16(L.w0, d.w0, (size_t)4 * H * I);
+                if (!rc) {
+                    std::vector<uint16_t> pk((size_t)4 * H * H);
+                    rc = bh_lstm_pack_whh(d.w1, H, pk.data());
+                    if (!rc) rc = upload(L.w1, pk.data(), pk.size() * 2);
+                }
+                if (!rc) {
+                    std::vector<float> b((size_t)4 * H, 0.0f);
+                    for (int j = 0; j < 4 * H; ++j) b[j] = (d.b0 ? d.b0[j] : 0.0f) + (d.b1 ? d.b1[j] : 0.0f);
+                    rc = upload_f32(L.b0, b.data(), b.size());
+                }
+                break;
+            }
+            case BH_LAYER_LINEAR_CRF: {
+                if (!(d.w0 && d.in_size > 0 && d.out_size > 0 && d.in_size % 8 == 0)) {
+                    bh_set_error("encoder_create: layer %d: malformed linearcrfencoder", i);
+                    return fail(-2);
+                }
+                rc = upload_f16(L.w0, d.w0, (size_t)d.out_size * d.in_size);
+                if (!rc && d.b0) rc = upload_f32(L.b0, d.b0, d.out_size);
+                e->out_features = d.out_size;
+                break;
+            }
+            case BH_LAYER_CLAMP: {
+                // fold into the producing layer's epilogue
+                int j = i - 1;
+                if (j < 0 || e->layers[j].d.kind == BH_LAYER_CLAMP || e->layers[j].d.kind == BH_LAYER_LSTM) {
+                    bh_set_error("encoder_create: layer %d: clamp must follow a convolution or linear layer", i);
+                    return fail(-2);
+                }
+                e->layers[j].fused_clamp = true;
+                e->layers[j].clamp_lo = d.clamp_lo;
+                e->layers[j].clamp_hi = d.clamp_hi;
+                break;
+            }
+            default:
+                bh_set_error("encoder_create: layer %d: kind %d is not supported by this build", i, d.kind);
+                return fail(-2);
+        }
+        if (rc) return fail(rc);
+        L.d.w0 = L.d.w1 = L.d.w2 = L.d.w3 = L.d.w4 = L.d.w5 = L.d.b0 = L.d.b1 = nullptr;
+    }
+    if (e->layers.back().d.kind != BH_LAYER_LINEAR_CRF &&
+        !(n_layers >= 2 && e->layers.back().d.kind == BH_LAYER_CLAMP &&
+          e->layers[n_layers - 2].d.kind == BH_LAYER_LINEAR_CRF)) {
+        bh_set_error("encoder_create: the chain must end in a linearcrfencoder (optionally followed by clamp)");
+        return fail(-2);
+    }
+    int T = 0, C = 0;
+    size_t ab = 0, gb = 0;
+    const int Np = pad16(max_batch);
+    if (walk(e, Np, max_chunk, &T, &C, &ab, &gb)) return fail(-2);
+    if (e->act[0].alloc(ab + 256) || e->act[1].alloc(ab + 256) || e->gates.alloc(gb + 256) ||
+        e->sig.alloc((size_t)Np * max_chunk * 2) || e->err.alloc(sizeof(int)))
+        return fail(-1);
+    if (hipMemset(e->err.p, 0, sizeof(int)) != hipSuccess || hipMemset(e->act[0].p, 0, e->act[0].bytes) != hipSuccess ||
+        hipMemset(e->act[1].p, 0, e->act[1].bytes) != hipSuccess) {
+        bh_set_error("encoder_create: hipMemset failed");
+        return fail(-1);
+    }
+    (void)hipSetDevice(prev);
+    *out = e;
+    return 0;
+}
+
+extern "C" void bh_encoder_destroy(bh_encoder_t* enc) {
+    if (!enc) return;
+    int prev = 0;
+    (void)hipGetDevice(&prev);
+    (void)hipSetDevice(enc->device);
+    delete enc;
+    (void)hipSetDevice(prev);
+}
+
+extern "C" int bh_encoder_output_shape(const bh_encoder_t* enc, int L, int* T, int* C, int* stride) {
+    BH_REQUIRE(enc && L > 0, "encoder_output_shape: bad arguments");
+    int t = 0, c = 0;
+    if (walk(enc, 16, L, &t, &c, nullptr, nullptr)) return -2;
+    if (T) *T = t;
+    if (C) *C = c;
+    if (stride) {
+        int s = 1;
+        for (const auto& l : enc->layers)
+            if (l.d.kind == BH_LAYER_CONV) s *= l.d.stride;
+        *stride = s;
+    }
+    return 0;
+}
+
+extern "C" int bh_encoder_forward(bh_encoder_t* e, const void* signal, int N, int L, void* scores, void* stream_) {
+    BH_REQUIRE(e && signal && scores, "encoder_forward: null argument");
+    BH_REQUIRE(N > 0 && N <= e->max_batch, "encoder_forward: batch %d outside 1..%d", N, e->max_batch);
+    BH_REQUIRE(L > 0 && L <= e->max_chunk, "encoder_forward: chunk %d outside 1..%d", L, e->max_chunk);
+    hipStream_t st = (hipStream_t)stream_;
+    int prev = 0;
+    BH_CHECK_HIP(hipGetDevice(&prev));
+    if (prev != e->device) BH_CHECK_HIP(hipSetDevice(e->device));
+    struct Restore {
+        int prev, dev;
+        ~Restore() { if (prev != dev) (void)hipSetDevice(prev); }
+    } restore{prev, e->device};
+
+    const int Np = pad16(N);
+    // stage the batch into an engine-owned [Np][L] buffer whose padding rows are zero
+    if (Np != N) BH_CHECK_HIP(hipMemsetAsync((char*)e->sig.p + (size_t)N * L * 2, 0, (size_t)(Np - N) * L * 2, st));
+    BH_CHECK_HIP(hipMemcpyAsync(e->sig.p, signal, (size_t)N * L * 2, hipMemcpyDeviceToDevice, st));
+
+    const void* cur = e->sig.p;
+    Layout lay = L_SIGNAL;
+    int len = L, C = 1, which = 0;
+    const size_t nl = e->layers.size();
+    for (size_t i = 0; i < nl; ++i) {
+        Layer& l = e->layers[i];
+        const bh_layer_t& d = l.d;
+        if (d.kind == BH_LAYER_CLAMP) continue;
+        // next non-clamp layer decides the output layout of a convolution
+        int next_kind = 0;
+        for (size_t j = i + 1; j < nl; ++j)
+            if (e->layers[j].d.kind != BH_LAYER_CLAMP) { next_kind = e->layers[j].d.kind; break; }
+        const float lo = l.fused_clamp ? l.clamp_lo : -INFINITY, hi = l.fused_clamp ? l.clamp_hi : INFINITY;
+        switch (d.kind) {
+            case BH_LAYER_CONV: {
+                BH_REQUIRE(lay == L_SIGNAL || lay == L_NLC, "encoder_forward: convolution after a time-major layer");
+                BH_REQUIRE(C == d.in_size, "encoder_forward: layer %zu expects %d channels, got %d", i, d.in_size, C);
+                const int lout = conv_out_len(len, d.winlen, d.stride, d.padding);
+                void* dst = e->act[which].p;
+                const bool tnc = next_kind == BH_LAYER_LSTM;
+                const long os_n = tnc ? d.out_size : (long)lout * d.out_size;
+                const long os_t = tnc ? (long)Np * d.out_size : d.out_size;
+                int rc;
+                if (lay == L_SIGNAL)
+                    rc = bh_k_conv_first(cur, (const float*)l.w0.p, (const float*)l.b0.p, dst, Np, len, lout,
+                                         d.out_size, d.winlen, d.stride, d.padding, d.activation, lo, hi, os_n, os_t, st);
+                else
+                    rc = bh_k_conv_igemm(cur, l.w0.p, (const float*)l.b0.p, dst, Np, len, lout, d.in_size,
+                                         d.out_size, d.winlen, d.stride, d.padding, d.activation, lo, hi, os_n, os_t, st);
+                if (rc) return rc;
+                cur = dst; which ^= 1; len = lout; C = d.out_size; lay = tnc ? L_TNC : L_NLC;
+                break;
+            }
+            case BH_LAYER_LSTM: {
+                BH_REQUIRE(lay == L_TNC, "encoder_forward: lstm needs time-major input");
+                BH_REQUIRE(C == d.in_size, "encoder_forward: layer %zu expects %d features, got %d", i, d.in_size, C);
+                const int H = d.out_size;
+                const int M = len * Np;
+                int rc = bh_k_linear(cur, l.w0.p, (const float*)l.b0.p, e->gates.p, M, 4 * H, d.in_size, d.in_size,
+                                     d.in_size, 4 * H, bh::ACT_NONE, 1.0f, -INFINITY, INFINITY, 0, 0, 0, 0, 0, st);
+                if (rc) return rc;
+                void* dst = e->act[which].p;
+                rc = bh_k_fill_u16(dst, 0xFFFFu, (size_t)M * H, st);
+                if (rc) return rc;
+                // co-residency: one launch serves at most (CUs / (8 * H/16)) * 32 rings
+                const int nsl = H / 16;
+                const int groups_fit = e->n_cus / (8 * nsl);
+                BH_REQUIRE(groups_fit >= 1, "encoder_forward: device has too few CUs (%d) for hidden size %d", e->n_cus, H);
+                const int rings_per_launch = groups_fit * 32;
+                const int n_rings = Np / 16;
+                for (int r0 = 0; r0 < n_rings; r0 += rings_per_launch) {
+                    const int nr = std::min(rings_per_launch, n_rings - r0);
+                    const size_t col = (size_t)r0 * 16;
+                    rc = bh_k_lstm_layer((const char*)e->gates.p + col * 4 * H * 2, l.w1.p,
+                                         (char*)dst + col * H * 2, len, Np, H, d.reverse, (int*)e->err.p, st, nr);
+                    if (rc) return rc;
+                }
+                cur = dst; which ^= 1; C = H;
+                break;
+            }
+            case BH_LAYER_LINEAR_CRF: {
+                BH_REQUIRE(lay == L_TNC || lay == L_NLC, "encoder_forward: linearcrfencoder needs encoded input");
+                BH_REQUIRE(C == d.in_size, "encoder_forward: layer %zu expects %d features, got %d", i, d.in_size, C);
+                const int M = len * Np;
+                const float sc = d.scale != 0.0f ? d.scale : 1.0f;
+                int rc;
+                if (lay == L_TNC)   // rows are (t, n): remap to the caller's [N][T][C], drop padding rows
+                    rc = bh_k_linear(cur, l.w0.p, (const float*)l.b0.p, scores, M, d.out_size, d.in_size, d.in_size,
+                                     d.in_size, d.out_size, d.activation, sc, lo, hi, 0, Np, 1, len, N, st);
+                else
+                    rc = bh_k_linear(cur, l.w0.p, (const float*)l.b0.p, scores, len * N, d.out_size, d.in_size, d.in_size,
+                                     d.in_size, d.out_size, d.activation, sc, lo, hi, 0, 0, 0, 0, 0, st);
+                if (rc) return rc;
+                C = d.out_size;
+                break;
+            }
+            default:
+                BH_REQUIRE(false, "encoder_forward: unsupported layer kind %d", d.kind);
+        }
+    }
+    return 0;
+}
+
+extern "C" int bh_encoder_check(bh_encoder_t* e, void* stream_) {
+    BH_REQUIRE(e, "encoder_check: null engine");
+    int flag = 0;
+    BH_CHECK_HIP(hipMemcpyAsync(&flag, e->err.p, sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream_));
+    BH_CHECK_HIP(hipStreamSynchronize((hipStream_t)stream_));
+    if (flag) {
+        BH_CHECK_HIP(hipMemsetAsync(e->err.p, 0, sizeof(int), (hipStream_t)stream_));
+        bh_set_error("device-side timeout in a persistent kernel (flag=%d)", flag);
+    }
+    return flag;
+}
+
+// ------------------------------------------------------------------------------------------------
+// operator-level shells
+extern "C" int bh_linear(const void* X, const void* W, const float* bias, void* out, int M, int N, int K, int ldx,
+                         int ldw, int ldo, int act, float scale, float clamp_lo, float clamp_hi, int gated,
+                         int row_div, long row_s_hi, long row_s_lo, int row_lim, void* stream) {
+    BH_REQUIRE(X && W && out, "linear: null pointer");
+    return bh_k_linear(X, W, bias, out, M, N, K, ldx, ldw, ldo, act, scale, clamp_lo, clamp_hi, gated, row_div,
+                       row_s_hi, row_s_lo, row_lim, (hipStream_t)stream);
+}
+extern "C" int bh_conv1d_first(const void* signal, const float* w, const float* bias, void* out, int N, int Lin,
+                               int Cout, int K, int stride, int pad, int act, float clamp_lo, float clamp_hi,
+                               long os_n, long os_t, void* stream) {
+    BH_REQUIRE(signal && w && out && stride > 0, "conv1d_first: bad arguments");
+    const int lout = conv_out_len(Lin, K, stride, pad);
+    BH_REQUIRE(lout > 0, "conv1d_first: input too short");
+    return bh_k_conv_first(signal, w, bias, out, N, Lin, lout, Cout, K, stride, pad, act, clamp_lo, clamp_hi, os_n,
+                           os_t, (hipStream_t)stream);
+}
+extern "C" int bh_conv1d(const void* in, const void* wpacked, const float* bias, void* out, int N, int Lin, int Cin,
+                         int Cout, int K, int stride, int pad, int act, float clamp_lo, float clamp_hi, long os_n,
+                         long os_t, void* stream) {
+    BH_REQUIRE(in && wpacked && out && stride > 0, "conv1d: bad arguments");
+    const int lout = conv_out_len(Lin, K, stride, pad);
+    BH_REQUIRE(lout > 0, "conv1d: input too short");
+    return bh_k_conv_igemm(in, wpacked, bias, out, N, Lin, lout, Cin, Cout, K, stride, pad, act, clamp_lo, clamp_hi,
+                           os_n, os_t, (hipStream_t)stream);
+}
+extern "C" int bh_lstm_layer(const void* gates_in, const void* whh_packed, void* h_out, int T, int N, int H,
+                             int reverse, int* err_flag, void* stream) {
+    BH_REQUIRE(gates_in && whh_packed && h_out && err_flag, "lstm_layer: null pointer");
+    BH_REQUIRE(T > 0, "lstm_layer: T must be positive");
+    int rc = bh_k_fill_u16(h_out, 0xFFFFu, (size_t)T * N * H, (hipStream_t)stream);
+    if (rc) return rc;
+    return bh_k_lstm_layer(gates_in, whh_packed, h_out, T, N, H, reverse, err_flag, (hipStream_t)stream, N / 16);
+}
+extern "C" size_t bh_crf_viterbi_workspace(int N, int T, int state_len) {
+    size_t S = 1;
+    for (int i = 0; i < state_len; ++i) S *= 4;
+    return (size_t)N * T * S + 256;
+}
+extern "C" int bh_crf_viterbi(const void* scores, int N, int T, int state_len, int layout_5s, float blank_score,
+                              long stride_n, long stride_t, void* workspace, int8_t* moves, int8_t* path,
+                              float* best, void* stream) {
+    BH_REQUIRE(scores && workspace && moves && path, "crf_viterbi: null pointer");
+    return bh_k_crf_viterbi(scores, N, T, state_len, layout_5s, blank_score, stride_n, stride_t, workspace, nullptr,
+                            moves, path, best, (hipStream_t)stream);
+}

@@ -1,0 +1,219 @@
+// fp16 "linear layer" GEMM on MFMA for gfx950:   out[m][n] = epi( sum_k X[m][k] * W[n][k] + bias[n] )
+//
+// Replaces the cuBLAS calls behind torch.nn.Linear on the reference's hot path
+// (bonito/nn.py:283-298 LinearCRFEncoder, nn.py:140-159 LinearUpsample, LSTM input projections
+// nn.py:396-415, transformer Wqkv/out_proj/fc1/fc2 bonito/transformer/model.py:52-53,102-109).
+//
+// Design (MI355X-first, not a CUDA tiling):
+//  * W is the MFMA *A* operand and X the *B* operand, so one lane's accumulators are
+//    4 (reg) x 4 (feature tiles) = 16 CONSECUTIVE output features of one token: the epilogue
+//    (bias, activation, scale, clamp, SwiGLU gating) is lane-local and stores two 16-byte
+//    vectors per token instead of 2-byte scattered stores.
+//  * 128(features) x 128(tokens) x 64(K) tile, 4 waves (2x2), each wave 64x64 = 4x4 MFMA 16x16x32 tiles.
+//  * LDS tiles are [row][64 halves] with the 16-byte chunk index XOR-swizzled by (row & 7): the
+//    ds_read_b128 fragment reads are bank-conflict free (see DESIGN.md "GEMM LDS layout").
+//  * W rows are staged into LDS already permuted into MFMA fragment order so the read side is the
+//    same conflict-free pattern for both operands.
+//  * XCD-aware block remap: blocks that land on the same XCD (blockIdx % 8) walk consecutive
+//    feature tiles of the same token tile, so the X tile is fetched into that XCD's L2 once.
+#include "common.h"
+#include "kernels.h"
+
+namespace bh {
+
+struct GemmArgs {
+    const half_t* X;   // [M][ldx]
+    const half_t* W;   // [N][ldw]
+    const float* bias; // [N] or null
+    half_t* out;       // rows remapped, see below; [.][ldo]
+    int M, N, K;
+    int ldx, ldw, ldo;
+    float scale;       // applied after activation
+    float clamp_lo, clamp_hi;
+    int row_div;       // out_row = (m / row_div) * row_s_hi + (m % row_div) * row_s_lo
+    long row_s_hi, row_s_lo;
+    int row_lim;       // rows with (m % row_div) >= row_lim are not stored (batch padding)
+    int n_ft, n_tt;    // tile counts
+};
+
+constexpr int BF = 128, BT = 128, BK = 64;
+constexpr int TILE_BYTES = 128 * BK * 2;  // 16 KiB per operand tile
+
+__device__ __forceinline__ int lds_off(int row, int chunk) {
+    return row * (BK * 2) + ((chunk ^ (row & 7)) << 4);
+}
+
+template <int ACT, bool GATED>
+__global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    // layout: [buf][A tile | B tile]
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wf = wave >> 1, wt = wave & 1;
+    const int r = lane & 15, kg = lane >> 4;
+
+    // XCD-aware bijective remap of the linear block id (guide T1).
+    const int nwg = gridDim.x;
+    const int bid = blockIdx.x;
+    const int q8 = nwg >> 3, r8 = nwg & 7;
+    const int xcd = bid & 7, loc = bid >> 3;
+    const int work = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + loc;
+    const int tile_t = work / p.n_ft;
+    const int tile_f = work - tile_t * p.n_ft;
+    const int f0 = tile_f * BF, t0 = tile_t * BT;
+
+    // staging assignment: 4 chunks per operand per thread
+    const int sc = tid & 7;
+    const int srow = tid >> 3;  // + 32*j
+    const half_t* xsrc[4];
+    const half_t* wsrc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        int row = srow + 32 * j;
+        int tok = min(t0 + row, p.M - 1);
+        xsrc[j] = p.X + (long)tok * p.ldx + sc * 8;
+        int wfb = row >> 6, within = row & 63;
+        int ft = within >> 4, rr = within & 15;
+        int feat = min(f0 + wfb * 64 + (rr >> 2) * 16 + ft * 4 + (rr & 3), p.N - 1);
+        wsrc[j] = p.W + (long)feat * p.ldw + sc * 8;
+    }
+
+    float4_t acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = float4_t{0.f, 0.f, 0.f, 0.f};
+
+    const int nk = (p.K + BK - 1) / BK;
+    uint4_t xr[4], wr[4];
+    auto gload = [&](int kt) {
+        int kofs = kt * BK + sc * 8;
+        bool ok = kofs < p.K;  // K % 8 == 0 is required by the host wrapper
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            xr[j] = ok ? *(const uint4_t*)(xsrc[j] + kt * BK) : uint4_t{0, 0, 0, 0};
+            wr[j] = ok ? *(const uint4_t*)(wsrc[j] + kt * BK) : uint4_t{0, 0, 0, 0};
+        }
+    };
+    auto lstore = [&](int buf) {
+        char* a = smem + buf * 2 * TILE_BYTES;
+        char* b = a + TILE_BYTES;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            int row = srow + 32 * j;
+            *(uint4_t*)(a + lds_off(row, sc)) = wr[j];
+            *(uint4_t*)(b + lds_off(row, sc)) = xr[j];
+        }
+    };
+
+    gload(0);
+    lstore(0);
+    __syncthreads();
+
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 1 < nk) gload(kt + 1);
+        const char* a = smem + (kt & 1) * 2 * TILE_BYTES;
+        const char* b = a + TILE_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            half8_t af[4], bf[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                af[i] = *(const half8_t*)(a + lds_off(wf * 64 + i * 16 + r, ks * 4 + kg));
+                bf[i] = *(const half8_t*)(b + lds_off(wt * 64 + i * 16 + r, ks * 4 + kg));
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = mfma16(af[i], bf[j], acc[i][j]);
+        }
+        if (kt + 1 < nk) lstore((kt + 1) & 1);
+        __syncthreads();
+    }
+
+    // Epilogue. lane (c = r: token column, q = kg): features fbase + ft*4 + reg, ft,reg in 0..3.
+    const int fbase = f0 + wf * 64 + kg * 16;
+    float bv[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        int f = fbase + i;
+        bv[i] = (p.bias != nullptr && f < p.N) ? p.bias[f] : 0.0f;
+    }
+#pragma unroll
+    for (int tt = 0; tt < 4; ++tt) {
+        int m = t0 + wt * 64 + tt * 16 + r;
+        if (m >= p.M || (m % p.row_div) >= p.row_lim) continue;
+        long orow = (long)(m / p.row_div) * p.row_s_hi + (long)(m % p.row_div) * p.row_s_lo;
+        float v[16];
+#pragma unroll
+        for (int ft = 0; ft < 4; ++ft)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) v[ft * 4 + g] = acc[ft][tt][g] + bv[ft * 4 + g];
+        if constexpr (GATED) {
+            // W rows were interleaved on the host: feature 2j = y_j, 2j+1 = gate_j
+            // (flash_attn GatedMlp semantics: y, gate = fc1(x).chunk(2); y * silu(gate)).
+            half8_t o;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) o[i] = (half_t)(v[2 * i] * swishf_(v[2 * i + 1]));
+            int fo = fbase >> 1;
+            if (fo + 8 <= (p.N >> 1)) *(half8_t*)(p.out + orow * p.ldo + fo) = o;
+            else
+                for (int i = 0; i < 8; ++i)
+                    if (fo + i < (p.N >> 1)) p.out[orow * p.ldo + fo + i] = o[i];
+        } else {
+            half8_t o0, o1;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                float x = apply_act<ACT>(v[i]) * p.scale;
+                x = fminf(fmaxf(x, p.clamp_lo), p.clamp_hi);
+                if (i < 8) o0[i] = (half_t)x; else o1[i - 8] = (half_t)x;
+            }
+            half_t* dst = p.out + orow * p.ldo + fbase;
+            if (fbase + 16 <= p.N) {
+                *(half8_t*)dst = o0;
+                *(half8_t*)(dst + 8) = o1;
+            } else {
+                for (int i = 0; i < 16; ++i)
+                    if (fbase + i < p.N) dst[i] = i < 8 ? o0[i] : o1[i - 8];
+            }
+        }
+    }
+}
+
+template <int ACT, bool GATED>
+static void launch(const GemmArgs& a, hipStream_t s) {
+    int grid = a.n_ft * a.n_tt;
+    hipLaunchKernelGGL((gemm_kernel<ACT, GATED>), dim3(grid), dim3(256), 4 * TILE_BYTES, s, a);
+}
+
+}  // namespace bh
+
+int bh_k_linear(const void* X, const void* W, const float* bias, void* out, int M, int N, int K,
+                int ldx, int ldw, int ldo, int act, float scale, float clamp_lo, float clamp_hi,
+                int gated, int row_div, long row_s_hi, long row_s_lo, int row_lim, hipStream_t stream) {
+    using namespace bh;
+    BH_REQUIRE(M > 0 && N > 0 && K > 0, "linear: empty problem M=%d N=%d K=%d", M, N, K);
+    BH_REQUIRE(K % 8 == 0 && ldx % 8 == 0 && ldw % 8 == 0, "linear: K/ldx/ldw must be multiples of 8 halves");
+    BH_REQUIRE(ldo % 8 == 0, "linear: ldo must be a multiple of 8 halves");
+    BH_REQUIRE(!gated || (N % 16 == 0), "linear: gated epilogue needs N %% 16 == 0");
+    GemmArgs a;
+    a.X = (const half_t*)X; a.W = (const half_t*)W; a.bias = bias; a.out = (half_t*)out;
+    a.M = M; a.N = N; a.K = K; a.ldx = ldx; a.ldw = ldw; a.ldo = ldo;
+    a.scale = scale; a.clamp_lo = clamp_lo; a.clamp_hi = clamp_hi;
+    a.row_div = row_div > 0 ? row_div : 1;
+    a.row_s_hi = row_div > 0 ? row_s_hi : 1;
+    a.row_s_lo = row_div > 0 ? row_s_lo : 0;
+    a.row_lim = (row_div > 0 && row_lim > 0) ? row_lim : 0x7fffffff;
+    a.n_ft = (N + BF - 1) / BF; a.n_tt = (M + BT - 1) / BT;
+    if (gated) { launch<ACT_NONE, true>(a, stream); }
+    else switch (act) {
+        case ACT_NONE: launch<ACT_NONE, false>(a, stream); break;
+        case ACT_SWISH: launch<ACT_SWISH, false>(a, stream); break;
+        case ACT_TANH: launch<ACT_TANH, false>(a, stream); break;
+        case ACT_RELU: launch<ACT_RELU, false>(a, stream); break;
+        default: BH_REQUIRE(false, "linear: unknown activation %d", act);
+    }
+    BH_CHECK_HIP(hipGetLastError());
+    return 0;
+}

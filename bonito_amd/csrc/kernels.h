@@ -1,0 +1,31 @@
+// Internal launcher prototypes (one per HIP translation unit). The public C ABI in
+// include/bonito_hip.h is a thin shell over these (bonito_amd/csrc/abi.cpp, engine.cpp).
+// All pointers are device pointers; all launchers are asynchronous on `stream` and return
+// 0 on success (error text via bh_last_error()).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+// gemm.hip
+int bh_k_linear(const void* X, const void* W, const float* bias, void* out, int M, int N, int K,
+                int ldx, int ldw, int ldo, int act, float scale, float clamp_lo, float clamp_hi,
+                int gated, int row_div, long row_s_hi, long row_s_lo, int row_lim, hipStream_t stream);
+
+// conv.hip
+int bh_k_conv_first(const void* signal, const float* w, const float* bias, void* out, int N, int Lin,
+                    int Lout, int Cout, int K, int stride, int pad, int act, float clamp_lo,
+                    float clamp_hi, long os_n, long os_t, hipStream_t stream);
+int bh_k_conv_igemm(const void* in, const void* wpk, const float* bias, void* out, int N, int Lin,
+                    int Lout, int Cin, int Cout, int K, int stride, int pad, int act, float clamp_lo,
+                    float clamp_hi, long os_n, long os_t, hipStream_t stream);
+
+// lstm.hip
+int bh_k_lstm_layer(const void* gates_in, const void* whh_packed, void* h_out, int T, int N, int H,
+                    int reverse, int* err_flag, hipStream_t stream, int n_rings);
+int bh_k_fill_u16(void* dst, uint16_t value, size_t count, hipStream_t stream);
+size_t bh_k_lstm_packed_bytes(int H);
+
+// crf.hip
+int bh_k_crf_viterbi(const void* scores, int N, int T, int state_len, int layout_5s, float blank_score,
+                     long s_n, long s_t, void* bp_ws, float* alpha_ws, int8_t* moves, int8_t* path,
+                     float* best_score, hipStream_t stream);

@@ -1,0 +1,201 @@
+// Persistent weight-stationary LSTM layer for gfx950 -- the dominant kernel of the fast/hac models.
+// Replaces koi.lstm.update_graph's fused CUDA LSTM (call site /root/reference bonito/crf/model.py:240-246)
+// and torch.nn.LSTM under bonito.nn.LSTM / RNNWrapper (bonito/nn.py:353-415: single layer,
+// unidirectional, gate order i,f,g,o, h0 = c0 = 0, `reverse` = run the time loop backwards).
+//
+// Decomposition (MI355X-first):
+//   * The input projection x_t W_ih^T + b for ALL t is one big MFMA GEMM (gemm.hip) -> G[T][N][4H].
+//   * Only h_{t-1} W_hh^T and the gate math are inside the time loop, which is strictly serial in t.
+//     The batch is cut into "rings" of 16 chunks (one MFMA column tile). A ring is served by H/16
+//     waves; wave (ring, slice) keeps the 64 rows of W_hh that produce hidden units
+//     [16*slice, 16*slice+16) x {i,f,g,o} RESIDENT IN REGISTERS for the whole layer (4 gate tiles x
+//     H/32 k-steps of 16x16x32 f16 A-fragments), so the recurrent weights are read from HBM once.
+//   * Per step a wave needs all H values of h_{t-1} for its 16 chunks (written by the other waves of
+//     its ring, which live on other CUs) and produces 16 hidden units x 16 chunks of h_t.
+//     The exchange buffer IS the layer output tensor h[T][N][H]: it is pre-filled with the fp16 bit
+//     pattern 0xFFFF, producers write h_t with write-through (sc1) 8-byte stores and consumers poll
+//     the data itself with L1-bypassing (sc1) 16-byte loads until no sentinel is left. |h| <= 1 so a
+//     valid value never has bit 14 set: one OR-reduction + one mask test validates 8 halves. No
+//     flags, no fences, no atomics, and every 2-byte element is checked individually so the protocol
+//     does not depend on store granularity, dispatch order or workgroup->XCD placement.
+//   * Rings are laid out so that the waves of one ring sit on one XCD when the dispatcher places
+//     block b on XCD b % 8 (speed only; correctness never relies on it).
+//   * W as the MFMA A operand: accumulator rows are hidden units, columns are chunks, so one lane
+//     holds i,f,g,o for 4 consecutive hidden units of one chunk -> lane-local gate math, c_t kept in
+//     fp32 registers for the whole layer, 8-byte packed h stores.
+// All spins are bounded; on timeout the kernel raises *err_flag and keeps going (never hangs).
+#include "common.h"
+#include "kernels.h"
+
+namespace bh {
+
+struct LstmArgs {
+    const half_t* G;    // [T][N][4H]  x W_ih^T + b_ih + b_hh, gate-major columns (torch order)
+    const half_t* whh;  // packed fragments, see bh_pack_whh
+    half_t* h;          // [T][N][H], pre-filled with 0xFFFF
+    int T, N, H;
+    int n_rings;        // N / 16
+    int reverse;
+    int* err;
+    unsigned max_spins;
+};
+
+constexpr unsigned SENTINEL_MASK = 0x40004000u;
+
+template <int NKS>
+__global__ __launch_bounds__(256, 1) void lstm_layer_kernel(LstmArgs p) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    constexpr int H = NKS * 32;
+    constexpr int NSL = H / 16;  // slices == waves per ring
+    // block -> (xcd, ring group, slice); wave -> ring inside the group
+    const int xcd = blockIdx.x & 7;
+    const int lwg = blockIdx.x >> 3;
+    const int rg = lwg / NSL;
+    const int slice = lwg - rg * NSL;
+    const int ring = (rg * 4 + wave) * 8 + xcd;
+    if (ring >= p.n_rings) return;
+
+    // ---- recurrent weights -> registers (once per layer) -------------------------------------
+    half8_t w[4][NKS];
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks)
+            w[g][ks] = *(const half8_t*)(p.whh + ((((long)slice * 4 + g) * NKS + ks) * 64 + lane) * 8);
+
+    const int c = lane & 15, q = lane >> 4;
+    const int n = ring * 16 + c;
+    const int hu0 = slice * 16 + q * 4;
+    const long row_bytes = (long)p.N * H * 2;           // one time step of h
+    const unsigned voff = (unsigned)(((ring * 16 + c) * H + q * 8) * 2);
+    float cst[4] = {0.f, 0.f, 0.f, 0.f};
+
+    const long g_row = (long)p.N * 4 * H;
+    const half_t* gptr = p.G + (long)n * 4 * H + hu0;
+    int t = p.reverse ? p.T - 1 : 0;
+    const int dt = p.reverse ? -1 : 1;
+
+    half4_t gin[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) gin[g] = *(const half4_t*)(gptr + (long)t * g_row + g * H);
+
+    for (int step = 0; step < p.T; ++step, t += dt) {
+        // prefetch next step's input projection (independent of the recurrence)
+        half4_t gnx[4];
+        {
+            int tn = (step + 1 < p.T) ? t + dt : t;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) gnx[g] = *(const half4_t*)(gptr + (long)tn * g_row + g * H);
+        }
+        float4_t acc[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) acc[g] = float4_t{0.f, 0.f, 0.f, 0.f};
+
+        if (step > 0) {
+            const char* base = (const char*)p.h + (long)(t - dt) * row_bytes;
+            __amdgpu_buffer_rsrc_t rs =
+                __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)row_bytes, 0x00020000);
+            uint4_t hf[NKS];
+            unsigned spins = 0;
+            while (true) {
+                unsigned orv = 0;
+#pragma unroll
+                for (int ks = 0; ks < NKS; ++ks) {
+                    hf[ks] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff + ks * 64, 0, (int)0x80000010 /*sc1 + volatile*/);
+                }
+#pragma unroll
+                for (int ks = 0; ks < NKS; ++ks) orv |= hf[ks].x | hf[ks].y | hf[ks].z | hf[ks].w;
+                if (!__any((orv & SENTINEL_MASK) != 0)) break;
+                if (++spins > p.max_spins) {
+                    if (lane == 0) atomicExch(p.err, 1);
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(2);
+            }
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) {
+                half8_t b = __builtin_bit_cast(half8_t, hf[ks]);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) acc[g] = mfma16(w[g][ks], b, acc[g]);
+            }
+        }
+
+        half4_t ho;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float ig = sigmoidf_(acc[0][i] + (float)gin[0][i]);
+            float fg = sigmoidf_(acc[1][i] + (float)gin[1][i]);
+            float gg = tanhf_(acc[2][i] + (float)gin[2][i]);
+            float og = sigmoidf_(acc[3][i] + (float)gin[3][i]);
+            cst[i] = fg * cst[i] + ig * gg;
+            float hv = og * tanhf_(cst[i]);
+            // keep the sentinel space clean: a non-finite or out-of-range h can never be published
+            hv = (fabsf(hv) <= 1.0f) ? hv : 0.0f;
+            ho[i] = (half_t)hv;
+        }
+        unsigned long long packed = __builtin_bit_cast(unsigned long long, ho);
+        unsigned long long* dst =
+            (unsigned long long*)(p.h + ((long)t * p.N + n) * H + hu0);
+        __hip_atomic_store(dst, packed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // sc1 write-through
+#pragma unroll
+        for (int g = 0; g < 4; ++g) gin[g] = gnx[g];
+    }
+}
+
+__global__ void fill_u16_kernel(uint16_t* dst, uint16_t v, size_t count) {
+    size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 8;
+    const size_t stride = (size_t)gridDim.x * blockDim.x * 8;
+    const unsigned vv = (unsigned)v | ((unsigned)v << 16);
+    for (; i + 8 <= count; i += stride) *(uint4_t*)(dst + i) = uint4_t{vv, vv, vv, vv};
+    if (i < count && i + 8 > count)
+        for (size_t j = i; j < count; ++j) dst[j] = v;
+}
+
+}  // namespace bh
+
+size_t bh_k_lstm_packed_bytes(int H) { return (size_t)4 * H * H * 2; }
+
+int bh_k_fill_u16(void* dst, uint16_t value, size_t count, hipStream_t stream) {
+    using namespace bh;
+    BH_REQUIRE(((uintptr_t)dst & 15) == 0, "fill_u16: destination must be 16-byte aligned");
+    size_t vecs = (count + 7) / 8;
+    int blocks = (int)((vecs + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(fill_u16_kernel, dim3(blocks), dim3(256), 0, stream, (uint16_t*)dst, value, count);
+    BH_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// One launch serves at most (CUs / (8 * H/16)) * 4 * 8 rings co-resident; the caller (engine.cpp)
+// splits larger batches by offsetting the base pointers by 16*ring0 columns: N stays the row stride of
+// G / h and n_rings is the number of 16-chunk rings this launch runs. N %% 16 == 0 (engine pads).
+int bh_k_lstm_layer(const void* gates_in, const void* whh_packed, void* h_out, int T, int N, int H,
+                    int reverse, int* err_flag, hipStream_t stream, int n_rings) {
+    using namespace bh;
+    BH_REQUIRE(N % 16 == 0, "lstm: batch must be padded to a multiple of 16 (N=%d)", N);
+    BH_REQUIRE(H % 32 == 0 && H >= 32 && H <= 512, "lstm: register-resident kernel needs H%%32==0, 32<=H<=512 (H=%d)", H);
+    int dev = 0, cus = 0;
+    BH_CHECK_HIP(hipGetDevice(&dev));
+    BH_CHECK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    const int nsl = H / 16;
+    BH_REQUIRE(n_rings > 0 && n_rings <= N / 16, "lstm: n_rings=%d outside 1..%d", n_rings, N / 16);
+    const int rl = (n_rings + 7) / 8;          // rings per XCD
+    const int groups = (rl + 3) / 4;           // 4 rings (waves) per workgroup
+    const int grid = 8 * groups * nsl;
+    BH_REQUIRE(grid <= cus, "lstm: %d workgroups must be co-resident but the device has %d CUs; split the batch", grid, cus);
+    LstmArgs a{(const half_t*)gates_in, (const half_t*)whh_packed, (half_t*)h_out, T, N, H, n_rings,
+               reverse, err_flag, 4000000u};
+#define BH_LSTM_CASE(NKS) \
+    case NKS: hipLaunchKernelGGL(lstm_layer_kernel<NKS>, dim3(grid), dim3(256), 0, stream, a); break;
+    switch (H / 32) {
+        BH_LSTM_CASE(1) BH_LSTM_CASE(2) BH_LSTM_CASE(3) BH_LSTM_CASE(4) BH_LSTM_CASE(5) BH_LSTM_CASE(6)
+        BH_LSTM_CASE(7) BH_LSTM_CASE(8) BH_LSTM_CASE(9) BH_LSTM_CASE(10) BH_LSTM_CASE(11) BH_LSTM_CASE(12)
+        BH_LSTM_CASE(13) BH_LSTM_CASE(14) BH_LSTM_CASE(15) BH_LSTM_CASE(16)
+        default: BH_REQUIRE(false, "lstm: unsupported H=%d", H);
+    }
+#undef BH_LSTM_CASE
+    BH_CHECK_HIP(hipGetLastError());
+    return 0;
+}

@@ -1,0 +1,79 @@
+"""Build libbonito_hip.so (gfx950) and the CPU oracle helpers in-tree.
+
+    python build.py            # everything
+    python build.py --force    # ignore timestamps
+
+hipcc cross-compiles for gfx950 without a GPU present. Outputs (git-ignored, shipped to the GPU box):
+    bonito_amd/libbonito_hip.so      the product: HIP kernels + engine + C ABI (include/bonito_hip.h)
+    oracle/liboracle.so              CPU restatement used ONLY by tests / smoke / bench cpu_baseline
+"""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(ROOT, "bonito_amd", "csrc")
+OBJ = os.path.join(ROOT, "build", "obj")
+LIB = os.path.join(ROOT, "bonito_amd", "libbonito_hip.so")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
+         "-I" + os.path.join(ROOT, "include")]
+
+
+def _newer(dst, srcs):
+    if not os.path.exists(dst):
+        return True
+    t = os.path.getmtime(dst)
+    return any(os.path.getmtime(s) > t for s in srcs)
+
+
+def build_hip(force=False):
+    os.makedirs(OBJ, exist_ok=True)
+    srcs = sorted(f for f in os.listdir(CSRC) if f.endswith((".hip", ".cpp")))
+    hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    hdrs.append(os.path.join(ROOT, "include", "bonito_hip.h"))
+    objs, jobs = [], []
+    for s in srcs:
+        src = os.path.join(CSRC, s)
+        obj = os.path.join(OBJ, s + ".o")
+        objs.append(obj)
+        if force or _newer(obj, [src] + hdrs):
+            cmd = [HIPCC] + FLAGS + (["-x", "hip"] if s.endswith(".cpp") else []) + ["-c", src, "-o", obj]
+            jobs.append(cmd)
+
+    def run(cmd):
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("build failed: %s\n%s\n%s" % (" ".join(cmd), r.stdout, r.stderr))
+        return r.stderr
+
+    with ThreadPoolExecutor(max_workers=min(8, max(1, len(jobs)))) as ex:
+        for warn in ex.map(run, jobs):
+            if warn.strip():
+                sys.stderr.write(warn)
+    if force or jobs or _newer(LIB, objs):
+        run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs)
+    return LIB
+
+
+def build_oracle(force=False):
+    odir = os.path.join(ROOT, "oracle")
+    src = os.path.join(odir, "crf_oracle.c")
+    lib = os.path.join(odir, "liboracle.so")
+    if os.path.exists(src) and (force or _newer(lib, [src])):
+        r = subprocess.run(["gcc", "-O2", "-std=c11", "-fPIC", "-shared", "-o", lib, src, "-lm"],
+                           capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("oracle build failed:\n" + r.stderr)
+    return lib
+
+
+def main():
+    force = "--force" in sys.argv
+    print(build_hip(force))
+    print(build_oracle(force))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,150 @@
+/* bonito_hip.h -- C ABI of libbonito_hip.so, the MI355X (gfx950) engine for bonito's
+ * chunked-signal inference hot path:  signal chunks -> encoder -> CRF scores -> decode.
+ *
+ * This is the drop-in boundary.  Each entry point replaces one FFI/library call the reference makes
+ * on this path (paths relative to /root/reference):
+ *
+ *   bh_encoder_create / bh_encoder_forward
+ *        koi.lstm.update_graph(encoder, batchsize, chunksize, quantize)        bonito/crf/model.py:240-246
+ *        + SeqdistModel.forward -> self.encoder(x) (cuDNN/cuBLAS/flash-attn)   bonito/crf/model.py:193-194
+ *        + transformer use_koi (NTC, expand_blanks=False output)               bonito/transformer/model.py:136-146
+ *        + bonito.ctc Model.forward (QuartzNet + log_softmax)                  bonito/ctc/model.py:35-37,195-207
+ *   bh_beam_search
+ *        koi.decode.beam_search(scores, beam_width, beam_cut, scale, offset, blank_score)
+ *                                                                              bonito/crf/basecall.py:36-40
+ *   bh_crf_viterbi / bh_crf_logz / bh_crf_posteriors
+ *        koi.ctc.{logZ_cu_sparse, fwd_scores_cu_sparse, bwd_scores_cu_sparse}, SequenceDist.posteriors
+ *        behind CTC_CRF.logZ / viterbi / decode_batch                          bonito/crf/model.py:47-67,98-103,196-199
+ *   bh_ctc_greedy_decode / bh_ctc_beam_search
+ *        fast_ctc_decode.viterbi_search / beam_search                          bonito/ctc/model.py:39-46
+ *   bh_linear, bh_conv1d_*, bh_lstm_layer, ...  (operator level, used by the parity tests)
+ *        torch.nn.Linear / Conv1d / LSTM kernels behind bonito/nn.py:27-38,222-241,396-415
+ *
+ * Conventions
+ *   - plain C: pointers + sizes, no torch / C++ types.  Device pointers are raw HIP device addresses.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream).  All launches are asynchronous;
+ *     nothing here synchronises the device unless documented.
+ *   - every function returns 0 on success, non-zero on error; bh_last_error() returns a
+ *     thread-local message.  Nothing ever falls back to a CPU path.
+ *   - caller owns input/output buffers; engines own their weights (copied at create) and workspace.
+ *   - an engine handle is not re-entrant: one handle per GPU worker thread (the reference drives
+ *     compute_scores from a single ThreadIterator, bonito/multiprocessing.py:20-24).
+ */
+#ifndef BONITO_HIP_H
+#define BONITO_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BH_ABI_VERSION 1
+
+/* activations (bonito.nn `layers` registry names: swish, tanh, relu; nn.py:22-23,54-56) */
+enum { BH_ACT_NONE = 0, BH_ACT_SWISH = 1, BH_ACT_TANH = 2, BH_ACT_RELU = 3 };
+
+/* layer kinds understood by bh_encoder_create (bonito.nn registry names in comments) */
+enum {
+    BH_LAYER_CONV = 1,        /* convolution  (nn.py:222; BatchNorm folded by the caller as nn.py:447-454) */
+    BH_LAYER_LSTM = 2,        /* lstm         (nn.py:396) */
+    BH_LAYER_LINEAR_CRF = 3,  /* linearcrfencoder (nn.py:269) */
+    BH_LAYER_CLAMP = 4,       /* clamp        (nn.py:60) -- fused into the producing kernel */
+    BH_LAYER_TRANSFORMER = 5, /* transformerencoderlayer (transformer/model.py:83) */
+    BH_LAYER_UPSAMPLE = 6,    /* linearupsample (nn.py:140) */
+    BH_LAYER_TCS_BLOCK = 7,   /* bonito.ctc Block (ctc/model.py:124) */
+    BH_LAYER_CTC_DECODER = 8  /* bonito.ctc Decoder: 1x1 conv + log_softmax (ctc/model.py:195) */
+};
+
+/* One layer of an encoder.  All weight pointers are HOST fp32 arrays in torch's native layout; the
+ * engine packs / rounds them to fp16 once at create time.  Unused fields are 0 / NULL. */
+typedef struct bh_layer {
+    int32_t kind;
+    int32_t in_size;     /* conv: in channels; lstm/linear: in features; transformer: d_model */
+    int32_t out_size;    /* conv: out channels; lstm: hidden; linear_crf: n_base^(state_len+1) (+ blanks if no blank_score) */
+    int32_t winlen, stride, padding;   /* conv */
+    int32_t activation;  /* BH_ACT_* */
+    int32_t reverse;     /* lstm */
+    int32_t nhead, dim_ff, win_left, win_right;   /* transformer */
+    int32_t scale_factor;               /* upsample */
+    int32_t groups;      /* conv: 1 or in_size (depthwise) */
+    int32_t reserved_i[3];
+    float scale;         /* linear_crf: multiply after activation (0 = none) */
+    float clamp_lo, clamp_hi;           /* clamp */
+    float blank_score;   /* linear_crf with fixed blank (scores keep the 4S koi layout) */
+    float alpha;         /* transformer: deepnorm_alpha */
+    float eps;           /* transformer: rmsnorm eps */
+    float reserved_f[2];
+    const float* w0;     /* conv [Cout][Cin/groups][K]; lstm W_ih [4H][I]; linear [out][in]; transformer Wqkv [3D][D] */
+    const float* b0;     /* conv bias [Cout]; lstm b_ih [4H]; linear bias; transformer: NULL */
+    const float* w1;     /* lstm W_hh [4H][H]; transformer out_proj.weight [D][D] */
+    const float* b1;     /* lstm b_hh [4H]; transformer out_proj.bias [D] */
+    const float* w2;     /* transformer ff.fc1.weight [2F][D] */
+    const float* w3;     /* transformer ff.fc2.weight [D][F] */
+    const float* w4;     /* transformer norm1.weight [D] */
+    const float* w5;     /* transformer norm2.weight [D] */
+} bh_layer_t;
+
+typedef struct bh_encoder bh_encoder_t;
+
+const char* bh_last_error(void);
+int bh_abi_version(void);
+/* number of visible HIP devices, or <0 on error */
+int bh_device_count(void);
+
+/* ---- encoder engine -------------------------------------------------------------------------- */
+/* Build an engine for a linear chain of layers on HIP device `device`.  Workspace is sized for
+ * batches of up to max_batch chunks of up to max_chunk samples (batch is padded to 16 internally). */
+int bh_encoder_create(const bh_layer_t* layers, int n_layers, int device, int max_batch, int max_chunk,
+                      bh_encoder_t** out);
+void bh_encoder_destroy(bh_encoder_t* enc);
+/* output geometry for chunks of L samples: T output steps, C scores per step, stride = L-per-step */
+int bh_encoder_output_shape(const bh_encoder_t* enc, int L, int* T, int* C, int* stride);
+/* signal: device fp16 [N][L] (the reference's [N,1,L] batch, bonito/crf/basecall.py:33).
+ * scores: device fp16, contiguous [N][T][C] (the layout koi.decode.beam_search consumes). */
+int bh_encoder_forward(bh_encoder_t* enc, const void* signal, int N, int L, void* scores, void* stream);
+/* non-zero if a device-side timeout was raised by a persistent kernel since the last call (synchronises stream) */
+int bh_encoder_check(bh_encoder_t* enc, void* stream);
+
+/* ---- CRF decode ------------------------------------------------------------------------------ */
+/* Bytes of device workspace bh_crf_viterbi needs. */
+size_t bh_crf_viterbi_workspace(int N, int T, int state_len);
+/* Max-semiring best path (CTC_CRF.viterbi, crf/model.py:98-103).
+ * scores fp16 with element strides (stride_n, stride_t); layout_5s=1: C=5S with the stay score in
+ * column 5j (expand_blanks layout); layout_5s=0: C=4S koi layout + scalar blank_score.
+ * moves[N][T] in {0,1}; path[N][T] in {0..4} (0 = no emission, else 1+base); best[N] path score (or NULL). */
+int bh_crf_viterbi(const void* scores, int N, int T, int state_len, int layout_5s, float blank_score,
+                   long stride_n, long stride_t, void* workspace, int8_t* moves, int8_t* path,
+                   float* best, void* stream);
+
+/* ---- operator level (parity tests, custom pipelines) ----------------------------------------- */
+/* out[m][n] = clamp(act(X[m][:] . W[n][:] + bias[n]) * scale); fp16 X [M][ldx], W [N][ldw], out [.][ldo].
+ * gated=1: SwiGLU epilogue over interleaved rows (out has N/2 columns).
+ * row remap: out_row = (m / row_div) * row_s_hi + (m % row_div) * row_s_lo   (row_div=0: identity);
+ * rows with (m % row_div) >= row_lim are skipped (row_lim=0: none) -- used to drop batch padding. */
+int bh_linear(const void* X, const void* W, const float* bias, void* out, int M, int N, int K, int ldx,
+              int ldw, int ldo, int act, float scale, float clamp_lo, float clamp_hi, int gated,
+              int row_div, long row_s_hi, long row_s_lo, int row_lim, void* stream);
+/* first convolution, Cin = 1: signal fp16 [N][Lin] -> out (n*os_n + t*os_t + c), w fp32 [Cout][K] on device */
+int bh_conv1d_first(const void* signal, const float* w, const float* bias, void* out, int N, int Lin,
+                    int Cout, int K, int stride, int pad, int act, float clamp_lo, float clamp_hi,
+                    long os_n, long os_t, void* stream);
+/* packed conv weight size in halves and host-side packer: torch [Cout][Cin][K] fp32 -> [Cout16][Kp] fp16 */
+size_t bh_conv1d_packed_halves(int Cin, int Cout, int K);
+int bh_conv1d_pack(const float* w, int Cin, int Cout, int K, uint16_t* packed);
+/* channel-minor implicit-GEMM conv: in fp16 [N][Lin][Cin] -> out (n*os_n + t*os_t + c) */
+int bh_conv1d(const void* in, const void* wpacked, const float* bias, void* out, int N, int Lin, int Cin,
+              int Cout, int K, int stride, int pad, int act, float clamp_lo, float clamp_hi, long os_n,
+              long os_t, void* stream);
+/* recurrent weights: torch W_hh [4H][H] fp32 (host) -> MFMA-fragment order fp16 (host, 4*H*H halves) */
+int bh_lstm_pack_whh(const float* whh, int H, uint16_t* packed);
+/* one LSTM layer over gates_in = x W_ih^T + b (fp16 [T][N][4H], torch gate order); h_out fp16 [T][N][H].
+ * N % 16 == 0.  err_flag: device int, set non-zero on a device-side timeout. */
+int bh_lstm_layer(const void* gates_in, const void* whh_packed, void* h_out, int T, int N, int H,
+                  int reverse, int* err_flag, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BONITO_HIP_H */
