@@ -1,0 +1,181 @@
+#!/usr/bin/env python3
+"""
+Headline benchmark: signal samples/sec/GPU at chunk=10000, batch=512 (BASELINE.json `metric`).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--model hac|fast] [--decoder viterbi|beam]
+
+One "step" = one pass of the hot path over one resident synthetic batch: fp16 signal [512, 10000] in HBM
+-> HIP encoder (conv x3, LSTM x5, LinearCRFEncoder) -> HIP CRF decode -> int8 moves/sequence/qstring on
+the host.  Weights are seeded random-init tensors of the named architecture (no checkpoints offline).
+For N > 1 launch with torch.distributed.run; each rank owns one GPU and the same per-GPU workload
+(read chunks shard embarrassingly, no data-path collective) -> "scaling": "weak".
+
+The JSON line also carries
+  roofline     -- dominant kernel's algorithmic FLOP/s from HIP-event timings on the engine stream
+  cpu_baseline -- the CPU oracle (PyTorch-CPU fp32 restatement of bonito/nn.py + C Viterbi) on a bounded sample
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+MFMA_F16_PEAK_TFLOPS = 2500.0     # MI355X dense fp16/bf16 (MI355X_MICROARCH.md)
+HBM_PEAK_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--model", default="hac", choices=["hac", "fast"])
+    ap.add_argument("--batch", type=int, default=512)
+    ap.add_argument("--chunk", type=int, default=10000)
+    ap.add_argument("--decoder", default="viterbi", choices=["viterbi", "beam"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(name, chunk, seconds_budget=20.0):
+    """CPU oracle timed on this host: oracle/nn_ref.py forward (fp32) + oracle/crf_oracle.c Viterbi."""
+    from bonito_amd import synthetic
+    from oracle import crf_ref, nn_ref
+    model = synthetic.make_model(name)
+    nn_ref.round_params_to_half_(model)
+    ncores = os.cpu_count() or 1
+    torch.set_num_threads(ncores)
+    n = 2
+    x = torch.randn(n, 1, chunk, generator=torch.Generator().manual_seed(25)).half().float()
+    reps, t_total = 0, 0.0
+    while t_total < seconds_budget and reps < 8:
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            y = nn_ref.forward(model.encoder, x, expand_blanks=False)
+        sc = y.permute(1, 0, 2).contiguous().half().numpy()
+        crf_ref.viterbi(sc, model.seqdist.state_len, blank=2.0)
+        t_total += time.perf_counter() - t0
+        reps += 1
+    return {"value": n * chunk * reps / t_total, "unit": "samples/s", "cores": ncores, "kind": "port",
+            "sample": "%d reps of %d chunks x %d samples, oracle/nn_ref.py fp32 forward + C Viterbi" % (reps, n, chunk)}
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    assert torch.cuda.is_available(), "bench.py needs a HIP device; there is no CPU fallback"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    from bonito_amd import decode, synthetic
+    model = synthetic.make_model(a.model, batchsize=a.batch, chunksize=a.chunk)
+    model.use_koi(batchsize=a.batch, chunksize=a.chunk, quantize=False)
+    model = model.half().to(dev)
+    gen = torch.Generator(device=dev).manual_seed(25 + rank)
+    signal = torch.randn(a.batch, 1, a.chunk, generator=gen, device=dev).half()
+
+    def step():
+        scores = model(signal)
+        if a.decoder == "viterbi":
+            moves, path = decode.viterbi(scores)          # includes D2H of the int8 outputs
+            return moves, path
+        return decode.beam_search(scores)
+
+    def barrier():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier(device_ids=[local])
+        torch.cuda.synchronize(dev)
+
+    for _ in range(a.warmup):
+        step()
+    model._hip.check()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    model._hip.check()
+
+    # ---- roofline leg: per-kernel-class HIP-event timings on the engine's stream (after the timed region)
+    roof = None
+    breakdown = None
+    if rank == 0:
+        enc = model._hip
+        enc.profile(True)
+        nprof = 3
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(2 * nprof)]
+        dec_ms = 0.0
+        for i in range(nprof):
+            scores = model(signal)
+            ev[2 * i].record()
+            decode.viterbi(scores) if a.decoder == "viterbi" else decode.beam_search(scores)
+            ev[2 * i + 1].record()
+        torch.cuda.synchronize(dev)
+        for i in range(nprof):
+            dec_ms += ev[2 * i].elapsed_time(ev[2 * i + 1])
+        prof = enc.profile_read()
+        enc.profile(False)
+        breakdown = {k: round(v[0] / nprof, 3) for k, v in prof.items() if v[1]}
+        breakdown["decode_incl_d2h"] = round(dec_ms / nprof, 3)
+        fl = synthetic.flops_per_chunk(a.model, a.chunk)
+        cls = max(("lstm_rec", "lstm_gemm", "crf_linear", "conv"), key=lambda k: prof[k][0])
+        ms, spans = prof[cls]
+        launches_per_fwd = spans / nprof
+        flops_per_launch = fl[cls] * a.batch / launches_per_fwd
+        avg_ms = ms / spans
+        achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12
+        roof = {"kernel": {"lstm_rec": "lstm_layer_kernel", "lstm_gemm": "gemm_kernel", "crf_linear": "gemm_kernel",
+                           "conv": "conv_igemm_kernel"}[cls],
+                "bound": "mfma", "achieved": round(achieved, 2), "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(achieved / MFMA_F16_PEAK_TFLOPS, 4), "traffic": None,
+                "avg_launch_ms": round(avg_ms, 4), "flops_per_launch": flops_per_launch}
+
+    if rank == 0:
+        samples = a.batch * a.chunk * a.steps * world
+        out = {
+            "metric": "signal samples/sec/GPU (chunk=10000, batch=512) + read accuracy vs ref",
+            "value": samples / elapsed,
+            "unit": "samples/s",
+            "n_gpus": world,
+            "steps": a.steps,
+            "warmup": a.warmup,
+            "ms_per_step": 1e3 * elapsed / a.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f16",
+            "data": "synthetic",
+            "config": {"workload": "dna_r10.4.1_e8.2_400bps_%s@v5.0.0-shaped CRF (seeded random weights), "
+                                   "batch %d x chunk %d, %s decode, 1 replica per GPU" %
+                                   (a.model, a.batch, a.chunk, a.decoder),
+                       "parallelism": "replicas x%d (shard-by-read, no collective)" % world},
+            "per_gpu": samples / elapsed / world,
+            "roofline": roof,
+            "kernel_ms_per_step": breakdown,
+            "cpu_baseline": None if (a.no_cpu_baseline or world > 1) else cpu_baseline(a.model, a.chunk),
+        }
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

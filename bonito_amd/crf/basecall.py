@@ -1,0 +1,70 @@
+"""
+CRF basecalling pipeline on the MI355X engine: chunk -> batch -> HIP encoder + HIP decode -> unbatch ->
+stitch -> format. Same function names, arguments and result dictionaries as /root/reference
+bonito/crf/basecall.py (stitch_results 13-24, compute_scores 27-45, fmt 48-55, basecall 58-82) so
+``load_symbol(config, "basecall")`` callers (cli/basecaller.py:71,131-136) need no change.
+"""
+import numpy as np
+import torch
+
+from bonito_amd import decode as hip_decode
+from bonito_amd.decode import to_str
+from bonito_amd.multiprocessing import thread_iter
+from bonito_amd.util import chunk, stitch, batchify, unbatchify
+
+
+def stitch_results(results, length, size, overlap, stride, reverse=False):
+    """Stitch per-chunk decode outputs ([n_chunks, T] int8 each) back into one read."""
+    if isinstance(results, dict):
+        return {k: stitch_results(v, length, size, overlap, stride, reverse=reverse) for k, v in results.items()}
+    if length < size:
+        return results[0, :int(np.floor(length / stride))]
+    return stitch(results, size, overlap, length, stride, reverse=reverse)
+
+
+def compute_scores(model, batch, beam_width=32, beam_cut=100.0, scale=1.0, offset=0.0, blank_score=2.0,
+                   reverse=False, decoder="beam"):
+    """fp16 forward on the HIP engine followed by the HIP decoder; returns CPU int8 [N, T] tensors
+    `sequence`, `qstring`, `moves` (zero where nothing is emitted), as koi.decode.beam_search does."""
+    with torch.inference_mode():
+        device = next(model.parameters()).device
+        scores = model(batch.to(torch.float16).to(device))
+        if reverse:
+            raise NotImplementedError("--revcomp is not implemented in the HIP engine yet")
+        with torch.cuda.device(scores.device):
+            if decoder == "viterbi":
+                moves, path = hip_decode.viterbi(scores, blank_score=blank_score)
+                sequence = hip_decode.path_to_sequence(path)
+                qstring = torch.where(sequence != 0, torch.tensor(33 + 20, dtype=torch.int8), torch.tensor(0, dtype=torch.int8))
+            else:
+                sequence, qstring, moves = hip_decode.beam_search(
+                    scores, beam_width=beam_width, beam_cut=beam_cut, scale=scale, offset=offset,
+                    blank_score=blank_score)
+        return {"moves": moves, "qstring": qstring, "sequence": sequence}
+
+
+def fmt(stride, attrs, rna=False):
+    flip = (lambda s: s[::-1]) if rna else (lambda s: s)
+    return {
+        "stride": stride,
+        "moves": attrs["moves"].numpy(),
+        "qstring": flip(to_str(attrs["qstring"])),
+        "sequence": flip(to_str(attrs["sequence"])),
+    }
+
+
+def basecall(model, reads, chunksize=4000, overlap=100, batchsize=32, reverse=False, rna=False, decoder="beam"):
+    """Basecalls a set of reads: yields (read, {sequence, qstring, moves, stride})."""
+    chunks = thread_iter(
+        ((read, 0, read.signal.shape[-1]), chunk(torch.from_numpy(read.signal), chunksize, overlap))
+        for read in reads
+    )
+    batches = thread_iter(batchify(chunks, batchsize=batchsize))
+    scores = thread_iter(
+        (keys, compute_scores(model, batch, reverse=reverse, decoder=decoder)) for keys, batch in batches
+    )
+    results = thread_iter(
+        (read, stitch_results(sc, end - start, chunksize, overlap, model.stride, reverse))
+        for ((read, start, end), sc) in unbatchify(scores)
+    )
+    return thread_iter((read, fmt(model.stride, attrs, rna)) for read, attrs in results)

@@ -32,6 +32,7 @@ void bh_set_error(const char* fmt, ...) {
 }
 extern "C" const char* bh_last_error(void) { return g_err; }
 extern "C" int bh_abi_version(void) { return BH_ABI_VERSION; }
+extern "C" size_t bh_sizeof_layer(void) { return sizeof(bh_layer_t); }
 extern "C" int bh_device_count(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) {
@@ -124,6 +125,13 @@ struct Layer {
 
 enum Layout { L_SIGNAL, L_NLC, L_TNC };
 
+// RAII span: records a pair of events around a group of launches when profiling is on.
+struct ProfSpan {
+    bh_encoder* e; hipStream_t st; int cls; hipEvent_t a = nullptr, b = nullptr;
+    ProfSpan(bh_encoder* e_, hipStream_t st_, int cls_);
+    ~ProfSpan();
+};
+
 static inline int pad16(int n) { return (n + 15) / 16 * 16; }
 static inline int conv_out_len(int L, int K, int stride, int pad) { return (L + 2 * pad - K) / stride + 1; }
 
@@ -136,7 +144,12 @@ struct bh_encoder {
     std::vector<Layer> layers;
     DevBuf act[2], gates, sig, err;
     int out_features = 0;
+    // optional per-kernel-class timing with HIP events on the caller's stream (bench.py roofline leg)
+    bool profiling = false;
+    struct Span { int cls; hipEvent_t a, b; };
+    std::vector<Span> spans;
     ~bh_encoder() {
+        for (auto& s : spans) { (void)hipEventDestroy(s.a); (void)hipEventDestroy(s.b); }
         for (auto& l : layers) {
             l.w0.release(); l.w1.release(); l.w2.release(); l.w3.release();
             l.w4.release(); l.w5.release(); l.b0.release(); l.b1.release();
@@ -146,6 +159,17 @@ struct bh_encoder {
 };
 
 namespace {
+
+ProfSpan::ProfSpan(bh_encoder* e_, hipStream_t st_, int cls_) : e(e_), st(st_), cls(cls_) {
+    if (!e->profiling) return;
+    if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { a = b = nullptr; return; }
+    (void)hipEventRecord(a, st);
+}
+ProfSpan::~ProfSpan() {
+    if (!a) return;
+    (void)hipEventRecord(b, st);
+    e->spans.push_back({cls, a, b});
+}
 
 // Walk the chain for chunks of L samples and batch N (padded): returns T, C, and optionally the
 // largest activation / gate buffer needed.
@@ -368,6 +392,7 @@ extern "C" int bh_encoder_forward(bh_encoder_t* e, const void* signal, int N, in
                 const long os_n = tnc ? d.out_size : (long)lout * d.out_size;
                 const long os_t = tnc ? (long)Np * d.out_size : d.out_size;
                 int rc;
+                ProfSpan span(e, st, BH_PROF_CONV);
                 if (lay == L_SIGNAL)
                     rc = bh_k_conv_first(cur, (const float*)l.w0.p, (const float*)l.b0.p, dst, Np, len, lout,
                                          d.out_size, d.winlen, d.stride, d.padding, d.activation, lo, hi, os_n, os_t, st);
@@ -383,12 +408,20 @@ extern "C" int bh_encoder_forward(bh_encoder_t* e, const void* signal, int N, in
                 BH_REQUIRE(C == d.in_size, "encoder_forward: layer %zu expects %d features, got %d", i, d.in_size, C);
                 const int H = d.out_size;
                 const int M = len * Np;
-                int rc = bh_k_linear(cur, l.w0.p, (const float*)l.b0.p, e->gates.p, M, 4 * H, d.in_size, d.in_size,
-                                     d.in_size, 4 * H, bh::ACT_NONE, 1.0f, -INFINITY, INFINITY, 0, 0, 0, 0, 0, st);
-                if (rc) return rc;
+                int rc;
                 void* dst = e->act[which].p;
-                rc = bh_k_fill_u16(dst, 0xFFFFu, (size_t)M * H, st);
-                if (rc) return rc;
+                {
+                    ProfSpan span(e, st, BH_PROF_LSTM_GEMM);
+                    rc = bh_k_linear(cur, l.w0.p, (const float*)l.b0.p, e->gates.p, M, 4 * H, d.in_size, d.in_size,
+                                     d.in_size, 4 * H, bh::ACT_NONE, 1.0f, -INFINITY, INFINITY, 0, 0, 0, 0, 0, st);
+                    if (rc) return rc;
+                }
+                {
+                    ProfSpan span(e, st, BH_PROF_FILL);
+                    rc = bh_k_fill_u16(dst, 0xFFFFu, (size_t)M * H, st);
+                    if (rc) return rc;
+                }
+                ProfSpan span(e, st, BH_PROF_LSTM_REC);
                 // co-residency: one launch serves at most (CUs / (8 * H/16)) * 32 rings
                 const int nsl = H / 16;
                 const int groups_fit = e->n_cus / (8 * nsl);
@@ -411,6 +444,7 @@ extern "C" int bh_encoder_forward(bh_encoder_t* e, const void* signal, int N, in
                 const int M = len * Np;
                 const float sc = d.scale != 0.0f ? d.scale : 1.0f;
                 int rc;
+                ProfSpan span(e, st, BH_PROF_CRF_LINEAR);
                 if (lay == L_TNC)   // rows are (t, n): remap to the caller's [N][T][C], drop padding rows
                     rc = bh_k_linear(cur, l.w0.p, (const float*)l.b0.p, scores, M, d.out_size, d.in_size, d.in_size,
                                      d.in_size, d.out_size, d.activation, sc, lo, hi, 0, Np, 1, len, N, st);
@@ -438,6 +472,25 @@ extern "C" int bh_encoder_check(bh_encoder_t* e, void* stream_) {
         bh_set_error("device-side timeout in a persistent kernel (flag=%d)", flag);
     }
     return flag;
+}
+
+extern "C" int bh_encoder_profile(bh_encoder_t* e, int enable) {
+    BH_REQUIRE(e, "encoder_profile: null engine");
+    e->profiling = enable != 0;
+    return 0;
+}
+extern "C" int bh_encoder_profile_read(bh_encoder_t* e, float* ms, int* launches) {
+    BH_REQUIRE(e && ms && launches, "encoder_profile_read: null argument");
+    for (int i = 0; i < BH_PROF_CLASSES; ++i) { ms[i] = 0.0f; launches[i] = 0; }
+    for (auto& s : e->spans) {
+        BH_CHECK_HIP(hipEventSynchronize(s.b));
+        float t = 0.0f;
+        BH_CHECK_HIP(hipEventElapsedTime(&t, s.a, s.b));
+        if (s.cls >= 0 && s.cls < BH_PROF_CLASSES) { ms[s.cls] += t; launches[s.cls] += 1; }
+        (void)hipEventDestroy(s.a); (void)hipEventDestroy(s.b);
+    }
+    e->spans.clear();
+    return 0;
 }
 
 // ------------------------------------------------------------------------------------------------

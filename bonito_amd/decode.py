@@ -1,0 +1,91 @@
+"""
+CRF decoding entry points with the call surface of ``koi.decode`` (the un-vendored dependency the
+reference calls at /root/reference bonito/crf/basecall.py:7,36-40,48-55), backed by the HIP kernels in
+bonito_amd/csrc/crf.hip through the C ABI (``bh_crf_viterbi`` ...).
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from bonito_amd import _lib
+
+_ALPHABET = np.frombuffer(b"NACGT", dtype=np.uint8)
+
+
+def _check_scores(scores):
+    if scores.dtype != torch.float16:
+        raise TypeError("Expected fp16 but received %s" % scores.dtype)   # koi raises TypeError too
+    if not scores.is_cuda:
+        raise _lib.HipEngineError("scores must live on a HIP device (no CPU decode fallback)")
+    if not scores.is_contiguous():
+        raise AssertionError("scores must be contiguous [N, T, C]")
+
+
+def state_len_of(C_, n_base=4):
+    """state_len such that C == n_base^(state_len+1) (koi layout, expand_blanks=False)."""
+    sl, size = 0, n_base
+    while size < C_:
+        size *= n_base
+        sl += 1
+    if size != C_:
+        raise ValueError("score width %d is not a power of %d" % (C_, n_base))
+    return sl
+
+
+def viterbi(scores, blank_score=2.0, return_score=False):
+    """Max-semiring best path of the CTC-CRF (CTC_CRF.viterbi, bonito/crf/model.py:98-103) on koi-layout
+    scores fp16 [N, T, 4^(state_len+1)].  Returns CPU int8 tensors (moves [N,T] in {0,1},
+    path [N,T] in {0..4}), like koi's decoders return CPU int8."""
+    _check_scores(scores)
+    N, T, Cc = scores.shape
+    sl = state_len_of(Cc)
+    lib = _lib.lib()
+    dev = scores.device
+    ws = torch.empty(lib.bh_crf_viterbi_workspace(N, T, sl), dtype=torch.uint8, device=dev)
+    moves = torch.empty((N, T), dtype=torch.int8, device=dev)
+    path = torch.empty((N, T), dtype=torch.int8, device=dev)
+    best = torch.empty((N,), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(lib.bh_crf_viterbi(_lib.ptr(scores), N, T, sl, 0, float(blank_score), T * Cc, Cc, _lib.ptr(ws),
+                                      _lib.ptr(moves), _lib.ptr(path), _lib.ptr(best), _lib.stream_ptr(dev)),
+                   "bh_crf_viterbi")
+    if return_score:
+        return moves.cpu(), path.cpu(), best.cpu()
+    return moves.cpu(), path.cpu()
+
+
+def viterbi_5s(scores_tnc, state_len, return_score=False):
+    """Same, on the reference's expand_blanks layout: fp16 [T, N, 5*4^state_len] (crf/model.py:49)."""
+    if scores_tnc.dtype != torch.float16 or not scores_tnc.is_cuda:
+        raise TypeError("expected cuda fp16 scores")
+    scores_tnc = scores_tnc.contiguous()
+    T, N, Cc = scores_tnc.shape
+    lib = _lib.lib()
+    dev = scores_tnc.device
+    ws = torch.empty(lib.bh_crf_viterbi_workspace(N, T, state_len), dtype=torch.uint8, device=dev)
+    moves = torch.empty((N, T), dtype=torch.int8, device=dev)
+    path = torch.empty((N, T), dtype=torch.int8, device=dev)
+    best = torch.empty((N,), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(lib.bh_crf_viterbi(_lib.ptr(scores_tnc), N, T, state_len, 1, 0.0, Cc, N * Cc, _lib.ptr(ws),
+                                      _lib.ptr(moves), _lib.ptr(path), _lib.ptr(best), _lib.stream_ptr(dev)),
+                   "bh_crf_viterbi")
+    if return_score:
+        return moves.cpu(), path.cpu(), best.cpu()
+    return moves.cpu(), path.cpu()
+
+
+def path_to_sequence(path):
+    """int8 path in {0..4} -> int8 ASCII bytes (0 where nothing is emitted): koi's `sequence` layout,
+    so ``to_str`` and ``stitch`` (crf/basecall.py:13-24,48-55) work on it unchanged."""
+    p = path.numpy() if isinstance(path, torch.Tensor) else np.asarray(path)
+    out = np.where(p != 0, _ALPHABET[p.astype(np.int64)], 0).astype(np.int8)
+    return torch.from_numpy(out)
+
+
+def to_str(x, encoding="ascii"):
+    """Non-zero bytes decoded as text (koi.decode.to_str)."""
+    a = x.numpy() if isinstance(x, torch.Tensor) else np.asarray(x)
+    a = a[a != 0]
+    return a.astype(np.uint8).tobytes().decode(encoding)

@@ -90,6 +90,8 @@ typedef struct bh_encoder bh_encoder_t;
 
 const char* bh_last_error(void);
 int bh_abi_version(void);
+/* sizeof(bh_layer_t) as compiled into the library (bindings check their struct mirror against it) */
+size_t bh_sizeof_layer(void);
 /* number of visible HIP devices, or <0 on error */
 int bh_device_count(void);
 
@@ -106,6 +108,14 @@ int bh_encoder_output_shape(const bh_encoder_t* enc, int L, int* T, int* C, int*
 int bh_encoder_forward(bh_encoder_t* enc, const void* signal, int N, int L, void* scores, void* stream);
 /* non-zero if a device-side timeout was raised by a persistent kernel since the last call (synchronises stream) */
 int bh_encoder_check(bh_encoder_t* enc, void* stream);
+
+/* Per-kernel-class timing with HIP events recorded on the forward's stream (measurement only).
+ * After enabling, every bh_encoder_forward appends spans; profile_read synchronises on them and returns
+ * accumulated milliseconds and span counts per class, then clears. */
+enum { BH_PROF_CONV = 0, BH_PROF_LSTM_GEMM = 1, BH_PROF_FILL = 2, BH_PROF_LSTM_REC = 3, BH_PROF_CRF_LINEAR = 4,
+       BH_PROF_ATTENTION = 5, BH_PROF_MLP = 6, BH_PROF_OTHER = 7, BH_PROF_CLASSES = 8 };
+int bh_encoder_profile(bh_encoder_t* enc, int enable);
+int bh_encoder_profile_read(bh_encoder_t* enc, float* ms /*[BH_PROF_CLASSES]*/, int* spans /*[BH_PROF_CLASSES]*/);
 
 /* ---- CRF decode ------------------------------------------------------------------------------ */
 /* Bytes of device workspace bh_crf_viterbi needs. */

@@ -1,0 +1,132 @@
+"""
+CPU ORACLE -- TEST INFRASTRUCTURE ONLY.  Python face of oracle/crf_oracle.c plus two independent
+restatements used to pin it:
+
+* ``viterbi_autograd``  -- literal torch restatement of the reference's formulation: the Max-semiring
+  "posteriors" are d logZ / d Ms (one-hot along the best path), then ``a = argmax``; ``moves = a % 5 != 0``;
+  ``paths = 1 + (a // 5) % 4`` (/root/reference bonito/crf/model.py:47-52,98-103; koi's
+  ``SequenceDist.posteriors`` is the autograd of logZ).
+* ``viterbi_bruteforce`` -- exhaustive enumeration over all (start state, transition) sequences for tiny T/S.
+
+PARITY UNPINNED by reference tests (none exist for this path); pinned by agreement of these three.
+"""
+import ctypes as C
+import itertools
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+def _lib():
+    global _LIB
+    if _LIB is None:
+        path = os.path.join(_HERE, "liboracle.so")
+        if not os.path.exists(path):
+            raise RuntimeError("oracle/liboracle.so missing: run `python build.py`")
+        _LIB = C.CDLL(path)
+    return _LIB
+
+
+def _as_half_bits(scores):
+    a = np.ascontiguousarray(np.asarray(scores, dtype=np.float16))
+    return a, a.view(np.uint16)
+
+
+def viterbi(scores, state_len, layout_5s=False, blank=2.0, time_major=False):
+    """scores: float16 array [N,T,C] (or [T,N,C] if time_major). Returns (moves, path, best)."""
+    a, bits = _as_half_bits(scores)
+    if time_major:
+        T, N, Cc = a.shape
+        s_n, s_t = Cc, N * Cc
+    else:
+        N, T, Cc = a.shape
+        s_n, s_t = T * Cc, Cc
+    moves = np.zeros((N, T), np.int8)
+    path = np.zeros((N, T), np.int8)
+    best = np.zeros((N,), np.float32)
+    rc = _lib().oracle_crf_viterbi(
+        bits.ctypes.data_as(C.c_void_p), N, T, int(state_len), int(layout_5s), C.c_float(blank),
+        C.c_long(s_n), C.c_long(s_t), moves.ctypes.data_as(C.c_void_p), path.ctypes.data_as(C.c_void_p),
+        best.ctypes.data_as(C.c_void_p))
+    if rc:
+        raise RuntimeError("oracle_crf_viterbi failed")
+    return moves, path, best
+
+
+def logz(scores, state_len, layout_5s=False, blank=2.0, time_major=False):
+    a, bits = _as_half_bits(scores)
+    if time_major:
+        T, N, Cc = a.shape
+        s_n, s_t = Cc, N * Cc
+    else:
+        N, T, Cc = a.shape
+        s_n, s_t = T * Cc, Cc
+    out = np.zeros((N,), np.float32)
+    rc = _lib().oracle_crf_logz(bits.ctypes.data_as(C.c_void_p), N, T, int(state_len), int(layout_5s),
+                                C.c_float(blank), C.c_long(s_n), C.c_long(s_t), out.ctypes.data_as(C.c_void_p))
+    if rc:
+        raise RuntimeError("oracle_crf_logz failed")
+    return out
+
+
+def expand_blanks(scores_4s, blank):
+    """koi layout [..., 4S] -> reference layout [..., 5S] (bonito/nn.py:291-297)."""
+    a = np.asarray(scores_4s)
+    x = a.reshape(*a.shape[:-1], -1, 4)
+    pad = np.full((*x.shape[:-1], 1), blank, dtype=a.dtype)
+    return np.concatenate([pad, x], axis=-1).reshape(*a.shape[:-1], -1)
+
+
+def idx_table(state_len, n_base=4):
+    S = n_base ** state_len
+    j = np.arange(S)
+    cols = [j] + [r * (S // n_base) + j // n_base for r in range(n_base)]
+    return np.stack(cols, axis=1).astype(np.int64)
+
+
+def viterbi_autograd(scores_tnc_5s, state_len):
+    """Reference formulation with torch autograd (fp64 to keep the argmax stable); returns path [T,N]."""
+    import torch
+    x = torch.as_tensor(np.asarray(scores_tnc_5s, dtype=np.float64)).requires_grad_(True)
+    T, N, _ = x.shape
+    S = 4 ** state_len
+    idx = torch.as_tensor(idx_table(state_len))
+    Ms = x.reshape(T, N, S, 5)
+    alpha = torch.zeros(N, S, dtype=torch.float64)
+    for t in range(T):
+        alpha = (Ms[t] + alpha[:, idx]).max(dim=-1).values
+    alpha.max(dim=-1).values.sum().backward()
+    tb = x.grad.reshape(T, N, -1)
+    a = tb.argmax(2)
+    moves = (a % 5) != 0
+    paths = 1 + (a // 5) % 4
+    return torch.where(moves, paths, torch.zeros_like(paths)).numpy()
+
+
+def viterbi_bruteforce(scores_tnc_5s, state_len):
+    """Exhaustive search; returns (best score [N], path [T,N]) for tiny problems."""
+    x = np.asarray(scores_tnc_5s, dtype=np.float64)
+    T, N, _ = x.shape
+    S = 4 ** state_len
+    idx = idx_table(state_len)
+    Ms = x.reshape(T, N, S, 5)
+    best = np.full(N, -np.inf)
+    paths = np.zeros((T, N), np.int64)
+    # a path = final state + the transition index k_t at every step, walked backwards
+    for n in range(N):
+        for final in range(S):
+            for ks in itertools.product(range(5), repeat=T):
+                st, sc = final, 0.0
+                for t in range(T - 1, -1, -1):
+                    sc += Ms[t, n, st, ks[t]]
+                    st = idx[st, ks[t]]
+                if sc > best[n]:
+                    best[n] = sc
+                    st = final
+                    for t in range(T - 1, -1, -1):
+                        paths[t, n] = 0 if ks[t] == 0 else 1 + (st % 4)
+                        st = idx[st, ks[t]]
+    return best, paths

@@ -1,0 +1,177 @@
+"""
+CPU ORACLE -- TEST INFRASTRUCTURE ONLY.  Plain PyTorch-CPU fp32 restatement of the encoder forward of
+``bonito.nn`` / ``bonito.crf`` / ``bonito.transformer`` module trees (/root/reference bonito/nn.py:
+Convolution 222-241, BatchNorm 192-198, LSTM/RNNWrapper 353-415, LinearCRFEncoder 269-298, Clamp 60-67,
+Permute 331-338, LinearUpsample 140-159, Serial 77-89; bonito/transformer/model.py:42-79,116-128).
+
+It walks either a reference module tree or a ``bonito_amd.nn`` parameter-container tree (they share
+attribute names) and evaluates it with explicit tensor algebra.  Pinned against the reference's own
+``bonito/nn.py`` executed by PyTorch-CPU: tests/golden/make_golden.py runs both on seeded weights and
+commits the vectors; tests/test_oracle_nn.py re-checks this file against them on every run.
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+
+def _name(m):
+    return getattr(m, "name", type(m).__name__.lower())
+
+
+def _act(m, x):
+    if m is None:
+        return x
+    n = _name(m)
+    if n in ("swish", "silu"):
+        return x * torch.sigmoid(x)
+    if n == "tanh":
+        return torch.tanh(x)
+    if n == "relu":
+        return torch.relu(x)
+    raise NotImplementedError(n)
+
+
+def conv_forward(m, x):
+    c = m.conv
+    h = F.conv1d(x, c.weight.float(), None if c.bias is None else c.bias.float(), stride=c.stride,
+                 padding=c.padding, dilation=c.dilation, groups=c.groups)
+    if m.norm is not None:
+        bn = m.norm.bn
+        h = (h - bn.running_mean.float()[None, :, None]) * torch.rsqrt(bn.running_var.float()[None, :, None] + bn.eps)
+        if bn.affine:
+            h = h * bn.weight.float()[None, :, None] + bn.bias.float()[None, :, None]
+    return _act(m.activation, h)
+
+
+def lstm_forward(m, x):
+    """x [T,N,I] -> [T,N,H]; gates i,f,g,o; h0=c0=0; `reverse` runs time backwards."""
+    r = m.rnn
+    W_ih, W_hh = r.weight_ih_l0.float(), r.weight_hh_l0.float()
+    b = 0
+    if r.bias:
+        b = r.bias_ih_l0.float() + r.bias_hh_l0.float()
+    T, N, _ = x.shape
+    H = r.hidden_size
+    h = torch.zeros(N, H)
+    c = torch.zeros(N, H)
+    out = torch.empty(T, N, H)
+    steps = range(T - 1, -1, -1) if m.reverse else range(T)
+    gx = x @ W_ih.T + b
+    for t in steps:
+        g = gx[t] + h @ W_hh.T
+        i, f, gg, o = g.chunk(4, dim=-1)
+        c = torch.sigmoid(f) * c + torch.sigmoid(i) * torch.tanh(gg)
+        h = torch.sigmoid(o) * torch.tanh(c)
+        out[t] = h
+    return out
+
+
+def crf_encoder_forward(m, x, expand_blanks=None):
+    if m.permute is not None:
+        x = x.permute(*m.permute)
+    s = x @ m.linear.weight.float().T
+    if m.linear.bias is not None:
+        s = s + m.linear.bias.float()
+    s = _act(m.activation, s)
+    if m.scale is not None:
+        s = s * m.scale
+    expand = m.expand_blanks if expand_blanks is None else expand_blanks
+    if m.blank_score is not None and expand:
+        T, N, C = s.shape
+        s = F.pad(s.view(T, N, C // m.n_base, m.n_base), (1, 0), value=m.blank_score).view(T, N, -1)
+    return s
+
+
+def rotary(qkv):
+    """RotaryEmbedding(head_dim, interleaved=False), base 10000, positions from 0, on q and k of a packed
+    [N,T,3,h,d] tensor ([EXT] flash_attn.layers.rotary)."""
+    N, T, _, h, d = qkv.shape
+    half = d // 2
+    inv = 1.0 / (10000.0 ** (torch.arange(0, d, 2, dtype=torch.float32) / d))
+    ang = torch.arange(T, dtype=torch.float32)[:, None] * inv[None, :]
+    cos, sin = ang.cos()[None, :, None, :], ang.sin()[None, :, None, :]
+    out = qkv.clone()
+    for i in (0, 1):
+        x1, x2 = qkv[:, :, i, :, :half], qkv[:, :, i, :, half:]
+        out[:, :, i, :, :half] = x1 * cos - x2 * sin
+        out[:, :, i, :, half:] = x1 * sin + x2 * cos
+    return out
+
+
+def window_mask(T, window):
+    i = torch.arange(T)[:, None]
+    j = torch.arange(T)[None, :]
+    return (j >= i - window[0]) & (j <= i + window[1])
+
+
+def transformer_layer_forward(m, x):
+    """x [N,T,D]; reference transformer/model.py:68-79,125-128 with the SDPA formulation (:62-65)."""
+    att = m.self_attn
+    N, T, D = x.shape
+    h, d = att.nhead, att.head_dim
+    qkv = (x @ att.Wqkv.weight.float().T).view(N, T, 3, h, d)
+    if att.Wqkv.bias is not None:
+        qkv = qkv + att.Wqkv.bias.float().view(3, h, d)
+    qkv = rotary(qkv)
+    q, k, v = (qkv[:, :, i].permute(0, 2, 1, 3) for i in range(3))
+    s = (q @ k.transpose(-1, -2)) / math.sqrt(d)
+    win = tuple(att.attn_window)
+    if win != (-1, -1):
+        s = s.masked_fill(~window_mask(T, win), float("-inf"))
+    o = (torch.softmax(s, dim=-1) @ v).permute(0, 2, 1, 3).reshape(N, T, D)
+    o = o @ att.out_proj.weight.float().T
+    if att.out_proj.bias is not None:
+        o = o + att.out_proj.bias.float()
+    alpha = float(m.deepnorm_alpha)
+
+    def rms(z, w, eps=1e-5):
+        return z * torch.rsqrt(z.pow(2).mean(-1, keepdim=True) + eps) * w.float()
+
+    x = rms(o + alpha * x, m.norm1.weight)
+    hmid = x @ m.ff.fc1.weight.float().T
+    y, gate = hmid.chunk(2, dim=-1)
+    f = (y * (gate * torch.sigmoid(gate))) @ m.ff.fc2.weight.float().T
+    return rms(f + alpha * x, m.norm2.weight)
+
+
+def forward(m, x, expand_blanks=None):
+    """Evaluate module tree `m` on fp32 CPU tensor x (reference layouts: NCL in, TNC scores out)."""
+    n = _name(m)
+    if n in ("serial", "namedserial", "stack", "sequential"):
+        for child in m.children():
+            x = forward(child, x, expand_blanks)
+        return x
+    if n == "convolution":
+        return conv_forward(m, x)
+    if n == "permute":
+        return x.permute(*m.dims)
+    if n == "makecontiguous":
+        return x.contiguous()
+    if n == "lstm":
+        return lstm_forward(m, x)
+    if n == "linearcrfencoder":
+        return crf_encoder_forward(m, x, expand_blanks)
+    if n == "clamp":
+        return torch.clamp(x, m.min, m.max)
+    if n == "linearupsample":
+        if not m.batch_first:
+            x = x.permute(1, 0, 2)
+        N, L, E = x.shape
+        hh = (x @ m.linear.weight.float().T + m.linear.bias.float()).reshape(N, m.scale_factor * L, E)
+        return hh if m.batch_first else hh.permute(1, 0, 2)
+    if n == "transformerencoderlayer":
+        return transformer_layer_forward(m, x)
+    if n == "seqdistmodel" or hasattr(m, "encoder"):
+        return forward(m.encoder, x, expand_blanks)
+    raise NotImplementedError("oracle has no restatement of layer %r" % n)
+
+
+def round_params_to_half_(m):
+    """Round every floating parameter/buffer to fp16 precision in place (kept as fp32): the oracle then
+    sees exactly the weights the fp16 engine sees."""
+    with torch.no_grad():
+        for p in list(m.parameters()) + list(m.buffers()):
+            if p.dtype.is_floating_point:
+                p.copy_(p.half().float())
+    return m

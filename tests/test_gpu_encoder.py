@@ -1,0 +1,88 @@
+"""End-to-end encoder engine (C ABI bh_encoder_*) vs the committed reference outputs (-m gpu)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import NN_FIXTURES, build_model, load_nn_fixture, ref_scores_to_koi
+from bonito_amd.engine import HipEncoder
+from oracle import crf_ref, nn_ref
+
+pytestmark = pytest.mark.gpu
+
+# fp16 activations / fp32 accumulation vs the fp32 CPU reference; scores live in [-5, 5] (fp16 ulp 4e-3)
+TOL_MAX, TOL_MEAN = 6e-2, 6e-3
+
+
+def _run(name, batch_pad=None):
+    cfg, sd, x, y = load_nn_fixture(name)
+    model = build_model(cfg, sd)
+    enc = HipEncoder(model, batchsize=batch_pad or x.shape[0], chunksize=x.shape[-1])
+    got = enc(x.half().cuda())
+    enc.check()
+    has_blank = any(getattr(m, "blank_score", None) is not None for m in model.modules())
+    want = ref_scores_to_koi(y, has_blank)
+    return got.cpu().float(), want
+
+
+@pytest.mark.parametrize("name", NN_FIXTURES)
+def test_encoder_matches_reference_fixture(name):
+    got, want = _run(name)
+    assert got.shape == want.shape
+    d = (got - want).abs()
+    assert d.max().item() < TOL_MAX and d.mean().item() < TOL_MEAN, (d.max().item(), d.mean().item())
+
+
+def test_encoder_batch_padding_and_reuse():
+    """N=3 is padded to 16 inside the engine; a larger max_batch and repeated calls change nothing."""
+    cfg, sd, x, y = load_nn_fixture("lstm32_sl2")
+    model = build_model(cfg, sd)
+    enc = HipEncoder(model, batchsize=40, chunksize=x.shape[-1])
+    xs = x.half().cuda()
+    a = enc(xs)
+    b = enc(xs)
+    big = enc(torch.cat([xs] * 11)[:33])
+    enc.check()
+    assert torch.equal(a, b)
+    assert torch.equal(big[:3], a) and torch.equal(big[30:33], a)
+
+
+def test_encoder_shorter_chunk_than_max():
+    cfg, sd, x, y = load_nn_fixture("lstm32_sl2")
+    model = build_model(cfg, sd)
+    enc = HipEncoder(model, batchsize=4, chunksize=1200)
+    xs = x[:, :, :300].half()
+    got = enc(xs.cuda()).cpu().float()
+    enc.check()
+    with torch.no_grad():
+        want = ref_scores_to_koi(nn_ref.forward(model, xs.float()))
+    assert got.shape == want.shape == (3, 50, 64)
+    assert (got - want).abs().max().item() < TOL_MAX
+
+
+def test_model_surface_forward_and_decode():
+    """bonito_amd.crf.Model: config -> use_koi -> load_state_dict -> half -> cuda -> forward -> HIP Viterbi,
+    and the HIP decode of the HIP scores equals the oracle decode of the same scores bit for bit."""
+    from bonito_amd import decode
+    from bonito_amd.crf.model import Model
+    cfg, sd, x, y = load_nn_fixture("lstm64_sl3")
+    config = {"model": {"package": "bonito.crf"}, "labels": {"labels": ["N", "A", "C", "G", "T"]},
+              "input": {"features": 1}, "global_norm": {"state_len": 3}, "encoder": cfg}
+    model = Model(config)
+    model.use_koi(batchsize=4, chunksize=1200, quantize=False)
+    model.load_state_dict({"encoder." + k: v for k, v in sd.items()})
+    model = model.half().eval().to("cuda")
+    assert model.stride == 6
+    scores = model(x.half().cuda())
+    assert scores.shape == (2, 200, 256) and scores.dtype == torch.float16 and scores.is_contiguous()
+    moves, path = decode.viterbi(scores)
+    om, op, _ = crf_ref.viterbi(scores.cpu().numpy(), 3, blank=2.0)
+    assert np.array_equal(path.numpy(), op) and np.array_equal(moves.numpy(), om)
+    seq = decode.to_str(decode.path_to_sequence(path[0]))
+    assert set(seq) <= set("ACGT") and len(seq) == int((path[0] != 0).sum())
+
+
+def test_engine_fails_loudly_on_unsupported_layers():
+    from bonito_amd import nn as bnn
+    from bonito_amd.engine import LoweringError
+    with pytest.raises(LoweringError):
+        HipEncoder(bnn.Serial([bnn.Linear(8, 8)]), 1, 100)

@@ -1,0 +1,207 @@
+"""GPU parity of the operator-level C ABI against fp32 CPU restatements (run with -m gpu on MI355X)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from bonito_amd import _lib
+
+pytestmark = pytest.mark.gpu
+INF = float("inf")
+
+
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    return torch.device("cuda", 0)
+
+
+def _linear(x, w, bias=None, act=0, scale=1.0, lo=-INF, hi=INF, gated=0, row=(0, 0, 0, 0), out_rows=None):
+    M, K = x.shape
+    N = w.shape[0]
+    ncol = N // 2 if gated else N
+    out = torch.zeros((out_rows or M, ncol), dtype=torch.float16, device=x.device)
+    b = None if bias is None else bias.float().contiguous()
+    _lib.check(_lib.lib().bh_linear(_lib.ptr(x), _lib.ptr(w), _lib.ptr(b), _lib.ptr(out), M, N, K, K, K, ncol,
+                                    act, scale, lo, hi, gated, row[0], row[1], row[2], row[3], _lib.stream_ptr()),
+               "bh_linear")
+    torch.cuda.synchronize()
+    return out
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 384, 96), (1000, 1024, 384), (77, 80, 32), (4096, 1536, 384)])
+def test_linear_plain(M, N, K):
+    g = torch.Generator().manual_seed(M + N + K)
+    x = (torch.randn(M, K, generator=g) * 0.5).half()
+    w = (torch.randn(N, K, generator=g) * 0.2).half()
+    b = torch.randn(N, generator=g)
+    want = x.float() @ w.float().T + b
+    got = _linear(x.to(dev()), w.to(dev()), b.to(dev())).cpu().float()
+    assert (got - want).abs().max().item() < 2e-2 + 2e-3 * want.abs().max().item()
+
+
+def test_linear_asymmetric_identity():
+    """A = I against an asymmetric W catches transposed / permuted fragment layouts exactly."""
+    K = N = 128
+    x = torch.eye(K).half()
+    w = (torch.arange(N * K).reshape(N, K) % 251 / 16.0).half()
+    got = _linear(x.to(dev()), w.to(dev())).cpu()
+    assert torch.equal(got, w.T.contiguous())
+
+
+@pytest.mark.parametrize("act,scale,lo,hi", [(2, 5.0, -INF, INF), (0, 1.0, -5.0, 5.0), (1, 1.0, -0.5, 3.5)])
+def test_linear_epilogues(act, scale, lo, hi):
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(200, 96, generator=g).half()
+    w = (torch.randn(256, 96, generator=g) * 0.3).half()
+    z = x.float() @ w.float().T
+    z = {0: z, 1: z * torch.sigmoid(z), 2: torch.tanh(z)}[act] * scale
+    want = z.clamp(lo, hi)
+    got = _linear(x.to(dev()), w.to(dev()), act=act, scale=scale, lo=lo, hi=hi).cpu().float()
+    assert (got - want).abs().max().item() < 1.5e-2
+
+
+def test_linear_row_remap_drops_padding():
+    """TNC rows -> NTC output with padded batch rows skipped (engine's final CRF linear)."""
+    T, Np, Nv, K, Cc = 7, 16, 11, 64, 64
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(T * Np, K, generator=g).half()
+    w = (torch.randn(Cc, K, generator=g) * 0.2).half()
+    want = (x.float() @ w.float().T).view(T, Np, Cc)[:, :Nv].permute(1, 0, 2).reshape(Nv * T, Cc)
+    got = _linear(x.to(dev()), w.to(dev()), row=(Np, 1, T, Nv), out_rows=Nv * T).cpu().float()
+    assert (got - want).abs().max().item() < 2e-2
+
+
+def test_linear_gated_swiglu():
+    g = torch.Generator().manual_seed(6)
+    x = torch.randn(130, 64, generator=g).half()
+    w = (torch.randn(256, 64, generator=g) * 0.3).half()     # rows already interleaved (y0, g0, y1, g1, ...)
+    z = x.float() @ w.float().T
+    y, gate = z[:, 0::2], z[:, 1::2]
+    want = y * gate * torch.sigmoid(gate)
+    got = _linear(x.to(dev()), w.to(dev()), gated=1).cpu().float()
+    assert (got - want).abs().max().item() < 2e-2
+
+
+def test_linear_rejects_bad_shapes():
+    x = torch.zeros(4, 12, dtype=torch.float16, device=dev())
+    w = torch.zeros(4, 12, dtype=torch.float16, device=dev())
+    out = torch.zeros(4, 8, dtype=torch.float16, device=dev())
+    rc = _lib.lib().bh_linear(_lib.ptr(x), _lib.ptr(w), None, _lib.ptr(out), 4, 4, 12, 12, 12, 8, 0, 1.0, -INF, INF,
+                              0, 0, 0, 0, 0, _lib.stream_ptr())
+    assert rc != 0 and "multiples of 8" in _lib.last_error()
+
+
+@pytest.mark.parametrize("Cout,K,stride,act", [(16, 5, 1, 1), (64, 5, 1, 1), (344, 9, 3, 0), (8, 19, 6, 2)])
+def test_conv_first(Cout, K, stride, act):
+    g = torch.Generator().manual_seed(Cout)
+    N, L = 3, 1000
+    x = torch.randn(N, L, generator=g).half()
+    w = torch.randn(Cout, 1, K, generator=g) * 0.4
+    b = torch.randn(Cout, generator=g) * 0.1
+    z = F.conv1d(x.float()[:, None], w, b, stride=stride, padding=K // 2)
+    want = {0: z, 1: z * torch.sigmoid(z), 2: torch.tanh(z)}[act].permute(0, 2, 1)   # [N][Lout][C]
+    Lout = want.shape[1]
+    out = torch.zeros((N, Lout, Cout), dtype=torch.float16, device=dev())
+    wd, bd = w.reshape(Cout, K).contiguous().to(dev()), b.to(dev())
+    _lib.check(_lib.lib().bh_conv1d_first(_lib.ptr(x.to(dev())), _lib.ptr(wd), _lib.ptr(bd), _lib.ptr(out), N, L, Cout,
+                                          K, stride, K // 2, act, -INF, INF, Lout * Cout, Cout, _lib.stream_ptr()),
+               "conv1d_first")
+    torch.cuda.synchronize()
+    assert (out.cpu().float() - want).abs().max().item() < 1e-2
+
+
+def _pack_conv(w):
+    Cout, Cin, K = w.shape
+    lib = _lib.lib()
+    n = lib.bh_conv1d_packed_halves(Cin, Cout, K)
+    pk = np.zeros(n, np.uint16)
+    wf = np.ascontiguousarray(w.numpy().astype(np.float32))
+    _lib.check(lib.bh_conv1d_pack(wf.ctypes.data_as(C.c_void_p), Cin, Cout, K, pk.ctypes.data_as(C.c_void_p)), "pack")
+    return torch.from_numpy(pk.view(np.int16)).to(dev())
+
+
+@pytest.mark.parametrize("Cin,Cout,K,stride,L,tnc", [
+    (16, 16, 5, 1, 1000, False), (16, 96, 19, 6, 1200, True), (16, 384, 19, 6, 3000, True),
+    (64, 128, 9, 3, 900, False), (128, 128, 9, 2, 700, False), (128, 512, 5, 2, 333, False), (8, 20, 3, 1, 50, False)])
+def test_conv_igemm(Cin, Cout, K, stride, L, tnc):
+    g = torch.Generator().manual_seed(Cin * Cout + K)
+    N = 3
+    x = (torch.randn(N, Cin, L, generator=g) * 0.7).half()
+    w = (torch.randn(Cout, Cin, K, generator=g) * (1.0 / (Cin * K) ** 0.5)).half().float()
+    b = torch.randn(Cout, generator=g) * 0.1
+    z = F.conv1d(x.float(), w, b, stride=stride, padding=K // 2)
+    want = (z * torch.sigmoid(z)).clamp(-0.5, 3.5)
+    Lout = want.shape[-1]
+    xin = x.permute(0, 2, 1).contiguous().to(dev())                       # channel-minor [N][L][Cin]
+    if tnc:
+        out = torch.zeros((Lout, N, Cout), dtype=torch.float16, device=dev())
+        os_n, os_t = Cout, N * Cout
+        want = want.permute(2, 0, 1)
+    else:
+        out = torch.zeros((N, Lout, Cout), dtype=torch.float16, device=dev())
+        os_n, os_t = Lout * Cout, Cout
+        want = want.permute(0, 2, 1)
+    _lib.check(_lib.lib().bh_conv1d(_lib.ptr(xin), _lib.ptr(_pack_conv(w)), _lib.ptr(b.to(dev())), _lib.ptr(out), N, L,
+                                    Cin, Cout, K, stride, K // 2, 1, -0.5, 3.5, os_n, os_t, _lib.stream_ptr()), "conv1d")
+    torch.cuda.synchronize()
+    assert (out.cpu().float() - want).abs().max().item() < 1.5e-2
+
+
+def _lstm_ref(G, Whh, reverse):
+    T, N, H4 = G.shape
+    H = H4 // 4
+    h = torch.zeros(N, H)
+    c = torch.zeros(N, H)
+    out = torch.empty(T, N, H)
+    for t in (range(T - 1, -1, -1) if reverse else range(T)):
+        g = G[t] + h @ Whh.T
+        i, f, gg, o = g.chunk(4, -1)
+        c = torch.sigmoid(f) * c + torch.sigmoid(i) * torch.tanh(gg)
+        h = torch.sigmoid(o) * torch.tanh(c)
+        out[t] = h
+        h = h.half().float()        # the engine publishes h in fp16
+    return out
+
+
+@pytest.mark.parametrize("H,N,T,reverse", [(32, 16, 40, 0), (96, 48, 60, 1), (384, 64, 50, 0), (384, 512, 30, 1),
+                                           (128, 16, 33, 1), (512, 32, 20, 0)])
+def test_lstm_layer(H, N, T, reverse):
+    g = torch.Generator().manual_seed(H + N)
+    G = (torch.randn(T, N, 4 * H, generator=g) * 1.5).half()
+    Whh = (torch.randn(4 * H, H, generator=g) * (1.0 / H ** 0.5)).half().float()
+    want = _lstm_ref(G.float(), Whh, reverse)
+    lib = _lib.lib()
+    pk = np.zeros(4 * H * H, np.uint16)
+    wf = np.ascontiguousarray(Whh.numpy())
+    _lib.check(lib.bh_lstm_pack_whh(wf.ctypes.data_as(C.c_void_p), H, pk.ctypes.data_as(C.c_void_p)), "pack_whh")
+    pkd = torch.from_numpy(pk.view(np.int16)).to(dev())
+    h = torch.zeros((T, N, H), dtype=torch.float16, device=dev())
+    err = torch.zeros(1, dtype=torch.int32, device=dev())
+    _lib.check(lib.bh_lstm_layer(_lib.ptr(G.to(dev())), _lib.ptr(pkd), _lib.ptr(h), T, N, H, reverse, _lib.ptr(err),
+                                 _lib.stream_ptr()), "lstm_layer")
+    torch.cuda.synchronize()
+    assert err.item() == 0, "persistent LSTM kernel hit its spin bound"
+    d = (h.cpu().float() - want).abs()
+    assert d.max().item() < 6e-3, d.max().item()
+
+
+def test_lstm_layer_is_deterministic_and_restartable():
+    """Same call twice (buffer re-poisoned by the ABI) -> identical bytes."""
+    H, N, T = 96, 32, 25
+    g = torch.Generator().manual_seed(1)
+    G = torch.randn(T, N, 4 * H, generator=g).half().to(dev())
+    Whh = (torch.randn(4 * H, H, generator=g) * 0.1).numpy()
+    lib = _lib.lib()
+    pk = np.zeros(4 * H * H, np.uint16)
+    lib.bh_lstm_pack_whh(np.ascontiguousarray(Whh).ctypes.data_as(C.c_void_p), H, pk.ctypes.data_as(C.c_void_p))
+    pkd = torch.from_numpy(pk.view(np.int16)).to(dev())
+    outs = []
+    err = torch.zeros(1, dtype=torch.int32, device=dev())
+    for _ in range(2):
+        h = torch.zeros((T, N, H), dtype=torch.float16, device=dev())
+        _lib.check(lib.bh_lstm_layer(_lib.ptr(G), _lib.ptr(pkd), _lib.ptr(h), T, N, H, 0, _lib.ptr(err), _lib.stream_ptr()))
+        torch.cuda.synchronize()
+        outs.append(h.cpu())
+    assert err.item() == 0 and torch.equal(outs[0], outs[1])

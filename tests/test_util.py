@@ -1,0 +1,105 @@
+"""Host logic (bonito_amd/util.py) vs fixtures produced by the reference's bonito/util.py (CPU only)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN
+from bonito_amd import util
+
+with open(os.path.join(GOLDEN, "util_cases.json")) as fh:
+    CASES = json.load(fh)
+
+
+@pytest.mark.parametrize("case", CASES["chunk_stitch"], ids=lambda c: "T%d_c%d_o%d" % (c["T"], c["chunksize"], c["overlap"]))
+def test_chunk_and_stitch(case):
+    T, cs, ov, stride = case["T"], case["chunksize"], case["overlap"], case["stride"]
+    sig = torch.arange(T, dtype=torch.float32)
+    ch = util.chunk(sig, cs, ov)
+    assert list(ch.shape) == case["chunk_shape"]
+    assert ch[:, 0, 0].tolist() == case["chunk_first"]
+    assert ch[:, 0, -1].tolist() == case["chunk_last"]
+    if not cs:
+        return
+    n, _, L = ch.shape
+    steps = L // stride
+    per = torch.stack([ch[i, 0, ::stride][:steps] for i in range(n)]).to(torch.int64)
+    if T < cs:
+        st = per[0, : int(np.floor(T / stride))]
+    else:
+        st = util.stitch(per, cs, ov, T, stride)
+    assert st.tolist() == case["stitched"]
+    if "stitched_rev" in case:
+        assert util.stitch(per, cs, ov, T, stride, reverse=True).tolist() == case["stitched_rev"]
+
+
+def test_stitch_covers_read_once():
+    """size-independent property: stitched steps are strictly increasing sample offsets covering the read."""
+    T, cs, ov, stride = 50000, 9996, 492, 6
+    sig = torch.arange(T, dtype=torch.float32)
+    ch = util.chunk(sig, cs, ov)
+    per = torch.stack([c[0, ::stride][: cs // stride] for c in ch]).to(torch.int64)
+    st = util.stitch(per, cs, ov, T, stride)
+    d = np.diff(st.numpy())
+    assert (d > 0).all() and d.max() <= 2 * stride
+    assert st[0] == 0 and st[-1] >= T - stride - 1
+
+
+def test_batchify_unbatchify_golden():
+    g = CASES["batchify"]
+    items = [("r%d" % i, torch.arange(n * 3, dtype=torch.float32).reshape(n, 1, 3) + 100 * i)
+             for i, n in enumerate([3, 1, 7, 2, 5])]
+    batches = list(util.batchify(iter(items), 4))
+    assert [[[k, list(r)] for k, r in ks] for ks, _ in batches] == g["batch_keys"]
+    assert [list(v.shape) for _, v in batches] == g["batch_shapes"]
+    assert [float(v.sum()) for _, v in batches] == g["batch_sums"]
+    rebuilt = list(util.unbatchify(batches))
+    assert [[k, list(v.shape), float(v.sum())] for k, v in rebuilt] == g["unbatch"]
+    for (k0, v0), (k1, v1) in zip(items, rebuilt):
+        assert k0 == k1 and torch.equal(v0, v1)
+
+
+def test_unbatchify_dict_values_and_empty():
+    """crf.basecall feeds unbatchify with dict-of-tensors batches keyed like batchify's output."""
+    assert list(util.batchify(iter([]), 4)) == []
+    keys0 = (("a", (0, 3)), ("b", (3, 4)))
+    keys1 = (("b", (0, 2)),)
+    b0 = {"x": np.arange(4), "y": np.arange(4) * 2}
+    b1 = {"x": np.arange(4, 6), "y": np.arange(4, 6) * 2}
+    out = list(util.unbatchify(iter([(keys0, b0), (keys1, b1)])))
+    assert [k for k, _ in out] == ["a", "b"]
+    assert out[0][1]["y"].tolist() == [0, 2, 4]
+    assert out[1][1]["x"].tolist() == [3, 4, 5]
+
+
+def test_phred_and_mean_qscore():
+    assert util.phred(0.0) == "!" and util.phred(1.0) == chr(33 + 40)
+    assert util.phred(0.9) == chr(33 + 10)
+    assert abs(util.mean_qscore_from_qstring("5555") - 20.0) < 1e-6
+    assert util.mean_qscore_from_qstring("") == 0.0
+
+
+def test_config_defaults_and_rounding():
+    cfg = util.set_config_defaults({}, None, None, None)
+    assert cfg["basecaller"] == {"chunksize": 4000, "overlap": 500, "batchsize": 64, "quantize": False}
+    cfg = util.set_config_defaults({"basecaller": {"chunksize": 10000, "overlap": 500, "batchsize": 96}}, batchsize=512)
+    assert cfg["basecaller"]["batchsize"] == 512 and cfg["basecaller"]["chunksize"] == 10000
+
+
+def test_match_names_by_shape_order():
+    from bonito_amd import nn as bnn
+    from conftest import load_nn_fixture
+    cfg, sd, _, _ = load_nn_fixture("lstm32_sl2")
+    model = bnn.from_dict(cfg)
+    renamed = {"foo.%d" % i: v for i, (k, v) in enumerate(sd.items())}
+    remap = util.match_names(renamed, model)
+    assert list(remap.values()) == list(sd.keys())
+
+
+def test_load_symbol_maps_reference_packages():
+    from bonito_amd.crf import Model, basecall
+    cfg = {"model": {"package": "bonito.crf"}}
+    assert util.load_symbol(cfg, "Model") is Model
+    assert util.load_symbol(cfg, "basecall") is basecall

@@ -1,0 +1,58 @@
+#!/usr/bin/env python3
+"""Prints parity error statistics + quick timings on the GPU box (used to set test tolerances)."""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+import torch
+
+from conftest import NN_FIXTURES, build_model, load_nn_fixture, ref_scores_to_koi
+from bonito_amd.engine import HipEncoder
+from bonito_amd import decode, synthetic
+from oracle import crf_ref
+
+print(torch.cuda.get_device_name(0), torch.cuda.get_device_properties(0).multi_processor_count, "CUs")
+for name in NN_FIXTURES:
+    cfg, sd, x, y = load_nn_fixture(name)
+    model = build_model(cfg, sd)
+    enc = HipEncoder(model, batchsize=x.shape[0], chunksize=x.shape[-1])
+    got = enc(x.half().cuda()); enc.check()
+    has_blank = any(getattr(m, "blank_score", None) is not None for m in model.modules())
+    want = ref_scores_to_koi(y, has_blank)
+    d = (got.cpu().float() - want).abs()
+    print("%-20s max %.4f mean %.5f  (|want| max %.2f)" % (name, d.max(), d.mean(), want.abs().max()))
+
+for name, N in (("fast", 512), ("hac", 512)):
+    model = synthetic.make_model(name)
+    model.use_koi(batchsize=N, chunksize=10000, quantize=False)
+    model = model.half().cuda()
+    sig = torch.randn(N, 1, 10000, device="cuda").half()
+    for _ in range(2):
+        sc = model(sig)
+    model._hip.check()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(3):
+        sc = model(sig)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    mv, pa = decode.viterbi(sc)
+    torch.cuda.synchronize()
+    t2 = time.perf_counter()
+    mv, pa = decode.viterbi(sc)
+    torch.cuda.synchronize()
+    t3 = time.perf_counter()
+    model._hip.check()
+    model._hip.profile(True)
+    model(sig)
+    prof = model._hip.profile_read()
+    print(name, "encoder ms/batch %.2f  viterbi ms %.2f  samples/s enc-only %.3e" % ((t1 - t0) / 3 * 1e3, (t3 - t2) * 1e3, N * 10000 / ((t1 - t0) / 3)))
+    print("   ", {k: (round(v[0], 3), v[1]) for k, v in prof.items() if v[1]})
+    print("    scores finite:", bool(torch.isfinite(sc).all()), "std %.3f" % sc.float().std().item(),
+          "bases/chunk %.1f" % float((pa != 0).sum() / N))
+    om, op, _ = crf_ref.viterbi(sc[:2].cpu().numpy(), model.seqdist.state_len)
+    print("    viterbi exact on 2 chunks:", np.array_equal(pa[:2].numpy(), op))
