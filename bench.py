@@ -42,15 +42,27 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline(name, chunk, seconds_budget=20.0):
+def log(msg):
+    sys.stderr.write("[bench %7.1fs] %s\n" % (time.perf_counter() - T_START, msg))
+    sys.stderr.flush()
+
+
+T_START = time.perf_counter()
+
+
+def cpu_baseline_worker(name, chunk, seconds_budget=15.0):
     """CPU oracle timed on this host: oracle/nn_ref.py forward (fp32) + oracle/crf_oracle.c Viterbi."""
     from bonito_amd import synthetic
     from oracle import crf_ref, nn_ref
     model = synthetic.make_model(name)
     nn_ref.round_params_to_half_(model)
-    ncores = os.cpu_count() or 1
+    try:
+        ncores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        ncores = os.cpu_count() or 1
+    ncores = max(1, min(ncores, 32))      # small per-step matmuls stop scaling long before that
     torch.set_num_threads(ncores)
-    n = 2
+    n = 8
     x = torch.randn(n, 1, chunk, generator=torch.Generator().manual_seed(25)).half().float()
     reps, t_total = 0, 0.0
     while t_total < seconds_budget and reps < 8:
@@ -63,6 +75,23 @@ def cpu_baseline(name, chunk, seconds_budget=20.0):
         reps += 1
     return {"value": n * chunk * reps / t_total, "unit": "samples/s", "cores": ncores, "kind": "port",
             "sample": "%d reps of %d chunks x %d samples, oracle/nn_ref.py fp32 forward + C Viterbi" % (reps, n, chunk)}
+
+
+def cpu_baseline(name, chunk, hard_timeout=90.0):
+    """Run the CPU leg in a child process with a hard wall-clock bound so it can never stall the bench."""
+    import subprocess
+    code = ("import json,sys; sys.path.insert(0, %r); import bench; "
+            "print('CPU_BASELINE ' + json.dumps(bench.cpu_baseline_worker(%r, %d)))" % (ROOT, name, chunk))
+    try:
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=hard_timeout,
+                           env=dict(os.environ, HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES=""))
+        for line in r.stdout.splitlines():
+            if line.startswith("CPU_BASELINE "):
+                return json.loads(line[len("CPU_BASELINE "):])
+        log("cpu baseline produced no result: " + r.stderr[-400:])
+    except subprocess.TimeoutExpired:
+        log("cpu baseline exceeded %.0fs and was abandoned" % hard_timeout)
+    return None
 
 
 def main():
@@ -80,6 +109,7 @@ def main():
     dev = torch.device("cuda", local)
 
     from bonito_amd import decode, synthetic
+    log("building model %s" % a.model)
     model = synthetic.make_model(a.model, batchsize=a.batch, chunksize=a.chunk)
     model.use_koi(batchsize=a.batch, chunksize=a.chunk, quantize=False)
     model = model.half().to(dev)
@@ -99,10 +129,12 @@ def main():
             dist.barrier(device_ids=[local])
         torch.cuda.synchronize(dev)
 
+    log("warmup")
     for _ in range(a.warmup):
         step()
     model._hip.check()
     barrier()
+    log("timed region")
     t0 = time.perf_counter()
     for _ in range(a.steps):
         step()
@@ -113,6 +145,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     model._hip.check()
+    log("timed region done: %.1f ms/step" % (1e3 * elapsed / a.steps))
 
     # ---- roofline leg: per-kernel-class HIP-event timings on the engine's stream (after the timed region)
     roof = None
@@ -149,6 +182,7 @@ def main():
                 "avg_launch_ms": round(avg_ms, 4), "flops_per_launch": flops_per_launch}
 
     if rank == 0:
+        log("roofline leg done; cpu baseline")
         samples = a.batch * a.chunk * a.steps * world
         out = {
             "metric": "signal samples/sec/GPU (chunk=10000, batch=512) + read accuracy vs ref",

@@ -58,7 +58,9 @@ SIGNATURES = {
     "bh_conv1d_pack": (_i, [_vp, _i, _i, _i, _vp]),
     "bh_conv1d": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _f, _f, _l, _l, _vp]),
     "bh_lstm_pack_whh": (_i, [_vp, _i, _vp]),
-    "bh_lstm_layer": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    "bh_lstm_workspace": (_sz, [_i, _i]),
+    "bh_lstm_layer": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _vp]),
+    "bh_encoder_set_option": (_i, [_vp, C.c_char_p, _i]),
 }
 
 _lib = None

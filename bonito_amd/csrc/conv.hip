@@ -27,6 +27,7 @@ struct ConvFirstArgs {
     int N, Lin, Lout, Cout, K, stride, pad, act;
     float clamp_lo, clamp_hi;
     long os_n, os_t;
+    int vec8;
 };
 
 __global__ __launch_bounds__(256) void conv_first_kernel(ConvFirstArgs p) {
@@ -49,19 +50,23 @@ __global__ __launch_bounds__(256) void conv_first_kernel(ConvFirstArgs p) {
     if (t >= p.Lout) return;
     const float* x = sl + threadIdx.x * p.stride;
     half_t* dst = p.out + (long)n * p.os_n + (long)t * p.os_t;
-    for (int c0 = 0; c0 < p.Cout; c0 += 8) {
-        half8_t o;
+    auto channel = [&](int c) {
+        const float* wr = wl + c * p.K;
+        float a = bl[c];
+        for (int k = 0; k < p.K; ++k) a = fmaf(wr[k], x[k], a);
+        a = apply_act_rt(a, p.act);
+        return (half_t)fminf(fmaxf(a, p.clamp_lo), p.clamp_hi);
+    };
+    int c0 = 0;
+    if (p.vec8) {   // Cout and both output strides are multiples of 8: 16-byte packed stores
+        for (; c0 + 8 <= p.Cout; c0 += 8) {
+            half8_t o;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const float* wr = wl + (c0 + j) * p.K;
-            float a = bl[c0 + j];
-            for (int k = 0; k < p.K; ++k) a = fmaf(wr[k], x[k], a);
-            a = apply_act_rt(a, p.act);
-            a = fminf(fmaxf(a, p.clamp_lo), p.clamp_hi);
-            o[j] = (half_t)a;
+            for (int j = 0; j < 8; ++j) o[j] = channel(c0 + j);
+            *(half8_t*)(dst + c0) = o;
         }
-        *(half8_t*)(dst + c0) = o;
     }
+    for (; c0 < p.Cout; ++c0) dst[c0] = channel(c0);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -153,10 +158,10 @@ int bh_k_conv_first(const void* signal, const float* w, const float* bias, void*
                     int Lout, int Cout, int K, int stride, int pad, int act, float clamp_lo,
                     float clamp_hi, long os_n, long os_t, hipStream_t stream) {
     using namespace bh;
-    BH_REQUIRE(K <= 32 && Cout % 8 == 0, "conv_first: need K<=32 and Cout%%8==0 (K=%d Cout=%d)", K, Cout);
-    BH_REQUIRE(os_t % 8 == 0 && os_n % 8 == 0, "conv_first: output strides must be multiples of 8");
+    BH_REQUIRE(K >= 1 && Cout >= 1, "conv_first: bad shape (K=%d Cout=%d)", K, Cout);
+    const int vec8 = (Cout % 8 == 0 && os_t % 8 == 0 && os_n % 8 == 0 && ((uintptr_t)out & 15) == 0) ? 1 : 0;
     ConvFirstArgs a{(const half_t*)signal, w, bias, (half_t*)out, N, Lin, Lout, Cout, K, stride, pad,
-                    act, clamp_lo, clamp_hi, os_n, os_t};
+                    act, clamp_lo, clamp_hi, os_n, os_t, vec8};
     size_t lds = (size_t)(Cout * K + Cout + 255 * stride + K) * sizeof(float);
     hipLaunchKernelGGL(conv_first_kernel, dim3((Lout + 255) / 256, N), dim3(256), lds, stream, a);
     BH_CHECK_HIP(hipGetLastError());

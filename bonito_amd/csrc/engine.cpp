@@ -121,6 +121,10 @@ struct Layer {
     DevBuf w0, w1, w2, w3, w4, w5, b0, b1;
     bool fused_clamp = false;   // a following CLAMP was folded into this layer
     float clamp_lo = -INFINITY, clamp_hi = INFINITY;
+    // convolution: channel counts as laid out in memory. Channel-minor activations between two
+    // convolutions are padded to a multiple of 8 channels (zero weights / zero bias -> act(0) = 0),
+    // so e.g. the old-style 1 -> 4 -> 16 front end (crf/model.py:153-154) still runs on MFMA.
+    int cin_eff = 0, cout_eff = 0;
 };
 
 enum Layout { L_SIGNAL, L_NLC, L_TNC };
@@ -133,6 +137,7 @@ struct ProfSpan {
 };
 
 static inline int pad16(int n) { return (n + 15) / 16 * 16; }
+static inline int pad8(int n) { return (n + 7) / 8 * 8; }
 static inline int conv_out_len(int L, int K, int stride, int pad) { return (L + 2 * pad - K) / stride + 1; }
 
 }  // namespace
@@ -142,8 +147,9 @@ struct bh_encoder {
     int max_batch = 0, max_chunk = 0;
     int n_cus = 0;
     std::vector<Layer> layers;
-    DevBuf act[2], gates, sig, err;
+    DevBuf act[2], gates, sig, err, lstm_ws;
     int out_features = 0;
+    int lstm_force_slow = 0;
     // optional per-kernel-class timing with HIP events on the caller's stream (bench.py roofline leg)
     bool profiling = false;
     struct Span { int cls; hipEvent_t a, b; };
@@ -154,7 +160,7 @@ struct bh_encoder {
             l.w0.release(); l.w1.release(); l.w2.release(); l.w3.release();
             l.w4.release(); l.w5.release(); l.b0.release(); l.b1.release();
         }
-        act[0].release(); act[1].release(); gates.release(); sig.release(); err.release();
+        act[0].release(); act[1].release(); gates.release(); sig.release(); err.release(); lstm_ws.release();
     }
 };
 
@@ -183,7 +189,7 @@ static int walk(const bh_encoder* e, int N, int L, int* T_out, int* C_out, size_
                 len = conv_out_len((int)len, l.d.winlen, l.d.stride, l.d.padding);
                 BH_REQUIRE(len > 0, "encoder: chunk of %d samples is too short for the convolution stack", L);
                 C = l.d.out_size;
-                amax = std::max(amax, (size_t)N * len * C * 2);
+                amax = std::max(amax, (size_t)N * len * std::max(l.cout_eff, C) * 2);
                 break;
             case BH_LAYER_LSTM:
                 C = l.d.out_size;
@@ -234,6 +240,7 @@ extern "C" int bh_encoder_create(const bh_layer_t* layers, int n_layers, int dev
         return fail(-1);
     }
     e->layers.resize(n_layers);
+    int cur_channels = 1, cur_channels_eff = 1;
     for (int i = 0; i < n_layers; ++i) {
         Layer& L = e->layers[i];
         L.d = layers[i];
@@ -245,14 +252,40 @@ extern "C" int bh_encoder_create(const bh_layer_t* layers, int n_layers, int dev
                     return fail(-2);
                 }
                 if (d.groups > 1) { bh_set_error("encoder_create: layer %d: grouped conv not supported here", i); return fail(-2); }
+                // does another convolution consume this output (possibly through a clamp)?
+                bool next_is_conv = false;
+                for (int j = i + 1; j < n_layers; ++j) {
+                    if (layers[j].kind == BH_LAYER_CLAMP) continue;
+                    next_is_conv = layers[j].kind == BH_LAYER_CONV;
+                    break;
+                }
+                const int K = d.winlen;
+                L.cin_eff = d.in_size == 1 ? 1 : cur_channels_eff;
+                L.cout_eff = next_is_conv ? pad8(d.out_size) : d.out_size;
+                if (d.in_size != 1 && (cur_channels != d.in_size || L.cin_eff < d.in_size)) {
+                    bh_set_error("encoder_create: layer %d: convolution expects %d input channels, chain provides %d", i, d.in_size, cur_channels);
+                    return fail(-2);
+                }
+                std::vector<float> bpad((size_t)L.cout_eff, 0.0f);
+                if (d.b0) for (int f = 0; f < d.out_size; ++f) bpad[f] = d.b0[f];
                 if (d.in_size == 1) {
-                    rc = upload_f32(L.w0, d.w0, (size_t)d.out_size * d.winlen);
+                    std::vector<float> wpad((size_t)L.cout_eff * K, 0.0f);
+                    for (int f = 0; f < d.out_size; ++f)
+                        for (int k = 0; k < K; ++k) wpad[(size_t)f * K + k] = d.w0[(size_t)f * K + k];
+                    rc = upload_f32(L.w0, wpad.data(), wpad.size());
                 } else {
-                    std::vector<uint16_t> pk(bh_conv1d_packed_halves(d.in_size, d.out_size, d.winlen));
-                    rc = bh_conv1d_pack(d.w0, d.in_size, d.out_size, d.winlen, pk.data());
+                    std::vector<float> wpad((size_t)L.cout_eff * L.cin_eff * K, 0.0f);
+                    for (int f = 0; f < d.out_size; ++f)
+                        for (int c = 0; c < d.in_size; ++c)
+                            for (int k = 0; k < K; ++k)
+                                wpad[((size_t)f * L.cin_eff + c) * K + k] = d.w0[((size_t)f * d.in_size + c) * K + k];
+                    std::vector<uint16_t> pk(bh_conv1d_packed_halves(L.cin_eff, L.cout_eff, K));
+                    rc = bh_conv1d_pack(wpad.data(), L.cin_eff, L.cout_eff, K, pk.data());
                     if (!rc) rc = upload(L.w0, pk.data(), pk.size() * 2);
                 }
-                if (!rc && d.b0) rc = upload_f32(L.b0, d.b0, d.out_size);
+                if (!rc) rc = upload_f32(L.b0, bpad.data(), bpad.size());
+                cur_channels = d.out_size;
+                cur_channels_eff = L.cout_eff;
                 break;
             }
             case BH_LAYER_LSTM: {
@@ -315,7 +348,7 @@ extern "C" int bh_encoder_create(const bh_layer_t* layers, int n_layers, int dev
     const int Np = pad16(max_batch);
     if (walk(e, Np, max_chunk, &T, &C, &ab, &gb)) return fail(-2);
     if (e->act[0].alloc(ab + 256) || e->act[1].alloc(ab + 256) || e->gates.alloc(gb + 256) ||
-        e->sig.alloc((size_t)Np * max_chunk * 2) || e->err.alloc(sizeof(int)))
+        e->sig.alloc((size_t)Np * max_chunk * 2) || e->err.alloc(sizeof(int)) || e->lstm_ws.alloc(bh_k_lstm_ws_bytes(Np, 512)))
         return fail(-1);
     if (hipMemset(e->err.p, 0, sizeof(int)) != hipSuccess || hipMemset(e->act[0].p, 0, e->act[0].bytes) != hipSuccess ||
         hipMemset(e->act[1].p, 0, e->act[1].bytes) != hipSuccess) {
@@ -389,16 +422,17 @@ extern "C" int bh_encoder_forward(bh_encoder_t* e, const void* signal, int N, in
                 const int lout = conv_out_len(len, d.winlen, d.stride, d.padding);
                 void* dst = e->act[which].p;
                 const bool tnc = next_kind == BH_LAYER_LSTM;
-                const long os_n = tnc ? d.out_size : (long)lout * d.out_size;
-                const long os_t = tnc ? (long)Np * d.out_size : d.out_size;
+                const int co = l.cout_eff;
+                const long os_n = tnc ? co : (long)lout * co;
+                const long os_t = tnc ? (long)Np * co : co;
                 int rc;
                 ProfSpan span(e, st, BH_PROF_CONV);
                 if (lay == L_SIGNAL)
                     rc = bh_k_conv_first(cur, (const float*)l.w0.p, (const float*)l.b0.p, dst, Np, len, lout,
-                                         d.out_size, d.winlen, d.stride, d.padding, d.activation, lo, hi, os_n, os_t, st);
+                                         co, d.winlen, d.stride, d.padding, d.activation, lo, hi, os_n, os_t, st);
                 else
-                    rc = bh_k_conv_igemm(cur, l.w0.p, (const float*)l.b0.p, dst, Np, len, lout, d.in_size,
-                                         d.out_size, d.winlen, d.stride, d.padding, d.activation, lo, hi, os_n, os_t, st);
+                    rc = bh_k_conv_igemm(cur, l.w0.p, (const float*)l.b0.p, dst, Np, len, lout, l.cin_eff,
+                                         co, d.winlen, d.stride, d.padding, d.activation, lo, hi, os_n, os_t, st);
                 if (rc) return rc;
                 cur = dst; which ^= 1; len = lout; C = d.out_size; lay = tnc ? L_TNC : L_NLC;
                 break;
@@ -432,7 +466,8 @@ extern "C" int bh_encoder_forward(bh_encoder_t* e, const void* signal, int N, in
                     const int nr = std::min(rings_per_launch, n_rings - r0);
                     const size_t col = (size_t)r0 * 16;
                     rc = bh_k_lstm_layer((const char*)e->gates.p + col * 4 * H * 2, l.w1.p,
-                                         (char*)dst + col * H * 2, len, Np, H, d.reverse, (int*)e->err.p, st, nr);
+                                         (char*)dst + col * H * 2, len, Np, H, d.reverse, (int*)e->err.p, st, nr,
+                                         (int*)e->lstm_ws.p, e->lstm_force_slow);
                     if (rc) return rc;
                 }
                 cur = dst; which ^= 1; C = H;
@@ -520,13 +555,20 @@ extern "C" int bh_conv1d(const void* in, const void* wpacked, const float* bias,
     return bh_k_conv_igemm(in, wpacked, bias, out, N, Lin, lout, Cin, Cout, K, stride, pad, act, clamp_lo, clamp_hi,
                            os_n, os_t, (hipStream_t)stream);
 }
+extern "C" size_t bh_lstm_workspace(int N, int H) { return bh_k_lstm_ws_bytes(N, H); }
 extern "C" int bh_lstm_layer(const void* gates_in, const void* whh_packed, void* h_out, int T, int N, int H,
-                             int reverse, int* err_flag, void* stream) {
-    BH_REQUIRE(gates_in && whh_packed && h_out && err_flag, "lstm_layer: null pointer");
+                             int reverse, void* workspace, int* err_flag, int flags, void* stream) {
+    BH_REQUIRE(gates_in && whh_packed && h_out && err_flag && workspace, "lstm_layer: null pointer");
     BH_REQUIRE(T > 0, "lstm_layer: T must be positive");
     int rc = bh_k_fill_u16(h_out, 0xFFFFu, (size_t)T * N * H, (hipStream_t)stream);
     if (rc) return rc;
-    return bh_k_lstm_layer(gates_in, whh_packed, h_out, T, N, H, reverse, err_flag, (hipStream_t)stream, N / 16);
+    return bh_k_lstm_layer(gates_in, whh_packed, h_out, T, N, H, reverse, err_flag, (hipStream_t)stream, N / 16,
+                           (int*)workspace, flags & 1);
+}
+extern "C" int bh_encoder_set_option(bh_encoder_t* e, const char* name, int value) {
+    BH_REQUIRE(e && name, "encoder_set_option: null argument");
+    if (!strcmp(name, "lstm_force_slow")) { e->lstm_force_slow = value; return 0; }
+    BH_REQUIRE(false, "encoder_set_option: unknown option '%s'", name);
 }
 extern "C" size_t bh_crf_viterbi_workspace(int N, int T, int state_len) {
     size_t S = 1;

@@ -19,7 +19,13 @@
 //     flags, no fences, no atomics, and every 2-byte element is checked individually so the protocol
 //     does not depend on store granularity, dispatch order or workgroup->XCD placement.
 //   * Rings are laid out so that the waves of one ring sit on one XCD when the dispatcher places
-//     block b on XCD b % 8 (speed only; correctness never relies on it).
+//     block b on XCD b % 8 (speed only; correctness never relies on it). At kernel start every wave
+//     publishes its HW_REG_XCC_ID and the ring agrees on ONE of two store policies:
+//       - all members on one XCD  -> plain stores (the line stays in that XCD's L2; the sc1 polls are
+//         L2 hits, ~3x lower hand-off latency and no fabric traffic from polling);
+//       - anything else (or the agreement times out) -> write-through sc1 stores, valid for any placement.
+//     Every member reads the same published ids, so the choice is identical across the ring.
+//   * Polling re-issues only the k-steps that still contain a sentinel (wave-uniform pending mask).
 //   * W as the MFMA A operand: accumulator rows are hidden units, columns are chunks, so one lane
 //     holds i,f,g,o for 4 consecutive hidden units of one chunk -> lane-local gate math, c_t kept in
 //     fp32 registers for the whole layer, 8-byte packed h stores.
@@ -38,7 +44,13 @@ struct LstmArgs {
     int reverse;
     int* err;
     unsigned max_spins;
+    int* xcc_ws;        // [n_rings][H/16], pre-set to -1: XCD agreement
+    int force_slow;     // test hook: always use the placement-independent write-through policy
 };
+
+__device__ __forceinline__ int xcc_id() {
+    return (int)(__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 0xF);   // hwreg(HW_REG_XCC_ID, 0, 4)
+}
 
 constexpr unsigned SENTINEL_MASK = 0x40004000u;
 
@@ -70,6 +82,24 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_kernel(LstmArgs p) {
     const long row_bytes = (long)p.N * H * 2;           // one time step of h
     const unsigned voff = (unsigned)(((ring * 16 + c) * H + q * 8) * 2);
     float cst[4] = {0.f, 0.f, 0.f, 0.f};
+    bool dead = false;
+
+    // ---- XCD agreement: publish my XCC id, read the ring's ids, fast policy iff all equal -------
+    bool fast = false;
+    {
+        int* slot = p.xcc_ws + (long)ring * NSL;
+        const int mine = xcc_id();
+        if (lane == 0) __hip_atomic_store(slot + slice, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned spins = 0;
+        bool ok = false;
+        while (true) {
+            int v = (lane < NSL) ? __hip_atomic_load(slot + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : mine;
+            if (!__any(v < 0)) { ok = !__any(v != mine); break; }
+            if (++spins > p.max_spins) break;     // not an error: fall back to the safe policy
+            __builtin_amdgcn_s_sleep(4);
+        }
+        fast = ok && !p.force_slow;
+    }
 
     const long g_row = (long)p.N * 4 * H;
     const half_t* gptr = p.G + (long)n * 4 * H + hu0;
@@ -97,21 +127,26 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_kernel(LstmArgs p) {
             __amdgpu_buffer_rsrc_t rs =
                 __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)row_bytes, 0x00020000);
             uint4_t hf[NKS];
-            unsigned spins = 0;
+            unsigned spins = dead ? p.max_spins : 0u;   // after one timeout never wait again
+            unsigned pend = (NKS >= 32) ? 0xffffffffu : ((1u << NKS) - 1u);   // wave-uniform
             while (true) {
-                unsigned orv = 0;
 #pragma unroll
-                for (int ks = 0; ks < NKS; ++ks) {
-                    hf[ks] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff + ks * 64, 0, (int)0x80000010 /*sc1 + volatile*/);
-                }
+                for (int ks = 0; ks < NKS; ++ks)
+                    if (pend & (1u << ks))
+                        hf[ks] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff + ks * 64, 0, (int)0x80000010 /*sc1 + volatile*/);
 #pragma unroll
-                for (int ks = 0; ks < NKS; ++ks) orv |= hf[ks].x | hf[ks].y | hf[ks].z | hf[ks].w;
-                if (!__any((orv & SENTINEL_MASK) != 0)) break;
+                for (int ks = 0; ks < NKS; ++ks)
+                    if (pend & (1u << ks)) {
+                        unsigned orv = hf[ks].x | hf[ks].y | hf[ks].z | hf[ks].w;
+                        if (!__any((orv & SENTINEL_MASK) != 0)) pend &= ~(1u << ks);
+                    }
+                if (pend == 0) break;
                 if (++spins > p.max_spins) {
-                    if (lane == 0) atomicExch(p.err, 1);
+                    if (lane == 0 && !dead) atomicExch(p.err, 1);
+                    dead = true;
                     break;
                 }
-                __builtin_amdgcn_s_sleep(2);
+                __builtin_amdgcn_s_sleep(1);
             }
 #pragma unroll
             for (int ks = 0; ks < NKS; ++ks) {
@@ -137,7 +172,8 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_kernel(LstmArgs p) {
         unsigned long long packed = __builtin_bit_cast(unsigned long long, ho);
         unsigned long long* dst =
             (unsigned long long*)(p.h + ((long)t * p.N + n) * H + hu0);
-        __hip_atomic_store(dst, packed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // sc1 write-through
+        if (fast) *dst = packed;                                                       // stays in this XCD's L2
+        else __hip_atomic_store(dst, packed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // sc1 write-through
 #pragma unroll
         for (int g = 0; g < 4; ++g) gin[g] = gnx[g];
     }
@@ -155,6 +191,7 @@ __global__ void fill_u16_kernel(uint16_t* dst, uint16_t v, size_t count) {
 }  // namespace bh
 
 size_t bh_k_lstm_packed_bytes(int H) { return (size_t)4 * H * H * 2; }
+size_t bh_k_lstm_ws_bytes(int N, int H) { return (size_t)((N + 15) / 16) * (H / 16) * sizeof(int) + 64; }
 
 int bh_k_fill_u16(void* dst, uint16_t value, size_t count, hipStream_t stream) {
     using namespace bh;
@@ -172,7 +209,7 @@ int bh_k_fill_u16(void* dst, uint16_t value, size_t count, hipStream_t stream) {
 // splits larger batches by offsetting the base pointers by 16*ring0 columns: N stays the row stride of
 // G / h and n_rings is the number of 16-chunk rings this launch runs. N %% 16 == 0 (engine pads).
 int bh_k_lstm_layer(const void* gates_in, const void* whh_packed, void* h_out, int T, int N, int H,
-                    int reverse, int* err_flag, hipStream_t stream, int n_rings) {
+                    int reverse, int* err_flag, hipStream_t stream, int n_rings, int* xcc_ws, int force_slow) {
     using namespace bh;
     BH_REQUIRE(N % 16 == 0, "lstm: batch must be padded to a multiple of 16 (N=%d)", N);
     BH_REQUIRE(H % 32 == 0 && H >= 32 && H <= 512, "lstm: register-resident kernel needs H%%32==0, 32<=H<=512 (H=%d)", H);
@@ -185,8 +222,10 @@ int bh_k_lstm_layer(const void* gates_in, const void* whh_packed, void* h_out, i
     const int groups = (rl + 3) / 4;           // 4 rings (waves) per workgroup
     const int grid = 8 * groups * nsl;
     BH_REQUIRE(grid <= cus, "lstm: %d workgroups must be co-resident but the device has %d CUs; split the batch", grid, cus);
+    BH_REQUIRE(xcc_ws != nullptr, "lstm: missing XCD agreement workspace");
+    BH_CHECK_HIP(hipMemsetAsync(xcc_ws, 0xFF, (size_t)n_rings * nsl * sizeof(int), stream));
     LstmArgs a{(const half_t*)gates_in, (const half_t*)whh_packed, (half_t*)h_out, T, N, H, n_rings,
-               reverse, err_flag, 4000000u};
+               reverse, err_flag, 1000000u, xcc_ws, force_slow};
 #define BH_LSTM_CASE(NKS) \
     case NKS: hipLaunchKernelGGL(lstm_layer_kernel<NKS>, dim3(grid), dim3(256), 0, stream, a); break;
     switch (H / 32) {

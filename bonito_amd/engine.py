@@ -173,6 +173,9 @@ class HipEncoder:
         _lib.check(_lib.lib().bh_encoder_profile_read(self._handle, ms, n), "bh_encoder_profile_read")
         return {k: (float(ms[i]), int(n[i])) for i, k in enumerate(self.PROF_CLASSES)}
 
+    def set_option(self, name, value):
+        _lib.check(_lib.lib().bh_encoder_set_option(self._handle, name.encode(), int(value)), "bh_encoder_set_option")
+
     def check(self):
         """Synchronise and raise if a persistent kernel hit its spin bound."""
         with torch.cuda.device(self.device):

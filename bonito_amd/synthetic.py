@@ -57,12 +57,20 @@ def randomise_batchnorm_(model, seed=26):
     return model
 
 
-def make_model(name, seed=25, **kw):
-    """Seeded random-init model of the named architecture (reference CLI seed, cli/basecaller.py:178)."""
+def make_model(name, seed=25, head_gain=24.0, **kw):
+    """Seeded random-init model of the named architecture (reference CLI seed, cli/basecaller.py:178).
+    A freshly initialised CRF head emits scores of std ~0.1, far below the fixed blank score 2.0, so
+    every decoder would only ever "stay"; `head_gain` scales the head so that synthetic runs emit bases
+    (trained heads use the whole +-5 clamp range)."""
     from bonito_amd.crf.model import Model
+    from bonito_amd.nn import LinearCRFEncoder
     torch.manual_seed(seed)
     model = Model(model_config(name, **kw))
     randomise_batchnorm_(model, seed + 1)
+    with torch.no_grad():
+        for m in model.modules():
+            if isinstance(m, LinearCRFEncoder):
+                m.linear.weight.mul_(head_gain)
     model.eval()
     return model
 

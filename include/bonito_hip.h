@@ -106,6 +106,8 @@ int bh_encoder_output_shape(const bh_encoder_t* enc, int L, int* T, int* C, int*
 /* signal: device fp16 [N][L] (the reference's [N,1,L] batch, bonito/crf/basecall.py:33).
  * scores: device fp16, contiguous [N][T][C] (the layout koi.decode.beam_search consumes). */
 int bh_encoder_forward(bh_encoder_t* enc, const void* signal, int N, int L, void* scores, void* stream);
+/* tuning / test options: "lstm_force_slow" (0/1) */
+int bh_encoder_set_option(bh_encoder_t* enc, const char* name, int value);
 /* non-zero if a device-side timeout was raised by a persistent kernel since the last call (synchronises stream) */
 int bh_encoder_check(bh_encoder_t* enc, void* stream);
 
@@ -150,9 +152,11 @@ int bh_conv1d(const void* in, const void* wpacked, const float* bias, void* out,
 /* recurrent weights: torch W_hh [4H][H] fp32 (host) -> MFMA-fragment order fp16 (host, 4*H*H halves) */
 int bh_lstm_pack_whh(const float* whh, int H, uint16_t* packed);
 /* one LSTM layer over gates_in = x W_ih^T + b (fp16 [T][N][4H], torch gate order); h_out fp16 [T][N][H].
- * N % 16 == 0.  err_flag: device int, set non-zero on a device-side timeout. */
+ * N % 16 == 0.  workspace: bh_lstm_workspace(N, H) device bytes.  err_flag: device int, set non-zero on a
+ * device-side timeout.  flags bit 0: force the placement-independent write-through exchange policy. */
+size_t bh_lstm_workspace(int N, int H);
 int bh_lstm_layer(const void* gates_in, const void* whh_packed, void* h_out, int T, int N, int H,
-                  int reverse, int* err_flag, void* stream);
+                  int reverse, void* workspace, int* err_flag, int flags, void* stream);
 
 #ifdef __cplusplus
 }

@@ -93,7 +93,7 @@ def test_linear_rejects_bad_shapes():
     assert rc != 0 and "multiples of 8" in _lib.last_error()
 
 
-@pytest.mark.parametrize("Cout,K,stride,act", [(16, 5, 1, 1), (64, 5, 1, 1), (344, 9, 3, 0), (8, 19, 6, 2)])
+@pytest.mark.parametrize("Cout,K,stride,act", [(16, 5, 1, 1), (64, 5, 1, 1), (344, 9, 3, 0), (8, 19, 6, 2), (4, 5, 1, 1), (6, 3, 2, 0)])
 def test_conv_first(Cout, K, stride, act):
     g = torch.Generator().manual_seed(Cout)
     N, L = 3, 1000
@@ -105,7 +105,8 @@ def test_conv_first(Cout, K, stride, act):
     Lout = want.shape[1]
     out = torch.zeros((N, Lout, Cout), dtype=torch.float16, device=dev())
     wd, bd = w.reshape(Cout, K).contiguous().to(dev()), b.to(dev())
-    _lib.check(_lib.lib().bh_conv1d_first(_lib.ptr(x.to(dev())), _lib.ptr(wd), _lib.ptr(bd), _lib.ptr(out), N, L, Cout,
+    xd = x.to(dev())
+    _lib.check(_lib.lib().bh_conv1d_first(_lib.ptr(xd), _lib.ptr(wd), _lib.ptr(bd), _lib.ptr(out), N, L, Cout,
                                           K, stride, K // 2, act, -INF, INF, Lout * Cout, Cout, _lib.stream_ptr()),
                "conv1d_first")
     torch.cuda.synchronize()
@@ -143,7 +144,8 @@ def test_conv_igemm(Cin, Cout, K, stride, L, tnc):
         out = torch.zeros((N, Lout, Cout), dtype=torch.float16, device=dev())
         os_n, os_t = Lout * Cout, Cout
         want = want.permute(0, 2, 1)
-    _lib.check(_lib.lib().bh_conv1d(_lib.ptr(xin), _lib.ptr(_pack_conv(w)), _lib.ptr(b.to(dev())), _lib.ptr(out), N, L,
+    wpk, bd = _pack_conv(w), b.to(dev())      # keep the device buffers alive across the async launch
+    _lib.check(_lib.lib().bh_conv1d(_lib.ptr(xin), _lib.ptr(wpk), _lib.ptr(bd), _lib.ptr(out), N, L,
                                     Cin, Cout, K, stride, K // 2, 1, -0.5, 3.5, os_n, os_t, _lib.stream_ptr()), "conv1d")
     torch.cuda.synchronize()
     assert (out.cpu().float() - want).abs().max().item() < 1.5e-2
@@ -165,9 +167,10 @@ def _lstm_ref(G, Whh, reverse):
     return out
 
 
-@pytest.mark.parametrize("H,N,T,reverse", [(32, 16, 40, 0), (96, 48, 60, 1), (384, 64, 50, 0), (384, 512, 30, 1),
-                                           (128, 16, 33, 1), (512, 32, 20, 0)])
-def test_lstm_layer(H, N, T, reverse):
+@pytest.mark.parametrize("H,N,T,reverse,flags", [(32, 16, 40, 0, 0), (96, 48, 60, 1, 0), (384, 64, 50, 0, 0),
+                                                 (384, 512, 30, 1, 0), (128, 16, 33, 1, 0), (512, 32, 20, 0, 0),
+                                                 (96, 48, 60, 0, 1), (384, 512, 30, 0, 1)])
+def test_lstm_layer(H, N, T, reverse, flags):
     g = torch.Generator().manual_seed(H + N)
     G = (torch.randn(T, N, 4 * H, generator=g) * 1.5).half()
     Whh = (torch.randn(4 * H, H, generator=g) * (1.0 / H ** 0.5)).half().float()
@@ -179,8 +182,10 @@ def test_lstm_layer(H, N, T, reverse):
     pkd = torch.from_numpy(pk.view(np.int16)).to(dev())
     h = torch.zeros((T, N, H), dtype=torch.float16, device=dev())
     err = torch.zeros(1, dtype=torch.int32, device=dev())
-    _lib.check(lib.bh_lstm_layer(_lib.ptr(G.to(dev())), _lib.ptr(pkd), _lib.ptr(h), T, N, H, reverse, _lib.ptr(err),
-                                 _lib.stream_ptr()), "lstm_layer")
+    Gd = G.to(dev())
+    ws = torch.zeros(lib.bh_lstm_workspace(N, H), dtype=torch.uint8, device=dev())
+    _lib.check(lib.bh_lstm_layer(_lib.ptr(Gd), _lib.ptr(pkd), _lib.ptr(h), T, N, H, reverse, _lib.ptr(ws), _lib.ptr(err),
+                                 flags, _lib.stream_ptr()), "lstm_layer")
     torch.cuda.synchronize()
     assert err.item() == 0, "persistent LSTM kernel hit its spin bound"
     d = (h.cpu().float() - want).abs()
@@ -199,9 +204,11 @@ def test_lstm_layer_is_deterministic_and_restartable():
     pkd = torch.from_numpy(pk.view(np.int16)).to(dev())
     outs = []
     err = torch.zeros(1, dtype=torch.int32, device=dev())
-    for _ in range(2):
+    ws = torch.zeros(lib.bh_lstm_workspace(N, H), dtype=torch.uint8, device=dev())
+    for flags in (0, 1):      # fast (same-XCD) and placement-independent exchange policies agree bit for bit
         h = torch.zeros((T, N, H), dtype=torch.float16, device=dev())
-        _lib.check(lib.bh_lstm_layer(_lib.ptr(G), _lib.ptr(pkd), _lib.ptr(h), T, N, H, 0, _lib.ptr(err), _lib.stream_ptr()))
+        _lib.check(lib.bh_lstm_layer(_lib.ptr(G), _lib.ptr(pkd), _lib.ptr(h), T, N, H, 0, _lib.ptr(ws), _lib.ptr(err),
+                                     flags, _lib.stream_ptr()))
         torch.cuda.synchronize()
         outs.append(h.cpu())
     assert err.item() == 0 and torch.equal(outs[0], outs[1])

@@ -17,6 +17,7 @@ from oracle import crf_ref
 
 print(torch.cuda.get_device_name(0), torch.cuda.get_device_properties(0).multi_processor_count, "CUs")
 for name in NN_FIXTURES:
+  try:
     cfg, sd, x, y = load_nn_fixture(name)
     model = build_model(cfg, sd)
     enc = HipEncoder(model, batchsize=x.shape[0], chunksize=x.shape[-1])
@@ -25,6 +26,8 @@ for name in NN_FIXTURES:
     want = ref_scores_to_koi(y, has_blank)
     d = (got.cpu().float() - want).abs()
     print("%-20s max %.4f mean %.5f  (|want| max %.2f)" % (name, d.max(), d.mean(), want.abs().max()))
+  except Exception as exc:
+    print(name, "FAILED", exc)
 
 for name, N in (("fast", 512), ("hac", 512)):
     model = synthetic.make_model(name)
