@@ -1,0 +1,597 @@
+// Beam-search CRF decode for gfx950: the MI355X replacement for koi.decode.beam_search
+// (call site /root/reference bonito/crf/basecall.py:36-40; koi itself is not in the reference tree).
+// Algorithm "BS-1" is defined in DESIGN.md and restated on the CPU in oracle/crf_oracle.c; this file
+// implements exactly that definition:
+//
+//   K1 crf_backward_kernel      beta~[N][T+1][S], B[N][T+1] (double), logZ[N]   (Log semiring, table lse2)
+//   K2 crf_forward_post_kernel  class posteriors P[N][T][4]
+//   K3 beam_kernel              beam of <=32 (state, sequence-hash) elements; back-pointers bp[N][T][32]
+//   K4 beam_finalize_kernel     traceback, sequence / moves / q-string
+//
+// All Log-semiring arithmetic that decides the decoded sequence (K1, K3) uses lse2(a,b) = max + table
+// interpolation with plain IEEE fp32 ops (include/bh_lse_table.h, shared with the oracle), so sequences
+// and move tables are bit-identical to the CPU oracle; only the q-scores (K2, expf) are tolerance-level.
+//
+// Mapping: K1/K2 one workgroup per chunk, one thread per k-mer state, alpha/beta ping-pong in LDS with
+// one barrier per step, score rows prefetched in registers; the scans are HBM-bound streaming reads of
+// the score tensor (2*C/stride bytes per signal sample each). K3 one wave per chunk, wave-synchronous,
+// score / guide rows staged through LDS in blocks of 8 steps, top-W selection by a 32-step radix select
+// on ballots (no sort), slots assigned by prefix popcount.
+#include "common.h"
+#include "kernels.h"
+#include "../../include/bh_lse_table.h"
+
+namespace bh {
+
+__device__ const float g_lse_tab[BH_LSE_TABLE_SIZE] = {BH_LSE_TABLE_VALUES};
+
+// deterministic log(exp(a)+exp(b)); `tab` may point to LDS or global memory
+__device__ __forceinline__ float lse2_tab(float a, float b, const float* tab) {
+    float m = fmaxf(a, b);
+    float d = fabsf(a - b);
+    if (!(d < BH_LSE_RANGE) || m == -INFINITY) return m;
+    float x = d * BH_LSE_SCALE;
+    int i = (int)x;
+    float f = x - (float)i;
+    float t0 = tab[i];
+    float sp = __fmaf_rn(f, tab[i + 1] - t0, t0);
+    return m + sp;
+}
+
+// ------------------------------------------------------------------------------------------------
+struct ScanArgs {
+    const half_t* scores;  // [N][T][4S]
+    int N, T, S, state_len;
+    float blank;
+    float* beta;           // [N][T+1][S]
+    double* Bcum;          // [N][T+1]
+    double* logZ;          // [N]
+    float* P;              // [N][T][4]   (forward only)
+};
+
+constexpr int SU = 4;  // score prefetch depth
+
+__global__ void crf_backward_kernel(ScanArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* tab = (float*)smem;                 // BH_LSE_TABLE_SIZE
+    float* buf = tab + BH_LSE_TABLE_SIZE + 2;  // [2][S]
+    half_t* rows = (half_t*)(buf + 2 * p.S);   // [2][4S] score rows, double buffered
+    const int S = p.S, T = p.T;
+    const int n = blockIdx.x, s = threadIdx.x;
+    const bool active = s < S;
+    for (int i = threadIdx.x; i < BH_LSE_TABLE_SIZE; i += blockDim.x) tab[i] = g_lse_tab[i];
+    if (active) buf[s] = 0.0f;
+    const int lead = s >> (2 * (p.state_len - 1));
+    const int sm = (s & ((S >> 2) - 1));       // successors of s are the states sm*4 + x
+    const half_t* sc = p.scores + (long)n * T * 4 * S + s * 4;   // this thread stages halves [4s, 4s+4) of a row
+    float* bn = p.beta + (long)n * (T + 1) * S;
+    double* Bn = p.Bcum + (long)n * (T + 1);
+    if (active) bn[(long)T * S + s] = 0.0f;
+    if (s == 0) Bn[T] = 0.0;
+
+    // register prefetch ring: pre[u] holds this thread's 8 bytes of row (thi - 1 - u)
+    half4_t cur[SU], nxt[SU];
+    auto load = [&](half4_t (&dst)[SU], int thi) {
+#pragma unroll
+        for (int u = 0; u < SU; ++u) {
+            int t = thi - 1 - u;
+            if (active && t >= 0) dst[u] = *(const half4_t*)(sc + (long)t * 4 * S);
+        }
+    };
+    load(cur, T);
+    if (active && T > 0) *(half4_t*)(rows + ((T - 1) & 1) * 4 * S + s * 4) = cur[0];
+    __syncthreads();
+
+    double cum = 0.0;
+    int cb = 0;
+    for (int thi = T; thi > 0; thi -= SU) {
+        load(nxt, thi - SU);
+#pragma unroll
+        for (int u = 0; u < SU; ++u) {
+            const int t = thi - 1 - u;
+            if (t >= 0) {
+                const float* prev = buf + cb * S;
+                const half_t* row = rows + (t & 1) * 4 * S;
+                const float ref = prev[0];
+                if (active) {
+                    float acc = p.blank + (prev[s] - ref);
+#pragma unroll
+                    for (int x = 0; x < 4; ++x) {
+                        const int s2 = sm * 4 + x;
+                        acc = lse2_tab(acc, (float)row[s2 * 4 + lead] + (prev[s2] - ref), tab);
+                    }
+                    buf[(cb ^ 1) * S + s] = acc;
+                    // stage the next (earlier) row for the following step
+                    if (t > 0) {
+                        const half4_t v = (u + 1 < SU) ? cur[(u + 1) % SU] : nxt[0];
+                        *(half4_t*)(rows + ((t - 1) & 1) * 4 * S + s * 4) = v;
+                    }
+                }
+                if (s == 0) { cum += (double)ref; Bn[t] = cum; }
+                cb ^= 1;
+                __syncthreads();
+                if (active) {
+                    const float* now = buf + cb * S;
+                    bn[(long)t * S + s] = now[s] - now[0];
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < SU; ++u) cur[u] = nxt[u];
+    }
+    // logZ = B_0 + raw_0[0] + LSE_s beta~_0[s]   (alpha_0 = 0); once per chunk, serial in double
+    if (s == 0) {
+        const float* now = buf + cb * S;
+        double m = -INFINITY, sum = 0.0;
+        for (int i = 0; i < S; ++i) m = fmax(m, (double)(now[i] - now[0]));
+        for (int i = 0; i < S; ++i) sum += exp((double)(now[i] - now[0]) - m);
+        p.logZ[n] = cum + (double)now[0] + m + log(sum);
+    }
+}
+
+__global__ void crf_forward_post_kernel(ScanArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* tab = (float*)smem;
+    float* buf = tab + BH_LSE_TABLE_SIZE + 2;   // [2][S]
+    float* part = buf + 2 * p.S;                // [2][waves][4] class partial sums
+    const int S = p.S, T = p.T, q = S >> 2;
+    const int n = blockIdx.x, j = threadIdx.x;
+    const bool active = j < S;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+    for (int i = threadIdx.x; i < BH_LSE_TABLE_SIZE; i += blockDim.x) tab[i] = g_lse_tab[i];
+    if (active) buf[j] = 0.0f;
+    const half_t* sc = p.scores + (long)n * T * 4 * S + j * 4;
+    const float* bn = p.beta + (long)n * (T + 1) * S;
+    const double* Bn = p.Bcum + (long)n * (T + 1);
+    const double lz = p.logZ[n];
+    float* Pn = p.P + (long)n * T * 4;
+    __syncthreads();
+
+    half4_t cur[SU], nxt[SU];
+    float bcur[SU], bnxt[SU];
+    auto load = [&](half4_t (&dst)[SU], float (&bd)[SU], int t0) {
+#pragma unroll
+        for (int u = 0; u < SU; ++u) {
+            int t = t0 + u;
+            if (active && t < T) {
+                dst[u] = *(const half4_t*)(sc + (long)t * 4 * S);
+                bd[u] = bn[(long)(t + 1) * S + j];
+            }
+        }
+    };
+    double A = 0.0;
+    int cb = 0;
+    load(cur, bcur, 0);
+    for (int t0 = 0; t0 < T; t0 += SU) {
+        load(nxt, bnxt, t0 + SU);
+#pragma unroll
+        for (int u = 0; u < SU; ++u) {
+            const int t = t0 + u;
+            if (t < T) {
+                const float* prev = buf + cb * S;
+                const float ref = prev[0];
+                float acc = 0.0f;
+                if (active) {
+                    acc = p.blank + (prev[j] - ref);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        acc = lse2_tab(acc, (float)cur[u][r] + (prev[r * q + (j >> 2)] - ref), tab);
+                    buf[(cb ^ 1) * S + j] = acc;
+                }
+                A += (double)ref;
+                cb ^= 1;
+                __syncthreads();
+                // boundary u = t+1: p[s] = exp(alpha~ + beta~ - (logZ - A_u - raw[0] - B_t))
+                const float* now = buf + cb * S;
+                const float now0 = now[0];
+                float pv = 0.0f;
+                if (active) {
+                    const double norm = lz - (A + (double)now0) - Bn[t];
+                    pv = __expf((float)((double)(acc - now0) + (double)bcur[u] - norm));
+                }
+                // class sums: lanes with equal (lane & 3) are one class
+                pv += __shfl_xor(pv, 4);
+                pv += __shfl_xor(pv, 8);
+                pv += __shfl_xor(pv, 16);
+                pv += __shfl_xor(pv, 32);
+                float* slot = part + ((t & 1) * nwaves + wave) * 4;
+                if (lane < 4) slot[lane] = pv;
+                __syncthreads();
+                if (threadIdx.x < 4) {
+                    float tot = 0.0f;
+                    for (int w = 0; w < nwaves; ++w) tot += part[((t & 1) * nwaves + w) * 4 + threadIdx.x];
+                    Pn[(long)t * 4 + threadIdx.x] = tot;
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < SU; ++u) { cur[u] = nxt[u]; bcur[u] = bnxt[u]; }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+struct BeamArgs {
+    const half_t* scores;  // [N][T][4S]
+    const float* beta;     // [N][T+1][S]
+    int N, T, S, state_len, W;
+    float blank, cut;      // cut = log(beam_cut)
+    uint8_t* bp;           // [N][T][32]  parent | move << 5 | base << 6
+    int* final_slot;       // [N]
+};
+
+constexpr int BTB = 8;     // steps staged per LDS block
+constexpr int MAXW = 32;
+
+__device__ __forceinline__ unsigned bs_hash0(int s) { return ((unsigned)s + 1u) * 2654435761u; }
+__device__ __forceinline__ unsigned bs_mix(unsigned h, int x) {
+    h = (h ^ ((unsigned)x + 1u)) * 16777619u;
+    return h ^ (h >> 15);
+}
+__device__ __forceinline__ unsigned bs_ukey(float k) {
+    unsigned u = __float_as_uint(k);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ int popc64(unsigned long long m) { return __popcll(m); }
+__device__ __forceinline__ unsigned long long lanemask_lt(int lane) { return (1ull << lane) - 1ull; }
+
+// Select the `want` largest ukeys among 3 per lane (0 = dead); ties at the threshold by ascending
+// candidate index c = lane + 64*i. Returns per-candidate selected flags and slot numbers.
+__device__ __forceinline__ int radix_select(const unsigned (&uk)[3], int want, int lane, bool (&sel)[3], int (&slot)[3]) {
+    unsigned long long alive[3];
+    int n_alive = 0;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { alive[i] = __ballot(uk[i] != 0u); n_alive += popc64(alive[i]); }
+    unsigned thr = 1u;   // smallest live key value is >= 1
+    if (n_alive > want) {
+        unsigned prefix = 0u;
+        for (int bit = 31; bit >= 0; --bit) {
+            const unsigned trial = prefix | (1u << bit);
+            int cnt = 0;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) cnt += popc64(__ballot(uk[i] >= trial));
+            if (cnt >= want) prefix = trial;
+        }
+        thr = prefix;     // the want-th largest key
+    }
+    int n_gt = 0;
+    unsigned long long gt[3], eq[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        gt[i] = __ballot(uk[i] != 0u && uk[i] > thr);
+        eq[i] = (n_alive > want) ? __ballot(uk[i] == thr) : 0ull;
+        n_gt += popc64(gt[i]);
+    }
+    if (n_alive <= want) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) gt[i] = alive[i];
+        n_gt = n_alive;
+    }
+    const int need = want - n_gt;    // ties to take, in index order
+    int tie_before = 0, total = 0;
+    unsigned long long selm[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int my_rank = tie_before + popc64(eq[i] & lanemask_lt(lane));
+        const bool tie_ok = ((eq[i] >> lane) & 1ull) && my_rank < need;
+        sel[i] = ((gt[i] >> lane) & 1ull) || tie_ok;
+        tie_before += popc64(eq[i]);
+        selm[i] = __ballot(sel[i]);
+    }
+    int before = 0;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        slot[i] = before + popc64(selm[i] & lanemask_lt(lane));
+        before += popc64(selm[i]);
+        total = before;
+    }
+    return total;
+}
+
+__global__ __launch_bounds__(64) void beam_kernel(BeamArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int S = p.S, T = p.T, W = p.W;
+    const int lane = threadIdx.x, n = blockIdx.x;
+    const int sh = 2 * (p.state_len - 1);
+    // LDS carve
+    half_t* st_sc = (half_t*)smem;                       // [BTB][4S]
+    float* st_b = (float*)(st_sc + BTB * 4 * S);         // [BTB][S]
+    int* b_state = (int*)(st_b + BTB * S);               // [32]
+    unsigned* b_hash = (unsigned*)(b_state + MAXW);      // [32]
+    float* b_score = (float*)(b_hash + MAXW);            // [32]
+    float* m_score = b_score + MAXW;                     // [32] merged-in move score
+    int* m_info = (int*)(m_score + MAXW);                // [32] merged-in move info or -1
+    uint8_t* st_bp = (uint8_t*)(m_info + MAXW);          // [BTB][32]
+    const float* tab = g_lse_tab;
+
+    const half_t* sc = p.scores + (long)n * T * 4 * S;
+    const float* bn = p.beta + (long)n * (T + 1) * S;
+    uint8_t* bpn = p.bp + (long)n * T * MAXW;
+
+    // ---- init: top-W states by beta~_0 (ties: lower state), slots in state order ------------------
+    int nb;
+    {
+        // S can exceed 3*64: run the radix select over the states in chunks is overkill -- use a
+        // threshold search over all S values held S/64 per lane.
+        const int per = (S + 63) / 64;
+        unsigned prefix = 0u;
+        const int want = W < S ? W : S;
+        for (int bit = 31; bit >= 0; --bit) {
+            const unsigned trial = prefix | (1u << bit);
+            int cnt = 0;
+            for (int i = 0; i < per; ++i) {
+                const int s = i * 64 + lane;
+                const unsigned u = s < S ? bs_ukey(bn[s]) : 0u;
+                cnt += popc64(__ballot(u >= trial));
+            }
+            if (cnt >= want) prefix = trial;
+        }
+        int n_gt = 0;
+        for (int i = 0; i < per; ++i) {
+            const int s = i * 64 + lane;
+            const unsigned u = s < S ? bs_ukey(bn[s]) : 0u;
+            n_gt += popc64(__ballot(u > prefix));
+        }
+        const int need = want - n_gt;
+        int tie_before = 0, before = 0;
+        for (int i = 0; i < per; ++i) {
+            const int s = i * 64 + lane;
+            const unsigned u = s < S ? bs_ukey(bn[s]) : 0u;
+            const unsigned long long eq = __ballot(s < S && u == prefix);
+            const bool tie_ok = ((eq >> lane) & 1ull) && (tie_before + popc64(eq & lanemask_lt(lane))) < need;
+            const bool take = (s < S && u > prefix) || tie_ok;
+            const unsigned long long tm = __ballot(take);
+            if (take) {
+                const int slot = before + popc64(tm & lanemask_lt(lane));
+                b_state[slot] = s;
+                b_hash[slot] = bs_hash0(s);
+                b_score[slot] = 0.0f;
+            }
+            tie_before += popc64(eq);
+            before += popc64(tm);
+        }
+        nb = before;
+    }
+    __syncthreads();
+
+    for (int tb = 0; tb < T; tb += BTB) {
+        const int nsteps = min(BTB, T - tb);
+        // ---- stage score rows tb..tb+nsteps-1 and guide rows tb+1..tb+nsteps ------------------------
+        {
+            const int halves = nsteps * 4 * S;     // multiple of 16
+            const uint4_t* src = (const uint4_t*)(sc + (long)tb * 4 * S);
+            uint4_t* dst = (uint4_t*)st_sc;
+            for (int i = lane; i < halves / 8; i += 64) dst[i] = src[i];
+            const int floats = nsteps * S;          // multiple of 4
+            const uint4_t* bs = (const uint4_t*)(bn + (long)(tb + 1) * S);
+            uint4_t* bd = (uint4_t*)st_b;
+            for (int i = lane; i < floats / 4; i += 64) bd[i] = bs[i];
+        }
+        __syncthreads();
+        for (int u = 0; u < nsteps; ++u) {
+            const half_t* row = st_sc + u * 4 * S;
+            const float* b1 = st_b + u * S;
+            // ---- candidates: c = lane + 64*i, e = c / 5, j = c % 5 -------------------------------
+            float cs[3];
+            unsigned ch[3];
+            int cst[3], cinfo[3];
+            bool alive[3];
+            if (lane < MAXW) m_info[lane] = -1;
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const int c = lane + 64 * i;
+                const int e = c / 5, j = c - e * 5;
+                alive[i] = e < nb;
+                cs[i] = -INFINITY; ch[i] = 0u; cst[i] = 0; cinfo[i] = 0;
+                if (alive[i]) {
+                    const int s = b_state[e];
+                    const unsigned h = b_hash[e];
+                    const float scv = b_score[e];
+                    if (j == 0) {
+                        cst[i] = s; ch[i] = h; cs[i] = scv + p.blank; cinfo[i] = e;
+                    } else {
+                        const int x = j - 1;
+                        const int s2 = ((s << 2) | x) & (S - 1);
+                        cst[i] = s2; ch[i] = bs_mix(h, x);
+                        cs[i] = scv + (float)row[s2 * 4 + (s >> sh)];
+                        cinfo[i] = e | (1 << 5) | (x << 6);
+                    }
+                }
+            }
+            // ---- merge: a move that spells the same sequence as a stay is folded into it ----------
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const int c = lane + 64 * i;
+                const int j = c % 5;
+                if (alive[i] && j != 0) {
+                    for (int d = 0; d < nb; ++d) {
+                        if (b_hash[d] == ch[i] && b_state[d] == cst[i]) {
+                            m_score[d] = cs[i];
+                            m_info[d] = cinfo[i];
+                            alive[i] = false;
+                            break;
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const int c = lane + 64 * i;
+                const int e = c / 5, j = c - e * 5;
+                if (alive[i] && j == 0 && m_info[e] >= 0) {
+                    const float ms = m_score[e];
+                    if (ms > cs[i]) cinfo[i] = m_info[e];
+                    cs[i] = lse2_tab(cs[i], ms, tab);
+                }
+            }
+            // ---- keys, cut -------------------------------------------------------------------------
+            float key[3];
+            float best = -INFINITY;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                key[i] = alive[i] ? cs[i] + b1[cst[i]] : -INFINITY;
+                best = fmaxf(best, key[i]);
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) best = fmaxf(best, __shfl_xor(best, off));
+            const float thr = best - p.cut;
+            unsigned uk[3];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                if (alive[i] && key[i] < thr) alive[i] = false;
+                uk[i] = alive[i] ? bs_ukey(key[i]) : 0u;
+            }
+            // ---- top-W, slots in candidate order ---------------------------------------------------
+            bool sel[3];
+            int slot[3];
+            const int nnew = radix_select(uk, W, lane, sel, slot);
+            // best selected candidate (max key, lowest index) gives the renormalisation shift
+            const unsigned ubest = bs_ukey(best);
+            float shift = 0.0f;
+            {
+                int found = 0;
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    const unsigned long long mm = __ballot(sel[i] && uk[i] == ubest);
+                    if (!found && mm) {
+                        const int src = __ffsll((long long)mm) - 1;
+                        shift = __shfl(cs[i], src);
+                        found = 1;
+                    }
+                }
+            }
+            __syncthreads();   // everyone has finished reading the old beam
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+                if (sel[i]) {
+                    b_state[slot[i]] = cst[i];
+                    b_hash[slot[i]] = ch[i];
+                    b_score[slot[i]] = cs[i] - shift;
+                    st_bp[u * MAXW + slot[i]] = (uint8_t)cinfo[i];
+                }
+            nb = nnew;
+            __syncthreads();
+        }
+        // ---- flush back-pointers of this block ------------------------------------------------------
+        for (int i = lane; i < nsteps * MAXW / 4; i += 64)
+            ((unsigned*)(bpn + (long)tb * MAXW))[i] = ((const unsigned*)st_bp)[i];
+        __syncthreads();
+    }
+    // ---- best final element: max score (beta~_T = 0), ties -> lower slot ---------------------------
+    {
+        const unsigned u = lane < nb ? bs_ukey(b_score[lane]) : 0u;
+        unsigned m = u;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, off));
+        const unsigned long long mm = __ballot(u == m && lane < nb);
+        if (lane == 0) p.final_slot[n] = __ffsll((long long)mm) - 1;
+    }
+}
+
+struct FinArgs {
+    const uint8_t* bp;     // [N][T][32]
+    const int* final_slot; // [N]
+    const float* P;        // [N][T][4]
+    int N, T;
+    float q_scale, q_offset;
+    int8_t* sequence;
+    int8_t* qstring;
+    int8_t* moves;
+    float* qfloat;         // optional [N][T]
+};
+
+// one thread per chunk: the walks are serial and short (T steps); 64 chunks per workgroup.
+__global__ void beam_finalize_kernel(FinArgs p) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= p.N) return;
+    const int T = p.T;
+    const uint8_t* bp = p.bp + (long)n * T * MAXW;
+    const float* P = p.P + (long)n * T * 4;
+    int8_t* sq = p.sequence + (long)n * T;
+    int8_t* qs = p.qstring + (long)n * T;
+    int8_t* mv = p.moves + (long)n * T;
+    float* qf = p.qfloat ? p.qfloat + (long)n * T : nullptr;
+    int r = p.final_slot[n];
+    for (int t = T - 1; t >= 0; --t) {
+        const int info = bp[(long)t * MAXW + r];
+        const int is_move = (info >> 5) & 1;
+        mv[t] = (int8_t)is_move;
+        sq[t] = is_move ? (int8_t)("ACGT"[info >> 6]) : (int8_t)0;
+        qs[t] = 0;
+        if (qf) qf[t] = 0.0f;
+        r = info & 31;
+    }
+    int t = 0;
+    while (t < T) {
+        if (!mv[t]) { ++t; continue; }
+        int t2 = t + 1;
+        while (t2 < T && !mv[t2]) ++t2;
+        const int c = sq[t];
+        const int x = c == 'A' ? 0 : c == 'C' ? 1 : c == 'G' ? 2 : 3;
+        double err = 0.0;
+        for (int u = t; u < t2; ++u) {
+            const float4_t pv = *(const float4_t*)(P + (long)u * 4);
+#pragma unroll
+            for (int y = 0; y < 4; ++y)
+                if (y != x) err += (double)pv[y];
+        }
+        err /= (double)(t2 - t);
+        if (err < 1e-10) err = 1e-10;
+        float qv = (float)(-10.0 * log10(err)) * p.q_scale + p.q_offset;
+        qv = fminf(fmaxf(qv, 1.0f), 50.0f);
+        if (qf) qf[t] = qv;
+        qs[t] = (int8_t)(33 + (int)floorf(qv + 0.5f));
+        t = t2;
+    }
+}
+
+}  // namespace bh
+
+size_t bh_k_beam_workspace(int N, int T, int state_len) {
+    size_t S = 1;
+    for (int i = 0; i < state_len; ++i) S *= 4;
+    size_t b = 0;
+    b += (size_t)N * (T + 1) * S * sizeof(float) + 256;   // beta~
+    b += (size_t)N * (T + 1) * sizeof(double) + 256;      // Bcum
+    b += (size_t)N * sizeof(double) + 256;                // logZ
+    b += (size_t)N * T * 4 * sizeof(float) + 256;         // P
+    b += (size_t)N * T * 32 + 256;                        // bp
+    b += (size_t)N * sizeof(int) + 256;                   // final slot
+    return b;
+}
+
+int bh_k_beam_search(const void* scores, int N, int T, int state_len, int beam_width, float beam_cut,
+                     float blank, float q_scale, float q_offset, void* workspace, int8_t* sequence,
+                     int8_t* qstring, int8_t* moves, float* qfloat, hipStream_t stream) {
+    using namespace bh;
+    BH_REQUIRE(state_len >= 1 && state_len <= 5, "beam_search: state_len must be in 1..5 (got %d)", state_len);
+    BH_REQUIRE(N > 0 && T > 0, "beam_search: empty problem N=%d T=%d", N, T);
+    BH_REQUIRE(beam_width >= 1 && beam_width <= 32, "beam_search: beam_width must be in 1..32 (got %d)", beam_width);
+    BH_REQUIRE(beam_cut >= 1.0f, "beam_search: beam_cut must be >= 1");
+    int S = 1;
+    for (int i = 0; i < state_len; ++i) S *= 4;
+    auto align = [](size_t x) { return (x + 255) / 256 * 256; };
+    char* w = (char*)workspace;
+    float* beta = (float*)w;   w += align((size_t)N * (T + 1) * S * sizeof(float));
+    double* Bcum = (double*)w; w += align((size_t)N * (T + 1) * sizeof(double));
+    double* logZ = (double*)w; w += align((size_t)N * sizeof(double));
+    float* P = (float*)w;      w += align((size_t)N * T * 4 * sizeof(float));
+    uint8_t* bp = (uint8_t*)w; w += align((size_t)N * T * 32);
+    int* fin = (int*)w;
+
+    ScanArgs sa{(const half_t*)scores, N, T, S, state_len, blank, beta, Bcum, logZ, P};
+    const int threads = S < 64 ? 64 : S;
+    const size_t lds_scan = (size_t)(BH_LSE_TABLE_SIZE + 2 + 2 * S + 2 * 16 * 4 + 8) * sizeof(float) + (size_t)2 * 4 * S * 2;
+    hipLaunchKernelGGL(crf_backward_kernel, dim3(N), dim3(threads), lds_scan, stream, sa);
+    hipLaunchKernelGGL(crf_forward_post_kernel, dim3(N), dim3(threads), lds_scan, stream, sa);
+    BeamArgs ba{(const half_t*)scores, beta, N, T, S, state_len, beam_width, blank, logf(beam_cut), bp, fin};
+    const size_t lds_beam = (size_t)BTB * 4 * S * 2 + (size_t)BTB * S * 4 + MAXW * 4 * 5 + BTB * MAXW + 64;
+    if (lds_beam > 64 * 1024)
+        BH_CHECK_HIP(hipFuncSetAttribute((const void*)beam_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_beam));
+    hipLaunchKernelGGL(beam_kernel, dim3(N), dim3(64), lds_beam, stream, ba);
+    FinArgs fa{bp, fin, P, N, T, q_scale, q_offset, sequence, qstring, moves, qfloat};
+    hipLaunchKernelGGL(beam_finalize_kernel, dim3((N + 63) / 64), dim3(64), 0, stream, fa);
+    BH_CHECK_HIP(hipGetLastError());
+    return 0;
+}

@@ -570,6 +570,14 @@ extern "C" int bh_encoder_set_option(bh_encoder_t* e, const char* name, int valu
     if (!strcmp(name, "lstm_force_slow")) { e->lstm_force_slow = value; return 0; }
     BH_REQUIRE(false, "encoder_set_option: unknown option '%s'", name);
 }
+extern "C" size_t bh_beam_search_workspace(int N, int T, int state_len) { return bh_k_beam_workspace(N, T, state_len); }
+extern "C" int bh_beam_search(const void* scores, int N, int T, int state_len, int beam_width, float beam_cut,
+                              float blank_score, float q_scale, float q_offset, void* workspace, int8_t* sequence,
+                              int8_t* qstring, int8_t* moves, float* qfloat, void* stream) {
+    BH_REQUIRE(scores && workspace && sequence && qstring && moves, "beam_search: null pointer");
+    return bh_k_beam_search(scores, N, T, state_len, beam_width, beam_cut, blank_score, q_scale, q_offset, workspace,
+                            sequence, qstring, moves, qfloat, (hipStream_t)stream);
+}
 extern "C" size_t bh_crf_viterbi_workspace(int N, int T, int state_len) {
     size_t S = 1;
     for (int i = 0; i < state_len; ++i) S *= 4;

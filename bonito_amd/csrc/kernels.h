@@ -30,3 +30,9 @@ size_t bh_k_lstm_packed_bytes(int H);
 int bh_k_crf_viterbi(const void* scores, int N, int T, int state_len, int layout_5s, float blank_score,
                      long s_n, long s_t, void* bp_ws, float* alpha_ws, int8_t* moves, int8_t* path,
                      float* best_score, hipStream_t stream);
+
+// beam.hip
+size_t bh_k_beam_workspace(int N, int T, int state_len);
+int bh_k_beam_search(const void* scores, int N, int T, int state_len, int beam_width, float beam_cut,
+                     float blank, float q_scale, float q_offset, void* workspace, int8_t* sequence,
+                     int8_t* qstring, int8_t* moves, float* qfloat, hipStream_t stream);

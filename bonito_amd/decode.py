@@ -33,6 +33,28 @@ def state_len_of(C_, n_base=4):
     return sl
 
 
+def beam_search(scores, beam_width=32, beam_cut=100.0, scale=1.0, offset=0.0, blank_score=2.0, return_qfloat=False):
+    """koi.decode.beam_search replacement (same arguments and defaults, bonito/crf/basecall.py:27,36-40).
+    scores: cuda fp16 contiguous [N, T, 4^(state_len+1)].  Returns CPU int8 tensors
+    (sequence, qstring, moves), each [N, T] with zeros where no base is emitted."""
+    _check_scores(scores)
+    N, T, Cc = scores.shape
+    sl = state_len_of(Cc)
+    lib = _lib.lib()
+    dev = scores.device
+    ws = torch.empty(lib.bh_beam_search_workspace(N, T, sl), dtype=torch.uint8, device=dev)
+    out = torch.empty((3, N, T), dtype=torch.int8, device=dev)
+    qf = torch.empty((N, T), dtype=torch.float32, device=dev) if return_qfloat else None
+    with torch.cuda.device(dev):
+        _lib.check(lib.bh_beam_search(_lib.ptr(scores), N, T, sl, int(beam_width), float(beam_cut), float(blank_score),
+                                      float(scale), float(offset), _lib.ptr(ws), _lib.ptr(out[0]), _lib.ptr(out[1]),
+                                      _lib.ptr(out[2]), _lib.ptr(qf), _lib.stream_ptr(dev)), "bh_beam_search")
+    host = out.cpu()          # one D2H copy of the three int8 planes (koi also returns CPU tensors)
+    if return_qfloat:
+        return host[0], host[1], host[2], qf.cpu()
+    return host[0], host[1], host[2]
+
+
 def viterbi(scores, blank_score=2.0, return_score=False):
     """Max-semiring best path of the CTC-CRF (CTC_CRF.viterbi, bonito/crf/model.py:98-103) on koi-layout
     scores fp16 [N, T, 4^(state_len+1)].  Returns CPU int8 tensors (moves [N,T] in {0,1},

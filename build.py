@@ -61,8 +61,9 @@ def build_oracle(force=False):
     odir = os.path.join(ROOT, "oracle")
     src = os.path.join(odir, "crf_oracle.c")
     lib = os.path.join(odir, "liboracle.so")
-    if os.path.exists(src) and (force or _newer(lib, [src])):
-        r = subprocess.run(["gcc", "-O2", "-std=c11", "-fPIC", "-shared", "-o", lib, src, "-lm"],
+    hdr = os.path.join(ROOT, "include", "bh_lse_table.h")
+    if os.path.exists(src) and (force or _newer(lib, [src, hdr])):
+        r = subprocess.run(["gcc", "-O2", "-std=c11", "-ffp-contract=off", "-fPIC", "-shared", "-o", lib, src, "-lm"],
                            capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("oracle build failed:\n" + r.stderr)

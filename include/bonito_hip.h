@@ -130,6 +130,17 @@ int bh_crf_viterbi(const void* scores, int N, int T, int state_len, int layout_5
                    long stride_n, long stride_t, void* workspace, int8_t* moves, int8_t* path,
                    float* best, void* stream);
 
+/* Beam-search decode: drop-in for koi.decode.beam_search(scores, beam_width=32, beam_cut=100.0, scale=1.0,
+ * offset=0.0, blank_score=2.0) (bonito/crf/basecall.py:27,36-40).  scores: device fp16 contiguous
+ * [N][T][4^(state_len+1)] (koi layout).  Outputs are DEVICE int8 [N][T], zero where nothing is emitted:
+ * sequence = ASCII base at emitting steps, qstring = 33 + round(q), moves in {0,1}; qfloat (optional,
+ * device fp32 [N][T]) receives the un-rounded q.  workspace: bh_beam_search_workspace(N, T, state_len) bytes.
+ * Algorithm "BS-1": DESIGN.md; bit-exact against oracle/crf_oracle.c for sequence and moves. */
+size_t bh_beam_search_workspace(int N, int T, int state_len);
+int bh_beam_search(const void* scores, int N, int T, int state_len, int beam_width, float beam_cut,
+                   float blank_score, float q_scale, float q_offset, void* workspace, int8_t* sequence,
+                   int8_t* qstring, int8_t* moves, float* qfloat, void* stream);
+
 /* ---- operator level (parity tests, custom pipelines) ----------------------------------------- */
 /* out[m][n] = clamp(act(X[m][:] . W[n][:] + bias[n]) * scale); fp16 X [M][ldx], W [N][ldw], out [.][ldo].
  * gated=1: SwiGLU epilogue over interleaved rows (out has N/2 columns).

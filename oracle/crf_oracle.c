@@ -95,7 +95,7 @@ int oracle_crf_viterbi(const uint16_t* scores, int N, int T, int state_len, int 
     return 0;
 }
 
-static inline float lse2(float a, float b) {
+static inline float lse2_libm(float a, float b) {
     if (a == -INFINITY) return b;
     if (b == -INFINITY) return a;
     float m = a > b ? a : b;
@@ -134,5 +134,277 @@ int oracle_crf_logz(const uint16_t* scores, int N, int T, int state_len, int lay
         out[n] = (float)(m + log(s));
     }
     free(a0); free(a1);
+    return 0;
+}
+
+/* =================================================================================================
+ * Beam-search decode ("BS-1").  koi.decode.beam_search (ont-koi==0.5.4, requirements.txt:19; call site
+ * bonito/crf/basecall.py:36-40) is a closed third-party dependency: its exact merging / q-score rules are
+ * NOT available in /root/reference, so the algorithm below is OUR definition (DESIGN.md "Beam search
+ * BS-1"), PARITY UNPINNED against koi; the HIP kernels (bonito_amd/csrc/beam.hip) implement exactly
+ * this and are tested against it bit for bit (sequence, moves) / within 1e-3 (q-scores).
+ *
+ * Scores: fp16 koi layout [N][T][4S]; entry s'*4 + r = move INTO state s' having dropped base r; stay
+ * (blank) score is the scalar `blank`.
+ *
+ *  1. backward guide (Log semiring, deterministic table lse2), normalised by state 0 each step:
+ *        raw_T[s] = 0
+ *        raw_t[s] = lse2(...lse2(blank + b[s], m_0 + b[s'_0])..., m_3 + b[s'_3]),  b = raw_{t+1} - raw_{t+1}[0]
+ *        s'_x = ((s << 2) | x) & (S-1),  m_x = score[t][s'_x*4 + (s >> 2(k-1))]
+ *        beta~_t[s] = raw_t[s] - raw_t[0]          stored for t = 0..T          ([T+1][S] fp32)
+ *        B_t = sum_{u > t} raw_u[0]   (double)  so that  beta_t[s] = beta~_t[s] + raw_t[0] + B_t
+ *  2. forward scan, same normalisation: alpha~_u, A_u; class posteriors
+ *        P_u[x] = sum_{s & 3 == x} exp(alpha~_u[s] + beta~_u[s] - (logZ - A_u - B_u)),  u = 1..T
+ *  3. beam search over (state, sequence hash): stay / 4 moves per element, merge a move into the stay
+ *     that spells the same sequence (lse2), rank by score + beta~_{t+1}[state], cut at best - log(beam_cut),
+ *     keep `beam_width` (ties: lower candidate index), slots in candidate-index order.
+ *  4. traceback from the best final element; per emitted base x with dwell u = t+1..t':
+ *        err = mean_u sum_{y != x} P_u[y];  q = -10 log10(max(err, 1e-10)) * scale + offset, clamped to [1, 50]
+ *        qstring = 33 + floor(q + 0.5) at the emitting step.
+ * ================================================================================================= */
+#include "../include/bh_lse_table.h"
+static const float LSE_TAB[BH_LSE_TABLE_SIZE] = {BH_LSE_TABLE_VALUES};
+
+float oracle_lse2(float a, float b) {
+    float m = a > b ? a : b;
+    if (m == -INFINITY) return m;
+    float d = fabsf(a - b);
+    if (!(d < BH_LSE_RANGE)) return m;
+    float x = d * BH_LSE_SCALE;
+    int i = (int)x;
+    float f = x - (float)i;
+    float t0 = LSE_TAB[i];
+    float sp = fmaf(f, LSE_TAB[i + 1] - t0, t0);
+    return m + sp;
+}
+
+/* beta~ [N][T+1][S] fp32, Bcum [N][T+1] double (B_t), logZ [N] double */
+int oracle_crf_backward(const uint16_t* scores, int N, int T, int state_len, float blank, float* beta,
+                        double* Bcum, double* logZ) {
+    const int S = ipow4(state_len), sh = 2 * (state_len - 1);
+    float* raw = (float*)malloc(sizeof(float) * S);
+    float* nxt = (float*)malloc(sizeof(float) * S);
+    if (!raw || !nxt) { free(raw); free(nxt); return -1; }
+    for (int n = 0; n < N; ++n) {
+        float* bn = beta + (size_t)n * (T + 1) * S;
+        double* Bn = Bcum + (size_t)n * (T + 1);
+        for (int s = 0; s < S; ++s) { raw[s] = 0.0f; bn[(size_t)T * S + s] = 0.0f; }
+        Bn[T] = 0.0;
+        double cum = 0.0;   /* sum of raw_u[0] for u > t */
+        for (int t = T - 1; t >= 0; --t) {
+            const uint16_t* sc = scores + ((size_t)n * T + t) * 4 * S;
+            const float ref = raw[0];
+            cum += (double)ref;                 /* raw_{t+1}[0] joins B_t */
+            Bn[t] = cum;
+            for (int s = 0; s < S; ++s) {
+                float acc = blank + (raw[s] - ref);
+                const int lead = s >> sh;
+                for (int x = 0; x < 4; ++x) {
+                    int s2 = ((s << 2) | x) & (S - 1);
+                    acc = oracle_lse2(acc, h2f(sc[s2 * 4 + lead]) + (raw[s2] - ref));
+                }
+                nxt[s] = acc;
+            }
+            float* tmp = raw; raw = nxt; nxt = tmp;
+            for (int s = 0; s < S; ++s) bn[(size_t)t * S + s] = raw[s] - raw[0];
+        }
+        /* logZ = B_0 + raw_0[0] + LSE_s beta~_0[s]  (alpha_0 = 0) */
+        double m = -INFINITY, sum = 0.0;
+        for (int s = 0; s < S; ++s) if (bn[s] > m) m = bn[s];
+        for (int s = 0; s < S; ++s) sum += exp((double)bn[s] - m);
+        logZ[n] = cum + (double)raw[0] + m + log(sum);
+    }
+    free(raw); free(nxt);
+    return 0;
+}
+
+/* class posteriors P [N][T][4] fp32 (boundary u = t+1 stored at index t) */
+int oracle_crf_forward_post(const uint16_t* scores, int N, int T, int state_len, float blank, const float* beta,
+                            const double* Bcum, const double* logZ, float* P) {
+    const int S = ipow4(state_len), q = S / 4;
+    float* raw = (float*)malloc(sizeof(float) * S);
+    float* nxt = (float*)malloc(sizeof(float) * S);
+    if (!raw || !nxt) { free(raw); free(nxt); return -1; }
+    for (int n = 0; n < N; ++n) {
+        const float* bn = beta + (size_t)n * (T + 1) * S;
+        const double* Bn = Bcum + (size_t)n * (T + 1);
+        for (int s = 0; s < S; ++s) raw[s] = 0.0f;
+        double A = 0.0;   /* sum of raw_v[0] for v <= u: alpha_u = alpha~_u + A_u */
+        for (int t = 0; t < T; ++t) {
+            const uint16_t* sc = scores + ((size_t)n * T + t) * 4 * S;
+            const float ref = raw[0];
+            A += (double)ref;
+            for (int j = 0; j < S; ++j) {
+                float acc = blank + (raw[j] - ref);
+                for (int r = 0; r < 4; ++r)
+                    acc = oracle_lse2(acc, h2f(sc[j * 4 + r]) + (raw[r * q + (j >> 2)] - ref));
+                nxt[j] = acc;
+            }
+            float* tmp = raw; raw = nxt; nxt = tmp;
+            /* boundary u = t+1: alpha_u[s] = (raw[s]-raw[0]) + raw[0] + A ; beta_u[s] = beta~_u[s] + B_u' where
+               the backward pass defines beta_u = beta~_u + raw^b_u[0] + B_u and B_{u-1} = B_u + raw^b_u[0]. */
+            const double norm = logZ[n] - (A + (double)raw[0]) - Bn[t];   /* Bn[t] = B_t = B_{t+1} + raw^b_{t+1}[0] */
+            double cls[4] = {0, 0, 0, 0};
+            for (int s = 0; s < S; ++s)
+                cls[s & 3] += exp((double)(raw[s] - raw[0]) + (double)bn[(size_t)(t + 1) * S + s] - norm);
+            for (int x = 0; x < 4; ++x) P[((size_t)n * T + t) * 4 + x] = (float)cls[x];
+        }
+    }
+    free(raw); free(nxt);
+    return 0;
+}
+
+static inline uint32_t bs_hash0(int s) { return ((uint32_t)s + 1u) * 2654435761u; }
+static inline uint32_t bs_mix(uint32_t h, int x) {
+    h = (h ^ ((uint32_t)x + 1u)) * 16777619u;
+    return h ^ (h >> 15);
+}
+static inline uint32_t bs_ukey(float k) {
+    uint32_t u;
+    memcpy(&u, &k, 4);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+#define BS_MAXW 32
+typedef struct { int state; uint32_t hash; float score; } bs_elem;
+
+/* Full decode.  sequence/qstring/moves: [N][T] int8 (0 where nothing is emitted).  qfloat: [N][T] fp32
+ * un-rounded q at emitting steps (0 elsewhere) or NULL.  Returns 0 / -1. */
+int oracle_beam_search(const uint16_t* scores, int N, int T, int state_len, int beam_width, float beam_cut,
+                       float blank, float q_scale, float q_offset, int8_t* sequence, int8_t* qstring,
+                       int8_t* moves, float* qfloat) {
+    const int S = ipow4(state_len), sh = 2 * (state_len - 1);
+    if (beam_width < 1 || beam_width > BS_MAXW) return -2;
+    const int W = beam_width;
+    float* beta = (float*)malloc(sizeof(float) * (size_t)N * (T + 1) * S);
+    double* Bcum = (double*)malloc(sizeof(double) * (size_t)N * (T + 1));
+    double* logZ = (double*)malloc(sizeof(double) * N);
+    float* P = (float*)malloc(sizeof(float) * (size_t)N * T * 4);
+    uint8_t* bp = (uint8_t*)malloc((size_t)T * BS_MAXW);
+    if (!beta || !Bcum || !logZ || !P || !bp) { free(beta); free(Bcum); free(logZ); free(P); free(bp); return -1; }
+    oracle_crf_backward(scores, N, T, state_len, blank, beta, Bcum, logZ);
+    oracle_crf_forward_post(scores, N, T, state_len, blank, beta, Bcum, logZ, P);
+    const float cut = logf(beam_cut);
+    for (int n = 0; n < N; ++n) {
+        const float* bn = beta + (size_t)n * (T + 1) * S;
+        bs_elem beam[BS_MAXW];
+        int nb = 0;
+        /* init: top-W states by beta~_0 (ties: lower state), slots in state order */
+        {
+            char* used = (char*)calloc(S, 1);
+            int take = W < S ? W : S;
+            for (int k = 0; k < take; ++k) {
+                int bi = -1;
+                for (int s = 0; s < S; ++s)
+                    if (!used[s] && (bi < 0 || bs_ukey(bn[s]) > bs_ukey(bn[bi]))) bi = s;
+                used[bi] = 1;
+            }
+            for (int s = 0; s < S; ++s)
+                if (used[s]) { beam[nb].state = s; beam[nb].hash = bs_hash0(s); beam[nb].score = 0.0f; ++nb; }
+            free(used);
+        }
+        for (int t = 0; t < T; ++t) {
+            const uint16_t* sc = scores + ((size_t)n * T + t) * 4 * S;
+            const float* b1 = bn + (size_t)(t + 1) * S;
+            /* candidates: index c = e*5 + j */
+            int c_state[BS_MAXW * 5];
+            uint32_t c_hash[BS_MAXW * 5];
+            float c_score[BS_MAXW * 5], c_key[BS_MAXW * 5];
+            uint8_t c_info[BS_MAXW * 5];   /* parent | move<<5 | base<<6 */
+            char c_alive[BS_MAXW * 5];
+            const int nc = nb * 5;
+            for (int e = 0; e < nb; ++e) {
+                const int s = beam[e].state, lead = s >> sh;
+                c_state[e * 5] = s; c_hash[e * 5] = beam[e].hash; c_score[e * 5] = beam[e].score + blank;
+                c_info[e * 5] = (uint8_t)e; c_alive[e * 5] = 1;
+                for (int x = 0; x < 4; ++x) {
+                    const int c = e * 5 + 1 + x, s2 = ((s << 2) | x) & (S - 1);
+                    c_state[c] = s2; c_hash[c] = bs_mix(beam[e].hash, x);
+                    c_score[c] = beam[e].score + h2f(sc[s2 * 4 + lead]);
+                    c_info[c] = (uint8_t)(e | (1 << 5) | (x << 6)); c_alive[c] = 1;
+                }
+            }
+            /* merge a move into the stay that spells the same sequence */
+            for (int e = 0; e < nb; ++e)
+                for (int x = 0; x < 4; ++x) {
+                    const int c = e * 5 + 1 + x;
+                    for (int d = 0; d < nb; ++d) {
+                        const int cs = d * 5;
+                        if (c_hash[cs] == c_hash[c] && c_state[cs] == c_state[c]) {
+                            const float stay_sc = beam[d].score + blank;   /* un-merged stay score */
+                            if (c_score[c] > stay_sc) c_info[cs] = c_info[c];
+                            c_score[cs] = oracle_lse2(stay_sc, c_score[c]);
+                            c_alive[c] = 0;
+                            break;
+                        }
+                    }
+                }
+            float best = -INFINITY;
+            for (int c = 0; c < nc; ++c) {
+                c_key[c] = c_alive[c] ? c_score[c] + b1[c_state[c]] : -INFINITY;
+                if (c_key[c] > best) best = c_key[c];
+            }
+            const float thr = best - cut;
+            for (int c = 0; c < nc; ++c) if (c_alive[c] && c_key[c] < thr) { c_alive[c] = 0; c_key[c] = -INFINITY; }
+            /* select top W by key (ties: lower index) */
+            char sel[BS_MAXW * 5];
+            memset(sel, 0, sizeof(sel));
+            int nsel = 0;
+            for (int k = 0; k < W; ++k) {
+                int bi = -1;
+                for (int c = 0; c < nc; ++c)
+                    if (c_alive[c] && !sel[c] && (bi < 0 || bs_ukey(c_key[c]) > bs_ukey(c_key[bi]))) bi = c;
+                if (bi < 0) break;
+                sel[bi] = 1; ++nsel;
+            }
+            /* new beam in candidate-index order; renormalise by the best element's score */
+            int bestc = -1;
+            for (int c = 0; c < nc; ++c)
+                if (sel[c] && (bestc < 0 || bs_ukey(c_key[c]) > bs_ukey(c_key[bestc]))) bestc = c;
+            const float shift = c_score[bestc];
+            nb = 0;
+            for (int c = 0; c < nc; ++c)
+                if (sel[c]) {
+                    beam[nb].state = c_state[c]; beam[nb].hash = c_hash[c]; beam[nb].score = c_score[c] - shift;
+                    bp[(size_t)t * BS_MAXW + nb] = c_info[c];
+                    ++nb;
+                }
+            (void)nsel;
+        }
+        /* best final element (beta~_T = 0 -> key = score); ties: lower slot */
+        int r = 0;
+        for (int e = 1; e < nb; ++e) if (bs_ukey(beam[e].score) > bs_ukey(beam[r].score)) r = e;
+        int8_t* sq = sequence + (size_t)n * T;
+        int8_t* qs = qstring + (size_t)n * T;
+        int8_t* mv = moves + (size_t)n * T;
+        float* qf = qfloat ? qfloat + (size_t)n * T : NULL;
+        const float* Pn = P + (size_t)n * T * 4;
+        for (int t = T - 1; t >= 0; --t) {
+            const uint8_t info = bp[(size_t)t * BS_MAXW + r];
+            const int is_move = (info >> 5) & 1;
+            mv[t] = (int8_t)is_move;
+            sq[t] = is_move ? (int8_t)"ACGT"[info >> 6] : 0;
+            qs[t] = 0;
+            if (qf) qf[t] = 0.0f;
+            r = info & 31;
+        }
+        for (int t = 0; t < T; ++t) {
+            if (!mv[t]) continue;
+            int t2 = t + 1;
+            while (t2 < T && !mv[t2]) ++t2;          /* dwell covers boundaries u = t+1 .. t2 (indices t .. t2-1) */
+            const int x = sq[t] == 'A' ? 0 : sq[t] == 'C' ? 1 : sq[t] == 'G' ? 2 : 3;
+            double err = 0.0;
+            for (int u = t; u < t2; ++u)
+                for (int y = 0; y < 4; ++y) if (y != x) err += (double)Pn[(size_t)u * 4 + y];
+            err /= (double)(t2 - t);
+            if (err < 1e-10) err = 1e-10;
+            float qv = (float)(-10.0 * log10(err)) * q_scale + q_offset;
+            if (qv < 1.0f) qv = 1.0f;
+            if (qv > 50.0f) qv = 50.0f;
+            if (qf) qf[t] = qv;
+            qs[t] = (int8_t)(33 + (int)floorf(qv + 0.5f));
+        }
+    }
+    free(beta); free(Bcum); free(logZ); free(P); free(bp);
     return 0;
 }

@@ -130,3 +130,54 @@ def viterbi_bruteforce(scores_tnc_5s, state_len):
                         paths[t, n] = 0 if ks[t] == 0 else 1 + (st % 4)
                         st = idx[st, ks[t]]
     return best, paths
+
+
+def beam_search(scores, state_len, beam_width=32, beam_cut=100.0, blank=2.0, scale=1.0, offset=0.0):
+    """BS-1 decode of koi-layout scores [N,T,4S] (float16). Returns (sequence, qstring, moves, qfloat)."""
+    a, bits = _as_half_bits(scores)
+    N, T, _ = a.shape
+    seq = np.zeros((N, T), np.int8)
+    qs = np.zeros((N, T), np.int8)
+    mv = np.zeros((N, T), np.int8)
+    qf = np.zeros((N, T), np.float32)
+    rc = _lib().oracle_beam_search(
+        bits.ctypes.data_as(C.c_void_p), N, T, int(state_len), int(beam_width), C.c_float(beam_cut),
+        C.c_float(blank), C.c_float(scale), C.c_float(offset), seq.ctypes.data_as(C.c_void_p),
+        qs.ctypes.data_as(C.c_void_p), mv.ctypes.data_as(C.c_void_p), qf.ctypes.data_as(C.c_void_p))
+    if rc:
+        raise RuntimeError("oracle_beam_search failed (%d)" % rc)
+    return seq, qs, mv, qf
+
+
+def backward(scores, state_len, blank=2.0):
+    """-> (beta~ [N,T+1,S] f32, Bcum [N,T+1] f64, logZ [N] f64)"""
+    a, bits = _as_half_bits(scores)
+    N, T, _ = a.shape
+    S = 4 ** state_len
+    beta = np.zeros((N, T + 1, S), np.float32)
+    B = np.zeros((N, T + 1), np.float64)
+    lz = np.zeros((N,), np.float64)
+    rc = _lib().oracle_crf_backward(bits.ctypes.data_as(C.c_void_p), N, T, int(state_len), C.c_float(blank),
+                                    beta.ctypes.data_as(C.c_void_p), B.ctypes.data_as(C.c_void_p),
+                                    lz.ctypes.data_as(C.c_void_p))
+    if rc:
+        raise RuntimeError("oracle_crf_backward failed")
+    return beta, B, lz
+
+
+def forward_post(scores, state_len, beta, B, lz, blank=2.0):
+    a, bits = _as_half_bits(scores)
+    N, T, _ = a.shape
+    P = np.zeros((N, T, 4), np.float32)
+    rc = _lib().oracle_crf_forward_post(bits.ctypes.data_as(C.c_void_p), N, T, int(state_len), C.c_float(blank),
+                                        beta.ctypes.data_as(C.c_void_p), B.ctypes.data_as(C.c_void_p),
+                                        lz.ctypes.data_as(C.c_void_p), P.ctypes.data_as(C.c_void_p))
+    if rc:
+        raise RuntimeError("oracle_crf_forward_post failed")
+    return P
+
+
+def lse2(a, b):
+    f = _lib().oracle_lse2
+    f.restype = C.c_float
+    return f(C.c_float(a), C.c_float(b))

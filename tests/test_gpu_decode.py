@@ -72,3 +72,71 @@ def test_decode_rejects_wrong_dtype_and_device():
         decode.viterbi(torch.zeros(1, 4, 64, device="cuda"))
     with pytest.raises(Exception):
         decode.viterbi(torch.zeros(1, 4, 64, dtype=torch.float16))
+
+
+# ---- beam search (BS-1) vs the C oracle ---------------------------------------------------------
+def _peaky_scores(rng, N, T, state_len, sharp=3.0):
+    """Scores with a planted path so the decoder emits realistic base runs."""
+    S = 4 ** state_len
+    x = rng.standard_normal((N, T, 4 * S)).astype(np.float32)
+    for n in range(N):
+        st = int(rng.integers(S))
+        for t in range(T):
+            if rng.random() < 0.35:
+                b = int(rng.integers(4))
+                new = ((st << 2) | b) & (S - 1)
+                x[n, t, new * 4 + (st >> (2 * (state_len - 1)))] += 2.0 * sharp
+                st = new
+            else:
+                x[n, t] -= sharp * 0.5
+    return np.clip(x, -5, 5).astype(np.float16)
+
+
+@pytest.mark.parametrize("state_len", [1, 2, 3, 4, 5])
+def test_beam_search_matches_oracle(state_len):
+    rng = np.random.default_rng(40 + state_len)
+    N, T = (3, 60) if state_len == 5 else (7, 150)
+    sc = _peaky_scores(rng, N, T, state_len)
+    seq, qs, mv, qf = decode.beam_search(torch.from_numpy(sc).cuda(), return_qfloat=True)
+    oseq, oqs, omv, oqf = crf_ref.beam_search(sc, state_len)
+    assert np.array_equal(mv.numpy(), omv)
+    assert np.array_equal(seq.numpy(), oseq)
+    assert np.abs(qf.numpy() - oqf).max() < 1e-3
+    assert (qs.numpy() != oqs).mean() < 1e-3          # a rounding boundary may flip at most very rarely
+    assert set(np.unique(seq.numpy())) <= {0, 65, 67, 71, 84}
+
+
+@pytest.mark.parametrize("kind", ["normal", "ties"])
+def test_beam_search_random_scores_and_params(kind):
+    rng = np.random.default_rng(77)
+    sc = _scores(rng, 5, 120, 256, kind)
+    for bw, cut, blank in [(32, 100.0, 2.0), (8, 10.0, 0.5), (1, 1.0, 2.0), (16, 1e6, -1.0)]:
+        seq, qs, mv, qf = decode.beam_search(torch.from_numpy(sc).cuda(), beam_width=bw, beam_cut=cut,
+                                             blank_score=blank, scale=1.05, offset=0.2, return_qfloat=True)
+        oseq, oqs, omv, oqf = crf_ref.beam_search(sc, 3, beam_width=bw, beam_cut=cut, blank=blank, scale=1.05, offset=0.2)
+        assert np.array_equal(mv.numpy(), omv), (bw, cut, blank)
+        assert np.array_equal(seq.numpy(), oseq)
+        assert np.abs(qf.numpy() - oqf).max() < 1e-3
+
+
+def test_beam_search_close_to_viterbi_on_confident_scores():
+    rng = np.random.default_rng(5)
+    sc = _peaky_scores(rng, 6, 300, 3, sharp=4.0)
+    seq, qs, mv = decode.beam_search(torch.from_numpy(sc).cuda())
+    m2, p2 = decode.viterbi(torch.from_numpy(sc).cuda())
+    assert (mv.numpy() == m2.numpy()).mean() > 0.97
+    q = qs.numpy()[mv.numpy() == 1]
+    assert q.min() >= 33 + 1 and q.max() <= 33 + 50 and np.median(q) > 33 + 10
+
+
+def test_beam_search_full_size():
+    """hac BASELINE shape: properties + exact agreement with the oracle on a few chunks."""
+    g = torch.Generator(device="cuda").manual_seed(1)
+    sc = (torch.randn(512, 1667, 1024, generator=g, device="cuda") * 2.5).clamp(-5, 5).half()
+    seq, qs, mv = decode.beam_search(sc)
+    s, m, q = seq.numpy(), mv.numpy(), qs.numpy()
+    assert ((s != 0) == (m == 1)).all() and ((q != 0) == (m == 1)).all()
+    idx = [3, 200, 511]
+    oseq, oqs, omv, _ = crf_ref.beam_search(sc[idx].cpu().numpy(), 4)
+    assert np.array_equal(s[idx], oseq) and np.array_equal(m[idx], omv)
+    assert (q[idx] != oqs).mean() < 1e-3

@@ -65,3 +65,58 @@ def test_logz_upper_bounds_viterbi():
     lz = crf_ref.logz(sc, 2, blank=2.0)
     assert (lz >= best - 1e-4).all()
     assert (lz <= best + 30 * np.log(5) + np.log(16) + 1e-3).all()
+
+
+# ---- beam search oracle self-consistency (CPU) ----------------------------------------------------
+def test_table_lse2_accuracy_and_symmetry():
+    rng = np.random.default_rng(0)
+    for a, b in rng.uniform(-20, 20, (200, 2)):
+        v = crf_ref.lse2(float(a), float(b))
+        assert abs(v - np.logaddexp(np.float32(a), np.float32(b))) < 2e-6 * max(1.0, abs(v)) + 1e-6
+        assert v == crf_ref.lse2(float(b), float(a))
+    assert crf_ref.lse2(1.0, -np.inf) == 1.0 and crf_ref.lse2(-np.inf, -np.inf) == -np.inf
+
+
+@pytest.mark.parametrize("state_len", [1, 2, 3])
+def test_backward_forward_normalisation(state_len):
+    """logZ from the normalised backward scan equals the plain fp64 scan; class posteriors sum to 1."""
+    rng = np.random.default_rng(state_len)
+    sc = _scores(rng, 90, 3, 4 ** (state_len + 1)).transpose(1, 0, 2).copy()      # [N,T,4S]
+    beta, B, lz = crf_ref.backward(sc, state_len)
+    assert np.allclose(lz, crf_ref.logz(sc, state_len), rtol=0, atol=2e-3)
+    P = crf_ref.forward_post(sc, state_len, beta, B, lz)
+    assert np.abs(P.sum(-1) - 1.0).max() < 1e-4 and P.min() >= 0
+    assert np.abs(beta[:, :, 0]).max() == 0.0                                        # normalised by state 0
+
+
+def test_beam_width_one_is_greedy_guided_and_outputs_are_consistent():
+    rng = np.random.default_rng(3)
+    sc = _scores(rng, 100, 2, 64).transpose(1, 0, 2).copy()
+    for bw in (1, 4, 32):
+        seq, qs, mv, qf = crf_ref.beam_search(sc, 2, beam_width=bw)
+        assert ((seq != 0) == (mv == 1)).all() and ((qs != 0) == (mv == 1)).all()
+        assert set(np.unique(seq)) <= {0, 65, 67, 71, 84}
+        assert (qf[mv == 1] >= 1).all() and (qf[mv == 1] <= 50).all()
+
+
+def test_wide_beam_recovers_planted_sequence():
+    """With sharply peaked scores every decoder must read the planted path back."""
+    rng = np.random.default_rng(8)
+    sl, S, T = 2, 16, 80
+    x = np.full((1, T, 4 * S), -4.0, np.float32)
+    st, want = 5, []
+    for t in range(T):
+        if t % 3 == 0:
+            b = int(rng.integers(4))
+            new = ((st << 2) | b) & (S - 1)
+            x[0, t, new * 4 + (st >> 2)] = 5.0
+            st = new
+            want.append("ACGT"[b])
+        else:
+            x[0, t] = -5.0          # every move is very unlikely -> stay (blank 2.0)
+    seq, qs, mv, qf = crf_ref.beam_search(x.astype(np.float16), sl)
+    got = "".join(chr(c) for c in seq[0] if c)
+    assert got == "".join(want)
+    _, path, _ = crf_ref.viterbi(x.astype(np.float16), sl)
+    assert "".join("NACGT"[p] for p in path[0] if p) == got
+    assert np.median(qf[mv == 1]) > 20

@@ -47,6 +47,7 @@ for name, N in (("fast", 512), ("hac", 512)):
     torch.cuda.synchronize()
     t2 = time.perf_counter()
     mv, pa = decode.viterbi(sc)
+    mv_v = mv
     torch.cuda.synchronize()
     t3 = time.perf_counter()
     model._hip.check()
@@ -59,3 +60,16 @@ for name, N in (("fast", 512), ("hac", 512)):
           "bases/chunk %.1f" % float((pa != 0).sum() / N))
     om, op, _ = crf_ref.viterbi(sc[:2].cpu().numpy(), model.seqdist.state_len)
     print("    viterbi exact on 2 chunks:", np.array_equal(pa[:2].numpy(), op))
+    try:
+        decode.beam_search(sc)
+        torch.cuda.synchronize()
+        t4 = time.perf_counter()
+        seq, qs, mv = decode.beam_search(sc)
+        torch.cuda.synchronize()
+        t5 = time.perf_counter()
+        oseq, oqs, omv, _ = crf_ref.beam_search(sc[:2].cpu().numpy(), model.seqdist.state_len)
+        print("    beam ms %.2f  exact on 2 chunks: %s  bases/chunk %.1f  agree-with-viterbi %.4f" % (
+            (t5 - t4) * 1e3, np.array_equal(seq[:2].numpy(), oseq) and np.array_equal(mv[:2].numpy(), omv),
+            float(mv.sum() / N), float((mv == mv_v).float().mean())))
+    except Exception as exc:
+        print("    beam FAILED", exc)
