@@ -235,57 +235,60 @@ __device__ __forceinline__ int popc64(unsigned long long m) { return __popcll(m)
 __device__ __forceinline__ unsigned long long lanemask_lt(int lane) { return (1ull << lane) - 1ull; }
 
 // Select the `want` largest ukeys among 3 per lane (0 = dead); ties at the threshold by ascending
-// candidate index c = lane + 64*i. Returns per-candidate selected flags and slot numbers.
+// candidate index c = lane + 64*i. Returns per-candidate selected flags and slot numbers
+// (slots in candidate-index order). MSB-first radix search on ballots, two bits per round, with an
+// early exit as soon as some prefix isolates exactly `want` keys.
+__device__ __forceinline__ int count_ge(const unsigned (&uk)[3], unsigned trial) {
+    return popc64(__ballot(uk[0] >= trial)) + popc64(__ballot(uk[1] >= trial)) + popc64(__ballot(uk[2] >= trial));
+}
 __device__ __forceinline__ int radix_select(const unsigned (&uk)[3], int want, int lane, bool (&sel)[3], int (&slot)[3]) {
-    unsigned long long alive[3];
+    unsigned long long selm[3];
     int n_alive = 0;
 #pragma unroll
-    for (int i = 0; i < 3; ++i) { alive[i] = __ballot(uk[i] != 0u); n_alive += popc64(alive[i]); }
-    unsigned thr = 1u;   // smallest live key value is >= 1
+    for (int i = 0; i < 3; ++i) { selm[i] = __ballot(uk[i] != 0u); n_alive += popc64(selm[i]); }
     if (n_alive > want) {
         unsigned prefix = 0u;
-        for (int bit = 31; bit >= 0; --bit) {
-            const unsigned trial = prefix | (1u << bit);
-            int cnt = 0;
-#pragma unroll
-            for (int i = 0; i < 3; ++i) cnt += popc64(__ballot(uk[i] >= trial));
-            if (cnt >= want) prefix = trial;
+        bool exact = false;
+        for (int bit = 30; bit >= 0; bit -= 2) {
+            const unsigned t1 = prefix | (1u << bit), t2 = prefix | (2u << bit), t3 = prefix | (3u << bit);
+            const int c1 = count_ge(uk, t1), c2 = count_ge(uk, t2), c3 = count_ge(uk, t3);
+            int cnt = -1;
+            if (c3 >= want) { prefix = t3; cnt = c3; }
+            else if (c2 >= want) { prefix = t2; cnt = c2; }
+            else if (c1 >= want) { prefix = t1; cnt = c1; }
+            if (cnt == want) { exact = true; break; }
         }
-        thr = prefix;     // the want-th largest key
-    }
-    int n_gt = 0;
-    unsigned long long gt[3], eq[3];
+        // prefix is now either an exact separator (exact) or the want-th largest key value
+        unsigned long long gt[3], eq[3];
+        int n_gt = 0;
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        gt[i] = __ballot(uk[i] != 0u && uk[i] > thr);
-        eq[i] = (n_alive > want) ? __ballot(uk[i] == thr) : 0ull;
-        n_gt += popc64(gt[i]);
-    }
-    if (n_alive <= want) {
+        for (int i = 0; i < 3; ++i) {
+            gt[i] = exact ? __ballot(uk[i] >= prefix) : __ballot(uk[i] > prefix);
+            eq[i] = exact ? 0ull : __ballot(uk[i] == prefix);
+            n_gt += popc64(gt[i]);
+        }
+        const int need = want - n_gt;    // ties to take, in index order
+        int tie_before = 0;
 #pragma unroll
-        for (int i = 0; i < 3; ++i) gt[i] = alive[i];
-        n_gt = n_alive;
-    }
-    const int need = want - n_gt;    // ties to take, in index order
-    int tie_before = 0, total = 0;
-    unsigned long long selm[3];
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        const int my_rank = tie_before + popc64(eq[i] & lanemask_lt(lane));
-        const bool tie_ok = ((eq[i] >> lane) & 1ull) && my_rank < need;
-        sel[i] = ((gt[i] >> lane) & 1ull) || tie_ok;
-        tie_before += popc64(eq[i]);
-        selm[i] = __ballot(sel[i]);
+        for (int i = 0; i < 3; ++i) {
+            const int my_rank = tie_before + popc64(eq[i] & lanemask_lt(lane));
+            const bool tie_ok = ((eq[i] >> lane) & 1ull) && my_rank < need;
+            const bool s_ = ((gt[i] >> lane) & 1ull) || tie_ok;
+            tie_before += popc64(eq[i]);
+            selm[i] = __ballot(s_);
+        }
     }
     int before = 0;
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
+        sel[i] = (selm[i] >> lane) & 1ull;
         slot[i] = before + popc64(selm[i] & lanemask_lt(lane));
         before += popc64(selm[i]);
-        total = before;
     }
-    return total;
+    return before;
 }
+
+constexpr int HT = 256;   // open-addressing table of stay elements keyed by sequence hash
 
 __global__ __launch_bounds__(64) void beam_kernel(BeamArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -293,25 +296,30 @@ __global__ __launch_bounds__(64) void beam_kernel(BeamArgs p) {
     const int lane = threadIdx.x, n = blockIdx.x;
     const int sh = 2 * (p.state_len - 1);
     // LDS carve
-    half_t* st_sc = (half_t*)smem;                       // [BTB][4S]
+    float* tab = (float*)smem;                           // lse table
+    half_t* st_sc = (half_t*)(tab + BH_LSE_TABLE_SIZE + 2);   // [BTB][4S]
     float* st_b = (float*)(st_sc + BTB * 4 * S);         // [BTB][S]
     int* b_state = (int*)(st_b + BTB * S);               // [32]
     unsigned* b_hash = (unsigned*)(b_state + MAXW);      // [32]
     float* b_score = (float*)(b_hash + MAXW);            // [32]
     float* m_score = b_score + MAXW;                     // [32] merged-in move score
     int* m_info = (int*)(m_score + MAXW);                // [32] merged-in move info or -1
-    uint8_t* st_bp = (uint8_t*)(m_info + MAXW);          // [BTB][32]
-    const float* tab = g_lse_tab;
+    int* htab = m_info + MAXW;                           // [HT]
+    uint8_t* st_bp = (uint8_t*)(htab + HT);              // [BTB][32]
+    for (int i = lane; i < BH_LSE_TABLE_SIZE; i += 64) tab[i] = g_lse_tab[i];
 
     const half_t* sc = p.scores + (long)n * T * 4 * S;
     const float* bn = p.beta + (long)n * (T + 1) * S;
     uint8_t* bpn = p.bp + (long)n * T * MAXW;
 
+    // candidate decomposition is time-invariant: c = lane + 64*i = e*5 + j
+    int ce[3], cj[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { const int c = lane + 64 * i; ce[i] = c / 5; cj[i] = c - ce[i] * 5; }
+
     // ---- init: top-W states by beta~_0 (ties: lower state), slots in state order ------------------
     int nb;
     {
-        // S can exceed 3*64: run the radix select over the states in chunks is overkill -- use a
-        // threshold search over all S values held S/64 per lane.
         const int per = (S + 63) / 64;
         unsigned prefix = 0u;
         const int want = W < S ? W : S;
@@ -370,17 +378,24 @@ __global__ __launch_bounds__(64) void beam_kernel(BeamArgs p) {
         for (int u = 0; u < nsteps; ++u) {
             const half_t* row = st_sc + u * 4 * S;
             const float* b1 = st_b + u * S;
-            // ---- candidates: c = lane + 64*i, e = c / 5, j = c % 5 -------------------------------
+            // ---- (a) reset merge slots and the hash table, then insert the stay elements -----------
+#pragma unroll
+            for (int i = 0; i < HT / 64; ++i) htab[lane + 64 * i] = -1;
+            if (lane < MAXW) m_info[lane] = -1;
+            __syncthreads();
+            if (lane < nb) {
+                int slot = (int)(b_hash[lane] & (HT - 1));
+                while (atomicCAS(&htab[slot], -1, lane) != -1) slot = (slot + 1) & (HT - 1);
+            }
+            __syncthreads();
+            // ---- (b) candidates; a move that spells the same sequence as a stay is folded into it ---
             float cs[3];
             unsigned ch[3];
             int cst[3], cinfo[3];
             bool alive[3];
-            if (lane < MAXW) m_info[lane] = -1;
-            __syncthreads();
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
-                const int c = lane + 64 * i;
-                const int e = c / 5, j = c - e * 5;
+                const int e = ce[i], j = cj[i];
                 alive[i] = e < nb;
                 cs[i] = -INFINITY; ch[i] = 0u; cst[i] = 0; cinfo[i] = 0;
                 if (alive[i]) {
@@ -395,21 +410,17 @@ __global__ __launch_bounds__(64) void beam_kernel(BeamArgs p) {
                         cst[i] = s2; ch[i] = bs_mix(h, x);
                         cs[i] = scv + (float)row[s2 * 4 + (s >> sh)];
                         cinfo[i] = e | (1 << 5) | (x << 6);
-                    }
-                }
-            }
-            // ---- merge: a move that spells the same sequence as a stay is folded into it ----------
-#pragma unroll
-            for (int i = 0; i < 3; ++i) {
-                const int c = lane + 64 * i;
-                const int j = c % 5;
-                if (alive[i] && j != 0) {
-                    for (int d = 0; d < nb; ++d) {
-                        if (b_hash[d] == ch[i] && b_state[d] == cst[i]) {
-                            m_score[d] = cs[i];
-                            m_info[d] = cinfo[i];
-                            alive[i] = false;
-                            break;
+                        int slot = (int)(ch[i] & (HT - 1));
+                        while (true) {
+                            const int d = htab[slot];
+                            if (d < 0) break;
+                            if (b_hash[d] == ch[i] && b_state[d] == cst[i]) {
+                                m_score[d] = cs[i];
+                                m_info[d] = cinfo[i];
+                                alive[i] = false;
+                                break;
+                            }
+                            slot = (slot + 1) & (HT - 1);
                         }
                     }
                 }
@@ -417,15 +428,13 @@ __global__ __launch_bounds__(64) void beam_kernel(BeamArgs p) {
             __syncthreads();
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
-                const int c = lane + 64 * i;
-                const int e = c / 5, j = c - e * 5;
-                if (alive[i] && j == 0 && m_info[e] >= 0) {
-                    const float ms = m_score[e];
-                    if (ms > cs[i]) cinfo[i] = m_info[e];
+                if (alive[i] && cj[i] == 0 && m_info[ce[i]] >= 0) {
+                    const float ms = m_score[ce[i]];
+                    if (ms > cs[i]) cinfo[i] = m_info[ce[i]];
                     cs[i] = lse2_tab(cs[i], ms, tab);
                 }
             }
-            // ---- keys, cut -------------------------------------------------------------------------
+            // ---- (c) keys, cut ---------------------------------------------------------------------
             float key[3];
             float best = -INFINITY;
 #pragma unroll
@@ -442,7 +451,7 @@ __global__ __launch_bounds__(64) void beam_kernel(BeamArgs p) {
                 if (alive[i] && key[i] < thr) alive[i] = false;
                 uk[i] = alive[i] ? bs_ukey(key[i]) : 0u;
             }
-            // ---- top-W, slots in candidate order ---------------------------------------------------
+            // ---- (d) top-W, slots in candidate order -----------------------------------------------
             bool sel[3];
             int slot[3];
             const int nnew = radix_select(uk, W, lane, sel, slot);
@@ -501,10 +510,15 @@ struct FinArgs {
     float* qfloat;         // optional [N][T]
 };
 
-// one thread per chunk: the walks are serial and short (T steps); 64 chunks per workgroup.
-__global__ void beam_finalize_kernel(FinArgs p) {
-    const int n = blockIdx.x * blockDim.x + threadIdx.x;
-    if (n >= p.N) return;
+constexpr int FTB = 256;   // back-pointer rows staged per block (8 KiB)
+
+// One wave per chunk. The pointer chase is serial (lane 0) but runs out of LDS-staged blocks; the
+// q-score pass is parallel over emitting steps.
+__global__ __launch_bounds__(64) void beam_finalize_kernel(FinArgs p) {
+    __shared__ __attribute__((aligned(16))) uint8_t st[FTB * MAXW];
+    __shared__ int8_t res_m[FTB], res_s[FTB];
+    __shared__ int s_r;
+    const int n = blockIdx.x, lane = threadIdx.x;
     const int T = p.T;
     const uint8_t* bp = p.bp + (long)n * T * MAXW;
     const float* P = p.P + (long)n * T * 4;
@@ -512,19 +526,38 @@ __global__ void beam_finalize_kernel(FinArgs p) {
     int8_t* qs = p.qstring + (long)n * T;
     int8_t* mv = p.moves + (long)n * T;
     float* qf = p.qfloat ? p.qfloat + (long)n * T : nullptr;
-    int r = p.final_slot[n];
-    for (int t = T - 1; t >= 0; --t) {
-        const int info = bp[(long)t * MAXW + r];
-        const int is_move = (info >> 5) & 1;
-        mv[t] = (int8_t)is_move;
-        sq[t] = is_move ? (int8_t)("ACGT"[info >> 6]) : (int8_t)0;
-        qs[t] = 0;
-        if (qf) qf[t] = 0.0f;
-        r = info & 31;
+    if (lane == 0) s_r = p.final_slot[n];
+    for (int thi = T; thi > 0; thi -= FTB) {
+        const int tlo = max(0, thi - FTB);
+        const int nbytes = (thi - tlo) * MAXW;
+        const uint4_t* src = (const uint4_t*)(bp + (long)tlo * MAXW);
+        for (int i = lane; i < nbytes / 16; i += 64) ((uint4_t*)st)[i] = src[i];
+        __syncthreads();
+        if (lane == 0) {
+            int r = s_r;
+            for (int t = thi - 1; t >= tlo; --t) {
+                const int info = st[(t - tlo) * MAXW + r];
+                const int is_move = (info >> 5) & 1;
+                res_m[t - tlo] = (int8_t)is_move;
+                res_s[t - tlo] = is_move ? (int8_t)("ACGT"[info >> 6]) : (int8_t)0;
+                r = info & 31;
+            }
+            s_r = r;
+        }
+        __syncthreads();
+        for (int i = lane; i < thi - tlo; i += 64) {
+            mv[tlo + i] = res_m[i];
+            sq[tlo + i] = res_s[i];
+            qs[tlo + i] = 0;
+            if (qf) qf[tlo + i] = 0.0f;
+        }
+        __syncthreads();
     }
-    int t = 0;
-    while (t < T) {
-        if (!mv[t]) { ++t; continue; }
+    __threadfence();
+    __syncthreads();
+    // q-scores: each lane takes emitting steps t = lane, lane+64, ...
+    for (int t = lane; t < T; t += 64) {
+        if (!mv[t]) continue;
         int t2 = t + 1;
         while (t2 < T && !mv[t2]) ++t2;
         const int c = sq[t];
@@ -542,7 +575,6 @@ __global__ void beam_finalize_kernel(FinArgs p) {
         qv = fminf(fmaxf(qv, 1.0f), 50.0f);
         if (qf) qf[t] = qv;
         qs[t] = (int8_t)(33 + (int)floorf(qv + 0.5f));
-        t = t2;
     }
 }
 
@@ -586,12 +618,12 @@ int bh_k_beam_search(const void* scores, int N, int T, int state_len, int beam_w
     hipLaunchKernelGGL(crf_backward_kernel, dim3(N), dim3(threads), lds_scan, stream, sa);
     hipLaunchKernelGGL(crf_forward_post_kernel, dim3(N), dim3(threads), lds_scan, stream, sa);
     BeamArgs ba{(const half_t*)scores, beta, N, T, S, state_len, beam_width, blank, logf(beam_cut), bp, fin};
-    const size_t lds_beam = (size_t)BTB * 4 * S * 2 + (size_t)BTB * S * 4 + MAXW * 4 * 5 + BTB * MAXW + 64;
+    const size_t lds_beam = (size_t)(BH_LSE_TABLE_SIZE + 2) * 4 + (size_t)BTB * 4 * S * 2 + (size_t)BTB * S * 4 + MAXW * 4 * 5 + HT * 4 + BTB * MAXW + 64;
     if (lds_beam > 64 * 1024)
         BH_CHECK_HIP(hipFuncSetAttribute((const void*)beam_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_beam));
     hipLaunchKernelGGL(beam_kernel, dim3(N), dim3(64), lds_beam, stream, ba);
     FinArgs fa{bp, fin, P, N, T, q_scale, q_offset, sequence, qstring, moves, qfloat};
-    hipLaunchKernelGGL(beam_finalize_kernel, dim3((N + 63) / 64), dim3(64), 0, stream, fa);
+    hipLaunchKernelGGL(beam_finalize_kernel, dim3(N), dim3(64), 0, stream, fa);
     BH_CHECK_HIP(hipGetLastError());
     return 0;
 }
