@@ -37,7 +37,7 @@ def parse():
     ap.add_argument("--model", default="hac", choices=["hac", "fast"])
     ap.add_argument("--batch", type=int, default=512)
     ap.add_argument("--chunk", type=int, default=10000)
-    ap.add_argument("--decoder", default="viterbi", choices=["viterbi", "beam"])
+    ap.add_argument("--decoder", default="beam", choices=["viterbi", "beam"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     return ap.parse_args()
 
@@ -116,12 +116,40 @@ def main():
     gen = torch.Generator(device=dev).manual_seed(25 + rank)
     signal = torch.randn(a.batch, 1, a.chunk, generator=gen, device=dev).half()
 
-    def step():
-        scores = model(signal)
-        if a.decoder == "viterbi":
-            moves, path = decode.viterbi(scores)          # includes D2H of the int8 outputs
-            return moves, path
-        return decode.beam_search(scores)
+    enc_stream, dec_stream = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+    T_out, C_out = None, None
+
+    def encode():
+        with torch.cuda.stream(enc_stream):
+            sc = model(signal)
+            ev = torch.cuda.Event()
+            ev.record(enc_stream)
+        return sc, ev
+
+    # probe output geometry, build two decode contexts (double buffered pinned outputs)
+    sc0, ev0 = encode()
+    ev0.synchronize()
+    T_out, C_out = sc0.shape[1], sc0.shape[2]
+    decs = [decode.CRFDecoder(a.batch, T_out, C_out, dev, mode=a.decoder) for _ in range(2)]
+    del sc0
+
+    def run(steps):
+        """`steps` passes of the hot path, software-pipelined over two HIP streams: encoder(i+1) overlaps
+        decode(i). Every step's int8 outputs are on the host when this returns."""
+        tickets = [None, None]
+        for i in range(steps):
+            sc, ev = encode()
+            if tickets[i & 1] is not None:
+                tickets[i & 1].result()            # its pinned buffers are about to be reused
+            with torch.cuda.stream(dec_stream):
+                dec_stream.wait_event(ev)
+                sc.record_stream(dec_stream)
+                tickets[i & 1] = decs[i & 1].submit(sc)
+        out = None
+        for tk in tickets:
+            if tk is not None:
+                out = tk.result()
+        return out
 
     def barrier():
         torch.cuda.synchronize(dev)
@@ -130,14 +158,12 @@ def main():
         torch.cuda.synchronize(dev)
 
     log("warmup")
-    for _ in range(a.warmup):
-        step()
+    run(a.warmup)
     model._hip.check()
     barrier()
     log("timed region")
     t0 = time.perf_counter()
-    for _ in range(a.steps):
-        step()
+    run(a.steps)
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -159,7 +185,7 @@ def main():
         for i in range(nprof):
             scores = model(signal)
             ev[2 * i].record()
-            decode.viterbi(scores) if a.decoder == "viterbi" else decode.beam_search(scores)
+            decs[0].submit(scores).result()
             ev[2 * i + 1].record()
         torch.cuda.synchronize(dev)
         for i in range(nprof):
@@ -198,7 +224,7 @@ def main():
             "dtype": "f16",
             "data": "synthetic",
             "config": {"workload": "dna_r10.4.1_e8.2_400bps_%s@v5.0.0-shaped CRF (seeded random weights), "
-                                   "batch %d x chunk %d, %s decode, 1 replica per GPU" %
+                                   "batch %d x chunk %d, %s decode, encoder/decoder software-pipelined on 2 HIP streams, 1 replica per GPU" %
                                    (a.model, a.batch, a.chunk, a.decoder),
                        "parallelism": "replicas x%d (shard-by-read, no collective)" % world},
             "per_gpu": samples / elapsed / world,

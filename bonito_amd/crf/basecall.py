@@ -53,16 +53,57 @@ def fmt(stride, attrs, rna=False):
     }
 
 
+class _Pipeline:
+    """Two-stage device pipeline: the encoder runs on one HIP stream (thread 1), the CRF decode + int8 D2H
+    on another (thread 2), so decode of batch i overlaps the encoder of batch i+1. The reference gets the
+    same overlap from its per-stage ThreadIterators (bonito/crf/basecall.py:63-82) with koi returning CPU
+    tensors; here the split is explicit because both halves are ours."""
+
+    def __init__(self, model, decoder="beam", **decode_kw):
+        self.model, self.mode, self.kw = model, decoder, decode_kw
+        self.device = next(model.parameters()).device
+        self.enc_stream = torch.cuda.Stream(self.device)
+        self.dec_stream = torch.cuda.Stream(self.device)
+        self.decoders = {}
+
+    def encode(self, batch):
+        with torch.inference_mode(), torch.cuda.stream(self.enc_stream):
+            scores = self.model(batch.to(torch.float16).to(self.device, non_blocking=True))
+            ready = torch.cuda.Event()
+            ready.record(self.enc_stream)
+        return scores, ready
+
+    def decode(self, scores, ready):
+        key = tuple(scores.shape[1:])
+        dec = self.decoders.get(key)
+        if dec is None or dec.N < scores.shape[0]:
+            cfg = getattr(self.model, "config", None) or {}
+            nmax = max(scores.shape[0], int(cfg.get("basecaller", {}).get("batchsize", 0) or 0))
+            dec = self.decoders[key] = hip_decode.CRFDecoder(nmax, key[0], key[1], self.device, mode=self.mode, **self.kw)
+        with torch.inference_mode(), torch.cuda.stream(self.dec_stream):
+            self.dec_stream.wait_event(ready)
+            scores.record_stream(self.dec_stream)
+            ticket = dec.submit(scores)
+        sequence, qstring, moves = ticket.result()
+        if self.mode == "viterbi":
+            path = qstring            # plane 1 carries the path for the Viterbi decoder
+            sequence = hip_decode.path_to_sequence(path)
+            qstring = torch.where(sequence != 0, torch.tensor(33 + 20, dtype=torch.int8), torch.tensor(0, dtype=torch.int8))
+        return {"moves": moves, "qstring": qstring, "sequence": sequence}
+
+
 def basecall(model, reads, chunksize=4000, overlap=100, batchsize=32, reverse=False, rna=False, decoder="beam"):
     """Basecalls a set of reads: yields (read, {sequence, qstring, moves, stride})."""
+    if reverse:
+        raise NotImplementedError("--revcomp is not implemented in the HIP engine yet")
+    pipe = _Pipeline(model, decoder=decoder)
     chunks = thread_iter(
         ((read, 0, read.signal.shape[-1]), chunk(torch.from_numpy(read.signal), chunksize, overlap))
         for read in reads
     )
     batches = thread_iter(batchify(chunks, batchsize=batchsize))
-    scores = thread_iter(
-        (keys, compute_scores(model, batch, reverse=reverse, decoder=decoder)) for keys, batch in batches
-    )
+    encoded = thread_iter((keys, pipe.encode(batch)) for keys, batch in batches)
+    scores = thread_iter((keys, pipe.decode(*enc)) for keys, enc in encoded)
     results = thread_iter(
         (read, stitch_results(sc, end - start, chunksize, overlap, model.stride, reverse))
         for ((read, start, end), sc) in unbatchify(scores)

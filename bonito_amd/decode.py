@@ -33,6 +33,60 @@ def state_len_of(C_, n_base=4):
     return sl
 
 
+class CRFDecoder:
+    """Pre-allocated decode context (workspace, device + pinned host output planes) for batches of up
+    to (max_batch, T, C). ``submit(scores)`` enqueues the HIP decode and the int8 D2H copy on the current
+    stream and returns a ticket; ``ticket.result()`` waits and returns CPU tensors. Used by the pipelined
+    basecaller / bench so that decode of batch i overlaps the encoder of batch i+1 on another stream."""
+
+    def __init__(self, max_batch, T, C, device, mode="beam", beam_width=32, beam_cut=100.0, scale=1.0, offset=0.0,
+                 blank_score=2.0):
+        lib = _lib.lib()
+        self.mode, self.device = mode, torch.device(device)
+        self.N, self.T, self.C = int(max_batch), int(T), int(C)
+        self.sl = state_len_of(self.C)
+        self.args = (int(beam_width), float(beam_cut), float(blank_score), float(scale), float(offset))
+        nbytes = (lib.bh_beam_search_workspace(self.N, self.T, self.sl) if mode == "beam"
+                  else lib.bh_crf_viterbi_workspace(self.N, self.T, self.sl))
+        self.ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        self.dev_out = torch.empty((3, self.N, self.T), dtype=torch.int8, device=self.device)
+        self.host_out = torch.empty((3, self.N, self.T), dtype=torch.int8).pin_memory()
+        self.done = torch.cuda.Event()
+
+    class Ticket:
+        def __init__(self, dec, n):
+            self.dec, self.n = dec, n
+
+        def result(self):
+            """(sequence, qstring, moves) CPU int8 [N, T] (copies, safe to keep)."""
+            self.dec.done.synchronize()
+            h = self.dec.host_out[:, : self.n]
+            return h[0].clone(), h[1].clone(), h[2].clone()
+
+    def submit(self, scores):
+        _check_scores(scores)
+        N, T, Cc = scores.shape
+        if N > self.N or T != self.T or Cc != self.C:
+            raise ValueError("decoder built for (<=%d, %d, %d), got %s" % (self.N, self.T, self.C, tuple(scores.shape)))
+        lib = _lib.lib()
+        bw, cut, blank, scale, offset = self.args
+        out = self.dev_out
+        with torch.cuda.device(self.device):
+            st = _lib.stream_ptr(self.device)
+            if self.mode == "beam":
+                _lib.check(lib.bh_beam_search(_lib.ptr(scores), N, T, self.sl, bw, cut, blank, scale, offset,
+                                              _lib.ptr(self.ws), _lib.ptr(out[0]), _lib.ptr(out[1]), _lib.ptr(out[2]),
+                                              None, st), "bh_beam_search")
+                self.host_out[:, :N].copy_(out[:, :N], non_blocking=True)
+            else:
+                # viterbi: plane 2 = moves, plane 1 = path (0..4); sequence/qstring are derived on the host
+                _lib.check(lib.bh_crf_viterbi(_lib.ptr(scores), N, T, self.sl, 0, blank, T * Cc, Cc, _lib.ptr(self.ws),
+                                              _lib.ptr(out[2]), _lib.ptr(out[1]), None, st), "bh_crf_viterbi")
+                self.host_out[1:, :N].copy_(out[1:, :N], non_blocking=True)
+            self.done.record(torch.cuda.current_stream(self.device))
+        return CRFDecoder.Ticket(self, N)
+
+
 def beam_search(scores, beam_width=32, beam_cut=100.0, scale=1.0, offset=0.0, blank_score=2.0, return_qfloat=False):
     """koi.decode.beam_search replacement (same arguments and defaults, bonito/crf/basecall.py:27,36-40).
     scores: cuda fp16 contiguous [N, T, 4^(state_len+1)].  Returns CPU int8 tensors
