@@ -96,15 +96,10 @@ def cpu_baseline(name, chunk, hard_timeout=90.0):
 
 def main():
     a = parse()
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    import torch.distributed as dist
+    from bonito_amd import parallel
     assert torch.cuda.is_available(), "bench.py needs a HIP device; there is no CPU fallback"
+    rank, world, local = parallel.init("nccl")     # one process per GPU; RCCL only for barrier + MAX-reduce
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
@@ -166,10 +161,7 @@ def main():
     run(a.steps)
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = parallel.max_over_ranks(elapsed, device=dev)
     model._hip.check()
     log("timed region done: %.1f ms/step" % (1e3 * elapsed / a.steps))
 
