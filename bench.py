@@ -34,12 +34,27 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--model", default="hac", choices=["hac", "fast"])
-    ap.add_argument("--batch", type=int, default=512)
-    ap.add_argument("--chunk", type=int, default=10000)
+    ap.add_argument("--model", default="hac", choices=["hac", "fast", "sup"])
+    ap.add_argument("--batch", type=int, default=0, help="default: 512 (hac/fast), 256 (sup)")
+    ap.add_argument("--chunk", type=int, default=0, help="default: 10000 (hac/fast), 12000 (sup)")
     ap.add_argument("--decoder", default="beam", choices=["viterbi", "beam"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    return ap.parse_args()
+    a = ap.parse_args()
+    a.batch = a.batch or (256 if a.model == "sup" else 512)
+    a.chunk = a.chunk or (12000 if a.model == "sup" else 10000)
+    return a
+
+
+def build_model(name, batch, chunk):
+    from bonito_amd import synthetic
+    if name == "sup":
+        return synthetic.make_transformer_model(head_gain=4.0, batchsize=batch, chunksize=chunk)
+    return synthetic.make_model(name, batchsize=batch, chunksize=chunk)
+
+
+def flops(name, chunk):
+    from bonito_amd import synthetic
+    return synthetic.transformer_flops_per_chunk(chunksize=chunk) if name == "sup" else synthetic.flops_per_chunk(name, chunk)
 
 
 def log(msg):
@@ -52,9 +67,8 @@ T_START = time.perf_counter()
 
 def cpu_baseline_worker(name, chunk, seconds_budget=15.0):
     """CPU oracle timed on this host: oracle/nn_ref.py forward (fp32) + oracle/crf_oracle.c Viterbi."""
-    from bonito_amd import synthetic
     from oracle import crf_ref, nn_ref
-    model = synthetic.make_model(name)
+    model = build_model(name, 8, chunk)
     nn_ref.round_params_to_half_(model)
     try:
         ncores = len(os.sched_getaffinity(0))
@@ -62,7 +76,7 @@ def cpu_baseline_worker(name, chunk, seconds_budget=15.0):
         ncores = os.cpu_count() or 1
     ncores = max(1, min(ncores, 32))      # small per-step matmuls stop scaling long before that
     torch.set_num_threads(ncores)
-    n = 8
+    n = 2 if name == "sup" else 8
     x = torch.randn(n, 1, chunk, generator=torch.Generator().manual_seed(25)).half().float()
     reps, t_total = 0, 0.0
     while t_total < seconds_budget and reps < 8:
@@ -105,7 +119,7 @@ def main():
 
     from bonito_amd import decode, synthetic
     log("building model %s" % a.model)
-    model = synthetic.make_model(a.model, batchsize=a.batch, chunksize=a.chunk)
+    model = build_model(a.model, a.batch, a.chunk)
     model.use_koi(batchsize=a.batch, chunksize=a.chunk, quantize=False)
     model = model.half().to(dev)
     gen = torch.Generator(device=dev).manual_seed(25 + rank)
@@ -186,15 +200,17 @@ def main():
         enc.profile(False)
         breakdown = {k: round(v[0] / nprof, 3) for k, v in prof.items() if v[1]}
         breakdown["decode_incl_d2h"] = round(dec_ms / nprof, 3)
-        fl = synthetic.flops_per_chunk(a.model, a.chunk)
-        cls = max(("lstm_rec", "lstm_gemm", "crf_linear", "conv"), key=lambda k: prof[k][0])
+        fl = flops(a.model, a.chunk)
+        cls = max((k for k in ("lstm_rec", "lstm_gemm", "crf_linear", "conv", "attention", "mlp") if k in fl),
+                  key=lambda k: prof[k][0])
         ms, spans = prof[cls]
         launches_per_fwd = spans / nprof
         flops_per_launch = fl[cls] * a.batch / launches_per_fwd
         avg_ms = ms / spans
         achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12
         roof = {"kernel": {"lstm_rec": "lstm_layer_kernel", "lstm_gemm": "gemm_kernel", "crf_linear": "gemm_kernel",
-                           "conv": "conv_igemm_kernel"}[cls],
+                           "conv": "conv_igemm_kernel", "mlp": "gemm_kernel (fc1 gated + fc2) + rmsnorm_residual_kernel",
+                           "attention": "gemm_kernel (Wqkv, out_proj) + attention_kernel + rmsnorm_residual_kernel"}[cls],
                 "bound": "mfma", "achieved": round(achieved, 2), "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(achieved / MFMA_F16_PEAK_TFLOPS, 4), "traffic": None,
                 "avg_launch_ms": round(avg_ms, 4), "flops_per_launch": flops_per_launch}
@@ -215,7 +231,7 @@ def main():
             "vs_baseline": None,
             "dtype": "f16",
             "data": "synthetic",
-            "config": {"workload": "dna_r10.4.1_e8.2_400bps_%s@v5.0.0-shaped CRF (seeded random weights), "
+            "config": {"workload": "dna_r10.4.1_e8.2_400bps_%s@v5.0.0-shaped model (seeded random weights), "
                                    "batch %d x chunk %d, %s decode, encoder/decoder software-pipelined on 2 HIP streams, 1 replica per GPU" %
                                    (a.model, a.batch, a.chunk, a.decoder),
                        "parallelism": "replicas x%d (shard-by-read, no collective)" % world},

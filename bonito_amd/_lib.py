@@ -59,6 +59,9 @@ SIGNATURES = {
     "bh_conv1d_packed_halves": (_sz, [_i, _i, _i]),
     "bh_conv1d_pack": (_i, [_vp, _i, _i, _i, _vp]),
     "bh_conv1d": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _f, _f, _l, _l, _vp]),
+    "bh_rotary_table": (_i, [_i, _i, _vp]),
+    "bh_attention": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "bh_rmsnorm_residual": (_i, [_vp, _vp, _vp, _vp, _l, _i, _f, _f, _vp]),
     "bh_lstm_pack_whh": (_i, [_vp, _i, _vp]),
     "bh_lstm_workspace": (_sz, [_i, _i]),
     "bh_lstm_layer": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _vp]),

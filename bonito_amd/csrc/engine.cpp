@@ -51,6 +51,7 @@ static inline uint16_t f2h(float f) {
     return u;
 }
 
+extern "C" int bh_rotary_table(int T, int dim, float* out);
 extern "C" size_t bh_conv1d_packed_halves(int Cin, int Cout, int K) {
     size_t kp = ((size_t)K * Cin + 31) / 32 * 32;
     size_t c16 = ((size_t)Cout + 15) / 16 * 16;
@@ -148,6 +149,8 @@ struct bh_encoder {
     int n_cus = 0;
     std::vector<Layer> layers;
     DevBuf act[2], gates, sig, err, lstm_ws;
+    DevBuf t_qkv, t_mid, t_a, t_b, rot;   // transformer workspace + rotary cos/sin table [Tmax][32][2]
+    int rot_len = 0;
     int out_features = 0;
     int lstm_force_slow = 0;
     // optional per-kernel-class timing with HIP events on the caller's stream (bench.py roofline leg)
@@ -161,6 +164,7 @@ struct bh_encoder {
             l.w4.release(); l.w5.release(); l.b0.release(); l.b1.release();
         }
         act[0].release(); act[1].release(); gates.release(); sig.release(); err.release(); lstm_ws.release();
+        t_qkv.release(); t_mid.release(); t_a.release(); t_b.release(); rot.release();
     }
 };
 
@@ -200,6 +204,13 @@ static int walk(const bh_encoder* e, int N, int L, int* T_out, int* C_out, size_
                 C = l.d.out_size;
                 break;
             case BH_LAYER_CLAMP:
+                break;
+            case BH_LAYER_TRANSFORMER:
+                amax = std::max(amax, (size_t)N * len * C * 2);
+                break;
+            case BH_LAYER_UPSAMPLE:
+                len *= l.d.scale_factor;
+                amax = std::max(amax, (size_t)N * len * C * 2);
                 break;
             default:
                 BH_REQUIRE(false, "encoder: layer kind %d is not supported by this build", l.d.kind);
@@ -318,10 +329,41 @@ extern "C" int bh_encoder_create(const bh_layer_t* layers, int n_layers, int dev
                 e->out_features = d.out_size;
                 break;
             }
+            case BH_LAYER_TRANSFORMER: {
+                const int D = d.in_size, F = d.dim_ff;
+                if (!(d.w0 && d.w1 && d.w2 && d.w3 && d.w4 && d.w5 && D > 0 && F > 0 && d.nhead > 0) ||
+                    D % d.nhead != 0 || D / d.nhead != 64 || D % 8 != 0 || F % 8 != 0) {
+                    bh_set_error("encoder_create: layer %d: transformer layer needs head_dim 64 and all weights", i);
+                    return fail(-2);
+                }
+                rc = upload_f16(L.w0, d.w0, (size_t)3 * D * D);
+                if (!rc && d.b0) rc = upload_f32(L.b0, d.b0, (size_t)3 * D);
+                if (!rc) rc = upload_f16(L.w1, d.w1, (size_t)D * D);
+                if (!rc && d.b1) rc = upload_f32(L.b1, d.b1, D);
+                if (!rc) {   // fc1 rows interleaved (y_j, gate_j) for the SwiGLU epilogue of the GEMM
+                    std::vector<float> wi((size_t)2 * F * D);
+                    for (int j = 0; j < F; ++j) {
+                        memcpy(&wi[(size_t)(2 * j) * D], d.w2 + (size_t)j * D, sizeof(float) * D);
+                        memcpy(&wi[(size_t)(2 * j + 1) * D], d.w2 + (size_t)(F + j) * D, sizeof(float) * D);
+                    }
+                    rc = upload_f16(L.w2, wi.data(), wi.size());
+                }
+                if (!rc) rc = upload_f16(L.w3, d.w3, (size_t)D * F);
+                if (!rc) rc = upload_f32(L.w4, d.w4, D);
+                if (!rc) rc = upload_f32(L.w5, d.w5, D);
+                break;
+            }
+            case BH_LAYER_UPSAMPLE: {
+                const int D = d.in_size, sf = d.scale_factor;
+                if (!(d.w0 && D > 0 && sf > 0 && D % 8 == 0)) { bh_set_error("encoder_create: layer %d: malformed upsample", i); return fail(-2); }
+                rc = upload_f16(L.w0, d.w0, (size_t)sf * D * D);
+                if (!rc && d.b0) rc = upload_f32(L.b0, d.b0, (size_t)sf * D);
+                break;
+            }
             case BH_LAYER_CLAMP: {
                 // fold into the producing layer's epilogue
                 int j = i - 1;
-                if (j < 0 || e->layers[j].d.kind == BH_LAYER_CLAMP || e->layers[j].d.kind == BH_LAYER_LSTM) {
+                if (j < 0 || (e->layers[j].d.kind != BH_LAYER_CONV && e->layers[j].d.kind != BH_LAYER_LINEAR_CRF)) {
                     bh_set_error("encoder_create: layer %d: clamp must follow a convolution or linear layer", i);
                     return fail(-2);
                 }
@@ -350,6 +392,31 @@ extern "C" int bh_encoder_create(const bh_layer_t* layers, int n_layers, int dev
     if (e->act[0].alloc(ab + 256) || e->act[1].alloc(ab + 256) || e->gates.alloc(gb + 256) ||
         e->sig.alloc((size_t)Np * max_chunk * 2) || e->err.alloc(sizeof(int)) || e->lstm_ws.alloc(bh_k_lstm_ws_bytes(Np, 512)))
         return fail(-1);
+    {   // transformer workspace: sized by walking to each transformer layer's token count
+        long len = max_chunk;
+        size_t m_qkv = 0, m_mid = 0, m_d = 0;
+        int tmax = 0;
+        for (const auto& l : e->layers) {
+            if (l.d.kind == BH_LAYER_CONV) len = conv_out_len((int)len, l.d.winlen, l.d.stride, l.d.padding);
+            else if (l.d.kind == BH_LAYER_UPSAMPLE) len *= l.d.scale_factor;
+            else if (l.d.kind == BH_LAYER_TRANSFORMER) {
+                const size_t M = (size_t)Np * len;
+                m_qkv = std::max(m_qkv, M * 3 * l.d.in_size * 2);
+                m_mid = std::max(m_mid, M * l.d.dim_ff * 2);
+                m_d = std::max(m_d, M * l.d.in_size * 2);
+                tmax = std::max(tmax, (int)len);
+            }
+        }
+        if (m_qkv) {
+            if (e->t_qkv.alloc(m_qkv + 256) || e->t_mid.alloc(m_mid + 256) || e->t_a.alloc(m_d + 256) || e->t_b.alloc(m_d + 256))
+                return fail(-1);
+            // rotary table: angle = t * 10000^(-i/32), fp32 like flash_attn.layers.rotary
+            std::vector<float> cs((size_t)tmax * 32 * 2);
+            if (bh_rotary_table(tmax, 64, cs.data())) return fail(-2);
+            if (upload_f32(e->rot, cs.data(), cs.size())) return fail(-1);
+            e->rot_len = tmax;
+        }
+    }
     if (hipMemset(e->err.p, 0, sizeof(int)) != hipSuccess || hipMemset(e->act[0].p, 0, e->act[0].bytes) != hipSuccess ||
         hipMemset(e->act[1].p, 0, e->act[1].bytes) != hipSuccess) {
         bh_set_error("encoder_create: hipMemset failed");
@@ -377,8 +444,10 @@ extern "C" int bh_encoder_output_shape(const bh_encoder_t* enc, int L, int* T, i
     if (C) *C = c;
     if (stride) {
         int s = 1;
-        for (const auto& l : enc->layers)
+        for (const auto& l : enc->layers) {
             if (l.d.kind == BH_LAYER_CONV) s *= l.d.stride;
+            else if (l.d.kind == BH_LAYER_UPSAMPLE && l.d.scale_factor > 0) s /= l.d.scale_factor;
+        }
         *stride = s;
     }
     return 0;
@@ -490,6 +559,49 @@ extern "C" int bh_encoder_forward(bh_encoder_t* e, const void* signal, int N, in
                 C = d.out_size;
                 break;
             }
+            case BH_LAYER_TRANSFORMER: {
+                BH_REQUIRE(lay == L_NLC, "encoder_forward: transformer layer needs [N][T][D] input");
+                BH_REQUIRE(C == d.in_size, "encoder_forward: layer %zu expects d_model %d, got %d", i, d.in_size, C);
+                BH_REQUIRE(len <= e->rot_len, "encoder_forward: %d tokens exceed the rotary table (%d)", len, e->rot_len);
+                const int D = d.in_size, F = d.dim_ff;
+                const int M = N * len;            // batch-major: padded chunks sit behind the valid rows
+                const float eps = d.eps > 0.0f ? d.eps : 1e-5f;
+                int rc;
+                {
+                    ProfSpan span(e, st, BH_PROF_ATTENTION);
+                    rc = bh_k_linear(cur, l.w0.p, (const float*)l.b0.p, e->t_qkv.p, M, 3 * D, D, D, D, 3 * D, bh::ACT_NONE,
+                                     1.0f, -INFINITY, INFINITY, 0, 0, 0, 0, 0, st);
+                    if (!rc) rc = bh_k_attention(e->t_qkv.p, e->t_a.p, (const float*)e->rot.p, N, len, d.nhead, D / d.nhead,
+                                                 d.win_left, d.win_right, st);
+                    if (!rc) rc = bh_k_linear(e->t_a.p, l.w1.p, (const float*)l.b1.p, e->t_b.p, M, D, D, D, D, D, bh::ACT_NONE,
+                                              1.0f, -INFINITY, INFINITY, 0, 0, 0, 0, 0, st);
+                    if (!rc) rc = bh_k_rmsnorm_residual(e->t_b.p, cur, (const float*)l.w4.p, e->t_a.p, M, D, d.alpha, eps, st);
+                    if (rc) return rc;
+                }
+                void* dst = e->act[which].p;
+                {
+                    ProfSpan span(e, st, BH_PROF_MLP);
+                    rc = bh_k_linear(e->t_a.p, l.w2.p, nullptr, e->t_mid.p, M, 2 * F, D, D, D, F, bh::ACT_NONE, 1.0f,
+                                     -INFINITY, INFINITY, 1, 0, 0, 0, 0, st);
+                    if (!rc) rc = bh_k_linear(e->t_mid.p, l.w3.p, nullptr, e->t_b.p, M, D, F, F, F, D, bh::ACT_NONE, 1.0f,
+                                              -INFINITY, INFINITY, 0, 0, 0, 0, 0, st);
+                    if (!rc) rc = bh_k_rmsnorm_residual(e->t_b.p, e->t_a.p, (const float*)l.w5.p, dst, M, D, d.alpha, eps, st);
+                    if (rc) return rc;
+                }
+                cur = dst; which ^= 1;
+                break;
+            }
+            case BH_LAYER_UPSAMPLE: {
+                BH_REQUIRE(lay == L_NLC && C == d.in_size, "encoder_forward: upsample needs [N][T][%d] input", d.in_size);
+                const int D = d.in_size, sf = d.scale_factor;
+                void* dst = e->act[which].p;
+                ProfSpan span(e, st, BH_PROF_OTHER);
+                int rc = bh_k_linear(cur, l.w0.p, (const float*)l.b0.p, dst, N * len, sf * D, D, D, D, sf * D, bh::ACT_NONE,
+                                     1.0f, -INFINITY, INFINITY, 0, 0, 0, 0, 0, st);
+                if (rc) return rc;
+                cur = dst; which ^= 1; len *= sf;     // [N][T][s*D] viewed as [N][s*T][D]
+                break;
+            }
             default:
                 BH_REQUIRE(false, "encoder_forward: unsupported layer kind %d", d.kind);
         }
@@ -554,6 +666,29 @@ extern "C" int bh_conv1d(const void* in, const void* wpacked, const float* bias,
     BH_REQUIRE(lout > 0, "conv1d: input too short");
     return bh_k_conv_igemm(in, wpacked, bias, out, N, Lin, lout, Cin, Cout, K, stride, pad, act, clamp_lo, clamp_hi,
                            os_n, os_t, (hipStream_t)stream);
+}
+// cos/sin of position * 10000^(-2i/dim), interleaved [T][dim/2][2], fp32 products like flash_attn's rotary
+extern "C" int bh_rotary_table(int T, int dim, float* out) {
+    BH_REQUIRE(out && T > 0 && dim > 0 && dim % 2 == 0, "rotary_table: bad arguments");
+    const int half = dim / 2;
+    for (int t = 0; t < T; ++t)
+        for (int i = 0; i < half; ++i) {
+            const float inv = 1.0f / powf(10000.0f, (float)(2 * i) / (float)dim);
+            const float ang = (float)t * inv;
+            out[((size_t)t * half + i) * 2] = cosf(ang);
+            out[((size_t)t * half + i) * 2 + 1] = sinf(ang);
+        }
+    return 0;
+}
+extern "C" int bh_attention(const void* qkv, void* out, const float* cos_sin, int N, int T, int nhead, int head_dim,
+                            int win_left, int win_right, void* stream) {
+    BH_REQUIRE(qkv && out && cos_sin, "attention: null pointer");
+    return bh_k_attention(qkv, out, cos_sin, N, T, nhead, head_dim, win_left, win_right, (hipStream_t)stream);
+}
+extern "C" int bh_rmsnorm_residual(const void* a, const void* x, const float* w, void* out, long M, int D, float alpha,
+                                   float eps, void* stream) {
+    BH_REQUIRE(a && x && w && out && M > 0, "rmsnorm_residual: bad arguments");
+    return bh_k_rmsnorm_residual(a, x, w, out, M, D, alpha, eps, (hipStream_t)stream);
 }
 extern "C" size_t bh_lstm_workspace(int N, int H) { return bh_k_lstm_ws_bytes(N, H); }
 extern "C" int bh_lstm_layer(const void* gates_in, const void* whh_packed, void* h_out, int T, int N, int H,

@@ -36,3 +36,9 @@ size_t bh_k_beam_workspace(int N, int T, int state_len);
 int bh_k_beam_search(const void* scores, int N, int T, int state_len, int beam_width, float beam_cut,
                      float blank, float q_scale, float q_offset, void* workspace, int8_t* sequence,
                      int8_t* qstring, int8_t* moves, float* qfloat, hipStream_t stream);
+
+// attention.hip
+int bh_k_attention(const void* qkv, void* out, const float* cos_sin, int N, int T, int nhead, int head_dim,
+                   int win_left, int win_right, hipStream_t stream);
+int bh_k_rmsnorm_residual(const void* a, const void* x, const float* w, void* out, long M, int D, float alpha,
+                          float eps, hipStream_t stream);

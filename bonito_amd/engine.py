@@ -111,6 +111,21 @@ def lower(encoder):
                     activation=_act_id(m.activation), scale=float(m.scale) if m.scale is not None else 0.0,
                     blank_score=float(m.blank_score) if m.blank_score is not None else 0.0,
                     w0=_f32(lin.weight), b0=_f32(lin.bias) if lin.bias is not None else 0)
+        elif type(m).__name__ == "TransformerEncoderLayer":
+            att, kw = m.self_attn, m.kwargs
+            win = tuple(att.attn_window)
+            if win[0] < 0 or win[1] < 0:
+                raise LoweringError("the HIP attention kernel needs a finite attn_window")
+            low.add(kind=_lib.BH_LAYER_TRANSFORMER, in_size=kw["d_model"], nhead=kw["nhead"], dim_ff=kw["dim_feedforward"],
+                    win_left=int(win[0]), win_right=int(win[1]), alpha=float(m.deepnorm_alpha), eps=float(m.norm1.eps),
+                    w0=_f32(att.Wqkv.weight), b0=_f32(att.Wqkv.bias) if att.Wqkv.bias is not None else 0,
+                    w1=_f32(att.out_proj.weight), b1=_f32(att.out_proj.bias) if att.out_proj.bias is not None else 0,
+                    w2=_f32(m.ff.fc1.weight), w3=_f32(m.ff.fc2.weight), w4=_f32(m.norm1.weight), w5=_f32(m.norm2.weight))
+        elif isinstance(m, bnn.LinearUpsample):
+            if not m.batch_first:
+                raise LoweringError("linearupsample with batch_first=False is not lowered")
+            low.add(kind=_lib.BH_LAYER_UPSAMPLE, in_size=m.d_model, scale_factor=m.scale_factor,
+                    w0=_f32(m.linear.weight), b0=_f32(m.linear.bias))
         elif isinstance(m, bnn.Clamp):
             low.add(kind=_lib.BH_LAYER_CLAMP, clamp_lo=float(m.min), clamp_hi=float(m.max))
         else:

@@ -34,6 +34,66 @@ def lstm_crf_encoder_config(features, state_len, conv3_activation="tanh", n_lstm
     return {"type": "serial", "sublayers": subs}
 
 
+def transformer_model_config(d_model=512, nhead=8, dim_ff=2048, depth=18, window=(127, 128), state_len=5,
+                             conv_channels=(64, 64, 128, 128), batchsize=256, chunksize=12000, overlap=600):
+    """The v5 `sup` architecture (layout of bonito/models/configs/dna_r10.4.1@v5.0.toml): conv x5 (strides
+    1,1,3,2,2) -> `depth` DeepNorm transformer layers (rotary, sliding window) -> x2 linear upsample -> CRF head."""
+    from bonito_amd.transformer.model import deepnorm_params
+    alpha, beta = deepnorm_params(depth)
+    c1, c2, c3, c4 = conv_channels
+    convs = [_conv(1, c1, 5), _conv(c1, c2, 5), _conv(c2, c3, 9, stride=3), _conv(c3, c4, 9, stride=2),
+             _conv(c4, d_model, 5, stride=2), {"type": "permute", "dims": [0, 2, 1]}]
+    return {
+        "model": {
+            "type": "seqdistmodel", "package": "bonito_amd.transformer",
+            "seqdist": {"state_len": state_len, "alphabet": ["N", "A", "C", "G", "T"]},
+            "encoder": {
+                "type": "namedserial",
+                "conv": {"type": "serial", "sublayers": convs},
+                "transformer_encoder": {"type": "stack", "depth": depth, "layer": {
+                    "type": "transformerencoderlayer", "d_model": d_model, "nhead": nhead, "dim_feedforward": dim_ff,
+                    "deepnorm_alpha": alpha, "deepnorm_beta": beta, "attn_window": list(window)}},
+                "upsample": {"type": "linearupsample", "d_model": d_model, "scale_factor": 2},
+                "crf": {"type": "linearcrfencoder", "insize": d_model, "n_base": 4, "state_len": state_len,
+                        "bias": False, "scale": 5.0, "blank_score": 2.0, "expand_blanks": True, "permute": [1, 0, 2]},
+            },
+        },
+        "basecaller": {"batchsize": batchsize, "chunksize": chunksize, "overlap": overlap},
+    }
+
+
+def make_transformer_model(seed=25, head_gain=1.0, **kw):
+    from bonito_amd.transformer import Model
+    from bonito_amd.nn import LinearCRFEncoder
+    torch.manual_seed(seed)
+    model = Model(transformer_model_config(**kw))
+    randomise_batchnorm_(model, seed + 1)
+    with torch.no_grad():
+        for m in model.modules():
+            if isinstance(m, LinearCRFEncoder):
+                m.linear.weight.mul_(head_gain)
+    model.eval()
+    return model
+
+
+def transformer_flops_per_chunk(d_model=512, dim_ff=2048, depth=18, window=(127, 128), state_len=5, chunksize=12000,
+                                conv_channels=(64, 64, 128, 128)):
+    """Algorithmic FLOPs of one chunk: convs + depth x (QKV, windowed QK^T + PV, out, fc1, fc2) + upsample + CRF."""
+    L = chunksize
+    c1, c2, c3, c4 = conv_channels
+    l3 = (L + 8 - 9) // 3 + 1
+    l4 = (l3 + 8 - 9) // 2 + 1
+    T = (l4 + 4 - 5) // 2 + 1
+    D, F, W = d_model, dim_ff, window[0] + window[1] + 1
+    conv = 2 * (c1 * 5 * L + c1 * c2 * 5 * L + c2 * c3 * 9 * l3 + c3 * c4 * 9 * l4 + c4 * D * 5 * T)
+    attn = 2 * T * D * 3 * D + 2 * 2 * T * W * D + 2 * T * D * D
+    mlp = 2 * T * D * 2 * F + 2 * T * F * D
+    parts = {"conv": conv, "attention": depth * attn, "mlp": depth * mlp, "other": 2 * T * D * 2 * D,
+             "crf_linear": 2 * (2 * T) * D * 4 ** (state_len + 1)}
+    parts["total"] = sum(parts.values())
+    return parts
+
+
 def model_config(name, batchsize=512, chunksize=10000, overlap=500):
     features, state_len = LSTM_MODELS[name]
     return {

@@ -160,6 +160,17 @@ int bh_conv1d_pack(const float* w, int Cin, int Cout, int K, uint16_t* packed);
 int bh_conv1d(const void* in, const void* wpacked, const float* bias, void* out, int N, int Lin, int Cin,
               int Cout, int K, int stride, int pad, int act, float clamp_lo, float clamp_hi, long os_n,
               long os_t, void* stream);
+/* rotary cos/sin table (host): out[t][i][0..1] = cos, sin(t * 10000^(-2i/dim)), i < dim/2, fp32
+ * (flash_attn.layers.rotary.RotaryEmbedding(dim, interleaved=False), bonito/transformer/model.py:55,73) */
+int bh_rotary_table(int T, int dim, float* out);
+/* rotary + sliding-window attention on packed qkv (flash_attn_qkvpacked_func(qkv, window_size=(l, r)),
+ * bonito/transformer/model.py:58-66): qkv fp16 [N*T][3*nhead*head_dim] -> out fp16 [N*T][nhead*head_dim];
+ * cos_sin = device copy of bh_rotary_table(T, head_dim). head_dim must be 64. */
+int bh_attention(const void* qkv, void* out, const float* cos_sin, int N, int T, int nhead, int head_dim,
+                 int win_left, int win_right, void* stream);
+/* out = rmsnorm(a + alpha * x) * w (fp32 statistics): RMSNorm(x, residual) of bonito/transformer/model.py:110-111,125-128 */
+int bh_rmsnorm_residual(const void* a, const void* x, const float* w, void* out, long M, int D, float alpha,
+                        float eps, void* stream);
 /* recurrent weights: torch W_hh [4H][H] fp32 (host) -> MFMA-fragment order fp16 (host, 4*H*H halves) */
 int bh_lstm_pack_whh(const float* whh, int H, uint16_t* packed);
 /* one LSTM layer over gates_in = x W_ih^T + b (fp16 [T][N][4H], torch gate order); h_out fp16 [T][N][H].

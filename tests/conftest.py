@@ -37,6 +37,26 @@ def load_nn_fixture(name):
     return cfg, sd, torch.from_numpy(z["x"]), torch.from_numpy(z["y"])
 
 
+def load_tf_fixture(name):
+    """-> (full config dict, state_dict, x, y) from tests/golden/tf_<name>.npz (reference transformer run)."""
+    import torch
+    z = np.load(os.path.join(GOLDEN, "tf_%s.npz" % name))
+    cfg = json.loads(str(z["config"]))
+    sd = {k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("sd/")}
+    return cfg, sd, torch.from_numpy(z["x"]), torch.from_numpy(z["y"])
+
+
+TF_FIXTURES = ["d128_w31_32", "d64_w127_128"]
+
+
+def build_tf_model(cfg, sd):
+    from bonito_amd.transformer import Model
+    model = Model(cfg)
+    model.load_state_dict(sd)
+    model.eval()
+    return model
+
+
 NN_FIXTURES = ["lstm32_sl2", "lstm64_sl3", "lstm96_sl3", "lstm32_clampconv", "lstm32_oldstyle"]
 
 

@@ -155,7 +155,130 @@ def make_util_fixture(util):
     print("util_cases.json: %d chunk/stitch cases, %d batches" % (len(cases), len(batches)))
 
 
+def ref_transformer():
+    """Import the reference's bonito.transformer.model without its un-installable dependencies.
+
+    * a bare `bonito` package object (its real __init__ imports every CLI -> mappy/pysam) with the right
+      __path__, so `bonito.nn`, `bonito.crf.model`, `bonito.transformer.model` are the REAL files;
+    * inert stubs for koi / toml / parasail (only names are needed at import time);
+    * flash_attn stubs that implement the PUBLIC semantics the builder assumed (SURVEY.md appendix C,
+      [EXT], parity unpinned): RotaryEmbedding(dim, interleaved=False), GatedMlp, RMSNorm(x, residual);
+    * torch.cuda.get_device_capability patched so MultiHeadAttention.attn_func takes its in-tree SDPA +
+      sliding_window_mask branch (transformer/model.py:62-65), which defines the attention semantics.
+    """
+    import math
+    pkg = types.ModuleType("bonito")
+    pkg.__path__ = [os.path.join(REF, "bonito")]
+    sys.modules["bonito"] = pkg
+    for name in ("toml", "parasail", "koi", "koi.lstm", "koi.ctc", "koi.decode", "flash_attn", "flash_attn.layers",
+                 "flash_attn.layers.rotary", "flash_attn.modules", "flash_attn.modules.mlp", "flash_attn.ops",
+                 "flash_attn.ops.triton", "flash_attn.ops.triton.layer_norm"):
+        sys.modules.setdefault(name, types.ModuleType(name))
+    kc = sys.modules["koi.ctc"]
+    kc.SequenceDist = type("SequenceDist", (), {"__init__": lambda self: None})
+    for n in ("Max", "Log", "semiring", "logZ_cu", "viterbi_alignments", "logZ_cu_sparse", "bwd_scores_cu_sparse",
+              "fwd_scores_cu_sparse"):
+        setattr(kc, n, object)
+    sys.modules["koi.decode"].beam_search = None
+    sys.modules["koi.decode"].to_str = None
+
+    class RotaryEmbedding(torch.nn.Module):
+        def __init__(self, dim, interleaved=False):
+            super().__init__()
+            assert not interleaved
+            self.dim = dim
+            self.register_buffer("inv_freq", 1.0 / (10000 ** (torch.arange(0, dim, 2).float() / dim)), persistent=False)
+
+        def forward(self, qkv):
+            N, T, _, h, d = qkv.shape
+            ang = torch.outer(torch.arange(T, dtype=torch.float32), self.inv_freq)
+            cos, sin = ang.cos()[None, :, None, :], ang.sin()[None, :, None, :]
+            out = qkv.clone()
+            half = d // 2
+            for i in (0, 1):
+                x1, x2 = qkv[:, :, i, :, :half], qkv[:, :, i, :, half:]
+                out[:, :, i, :, :half] = x1 * cos - x2 * sin
+                out[:, :, i, :, half:] = x1 * sin + x2 * cos
+            return out
+
+    class GatedMlp(torch.nn.Module):
+        def __init__(self, in_features, hidden_features=None, activation=None, bias1=True, bias2=True, multiple_of=1):
+            super().__init__()
+            self.activation = activation
+            self.fc1 = torch.nn.Linear(in_features, 2 * hidden_features, bias=bias1)
+            self.fc2 = torch.nn.Linear(hidden_features, in_features, bias=bias2)
+
+        def forward(self, x):
+            y, gate = self.fc1(x).chunk(2, dim=-1)
+            return self.fc2(y * self.activation(gate))
+
+    class RMSNorm(torch.nn.Module):
+        def __init__(self, hidden_size, eps=1e-5):
+            super().__init__()
+            self.eps = eps
+            self.weight = torch.nn.Parameter(torch.ones(hidden_size))
+
+        def forward(self, x, residual=None):
+            z = x if residual is None else x + residual
+            return z * torch.rsqrt(z.pow(2).mean(-1, keepdim=True) + self.eps) * self.weight
+
+    sys.modules["flash_attn"].flash_attn_qkvpacked_func = None
+    sys.modules["flash_attn.layers.rotary"].RotaryEmbedding = RotaryEmbedding
+    sys.modules["flash_attn.modules.mlp"].GatedMlp = GatedMlp
+    sys.modules["flash_attn.ops.triton.layer_norm"].RMSNorm = RMSNorm
+    torch.cuda.get_device_capability = lambda *a, **k: (7, 0)
+    import importlib
+    return importlib.import_module("bonito.transformer.model")
+
+
+def make_transformer_fixture(name, d_model, nhead, dim_ff, depth, window, state_len, N, L, seed=25):
+    tm = ref_transformer()
+    alpha, beta = tm.deepnorm_params(depth)
+    convs = [conv(1, 16, 5), conv(16, 16, 5), conv(16, 32, 9, stride=3), conv(32, 32, 9, stride=2),
+             conv(32, d_model, 5, stride=2), {"type": "permute", "dims": [0, 2, 1]}]
+    cfg = {"model": {
+        "type": "seqdistmodel", "package": "bonito.transformer",
+        "seqdist": {"state_len": state_len, "alphabet": ["N", "A", "C", "G", "T"]},
+        "encoder": {
+            "type": "namedserial",
+            "conv": {"type": "serial", "sublayers": convs},
+            "transformer_encoder": {"type": "stack", "depth": depth, "layer": {
+                "type": "transformerencoderlayer", "d_model": d_model, "nhead": nhead, "dim_feedforward": dim_ff,
+                "deepnorm_alpha": alpha, "deepnorm_beta": beta, "attn_window": list(window)}},
+            "upsample": {"type": "linearupsample", "d_model": d_model, "scale_factor": 2},
+            "crf": {"type": "linearcrfencoder", "insize": d_model, "n_base": 4, "state_len": state_len, "bias": False,
+                    "scale": 5.0, "blank_score": 2.0, "expand_blanks": True, "permute": [1, 0, 2]},
+        }}}
+    torch.manual_seed(seed)
+    model = tm.Model(cfg)
+    gen = torch.Generator().manual_seed(seed + 1)
+    randomise_bn_(model, gen)
+    with torch.no_grad():
+        for m in model.modules():       # non-trivial norm gains
+            if type(m).__name__ == "RMSNorm":
+                m.weight.copy_(1.0 + 0.1 * torch.randn(m.weight.shape, generator=gen))
+    model.eval()
+    nn_ref.round_params_to_half_(model)
+    x = torch.randn(N, 1, L, generator=gen).half().float()
+    with torch.no_grad():
+        y = model(x)
+        y_oracle = nn_ref.forward(model.encoder, x)
+    err = (y - y_oracle).abs().max().item()
+    assert err < 5e-4, "oracle/nn_ref.py disagrees with the reference transformer on %s: %g" % (name, err)
+    out = {"config": np.array(json.dumps(cfg)), "x": x.numpy(), "y": y.numpy()}
+    for k, v in model.state_dict().items():
+        out["sd/" + k] = v.numpy()
+    path = os.path.join(HERE, "tf_%s.npz" % name)
+    np.savez_compressed(path, **out)
+    print("%-28s y%s  oracle-vs-reference max|d| = %.2e  -> %s (%d KiB)" %
+          (name, tuple(y.shape), err, os.path.basename(path), os.path.getsize(path) // 1024))
+
+
 def main():
+    if "--transformer-only" in sys.argv:
+        make_transformer_fixture("d128_w31_32", 128, 2, 256, 2, (31, 32), 3, N=2, L=1200)
+        make_transformer_fixture("d64_w127_128", 64, 1, 128, 1, (127, 128), 2, N=2, L=2400)
+        return
     nn = ref_nn()
     # v4.3-style (tanh conv3, fixed blank, clamp +-5) at toy width; alternating directions 1,0,1
     make_nn_fixture(nn, "lstm32_sl2", lstm_crf_config(4, 16, 32, 3, 2), N=3, L=600)
@@ -170,6 +293,8 @@ def main():
     make_nn_fixture(nn, "lstm32_oldstyle", lstm_crf_config(4, 16, 32, 2, 2, conv3_act="swish", blank_score=None,
                                                             clamp=None, scale=5.0, crf_act="tanh"), N=2, L=480)
     make_util_fixture(ref_util())
+    make_transformer_fixture("d128_w31_32", 128, 2, 256, 2, (31, 32), 3, N=2, L=1200)
+    make_transformer_fixture("d64_w127_128", 64, 1, 128, 1, (127, 128), 2, N=2, L=2400)
 
 
 if __name__ == "__main__":

@@ -86,3 +86,24 @@ def test_engine_fails_loudly_on_unsupported_layers():
     from bonito_amd.engine import LoweringError
     with pytest.raises(LoweringError):
         HipEncoder(bnn.Serial([bnn.Linear(8, 8)]), 1, 100)
+
+
+# ---- transformer encoder ----------------------------------------------------------------------------
+from conftest import TF_FIXTURES, build_tf_model, load_tf_fixture  # noqa: E402
+
+
+@pytest.mark.parametrize("name", TF_FIXTURES)
+def test_transformer_encoder_matches_reference_fixture(name):
+    cfg, sd, x, y = load_tf_fixture(name)
+    model = build_tf_model(cfg, sd)
+    model.use_koi(batchsize=x.shape[0], chunksize=x.shape[-1], quantize=False)
+    model = model.half().to("cuda")
+    got = model(x.half().cuda()).cpu().float()
+    model._hip.check()
+    want = ref_scores_to_koi(y)
+    assert got.shape == want.shape
+    d = (got - want).abs()
+    # scores are scaled by 5 with no squashing: tolerance relative to their range
+    rng = want.abs().max().item()
+    assert d.max().item() < 2e-2 * max(rng, 1.0) and d.mean().item() < 3e-3 * max(rng, 1.0), (d.max().item(), d.mean().item(), rng)
+    assert model.stride == 6

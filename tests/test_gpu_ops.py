@@ -212,3 +212,57 @@ def test_lstm_layer_is_deterministic_and_restartable():
         torch.cuda.synchronize()
         outs.append(h.cpu())
     assert err.item() == 0 and torch.equal(outs[0], outs[1])
+
+
+# ---- transformer operators -------------------------------------------------------------------------
+def _rot_table(T, dim=64):
+    lib = _lib.lib()
+    tab = np.zeros((T, dim // 2, 2), np.float32)
+    _lib.check(lib.bh_rotary_table(T, dim, tab.ctypes.data_as(C.c_void_p)), "rotary_table")
+    return torch.from_numpy(tab)
+
+
+@pytest.mark.parametrize("T,H,win", [(100, 2, (31, 32)), (1000, 8, (127, 128)), (333, 1, (5, 0)), (130, 2, (0, 7)),
+                                     (64, 1, (200, 200))])
+def test_attention_matches_sdpa_restatement(T, H, win):
+    from oracle import nn_ref
+    g = torch.Generator().manual_seed(T + H)
+    N, D = 2, 64 * H
+    qkv = (torch.randn(N, T, 3, H, 64, generator=g) * 0.8).half()
+    want_qkv = nn_ref.rotary(qkv.float())
+    q, k, v = (want_qkv[:, :, i].permute(0, 2, 1, 3) for i in range(3))
+    s = (q @ k.transpose(-1, -2)) / 8.0
+    s = s.masked_fill(~nn_ref.window_mask(T, win), float("-inf"))
+    want = (torch.softmax(s, -1) @ v).permute(0, 2, 1, 3).reshape(N, T, D)
+    tab = _rot_table(T).to(dev())
+    qd = qkv.reshape(N * T, 3 * D).contiguous().to(dev())
+    out = torch.zeros((N * T, D), dtype=torch.float16, device=dev())
+    _lib.check(_lib.lib().bh_attention(_lib.ptr(qd), _lib.ptr(out), _lib.ptr(tab), N, T, H, 64, win[0], win[1],
+                                       _lib.stream_ptr()), "attention")
+    torch.cuda.synchronize()
+    d = (out.cpu().float().view(N, T, D) - want).abs()
+    assert d.max().item() < 8e-3, d.max().item()
+
+
+def test_rotary_table_matches_flash_attn_convention():
+    tab = _rot_table(50)
+    inv = 1.0 / (10000 ** (torch.arange(0, 64, 2).float() / 64))
+    ang = torch.outer(torch.arange(50, dtype=torch.float32), inv)
+    assert (tab[..., 0] - ang.cos()).abs().max() < 1e-5 and (tab[..., 1] - ang.sin()).abs().max() < 1e-5
+
+
+@pytest.mark.parametrize("M,D", [(1000, 512), (7, 128), (300, 1024), (5, 64)])
+def test_rmsnorm_residual(M, D):
+    g = torch.Generator().manual_seed(M)
+    a = torch.randn(M, D, generator=g).half()
+    x = torch.randn(M, D, generator=g).half()
+    w = 1 + 0.1 * torch.randn(D, generator=g)
+    alpha = 2.4494897
+    z = a.float() + alpha * x.float()
+    want = z * torch.rsqrt(z.pow(2).mean(-1, keepdim=True) + 1e-5) * w
+    ad, xd, wd = a.to(dev()), x.to(dev()), w.to(dev())
+    out = torch.zeros((M, D), dtype=torch.float16, device=dev())
+    _lib.check(_lib.lib().bh_rmsnorm_residual(_lib.ptr(ad), _lib.ptr(xd), _lib.ptr(wd), _lib.ptr(out), M, D, alpha, 1e-5,
+                                              _lib.stream_ptr()), "rmsnorm")
+    torch.cuda.synchronize()
+    assert (out.cpu().float() - want).abs().max().item() < 4e-3
