@@ -22,7 +22,7 @@ class bh_layer_t(C.Structure):
         ("winlen", C.c_int32), ("stride", C.c_int32), ("padding", C.c_int32),
         ("activation", C.c_int32), ("reverse", C.c_int32),
         ("nhead", C.c_int32), ("dim_ff", C.c_int32), ("win_left", C.c_int32), ("win_right", C.c_int32),
-        ("scale_factor", C.c_int32), ("groups", C.c_int32), ("reserved_i", C.c_int32 * 3),
+        ("scale_factor", C.c_int32), ("groups", C.c_int32), ("add_residual", C.c_int32), ("reserved_i", C.c_int32 * 2),
         ("scale", C.c_float), ("clamp_lo", C.c_float), ("clamp_hi", C.c_float),
         ("blank_score", C.c_float), ("alpha", C.c_float), ("eps", C.c_float), ("reserved_f", C.c_float * 2),
         ("w0", C.c_void_p), ("b0", C.c_void_p), ("w1", C.c_void_p), ("b1", C.c_void_p),
@@ -33,6 +33,7 @@ class bh_layer_t(C.Structure):
 BH_ACT = {None: 0, "none": 0, "swish": 1, "tanh": 2, "relu": 3}
 BH_LAYER_CONV, BH_LAYER_LSTM, BH_LAYER_LINEAR_CRF, BH_LAYER_CLAMP = 1, 2, 3, 4
 BH_LAYER_TRANSFORMER, BH_LAYER_UPSAMPLE, BH_LAYER_TCS_BLOCK, BH_LAYER_CTC_DECODER = 5, 6, 7, 8
+BH_LAYER_DWCONV, BH_LAYER_RESIDUAL_PROJ = 9, 10
 
 _vp, _i, _f, _l, _sz = C.c_void_p, C.c_int, C.c_float, C.c_long, C.c_size_t
 
@@ -59,6 +60,8 @@ SIGNATURES = {
     "bh_conv1d_packed_halves": (_sz, [_i, _i, _i]),
     "bh_conv1d_pack": (_i, [_vp, _i, _i, _i, _vp]),
     "bh_conv1d": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _f, _f, _l, _l, _vp]),
+    "bh_ctc_greedy_decode": (_i, [_vp, _vp, _i, _i, _f, _f, _vp, _vp, _vp, _vp, _vp]),
+    "bh_dwconv1d": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "bh_rotary_table": (_i, [_i, _i, _vp]),
     "bh_attention": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "bh_rmsnorm_residual": (_i, [_vp, _vp, _vp, _vp, _l, _i, _f, _f, _vp]),

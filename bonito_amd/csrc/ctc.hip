@@ -1,0 +1,222 @@
+// Kernels specific to the QuartzNet CTC models (legacy dna_r9.4.1 `bonito.ctc`, /root/reference
+// bonito/ctc/model.py): depthwise time-channel-separable convolution (TCSConv1d.depthwise, :99-103),
+// the 1x1 decoder convolution + log_softmax (Decoder, :195-207), and the CTC decoders that replace the
+// fast_ctc_decode Rust crate (:39-46).
+#include "common.h"
+#include "kernels.h"
+
+namespace bh {
+
+// ---- depthwise conv, channel-minor: out[n][t][c] = sum_k w[c][k] * in[n][t*stride + k - pad][c] ----
+struct DwArgs {
+    const half_t* in;
+    const float* w;   // [C][K]
+    half_t* out;
+    int N, Lin, Lout, C, K, stride, pad;
+};
+
+constexpr int DW_T = 64;   // output steps per workgroup
+constexpr int DW_C = 64;   // channels per workgroup
+
+__global__ __launch_bounds__(256) void dwconv_kernel(DwArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int span = (DW_T - 1) * p.stride + p.K;
+    half_t* xs = (half_t*)smem;                         // [span][DW_C]
+    float* ws = (float*)(xs + (size_t)span * DW_C);     // [K][DW_C]  (tap-major: lanes read consecutive channels)
+    const int n = blockIdx.z, c0 = blockIdx.y * DW_C, t0 = blockIdx.x * DW_T;
+    const int tid = threadIdx.x;
+    const int p0 = t0 * p.stride - p.pad;
+    const half_t* src = p.in + (long)n * p.Lin * p.C;
+    for (int i = tid; i < span * (DW_C / 8); i += 256) {
+        const int r = i / (DW_C / 8), cc = (i % (DW_C / 8)) * 8;
+        const int pos = p0 + r;
+        uint4_t v = {0, 0, 0, 0};
+        if (pos >= 0 && pos < p.Lin && c0 + cc < p.C) v = *(const uint4_t*)(src + (long)pos * p.C + c0 + cc);
+        *(uint4_t*)(xs + r * DW_C + cc) = v;
+    }
+    for (int i = tid; i < p.K * DW_C; i += 256) {
+        const int k = i / DW_C, c = i % DW_C;
+        ws[i] = (c0 + c < p.C) ? p.w[(long)(c0 + c) * p.K + k] : 0.0f;
+    }
+    __syncthreads();
+    // thread -> (8 channels, 2 output steps)
+    const int cc = (tid & 7) * 8;
+    for (int tt = tid >> 3; tt < DW_T; tt += 32) {
+        const int t = t0 + tt;
+        if (t >= p.Lout || c0 + cc >= p.C) continue;
+        float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        const half_t* xr = xs + tt * p.stride * DW_C + cc;
+        for (int k = 0; k < p.K; ++k) {
+            const half8_t xv = *(const half8_t*)(xr + k * DW_C);
+            const float* wk = ws + k * DW_C + cc;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] = fmaf(wk[e], (float)xv[e], acc[e]);
+        }
+        half8_t o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (half_t)acc[e];
+        *(half8_t*)(p.out + ((long)n * p.Lout + t) * p.C + c0 + cc) = o;
+    }
+}
+
+// ---- CTC head: logits = x W^T + b (classes <= 8), log_softmax over classes -> fp16 [M][classes] ----
+struct HeadArgs {
+    const half_t* in;   // [M][F]
+    const float* w;     // [classes][F]
+    const float* b;     // [classes]
+    half_t* out;        // [M][classes]
+    long M;
+    int F, classes;
+};
+
+__global__ __launch_bounds__(256) void ctc_head_kernel(HeadArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* ws = (float*)smem;   // [classes][F]
+    for (int i = threadIdx.x; i < p.classes * p.F; i += 256) ws[i] = p.w[i];
+    __syncthreads();
+    const long m = (long)blockIdx.x * 256 + threadIdx.x;
+    if (m >= p.M) return;
+    float logit[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) logit[c] = (c < p.classes) ? p.b[c] : -INFINITY;
+    const half_t* x = p.in + m * p.F;
+    for (int f = 0; f < p.F; f += 8) {
+        const half8_t xv = *(const half8_t*)(x + f);
+#pragma unroll
+        for (int c = 0; c < 8; ++c)
+            if (c < p.classes) {
+                const float* wc = ws + c * p.F + f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) logit[c] = fmaf(wc[e], (float)xv[e], logit[c]);
+            }
+    }
+    float mx = logit[0];
+#pragma unroll
+    for (int c = 1; c < 8; ++c) mx = fmaxf(mx, logit[c]);
+    float sum = 0.0f;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) sum += (c < p.classes) ? __expf(logit[c] - mx) : 0.0f;
+    const float lse = mx + __logf(sum);
+    for (int c = 0; c < p.classes; ++c) p.out[m * p.classes + c] = (half_t)(logit[c] - lse);
+}
+
+}  // namespace bh
+
+int bh_k_dwconv(const void* in, const float* w, void* out, int N, int Lin, int Lout, int C, int K, int stride,
+                int pad, hipStream_t stream) {
+    using namespace bh;
+    BH_REQUIRE(C % 8 == 0 && K >= 1 && stride >= 1, "dwconv: need C%%8==0 (C=%d K=%d)", C, K);
+    DwArgs a{(const half_t*)in, w, (half_t*)out, N, Lin, Lout, C, K, stride, pad};
+    const size_t lds = (size_t)((DW_T - 1) * stride + K) * DW_C * 2 + (size_t)K * DW_C * 4;
+    BH_REQUIRE(lds <= 160 * 1024, "dwconv: kernel %d x stride %d does not fit LDS", K, stride);
+    if (lds > 64 * 1024)
+        BH_CHECK_HIP(hipFuncSetAttribute((const void*)dwconv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    dim3 grid((Lout + DW_T - 1) / DW_T, (C + DW_C - 1) / DW_C, N);
+    hipLaunchKernelGGL(dwconv_kernel, grid, dim3(256), lds, stream, a);
+    BH_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+int bh_k_ctc_head(const void* in, const float* w, const float* bias, void* out, long M, int features, int classes,
+                  hipStream_t stream) {
+    using namespace bh;
+    BH_REQUIRE(classes >= 1 && classes <= 8 && features % 8 == 0 && features > 0,
+               "ctc_head: need classes<=8 and features%%8==0 (classes=%d features=%d)", classes, features);
+    HeadArgs a{(const half_t*)in, w, bias, (half_t*)out, M, features, classes};
+    const size_t lds = (size_t)classes * features * 4;
+    hipLaunchKernelGGL(ctc_head_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), lds, stream, a);
+    BH_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Greedy CTC decode of R stitched reads in one launch (replaces fast_ctc_decode.viterbi_search,
+// /root/reference bonito/ctc/model.py:39-42): per step argmax label (ties: lowest label), collapse
+// repeats, drop blank (label 0). For every emitted base: path = first step of its run, quality from the
+// MEAN probability of the label over the run:  q = -10 log10(max(1 - p, 1e-4)) * scale + bias,
+// char = 33 + round(q)  (bonito/util.py:105-111 `phred`).  One workgroup per read.
+namespace bh {
+
+struct CtcArgs {
+    const float* logp;     // concatenated [sum T_r][C] log-probabilities
+    const long* offs;      // [R+1] step offsets
+    int R, C;
+    float qscale, qbias;
+    int8_t* seq;           // [sum T_r] label index (1..C-1) per emitted base, compacted per read at offs[r]
+    int8_t* qual;          // [sum T_r] phred char
+    int* path;             // [sum T_r] step index within the read
+    int* count;            // [R] emitted bases
+};
+
+__device__ __forceinline__ int ctc_argmax(const float* row, int C) {
+    int best = 0;
+    float bv = row[0];
+    for (int c = 1; c < C; ++c)
+        if (row[c] > bv) { bv = row[c]; best = c; }
+    return best;
+}
+
+__global__ __launch_bounds__(256) void ctc_greedy_kernel(CtcArgs p) {
+    __shared__ int scan[256];
+    const int r = blockIdx.x, tid = threadIdx.x;
+    const long o0 = p.offs[r];
+    const int T = (int)(p.offs[r + 1] - o0);
+    const float* lp = p.logp + o0 * p.C;
+    const int per = (T + 255) / 256;
+    const int t0 = tid * per, t1 = min(T, t0 + per);
+    // pass 1: count emissions in my segment (a run start: label != 0 and label != previous step's label)
+    int cnt = 0;
+    {
+        int prev = (t0 > 0 && t0 < T) ? ctc_argmax(lp + (long)(t0 - 1) * p.C, p.C) : 0;
+        for (int t = t0; t < t1; ++t) {
+            const int lab = ctc_argmax(lp + (long)t * p.C, p.C);
+            cnt += (lab != 0 && lab != prev);
+            prev = lab;
+        }
+    }
+    scan[tid] = cnt;
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) {     // inclusive Hillis-Steele scan
+        int v = tid >= off ? scan[tid - off] : 0;
+        __syncthreads();
+        scan[tid] += v;
+        __syncthreads();
+    }
+    int pos = scan[tid] - cnt;
+    if (tid == 255) p.count[r] = scan[255];
+    // pass 2: emit
+    int prev = (t0 > 0 && t0 < T) ? ctc_argmax(lp + (long)(t0 - 1) * p.C, p.C) : 0;
+    for (int t = t0; t < t1; ++t) {
+        const int lab = ctc_argmax(lp + (long)t * p.C, p.C);
+        if (lab != 0 && lab != prev) {
+            double sum = 0.0;
+            int n = 0;
+            for (int u = t; u < T; ++u) {            // the run may extend past my segment
+                const float* row = lp + (long)u * p.C;
+                if (ctc_argmax(row, p.C) != lab) break;
+                sum += (double)__expf(row[lab]);
+                ++n;
+            }
+            const float prob = (float)(sum / (double)n);
+            const float e = fmaxf(1.0f - prob, 1e-4f);
+            const float q = -10.0f * log10f(e) * p.qscale + p.qbias;
+            p.seq[o0 + pos] = (int8_t)lab;
+            p.qual[o0 + pos] = (int8_t)((int)rintf(q) + 33);
+            p.path[o0 + pos] = t;
+            ++pos;
+        }
+        prev = lab;
+    }
+}
+
+}  // namespace bh
+
+int bh_k_ctc_greedy(const float* logp, const long* offs, int R, int C, float qscale, float qbias, int8_t* seq,
+                    int8_t* qual, int* path, int* count, hipStream_t stream) {
+    using namespace bh;
+    BH_REQUIRE(R > 0 && C >= 2 && C <= 8, "ctc_greedy: need R > 0 and 2 <= classes <= 8 (R=%d C=%d)", R, C);
+    CtcArgs a{logp, offs, R, C, qscale, qbias, seq, qual, path, count};
+    hipLaunchKernelGGL(ctc_greedy_kernel, dim3(R), dim3(256), 0, stream, a);
+    BH_CHECK_HIP(hipGetLastError());
+    return 0;
+}

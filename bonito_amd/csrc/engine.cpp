@@ -126,6 +126,7 @@ struct Layer {
     // convolutions are padded to a multiple of 8 channels (zero weights / zero bias -> act(0) = 0),
     // so e.g. the old-style 1 -> 4 -> 16 front end (crf/model.py:153-154) still runs on MFMA.
     int cin_eff = 0, cout_eff = 0;
+    bool pointwise = false;     // K=1, stride 1 convolution executed by the GEMM kernel (supports the residual add)
 };
 
 enum Layout { L_SIGNAL, L_NLC, L_TNC };
@@ -149,6 +150,7 @@ struct bh_encoder {
     int n_cus = 0;
     std::vector<Layer> layers;
     DevBuf act[2], gates, sig, err, lstm_ws;
+    DevBuf res;                            // pending residual projection of a QuartzNet block
     DevBuf t_qkv, t_mid, t_a, t_b, rot;   // transformer workspace + rotary cos/sin table [Tmax][32][2]
     int rot_len = 0;
     int out_features = 0;
@@ -164,7 +166,7 @@ struct bh_encoder {
             l.w4.release(); l.w5.release(); l.b0.release(); l.b1.release();
         }
         act[0].release(); act[1].release(); gates.release(); sig.release(); err.release(); lstm_ws.release();
-        t_qkv.release(); t_mid.release(); t_a.release(); t_b.release(); rot.release();
+        res.release(); t_qkv.release(); t_mid.release(); t_a.release(); t_b.release(); rot.release();
     }
 };
 
@@ -207,6 +209,17 @@ static int walk(const bh_encoder* e, int N, int L, int* T_out, int* C_out, size_
                 break;
             case BH_LAYER_TRANSFORMER:
                 amax = std::max(amax, (size_t)N * len * C * 2);
+                break;
+            case BH_LAYER_DWCONV:
+                len = conv_out_len((int)len, l.d.winlen, l.d.stride, l.d.padding);
+                BH_REQUIRE(len > 0, "encoder: chunk of %d samples is too short for the convolution stack", L);
+                amax = std::max(amax, (size_t)N * len * C * 2);
+                break;
+            case BH_LAYER_RESIDUAL_PROJ:
+                amax = std::max(amax, (size_t)N * len * l.d.out_size * 2);   // res buffer uses the same bound
+                break;
+            case BH_LAYER_CTC_DECODER:
+                C = l.d.out_size;
                 break;
             case BH_LAYER_UPSAMPLE:
                 len *= l.d.scale_factor;
@@ -279,7 +292,15 @@ extern "C" int bh_encoder_create(const bh_layer_t* layers, int n_layers, int dev
                 }
                 std::vector<float> bpad((size_t)L.cout_eff, 0.0f);
                 if (d.b0) for (int f = 0; f < d.out_size; ++f) bpad[f] = d.b0[f];
-                if (d.in_size == 1) {
+                L.pointwise = d.in_size != 1 && K == 1 && d.stride == 1 && d.padding == 0 && L.cin_eff == d.in_size &&
+                              d.in_size % 8 == 0 && L.cout_eff == d.out_size && d.out_size % 8 == 0;
+                if (d.add_residual && !L.pointwise) {
+                    bh_set_error("encoder_create: layer %d: only pointwise convolutions can add a residual", i);
+                    return fail(-2);
+                }
+                if (L.pointwise) {
+                    rc = upload_f16(L.w0, d.w0, (size_t)d.out_size * d.in_size);
+                } else if (d.in_size == 1) {
                     std::vector<float> wpad((size_t)L.cout_eff * K, 0.0f);
                     for (int f = 0; f < d.out_size; ++f)
                         for (int k = 0; k < K; ++k) wpad[(size_t)f * K + k] = d.w0[(size_t)f * K + k];
@@ -353,6 +374,43 @@ extern "C" int bh_encoder_create(const bh_layer_t* layers, int n_layers, int dev
                 if (!rc) rc = upload_f32(L.w5, d.w5, D);
                 break;
             }
+            case BH_LAYER_DWCONV: {
+                if (!(d.w0 && d.in_size > 0 && d.in_size % 8 == 0 && d.winlen > 0 && d.stride > 0) || cur_channels != d.in_size ||
+                    cur_channels_eff != d.in_size) {
+                    bh_set_error("encoder_create: layer %d: depthwise conv needs %d (multiple of 8) input channels, chain provides %d", i, d.in_size, cur_channels);
+                    return fail(-2);
+                }
+                rc = upload_f32(L.w0, d.w0, (size_t)d.in_size * d.winlen);
+                break;
+            }
+            case BH_LAYER_RESIDUAL_PROJ: {
+                if (!(d.w0 && d.in_size % 8 == 0 && d.out_size % 8 == 0 && d.in_size > 0 && d.out_size > 0) ||
+                    cur_channels != d.in_size || cur_channels_eff != d.in_size) {
+                    bh_set_error("encoder_create: layer %d: residual projection shape mismatch", i);
+                    return fail(-2);
+                }
+                rc = upload_f16(L.w0, d.w0, (size_t)d.out_size * d.in_size);
+                if (!rc) {
+                    std::vector<float> b((size_t)d.out_size, 0.0f);
+                    if (d.b0) memcpy(b.data(), d.b0, sizeof(float) * d.out_size);
+                    rc = upload_f32(L.b0, b.data(), b.size());
+                }
+                break;
+            }
+            case BH_LAYER_CTC_DECODER: {
+                if (!(d.w0 && d.in_size % 8 == 0 && d.out_size >= 1 && d.out_size <= 8) || cur_channels != d.in_size) {
+                    bh_set_error("encoder_create: layer %d: ctc decoder needs features %% 8 == 0 and <= 8 classes", i);
+                    return fail(-2);
+                }
+                rc = upload_f32(L.w0, d.w0, (size_t)d.out_size * d.in_size);
+                if (!rc) {
+                    std::vector<float> b((size_t)d.out_size, 0.0f);
+                    if (d.b0) memcpy(b.data(), d.b0, sizeof(float) * d.out_size);
+                    rc = upload_f32(L.b0, b.data(), b.size());
+                }
+                e->out_features = d.out_size;
+                break;
+            }
             case BH_LAYER_UPSAMPLE: {
                 const int D = d.in_size, sf = d.scale_factor;
                 if (!(d.w0 && D > 0 && sf > 0 && D % 8 == 0)) { bh_set_error("encoder_create: layer %d: malformed upsample", i); return fail(-2); }
@@ -379,16 +437,19 @@ extern "C" int bh_encoder_create(const bh_layer_t* layers, int n_layers, int dev
         if (rc) return fail(rc);
         L.d.w0 = L.d.w1 = L.d.w2 = L.d.w3 = L.d.w4 = L.d.w5 = L.d.b0 = L.d.b1 = nullptr;
     }
-    if (e->layers.back().d.kind != BH_LAYER_LINEAR_CRF &&
+    if (e->layers.back().d.kind != BH_LAYER_LINEAR_CRF && e->layers.back().d.kind != BH_LAYER_CTC_DECODER &&
         !(n_layers >= 2 && e->layers.back().d.kind == BH_LAYER_CLAMP &&
           e->layers[n_layers - 2].d.kind == BH_LAYER_LINEAR_CRF)) {
-        bh_set_error("encoder_create: the chain must end in a linearcrfencoder (optionally followed by clamp)");
+        bh_set_error("encoder_create: the chain must end in a linearcrfencoder (optionally followed by clamp) or a ctc decoder");
         return fail(-2);
     }
     int T = 0, C = 0;
     size_t ab = 0, gb = 0;
     const int Np = pad16(max_batch);
     if (walk(e, Np, max_chunk, &T, &C, &ab, &gb)) return fail(-2);
+    bool has_res = false;
+    for (const auto& l : e->layers) has_res |= l.d.kind == BH_LAYER_RESIDUAL_PROJ;
+    if (has_res && e->res.alloc(ab + 256)) return fail(-1);
     if (e->act[0].alloc(ab + 256) || e->act[1].alloc(ab + 256) || e->gates.alloc(gb + 256) ||
         e->sig.alloc((size_t)Np * max_chunk * 2) || e->err.alloc(sizeof(int)) || e->lstm_ws.alloc(bh_k_lstm_ws_bytes(Np, 512)))
         return fail(-1);
@@ -445,7 +506,7 @@ extern "C" int bh_encoder_output_shape(const bh_encoder_t* enc, int L, int* T, i
     if (stride) {
         int s = 1;
         for (const auto& l : enc->layers) {
-            if (l.d.kind == BH_LAYER_CONV) s *= l.d.stride;
+            if (l.d.kind == BH_LAYER_CONV || l.d.kind == BH_LAYER_DWCONV) s *= l.d.stride;
             else if (l.d.kind == BH_LAYER_UPSAMPLE && l.d.scale_factor > 0) s /= l.d.scale_factor;
         }
         *stride = s;
@@ -474,6 +535,7 @@ extern "C" int bh_encoder_forward(bh_encoder_t* e, const void* signal, int N, in
     const void* cur = e->sig.p;
     Layout lay = L_SIGNAL;
     int len = L, C = 1, which = 0;
+    bool res_ready = false;
     const size_t nl = e->layers.size();
     for (size_t i = 0; i < nl; ++i) {
         Layer& l = e->layers[i];
@@ -496,7 +558,13 @@ extern "C" int bh_encoder_forward(bh_encoder_t* e, const void* signal, int N, in
                 const long os_t = tnc ? (long)Np * co : co;
                 int rc;
                 ProfSpan span(e, st, BH_PROF_CONV);
-                if (lay == L_SIGNAL)
+                if (l.pointwise && !tnc) {
+                    const void* rsd = d.add_residual ? e->res.p : nullptr;
+                    BH_REQUIRE(!d.add_residual || res_ready, "encoder_forward: layer %zu adds a residual that was never projected", i);
+                    rc = bh_k_linear(cur, l.w0.p, (const float*)l.b0.p, dst, Np * len, d.out_size, d.in_size, d.in_size,
+                                     d.in_size, d.out_size, d.activation, 1.0f, lo, hi, 0, 0, 0, 0, 0, st, rsd, d.out_size);
+                    if (d.add_residual) res_ready = false;
+                } else if (lay == L_SIGNAL)
                     rc = bh_k_conv_first(cur, (const float*)l.w0.p, (const float*)l.b0.p, dst, Np, len, lout,
                                          co, d.winlen, d.stride, d.padding, d.activation, lo, hi, os_n, os_t, st);
                 else
@@ -589,6 +657,34 @@ extern "C" int bh_encoder_forward(bh_encoder_t* e, const void* signal, int N, in
                     if (rc) return rc;
                 }
                 cur = dst; which ^= 1;
+                break;
+            }
+            case BH_LAYER_DWCONV: {
+                BH_REQUIRE(lay == L_NLC && C == d.in_size, "encoder_forward: depthwise conv needs [N][L][%d] input", d.in_size);
+                const int lout = conv_out_len(len, d.winlen, d.stride, d.padding);
+                void* dst = e->act[which].p;
+                ProfSpan span(e, st, BH_PROF_CONV);
+                int rc = bh_k_dwconv(cur, (const float*)l.w0.p, dst, Np, len, lout, C, d.winlen, d.stride, d.padding, st);
+                if (rc) return rc;
+                cur = dst; which ^= 1; len = lout;
+                break;
+            }
+            case BH_LAYER_RESIDUAL_PROJ: {
+                BH_REQUIRE(lay == L_NLC && C == d.in_size, "encoder_forward: residual projection needs [N][L][%d] input", d.in_size);
+                ProfSpan span(e, st, BH_PROF_CONV);
+                int rc = bh_k_linear(cur, l.w0.p, (const float*)l.b0.p, e->res.p, Np * len, d.out_size, d.in_size, d.in_size,
+                                     d.in_size, d.out_size, bh::ACT_NONE, 1.0f, -INFINITY, INFINITY, 0, 0, 0, 0, 0, st);
+                if (rc) return rc;
+                res_ready = true;
+                break;
+            }
+            case BH_LAYER_CTC_DECODER: {
+                BH_REQUIRE(lay == L_NLC && C == d.in_size, "encoder_forward: ctc decoder needs [N][T][%d] input", d.in_size);
+                ProfSpan span(e, st, BH_PROF_CRF_LINEAR);
+                int rc = bh_k_ctc_head(cur, (const float*)l.w0.p, (const float*)l.b0.p, scores, (long)N * len, d.in_size,
+                                       d.out_size, st);
+                if (rc) return rc;
+                C = d.out_size;
                 break;
             }
             case BH_LAYER_UPSAMPLE: {
@@ -689,6 +785,18 @@ extern "C" int bh_rmsnorm_residual(const void* a, const void* x, const float* w,
                                    float eps, void* stream) {
     BH_REQUIRE(a && x && w && out && M > 0, "rmsnorm_residual: bad arguments");
     return bh_k_rmsnorm_residual(a, x, w, out, M, D, alpha, eps, (hipStream_t)stream);
+}
+extern "C" int bh_ctc_greedy_decode(const float* logp, const long* offsets, int R, int classes, float qscale, float qbias,
+                                    int8_t* labels, int8_t* qual, int* path, int* count, void* stream) {
+    BH_REQUIRE(logp && offsets && labels && qual && path && count, "ctc_greedy_decode: null pointer");
+    return bh_k_ctc_greedy(logp, offsets, R, classes, qscale, qbias, labels, qual, path, count, (hipStream_t)stream);
+}
+extern "C" int bh_dwconv1d(const void* in, const float* w, void* out, int N, int Lin, int C, int K, int stride, int pad,
+                           void* stream) {
+    BH_REQUIRE(in && w && out && stride > 0, "dwconv1d: bad arguments");
+    const int lout = conv_out_len(Lin, K, stride, pad);
+    BH_REQUIRE(lout > 0, "dwconv1d: input too short");
+    return bh_k_dwconv(in, w, out, N, Lin, lout, C, K, stride, pad, (hipStream_t)stream);
 }
 extern "C" size_t bh_lstm_workspace(int N, int H) { return bh_k_lstm_ws_bytes(N, H); }
 extern "C" int bh_lstm_layer(const void* gates_in, const void* whh_packed, void* h_out, int T, int N, int H,

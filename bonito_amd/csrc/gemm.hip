@@ -25,6 +25,8 @@ struct GemmArgs {
     const half_t* X;   // [M][ldx]
     const half_t* W;   // [N][ldw]
     const float* bias; // [N] or null
+    const half_t* res; // optional residual [M][ldres], added before the activation
+    int ldres;
     half_t* out;       // rows remapped, see below; [.][ldo]
     int M, N, K;
     int ldx, ldw, ldo;
@@ -150,6 +152,12 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
         for (int ft = 0; ft < 4; ++ft)
 #pragma unroll
             for (int g = 0; g < 4; ++g) v[ft * 4 + g] = acc[ft][tt][g] + bv[ft * 4 + g];
+        if (p.res != nullptr) {
+            const half_t* rp = p.res + (long)m * p.ldres + fbase;
+#pragma unroll
+            for (int i = 0; i < 16; ++i)
+                if (fbase + i < p.N) v[i] += (float)rp[i];
+        }
         if constexpr (GATED) {
             // W rows were interleaved on the host: feature 2j = y_j, 2j+1 = gate_j
             // (flash_attn GatedMlp semantics: y, gate = fc1(x).chunk(2); y * silu(gate)).
@@ -191,7 +199,8 @@ static void launch(const GemmArgs& a, hipStream_t s) {
 
 int bh_k_linear(const void* X, const void* W, const float* bias, void* out, int M, int N, int K,
                 int ldx, int ldw, int ldo, int act, float scale, float clamp_lo, float clamp_hi,
-                int gated, int row_div, long row_s_hi, long row_s_lo, int row_lim, hipStream_t stream) {
+                int gated, int row_div, long row_s_hi, long row_s_lo, int row_lim, hipStream_t stream,
+                const void* residual, int ldres) {
     using namespace bh;
     BH_REQUIRE(M > 0 && N > 0 && K > 0, "linear: empty problem M=%d N=%d K=%d", M, N, K);
     BH_REQUIRE(K % 8 == 0 && ldx % 8 == 0 && ldw % 8 == 0, "linear: K/ldx/ldw must be multiples of 8 halves");
@@ -199,6 +208,7 @@ int bh_k_linear(const void* X, const void* W, const float* bias, void* out, int 
     BH_REQUIRE(!gated || (N % 16 == 0), "linear: gated epilogue needs N %% 16 == 0");
     GemmArgs a;
     a.X = (const half_t*)X; a.W = (const half_t*)W; a.bias = bias; a.out = (half_t*)out;
+    a.res = (const half_t*)residual; a.ldres = ldres;
     a.M = M; a.N = N; a.K = K; a.ldx = ldx; a.ldw = ldw; a.ldo = ldo;
     a.scale = scale; a.clamp_lo = clamp_lo; a.clamp_hi = clamp_hi;
     a.row_div = row_div > 0 ? row_div : 1;

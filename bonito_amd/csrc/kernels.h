@@ -9,7 +9,8 @@
 // gemm.hip
 int bh_k_linear(const void* X, const void* W, const float* bias, void* out, int M, int N, int K,
                 int ldx, int ldw, int ldo, int act, float scale, float clamp_lo, float clamp_hi,
-                int gated, int row_div, long row_s_hi, long row_s_lo, int row_lim, hipStream_t stream);
+                int gated, int row_div, long row_s_hi, long row_s_lo, int row_lim, hipStream_t stream,
+                const void* residual = nullptr, int ldres = 0);
 
 // conv.hip
 int bh_k_conv_first(const void* signal, const float* w, const float* bias, void* out, int N, int Lin,
@@ -42,3 +43,11 @@ int bh_k_attention(const void* qkv, void* out, const float* cos_sin, int N, int 
                    int win_left, int win_right, hipStream_t stream);
 int bh_k_rmsnorm_residual(const void* a, const void* x, const float* w, void* out, long M, int D, float alpha,
                           float eps, hipStream_t stream);
+
+// ctc.hip
+int bh_k_dwconv(const void* in, const float* w, void* out, int N, int Lin, int Lout, int C, int K, int stride,
+                int pad, hipStream_t stream);
+int bh_k_ctc_head(const void* in, const float* w, const float* bias, void* out, long M, int features, int classes,
+                  hipStream_t stream);
+int bh_k_ctc_greedy(const float* logp, const long* offs, int R, int C, float qscale, float qbias, int8_t* seq,
+                    int8_t* qual, int* path, int* count, hipStream_t stream);

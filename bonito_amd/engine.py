@@ -133,10 +133,60 @@ def lower(encoder):
     return low
 
 
+def _fold(conv, bn):
+    """fp32 (weight, bias) of `conv` followed by eval-mode BatchNorm `bn`."""
+    w = _f32(conv.weight)
+    b = _f32(conv.bias) if conv.bias is not None else torch.zeros(w.shape[0])
+    s = _f32(bn.weight) * torch.rsqrt(_f32(bn.running_var) + bn.eps)
+    return (w * s[:, None, None]).contiguous(), ((b - _f32(bn.running_mean)) * s + _f32(bn.bias)).contiguous()
+
+
+def lower_ctc(model):
+    """bonito_amd.ctc.Model (QuartzNet) -> primitive engine layers:
+    Block = [residual projection] + repeat x ([depthwise conv] + pointwise/plain conv with folded BatchNorm,
+    activation fused; the last one adds the residual before the activation) ; Decoder = 1x1 conv + log_softmax."""
+    low = _Lowered()
+    for block in model.encoder.encoder:
+        mods = list(block.conv)
+        pairs = [(mods[i], mods[i + 1]) for i in range(0, len(mods), 4)]      # (TCSConv1d, BatchNorm1d) every 4
+        act = _act_id(block.activation[0])
+        first = pairs[0][0]
+        cin = (first.depthwise if first.separable else first.conv).in_channels
+        if block.use_res:
+            rconv, rbn = block.residual[0].conv, block.residual[1]
+            w, b = _fold(rconv, rbn)
+            low.add(kind=_lib.BH_LAYER_RESIDUAL_PROJ, in_size=cin, out_size=rconv.out_channels,
+                    w0=w.reshape(w.shape[0], -1).contiguous(), b0=b)
+        for r, (tcs, bn) in enumerate(pairs):
+            last = r == len(pairs) - 1
+            if tcs.separable:
+                dw, pw = tcs.depthwise, tcs.pointwise
+                if dw.dilation[0] != 1:
+                    raise LoweringError("dilated depthwise convolutions are not lowered")
+                low.add(kind=_lib.BH_LAYER_DWCONV, in_size=dw.in_channels, out_size=dw.in_channels,
+                        winlen=dw.kernel_size[0], stride=dw.stride[0], padding=dw.padding[0],
+                        w0=_f32(dw.weight).reshape(dw.in_channels, -1).contiguous())
+                w, b = _fold(pw, bn)
+                low.add(kind=_lib.BH_LAYER_CONV, in_size=pw.in_channels, out_size=pw.out_channels, winlen=1, stride=1,
+                        padding=0, activation=act, groups=1, add_residual=int(last and block.use_res), w0=w, b0=b)
+            else:
+                c = tcs.conv
+                if c.dilation[0] != 1:
+                    raise LoweringError("dilated convolutions are not lowered")
+                w, b = _fold(c, bn)
+                low.add(kind=_lib.BH_LAYER_CONV, in_size=c.in_channels, out_size=c.out_channels, winlen=c.kernel_size[0],
+                        stride=c.stride[0], padding=c.padding[0], activation=act, groups=1,
+                        add_residual=int(last and block.use_res), w0=w, b0=b)
+    head = model.decoder.layers[0]
+    low.add(kind=_lib.BH_LAYER_CTC_DECODER, in_size=head.in_channels, out_size=head.out_channels,
+            w0=_f32(head.weight).reshape(head.out_channels, -1).contiguous(), b0=_f32(head.bias))
+    return low
+
+
 class HipEncoder:
     """Callable engine handle: ``scores = enc(signal)`` with signal fp16 cuda [N,1,L] or [N,L]."""
 
-    def __init__(self, encoder, batchsize, chunksize, device=None):
+    def __init__(self, encoder, batchsize, chunksize, device=None, lowering=None):
         self._handle = None
         lib = _lib.lib()
         if not torch.cuda.is_available():
@@ -146,7 +196,7 @@ class HipEncoder:
             raise _lib.HipEngineError("the encoder engine needs a GPU device, got %s" % (dev,))
         self.device = dev
         self.max_batch, self.max_chunk = int(batchsize), int(chunksize)
-        low = lower(encoder)
+        low = (lowering or lower)(encoder)
         handle = C.c_void_p()
         _lib.check(lib.bh_encoder_create(low.array(), len(low.descs), dev.index or 0, self.max_batch,
                                          self.max_chunk, C.byref(handle)), "bh_encoder_create")

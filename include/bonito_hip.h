@@ -53,8 +53,11 @@ enum {
     BH_LAYER_CLAMP = 4,       /* clamp        (nn.py:60) -- fused into the producing kernel */
     BH_LAYER_TRANSFORMER = 5, /* transformerencoderlayer (transformer/model.py:83) */
     BH_LAYER_UPSAMPLE = 6,    /* linearupsample (nn.py:140) */
-    BH_LAYER_TCS_BLOCK = 7,   /* bonito.ctc Block (ctc/model.py:124) */
-    BH_LAYER_CTC_DECODER = 8  /* bonito.ctc Decoder: 1x1 conv + log_softmax (ctc/model.py:195) */
+    BH_LAYER_TCS_BLOCK = 7,   /* reserved */
+    BH_LAYER_CTC_DECODER = 8, /* bonito.ctc Decoder: 1x1 conv + log_softmax (ctc/model.py:195-207); final layer */
+    BH_LAYER_DWCONV = 9,      /* depthwise half of TCSConv1d (ctc/model.py:99-103): groups = channels, no bias */
+    BH_LAYER_RESIDUAL_PROJ = 10 /* Block.residual (ctc/model.py:166-167): 1x1 conv + folded BN of the block input,
+                                 * kept aside and added by the next BH_LAYER_CONV whose `add_residual` is set */
 };
 
 /* One layer of an encoder.  All weight pointers are HOST fp32 arrays in torch's native layout; the
@@ -68,8 +71,9 @@ typedef struct bh_layer {
     int32_t reverse;     /* lstm */
     int32_t nhead, dim_ff, win_left, win_right;   /* transformer */
     int32_t scale_factor;               /* upsample */
-    int32_t groups;      /* conv: 1 or in_size (depthwise) */
-    int32_t reserved_i[3];
+    int32_t groups;      /* conv: 1 */
+    int32_t add_residual;               /* conv (pointwise): add the pending residual projection before the activation */
+    int32_t reserved_i[2];
     float scale;         /* linear_crf: multiply after activation (0 = none) */
     float clamp_lo, clamp_hi;           /* clamp */
     float blank_score;   /* linear_crf with fixed blank (scores keep the 4S koi layout) */
@@ -160,6 +164,15 @@ int bh_conv1d_pack(const float* w, int Cin, int Cout, int K, uint16_t* packed);
 int bh_conv1d(const void* in, const void* wpacked, const float* bias, void* out, int N, int Lin, int Cin,
               int Cout, int K, int stride, int pad, int act, float clamp_lo, float clamp_hi, long os_n,
               long os_t, void* stream);
+/* Greedy CTC decode of R reads in one launch: replaces fast_ctc_decode.viterbi_search(probs, alphabet,
+ * qstring=True, qscale, qbias) (bonito/ctc/model.py:39-42).  logp: device fp32 [sum T_r][classes]
+ * log-probabilities, offsets: device int64 [R+1].  Outputs (device, compacted per read at offsets[r]):
+ * labels (1..classes-1), qual (phred chars), path (step of each base), count[R]. */
+int bh_ctc_greedy_decode(const float* logp, const long* offsets, int R, int classes, float qscale, float qbias,
+                         int8_t* labels, int8_t* qual, int* path, int* count, void* stream);
+/* depthwise conv (TCSConv1d.depthwise, ctc/model.py:99-103): in/out fp16 channel-minor [N][L][C], w fp32 device [C][K] */
+int bh_dwconv1d(const void* in, const float* w, void* out, int N, int Lin, int C, int K, int stride, int pad,
+                void* stream);
 /* rotary cos/sin table (host): out[t][i][0..1] = cos, sin(t * 10000^(-2i/dim)), i < dim/2, fp32
  * (flash_attn.layers.rotary.RotaryEmbedding(dim, interleaved=False), bonito/transformer/model.py:55,73) */
 int bh_rotary_table(int T, int dim, float* out);

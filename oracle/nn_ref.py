@@ -135,6 +135,55 @@ def transformer_layer_forward(m, x):
     return rms(f + alpha * x, m.norm2.weight)
 
 
+def _bn_eval(bn, h):
+    h = (h - bn.running_mean.float()[None, :, None]) * torch.rsqrt(bn.running_var.float()[None, :, None] + bn.eps)
+    if bn.affine:
+        h = h * bn.weight.float()[None, :, None] + bn.bias.float()[None, :, None]
+    return h
+
+
+def _conv1d(c, x):
+    return F.conv1d(x, c.weight.float(), None if c.bias is None else c.bias.float(), stride=c.stride,
+                    padding=c.padding, dilation=c.dilation, groups=c.groups)
+
+
+def _tcs(m, x):
+    """TCSConv1d (bonito/ctc/model.py:90-121): depthwise + pointwise, or a plain convolution."""
+    if m.separable:
+        return _conv1d(m.pointwise, _conv1d(m.depthwise, x))
+    return _conv1d(m.conv, x)
+
+
+def _quartznet_layer(layer, x):
+    n = type(layer).__name__
+    if n == "TCSConv1d":
+        return _tcs(layer, x)
+    if n == "BatchNorm1d":
+        return _bn_eval(layer, x)
+    if n == "Dropout":
+        return x
+    return _act(layer, x)      # Swish / SiLU / ReLU / Tanh marker
+
+
+def ctc_forward(model, x):
+    """bonito.ctc Model.forward (ctc/model.py:35-37): Encoder blocks (:177-192) then Decoder (:206-207).
+    Returns log-probabilities [T, N, n_labels]."""
+    for block in model.encoder.encoder:
+        h = x
+        for layer in block.conv:
+            h = _quartznet_layer(layer, h)
+        if block.use_res:
+            r = x
+            for layer in block.residual:
+                r = _quartznet_layer(layer, r)
+            h = h + r
+        for layer in block.activation:
+            h = _quartznet_layer(layer, h)
+        x = h
+    logits = _conv1d(model.decoder.layers[0], x).permute(2, 0, 1)
+    return torch.log_softmax(logits, dim=-1)
+
+
 def forward(m, x, expand_blanks=None):
     """Evaluate module tree `m` on fp32 CPU tensor x (reference layouts: NCL in, TNC scores out)."""
     n = _name(m)

@@ -57,6 +57,22 @@ def build_tf_model(cfg, sd):
     return model
 
 
+def load_ctc_fixture(name="quartz_small"):
+    import torch
+    z = np.load(os.path.join(GOLDEN, "ctc_%s.npz" % name))
+    cfg = json.loads(str(z["config"]))
+    sd = {k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("sd/")}
+    return cfg, sd, torch.from_numpy(z["x"]), torch.from_numpy(z["y"])
+
+
+def build_ctc_model(cfg, sd):
+    from bonito_amd.ctc import Model
+    model = Model(cfg)
+    model.load_state_dict(sd)
+    model.eval()
+    return model
+
+
 NN_FIXTURES = ["lstm32_sl2", "lstm64_sl3", "lstm96_sl3", "lstm32_clampconv", "lstm32_oldstyle"]
 
 

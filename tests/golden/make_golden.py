@@ -274,7 +274,59 @@ def make_transformer_fixture(name, d_model, nhead, dim_ff, depth, window, state_
           (name, tuple(y.shape), err, os.path.basename(path), os.path.getsize(path) // 1024))
 
 
+def ref_ctc():
+    """The reference's bonito.ctc.model (pure torch apart from the fast_ctc_decode import, stubbed)."""
+    if "bonito" not in sys.modules or not hasattr(sys.modules["bonito"], "__path__"):
+        pkg = types.ModuleType("bonito")
+        pkg.__path__ = [os.path.join(REF, "bonito")]
+        sys.modules["bonito"] = pkg
+    for name in ("toml", "parasail", "fast_ctc_decode"):
+        sys.modules.setdefault(name, types.ModuleType(name))
+    sys.modules["fast_ctc_decode"].beam_search = None
+    sys.modules["fast_ctc_decode"].viterbi_search = None
+    return load_by_path("bonito.ctc.model", os.path.join(REF, "bonito", "ctc", "model.py"))
+
+
+def quartznet_config(blocks):
+    return {"model": {"package": "bonito.ctc"}, "labels": {"labels": ["N", "A", "C", "G", "T"]},
+            "input": {"features": 1}, "encoder": {"activation": "swish"},
+            "qscore": {"scale": 0.9356, "bias": -0.1721},
+            "block": [{"filters": f, "repeat": r, "kernel": [k], "stride": [s], "dilation": [1], "dropout": 0.05,
+                       "residual": res, "separable": sep} for f, r, k, s, res, sep in blocks]}
+
+
+def make_ctc_fixture(name, blocks, N, L, seed=25):
+    cm = ref_ctc()
+    cfg = quartznet_config(blocks)
+    torch.manual_seed(seed)
+    model = cm.Model(cfg)
+    gen = torch.Generator().manual_seed(seed + 1)
+    randomise_bn_(model, gen)
+    model.eval()
+    nn_ref.round_params_to_half_(model)
+    x = torch.randn(N, 1, L, generator=gen).half().float()
+    with torch.no_grad():
+        y = model(x)
+        y_oracle = nn_ref.ctc_forward(model, x)
+    err = (y - y_oracle).abs().max().item()
+    assert err < 2e-4, "oracle ctc_forward disagrees with reference ctc/model.py on %s: %g" % (name, err)
+    out = {"config": np.array(json.dumps(cfg)), "x": x.numpy(), "y": y.numpy()}
+    for k, v in model.state_dict().items():
+        out["sd/" + k] = v.numpy()
+    path = os.path.join(HERE, "ctc_%s.npz" % name)
+    np.savez_compressed(path, **out)
+    print("%-28s y%s  oracle-vs-reference max|d| = %.2e  -> %s (%d KiB)" %
+          (name, tuple(y.shape), err, os.path.basename(path), os.path.getsize(path) // 1024))
+
+
+CTC_BLOCKS_SMALL = [(32, 1, 9, 3, False, False), (48, 2, 33, 1, True, True), (48, 3, 5, 1, True, True),
+                    (64, 1, 29, 1, False, True), (40, 1, 15, 1, False, False)]
+
+
 def main():
+    if "--ctc-only" in sys.argv:
+        make_ctc_fixture("quartz_small", CTC_BLOCKS_SMALL, N=3, L=600)
+        return
     if "--transformer-only" in sys.argv:
         make_transformer_fixture("d128_w31_32", 128, 2, 256, 2, (31, 32), 3, N=2, L=1200)
         make_transformer_fixture("d64_w127_128", 64, 1, 128, 1, (127, 128), 2, N=2, L=2400)
@@ -295,6 +347,7 @@ def main():
     make_util_fixture(ref_util())
     make_transformer_fixture("d128_w31_32", 128, 2, 256, 2, (31, 32), 3, N=2, L=1200)
     make_transformer_fixture("d64_w127_128", 64, 1, 128, 1, (127, 128), 2, N=2, L=2400)
+    make_ctc_fixture("quartz_small", CTC_BLOCKS_SMALL, N=3, L=600)
 
 
 if __name__ == "__main__":

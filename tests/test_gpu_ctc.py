@@ -1,0 +1,96 @@
+"""bonito.ctc path on the GPU: QuartzNet engine vs the reference fixture, greedy decode vs the oracle,
+end-to-end basecall (BASELINE config 1 shape: 16 chunks of 4000 samples) (-m gpu)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import build_ctc_model, load_ctc_fixture
+from bonito_amd import _lib
+from bonito_amd.ctc import basecall as ctc_basecall
+from bonito_amd.ctc import decode as ctc_decode
+from oracle import ctc_ref, nn_ref
+
+pytestmark = pytest.mark.gpu
+
+
+def _gpu_model():
+    cfg, sd, x, y = load_ctc_fixture()
+    model = build_ctc_model(cfg, sd)
+    model.use_koi(batchsize=16, chunksize=4000, quantize=False)      # the reference CLI calls use_koi on every model
+    return model.half().to("cuda"), x, y
+
+
+def test_quartznet_engine_matches_reference_fixture():
+    model, x, y = _gpu_model()
+    got = model(x.half().cuda())
+    assert got.shape == y.shape == (200, 3, 5)                        # TNC, like the reference
+    d = (got.cpu().float() - y).abs()
+    assert d.max().item() < 3e-2 and d.mean().item() < 3e-3, (d.max().item(), d.mean().item())
+    assert (got.float().exp().sum(-1) - 1).abs().max().item() < 5e-3
+
+
+@pytest.mark.parametrize("C_,K,stride,L", [(64, 33, 1, 500), (48, 115, 1, 300), (344, 9, 3, 1000), (8, 123, 1, 200)])
+def test_depthwise_conv(C_, K, stride, L):
+    g = torch.Generator().manual_seed(K)
+    N = 2
+    x = torch.randn(N, C_, L, generator=g).half()
+    w = torch.randn(C_, 1, K, generator=g) * 0.2
+    want = F.conv1d(x.float(), w, None, stride=stride, padding=K // 2, groups=C_).permute(0, 2, 1)
+    xin = x.permute(0, 2, 1).contiguous().cuda()
+    wd = w.reshape(C_, K).contiguous().cuda()
+    out = torch.zeros(want.shape, dtype=torch.float16, device="cuda")
+    _lib.check(_lib.lib().bh_dwconv1d(_lib.ptr(xin), _lib.ptr(wd), _lib.ptr(out), N, L, C_, K, stride, K // 2,
+                                      _lib.stream_ptr()), "dwconv1d")
+    torch.cuda.synchronize()
+    assert (out.cpu().float() - want).abs().max().item() < 2e-2
+
+
+def test_greedy_decode_matches_oracle():
+    rng = np.random.default_rng(0)
+    alphabet = ["N", "A", "C", "G", "T"]
+    reads = []
+    for T in (1, 7, 300, 2571):
+        logits = rng.standard_normal((T, 5)).astype(np.float32) * 3
+        # make runs: repeat rows
+        logits = np.repeat(logits, rng.integers(1, 4, size=T), axis=0)[:max(T, 1)]
+        reads.append(torch.log_softmax(torch.from_numpy(logits), -1))
+    got = ctc_decode.viterbi_search_batch(reads, alphabet, 0.9356, -0.1721)
+    for lp, (seq, qs, path) in zip(reads, got):
+        oseq, oqs, opath = ctc_ref.viterbi_search(lp.numpy(), alphabet, 0.9356, -0.1721)
+        assert seq == oseq and path == opath
+        assert len(qs) == len(oqs) and sum(a != b for a, b in zip(qs, oqs)) <= max(1, len(qs) // 200)
+    s, p = ctc_decode.viterbi_search(reads[2], alphabet, True, 1.0, 0.0)
+    assert len(s) == 2 * len(p)
+
+
+class Read:
+    def __init__(self, read_id, signal):
+        self.read_id, self.signal = read_id, signal
+
+
+def test_ctc_basecall_config1_shape():
+    """BASELINE config 1: 16 synthetic chunks of 4000 samples through chunk -> batchify -> forward -> unbatchify
+    -> stitch -> decode; checked against the oracle forward + oracle decode on the same reads."""
+    model, _, _ = _gpu_model()
+    rng = np.random.default_rng(4)
+    reads = [Read("r%d" % i, rng.standard_normal(n).astype(np.float32)) for i, n in enumerate([16000, 24000, 4000, 20000])]
+    got = list(ctc_basecall(model, iter(reads), beamsize=5, chunksize=4000, overlap=400, batchsize=16))
+    assert [r.read_id for r, _ in got] == ["r0", "r1", "r2", "r3"]
+    cpu_model = build_ctc_model(*load_ctc_fixture()[:2])
+    for read, res in got:
+        assert res["stride"] == 3 and set(res["sequence"]) <= set("ACGT")
+        assert len(res["sequence"]) == len(res["qstring"]) == len(res["moves"])
+        # oracle: fp32 forward of the whole read in chunks, stitched, greedy decoded
+        from bonito_amd import util
+        ch = util.chunk(torch.from_numpy(read.signal), 4000, 400)
+        with torch.no_grad():
+            lp = nn_ref.ctc_forward(cpu_model, ch.float()).permute(1, 0, 2)
+        st = util.stitch(lp, 4000, 400, len(read.signal), 3)
+        oseq, _, opath = ctc_ref.viterbi_search(st.numpy(), model.alphabet, model.qscale, model.qbias)
+        # fp16 engine vs fp32 oracle: near-tie argmaxes may flip; demand high identity, not equality
+        import difflib
+        ratio = difflib.SequenceMatcher(None, res["sequence"], oseq, autojunk=False).ratio()
+        assert ratio > 0.97, ratio
