@@ -30,7 +30,7 @@ def compute_scores(model, batch, beam_width=32, beam_cut=100.0, scale=1.0, offse
         device = next(model.parameters()).device
         scores = model(batch.to(torch.float16).to(device))
         if reverse:
-            raise NotImplementedError("--revcomp is not implemented in the HIP engine yet")
+            scores = model.seqdist.reverse_complement(scores)
         with torch.cuda.device(scores.device):
             if decoder == "viterbi":
                 moves, path = hip_decode.viterbi(scores, blank_score=blank_score)
@@ -59,8 +59,8 @@ class _Pipeline:
     same overlap from its per-stage ThreadIterators (bonito/crf/basecall.py:63-82) with koi returning CPU
     tensors; here the split is explicit because both halves are ours."""
 
-    def __init__(self, model, decoder="beam", **decode_kw):
-        self.model, self.mode, self.kw = model, decoder, decode_kw
+    def __init__(self, model, decoder="beam", reverse=False, **decode_kw):
+        self.model, self.mode, self.kw, self.reverse = model, decoder, decode_kw, reverse
         self.device = next(model.parameters()).device
         self.enc_stream = torch.cuda.Stream(self.device)
         self.dec_stream = torch.cuda.Stream(self.device)
@@ -69,6 +69,8 @@ class _Pipeline:
     def encode(self, batch):
         with torch.inference_mode(), torch.cuda.stream(self.enc_stream):
             scores = self.model(batch.to(torch.float16).to(self.device, non_blocking=True))
+            if self.reverse:
+                scores = self.model.seqdist.reverse_complement(scores)
             ready = torch.cuda.Event()
             ready.record(self.enc_stream)
         return scores, ready
@@ -94,9 +96,7 @@ class _Pipeline:
 
 def basecall(model, reads, chunksize=4000, overlap=100, batchsize=32, reverse=False, rna=False, decoder="beam"):
     """Basecalls a set of reads: yields (read, {sequence, qstring, moves, stride})."""
-    if reverse:
-        raise NotImplementedError("--revcomp is not implemented in the HIP engine yet")
-    pipe = _Pipeline(model, decoder=decoder)
+    pipe = _Pipeline(model, decoder=decoder, reverse=reverse)
     chunks = thread_iter(
         ((read, 0, read.signal.shape[-1]), chunk(torch.from_numpy(read.signal), chunksize, overlap))
         for read in reads

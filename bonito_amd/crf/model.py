@@ -64,16 +64,16 @@ class CTC_CRF:
         return seq.tobytes().decode()
 
     def reverse_complement(self, scores):
-        """Score-tensor permutation so that decoding yields the reverse-complement strand
-        (reference crf/model.py:84-96); pure index shuffling, done with torch views on the device."""
-        T, N, _ = scores.shape
-        nb, sl = self.n_base, self.state_len
-        x = scores.reshape(T, N, *([nb] * sl), nb + 1)
-        kmer_axes = list(range(2, 2 + sl))
-        blanks = x[..., 0].permute(0, 1, *reversed(kmer_axes)).reshape(T, N, -1, 1).flip([0, 2])
-        # emission axes: (k-mer axes..., dropped base) -> reversed k-mer order with the dropped base moved
-        emis = x[..., 1:].permute(0, 1, *range(sl, 1, -1), sl + 2, sl + 1).reshape(T, N, -1, nb).flip([0, 2, 3])
-        return torch.cat([blanks, emis], dim=-1).reshape(T, N, -1)
+        """Permute scores so that decoding yields the reverse-complement strand (reference crf/model.py:84-96).
+        Accepts the engine's koi layout [N, T, 4S] or the reference layout [T, N, 5S] (cuda fp16)."""
+        S = self.n_base ** self.state_len
+        if scores.shape[-1] == 4 * S:
+            return hip_decode.reverse_complement(scores.contiguous())
+        return hip_decode.reverse_complement_5s(scores, self.state_len)
+
+    def logZ(self, scores, blank_score=2.0):
+        """Log partition function per chunk of koi-layout scores [N, T, 4S] (reference crf/model.py:47-52)."""
+        return hip_decode.logz(scores.contiguous(), blank_score)
 
 
 def conv(c_in, c_out, ks, stride=1, bias=False, activation=None, norm=None):

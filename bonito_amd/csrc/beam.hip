@@ -593,6 +593,26 @@ size_t bh_k_beam_workspace(int N, int T, int state_len) {
     return b;
 }
 
+// Log-semiring partition function (CTC_CRF.logZ, bonito/crf/model.py:47-52) on koi-layout scores: the
+// backward scan of the beam decoder already produces it. workspace: bh_k_beam_workspace bytes.
+int bh_k_crf_logz(const void* scores, int N, int T, int state_len, float blank, void* workspace, double* logz_out,
+                  hipStream_t stream) {
+    using namespace bh;
+    BH_REQUIRE(state_len >= 1 && state_len <= 5 && N > 0 && T > 0, "crf_logz: bad shape");
+    int S = 1;
+    for (int i = 0; i < state_len; ++i) S *= 4;
+    auto align = [](size_t x) { return (x + 255) / 256 * 256; };
+    char* w = (char*)workspace;
+    float* beta = (float*)w;   w += align((size_t)N * (T + 1) * S * sizeof(float));
+    double* Bcum = (double*)w;
+    ScanArgs sa{(const half_t*)scores, N, T, S, state_len, blank, beta, Bcum, logz_out, nullptr};
+    const int threads = S < 64 ? 64 : S;
+    const size_t lds_scan = (size_t)(BH_LSE_TABLE_SIZE + 2 + 2 * S + 2 * 16 * 4 + 8) * sizeof(float) + (size_t)2 * 4 * S * 2;
+    hipLaunchKernelGGL(crf_backward_kernel, dim3(N), dim3(threads), lds_scan, stream, sa);
+    BH_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
 int bh_k_beam_search(const void* scores, int N, int T, int state_len, int beam_width, float beam_cut,
                      float blank, float q_scale, float q_offset, void* workspace, int8_t* sequence,
                      int8_t* qstring, int8_t* moves, float* qfloat, hipStream_t stream) {

@@ -14,6 +14,8 @@
 // One workgroup per chunk, one thread per state; alpha ping-pongs in LDS (one barrier per step);
 // score loads are register-prefetched U steps ahead so the serial alpha chain never waits on HBM;
 // 3-bit back-pointers go to a [N][T][S] byte workspace and are chased back in LDS-staged blocks.
+#include <algorithm>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -165,6 +167,68 @@ int bh_k_crf_viterbi(const void* scores, int N, int T, int state_len, int layout
     size_t lds = 16 + (size_t)2 * S * sizeof(float) + (size_t)TB * S + 2 * TB + 16;
     if (layout_5s) hipLaunchKernelGGL(crf_viterbi_kernel<true>, dim3(N), dim3(threads), lds, stream, a);
     else hipLaunchKernelGGL(crf_viterbi_kernel<false>, dim3(N), dim3(threads), lds, stream, a);
+    BH_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// CTC_CRF.reverse_complement (/root/reference bonito/crf/model.py:84-96) as one gather kernel: the score
+// tensor is permuted so that decoding it yields the reverse-complement strand.  A transition into state
+// j = (d1..dk) that dropped base r is the (k+1)-mer (r, d1..dk); on the other strand it becomes the
+// transition into j' = comp(d_{k-1}, .., d1, r) dropping r' = comp(dk), at time T-1-t.  Stay scores move
+// to the reverse-complemented state.  Works on the koi layout [N][T][4S] and on [T][N][5S].
+namespace bh {
+
+struct RcArgs {
+    const half_t* in;
+    half_t* out;
+    int N, T, S, k, five;
+    long s_n, s_t;       // element strides of both tensors
+};
+
+__device__ __forceinline__ int rc_digits(int j, int k) {   // reverse the k base-4 digits and complement them
+    int r = 0;
+    for (int i = 0; i < k; ++i) { r = (r << 2) | (3 - (j & 3)); j >>= 2; }
+    return r;
+}
+
+__global__ void crf_revcomp_kernel(RcArgs p) {
+    const int W = p.five ? 5 * p.S : 4 * p.S;
+    const long total = (long)p.N * p.T * W;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c2 = (int)(i % W);
+        const long nt = i / W;
+        const int t2 = (int)(nt % p.T), n = (int)(nt / p.T);
+        const int per = p.five ? 5 : 4;
+        const int j2 = c2 / per, m = c2 % per;
+        int src_c;
+        if (p.five && m == 0) {
+            src_c = rc_digits(j2, p.k) * 5;                      // stay score of the rev-comp state
+        } else {
+            const int r2 = p.five ? m - 1 : m;
+            // (k+1)-mer on this strand: (r2, digits of j2) ; source (k+1)-mer = its reverse complement
+            const int kmer1 = r2 * p.S + j2;                     // r2 is the most significant digit
+            const int src = rc_digits(kmer1, p.k + 1);           // = (r, d1..dk) of the source
+            const int r = src / p.S, j = src % p.S;
+            src_c = p.five ? j * 5 + 1 + r : j * 4 + r;
+        }
+        p.out[(long)n * p.s_n + (long)t2 * p.s_t + c2] = p.in[(long)n * p.s_n + (long)(p.T - 1 - t2) * p.s_t + src_c];
+    }
+}
+
+}  // namespace bh
+
+int bh_k_crf_revcomp(const void* in, void* out, int N, int T, int state_len, int layout_5s, long s_n, long s_t,
+                     hipStream_t stream) {
+    using namespace bh;
+    BH_REQUIRE(state_len >= 1 && state_len <= 5 && N > 0 && T > 0, "revcomp: bad shape");
+    BH_REQUIRE(in != out, "revcomp: in-place operation is not supported");
+    int S = 1;
+    for (int i = 0; i < state_len; ++i) S *= 4;
+    RcArgs a{(const half_t*)in, (half_t*)out, N, T, S, state_len, layout_5s, s_n, s_t};
+    const long total = (long)N * T * (layout_5s ? 5 : 4) * S;
+    int blocks = (int)std::min<long>((total + 255) / 256, 8192);
+    hipLaunchKernelGGL(crf_revcomp_kernel, dim3(blocks), dim3(256), 0, stream, a);
     BH_CHECK_HIP(hipGetLastError());
     return 0;
 }

@@ -821,6 +821,16 @@ extern "C" int bh_beam_search(const void* scores, int N, int T, int state_len, i
     return bh_k_beam_search(scores, N, T, state_len, beam_width, beam_cut, blank_score, q_scale, q_offset, workspace,
                             sequence, qstring, moves, qfloat, (hipStream_t)stream);
 }
+extern "C" int bh_crf_reverse_complement(const void* in, void* out, int N, int T, int state_len, int layout_5s,
+                                         long stride_n, long stride_t, void* stream) {
+    BH_REQUIRE(in && out, "crf_reverse_complement: null pointer");
+    return bh_k_crf_revcomp(in, out, N, T, state_len, layout_5s, stride_n, stride_t, (hipStream_t)stream);
+}
+extern "C" int bh_crf_logz(const void* scores, int N, int T, int state_len, float blank_score, void* workspace,
+                           double* logz, void* stream) {
+    BH_REQUIRE(scores && workspace && logz, "crf_logz: null pointer");
+    return bh_k_crf_logz(scores, N, T, state_len, blank_score, workspace, logz, (hipStream_t)stream);
+}
 extern "C" size_t bh_crf_viterbi_workspace(int N, int T, int state_len) {
     size_t S = 1;
     for (int i = 0; i < state_len; ++i) S *= 4;

@@ -32,8 +32,13 @@ int bh_k_crf_viterbi(const void* scores, int N, int T, int state_len, int layout
                      long s_n, long s_t, void* bp_ws, float* alpha_ws, int8_t* moves, int8_t* path,
                      float* best_score, hipStream_t stream);
 
+int bh_k_crf_revcomp(const void* in, void* out, int N, int T, int state_len, int layout_5s, long s_n, long s_t,
+                     hipStream_t stream);
+
 // beam.hip
 size_t bh_k_beam_workspace(int N, int T, int state_len);
+int bh_k_crf_logz(const void* scores, int N, int T, int state_len, float blank, void* workspace, double* logz_out,
+                   hipStream_t stream);
 int bh_k_beam_search(const void* scores, int N, int T, int state_len, int beam_width, float beam_cut,
                      float blank, float q_scale, float q_offset, void* workspace, int8_t* sequence,
                      int8_t* qstring, int8_t* moves, float* qfloat, hipStream_t stream);

@@ -165,3 +165,39 @@ def to_str(x, encoding="ascii"):
     a = x.numpy() if isinstance(x, torch.Tensor) else np.asarray(x)
     a = a[a != 0]
     return a.astype(np.uint8).tobytes().decode(encoding)
+
+
+def reverse_complement(scores):
+    """CTC_CRF.reverse_complement (bonito/crf/model.py:84-96) on koi-layout scores cuda fp16 [N, T, 4S]."""
+    _check_scores(scores)
+    N, T, Cc = scores.shape
+    out = torch.empty_like(scores)
+    with torch.cuda.device(scores.device):
+        _lib.check(_lib.lib().bh_crf_reverse_complement(_lib.ptr(scores), _lib.ptr(out), N, T, state_len_of(Cc), 0,
+                                                        T * Cc, Cc, _lib.stream_ptr(scores.device)), "bh_crf_reverse_complement")
+    return out
+
+
+def reverse_complement_5s(scores_tnc, state_len):
+    """Same on the reference layout [T, N, 5S] (cuda fp16)."""
+    scores_tnc = scores_tnc.contiguous()
+    T, N, Cc = scores_tnc.shape
+    out = torch.empty_like(scores_tnc)
+    with torch.cuda.device(scores_tnc.device):
+        _lib.check(_lib.lib().bh_crf_reverse_complement(_lib.ptr(scores_tnc), _lib.ptr(out), N, T, int(state_len), 1,
+                                                        Cc, N * Cc, _lib.stream_ptr(scores_tnc.device)), "bh_crf_reverse_complement")
+    return out
+
+
+def logz(scores, blank_score=2.0):
+    """Log-partition function per chunk (CTC_CRF.logZ, crf/model.py:47-52) of koi-layout scores -> CPU float64 [N]."""
+    _check_scores(scores)
+    N, T, Cc = scores.shape
+    sl = state_len_of(Cc)
+    lib = _lib.lib()
+    ws = torch.empty(lib.bh_beam_search_workspace(N, T, sl), dtype=torch.uint8, device=scores.device)
+    out = torch.empty(N, dtype=torch.float64, device=scores.device)
+    with torch.cuda.device(scores.device):
+        _lib.check(lib.bh_crf_logz(_lib.ptr(scores), N, T, sl, float(blank_score), _lib.ptr(ws), _lib.ptr(out),
+                                   _lib.stream_ptr(scores.device)), "bh_crf_logz")
+    return out.cpu()

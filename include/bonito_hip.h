@@ -134,6 +134,16 @@ int bh_crf_viterbi(const void* scores, int N, int T, int state_len, int layout_5
                    long stride_n, long stride_t, void* workspace, int8_t* moves, int8_t* path,
                    float* best, void* stream);
 
+/* CTC_CRF.reverse_complement (crf/model.py:84-96): permute scores so that decoding yields the reverse-complement
+ * strand.  layout_5s=0: koi layout (stride_n = T*4S, stride_t = 4S for contiguous NTC); layout_5s=1: [T][N][5S]
+ * (stride_n = 5S, stride_t = N*5S).  Out of place. */
+int bh_crf_reverse_complement(const void* in, void* out, int N, int T, int state_len, int layout_5s,
+                              long stride_n, long stride_t, void* stream);
+/* CTC_CRF.logZ (crf/model.py:47-52), Log semiring, on contiguous koi-layout scores: logz[N] (device double).
+ * workspace: bh_beam_search_workspace(N, T, state_len) bytes. */
+int bh_crf_logz(const void* scores, int N, int T, int state_len, float blank_score, void* workspace, double* logz,
+                void* stream);
+
 /* Beam-search decode: drop-in for koi.decode.beam_search(scores, beam_width=32, beam_cut=100.0, scale=1.0,
  * offset=0.0, blank_score=2.0) (bonito/crf/basecall.py:27,36-40).  scores: device fp16 contiguous
  * [N][T][4^(state_len+1)] (koi layout).  Outputs are DEVICE int8 [N][T], zero where nothing is emitted:

@@ -181,3 +181,34 @@ def lse2(a, b):
     f = _lib().oracle_lse2
     f.restype = C.c_float
     return f(C.c_float(a), C.c_float(b))
+
+
+def _rc_digits(j, k):
+    r = 0
+    for _ in range(k):
+        r = (r << 2) | (3 - (j & 3))
+        j >>= 2
+    return r
+
+
+def reverse_complement(scores, state_len, layout_5s=True):
+    """Index-level restatement of CTC_CRF.reverse_complement (bonito/crf/model.py:84-96).
+    layout_5s: [T,N,5S]; else koi layout [N,T,4S]. Pinned against tests/golden/crf_rc.npz (reference output)."""
+    a = np.asarray(scores)
+    S = 4 ** state_len
+    out = np.empty_like(a)
+    if layout_5s:
+        T = a.shape[0]
+        for j2 in range(S):
+            out[:, :, j2 * 5] = a[::-1, :, _rc_digits(j2, state_len) * 5]
+            for r2 in range(4):
+                src = _rc_digits(r2 * S + j2, state_len + 1)
+                r, j = divmod(src, S)
+                out[:, :, j2 * 5 + 1 + r2] = a[::-1, :, j * 5 + 1 + r]
+    else:
+        for j2 in range(S):
+            for r2 in range(4):
+                src = _rc_digits(r2 * S + j2, state_len + 1)
+                r, j = divmod(src, S)
+                out[:, :, j2 * 4 + r2] = a[:, ::-1, j * 4 + r]
+    return out

@@ -87,3 +87,50 @@ def test_decoder_context_reuse_and_ragged_batch():
         assert torch.equal(x, z) and torch.equal(y, z[:4])
     with pytest.raises(ValueError):
         dec.submit(torch.zeros(17, 64, 256, dtype=torch.float16, device="cuda"))
+
+
+def test_basecall_reverse_gives_reverse_complement_calls():
+    """--revcomp path (crf/basecall.py:35, reverse=True): scores are permuted on the device before decoding."""
+    model = _model(996, 4)
+    rng = np.random.default_rng(9)
+    reads = _reads(rng, [3000])
+    (_, fwd), = list(crf_basecall_fn(model, iter(reads), chunksize=996, overlap=96, batchsize=4, decoder="viterbi"))
+    (_, rev), = list(crf_basecall_fn(model, iter(reads), chunksize=996, overlap=96, batchsize=4, decoder="viterbi",
+                                      reverse=True))
+    comp = {"A": "T", "C": "G", "G": "C", "T": "A"}
+    rc = "".join(comp[b] for b in reversed(fwd["sequence"]))
+    import difflib
+    assert difflib.SequenceMatcher(None, rc, rev["sequence"], autojunk=False).ratio() > 0.9
+
+
+def test_load_model_from_directory_roundtrip(tmp_path):
+    """util.load_model: config.toml + weights_N.tar with foreign key names -> HIP model (reference util.py:271-311)."""
+    import json
+    from conftest import load_nn_fixture, ref_scores_to_koi
+    from bonito_amd import util
+    cfg, sd, x, y = load_nn_fixture("lstm64_sl3")
+
+    def toml_value(v):
+        if isinstance(v, bool):
+            return "true" if v else "false"
+        if isinstance(v, str):
+            return json.dumps(v)
+        if isinstance(v, list):
+            return "[" + ", ".join(toml_value(i) for i in v) + "]"
+        return repr(v)
+
+    lines = ['[model]', 'package = "bonito.crf"', '[labels]', 'labels = ["N", "A", "C", "G", "T"]', '[input]',
+             'features = 1', '[global_norm]', 'state_len = 3', '[basecaller]', 'batchsize = 4', 'chunksize = 1200',
+             'overlap = 120', '[encoder]', 'type = "serial"']
+    for sub in cfg["sublayers"]:
+        lines.append("[[encoder.sublayers]]")
+        lines += ["%s = %s" % (k, toml_value(v)) for k, v in sub.items()]
+    (tmp_path / "config.toml").write_text("\n".join(lines) + "\n")
+    renamed = {"module.layer%d" % i: v for i, (k, v) in enumerate(sd.items())}     # match_names + "module." stripping
+    torch.save(renamed, str(tmp_path / "weights_3.tar"))
+    torch.save({}, str(tmp_path / "weights_1.tar"))
+    model = util.load_model(str(tmp_path), "cuda", use_koi=True)
+    assert model.config["basecaller"]["chunksize"] == 1200 and model.config["basecaller"]["overlap"] == 120
+    got = model(x.half().cuda()).cpu().float()
+    assert (got - ref_scores_to_koi(y)).abs().max().item() < 6e-2
+    assert util.load_symbol(str(tmp_path), "basecall") is crf_basecall_fn

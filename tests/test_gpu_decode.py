@@ -140,3 +140,28 @@ def test_beam_search_full_size():
     oseq, oqs, omv, _ = crf_ref.beam_search(sc[idx].cpu().numpy(), 4)
     assert np.array_equal(s[idx], oseq) and np.array_equal(m[idx], omv)
     assert (q[idx] != oqs).mean() < 1e-3
+
+
+# ---- reverse_complement / logZ ----------------------------------------------------------------------
+def test_reverse_complement_kernel_matches_reference_fixture_and_oracle():
+    import os
+    from conftest import GOLDEN
+    z = np.load(os.path.join(GOLDEN, "crf_rc.npz"))
+    for sl in (1, 2, 3):
+        x = torch.from_numpy(z["x%d" % sl]).half()
+        got = decode.reverse_complement_5s(x.cuda(), sl).cpu().float().numpy()
+        assert np.array_equal(got, z["y%d" % sl]), sl                 # reference output (pure permutation -> exact)
+    rng = np.random.default_rng(2)
+    sc = _scores(rng, 3, 50, 1024, "normal")
+    got = decode.reverse_complement(torch.from_numpy(sc).cuda()).cpu().numpy()
+    assert np.array_equal(got, crf_ref.reverse_complement(sc, 4, layout_5s=False))
+
+
+def test_logz_matches_oracle():
+    rng = np.random.default_rng(6)
+    for sl in (2, 3, 4):
+        sc = _scores(rng, 4, 90, 4 ** (sl + 1), "normal")
+        got = decode.logz(torch.from_numpy(sc).cuda()).numpy()
+        _, _, lz = crf_ref.backward(sc, sl)
+        assert np.allclose(got, lz, rtol=0, atol=1e-6 * np.abs(lz).max() + 1e-4)
+        assert np.allclose(got, crf_ref.logz(sc, sl), rtol=0, atol=5e-3)

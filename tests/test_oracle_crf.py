@@ -120,3 +120,33 @@ def test_wide_beam_recovers_planted_sequence():
     _, path, _ = crf_ref.viterbi(x.astype(np.float16), sl)
     assert "".join("NACGT"[p] for p in path[0] if p) == got
     assert np.median(qf[mv == 1]) > 20
+
+
+def test_reverse_complement_matches_reference_fixture():
+    import os
+    from conftest import GOLDEN
+    z = np.load(os.path.join(GOLDEN, "crf_rc.npz"))
+    for sl in (1, 2, 3):
+        got = crf_ref.reverse_complement(z["x%d" % sl], sl, layout_5s=True)
+        assert np.array_equal(got, z["y%d" % sl]), sl
+        # involution
+        assert np.array_equal(crf_ref.reverse_complement(got, sl), z["x%d" % sl])
+
+
+def test_reverse_complement_decodes_to_revcomp_sequence():
+    """Paths map one-to-one with equal total score, so the best score is preserved and the Viterbi basecall
+    of the permuted scores is the reverse complement of the original (up to the k-mer context at the ends)."""
+    rng = np.random.default_rng(21)
+    sl = 3
+    sc = _scores(rng, 80, 2, 4 * 64).transpose(1, 0, 2).copy()          # koi layout [N,T,4S]
+    _, p_fwd, b_fwd = crf_ref.viterbi(sc, sl)
+    rc = crf_ref.reverse_complement(sc, sl, layout_5s=False)
+    _, p_rev, b_rev = crf_ref.viterbi(rc, sl)
+    assert np.allclose(b_fwd, b_rev, rtol=0, atol=1e-3)
+    comp = {1: 4, 2: 3, 3: 2, 4: 1}
+    for n in range(2):
+        fwd = "".join("NACGT"[comp[b]] for b in reversed([b for b in p_fwd[n] if b]))
+        rev = "".join("NACGT"[b] for b in p_rev[n] if b)
+        core = fwd[sl:-sl]
+        assert len(core) > 10 and core in rev, (fwd, rev)
+    assert np.array_equal(crf_ref.reverse_complement(rc, sl, layout_5s=False), sc)      # involution
