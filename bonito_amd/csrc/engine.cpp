@@ -155,6 +155,7 @@ struct bh_encoder {
     int rot_len = 0;
     int out_features = 0;
     int lstm_force_slow = 0;
+    int lstm_fused = 1;          // compute the input projection inside the recurrence kernel when insize == hidden
     // optional per-kernel-class timing with HIP events on the caller's stream (bench.py roofline leg)
     bool profiling = false;
     struct Span { int cls; hipEvent_t a, b; };
@@ -337,6 +338,11 @@ extern "C" int bh_encoder_create(const bh_layer_t* layers, int n_layers, int dev
                     std::vector<float> b((size_t)4 * H, 0.0f);
                     for (int j = 0; j < 4 * H; ++j) b[j] = (d.b0 ? d.b0[j] : 0.0f) + (d.b1 ? d.b1[j] : 0.0f);
                     rc = upload_f32(L.b0, b.data(), b.size());
+                }
+                if (!rc && I == H) {      // fragment-packed W_ih for the fused kernel
+                    std::vector<uint16_t> pk((size_t)4 * H * H);
+                    rc = bh_lstm_pack_whh(d.w0, H, pk.data());
+                    if (!rc) rc = upload(L.w2, pk.data(), pk.size() * 2);
                 }
                 break;
             }
@@ -581,7 +587,8 @@ extern "C" int bh_encoder_forward(bh_encoder_t* e, const void* signal, int N, in
                 const int M = len * Np;
                 int rc;
                 void* dst = e->act[which].p;
-                {
+                const bool fused = e->lstm_fused && d.in_size == H && l.w2.p != nullptr;
+                if (!fused) {
                     ProfSpan span(e, st, BH_PROF_LSTM_GEMM);
                     rc = bh_k_linear(cur, l.w0.p, (const float*)l.b0.p, e->gates.p, M, 4 * H, d.in_size, d.in_size,
                                      d.in_size, 4 * H, bh::ACT_NONE, 1.0f, -INFINITY, INFINITY, 0, 0, 0, 0, 0, st);
@@ -602,9 +609,14 @@ extern "C" int bh_encoder_forward(bh_encoder_t* e, const void* signal, int N, in
                 for (int r0 = 0; r0 < n_rings; r0 += rings_per_launch) {
                     const int nr = std::min(rings_per_launch, n_rings - r0);
                     const size_t col = (size_t)r0 * 16;
-                    rc = bh_k_lstm_layer((const char*)e->gates.p + col * 4 * H * 2, l.w1.p,
-                                         (char*)dst + col * H * 2, len, Np, H, d.reverse, (int*)e->err.p, st, nr,
-                                         (int*)e->lstm_ws.p, e->lstm_force_slow);
+                    if (fused)
+                        rc = bh_k_lstm_layer_fused((const char*)cur + col * H * 2, l.w2.p, (const float*)l.b0.p, l.w1.p,
+                                                   (char*)dst + col * H * 2, len, Np, H, d.reverse, (int*)e->err.p, st, nr,
+                                                   (int*)e->lstm_ws.p, e->lstm_force_slow);
+                    else
+                        rc = bh_k_lstm_layer((const char*)e->gates.p + col * 4 * H * 2, l.w1.p,
+                                             (char*)dst + col * H * 2, len, Np, H, d.reverse, (int*)e->err.p, st, nr,
+                                             (int*)e->lstm_ws.p, e->lstm_force_slow);
                     if (rc) return rc;
                 }
                 cur = dst; which ^= 1; C = H;
@@ -811,6 +823,7 @@ extern "C" int bh_lstm_layer(const void* gates_in, const void* whh_packed, void*
 extern "C" int bh_encoder_set_option(bh_encoder_t* e, const char* name, int value) {
     BH_REQUIRE(e && name, "encoder_set_option: null argument");
     if (!strcmp(name, "lstm_force_slow")) { e->lstm_force_slow = value; return 0; }
+    if (!strcmp(name, "lstm_fused")) { e->lstm_fused = value; return 0; }
     BH_REQUIRE(false, "encoder_set_option: unknown option '%s'", name);
 }
 extern "C" size_t bh_beam_search_workspace(int N, int T, int state_len) { return bh_k_beam_workspace(N, T, state_len); }

@@ -179,6 +179,162 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_kernel(LstmArgs p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Fused variant: the input projection x_t W_ih^T + b is computed INSIDE the recurrence instead of by a
+// separate GEMM. x_t (the previous layer's output, available for all t up front) is prefetched one step
+// ahead and its 4 x NKS MFMAs run while the wave would otherwise be waiting for h_{t-1} from the other
+// CUs, so they are free; the G tensor (T*N*4H fp16 = 2.6 GB per hac layer) is never written or read and
+// one GEMM launch per layer disappears. W_ih's fragments for this workgroup's 16 hidden units live in
+// LDS (4*NKS KiB, shared by the 4 waves of the workgroup, which serve 4 different rings of the SAME slice);
+// W_hh stays in registers. Requires input size == hidden size (true for every LSTM layer of the CRF models).
+struct LstmFusedArgs {
+    const half_t* x;     // [T][N][H] layer input (time-major)
+    const half_t* wih;   // packed fragments like whh
+    const float* bias;   // [4H] b_ih + b_hh
+    LstmArgs a;          // G unused
+};
+
+template <int NKS>
+__global__ __launch_bounds__(256, 1) void lstm_layer_fused_kernel(LstmFusedArgs fp) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const LstmArgs& p = fp.a;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    constexpr int H = NKS * 32;
+    constexpr int NSL = H / 16;
+    const int xcd = blockIdx.x & 7;
+    const int lwg = blockIdx.x >> 3;
+    const int rg = lwg / NSL;
+    const int slice = lwg - rg * NSL;
+    const int ring = (rg * 4 + wave) * 8 + xcd;
+
+    // ---- W_ih fragments of this slice -> LDS (all 256 threads, before any wave may leave) -------------
+    {
+        const uint4_t* src = (const uint4_t*)(fp.wih + (long)slice * 4 * NKS * 64 * 8);
+        uint4_t* dst = (uint4_t*)smem;
+        for (int i = threadIdx.x; i < 4 * NKS * 64; i += 256) dst[i] = src[i];
+    }
+    __syncthreads();
+    if (ring >= p.n_rings) return;
+
+    half8_t w[4][NKS];
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks)
+            w[g][ks] = *(const half8_t*)(p.whh + ((((long)slice * 4 + g) * NKS + ks) * 64 + lane) * 8);
+
+    const int c = lane & 15, q = lane >> 4;
+    const int n = ring * 16 + c;
+    const int hu0 = slice * 16 + q * 4;
+    const long row_bytes = (long)p.N * H * 2;
+    const unsigned voff = (unsigned)(((ring * 16 + c) * H + q * 8) * 2);
+    float cst[4] = {0.f, 0.f, 0.f, 0.f};
+    bool dead = false;
+    float4_t bias4[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) bias4[g][i] = fp.bias[g * H + hu0 + i];
+
+    bool fast = false;
+    {
+        int* slot = p.xcc_ws + (long)ring * NSL;
+        const int mine = xcc_id();
+        if (lane == 0) __hip_atomic_store(slot + slice, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned spins = 0;
+        bool ok = false;
+        while (true) {
+            int v = (lane < NSL) ? __hip_atomic_load(slot + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : mine;
+            if (!__any(v < 0)) { ok = !__any(v != mine); break; }
+            if (++spins > p.max_spins) break;
+            __builtin_amdgcn_s_sleep(4);
+        }
+        fast = ok && !p.force_slow;
+    }
+
+    int t = p.reverse ? p.T - 1 : 0;
+    const int dt = p.reverse ? -1 : 1;
+    const half_t* xptr = fp.x + ((long)(ring * 16 + c) * H + q * 8);
+    const long x_row = (long)p.N * H;
+    const char* wl = smem + lane * 16;
+
+    uint4_t xf[NKS];
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) xf[ks] = *(const uint4_t*)(xptr + (long)t * x_row + ks * 32);
+
+    for (int step = 0; step < p.T; ++step, t += dt) {
+        // ---- input projection of THIS step (operands were prefetched during the previous step) ---------
+        float4_t acc[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) acc[g] = bias4[g];
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+            const half8_t b = __builtin_bit_cast(half8_t, xf[ks]);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const half8_t a = *(const half8_t*)(wl + (g * NKS + ks) * 1024);
+                acc[g] = mfma16(a, b, acc[g]);
+            }
+        }
+        // ---- prefetch x of the next step into the same registers (in flight while we wait for h) -------
+        {
+            const int tn = (step + 1 < p.T) ? t + dt : t;
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) xf[ks] = *(const uint4_t*)(xptr + (long)tn * x_row + ks * 32);
+        }
+        if (step > 0) {
+            const char* base = (const char*)p.h + (long)(t - dt) * row_bytes;
+            __amdgpu_buffer_rsrc_t rs =
+                __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)row_bytes, 0x00020000);
+            uint4_t hf[NKS];
+            unsigned spins = dead ? p.max_spins : 0u;
+            unsigned pend = (NKS >= 32) ? 0xffffffffu : ((1u << NKS) - 1u);
+            while (true) {
+#pragma unroll
+                for (int ks = 0; ks < NKS; ++ks)
+                    if (pend & (1u << ks))
+                        hf[ks] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff + ks * 64, 0, (int)0x80000010);
+#pragma unroll
+                for (int ks = 0; ks < NKS; ++ks)
+                    if (pend & (1u << ks)) {
+                        unsigned orv = hf[ks].x | hf[ks].y | hf[ks].z | hf[ks].w;
+                        if (!__any((orv & SENTINEL_MASK) != 0)) pend &= ~(1u << ks);
+                    }
+                if (pend == 0) break;
+                if (++spins > p.max_spins) {
+                    if (lane == 0 && !dead) atomicExch(p.err, 1);
+                    dead = true;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(1);
+            }
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) {
+                half8_t b = __builtin_bit_cast(half8_t, hf[ks]);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) acc[g] = mfma16(w[g][ks], b, acc[g]);
+            }
+        }
+        half4_t ho;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float ig = sigmoidf_(acc[0][i]);
+            float fg = sigmoidf_(acc[1][i]);
+            float gg = tanhf_(acc[2][i]);
+            float og = sigmoidf_(acc[3][i]);
+            cst[i] = fg * cst[i] + ig * gg;
+            float hv = og * tanhf_(cst[i]);
+            hv = (fabsf(hv) <= 1.0f) ? hv : 0.0f;
+            ho[i] = (half_t)hv;
+        }
+        unsigned long long packed = __builtin_bit_cast(unsigned long long, ho);
+        unsigned long long* dst = (unsigned long long*)(p.h + ((long)t * p.N + n) * H + hu0);
+        if (fast) *dst = packed;
+        else __hip_atomic_store(dst, packed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
 __global__ void fill_u16_kernel(uint16_t* dst, uint16_t v, size_t count) {
     size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 8;
     const size_t stride = (size_t)gridDim.x * blockDim.x * 8;
@@ -228,6 +384,46 @@ int bh_k_lstm_layer(const void* gates_in, const void* whh_packed, void* h_out, i
                reverse, err_flag, 1000000u, xcc_ws, force_slow};
 #define BH_LSTM_CASE(NKS) \
     case NKS: hipLaunchKernelGGL(lstm_layer_kernel<NKS>, dim3(grid), dim3(256), 0, stream, a); break;
+    switch (H / 32) {
+        BH_LSTM_CASE(1) BH_LSTM_CASE(2) BH_LSTM_CASE(3) BH_LSTM_CASE(4) BH_LSTM_CASE(5) BH_LSTM_CASE(6)
+        BH_LSTM_CASE(7) BH_LSTM_CASE(8) BH_LSTM_CASE(9) BH_LSTM_CASE(10) BH_LSTM_CASE(11) BH_LSTM_CASE(12)
+        BH_LSTM_CASE(13) BH_LSTM_CASE(14) BH_LSTM_CASE(15) BH_LSTM_CASE(16)
+        default: BH_REQUIRE(false, "lstm: unsupported H=%d", H);
+    }
+#undef BH_LSTM_CASE
+    BH_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+int bh_k_lstm_layer_fused(const void* x, const void* wih_packed, const float* bias, const void* whh_packed, void* h_out,
+                          int T, int N, int H, int reverse, int* err_flag, hipStream_t stream, int n_rings, int* xcc_ws,
+                          int force_slow) {
+    using namespace bh;
+    BH_REQUIRE(N % 16 == 0, "lstm: batch must be padded to a multiple of 16 (N=%d)", N);
+    BH_REQUIRE(H % 32 == 0 && H >= 32 && H <= 512, "lstm: register-resident kernel needs H%%32==0, 32<=H<=512 (H=%d)", H);
+    BH_REQUIRE(x != h_out, "lstm: fused layer cannot run in place");
+    int dev = 0, cus = 0;
+    BH_CHECK_HIP(hipGetDevice(&dev));
+    BH_CHECK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    const int nsl = H / 16;
+    BH_REQUIRE(n_rings > 0 && n_rings <= N / 16, "lstm: n_rings=%d outside 1..%d", n_rings, N / 16);
+    const int rl = (n_rings + 7) / 8;
+    const int groups = (rl + 3) / 4;
+    const int grid = 8 * groups * nsl;
+    BH_REQUIRE(grid <= cus, "lstm: %d workgroups must be co-resident but the device has %d CUs; split the batch", grid, cus);
+    BH_REQUIRE(xcc_ws != nullptr, "lstm: missing XCD agreement workspace");
+    BH_CHECK_HIP(hipMemsetAsync(xcc_ws, 0xFF, (size_t)n_rings * nsl * sizeof(int), stream));
+    LstmFusedArgs a{(const half_t*)x, (const half_t*)wih_packed, bias,
+                    LstmArgs{nullptr, (const half_t*)whh_packed, (half_t*)h_out, T, N, H, n_rings, reverse, err_flag, 1000000u,
+                             xcc_ws, force_slow}};
+    const size_t lds = (size_t)(H / 32) * 4096;
+#define BH_LSTM_CASE(NKS)                                                                                        \
+    case NKS:                                                                                                    \
+        if (lds > 64 * 1024)                                                                                     \
+            BH_CHECK_HIP(hipFuncSetAttribute((const void*)lstm_layer_fused_kernel<NKS>,                          \
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));            \
+        hipLaunchKernelGGL(lstm_layer_fused_kernel<NKS>, dim3(grid), dim3(256), lds, stream, a);                 \
+        break;
     switch (H / 32) {
         BH_LSTM_CASE(1) BH_LSTM_CASE(2) BH_LSTM_CASE(3) BH_LSTM_CASE(4) BH_LSTM_CASE(5) BH_LSTM_CASE(6)
         BH_LSTM_CASE(7) BH_LSTM_CASE(8) BH_LSTM_CASE(9) BH_LSTM_CASE(10) BH_LSTM_CASE(11) BH_LSTM_CASE(12)

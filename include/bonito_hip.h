@@ -110,7 +110,7 @@ int bh_encoder_output_shape(const bh_encoder_t* enc, int L, int* T, int* C, int*
 /* signal: device fp16 [N][L] (the reference's [N,1,L] batch, bonito/crf/basecall.py:33).
  * scores: device fp16, contiguous [N][T][C] (the layout koi.decode.beam_search consumes). */
 int bh_encoder_forward(bh_encoder_t* enc, const void* signal, int N, int L, void* scores, void* stream);
-/* tuning / test options: "lstm_force_slow" (0/1) */
+/* tuning / test options: "lstm_force_slow" (0/1), "lstm_fused" (0/1, default 1: input projection inside the recurrence) */
 int bh_encoder_set_option(bh_encoder_t* enc, const char* name, int value);
 /* non-zero if a device-side timeout was raised by a persistent kernel since the last call (synchronises stream) */
 int bh_encoder_check(bh_encoder_t* enc, void* stream);

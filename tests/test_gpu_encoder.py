@@ -107,3 +107,25 @@ def test_transformer_encoder_matches_reference_fixture(name):
     rng = want.abs().max().item()
     assert d.max().item() < 2e-2 * max(rng, 1.0) and d.mean().item() < 3e-3 * max(rng, 1.0), (d.max().item(), d.mean().item(), rng)
     assert model.stride == 6
+
+
+def test_fused_and_unfused_lstm_paths_agree():
+    """The fused kernel (input projection inside the recurrence) and the GEMM + recurrence pair are two
+    implementations of the same layer: both must match the reference fixture; they differ only by the fp16
+    rounding of the intermediate gate tensor."""
+    cfg, sd, x, y = load_nn_fixture("lstm96_sl3")
+    model = build_model(cfg, sd)
+    want = ref_scores_to_koi(y)
+    outs = {}
+    for fused in (1, 0):
+        enc = HipEncoder(model, batchsize=x.shape[0], chunksize=x.shape[-1])
+        enc.set_option("lstm_fused", fused)
+        outs[fused] = enc(x.half().cuda()).cpu().float()
+        enc.check()
+        assert (outs[fused] - want).abs().max().item() < TOL_MAX
+    assert (outs[0] - outs[1]).abs().max().item() < 2e-2
+    enc = HipEncoder(model, batchsize=x.shape[0], chunksize=x.shape[-1])
+    enc.set_option("lstm_force_slow", 1)
+    slow = enc(x.half().cuda()).cpu().float()
+    enc.check()
+    assert torch.equal(slow, outs[1])               # exchange policy never changes the bytes
