@@ -324,8 +324,9 @@ extern "C" int bh_encoder_create(const bh_layer_t* layers, int n_layers, int dev
             case BH_LAYER_LSTM: {
                 const int H = d.out_size, I = d.in_size;
                 if (!(d.w0 && d.w1 && H > 0 && I > 0)) { bh_set_error("encoder_create: layer %d: malformed lstm", i); return fail(-2); }
-                if (H % 32 != 0 || H > 512 || I % 8 != 0) {
-                    bh_set_error("encoder_create: layer %d: lstm needs hidden %% 32 == 0, hidden <= 512, insize %% 8 == 0 (got %d, %d)", i, H, I);
+                const bool reg_ok = H % 32 == 0 && H <= 512, stream_ok = H % 64 == 0 && H <= 1024;
+                if (!(reg_ok || stream_ok) || I % 8 != 0) {
+                    bh_set_error("encoder_create: layer %d: lstm needs hidden %% 32 == 0 (<= 512) or %% 64 == 0 (<= 1024), insize %% 8 == 0 (got %d, %d)", i, H, I);
                     return fail(-2);
                 }
                 rc = upload_f16(L.w0, d.w0, (size_t)4 * H * I);
@@ -339,7 +340,7 @@ extern "C" int bh_encoder_create(const bh_layer_t* layers, int n_layers, int dev
                     for (int j = 0; j < 4 * H; ++j) b[j] = (d.b0 ? d.b0[j] : 0.0f) + (d.b1 ? d.b1[j] : 0.0f);
                     rc = upload_f32(L.b0, b.data(), b.size());
                 }
-                if (!rc && I == H) {      // fragment-packed W_ih for the fused kernel
+                if (!rc && I == H && reg_ok) {      // fragment-packed W_ih for the fused kernel
                     std::vector<uint16_t> pk((size_t)4 * H * H);
                     rc = bh_lstm_pack_whh(d.w0, H, pk.data());
                     if (!rc) rc = upload(L.w2, pk.data(), pk.size() * 2);
@@ -457,7 +458,7 @@ extern "C" int bh_encoder_create(const bh_layer_t* layers, int n_layers, int dev
     for (const auto& l : e->layers) has_res |= l.d.kind == BH_LAYER_RESIDUAL_PROJ;
     if (has_res && e->res.alloc(ab + 256)) return fail(-1);
     if (e->act[0].alloc(ab + 256) || e->act[1].alloc(ab + 256) || e->gates.alloc(gb + 256) ||
-        e->sig.alloc((size_t)Np * max_chunk * 2) || e->err.alloc(sizeof(int)) || e->lstm_ws.alloc(bh_k_lstm_ws_bytes(Np, 512)))
+        e->sig.alloc((size_t)Np * max_chunk * 2) || e->err.alloc(sizeof(int)) || e->lstm_ws.alloc(bh_k_lstm_ws_bytes(Np, 1024)))
         return fail(-1);
     {   // transformer workspace: sized by walking to each transformer layer's token count
         long len = max_chunk;
@@ -587,7 +588,8 @@ extern "C" int bh_encoder_forward(bh_encoder_t* e, const void* signal, int N, in
                 const int M = len * Np;
                 int rc;
                 void* dst = e->act[which].p;
-                const bool fused = e->lstm_fused && d.in_size == H && l.w2.p != nullptr;
+                const bool reg_path = H <= 512 && H % 32 == 0;
+                const bool fused = reg_path && e->lstm_fused && d.in_size == H && l.w2.p != nullptr;
                 if (!fused) {
                     ProfSpan span(e, st, BH_PROF_LSTM_GEMM);
                     rc = bh_k_linear(cur, l.w0.p, (const float*)l.b0.p, e->gates.p, M, 4 * H, d.in_size, d.in_size,
@@ -602,9 +604,9 @@ extern "C" int bh_encoder_forward(bh_encoder_t* e, const void* signal, int N, in
                 ProfSpan span(e, st, BH_PROF_LSTM_REC);
                 // co-residency: one launch serves at most (CUs / (8 * H/16)) * 32 rings
                 const int nsl = H / 16;
-                const int groups_fit = e->n_cus / (8 * nsl);
+                const int groups_fit = reg_path ? e->n_cus / (8 * nsl) : e->n_cus / (8 * (nsl / 4));
                 BH_REQUIRE(groups_fit >= 1, "encoder_forward: device has too few CUs (%d) for hidden size %d", e->n_cus, H);
-                const int rings_per_launch = groups_fit * 32;
+                const int rings_per_launch = reg_path ? groups_fit * 32 : groups_fit * 8;
                 const int n_rings = Np / 16;
                 for (int r0 = 0; r0 < n_rings; r0 += rings_per_launch) {
                     const int nr = std::min(rings_per_launch, n_rings - r0);
@@ -613,10 +615,14 @@ extern "C" int bh_encoder_forward(bh_encoder_t* e, const void* signal, int N, in
                         rc = bh_k_lstm_layer_fused((const char*)cur + col * H * 2, l.w2.p, (const float*)l.b0.p, l.w1.p,
                                                    (char*)dst + col * H * 2, len, Np, H, d.reverse, (int*)e->err.p, st, nr,
                                                    (int*)e->lstm_ws.p, e->lstm_force_slow);
-                    else
+                    else if (reg_path)
                         rc = bh_k_lstm_layer((const char*)e->gates.p + col * 4 * H * 2, l.w1.p,
                                              (char*)dst + col * H * 2, len, Np, H, d.reverse, (int*)e->err.p, st, nr,
                                              (int*)e->lstm_ws.p, e->lstm_force_slow);
+                    else
+                        rc = bh_k_lstm_layer_stream((const char*)e->gates.p + col * 4 * H * 2, l.w1.p,
+                                                    (char*)dst + col * H * 2, len, Np, H, d.reverse, (int*)e->err.p, st, nr,
+                                                    (int*)e->lstm_ws.p, e->lstm_force_slow);
                     if (rc) return rc;
                 }
                 cur = dst; which ^= 1; C = H;
@@ -817,6 +823,20 @@ extern "C" int bh_lstm_layer(const void* gates_in, const void* whh_packed, void*
     BH_REQUIRE(T > 0, "lstm_layer: T must be positive");
     int rc = bh_k_fill_u16(h_out, 0xFFFFu, (size_t)T * N * H, (hipStream_t)stream);
     if (rc) return rc;
+    if (H > 512 || (flags & 2)) {     // flags bit 1: force the weight-streaming kernel
+        int dev = 0, cus = 0;
+        BH_CHECK_HIP(hipGetDevice(&dev));
+        BH_CHECK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+        const int per = std::max(1, cus / (8 * (H / 64))) * 8;
+        for (int r0 = 0; r0 < N / 16; r0 += per) {
+            const int nr = std::min(per, N / 16 - r0);
+            rc = bh_k_lstm_layer_stream((const char*)gates_in + (size_t)r0 * 16 * 4 * H * 2, whh_packed,
+                                        (char*)h_out + (size_t)r0 * 16 * H * 2, T, N, H, reverse, err_flag,
+                                        (hipStream_t)stream, nr, (int*)workspace, flags & 1);
+            if (rc) return rc;
+        }
+        return 0;
+    }
     return bh_k_lstm_layer(gates_in, whh_packed, h_out, T, N, H, reverse, err_flag, (hipStream_t)stream, N / 16,
                            (int*)workspace, flags & 1);
 }

@@ -24,6 +24,8 @@ int bh_k_conv_igemm(const void* in, const void* wpk, const float* bias, void* ou
 int bh_k_lstm_layer(const void* gates_in, const void* whh_packed, void* h_out, int T, int N, int H,
                     int reverse, int* err_flag, hipStream_t stream, int n_rings, int* xcc_ws, int force_slow);
 size_t bh_k_lstm_ws_bytes(int N, int H);
+int bh_k_lstm_layer_stream(const void* gates_in, const void* whh_packed, void* h_out, int T, int N, int H,
+                           int reverse, int* err_flag, hipStream_t stream, int n_rings, int* xcc_ws, int force_slow);
 int bh_k_lstm_layer_fused(const void* x, const void* wih_packed, const float* bias, const void* whh_packed, void* h_out,
                           int T, int N, int H, int reverse, int* err_flag, hipStream_t stream, int n_rings, int* xcc_ws,
                           int force_slow);

@@ -180,6 +180,132 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_kernel(LstmArgs p) {
 }
 
 // ---------------------------------------------------------------------------------------------------
+// Weight-streaming variant for hidden sizes the register file cannot hold (H > 512: the 768-wide old-style
+// r9.4.1 models, the 1024-wide v4.3 `sup`). Same ring exchange protocol; the W_hh fragments are re-read from
+// L2 / Infinity Cache every step instead of living in registers, and a workgroup serves 4 slices of ONE ring.
+// Slower per step than the register-resident kernel, but correct for any H % 64 == 0.
+template <int NKS>
+__global__ __launch_bounds__(256, 1) void lstm_layer_stream_kernel(LstmArgs p) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    constexpr int H = NKS * 32;
+    constexpr int NSL = H / 16;  // slices == waves per ring
+    // block -> (xcd, ring, group of 4 slices); wave -> slice inside the group. Nothing is register resident,
+    // so a ring costs only NSL/4 workgroups and any hidden size that is a multiple of 64 fits the device.
+    const int xcd = blockIdx.x & 7;
+    const int lwg = blockIdx.x >> 3;
+    constexpr int WPR = NSL / 4;          // workgroups per ring
+    const int rl = lwg / WPR;
+    const int slice = (lwg - rl * WPR) * 4 + wave;
+    const int ring = rl * 8 + xcd;
+    if (ring >= p.n_rings) return;
+    const half_t* wbase = p.whh + ((long)slice * 4 * NKS * 64 + lane) * 8;
+
+    const int c = lane & 15, q = lane >> 4;
+    const int n = ring * 16 + c;
+    const int hu0 = slice * 16 + q * 4;
+    const long row_bytes = (long)p.N * H * 2;           // one time step of h
+    const unsigned voff = (unsigned)(((ring * 16 + c) * H + q * 8) * 2);
+    float cst[4] = {0.f, 0.f, 0.f, 0.f};
+    bool dead = false;
+
+    // ---- XCD agreement: publish my XCC id, read the ring's ids, fast policy iff all equal -------
+    bool fast = false;
+    {
+        int* slot = p.xcc_ws + (long)ring * NSL;
+        const int mine = xcc_id();
+        if (lane == 0) __hip_atomic_store(slot + slice, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned spins = 0;
+        bool ok = false;
+        while (true) {
+            int v = (lane < NSL) ? __hip_atomic_load(slot + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : mine;
+            if (!__any(v < 0)) { ok = !__any(v != mine); break; }
+            if (++spins > p.max_spins) break;     // not an error: fall back to the safe policy
+            __builtin_amdgcn_s_sleep(4);
+        }
+        fast = ok && !p.force_slow;
+    }
+
+    const long g_row = (long)p.N * 4 * H;
+    const half_t* gptr = p.G + (long)n * 4 * H + hu0;
+    int t = p.reverse ? p.T - 1 : 0;
+    const int dt = p.reverse ? -1 : 1;
+
+    half4_t gin[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) gin[g] = *(const half4_t*)(gptr + (long)t * g_row + g * H);
+
+    for (int step = 0; step < p.T; ++step, t += dt) {
+        // prefetch next step's input projection (independent of the recurrence)
+        half4_t gnx[4];
+        {
+            int tn = (step + 1 < p.T) ? t + dt : t;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) gnx[g] = *(const half4_t*)(gptr + (long)tn * g_row + g * H);
+        }
+        float4_t acc[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) acc[g] = float4_t{0.f, 0.f, 0.f, 0.f};
+
+        if (step > 0) {
+            const char* base = (const char*)p.h + (long)(t - dt) * row_bytes;
+            __amdgpu_buffer_rsrc_t rs =
+                __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)row_bytes, 0x00020000);
+            uint4_t hf[NKS];
+            unsigned spins = dead ? p.max_spins : 0u;   // after one timeout never wait again
+            unsigned pend = (NKS >= 32) ? 0xffffffffu : ((1u << NKS) - 1u);   // wave-uniform
+            while (true) {
+#pragma unroll
+                for (int ks = 0; ks < NKS; ++ks)
+                    if (pend & (1u << ks))
+                        hf[ks] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff + ks * 64, 0, (int)0x80000010 /*sc1 + volatile*/);
+#pragma unroll
+                for (int ks = 0; ks < NKS; ++ks)
+                    if (pend & (1u << ks)) {
+                        unsigned orv = hf[ks].x | hf[ks].y | hf[ks].z | hf[ks].w;
+                        if (!__any((orv & SENTINEL_MASK) != 0)) pend &= ~(1u << ks);
+                    }
+                if (pend == 0) break;
+                if (++spins > p.max_spins) {
+                    if (lane == 0 && !dead) atomicExch(p.err, 1);
+                    dead = true;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(1);
+            }
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) {
+                half8_t b = __builtin_bit_cast(half8_t, hf[ks]);
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    acc[g] = mfma16(*(const half8_t*)(wbase + (long)(g * NKS + ks) * 512), b, acc[g]);
+            }
+        }
+
+        half4_t ho;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float ig = sigmoidf_(acc[0][i] + (float)gin[0][i]);
+            float fg = sigmoidf_(acc[1][i] + (float)gin[1][i]);
+            float gg = tanhf_(acc[2][i] + (float)gin[2][i]);
+            float og = sigmoidf_(acc[3][i] + (float)gin[3][i]);
+            cst[i] = fg * cst[i] + ig * gg;
+            float hv = og * tanhf_(cst[i]);
+            // keep the sentinel space clean: a non-finite or out-of-range h can never be published
+            hv = (fabsf(hv) <= 1.0f) ? hv : 0.0f;
+            ho[i] = (half_t)hv;
+        }
+        unsigned long long packed = __builtin_bit_cast(unsigned long long, ho);
+        unsigned long long* dst =
+            (unsigned long long*)(p.h + ((long)t * p.N + n) * H + hu0);
+        if (fast) *dst = packed;                                                       // stays in this XCD's L2
+        else __hip_atomic_store(dst, packed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // sc1 write-through
+#pragma unroll
+        for (int g = 0; g < 4; ++g) gin[g] = gnx[g];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // Fused variant: the input projection x_t W_ih^T + b is computed INSIDE the recurrence instead of by a
 // separate GEMM. x_t (the previous layer's output, available for all t up front) is prefetched one step
 // ahead and its 4 x NKS MFMAs run while the wave would otherwise be waiting for h_{t-1} from the other
@@ -391,6 +517,39 @@ int bh_k_lstm_layer(const void* gates_in, const void* whh_packed, void* h_out, i
         default: BH_REQUIRE(false, "lstm: unsupported H=%d", H);
     }
 #undef BH_LSTM_CASE
+    BH_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+int bh_k_lstm_layer_stream(const void* gates_in, const void* whh_packed, void* h_out, int T, int N, int H,
+                           int reverse, int* err_flag, hipStream_t stream, int n_rings, int* xcc_ws, int force_slow) {
+    using namespace bh;
+    BH_REQUIRE(N % 16 == 0, "lstm: batch must be padded to a multiple of 16 (N=%d)", N);
+    BH_REQUIRE(H % 64 == 0 && H >= 64 && H <= 1024, "lstm: streaming kernel needs H%%64==0, 64<=H<=1024 (H=%d)", H);
+    int dev = 0, cus = 0;
+    BH_CHECK_HIP(hipGetDevice(&dev));
+    BH_CHECK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    const int nsl = H / 16, wpr = nsl / 4;
+    BH_REQUIRE(n_rings > 0 && n_rings <= N / 16, "lstm: n_rings=%d outside 1..%d", n_rings, N / 16);
+    const int rl = (n_rings + 7) / 8;
+    const int grid = 8 * rl * wpr;
+    BH_REQUIRE(grid <= cus, "lstm: %d workgroups must be co-resident but the device has %d CUs; split the batch", grid, cus);
+    BH_REQUIRE(xcc_ws != nullptr, "lstm: missing XCD agreement workspace");
+    BH_CHECK_HIP(hipMemsetAsync(xcc_ws, 0xFF, (size_t)n_rings * nsl * sizeof(int), stream));
+    LstmArgs a{(const half_t*)gates_in, (const half_t*)whh_packed, (half_t*)h_out, T, N, H, n_rings,
+               reverse, err_flag, 1000000u, xcc_ws, force_slow};
+    switch (H / 32) {
+        case 2: hipLaunchKernelGGL(lstm_layer_stream_kernel<2>, dim3(grid), dim3(256), 0, stream, a); break;
+        case 4: hipLaunchKernelGGL(lstm_layer_stream_kernel<4>, dim3(grid), dim3(256), 0, stream, a); break;
+        case 8: hipLaunchKernelGGL(lstm_layer_stream_kernel<8>, dim3(grid), dim3(256), 0, stream, a); break;
+        case 12: hipLaunchKernelGGL(lstm_layer_stream_kernel<12>, dim3(grid), dim3(256), 0, stream, a); break;
+        case 16: hipLaunchKernelGGL(lstm_layer_stream_kernel<16>, dim3(grid), dim3(256), 0, stream, a); break;
+        case 20: hipLaunchKernelGGL(lstm_layer_stream_kernel<20>, dim3(grid), dim3(256), 0, stream, a); break;
+        case 24: hipLaunchKernelGGL(lstm_layer_stream_kernel<24>, dim3(grid), dim3(256), 0, stream, a); break;
+        case 28: hipLaunchKernelGGL(lstm_layer_stream_kernel<28>, dim3(grid), dim3(256), 0, stream, a); break;
+        case 32: hipLaunchKernelGGL(lstm_layer_stream_kernel<32>, dim3(grid), dim3(256), 0, stream, a); break;
+        default: BH_REQUIRE(false, "lstm: unsupported H=%d for the streaming kernel", H);
+    }
     BH_CHECK_HIP(hipGetLastError());
     return 0;
 }

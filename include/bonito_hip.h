@@ -198,7 +198,8 @@ int bh_rmsnorm_residual(const void* a, const void* x, const float* w, void* out,
 int bh_lstm_pack_whh(const float* whh, int H, uint16_t* packed);
 /* one LSTM layer over gates_in = x W_ih^T + b (fp16 [T][N][4H], torch gate order); h_out fp16 [T][N][H].
  * N % 16 == 0.  workspace: bh_lstm_workspace(N, H) device bytes.  err_flag: device int, set non-zero on a
- * device-side timeout.  flags bit 0: force the placement-independent write-through exchange policy. */
+ * device-side timeout.  flags bit 0: force the placement-independent write-through exchange policy;
+ * bit 1: force the weight-streaming kernel (always used for H > 512; needs H % 64 == 0, H <= 1024). */
 size_t bh_lstm_workspace(int N, int H);
 int bh_lstm_layer(const void* gates_in, const void* whh_packed, void* h_out, int T, int N, int H,
                   int reverse, void* workspace, int* err_flag, int flags, void* stream);

@@ -129,3 +129,20 @@ def test_fused_and_unfused_lstm_paths_agree():
     slow = enc(x.half().cuda()).cpu().float()
     enc.check()
     assert torch.equal(slow, outs[1])               # exchange policy never changes the bytes
+
+
+def test_wide_lstm_model_runs_through_streaming_kernel():
+    """H = 768 (old-style r9.4.1 width): weights do not fit the register file -> streaming kernel; vs oracle."""
+    from bonito_amd import nn as bnn, synthetic
+    torch.manual_seed(3)
+    cfg = synthetic.lstm_crf_encoder_config(768, 3, n_lstm=2)
+    model = bnn.from_dict(cfg)
+    synthetic.randomise_batchnorm_(model)
+    nn_ref.round_params_to_half_(model)
+    x = torch.randn(3, 1, 600).half()
+    enc = HipEncoder(model, batchsize=3, chunksize=600)
+    got = enc(x.cuda()).cpu().float()
+    enc.check()
+    with torch.no_grad():
+        want = nn_ref.forward(model, x.float(), expand_blanks=False).permute(1, 0, 2)
+    assert (got - want).abs().max().item() < TOL_MAX

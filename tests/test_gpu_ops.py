@@ -169,7 +169,8 @@ def _lstm_ref(G, Whh, reverse):
 
 @pytest.mark.parametrize("H,N,T,reverse,flags", [(32, 16, 40, 0, 0), (96, 48, 60, 1, 0), (384, 64, 50, 0, 0),
                                                  (384, 512, 30, 1, 0), (128, 16, 33, 1, 0), (512, 32, 20, 0, 0),
-                                                 (96, 48, 60, 0, 1), (384, 512, 30, 0, 1)])
+                                                 (96, 48, 60, 0, 1), (384, 512, 30, 0, 1),
+                                                 (1024, 64, 12, 1, 0), (768, 32, 10, 0, 0), (128, 48, 20, 0, 2), (1024, 512, 6, 0, 0)])
 def test_lstm_layer(H, N, T, reverse, flags):
     g = torch.Generator().manual_seed(H + N)
     G = (torch.randn(T, N, 4 * H, generator=g) * 1.5).half()
