@@ -70,6 +70,7 @@ SIGNATURES = {
     "bh_lstm_pack_whh": (_i, [_vp, _i, _vp]),
     "bh_lstm_workspace": (_sz, [_i, _i]),
     "bh_lstm_layer": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _vp]),
+    "bh_encoder_debug_read": (_i, [_vp, _vp, _sz, _sz]),
     "bh_encoder_set_option": (_i, [_vp, C.c_char_p, _i]),
 }
 

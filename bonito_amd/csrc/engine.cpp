@@ -840,10 +840,17 @@ extern "C" int bh_lstm_layer(const void* gates_in, const void* whh_packed, void*
     return bh_k_lstm_layer(gates_in, whh_packed, h_out, T, N, H, reverse, err_flag, (hipStream_t)stream, N / 16,
                            (int*)workspace, flags & 1);
 }
+// debug: copy the LSTM statistics block (tune bit 4) of the last launch to the host
+extern "C" int bh_encoder_debug_read(bh_encoder_t* e, void* host, size_t bytes, size_t offset) {
+    BH_REQUIRE(e && host && offset + bytes <= e->lstm_ws.bytes, "encoder_debug_read: out of range");
+    BH_CHECK_HIP(hipMemcpy(host, (char*)e->lstm_ws.p + offset, bytes, hipMemcpyDeviceToHost));
+    return 0;
+}
 extern "C" int bh_encoder_set_option(bh_encoder_t* e, const char* name, int value) {
     BH_REQUIRE(e && name, "encoder_set_option: null argument");
-    if (!strcmp(name, "lstm_force_slow")) { e->lstm_force_slow = value; return 0; }
+    if (!strcmp(name, "lstm_force_slow")) { e->lstm_force_slow = (e->lstm_force_slow & ~1) | (value & 1); return 0; }
     if (!strcmp(name, "lstm_fused")) { e->lstm_fused = value; return 0; }
+    if (!strcmp(name, "lstm_tune")) { e->lstm_force_slow = (e->lstm_force_slow & 1) | (value << 8); return 0; }
     BH_REQUIRE(false, "encoder_set_option: unknown option '%s'", name);
 }
 extern "C" size_t bh_beam_search_workspace(int N, int T, int state_len) { return bh_k_beam_workspace(N, T, state_len); }

@@ -46,6 +46,7 @@ struct LstmArgs {
     unsigned max_spins;
     int* xcc_ws;        // [n_rings][H/16], pre-set to -1: XCD agreement
     int force_slow;     // test hook: always use the placement-independent write-through policy
+    int tune;           // experiment bits: 1 = spin without s_sleep, 2 = single-k-step canary poll before the full read
 };
 
 __device__ __forceinline__ int xcc_id() {
@@ -53,6 +54,10 @@ __device__ __forceinline__ int xcc_id() {
 }
 
 constexpr unsigned SENTINEL_MASK = 0x40004000u;
+
+// Gate-math tanh: the exp form has absolute error ~1e-7 everywhere, which is all the recurrence needs
+// (h and c are consumed at fp16 / additive precision); the relative-accuracy branch of common.h's tanhf_ is skipped.
+__device__ __forceinline__ float tanh_gate(float x) { return 1.0f - 2.0f * rcpf_(__expf(2.0f * x) + 1.0f); }
 
 template <int NKS>
 __global__ __launch_bounds__(256, 1) void lstm_layer_kernel(LstmArgs p) {
@@ -161,10 +166,10 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_kernel(LstmArgs p) {
         for (int i = 0; i < 4; ++i) {
             float ig = sigmoidf_(acc[0][i] + (float)gin[0][i]);
             float fg = sigmoidf_(acc[1][i] + (float)gin[1][i]);
-            float gg = tanhf_(acc[2][i] + (float)gin[2][i]);
+            float gg = tanh_gate(acc[2][i] + (float)gin[2][i]);
             float og = sigmoidf_(acc[3][i] + (float)gin[3][i]);
             cst[i] = fg * cst[i] + ig * gg;
-            float hv = og * tanhf_(cst[i]);
+            float hv = og * tanh_gate(cst[i]);
             // keep the sentinel space clean: a non-finite or out-of-range h can never be published
             hv = (fabsf(hv) <= 1.0f) ? hv : 0.0f;
             ho[i] = (half_t)hv;
@@ -287,10 +292,10 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_stream_kernel(LstmArgs p) {
         for (int i = 0; i < 4; ++i) {
             float ig = sigmoidf_(acc[0][i] + (float)gin[0][i]);
             float fg = sigmoidf_(acc[1][i] + (float)gin[1][i]);
-            float gg = tanhf_(acc[2][i] + (float)gin[2][i]);
+            float gg = tanh_gate(acc[2][i] + (float)gin[2][i]);
             float og = sigmoidf_(acc[3][i] + (float)gin[3][i]);
             cst[i] = fg * cst[i] + ig * gg;
-            float hv = og * tanhf_(cst[i]);
+            float hv = og * tanh_gate(cst[i]);
             // keep the sentinel space clean: a non-finite or out-of-range h can never be published
             hv = (fabsf(hv) <= 1.0f) ? hv : 0.0f;
             ho[i] = (half_t)hv;
@@ -388,34 +393,32 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_fused_kernel(LstmFusedArgs 
     uint4_t xf[NKS];
 #pragma unroll
     for (int ks = 0; ks < NKS; ++ks) xf[ks] = *(const uint4_t*)(xptr + (long)t * x_row + ks * 32);
+    long long st_poll = 0, st_rounds = 0, st_first_ok = 0;
+    const long long st_t0 = __builtin_readcyclecounter();
 
     for (int step = 0; step < p.T; ++step, t += dt) {
-        // ---- input projection of THIS step (operands were prefetched during the previous step) ---------
         float4_t acc[4];
 #pragma unroll
         for (int g = 0; g < 4; ++g) acc[g] = bias4[g];
-#pragma unroll
-        for (int ks = 0; ks < NKS; ++ks) {
-            const half8_t b = __builtin_bit_cast(half8_t, xf[ks]);
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const half8_t a = *(const half8_t*)(wl + (g * NKS + ks) * 1024);
-                acc[g] = mfma16(a, b, acc[g]);
-            }
-        }
-        // ---- prefetch x of the next step into the same registers (in flight while we wait for h) -------
-        {
-            const int tn = (step + 1 < p.T) ? t + dt : t;
-#pragma unroll
-            for (int ks = 0; ks < NKS; ++ks) xf[ks] = *(const uint4_t*)(xptr + (long)tn * x_row + ks * 32);
-        }
+        uint4_t hf[NKS];
+        // ---- 1. wait for h_{t-1}: nothing of ours is ahead of these loads in the memory queue -------------
         if (step > 0) {
             const char* base = (const char*)p.h + (long)(t - dt) * row_bytes;
             __amdgpu_buffer_rsrc_t rs =
                 __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)row_bytes, 0x00020000);
-            uint4_t hf[NKS];
             unsigned spins = dead ? p.max_spins : 0u;
             unsigned pend = (NKS >= 32) ? 0xffffffffu : ((1u << NKS) - 1u);
+            const long long pc0 = (p.tune & 4) ? __builtin_readcyclecounter() : 0;
+            unsigned rounds = 0;
+            if (p.tune & 2) {     // canary: spin on ONE k-step (1/NKS of the traffic) until it is valid
+                const int kc = (slice * 5 + 3) % NKS;
+                while (spins <= p.max_spins) {
+                    const uint4_t v = __builtin_amdgcn_raw_buffer_load_b128(rs, voff + kc * 64, 0, (int)0x80000010);
+                    if (!__any(((v.x | v.y | v.z | v.w) & SENTINEL_MASK) != 0)) break;
+                    ++spins;
+                    if (!(p.tune & 1)) __builtin_amdgcn_s_sleep(1);
+                }
+            }
             while (true) {
 #pragma unroll
                 for (int ks = 0; ks < NKS; ++ks)
@@ -427,14 +430,37 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_fused_kernel(LstmFusedArgs 
                         unsigned orv = hf[ks].x | hf[ks].y | hf[ks].z | hf[ks].w;
                         if (!__any((orv & SENTINEL_MASK) != 0)) pend &= ~(1u << ks);
                     }
+                ++rounds;
                 if (pend == 0) break;
                 if (++spins > p.max_spins) {
                     if (lane == 0 && !dead) atomicExch(p.err, 1);
                     dead = true;
                     break;
                 }
-                __builtin_amdgcn_s_sleep(1);
+                if (!(p.tune & 1)) __builtin_amdgcn_s_sleep(1);
             }
+            if (p.tune & 4) { st_poll += __builtin_readcyclecounter() - pc0; st_rounds += rounds; st_first_ok += (rounds == 1); }
+        }
+        // ---- 2. input projection of this step (x_t was fetched during the previous step) ------------------
+        half8_t xb[NKS];
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) xb[ks] = __builtin_bit_cast(half8_t, xf[ks]);
+        // ---- 3. fetch x of the next step: a whole step (exchange + compute) to land -----------------------
+        {
+            const int tn = (step + 1 < p.T) ? t + dt : t;
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) xf[ks] = *(const uint4_t*)(xptr + (long)tn * x_row + ks * 32);
+        }
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const half8_t a = *(const half8_t*)(wl + (g * NKS + ks) * 1024);
+                acc[g] = mfma16(a, xb[ks], acc[g]);
+            }
+        }
+        // ---- 4. recurrent part ------------------------------------------------------------------------------
+        if (step > 0) {
 #pragma unroll
             for (int ks = 0; ks < NKS; ++ks) {
                 half8_t b = __builtin_bit_cast(half8_t, hf[ks]);
@@ -447,10 +473,10 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_fused_kernel(LstmFusedArgs 
         for (int i = 0; i < 4; ++i) {
             float ig = sigmoidf_(acc[0][i]);
             float fg = sigmoidf_(acc[1][i]);
-            float gg = tanhf_(acc[2][i]);
+            float gg = tanh_gate(acc[2][i]);
             float og = sigmoidf_(acc[3][i]);
             cst[i] = fg * cst[i] + ig * gg;
-            float hv = og * tanhf_(cst[i]);
+            float hv = og * tanh_gate(cst[i]);
             hv = (fabsf(hv) <= 1.0f) ? hv : 0.0f;
             ho[i] = (half_t)hv;
         }
@@ -458,6 +484,13 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_fused_kernel(LstmFusedArgs 
         unsigned long long* dst = (unsigned long long*)(p.h + ((long)t * p.N + n) * H + hu0);
         if (fast) *dst = packed;
         else __hip_atomic_store(dst, packed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if ((p.tune & 4) && lane == 0) {
+        long long* st = (long long*)((char*)p.xcc_ws + (((size_t)p.n_rings * NSL * sizeof(int) + 64 + 7) & ~(size_t)7)) + ((long)ring * NSL + slice) * 4;
+        st[0] = __builtin_readcyclecounter() - st_t0;
+        st[1] = st_poll;
+        st[2] = st_rounds;
+        st[3] = st_first_ok;
     }
 }
 
@@ -473,7 +506,11 @@ __global__ void fill_u16_kernel(uint16_t* dst, uint16_t v, size_t count) {
 }  // namespace bh
 
 size_t bh_k_lstm_packed_bytes(int H) { return (size_t)4 * H * H * 2; }
-size_t bh_k_lstm_ws_bytes(int N, int H) { return (size_t)((N + 15) / 16) * (H / 16) * sizeof(int) + 64; }
+size_t bh_k_lstm_ws_bytes(int N, int H) {
+    // XCD agreement slots + (tune bit 4) per-wave statistics: 4 x int64 per (ring, slice)
+    const size_t waves = (size_t)((N + 15) / 16) * (H / 16);
+    return waves * sizeof(int) + 64 + waves * 4 * sizeof(long long) + 64;
+}
 
 int bh_k_fill_u16(void* dst, uint16_t value, size_t count, hipStream_t stream) {
     using namespace bh;
@@ -507,7 +544,7 @@ int bh_k_lstm_layer(const void* gates_in, const void* whh_packed, void* h_out, i
     BH_REQUIRE(xcc_ws != nullptr, "lstm: missing XCD agreement workspace");
     BH_CHECK_HIP(hipMemsetAsync(xcc_ws, 0xFF, (size_t)n_rings * nsl * sizeof(int), stream));
     LstmArgs a{(const half_t*)gates_in, (const half_t*)whh_packed, (half_t*)h_out, T, N, H, n_rings,
-               reverse, err_flag, 1000000u, xcc_ws, force_slow};
+               reverse, err_flag, 1000000u, xcc_ws, force_slow & 1, force_slow >> 8};
 #define BH_LSTM_CASE(NKS) \
     case NKS: hipLaunchKernelGGL(lstm_layer_kernel<NKS>, dim3(grid), dim3(256), 0, stream, a); break;
     switch (H / 32) {
@@ -537,7 +574,7 @@ int bh_k_lstm_layer_stream(const void* gates_in, const void* whh_packed, void* h
     BH_REQUIRE(xcc_ws != nullptr, "lstm: missing XCD agreement workspace");
     BH_CHECK_HIP(hipMemsetAsync(xcc_ws, 0xFF, (size_t)n_rings * nsl * sizeof(int), stream));
     LstmArgs a{(const half_t*)gates_in, (const half_t*)whh_packed, (half_t*)h_out, T, N, H, n_rings,
-               reverse, err_flag, 1000000u, xcc_ws, force_slow};
+               reverse, err_flag, 1000000u, xcc_ws, force_slow & 1, force_slow >> 8};
     switch (H / 32) {
         case 2: hipLaunchKernelGGL(lstm_layer_stream_kernel<2>, dim3(grid), dim3(256), 0, stream, a); break;
         case 4: hipLaunchKernelGGL(lstm_layer_stream_kernel<4>, dim3(grid), dim3(256), 0, stream, a); break;
@@ -574,7 +611,7 @@ int bh_k_lstm_layer_fused(const void* x, const void* wih_packed, const float* bi
     BH_CHECK_HIP(hipMemsetAsync(xcc_ws, 0xFF, (size_t)n_rings * nsl * sizeof(int), stream));
     LstmFusedArgs a{(const half_t*)x, (const half_t*)wih_packed, bias,
                     LstmArgs{nullptr, (const half_t*)whh_packed, (half_t*)h_out, T, N, H, n_rings, reverse, err_flag, 1000000u,
-                             xcc_ws, force_slow}};
+                             xcc_ws, force_slow & 1, force_slow >> 8}};
     const size_t lds = (size_t)(H / 32) * 4096;
 #define BH_LSTM_CASE(NKS)                                                                                        \
     case NKS:                                                                                                    \

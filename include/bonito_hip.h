@@ -112,6 +112,8 @@ int bh_encoder_output_shape(const bh_encoder_t* enc, int L, int* T, int* C, int*
 int bh_encoder_forward(bh_encoder_t* enc, const void* signal, int N, int L, void* scores, void* stream);
 /* tuning / test options: "lstm_force_slow" (0/1), "lstm_fused" (0/1, default 1: input projection inside the recurrence) */
 int bh_encoder_set_option(bh_encoder_t* enc, const char* name, int value);
+/* debug: read back the LSTM workspace (XCD agreement slots, per-wave cycle statistics when lstm_tune bit 2 is set) */
+int bh_encoder_debug_read(bh_encoder_t* enc, void* host, size_t bytes, size_t offset);
 /* non-zero if a device-side timeout was raised by a persistent kernel since the last call (synchronises stream) */
 int bh_encoder_check(bh_encoder_t* enc, void* stream);
 

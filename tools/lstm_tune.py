@@ -1,0 +1,23 @@
+#!/usr/bin/env python3
+"""A/B of LSTM exchange knobs on the hac shape (timing only)."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from bonito_amd import synthetic
+model = synthetic.make_model("hac")
+model.use_koi(batchsize=512, chunksize=10000, quantize=False)
+model = model.half().cuda()
+sig = torch.randn(512, 1, 10000, device="cuda").half()
+ref = model(sig)
+for tune in (0, 1, 2, 3, 0):
+    model._hip.set_option("lstm_tune", tune)
+    for _ in range(2):
+        out = model(sig)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(4):
+        out = model(sig)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / 4
+    model._hip.check()
+    print("tune=%d  encoder %.2f ms  identical=%s" % (tune, dt * 1e3, bool(torch.equal(out, ref))))
