@@ -17,6 +17,8 @@
 // the score tensor (2*C/stride bytes per signal sample each). K3 one wave per chunk, wave-synchronous,
 // score / guide rows staged through LDS in blocks of 8 steps, top-W selection by a 32-step radix select
 // on ballots (no sort), slots assigned by prefix popcount.
+#include <stdlib.h>
+
 #include "common.h"
 #include "kernels.h"
 #include "../../include/bh_lse_table.h"
@@ -217,6 +219,7 @@ struct BeamArgs {
     float blank, cut;      // cut = log(beam_cut)
     uint8_t* bp;           // [N][T][32]  parent | move << 5 | base << 6
     int* final_slot;       // [N]
+    long long* dbg;        // optional [N][8] per-section cycle counters (BH_BEAM_DEBUG)
 };
 
 constexpr int BTB = 8;     // steps staged per LDS block
@@ -241,15 +244,18 @@ __device__ __forceinline__ unsigned long long lanemask_lt(int lane) { return (1u
 __device__ __forceinline__ int count_ge(const unsigned (&uk)[3], unsigned trial) {
     return popc64(__ballot(uk[0] >= trial)) + popc64(__ballot(uk[1] >= trial)) + popc64(__ballot(uk[2] >= trial));
 }
-__device__ __forceinline__ int radix_select(const unsigned (&uk)[3], int want, int lane, bool (&sel)[3], int (&slot)[3]) {
+__device__ __forceinline__ int radix_select(const unsigned (&uk)[3], int want, int lane, bool (&sel)[3], int (&slot)[3],
+                                            unsigned ulo, unsigned uhi) {
     unsigned long long selm[3];
     int n_alive = 0;
 #pragma unroll
     for (int i = 0; i < 3; ++i) { selm[i] = __ballot(uk[i] != 0u); n_alive += popc64(selm[i]); }
     if (n_alive > want) {
-        unsigned prefix = 0u;
+        // every live key lies in [ulo, uhi]: their common leading bits are already known
+        const int common = __clz((int)(ulo ^ uhi)) & ~1;            // even number of shared leading bits (32 if equal)
+        unsigned prefix = common >= 32 ? uhi : (uhi & ~(0xffffffffu >> common));
         bool exact = false;
-        for (int bit = 30; bit >= 0; bit -= 2) {
+        for (int bit = 30 - common; bit >= 0; bit -= 2) {
             const unsigned t1 = prefix | (1u << bit), t2 = prefix | (2u << bit), t3 = prefix | (3u << bit);
             const int c1 = count_ge(uk, t1), c2 = count_ge(uk, t2), c3 = count_ge(uk, t3);
             int cnt = -1;
@@ -288,6 +294,23 @@ __device__ __forceinline__ int radix_select(const unsigned (&uk)[3], int want, i
     return before;
 }
 
+// wave-wide max without LDS traffic: DPP butterflies inside each row of 16 lanes, then row broadcasts;
+// the total ends up in lane 63 (classic GCN reduction, valid on the gfx9 family incl. gfx950).
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_f(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v),
+                                                                CTRL, ROW_MASK, 0xF, false));
+}
+__device__ __forceinline__ float wave_max_f32(float v) {
+    v = fmaxf(v, dpp_f<0xB1, 0xF>(v));     // quad_perm [1,0,3,2]
+    v = fmaxf(v, dpp_f<0x4E, 0xF>(v));     // quad_perm [2,3,0,1]
+    v = fmaxf(v, dpp_f<0x124, 0xF>(v));    // row_ror:4
+    v = fmaxf(v, dpp_f<0x128, 0xF>(v));    // row_ror:8   -> every lane holds its row's max
+    v = fmaxf(v, dpp_f<0x142, 0xA>(v));    // row_bcast15 into rows 1 and 3
+    v = fmaxf(v, dpp_f<0x143, 0xC>(v));    // row_bcast31 into rows 2 and 3 -> lane 63 holds the total
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+
 constexpr int HT = 256;   // open-addressing table of stay elements keyed by sequence hash
 
 __global__ __launch_bounds__(64) void beam_kernel(BeamArgs p) {
@@ -312,6 +335,7 @@ __global__ __launch_bounds__(64) void beam_kernel(BeamArgs p) {
     const float* bn = p.beta + (long)n * (T + 1) * S;
     uint8_t* bpn = p.bp + (long)n * T * MAXW;
 
+    long long dsec[5] = {0, 0, 0, 0, 0};
     // candidate decomposition is time-invariant: c = lane + 64*i = e*5 + j
     int ce[3], cj[3];
 #pragma unroll
@@ -359,6 +383,14 @@ __global__ __launch_bounds__(64) void beam_kernel(BeamArgs p) {
         }
         nb = before;
     }
+#pragma unroll
+    for (int i = 0; i < HT / 64; ++i) htab[lane + 64 * i] = -1;
+    if (lane < MAXW) m_info[lane] = -1;
+    __syncthreads();
+    if (lane < nb) {
+        int hs = (int)(b_hash[lane] & (HT - 1));
+        while (atomicCAS(&htab[hs], -1, lane) != -1) hs = (hs + 1) & (HT - 1);
+    }
     __syncthreads();
 
     for (int tb = 0; tb < T; tb += BTB) {
@@ -378,53 +410,75 @@ __global__ __launch_bounds__(64) void beam_kernel(BeamArgs p) {
         for (int u = 0; u < nsteps; ++u) {
             const half_t* row = st_sc + u * 4 * S;
             const float* b1 = st_b + u * S;
-            // ---- (a) reset merge slots and the hash table, then insert the stay elements -----------
-#pragma unroll
-            for (int i = 0; i < HT / 64; ++i) htab[lane + 64 * i] = -1;
-            if (lane < MAXW) m_info[lane] = -1;
-            __syncthreads();
-            if (lane < nb) {
-                int slot = (int)(b_hash[lane] & (HT - 1));
-                while (atomicCAS(&htab[slot], -1, lane) != -1) slot = (slot + 1) & (HT - 1);
-            }
-            __syncthreads();
+            // (the hash table of the current beam was built when the beam was written)
+            long long tc0 = 0;
+            if (p.dbg) tc0 = __builtin_readcyclecounter();
             // ---- (b) candidates; a move that spells the same sequence as a stay is folded into it ---
             float cs[3];
             unsigned ch[3];
-            int cst[3], cinfo[3];
+            int cst[3], cinfo[3], pslot[3], d0[3];
             bool alive[3];
+            // branch-free generation: every LDS level is issued for all three candidates before it is consumed
+            int es[3];
+            unsigned eh[3];
+            float esc[3];
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
-                const int e = ce[i], j = cj[i];
-                alive[i] = e < nb;
-                cs[i] = -INFINITY; ch[i] = 0u; cst[i] = 0; cinfo[i] = 0;
-                if (alive[i]) {
-                    const int s = b_state[e];
-                    const unsigned h = b_hash[e];
-                    const float scv = b_score[e];
-                    if (j == 0) {
-                        cst[i] = s; ch[i] = h; cs[i] = scv + p.blank; cinfo[i] = e;
-                    } else {
-                        const int x = j - 1;
-                        const int s2 = ((s << 2) | x) & (S - 1);
-                        cst[i] = s2; ch[i] = bs_mix(h, x);
-                        cs[i] = scv + (float)row[s2 * 4 + (s >> sh)];
-                        cinfo[i] = e | (1 << 5) | (x << 6);
-                        int slot = (int)(ch[i] & (HT - 1));
-                        while (true) {
-                            const int d = htab[slot];
-                            if (d < 0) break;
-                            if (b_hash[d] == ch[i] && b_state[d] == cst[i]) {
-                                m_score[d] = cs[i];
-                                m_info[d] = cinfo[i];
-                                alive[i] = false;
-                                break;
-                            }
-                            slot = (slot + 1) & (HT - 1);
-                        }
+                alive[i] = ce[i] < nb;
+                const int e = alive[i] ? ce[i] : 0;
+                es[i] = b_state[e];
+                eh[i] = b_hash[e];
+                esc[i] = b_score[e];
+            }
+            float mv[3];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const int x = cj[i] > 0 ? cj[i] - 1 : 0;
+                const int s2 = ((es[i] << 2) | x) & (S - 1);
+                cst[i] = cj[i] == 0 ? es[i] : s2;
+                mv[i] = (float)row[s2 * 4 + (es[i] >> sh)];
+                ch[i] = cj[i] == 0 ? eh[i] : bs_mix(eh[i], x);
+                cinfo[i] = cj[i] == 0 ? ce[i] : (ce[i] | (1 << 5) | (x << 6));
+                pslot[i] = (int)(ch[i] & (HT - 1));
+                d0[i] = -1;
+            }
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                cs[i] = esc[i] + (cj[i] == 0 ? p.blank : mv[i]);
+                if (!alive[i]) { cs[i] = -INFINITY; ch[i] = 0u; cst[i] = 0; cinfo[i] = 0; }
+            }
+            // probes: level 1 (table slot) and level 2 (hash/state of the occupant) are issued for all three
+            // candidates before anything is compared -> two dependent LDS latencies instead of six
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+                if (alive[i] && cj[i] != 0) d0[i] = htab[pslot[i]];
+            unsigned oh[3];
+            int os[3];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const int d = d0[i] < 0 ? 0 : d0[i];
+                oh[i] = b_hash[d];
+                os[i] = b_state[d];
+            }
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                if (d0[i] >= 0) {
+                    int d = d0[i], slot = pslot[i];
+                    bool hit = oh[i] == ch[i] && os[i] == cst[i];
+                    while (!hit) {                       // rare: another sequence occupies the slot
+                        slot = (slot + 1) & (HT - 1);
+                        d = htab[slot];
+                        if (d < 0) break;
+                        hit = b_hash[d] == ch[i] && b_state[d] == cst[i];
+                    }
+                    if (hit) {
+                        m_score[d] = cs[i];
+                        m_info[d] = cinfo[i];
+                        alive[i] = false;
                     }
                 }
             }
+            if (p.dbg) { const long long t1 = __builtin_readcyclecounter(); dsec[0] += t1 - tc0; tc0 = t1; }
             __syncthreads();
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
@@ -442,8 +496,7 @@ __global__ __launch_bounds__(64) void beam_kernel(BeamArgs p) {
                 key[i] = alive[i] ? cs[i] + b1[cst[i]] : -INFINITY;
                 best = fmaxf(best, key[i]);
             }
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) best = fmaxf(best, __shfl_xor(best, off));
+            best = wave_max_f32(best);
             const float thr = best - p.cut;
             unsigned uk[3];
 #pragma unroll
@@ -451,10 +504,12 @@ __global__ __launch_bounds__(64) void beam_kernel(BeamArgs p) {
                 if (alive[i] && key[i] < thr) alive[i] = false;
                 uk[i] = alive[i] ? bs_ukey(key[i]) : 0u;
             }
+            if (p.dbg) { const long long t1 = __builtin_readcyclecounter(); dsec[1] += t1 - tc0; tc0 = t1; }
             // ---- (d) top-W, slots in candidate order -----------------------------------------------
             bool sel[3];
             int slot[3];
-            const int nnew = radix_select(uk, W, lane, sel, slot);
+            const int nnew = radix_select(uk, W, lane, sel, slot, bs_ukey(thr), bs_ukey(best));
+            if (p.dbg) { const long long t1 = __builtin_readcyclecounter(); dsec[2] += t1 - tc0; tc0 = t1; }
             // best selected candidate (max key, lowest index) gives the renormalisation shift
             const unsigned ubest = bs_ukey(best);
             float shift = 0.0f;
@@ -470,7 +525,7 @@ __global__ __launch_bounds__(64) void beam_kernel(BeamArgs p) {
                     }
                 }
             }
-            __syncthreads();   // everyone has finished reading the old beam
+            __syncthreads();   // everyone has finished reading the old beam and its hash table
 #pragma unroll
             for (int i = 0; i < 3; ++i)
                 if (sel[i]) {
@@ -479,8 +534,17 @@ __global__ __launch_bounds__(64) void beam_kernel(BeamArgs p) {
                     b_score[slot[i]] = cs[i] - shift;
                     st_bp[u * MAXW + slot[i]] = (uint8_t)cinfo[i];
                 }
+#pragma unroll
+            for (int i = 0; i < HT / 64; ++i) htab[lane + 64 * i] = -1;
+            if (lane < MAXW) m_info[lane] = -1;
             nb = nnew;
             __syncthreads();
+            if (lane < nb) {   // table of the new beam's sequence hashes, used by the next step's probes
+                int hs = (int)(b_hash[lane] & (HT - 1));
+                while (atomicCAS(&htab[hs], -1, lane) != -1) hs = (hs + 1) & (HT - 1);
+            }
+            __syncthreads();
+            if (p.dbg) { const long long t1 = __builtin_readcyclecounter(); dsec[3] += t1 - tc0; dsec[4] += nb; }
         }
         // ---- flush back-pointers of this block ------------------------------------------------------
         for (int i = lane; i < nsteps * MAXW / 4; i += 64)
@@ -496,6 +560,8 @@ __global__ __launch_bounds__(64) void beam_kernel(BeamArgs p) {
         const unsigned long long mm = __ballot(u == m && lane < nb);
         if (lane == 0) p.final_slot[n] = __ffsll((long long)mm) - 1;
     }
+    if (p.dbg && lane == 0)
+        for (int i = 0; i < 5; ++i) p.dbg[(long)n * 8 + i] = dsec[i];
 }
 
 struct FinArgs {
@@ -590,6 +656,7 @@ size_t bh_k_beam_workspace(int N, int T, int state_len) {
     b += (size_t)N * T * 4 * sizeof(float) + 256;         // P
     b += (size_t)N * T * 32 + 256;                        // bp
     b += (size_t)N * sizeof(int) + 256;                   // final slot
+    b += (size_t)N * 8 * sizeof(long long) + 256;         // debug counters
     return b;
 }
 
@@ -630,14 +697,15 @@ int bh_k_beam_search(const void* scores, int N, int T, int state_len, int beam_w
     double* logZ = (double*)w; w += align((size_t)N * sizeof(double));
     float* P = (float*)w;      w += align((size_t)N * T * 4 * sizeof(float));
     uint8_t* bp = (uint8_t*)w; w += align((size_t)N * T * 32);
-    int* fin = (int*)w;
+    int* fin = (int*)w;         w += align((size_t)N * sizeof(int));
+    long long* dbg = getenv("BH_BEAM_DEBUG") ? (long long*)w : nullptr;
 
     ScanArgs sa{(const half_t*)scores, N, T, S, state_len, blank, beta, Bcum, logZ, P};
     const int threads = S < 64 ? 64 : S;
     const size_t lds_scan = (size_t)(BH_LSE_TABLE_SIZE + 2 + 2 * S + 2 * 16 * 4 + 8) * sizeof(float) + (size_t)2 * 4 * S * 2;
     hipLaunchKernelGGL(crf_backward_kernel, dim3(N), dim3(threads), lds_scan, stream, sa);
     hipLaunchKernelGGL(crf_forward_post_kernel, dim3(N), dim3(threads), lds_scan, stream, sa);
-    BeamArgs ba{(const half_t*)scores, beta, N, T, S, state_len, beam_width, blank, logf(beam_cut), bp, fin};
+    BeamArgs ba{(const half_t*)scores, beta, N, T, S, state_len, beam_width, blank, logf(beam_cut), bp, fin, dbg};
     const size_t lds_beam = (size_t)(BH_LSE_TABLE_SIZE + 2) * 4 + (size_t)BTB * 4 * S * 2 + (size_t)BTB * S * 4 + MAXW * 4 * 5 + HT * 4 + BTB * MAXW + 64;
     if (lds_beam > 64 * 1024)
         BH_CHECK_HIP(hipFuncSetAttribute((const void*)beam_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_beam));

@@ -850,6 +850,7 @@ extern "C" int bh_encoder_set_option(bh_encoder_t* e, const char* name, int valu
     BH_REQUIRE(e && name, "encoder_set_option: null argument");
     if (!strcmp(name, "lstm_force_slow")) { e->lstm_force_slow = (e->lstm_force_slow & ~1) | (value & 1); return 0; }
     if (!strcmp(name, "lstm_fused")) { e->lstm_fused = value; return 0; }
+    if (!strcmp(name, "gemm_v1")) { bh_k_linear_force_v1(value); return 0; }   // process-wide A/B switch
     if (!strcmp(name, "lstm_tune")) { e->lstm_force_slow = (e->lstm_force_slow & 1) | (value << 8); return 0; }
     BH_REQUIRE(false, "encoder_set_option: unknown option '%s'", name);
 }

@@ -46,6 +46,64 @@ __device__ __forceinline__ int lds_off(int row, int chunk) {
 }
 
 template <int ACT, bool GATED>
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, float4_t (&acc)[4][4], int f0, int t0, int wf, int wt,
+                                              int r, int kg) {
+    // Epilogue. lane (c = r: token column, q = kg): features fbase + ft*4 + reg, ft,reg in 0..3.
+    const int fbase = f0 + wf * 64 + kg * 16;
+    float bv[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        int f = fbase + i;
+        bv[i] = (p.bias != nullptr && f < p.N) ? p.bias[f] : 0.0f;
+    }
+#pragma unroll
+    for (int tt = 0; tt < 4; ++tt) {
+        int m = t0 + wt * 64 + tt * 16 + r;
+        if (m >= p.M || (m % p.row_div) >= p.row_lim) continue;
+        long orow = (long)(m / p.row_div) * p.row_s_hi + (long)(m % p.row_div) * p.row_s_lo;
+        float v[16];
+#pragma unroll
+        for (int ft = 0; ft < 4; ++ft)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) v[ft * 4 + g] = acc[ft][tt][g] + bv[ft * 4 + g];
+        if (p.res != nullptr) {
+            const half_t* rp = p.res + (long)m * p.ldres + fbase;
+#pragma unroll
+            for (int i = 0; i < 16; ++i)
+                if (fbase + i < p.N) v[i] += (float)rp[i];
+        }
+        if constexpr (GATED) {
+            // W rows were interleaved on the host: feature 2j = y_j, 2j+1 = gate_j
+            // (flash_attn GatedMlp semantics: y, gate = fc1(x).chunk(2); y * silu(gate)).
+            half8_t o;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) o[i] = (half_t)(v[2 * i] * swishf_(v[2 * i + 1]));
+            int fo = fbase >> 1;
+            if (fo + 8 <= (p.N >> 1)) *(half8_t*)(p.out + orow * p.ldo + fo) = o;
+            else
+                for (int i = 0; i < 8; ++i)
+                    if (fo + i < (p.N >> 1)) p.out[orow * p.ldo + fo + i] = o[i];
+        } else {
+            half8_t o0, o1;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                float x = apply_act<ACT>(v[i]) * p.scale;
+                x = fminf(fmaxf(x, p.clamp_lo), p.clamp_hi);
+                if (i < 8) o0[i] = (half_t)x; else o1[i - 8] = (half_t)x;
+            }
+            half_t* dst = p.out + orow * p.ldo + fbase;
+            if (fbase + 16 <= p.N) {
+                *(half8_t*)dst = o0;
+                *(half8_t*)(dst + 8) = o1;
+            } else {
+                for (int i = 0; i < 16; ++i)
+                    if (fbase + i < p.N) dst[i] = i < 8 ? o0[i] : o1[i - 8];
+            }
+        }
+    }
+}
+
+template <int ACT, bool GATED>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // layout: [buf][A tile | B tile]
@@ -134,68 +192,113 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
         __syncthreads();
     }
 
-    // Epilogue. lane (c = r: token column, q = kg): features fbase + ft*4 + reg, ft,reg in 0..3.
-    const int fbase = f0 + wf * 64 + kg * 16;
-    float bv[16];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        int f = fbase + i;
-        bv[i] = (p.bias != nullptr && f < p.N) ? p.bias[f] : 0.0f;
-    }
-#pragma unroll
-    for (int tt = 0; tt < 4; ++tt) {
-        int m = t0 + wt * 64 + tt * 16 + r;
-        if (m >= p.M || (m % p.row_div) >= p.row_lim) continue;
-        long orow = (long)(m / p.row_div) * p.row_s_hi + (long)(m % p.row_div) * p.row_s_lo;
-        float v[16];
-#pragma unroll
-        for (int ft = 0; ft < 4; ++ft)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) v[ft * 4 + g] = acc[ft][tt][g] + bv[ft * 4 + g];
-        if (p.res != nullptr) {
-            const half_t* rp = p.res + (long)m * p.ldres + fbase;
-#pragma unroll
-            for (int i = 0; i < 16; ++i)
-                if (fbase + i < p.N) v[i] += (float)rp[i];
-        }
-        if constexpr (GATED) {
-            // W rows were interleaved on the host: feature 2j = y_j, 2j+1 = gate_j
-            // (flash_attn GatedMlp semantics: y, gate = fc1(x).chunk(2); y * silu(gate)).
-            half8_t o;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) o[i] = (half_t)(v[2 * i] * swishf_(v[2 * i + 1]));
-            int fo = fbase >> 1;
-            if (fo + 8 <= (p.N >> 1)) *(half8_t*)(p.out + orow * p.ldo + fo) = o;
-            else
-                for (int i = 0; i < 8; ++i)
-                    if (fo + i < (p.N >> 1)) p.out[orow * p.ldo + fo + i] = o[i];
-        } else {
-            half8_t o0, o1;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                float x = apply_act<ACT>(v[i]) * p.scale;
-                x = fminf(fmaxf(x, p.clamp_lo), p.clamp_hi);
-                if (i < 8) o0[i] = (half_t)x; else o1[i - 8] = (half_t)x;
-            }
-            half_t* dst = p.out + orow * p.ldo + fbase;
-            if (fbase + 16 <= p.N) {
-                *(half8_t*)dst = o0;
-                *(half8_t*)(dst + 8) = o1;
-            } else {
-                for (int i = 0; i < 16; ++i)
-                    if (fbase + i < p.N) dst[i] = i < 8 ? o0[i] : o1[i - 8];
-            }
-        }
-    }
+    gemm_epilogue<ACT, GATED>(p, acc, f0, t0, wf, wt, r, kg);
 }
+
+// ---------------------------------------------------------------------------------------------------
+// v2: direct global->LDS staging (global_load_lds, 16 B per lane, no VGPR round trip), BK = 32, two LDS
+// buffers of 16 KiB -> 32 KiB per workgroup and <= 128 VGPRs, so 4 workgroups (16 waves) share a CU and
+// hide each other's HBM / barrier latency. One barrier per K-step: wait(tile k) -> barrier -> issue the DMA
+// of tile k+1 into the other buffer -> MFMAs of tile k.
+// The DMA writes LDS linearly (wave-uniform base + lane*16), so the bank swizzle is applied on the SOURCE
+// side: lane (row r = lane>>2, slot = lane&3) fetches global chunk slot ^ g[(r>>2)&3], g = {0,3,2,1}; a
+// fragment read of chunk kg of row r goes to slot kg ^ g[(r>>2)&3]. With that permutation every 16-lane
+// group of a ds_read_b128 fragment read touches 16 distinct 16-byte slots (derivation: DESIGN.md).
+// Requires K % 32 == 0 (no K tail) -- the launcher falls back to gemm_kernel otherwise.
+constexpr int BK2 = 32;
+constexpr int TILE2 = 128 * BK2 * 2;   // 8 KiB per operand tile
+
+__device__ __forceinline__ int swz2(int r) { return (0x1230 >> (((r >> 2) & 3) * 4)) & 3; }   // g = {0,3,2,1}
+
+template <int ACT, bool GATED>
+__global__ __launch_bounds__(256, 4) void gemm_glds_kernel(GemmArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // [buf][A 8K | B 8K]
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wf = wave >> 1, wt = wave & 1;
+    const int r = lane & 15, kg = lane >> 4;
+
+    const int nwg = gridDim.x;
+    const int bid = blockIdx.x;
+    const int q8 = nwg >> 3, r8 = nwg & 7;
+    const int xcd = bid & 7, loc = bid >> 3;
+    const int work = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + loc;
+    const int tile_t = work / p.n_ft;
+    const int tile_f = work - tile_t * p.n_ft;
+    const int f0 = tile_f * BF, t0 = tile_t * BT;
+
+    // DMA assignment: wave w, instruction j in {0,1} covers LDS rows (w*2+j)*16 .. +15 of each operand tile
+    const int lr = lane >> 2, slot = lane & 3;
+    const half_t* asrc[2];
+    const half_t* bsrc[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int row = (wave * 2 + j) * 16 + lr;
+        const int chunk = slot ^ swz2(lr);
+        const int wfb = row >> 6, within = row & 63;
+        const int ft = within >> 4, rr = within & 15;
+        const int feat = min(f0 + wfb * 64 + (rr >> 2) * 16 + ft * 4 + (rr & 3), p.N - 1);
+        asrc[j] = p.W + (long)feat * p.ldw + chunk * 8;
+        const int tok = min(t0 + row, p.M - 1);
+        bsrc[j] = p.X + (long)tok * p.ldx + chunk * 8;
+    }
+    auto dma = [&](int kt, int buf) {
+        char* a = smem + buf * 2 * TILE2;
+        char* b = a + TILE2;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int off = (wave * 2 + j) * 1024;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(asrc[j] + kt * BK2),
+                                             (__attribute__((address_space(3))) void*)(a + off), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(bsrc[j] + kt * BK2),
+                                             (__attribute__((address_space(3))) void*)(b + off), 16, 0, 0);
+        }
+    };
+
+    float4_t acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = float4_t{0.f, 0.f, 0.f, 0.f};
+
+    const int nk = p.K / BK2;
+    const int fpos = (kg ^ swz2(r)) << 4;          // byte position of this lane's chunk inside a 64-byte row
+    dma(0, 0);
+    for (int kt = 0; kt < nk; ++kt) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // tile kt has landed (this wave's part)
+        __syncthreads();                                    // ... and everybody's; all reads of tile kt-1 are done
+        if (kt + 1 < nk) dma(kt + 1, (kt + 1) & 1);
+        const char* a = smem + (kt & 1) * 2 * TILE2;
+        const char* b = a + TILE2;
+        half8_t af[4], bf[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            af[i] = *(const half8_t*)(a + (wf * 64 + i * 16 + r) * 64 + fpos);
+            bf[i] = *(const half8_t*)(b + (wt * 64 + i * 16 + r) * 64 + fpos);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = mfma16(af[i], bf[j], acc[i][j]);
+    }
+    gemm_epilogue<ACT, GATED>(p, acc, f0, t0, wf, wt, r, kg);
+}
+
+static int g_force_v1 = 0;   // test / A-B hook (bh_k_linear_force_v1)
 
 template <int ACT, bool GATED>
 static void launch(const GemmArgs& a, hipStream_t s) {
     int grid = a.n_ft * a.n_tt;
-    hipLaunchKernelGGL((gemm_kernel<ACT, GATED>), dim3(grid), dim3(256), 4 * TILE_BYTES, s, a);
+    if (a.K % BK2 == 0 && !g_force_v1)
+        hipLaunchKernelGGL((gemm_glds_kernel<ACT, GATED>), dim3(grid), dim3(256), 4 * TILE2, s, a);
+    else
+        hipLaunchKernelGGL((gemm_kernel<ACT, GATED>), dim3(grid), dim3(256), 4 * TILE_BYTES, s, a);
 }
 
 }  // namespace bh
+
+void bh_k_linear_force_v1(int on) { bh::g_force_v1 = on; }
 
 int bh_k_linear(const void* X, const void* W, const float* bias, void* out, int M, int N, int K,
                 int ldx, int ldw, int ldo, int act, float scale, float clamp_lo, float clamp_hi,

@@ -12,6 +12,8 @@ int bh_k_linear(const void* X, const void* W, const float* bias, void* out, int 
                 int gated, int row_div, long row_s_hi, long row_s_lo, int row_lim, hipStream_t stream,
                 const void* residual = nullptr, int ldres = 0);
 
+void bh_k_linear_force_v1(int on);
+
 // conv.hip
 int bh_k_conv_first(const void* signal, const float* w, const float* bias, void* out, int N, int Lin,
                     int Lout, int Cout, int K, int stride, int pad, int act, float clamp_lo,
