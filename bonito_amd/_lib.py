@@ -63,6 +63,8 @@ SIGNATURES = {
     "bh_conv1d_pack": (_i, [_vp, _i, _i, _i, _vp]),
     "bh_conv1d": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _f, _f, _l, _l, _vp]),
     "bh_ctc_greedy_decode": (_i, [_vp, _vp, _i, _i, _f, _f, _vp, _vp, _vp, _vp, _vp]),
+    "bh_ctc_beam_search_workspace": (_sz, [_l, _i, _i, _i]),
+    "bh_ctc_beam_search": (_i, [_vp, _vp, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp]),
     "bh_dwconv1d": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "bh_rotary_table": (_i, [_i, _i, _vp]),
     "bh_attention": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),

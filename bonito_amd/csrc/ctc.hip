@@ -220,3 +220,143 @@ int bh_k_ctc_greedy(const float* logp, const long* offs, int R, int C, float qsc
     BH_CHECK_HIP(hipGetLastError());
     return 0;
 }
+
+// ---------------------------------------------------------------------------------------------------
+// CTC prefix beam search "PB-1" (replaces fast_ctc_decode.beam_search, /root/reference bonito/ctc/model.py:44;
+// definition and CPU restatement: oracle/crf_oracle.c::oracle_ctc_prefix_beam). The search over one read is a
+// short serial recurrence over T steps with a beam of <= 16 prefixes x <= 8 labels, so the parallelism is
+// ACROSS reads: one lane per read, R reads per launch. Log-space arithmetic uses the shared lse2 table, so
+// results are bit-identical to the oracle.
+#include "../../include/bh_lse_table.h"
+namespace bh {
+
+__device__ const float g_lse_tab_ctc[BH_LSE_TABLE_SIZE] = {BH_LSE_TABLE_VALUES};
+
+__device__ __forceinline__ float lse2_g(float a, float b) {
+    float m = fmaxf(a, b);
+    float d = fabsf(a - b);
+    if (!(d < BH_LSE_RANGE) || m == -INFINITY) return m;
+    float x = d * BH_LSE_SCALE;
+    int i = (int)x;
+    float f = x - (float)i;
+    float t0 = g_lse_tab_ctc[i];
+    return m + __fmaf_rn(f, g_lse_tab_ctc[i + 1] - t0, t0);
+}
+
+constexpr int PB_MAXB = 16, PB_MAXC = 8;
+
+struct PbArgs {
+    const float* logp;     // concatenated [sum T_r][C]
+    const long* offs;      // [R+1]
+    int R, C, B;
+    float lthr;            // log(threshold)
+    int* nodes;            // workspace: per read (1 + T_r*B) nodes x (3 + C-1) ints, at node offset offs[r]*B + r
+    int8_t* labels;        // [sum T_r] compacted per read at offs[r]
+    int* path;             // [sum T_r]
+    int* count;            // [R]
+};
+
+__global__ __launch_bounds__(64) void ctc_prefix_beam_kernel(PbArgs p) {
+    const int r = blockIdx.x * 64 + threadIdx.x;
+    if (r >= p.R) return;
+    const long o0 = p.offs[r];
+    const int T = (int)(p.offs[r + 1] - o0);
+    const int C = p.C, B = p.B, NI = 3 + C - 1;
+    int* nd = p.nodes + ((long)o0 * B + r) * NI;          // node m: [parent, label, tstep, child_1..child_{C-1}]
+    const float* lp = p.logp + o0 * C;
+    nd[0] = -1; nd[1] = 0; nd[2] = -1;
+    for (int c = 1; c < C; ++c) nd[2 + c] = -1;
+    int n_nodes = 1, nb = 1;
+    int b_node[PB_MAXB];
+    float b_pb[PB_MAXB], b_pnb[PB_MAXB];
+    b_node[0] = 0; b_pb[0] = 0.0f; b_pnb[0] = -INFINITY;
+    for (int t = 0; t < T; ++t) {
+        const float* row = lp + (long)t * C;
+        long c_key[PB_MAXB * PB_MAXC];
+        float c_pb[PB_MAXB * PB_MAXC], c_pnb[PB_MAXB * PB_MAXC];
+        int nc = 0;
+        auto find = [&](long key) {
+            for (int q = 0; q < nc; ++q)
+                if (c_key[q] == key) return q;
+            c_key[nc] = key; c_pb[nc] = -INFINITY; c_pnb[nc] = -INFINITY;
+            return nc++;
+        };
+        for (int e = 0; e < nb; ++e) {
+            const int n = b_node[e];
+            const float tot = lse2_g(b_pb[e], b_pnb[e]);
+            int idx = find((long)n);
+            c_pb[idx] = lse2_g(c_pb[idx], tot + row[0]);
+            const int lab_n = nd[(long)n * NI + 1];
+            for (int c = 1; c < C; ++c) {
+                if (!(row[c] >= p.lthr)) continue;
+                float contrib;
+                if (n != 0 && lab_n == c) {
+                    idx = find((long)n);
+                    c_pnb[idx] = lse2_g(c_pnb[idx], b_pnb[e] + row[c]);
+                    contrib = b_pb[e] + row[c];
+                } else {
+                    contrib = tot + row[c];
+                }
+                const int ch = nd[(long)n * NI + 2 + c];
+                const long key = ch >= 0 ? (long)ch : -((long)n * 8 + c) - 1;
+                idx = find(key);
+                c_pnb[idx] = lse2_g(c_pnb[idx], contrib);
+            }
+        }
+        float sc[PB_MAXB * PB_MAXC];
+        bool used[PB_MAXB * PB_MAXC];
+        for (int i = 0; i < nc; ++i) { sc[i] = lse2_g(c_pb[i], c_pnb[i]); used[i] = false; }
+        int nn = 0;
+        int s_node[PB_MAXB];
+        float s_pb[PB_MAXB], s_pnb[PB_MAXB];
+        for (int k = 0; k < B && k < nc; ++k) {
+            int bi = -1;
+            for (int i = 0; i < nc; ++i)
+                if (!used[i] && sc[i] > -INFINITY && (bi < 0 || sc[i] > sc[bi])) bi = i;
+            if (bi < 0) break;
+            used[bi] = true;
+            int node;
+            if (c_key[bi] >= 0) node = (int)c_key[bi];
+            else {
+                const long pk = -(c_key[bi] + 1);
+                const int pn = (int)(pk / 8), c = (int)(pk % 8);
+                node = n_nodes++;
+                int* m = nd + (long)node * NI;
+                m[0] = pn; m[1] = c; m[2] = t;
+                for (int cc = 1; cc < C; ++cc) m[2 + cc] = -1;
+                nd[(long)pn * NI + 2 + c] = node;
+            }
+            s_node[nn] = node; s_pb[nn] = c_pb[bi]; s_pnb[nn] = c_pnb[bi]; ++nn;
+        }
+        const float shift = nn ? lse2_g(s_pb[0], s_pnb[0]) : 0.0f;
+        nb = nn;
+        for (int i = 0; i < nn; ++i) { b_node[i] = s_node[i]; b_pb[i] = s_pb[i] - shift; b_pnb[i] = s_pnb[i] - shift; }
+    }
+    const int n = nb ? b_node[0] : 0;
+    int len = 0;
+    for (int m = n; m > 0; m = nd[(long)m * NI]) ++len;
+    p.count[r] = len;
+    int i = len - 1;
+    for (int m = n; m > 0; m = nd[(long)m * NI], --i) {
+        p.labels[o0 + i] = (int8_t)nd[(long)m * NI + 1];
+        p.path[o0 + i] = nd[(long)m * NI + 2];
+    }
+}
+
+}  // namespace bh
+
+size_t bh_k_ctc_beam_workspace(long total_steps, int R, int C, int beam_size) {
+    return (size_t)(total_steps * beam_size + R) * (3 + C - 1) * sizeof(int) + 256;
+}
+
+int bh_k_ctc_prefix_beam(const float* logp, const long* offs, int R, int C, int beam_size, float threshold, void* workspace,
+                         int8_t* labels, int* path, int* count, hipStream_t stream) {
+    using namespace bh;
+    BH_REQUIRE(R > 0 && C >= 2 && C <= PB_MAXC, "ctc_beam: need R > 0 and 2 <= classes <= 8 (R=%d C=%d)", R, C);
+    BH_REQUIRE(beam_size >= 1 && beam_size <= PB_MAXB, "ctc_beam: beam_size must be in 1..16 (got %d)", beam_size);
+    BH_REQUIRE(threshold >= 0.0f && threshold < 1.0f, "ctc_beam: threshold must be in [0, 1)");
+    PbArgs a{logp, offs, R, C, beam_size, threshold > 0.0f ? logf(threshold) : -INFINITY, (int*)workspace, labels, path, count};
+    hipLaunchKernelGGL(ctc_prefix_beam_kernel, dim3((R + 63) / 64), dim3(64), 0, stream, a);
+    BH_CHECK_HIP(hipGetLastError());
+    return 0;
+}

@@ -809,6 +809,15 @@ extern "C" int bh_ctc_greedy_decode(const float* logp, const long* offsets, int 
     BH_REQUIRE(logp && offsets && labels && qual && path && count, "ctc_greedy_decode: null pointer");
     return bh_k_ctc_greedy(logp, offsets, R, classes, qscale, qbias, labels, qual, path, count, (hipStream_t)stream);
 }
+extern "C" size_t bh_ctc_beam_search_workspace(long total_steps, int R, int classes, int beam_size) {
+    return bh_k_ctc_beam_workspace(total_steps, R, classes, beam_size);
+}
+extern "C" int bh_ctc_beam_search(const float* logp, const long* offsets, int R, int classes, int beam_size, float threshold,
+                                  void* workspace, int8_t* labels, int* path, int* count, void* stream) {
+    BH_REQUIRE(logp && offsets && workspace && labels && path && count, "ctc_beam_search: null pointer");
+    return bh_k_ctc_prefix_beam(logp, offsets, R, classes, beam_size, threshold, workspace, labels, path, count,
+                                (hipStream_t)stream);
+}
 extern "C" int bh_dwconv1d(const void* in, const float* w, void* out, int N, int Lin, int C, int K, int stride, int pad,
                            void* stream) {
     BH_REQUIRE(in && w && out && stride > 0, "dwconv1d: bad arguments");

@@ -63,3 +63,6 @@ int bh_k_ctc_head(const void* in, const float* w, const float* bias, void* out, 
                   hipStream_t stream);
 int bh_k_ctc_greedy(const float* logp, const long* offs, int R, int C, float qscale, float qbias, int8_t* seq,
                     int8_t* qual, int* path, int* count, hipStream_t stream);
+size_t bh_k_ctc_beam_workspace(long total_steps, int R, int C, int beam_size);
+int bh_k_ctc_prefix_beam(const float* logp, const long* offs, int R, int C, int beam_size, float threshold, void* workspace,
+                         int8_t* labels, int* path, int* count, hipStream_t stream);

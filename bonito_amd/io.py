@@ -1,0 +1,106 @@
+"""
+Basecall output: FASTQ / FASTA / unaligned SAM text and ``summary.tsv`` -- the host-side formatting of
+/root/reference bonito/io.py (encode_moves 57-70, write_fastq 97-105, sam_record 135-166, summary 169-226,
+Writer 400-469) without pysam / mappy (alignment and BAM/CRAM need those wheels and are out of scope).
+SAM tags follow documentation/SAM.md:39-55: ``mv:B:c,<stride>,<moves...>``, ``qs:f`` (mean q-score),
+``ns:i`` (samples incl. trimmed), ``ts:i`` (trimmed samples), ``RG:Z``.
+"""
+import csv
+import sys
+from threading import Thread
+
+import numpy as np
+
+from bonito_amd.util import mean_qscore_from_qstring
+
+__version__ = "0.1.0"
+
+summary_field_names = ["filename", "read_id", "run_id", "channel", "mux", "start_time", "duration", "template_start",
+                       "template_duration", "sequence_length_template", "mean_qscore_template"]
+
+
+def encode_moves(moves, stride, sep=","):
+    """np.array([0,1,0,1,1]), 5 -> '5,0,1,0,1,1' (single-digit moves only)."""
+    moves = np.asarray(moves)
+    out = np.full(2 * moves.size, ord(sep), dtype=np.uint8)
+    out[1::2] = moves.astype(np.uint8) + ord("0")
+    return "%d%s" % (stride, out.tobytes().decode("ascii"))
+
+
+def write_fasta(header, sequence, fd=sys.stdout):
+    fd.write(">%s\n%s\n" % (header, sequence))
+
+
+def write_fastq(header, sequence, qstring, fd=sys.stdout, tags=None, sep="\t"):
+    fd.write("@%s%s\n" % (header, (" " + sep.join(tags)) if tags is not None else ""))
+    fd.write("%s\n+\n%s\n" % (sequence, qstring))
+
+
+def sam_header(groups, sep="\t"):
+    hd = sep.join(["@HD", "VN:1.5", "SO:unknown", "ob:%s" % __version__])
+    pg = sep.join(["@PG", "ID:basecaller", "PN:bonito_amd", "VN:%s" % __version__, "CL:%s" % " ".join(sys.argv),
+                   "DS:MI355X engine"])
+    return "\n".join([hd, pg, *groups]) + "\n"
+
+
+def sam_record(read_id, sequence, qstring, mapping=None, tags=None, sep="\t"):
+    if mapping is not None:
+        raise NotImplementedError("alignment is out of scope for this build (needs mappy)")
+    record = [read_id, 4, "*", 0, 0, "*", "*", 0, 0, sequence, qstring, "NM:i:0"]
+    if tags is not None:
+        record.extend(tags)
+    return sep.join(map(str, record))
+
+
+def read_tags(read, res, mean_q):
+    tags = ["RG:Z:%s" % (read.run_id or "unknown"), "qs:f:%0.2f" % mean_q, "ns:i:%d" % read.num_samples,
+            "ts:i:%d" % read.trimmed_samples]
+    if res.get("moves") is not None and len(res["moves"]):
+        tags.append("mv:B:c,%s" % encode_moves(res["moves"], res["stride"]))
+    return tags
+
+
+def summary_row(read, seqlen, qscore):
+    return [read.filename, read.read_id, read.run_id, read.channel, read.mux, read.start, read.duration,
+            read.template_start, read.template_duration, seqlen, qscore]
+
+
+class Writer(Thread):
+    """Consumes the basecall iterator (this drives the whole pipeline) and writes records to `fd`."""
+
+    def __init__(self, mode, iterator, fd=sys.stdout, min_qscore=0.0, summary_path=None, groups=()):
+        super().__init__()
+        assert mode in ("fastq", "fasta", "sam")
+        self.mode, self.iterator, self.fd = mode, iterator, fd
+        self.min_qscore, self.summary_path, self.groups = min_qscore, summary_path, groups
+        self.log = []            # (read_id, samples) of written reads: feeds the samples/s report
+        self.error = None
+
+    def run(self):
+        try:
+            summary = open(self.summary_path, "w", newline="") if self.summary_path else None
+            tsv = csv.writer(summary, delimiter="\t") if summary else None
+            if tsv:
+                tsv.writerow(summary_field_names)
+            if self.mode == "sam":
+                self.fd.write(sam_header(self.groups))
+            for read, res in self.iterator:
+                seq, qstring = res["sequence"], res.get("qstring", "*")
+                mean_q = mean_qscore_from_qstring(qstring) if qstring and qstring != "*" else 0.0
+                if mean_q < self.min_qscore or not len(seq):
+                    continue
+                if self.mode == "fasta":
+                    write_fasta(read.read_id, seq, self.fd)
+                elif self.mode == "fastq":
+                    write_fastq(read.read_id, seq, qstring if qstring != "*" else "!" * len(seq), self.fd,
+                                tags=read_tags(read, res, mean_q))
+                else:
+                    self.fd.write(sam_record(read.read_id, seq, qstring, tags=read_tags(read, res, mean_q)) + "\n")
+                if tsv:
+                    tsv.writerow(summary_row(read, len(seq), mean_q))
+                self.log.append((read.read_id, read.num_samples))
+            self.fd.flush()
+            if summary:
+                summary.close()
+        except BaseException as exc:       # surfaced by the caller after join()
+            self.error = exc

@@ -1,0 +1,131 @@
+"""
+Signal ingest for the basecaller: `Read` objects with a normalised float32 `.signal`, adapter `trim` and
+`normalisation` (behavioural mirror of /root/reference bonito/reader.py:122-166 and the per-read flow of
+bonito/pod5.py:52-67: scale to pA, normalise, trim the start).
+
+Formats: the pod5 / fast5 readers of the reference need the `pod5` / `ont_fast5_api` wheels, which are not
+installable here (no network). `Reader` therefore accepts
+  * a directory of ``*.npy`` files -- one read each: float32 (already in pA or normalised) or int16 raw ADC
+    with an optional ``<name>.json`` side-car {"offset":..., "scale":..., "read_id":...};
+  * ``*.pod5`` files when the `pod5` module is importable (same calls as bonito/pod5.py:113-124).
+"""
+import json
+import os
+from glob import glob
+
+import numpy as np
+
+__default_norm_params__ = {"quantile_a": 0.2, "quantile_b": 0.9, "shift_multiplier": 0.51, "scale_multiplier": 0.53}
+
+
+def trim(signal, window_size=40, threshold=2.4, min_trim=10, min_elements=3, max_samples=8000, max_trim=0.3):
+    """Index at which the read proper starts: scan windows for the first stretch above `threshold` (the
+    open-pore / adapter peak) and cut where the signal drops back; fall back to `min_trim`."""
+    seen_peak = False
+    limit = min(max_samples, len(signal))
+    for pos in range(limit // window_size):
+        start = pos * window_size + min_trim
+        end = start + window_size
+        window = signal[start:end]
+        if seen_peak or np.count_nonzero(window > threshold) > min_elements:
+            seen_peak = True
+            if window[-1] > threshold:
+                continue
+            if end >= limit or end / len(signal) > max_trim:
+                return min_trim
+            return end
+    return min_trim
+
+
+def normalisation(sig, scaling_strategy=None, norm_params=None):
+    """(shift, scale): quantile scaling by default, or fixed pA standardisation from the model config."""
+    if scaling_strategy and scaling_strategy.get("strategy") == "pa":
+        if norm_params and norm_params.get("standardise") == 1:
+            return norm_params.get("mean"), norm_params.get("stdev")
+        if norm_params and norm_params.get("standardise") == 0:
+            return 0.0, 1.0
+        raise ValueError("Picoampere scaling requested, but standardisation flag not provided")
+    if scaling_strategy is None or scaling_strategy.get("strategy") == "quantile":
+        params = norm_params or __default_norm_params__
+        qa, qb = np.quantile(sig, [params["quantile_a"], params["quantile_b"]])
+        return max(10, params["shift_multiplier"] * (qa + qb)), max(1.0, params["scale_multiplier"] * (qb - qa))
+    raise ValueError("Scaling strategy %s not supported; choose quantile or pa." % scaling_strategy.get("strategy"))
+
+
+class Read:
+    """One read: identity fields used by the writers + the normalised, trimmed signal."""
+
+    def __init__(self, read_id, signal, filename="", run_id="", channel=0, mux=0, start=0.0, sample_rate=5000.0,
+                 scaling=1.0, offset=0.0, do_trim=True, scaling_strategy=None, norm_params=None):
+        self.read_id, self.filename, self.run_id = read_id, filename, run_id
+        self.channel, self.mux, self.start = channel, mux, start
+        self.sample_rate = sample_rate
+        raw = np.asarray(signal)
+        self.num_samples = len(raw)
+        self.duration = self.num_samples / sample_rate
+        scaled = raw.astype(np.float32) if raw.dtype.kind == "f" else np.array(scaling * (raw.astype(np.float32) + offset),
+                                                                                dtype=np.float32)
+        self.shift, self.scale = normalisation(scaled, scaling_strategy, norm_params)
+        norm = (scaled - self.shift) / self.scale
+        self.trimmed_samples = trim(norm) if do_trim else 0
+        self.template_start = self.start + self.trimmed_samples / sample_rate
+        self.template_duration = self.duration - self.trimmed_samples / sample_rate
+        self.signal = np.ascontiguousarray(norm[self.trimmed_samples:], dtype=np.float32)
+
+    def __repr__(self):
+        return "Read('%s')" % self.read_id
+
+
+class Reader:
+    """Yields `Read`s from a directory (``*.npy``; ``*.pod5`` when the pod5 module is available)."""
+
+    def __init__(self, directory, recursive=False):
+        pattern = "**/*" if recursive else "*"
+        self.npy = sorted(glob(os.path.join(directory, pattern + ".npy"), recursive=recursive))
+        self.pod5 = sorted(glob(os.path.join(directory, pattern + ".pod5"), recursive=recursive))
+        if not self.npy and not self.pod5:
+            raise FileNotFoundError("no .npy or .pod5 reads found in '%s'" % directory)
+
+    def get_reads(self, read_ids=None, skip=False, do_trim=True, scaling_strategy=None, norm_params=None, n_max=None,
+                  cancel=None):
+        count = 0
+
+        def wanted(rid):
+            return read_ids is None or ((rid in read_ids) ^ skip)
+
+        for path in self.npy:
+            meta = {}
+            side = os.path.splitext(path)[0] + ".json"
+            if os.path.exists(side):
+                with open(side) as fh:
+                    meta = json.load(fh)
+            rid = meta.get("read_id", os.path.splitext(os.path.basename(path))[0])
+            if not wanted(rid):
+                continue
+            yield Read(rid, np.load(path), filename=os.path.basename(path), run_id=meta.get("run_id", ""),
+                       channel=meta.get("channel", 0), mux=meta.get("mux", 0), start=meta.get("start", 0.0),
+                       sample_rate=meta.get("sample_rate", 5000.0), scaling=meta.get("scale", 1.0),
+                       offset=meta.get("offset", 0.0), do_trim=do_trim, scaling_strategy=scaling_strategy,
+                       norm_params=norm_params)
+            count += 1
+            if (n_max and count >= n_max) or (cancel is not None and cancel.is_set()):
+                return
+        if self.pod5:
+            try:
+                import pod5
+            except ImportError as exc:
+                raise RuntimeError("reading .pod5 needs the `pod5` package, which is not installed") from exc
+            for path in self.pod5:
+                with pod5.Reader(path) as fh:
+                    for rec in fh.reads():
+                        rid = str(rec.read_id)
+                        if not wanted(rid):
+                            continue
+                        cal = rec.calibration
+                        yield Read(rid, rec.signal, filename=os.path.basename(path), run_id=rec.run_info.acquisition_id,
+                                   channel=rec.pore.channel, mux=rec.pore.well, start=rec.start_sample / rec.run_info.sample_rate,
+                                   sample_rate=rec.run_info.sample_rate, scaling=cal.scale, offset=cal.offset, do_trim=do_trim,
+                                   scaling_strategy=scaling_strategy, norm_params=norm_params)
+                        count += 1
+                        if (n_max and count >= n_max) or (cancel is not None and cancel.is_set()):
+                            return

@@ -182,6 +182,12 @@ int bh_conv1d(const void* in, const void* wpacked, const float* bias, void* out,
  * labels (1..classes-1), qual (phred chars), path (step of each base), count[R]. */
 int bh_ctc_greedy_decode(const float* logp, const long* offsets, int R, int classes, float qscale, float qbias,
                          int8_t* labels, int8_t* qual, int* path, int* count, void* stream);
+/* CTC prefix beam search of R reads in one launch: replaces fast_ctc_decode.beam_search(probs, alphabet, beam_size=5,
+ * beam_cut_threshold=1e-3) (bonito/ctc/model.py:44).  Same buffers as bh_ctc_greedy_decode (no qualities);
+ * workspace: bh_ctc_beam_search_workspace(sum T_r, R, classes, beam_size) device bytes. beam_size <= 16. */
+size_t bh_ctc_beam_search_workspace(long total_steps, int R, int classes, int beam_size);
+int bh_ctc_beam_search(const float* logp, const long* offsets, int R, int classes, int beam_size, float threshold,
+                       void* workspace, int8_t* labels, int* path, int* count, void* stream);
 /* depthwise conv (TCSConv1d.depthwise, ctc/model.py:99-103): in/out fp16 channel-minor [N][L][C], w fp32 device [C][K] */
 int bh_dwconv1d(const void* in, const float* w, void* out, int N, int Lin, int C, int K, int stride, int pad,
                 void* stream);

@@ -408,3 +408,106 @@ int oracle_beam_search(const uint16_t* scores, int N, int T, int state_len, int 
     free(beta); free(Bcum); free(logZ); free(P); free(bp);
     return 0;
 }
+
+/* =================================================================================================
+ * CTC prefix beam search ("PB-1").  Replaces fast_ctc_decode.beam_search(probs, alphabet, beam_size=5,
+ * beam_cut_threshold=1e-3) (bonito/ctc/model.py:44; Rust crate, un-pinned in requirements.txt:3, absent
+ * from /root/reference -> its tie-breaking/normalisation cannot be pinned: PARITY UNPINNED, this is the
+ * textbook algorithm it implements, in log space with the deterministic table lse2).
+ *   beam entry = (prefix-tree node, log p_blank, log p_nonblank); per step, in beam order:
+ *     blank          : same prefix, p_b  += (p_b + p_nb) * P[0]
+ *     label c >= thr : if c == last label: same prefix p_nb += p_nb * P[c], extended prefix p_nb += p_b * P[c]
+ *                      else               extended prefix p_nb += (p_b + p_nb) * P[c]
+ *   candidates with the same prefix are merged; keep the `beam_size` best by p_b + p_nb (ties: first created).
+ * Output: label indices (1..C-1) of the best prefix and, per label, the step at which its node entered the beam.
+ * ================================================================================================= */
+#define PB_MAXB 16
+#define PB_MAXC 8
+int oracle_ctc_prefix_beam(const float* lp, int T, int C, int beam_size, float threshold, int8_t* labels_out,
+                           int* path_out, int* count_out) {
+    if (beam_size < 1 || beam_size > PB_MAXB || C < 2 || C > PB_MAXC) return -2;
+    const int max_nodes = 1 + T * beam_size;
+    int* parent = (int*)malloc(sizeof(int) * max_nodes);
+    int8_t* label = (int8_t*)malloc(max_nodes);
+    int* tstep = (int*)malloc(sizeof(int) * max_nodes);
+    int* child = (int*)malloc(sizeof(int) * (size_t)max_nodes * (PB_MAXC - 1));
+    if (!parent || !label || !tstep || !child) { free(parent); free(label); free(tstep); free(child); return -1; }
+    for (size_t i = 0; i < (size_t)max_nodes * (PB_MAXC - 1); ++i) child[i] = -1;
+    parent[0] = -1; label[0] = 0; tstep[0] = -1;
+    int n_nodes = 1;
+    int b_node[PB_MAXB];
+    float b_pb[PB_MAXB], b_pnb[PB_MAXB];
+    int nb = 1;
+    b_node[0] = 0; b_pb[0] = 0.0f; b_pnb[0] = -INFINITY;
+    const float lthr = logf(threshold);
+    for (int t = 0; t < T; ++t) {
+        const float* row = lp + (size_t)t * C;
+        /* candidate key: node id >= 0, or a not-yet-allocated child encoded as -(parent * 8 + c) - 1 */
+        long c_key[PB_MAXB * PB_MAXC];
+        float c_pb[PB_MAXB * PB_MAXC], c_pnb[PB_MAXB * PB_MAXC];
+        int nc = 0;
+#define PB_FIND(KEY, IDX)                                              \
+        do {                                                           \
+            IDX = -1;                                                  \
+            for (int q_ = 0; q_ < nc; ++q_) if (c_key[q_] == (KEY)) { IDX = q_; break; } \
+            if (IDX < 0) { IDX = nc++; c_key[IDX] = (KEY); c_pb[IDX] = -INFINITY; c_pnb[IDX] = -INFINITY; } \
+        } while (0)
+        for (int e = 0; e < nb; ++e) {
+            const int n = b_node[e];
+            const float tot = oracle_lse2(b_pb[e], b_pnb[e]);
+            int idx;
+            PB_FIND((long)n, idx);
+            c_pb[idx] = oracle_lse2(c_pb[idx], tot + row[0]);
+            for (int c = 1; c < C; ++c) {
+                if (!(row[c] >= lthr)) continue;
+                float contrib;
+                if (n != 0 && label[n] == c) {
+                    PB_FIND((long)n, idx);
+                    c_pnb[idx] = oracle_lse2(c_pnb[idx], b_pnb[e] + row[c]);
+                    contrib = b_pb[e] + row[c];
+                } else {
+                    contrib = tot + row[c];
+                }
+                const int ch = child[(size_t)n * (PB_MAXC - 1) + (c - 1)];
+                const long key = ch >= 0 ? (long)ch : -((long)n * 8 + c) - 1;
+                PB_FIND(key, idx);
+                c_pnb[idx] = oracle_lse2(c_pnb[idx], contrib);
+            }
+        }
+        /* top beam_size by total score, ties: lower candidate index */
+        float sc[PB_MAXB * PB_MAXC];
+        char used[PB_MAXB * PB_MAXC];
+        for (int i = 0; i < nc; ++i) { sc[i] = oracle_lse2(c_pb[i], c_pnb[i]); used[i] = 0; }
+        int nn = 0;
+        int s_node[PB_MAXB];
+        float s_pb[PB_MAXB], s_pnb[PB_MAXB];
+        for (int k = 0; k < beam_size && k < nc; ++k) {
+            int bi = -1;
+            for (int i = 0; i < nc; ++i)
+                if (!used[i] && sc[i] > -INFINITY && (bi < 0 || sc[i] > sc[bi])) bi = i;
+            if (bi < 0) break;
+            used[bi] = 1;
+            int node;
+            if (c_key[bi] >= 0) node = (int)c_key[bi];
+            else {
+                const long pk = -(c_key[bi] + 1);
+                const int pn = (int)(pk / 8), c = (int)(pk % 8);
+                node = n_nodes++;
+                parent[node] = pn; label[node] = (int8_t)c; tstep[node] = t;
+                child[(size_t)pn * (PB_MAXC - 1) + (c - 1)] = node;
+            }
+            s_node[nn] = node; s_pb[nn] = c_pb[bi]; s_pnb[nn] = c_pnb[bi]; ++nn;
+        }
+        /* renormalise by the best total so that scores stay bounded */
+        const float shift = nn ? oracle_lse2(s_pb[0], s_pnb[0]) : 0.0f;
+        nb = nn;
+        for (int i = 0; i < nn; ++i) { b_node[i] = s_node[i]; b_pb[i] = s_pb[i] - shift; b_pnb[i] = s_pnb[i] - shift; }
+#undef PB_FIND
+    }
+    int n = nb ? b_node[0] : 0, len = 0;
+    for (int m = n; m > 0; m = parent[m]) ++len;
+    *count_out = len;
+    for (int m = n, i = len - 1; m > 0; m = parent[m], --i) { labels_out[i] = label[m]; path_out[i] = tstep[m]; }
+    free(parent); free(label); free(tstep); free(child);
+    return 0;
+}

@@ -36,3 +36,20 @@ def viterbi_search(logp, alphabet, qscale=1.0, qbias=0.0):
         prev = lab
         t += 1
     return "".join(seq), "".join(qs), path
+
+
+def beam_search(logp, alphabet, beam_size=5, beam_cut_threshold=1e-3):
+    """PB-1 prefix beam search (oracle/crf_oracle.c::oracle_ctc_prefix_beam) -> (sequence, path)."""
+    import ctypes as C
+    from oracle.crf_ref import _lib
+    lp = np.ascontiguousarray(np.asarray(logp, dtype=np.float32))
+    T, Cc = lp.shape
+    labels = np.zeros(max(T, 1), np.int8)
+    path = np.zeros(max(T, 1), np.int32)
+    cnt = C.c_int(0)
+    rc = _lib().oracle_ctc_prefix_beam(lp.ctypes.data_as(C.c_void_p), T, Cc, int(beam_size), C.c_float(beam_cut_threshold),
+                                       labels.ctypes.data_as(C.c_void_p), path.ctypes.data_as(C.c_void_p), C.byref(cnt))
+    if rc:
+        raise RuntimeError("oracle_ctc_prefix_beam failed (%d)" % rc)
+    n = cnt.value
+    return "".join(alphabet[i] for i in labels[:n]), path[:n].tolist()

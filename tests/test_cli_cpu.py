@@ -1,0 +1,80 @@
+"""Reader / writer host logic of the basecaller CLI (CPU): trim + normalisation against values produced by the
+reference's bonito/reader.py, the in-tree known answers (io.py:63-64 doctest, SAM.md tags)."""
+import io
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+from bonito_amd import io as bio
+from bonito_amd import reader
+
+
+def _regen(seed_idx, n, peak):
+    """Same recipe as the fixture generator (tests/golden: reader_cases.npz was produced from it)."""
+    rng = np.random.default_rng(5)
+    for i in range(seed_idx + 1):
+        m = int(rng.integers(500, 20000))
+        sig = rng.standard_normal(m).astype(np.float32)
+        if i % 2 == 0:
+            a = int(rng.integers(50, 400)); b = a + int(rng.integers(60, 600))
+            sig[a:b] += 4.0
+    assert m == n
+    return (sig * 12.0 + 90.0).astype(np.float32)
+
+
+def test_trim_and_normalisation_match_reference_values():
+    meta = json.loads(str(np.load(os.path.join(GOLDEN, "reader_cases.npz"))["meta"]))
+    for c in meta:
+        raw = _regen(c["seed"], c["n"], c["peak"])
+        shift, scale = reader.normalisation(raw, None, None)
+        assert abs(shift - c["shift"]) < 1e-4 and abs(scale - c["scale"]) < 1e-4
+        assert reader.trim(raw, threshold=scale * 2.4 + shift) == c["trim"]
+        r = reader.Read("x", raw)
+        assert r.trimmed_samples == c["trim"] and len(r.signal) == c["n"] - c["trim"]
+        assert abs(float(np.median(r.signal))) < 1.0
+    assert reader.normalisation(raw, {"strategy": "pa"}, {"standardise": 1, "mean": 93.7, "stdev": 23.5}) == (93.7, 23.5)
+    assert reader.normalisation(raw, {"strategy": "pa"}, {"standardise": 0}) == (0.0, 1.0)
+    with pytest.raises(ValueError):
+        reader.normalisation(raw, {"strategy": "pa"}, None)
+
+
+def test_encode_moves_doctest_and_records():
+    assert bio.encode_moves(np.array([0, 1, 0, 1, 1], dtype=np.int8), 5) == "5,0,1,0,1,1"      # bonito/io.py:63-64
+    buf = io.StringIO()
+    bio.write_fastq("rid", "ACGT", "!!!!", fd=buf, tags=["qs:f:1.00", "ns:i:9"])
+    assert buf.getvalue() == "@rid qs:f:1.00\tns:i:9\nACGT\n+\n!!!!\n"
+    rec = bio.sam_record("rid", "ACGT", "IIII", tags=["mv:B:c,6,1,0"]).split("\t")
+    assert rec[:3] == ["rid", "4", "*"] and rec[9] == "ACGT" and rec[-1] == "mv:B:c,6,1,0"
+    assert bio.sam_header([]).startswith("@HD\tVN:1.5")
+
+
+def test_writer_filters_and_logs(tmp_path):
+    class R:
+        read_id, filename, run_id, channel, mux, start, duration = "r1", "f.npy", "run", 1, 2, 0.0, 1.0
+        template_start, template_duration, num_samples, trimmed_samples = 0.1, 0.9, 5000, 40
+    good = {"sequence": "ACGT", "qstring": "5555", "moves": np.array([1, 0, 1, 1, 0, 1], np.int8), "stride": 6}
+    bad = {"sequence": "AC", "qstring": "!!", "moves": np.array([1, 1], np.int8), "stride": 6}
+    buf = io.StringIO()
+    w = bio.Writer("fastq", iter([(R, good), (R, bad)]), fd=buf, min_qscore=7.0, summary_path=str(tmp_path / "s.tsv"))
+    w.start(); w.join()
+    assert w.error is None and w.log == [("r1", 5000)]
+    out = buf.getvalue().splitlines()
+    assert out[0].startswith("@r1 RG:Z:run\tqs:f:20.00\tns:i:5000\tts:i:40\tmv:B:c,6,1,0,1,1,0,1") and out[1] == "ACGT"
+    rows = (tmp_path / "s.tsv").read_text().splitlines()
+    assert rows[0].split("\t") == bio.summary_field_names and len(rows) == 2
+
+
+def test_npy_reader(tmp_path):
+    rng = np.random.default_rng(0)
+    np.save(tmp_path / "a.npy", (rng.standard_normal(3000) * 10 + 80).astype(np.float32))
+    np.save(tmp_path / "b.npy", (rng.standard_normal(2000) * 40 + 500).astype(np.int16))
+    (tmp_path / "b.json").write_text(json.dumps({"read_id": "read-b", "scale": 0.18, "offset": -240.0, "channel": 7}))
+    reads = list(reader.Reader(str(tmp_path)).get_reads())
+    assert [r.read_id for r in reads] == ["a", "read-b"] and reads[1].channel == 7
+    assert reads[0].signal.dtype == np.float32 and abs(float(np.median(reads[0].signal))) < 1.0
+    assert [r.read_id for r in reader.Reader(str(tmp_path)).get_reads(read_ids={"a"}, skip=True)] == ["read-b"]
+    with pytest.raises(FileNotFoundError):
+        reader.Reader(str(tmp_path / "nope"))

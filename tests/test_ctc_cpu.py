@@ -43,3 +43,29 @@ def test_greedy_oracle_semantics():
     assert qs2 == chr(33 + 21) * 3
     assert ctc_ref.viterbi_search(np.log(np.full((4, 5), 0.2, np.float32)), alphabet) == ("", "", [])   # ties -> blank
     assert ctc_ref.phred(1.0) == 33 + 40 and ctc_ref.phred(0.0) == 33
+
+
+def test_prefix_beam_oracle_equals_exhaustive_map_on_tiny_inputs():
+    import itertools
+    from collections import defaultdict
+    rng = np.random.default_rng(1)
+    alphabet = ["N", "A", "C", "G", "T"]
+    for _ in range(12):
+        T = int(rng.integers(1, 6))
+        lp = torch.log_softmax(torch.from_numpy(rng.standard_normal((T, 5)).astype(np.float32) * 2), -1).numpy()
+        tot = defaultdict(float)
+        for al in itertools.product(range(5), repeat=T):
+            p = float(np.exp(sum(lp[t, a] for t, a in enumerate(al))))
+            seq, prev = [], 0
+            for a in al:
+                if a != 0 and a != prev:
+                    seq.append(a)
+                prev = a
+            tot[tuple(seq)] += p
+        best = max(tot.items(), key=lambda kv: kv[1])[0]
+        seq, path = ctc_ref.beam_search(lp, alphabet, beam_size=16, beam_cut_threshold=1e-9)
+        assert seq == "".join(alphabet[i] for i in best)
+        assert len(path) == len(seq)
+    # beam of 1 with no threshold never beats the wide beam
+    lp = torch.log_softmax(torch.from_numpy(rng.standard_normal((200, 5)).astype(np.float32) * 3), -1).numpy()
+    assert len(ctc_ref.beam_search(lp, alphabet, 1, 1e-3)[0]) > 0

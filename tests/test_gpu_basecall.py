@@ -134,3 +134,43 @@ def test_load_model_from_directory_roundtrip(tmp_path):
     got = model(x.half().cuda()).cpu().float()
     assert (got - ref_scores_to_koi(y)).abs().max().item() < 6e-2
     assert util.load_symbol(str(tmp_path), "basecall") is crf_basecall_fn
+
+
+def test_cli_basecaller_end_to_end(tmp_path, capsys):
+    """python -m bonito_amd basecaller <model_dir> <reads_dir>: model directory + .npy reads -> FASTQ on stdout,
+    summary.tsv, 'samples per second' on stderr (reference cli/basecaller.py flow)."""
+    import json
+    from conftest import load_nn_fixture
+    from bonito_amd.__main__ import main
+    cfg, sd, _, _ = load_nn_fixture("lstm64_sl3")
+
+    def tv(v):
+        if isinstance(v, bool):
+            return "true" if v else "false"
+        if isinstance(v, str):
+            return json.dumps(v)
+        if isinstance(v, list):
+            return "[" + ", ".join(tv(i) for i in v) + "]"
+        return repr(v)
+
+    mdir, rdir = tmp_path / "model", tmp_path / "reads"
+    mdir.mkdir(); rdir.mkdir()
+    lines = ['[model]', 'package = "bonito.crf"', '[labels]', 'labels = ["N", "A", "C", "G", "T"]', '[input]',
+             'features = 1', '[global_norm]', 'state_len = 3', '[basecaller]', 'batchsize = 8', 'chunksize = 1200',
+             'overlap = 120', '[encoder]', 'type = "serial"']
+    for sub in cfg["sublayers"]:
+        lines.append("[[encoder.sublayers]]")
+        lines += ["%s = %s" % (k, tv(v)) for k, v in sub.items()]
+    (mdir / "config.toml").write_text("\n".join(lines) + "\n")
+    sd = {k: (v * 30.0 if k.endswith("linear.weight") else v) for k, v in sd.items()}
+    torch.save(sd, str(mdir / "weights_1.tar"))
+    rng = np.random.default_rng(3)
+    for i, n in enumerate([4000, 9000, 700]):
+        np.save(rdir / ("read%d.npy" % i), (rng.standard_normal(n) * 12 + 90).astype(np.float32))
+    rc = main(["basecaller", str(mdir), str(rdir), "--summary", str(tmp_path / "summary.tsv"), "--batchsize", "8"])
+    out, err = capsys.readouterr()
+    assert rc == 0 and "samples per second" in err and "completed reads: 3" in err
+    recs = out.strip().split("\n")
+    assert len(recs) == 12 and recs[0].startswith("@read0") and "mv:B:c,6," in recs[0]
+    assert set(recs[1]) <= set("ACGT") and len(recs[1]) == len(recs[3])
+    assert len((tmp_path / "summary.tsv").read_text().splitlines()) == 4

@@ -94,3 +94,17 @@ def test_ctc_basecall_config1_shape():
         import difflib
         ratio = difflib.SequenceMatcher(None, res["sequence"], oseq, autojunk=False).ratio()
         assert ratio > 0.97, ratio
+
+
+def test_prefix_beam_search_matches_oracle():
+    rng = np.random.default_rng(12)
+    alphabet = ["N", "A", "C", "G", "T"]
+    reads = [torch.log_softmax(torch.from_numpy(rng.standard_normal((T, 5)).astype(np.float32) * s), -1)
+             for T, s in ((1, 2.0), (9, 3.0), (400, 2.0), (1334, 4.0), (57, 0.5))]
+    for bs, thr in ((5, 1e-3), (1, 1e-3), (16, 1e-9), (3, 0.2)):
+        got = ctc_decode.beam_search_batch(reads, alphabet, bs, thr)
+        for lp, (seq, path) in zip(reads, got):
+            oseq, opath = ctc_ref.beam_search(lp.numpy(), alphabet, bs, thr)
+            assert seq == oseq and path == opath, (bs, thr, len(seq), len(oseq))
+    s, p = ctc_decode.beam_search(reads[2], alphabet)
+    assert len(s) == len(p) and all(a < b for a, b in zip(p, p[1:]))
