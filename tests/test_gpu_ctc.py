@@ -77,23 +77,30 @@ def test_ctc_basecall_config1_shape():
     model, _, _ = _gpu_model()
     rng = np.random.default_rng(4)
     reads = [Read("r%d" % i, rng.standard_normal(n).astype(np.float32)) for i, n in enumerate([16000, 24000, 4000, 20000])]
-    got = list(ctc_basecall(model, iter(reads), beamsize=5, chunksize=4000, overlap=400, batchsize=16))
-    assert [r.read_id for r, _ in got] == ["r0", "r1", "r2", "r3"]
+    import difflib
+    from bonito_amd import util
     cpu_model = build_ctc_model(*load_ctc_fixture()[:2])
-    for read, res in got:
-        assert res["stride"] == 3 and set(res["sequence"]) <= set("ACGT")
-        assert len(res["sequence"]) == len(res["qstring"]) == len(res["moves"])
-        # oracle: fp32 forward of the whole read in chunks, stitched, greedy decoded
-        from bonito_amd import util
-        ch = util.chunk(torch.from_numpy(read.signal), 4000, 400)
-        with torch.no_grad():
-            lp = nn_ref.ctc_forward(cpu_model, ch.float()).permute(1, 0, 2)
-        st = util.stitch(lp, 4000, 400, len(read.signal), 3)
-        oseq, _, opath = ctc_ref.viterbi_search(st.numpy(), model.alphabet, model.qscale, model.qbias)
-        # fp16 engine vs fp32 oracle: near-tie argmaxes may flip; demand high identity, not equality
-        import difflib
-        ratio = difflib.SequenceMatcher(None, res["sequence"], oseq, autojunk=False).ratio()
-        assert ratio > 0.97, ratio
+    for beamsize in (1, 5):
+        got = list(ctc_basecall(model, iter(reads), beamsize=beamsize, chunksize=4000, overlap=400, batchsize=16))
+        assert [r.read_id for r, _ in got] == ["r0", "r1", "r2", "r3"]
+        for read, res in got:
+            assert res["stride"] == 3 and set(res["sequence"]) <= set("ACGT")
+            if beamsize == 1:      # greedy: per-base qualities and the move path
+                assert len(res["sequence"]) == len(res["qstring"]) == len(res["moves"])
+            else:                  # reference semantics (ctc/basecall.py:52-58): beam sequence, no qualities / path
+                assert res["qstring"] == "*" and res["moves"] is None
+            # oracle: fp32 forward of the whole read in chunks, stitched, decoded by the CPU oracle
+            ch = util.chunk(torch.from_numpy(read.signal), 4000, 400)
+            with torch.no_grad():
+                lp = nn_ref.ctc_forward(cpu_model, ch.float()).permute(1, 0, 2)
+            st = util.stitch(lp, 4000, 400, len(read.signal), 3)
+            if beamsize == 1:
+                oseq, _, _ = ctc_ref.viterbi_search(st.numpy(), model.alphabet, model.qscale, model.qbias)
+            else:
+                oseq, _ = ctc_ref.beam_search(st.numpy(), model.alphabet, 5, 1e-3)
+            # fp16 engine vs fp32 oracle: near-tie decisions may flip; demand high identity, not equality
+            ratio = difflib.SequenceMatcher(None, res["sequence"], oseq, autojunk=False).ratio()
+            assert ratio > 0.97, (beamsize, ratio)
 
 
 def test_prefix_beam_search_matches_oracle():
