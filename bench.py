@@ -205,10 +205,13 @@ def main():
                   key=lambda k: prof[k][0])
         ms, spans = prof[cls]
         launches_per_fwd = spans / nprof
-        flops_per_launch = fl[cls] * a.batch / launches_per_fwd
+        work = fl[cls]
+        if cls == "lstm_rec" and prof["lstm_gemm"][1] == 0:
+            work += fl["lstm_gemm"]          # fused kernel: the input projection runs inside the recurrence launch
+        flops_per_launch = work * a.batch / launches_per_fwd
         avg_ms = ms / spans
         achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12
-        roof = {"kernel": {"lstm_rec": "lstm_layer_kernel", "lstm_gemm": "gemm_kernel", "crf_linear": "gemm_kernel",
+        roof = {"kernel": {"lstm_rec": "lstm_layer_fused_kernel" if prof["lstm_gemm"][1] == 0 else "lstm_layer_kernel", "lstm_gemm": "gemm_kernel", "crf_linear": "gemm_kernel",
                            "conv": "conv_igemm_kernel", "mlp": "gemm_kernel (fc1 gated + fc2) + rmsnorm_residual_kernel",
                            "attention": "gemm_kernel (Wqkv, out_proj) + attention_kernel + rmsnorm_residual_kernel"}[cls],
                 "bound": "mfma", "achieved": round(achieved, 2), "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
