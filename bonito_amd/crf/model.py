@@ -151,11 +151,14 @@ class SeqdistModel(Module):
             raise NoTorchCompute("bonito_amd models only run on a HIP device; got a %s tensor" % x.device)
         return self._engine(x)(x)
 
-    def decode_batch(self, x):
-        raise NotImplementedError("posterior decoding (decode_batch) is not part of this build")
+    def decode_batch(self, x, blank_score=2.0):
+        """Posterior decoding of engine scores [N, T, 4S] (cuda fp16) -> list of strings
+        (reference crf/model.py:196-199: viterbi over log(posteriors + 1e-8))."""
+        _, paths = hip_decode.posterior_viterbi(x.contiguous(), blank_score)
+        return [self.seqdist.path_to_str(p) for p in paths.numpy()]
 
     def decode(self, x):
-        return self.decode_batch(x.unsqueeze(1))[0]
+        return self.decode_batch(x.unsqueeze(0))[0]
 
     def to_dict(self, include_weights=False):
         if include_weights:

@@ -212,6 +212,110 @@ __global__ void crf_forward_post_kernel(ScanArgs p) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// Posterior decoding = SeqdistModel.decode_batch (/root/reference bonito/crf/model.py:196-199):
+//     post = posteriors(scores) + 1e-8 ; path = viterbi(log post)
+// i.e. the Max-semiring best path over the LOG EDGE POSTERIORS
+//     log p[t][j][k] = alpha_t[idx[j][k]] + Ms[t][j][k] + beta_{t+1}[j] - logZ .
+// One forward pass carries both recurrences: the log-semiring alpha (table lse2, as K2) and, on the fly,
+// v_{t+1}[j] = max_k log(p[t][j][k] + 1e-8) + v_t[idx[j][k]] with 3-bit back-pointers; then the same
+// LDS-staged traceback as the plain Viterbi kernel. Needs beta~/B/logZ from crf_backward_kernel.
+struct PostVitArgs {
+    ScanArgs sc;
+    uint8_t* bp;      // [N][T][S]
+    int8_t* moves;    // [N][T]
+    int8_t* path;     // [N][T]
+};
+
+__global__ void crf_posterior_viterbi_kernel(PostVitArgs pa) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const ScanArgs& p = pa.sc;
+    const int S = p.S, T = p.T, q = S >> 2;
+    float* tab = (float*)smem;
+    float* buf = tab + BH_LSE_TABLE_SIZE + 2;   // [2][S] alpha raw
+    float* vb = buf + 2 * S;                    // [2][S] max-semiring scores
+    int* s_state = (int*)(vb + 2 * S);          // [4]
+    uint8_t* stage = (uint8_t*)(s_state + 4);   // traceback staging
+    const int n = blockIdx.x, j = threadIdx.x;
+    const bool active = j < S;
+    for (int i = threadIdx.x; i < BH_LSE_TABLE_SIZE; i += blockDim.x) tab[i] = g_lse_tab[i];
+    if (active) { buf[j] = 0.0f; vb[j] = 0.0f; }
+    const half_t* sc = p.scores + (long)n * T * 4 * S + j * 4;
+    const float* bn = p.beta + (long)n * (T + 1) * S;
+    const double* Bn = p.Bcum + (long)n * (T + 1);
+    const double lz = p.logZ[n];
+    uint8_t* bp = pa.bp + (long)n * T * S;
+    __syncthreads();
+
+    double A = 0.0;
+    int cb = 0;
+    for (int t = 0; t < T; ++t) {
+        const float* prev = buf + cb * S;
+        const float* vprev = vb + cb * S;
+        const float ref = prev[0];
+        if (active) {
+            const half4_t m4 = *(const half4_t*)(sc + (long)t * 4 * S);
+            const float b1 = bn[(long)(t + 1) * S + j];
+            // log edge posterior = alpha_t[src] + Ms + beta_{t+1}[j] - logZ, alpha_t = prev + D_t, beta_{t+1} = b1 + B_t
+            const double off = A + (double)b1 + Bn[t] - lz;
+            float acc = p.blank + (prev[j] - ref);
+            float e0 = (float)((double)prev[j] + (double)p.blank + off);
+            float best = __logf(__expf(e0) + 1e-8f) + vprev[j];
+            int bk = 0;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int src = r * q + (j >> 2);
+                const float ms = (float)m4[r];
+                acc = lse2_tab(acc, ms + (prev[src] - ref), tab);
+                const float e = (float)((double)prev[src] + (double)ms + off);
+                const float cand = __logf(__expf(e) + 1e-8f) + vprev[src];
+                if (cand > best) { best = cand; bk = 1 + r; }
+            }
+            buf[(cb ^ 1) * S + j] = acc;
+            vb[(cb ^ 1) * S + j] = best;
+            bp[(long)t * S + j] = (uint8_t)bk;
+        }
+        A += (double)ref;
+        cb ^= 1;
+        __syncthreads();
+    }
+    if (j == 0) {
+        const float* a = vb + cb * S;
+        float best = a[0];
+        int bj = 0;
+        for (int i = 1; i < S; ++i)
+            if (a[i] > best) { best = a[i]; bj = i; }
+        s_state[0] = bj;
+    }
+    __threadfence();
+    __syncthreads();
+    const int TB = max(1, min(512, (32 * 1024) / S));
+    int8_t* res_m = (int8_t*)(stage + TB * S);
+    int8_t* res_p = res_m + TB;
+    int8_t* mo = pa.moves + (long)n * T;
+    int8_t* pth = pa.path + (long)n * T;
+    for (int thi = T; thi > 0; thi -= TB) {
+        const int tlo = max(0, thi - TB);
+        const int nbytes = (thi - tlo) * S;
+        const uint8_t* src = bp + (long)tlo * S;
+        for (int i = threadIdx.x * 4; i < nbytes; i += blockDim.x * 4) *(unsigned*)(stage + i) = *(const unsigned*)(src + i);
+        __syncthreads();
+        if (j == 0) {
+            int st = s_state[0];
+            for (int t = thi - 1; t >= tlo; --t) {
+                const int k = stage[(t - tlo) * S + st];
+                res_m[t - tlo] = (int8_t)(k != 0);
+                res_p[t - tlo] = (int8_t)(k != 0 ? 1 + (st & 3) : 0);
+                if (k != 0) st = (k - 1) * q + (st >> 2);
+            }
+            s_state[0] = st;
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < thi - tlo; i += blockDim.x) { mo[tlo + i] = res_m[i]; pth[tlo + i] = res_p[i]; }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 struct BeamArgs {
     const half_t* scores;  // [N][T][4S]
     const float* beta;     // [N][T+1][S]
@@ -676,6 +780,36 @@ int bh_k_crf_logz(const void* scores, int N, int T, int state_len, float blank, 
     const int threads = S < 64 ? 64 : S;
     const size_t lds_scan = (size_t)(BH_LSE_TABLE_SIZE + 2 + 2 * S + 2 * 16 * 4 + 8) * sizeof(float) + (size_t)2 * 4 * S * 2;
     hipLaunchKernelGGL(crf_backward_kernel, dim3(N), dim3(threads), lds_scan, stream, sa);
+    BH_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+size_t bh_k_posterior_viterbi_workspace(int N, int T, int state_len) {
+    size_t S = 1;
+    for (int i = 0; i < state_len; ++i) S *= 4;
+    return bh_k_beam_workspace(N, T, state_len) + (size_t)N * T * S + 256;
+}
+
+int bh_k_posterior_viterbi(const void* scores, int N, int T, int state_len, float blank, void* workspace, int8_t* moves,
+                           int8_t* path, hipStream_t stream) {
+    using namespace bh;
+    BH_REQUIRE(state_len >= 1 && state_len <= 5 && N > 0 && T > 0, "posterior_viterbi: bad shape");
+    int S = 1;
+    for (int i = 0; i < state_len; ++i) S *= 4;
+    auto align = [](size_t x) { return (x + 255) / 256 * 256; };
+    char* w = (char*)workspace;
+    float* beta = (float*)w;   w += align((size_t)N * (T + 1) * S * sizeof(float));
+    double* Bcum = (double*)w; w += align((size_t)N * (T + 1) * sizeof(double));
+    double* logZ = (double*)w;
+    uint8_t* bp = (uint8_t*)workspace + bh_k_beam_workspace(N, T, state_len);
+    ScanArgs sa{(const half_t*)scores, N, T, S, state_len, blank, beta, Bcum, logZ, nullptr};
+    const int threads = S < 64 ? 64 : S;
+    const size_t lds_scan = (size_t)(BH_LSE_TABLE_SIZE + 2 + 2 * S + 2 * 16 * 4 + 8) * sizeof(float) + (size_t)2 * 4 * S * 2;
+    hipLaunchKernelGGL(crf_backward_kernel, dim3(N), dim3(threads), lds_scan, stream, sa);
+    PostVitArgs pa{sa, bp, moves, path};
+    int TB = (32 * 1024) / S; if (TB > 512) TB = 512; if (TB < 1) TB = 1;
+    const size_t lds_pv = (size_t)(BH_LSE_TABLE_SIZE + 2 + 4 * S + 4) * sizeof(float) + (size_t)TB * S + 2 * TB + 32;
+    hipLaunchKernelGGL(crf_posterior_viterbi_kernel, dim3(N), dim3(threads), lds_pv, stream, pa);
     BH_CHECK_HIP(hipGetLastError());
     return 0;
 }

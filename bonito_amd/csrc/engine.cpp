@@ -881,6 +881,14 @@ extern "C" int bh_crf_logz(const void* scores, int N, int T, int state_len, floa
     BH_REQUIRE(scores && workspace && logz, "crf_logz: null pointer");
     return bh_k_crf_logz(scores, N, T, state_len, blank_score, workspace, logz, (hipStream_t)stream);
 }
+extern "C" size_t bh_crf_posterior_viterbi_workspace(int N, int T, int state_len) {
+    return bh_k_posterior_viterbi_workspace(N, T, state_len);
+}
+extern "C" int bh_crf_posterior_viterbi(const void* scores, int N, int T, int state_len, float blank_score, void* workspace,
+                                        int8_t* moves, int8_t* path, void* stream) {
+    BH_REQUIRE(scores && workspace && moves && path, "crf_posterior_viterbi: null pointer");
+    return bh_k_posterior_viterbi(scores, N, T, state_len, blank_score, workspace, moves, path, (hipStream_t)stream);
+}
 extern "C" size_t bh_crf_viterbi_workspace(int N, int T, int state_len) {
     size_t S = 1;
     for (int i = 0; i < state_len; ++i) S *= 4;

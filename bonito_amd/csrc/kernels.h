@@ -66,3 +66,6 @@ int bh_k_ctc_greedy(const float* logp, const long* offs, int R, int C, float qsc
 size_t bh_k_ctc_beam_workspace(long total_steps, int R, int C, int beam_size);
 int bh_k_ctc_prefix_beam(const float* logp, const long* offs, int R, int C, int beam_size, float threshold, void* workspace,
                          int8_t* labels, int* path, int* count, hipStream_t stream);
+size_t bh_k_posterior_viterbi_workspace(int N, int T, int state_len);
+int bh_k_posterior_viterbi(const void* scores, int N, int T, int state_len, float blank, void* workspace, int8_t* moves,
+                           int8_t* path, hipStream_t stream);

@@ -204,3 +204,20 @@ def logz(scores, blank_score=2.0):
         _lib.check(lib.bh_crf_logz(_lib.ptr(scores), N, T, sl, float(blank_score), _lib.ptr(ws), _lib.ptr(out),
                                    _lib.stream_ptr(scores.device)), "bh_crf_logz")
     return out.cpu()
+
+
+def posterior_viterbi(scores, blank_score=2.0):
+    """SeqdistModel.decode_batch's decoder (crf/model.py:196-199): best path over log edge posteriors.
+    scores cuda fp16 [N, T, 4S] -> CPU int8 (moves, path)."""
+    _check_scores(scores)
+    N, T, Cc = scores.shape
+    sl = state_len_of(Cc)
+    lib = _lib.lib()
+    dev = scores.device
+    ws = torch.empty(lib.bh_crf_posterior_viterbi_workspace(N, T, sl), dtype=torch.uint8, device=dev)
+    moves = torch.empty((N, T), dtype=torch.int8, device=dev)
+    path = torch.empty((N, T), dtype=torch.int8, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(lib.bh_crf_posterior_viterbi(_lib.ptr(scores), N, T, sl, float(blank_score), _lib.ptr(ws),
+                                                _lib.ptr(moves), _lib.ptr(path), _lib.stream_ptr(dev)), "bh_crf_posterior_viterbi")
+    return moves.cpu(), path.cpu()

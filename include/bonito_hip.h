@@ -146,6 +146,13 @@ int bh_crf_reverse_complement(const void* in, void* out, int N, int T, int state
 int bh_crf_logz(const void* scores, int N, int T, int state_len, float blank_score, void* workspace, double* logz,
                 void* stream);
 
+/* Posterior decoding = SeqdistModel.decode_batch (crf/model.py:196-199): Viterbi over log(edge posteriors + 1e-8).
+ * scores: contiguous koi layout [N][T][4S]; moves/path as bh_crf_viterbi.
+ * workspace: bh_crf_posterior_viterbi_workspace(N, T, state_len) bytes. */
+size_t bh_crf_posterior_viterbi_workspace(int N, int T, int state_len);
+int bh_crf_posterior_viterbi(const void* scores, int N, int T, int state_len, float blank_score, void* workspace,
+                             int8_t* moves, int8_t* path, void* stream);
+
 /* Beam-search decode: drop-in for koi.decode.beam_search(scores, beam_width=32, beam_cut=100.0, scale=1.0,
  * offset=0.0, blank_score=2.0) (bonito/crf/basecall.py:27,36-40).  scores: device fp16 contiguous
  * [N][T][4^(state_len+1)] (koi layout).  Outputs are DEVICE int8 [N][T], zero where nothing is emitted:

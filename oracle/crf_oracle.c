@@ -511,3 +511,73 @@ int oracle_ctc_prefix_beam(const float* lp, int T, int C, int beam_size, float t
     free(parent); free(label); free(tstep); free(child);
     return 0;
 }
+
+/* Posterior decoding (SeqdistModel.decode_batch, bonito/crf/model.py:196-199): post = posteriors(scores) + 1e-8,
+ * then the Max-semiring best path over log(post). Plain fp64 forward/backward here (independent of the table
+ * LSE used by the kernel), koi layout. */
+int oracle_crf_posterior_viterbi(const uint16_t* scores, int N, int T, int state_len, float blank, int8_t* moves,
+                                 int8_t* path) {
+    const int S = ipow4(state_len), q = S / 4;
+    double* al = (double*)malloc(sizeof(double) * (size_t)(T + 1) * S);
+    double* be = (double*)malloc(sizeof(double) * (size_t)(T + 1) * S);
+    double* v0 = (double*)malloc(sizeof(double) * S);
+    double* v1 = (double*)malloc(sizeof(double) * S);
+    uint8_t* bp = (uint8_t*)malloc((size_t)T * S);
+    if (!al || !be || !v0 || !v1 || !bp) { free(al); free(be); free(v0); free(v1); free(bp); return -1; }
+    for (int n = 0; n < N; ++n) {
+        const uint16_t* sn = scores + (size_t)n * T * 4 * S;
+        for (int j = 0; j < S; ++j) { al[j] = 0.0; be[(size_t)T * S + j] = 0.0; }
+        for (int t = 0; t < T; ++t)
+            for (int j = 0; j < S; ++j) {
+                double v[5], m;
+                for (int k = 0; k < 5; ++k) {
+                    const int src = k == 0 ? j : (k - 1) * q + (j >> 2);
+                    v[k] = al[(size_t)t * S + src] + ms(sn + (size_t)t * 4 * S, 0, blank, j, k);
+                }
+                m = v[0];
+                for (int k = 1; k < 5; ++k) if (v[k] > m) m = v[k];
+                double s = 0;
+                for (int k = 0; k < 5; ++k) s += exp(v[k] - m);
+                al[(size_t)(t + 1) * S + j] = m + log(s);
+            }
+        for (int t = T - 1; t >= 0; --t) {
+            for (int i = 0; i < S; ++i) be[(size_t)t * S + i] = -INFINITY;
+            for (int j = 0; j < S; ++j)
+                for (int k = 0; k < 5; ++k) {
+                    const int src = k == 0 ? j : (k - 1) * q + (j >> 2);
+                    const double x = ms(sn + (size_t)t * 4 * S, 0, blank, j, k) + be[(size_t)(t + 1) * S + j];
+                    double* d = &be[(size_t)t * S + src];
+                    if (*d == -INFINITY) *d = x;
+                    else { const double m = *d > x ? *d : x; *d = m + log(exp(*d - m) + exp(x - m)); }
+                }
+        }
+        double lz;
+        { double m = -INFINITY, s = 0; for (int j = 0; j < S; ++j) if (al[(size_t)T * S + j] > m) m = al[(size_t)T * S + j];
+          for (int j = 0; j < S; ++j) s += exp(al[(size_t)T * S + j] - m); lz = m + log(s); }
+        for (int j = 0; j < S; ++j) v0[j] = 0.0;
+        for (int t = 0; t < T; ++t) {
+            for (int j = 0; j < S; ++j) {
+                double best = 0; int bk = 0;
+                for (int k = 0; k < 5; ++k) {
+                    const int src = k == 0 ? j : (k - 1) * q + (j >> 2);
+                    const double lp = al[(size_t)t * S + src] + ms(sn + (size_t)t * 4 * S, 0, blank, j, k) +
+                                      be[(size_t)(t + 1) * S + j] - lz;
+                    const double c = log(exp(lp) + 1e-8) + v0[src];
+                    if (k == 0 || c > best) { best = c; bk = k; }
+                }
+                v1[j] = best; bp[(size_t)t * S + j] = (uint8_t)bk;
+            }
+            double* tmp = v0; v0 = v1; v1 = tmp;
+        }
+        int st = 0;
+        for (int j = 1; j < S; ++j) if (v0[j] > v0[st]) st = j;
+        for (int t = T - 1; t >= 0; --t) {
+            const int k = bp[(size_t)t * S + st];
+            moves[(size_t)n * T + t] = (int8_t)(k != 0);
+            path[(size_t)n * T + t] = (int8_t)(k != 0 ? 1 + (st & 3) : 0);
+            if (k != 0) st = (k - 1) * q + (st >> 2);
+        }
+    }
+    free(al); free(be); free(v0); free(v1); free(bp);
+    return 0;
+}

@@ -212,3 +212,33 @@ def reverse_complement(scores, state_len, layout_5s=True):
                 r, j = divmod(src, S)
                 out[:, :, j2 * 4 + r2] = a[:, ::-1, j * 4 + r]
     return out
+
+
+def posterior_viterbi(scores, state_len, blank=2.0):
+    """decode_batch's decoder on koi-layout scores [N,T,4S]: (moves, path)."""
+    a, bits = _as_half_bits(scores)
+    N, T, _ = a.shape
+    moves = np.zeros((N, T), np.int8)
+    path = np.zeros((N, T), np.int8)
+    rc = _lib().oracle_crf_posterior_viterbi(bits.ctypes.data_as(C.c_void_p), N, T, int(state_len), C.c_float(blank),
+                                             moves.ctypes.data_as(C.c_void_p), path.ctypes.data_as(C.c_void_p))
+    if rc:
+        raise RuntimeError("oracle_crf_posterior_viterbi failed")
+    return moves, path
+
+
+def posterior_viterbi_autograd(scores_4s, state_len, blank=2.0):
+    """Literal restatement of crf/model.py:196-199 with torch autograd posteriors (fp64): path [N,T]."""
+    import torch
+    x5 = expand_blanks(np.asarray(scores_4s, dtype=np.float64), blank).transpose(1, 0, 2).copy()      # [T,N,5S]
+    x = torch.as_tensor(x5).requires_grad_(True)
+    T, N, _ = x.shape
+    S = 4 ** state_len
+    idx = torch.as_tensor(idx_table(state_len))
+    Ms = x.reshape(T, N, S, 5)
+    alpha = torch.zeros(N, S, dtype=torch.float64)
+    for t in range(T):
+        alpha = torch.logsumexp(Ms[t] + alpha[:, idx], dim=-1)
+    torch.logsumexp(alpha, dim=-1).sum().backward()
+    post = x.grad + 1e-8
+    return viterbi_autograd(post.log().numpy(), state_len).T

@@ -165,3 +165,41 @@ def test_logz_matches_oracle():
         _, _, lz = crf_ref.backward(sc, sl)
         assert np.allclose(got, lz, rtol=0, atol=1e-6 * np.abs(lz).max() + 1e-4)
         assert np.allclose(got, crf_ref.logz(sc, sl), rtol=0, atol=5e-3)
+
+
+@pytest.mark.parametrize("state_len", [1, 3, 4, 5])
+def test_posterior_viterbi_matches_oracle(state_len):
+    # decode_batch's decoder (crf/model.py:196-199). The kernel's alpha/beta are fp32 table-LSE scans, the oracle
+    # is fp64: near-ties of the edge posteriors may resolve differently, so require >= 99.5 % identical path entries
+    # on random scores and identical decoded sequences on confident (model-like) scores.
+    rng = np.random.default_rng(60 + state_len)
+    N, T = (3, 90) if state_len == 5 else (8, 250)
+    sc = _scores(rng, N, T, 4 ** (state_len + 1), "normal")
+    moves, path = decode.posterior_viterbi(torch.from_numpy(sc).cuda())
+    om, op = crf_ref.posterior_viterbi(sc, state_len)
+    agree = (path.numpy() == op).mean()
+    assert agree >= 0.995, agree
+    assert np.array_equal(moves.numpy(), (path.numpy() != 0).astype(np.int8))
+
+
+def test_posterior_viterbi_confident_scores_exact_and_model_api():
+    from bonito_amd.synthetic import make_model
+    rng = np.random.default_rng(9)
+    model = make_model("fast")
+    state_len, N, T = model.seqdist.state_len, 6, 400
+    S = 4 ** state_len
+    sc = (rng.standard_normal((N, T, 4 * S)) * 0.5 - 3.0)
+    for n in range(N):
+        st = int(rng.integers(S))
+        for t in range(T):
+            if rng.random() < 0.45:
+                new = (st * 4 + int(rng.integers(4))) % S
+                sc[n, t, new * 4 + st // (S // 4)] = 4.5
+                st = new
+    sc = np.clip(sc, -5, 5).astype(np.float16)
+    moves, path = decode.posterior_viterbi(torch.from_numpy(sc).cuda())
+    om, op = crf_ref.posterior_viterbi(sc, state_len)
+    assert np.array_equal(path.numpy(), op)
+    assert np.array_equal(moves.numpy(), om)
+    seqs = model.decode_batch(torch.from_numpy(sc).cuda())
+    assert seqs == [model.seqdist.path_to_str(p) for p in op]

@@ -150,3 +150,32 @@ def test_reverse_complement_decodes_to_revcomp_sequence():
         core = fwd[sl:-sl]
         assert len(core) > 10 and core in rev, (fwd, rev)
     assert np.array_equal(crf_ref.reverse_complement(rc, sl, layout_5s=False), sc)      # involution
+
+
+@pytest.mark.parametrize("state_len", [1, 2, 3])
+def test_posterior_viterbi_matches_autograd_reference_formulation(state_len):
+    # decode_batch (crf/model.py:196-199): viterbi(log(posteriors + 1e-8)); the C oracle uses explicit fp64
+    # forward/backward, the restatement uses autograd posteriors as the reference does.
+    rng = np.random.default_rng(40 + state_len)
+    sc = np.clip(rng.standard_normal((3, 60, 4 ** (state_len + 1))) * 2.5, -5, 5).astype(np.float16)
+    moves, path = crf_ref.posterior_viterbi(sc, state_len)
+    ref = crf_ref.posterior_viterbi_autograd(sc, state_len)
+    assert np.array_equal(path, ref)
+    assert np.array_equal(moves, (path != 0).astype(np.int8))
+
+
+def test_posterior_viterbi_equals_viterbi_on_peaked_scores():
+    # one dominant path -> posterior decoding and MAP decoding agree
+    rng = np.random.default_rng(5)
+    state_len, T = 3, 120
+    S = 4 ** state_len
+    sc = np.full((1, T, 4 * S), -5.0, np.float16)
+    st = 0
+    for t in range(T):
+        if rng.random() < 0.5:
+            b = int(rng.integers(4)); new = (st * 4 + b) % S
+            sc[0, t, new * 4 + (st // (S // 4))] = 5.0
+            st = new
+    _, p1 = crf_ref.posterior_viterbi(sc, state_len)
+    _, p2, _ = crf_ref.viterbi(sc, state_len, layout_5s=False, blank=2.0)
+    assert np.array_equal(p1, p2)
