@@ -325,6 +325,18 @@ struct LstmFusedArgs {
     LstmArgs a;          // G unused
 };
 
+// MFMA whose A operand (a stationary W_hh fragment) lives in the accumulation-register half of the unified
+// register file: the 48 fragments of a slice (192 registers at H=384) would otherwise crowd the 256 architected
+// VGPRs and serialise every LDS read behind its consumer. The compiler does not track MFMA hazards through
+// inline asm: callers keep >= 19 wait states between the last mfma16_a() and the first VALU read of `c`
+// (mfma_settle()) and never issue one directly after a VALU write of its operands.
+__device__ __forceinline__ void mfma16_a(const half8_t& a_agpr, const half8_t& b, float4_t& c) {
+    asm("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(c) : "a"(a_agpr), "v"(b));
+}
+__device__ __forceinline__ void mfma_settle(float4_t& c0, float4_t& c1, float4_t& c2, float4_t& c3) {
+    asm volatile("s_nop 15\n\ts_nop 7" : "+a"(c0), "+a"(c1), "+a"(c2), "+a"(c3));
+}
+
 template <int NKS>
 __global__ __launch_bounds__(256, 1) void lstm_layer_fused_kernel(LstmFusedArgs fp) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -393,7 +405,9 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_fused_kernel(LstmFusedArgs 
     uint4_t xf[NKS];
 #pragma unroll
     for (int ks = 0; ks < NKS; ++ks) xf[ks] = *(const uint4_t*)(xptr + (long)t * x_row + ks * 32);
-    long long st_poll = 0, st_rounds = 0, st_first_ok = 0;
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) asm volatile("" : "+v"(xf[ks]));      // landed (see the step loop)
+    long long st_poll = 0, st_rounds = 0, st_first_ok = 0, st_x = 0, st_re = 0, st_rec = 0, st_hist = 0;
     const long long st_t0 = __builtin_readcyclecounter();
 
     for (int step = 0; step < p.T; ++step, t += dt) {
@@ -401,25 +415,59 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_fused_kernel(LstmFusedArgs 
 #pragma unroll
         for (int g = 0; g < 4; ++g) acc[g] = bias4[g];
         uint4_t hf[NKS];
-        // ---- 1. wait for h_{t-1}: nothing of ours is ahead of these loads in the memory queue -------------
+        // ---- 1. ask for h_{t-1} (first poll round): the x_t loads of the previous step are the only thing ahead
+        //         of these in the memory queue, and they have had a whole recurrent phase to land -----------------
+        const char* base = (const char*)p.h + (long)(t - dt) * row_bytes;
+        __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(step > 0 ? base : (const char*)p.h), 0,
+                                                                      (int)row_bytes, 0x00020000);
+        const long long pc0 = (p.tune & 4) ? __builtin_readcyclecounter() : 0;
         if (step > 0) {
-            const char* base = (const char*)p.h + (long)(t - dt) * row_bytes;
-            __amdgpu_buffer_rsrc_t rs =
-                __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)row_bytes, 0x00020000);
-            unsigned spins = dead ? p.max_spins : 0u;
-            unsigned pend = (NKS >= 32) ? 0xffffffffu : ((1u << NKS) - 1u);
-            const long long pc0 = (p.tune & 4) ? __builtin_readcyclecounter() : 0;
-            unsigned rounds = 0;
-            if (p.tune & 2) {     // canary: spin on ONE k-step (1/NKS of the traffic) until it is valid
-                const int kc = (slice * 5 + 3) % NKS;
-                while (spins <= p.max_spins) {
-                    const uint4_t v = __builtin_amdgcn_raw_buffer_load_b128(rs, voff + kc * 64, 0, (int)0x80000010);
-                    if (!__any(((v.x | v.y | v.z | v.w) & SENTINEL_MASK) != 0)) break;
-                    ++spins;
-                    if (!(p.tune & 1)) __builtin_amdgcn_s_sleep(1);
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks)
+                hf[ks] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff + ks * 64, 0, (int)0x80000010);
+        }
+        // ---- 2. input projection of this step while the exchange is in flight (W_ih fragments stream from LDS,
+        //         one k-step ahead of the MFMAs that consume them) -----------------------------------------------
+        {
+            half8_t a_cur[4], a_nxt[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) a_cur[g] = *(const half8_t*)(wl + (g * NKS) * 1024);
+            __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) {
+                if (ks + 1 < NKS) {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) a_nxt[g] = *(const half8_t*)(wl + (g * NKS + ks + 1) * 1024);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
                 }
+                const half8_t xb = __builtin_bit_cast(half8_t, xf[ks]);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) acc[g] = mfma16(a_cur[g], xb, acc[g]);
+                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) a_cur[g] = a_nxt[g];
             }
-            while (true) {
+        }
+        const long long pc1 = (p.tune & 4) ? __builtin_readcyclecounter() : 0;
+        // ---- 3. h_{t-1} must be complete: check the first round, re-poll only the k-steps still holding a
+        //         sentinel ---------------------------------------------------------------------------------------
+        if (step > 0) {
+            unsigned spins = dead ? p.max_spins : 0u;
+            unsigned pend = 0;
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) {
+                unsigned orv = hf[ks].x | hf[ks].y | hf[ks].z | hf[ks].w;
+                if (__any((orv & SENTINEL_MASK) != 0)) pend |= (1u << ks);
+            }
+            unsigned rounds = 1;
+            const long long pc2 = (p.tune & 4) ? __builtin_readcyclecounter() : 0;
+            while (pend != 0) {
+                if (++spins > p.max_spins) {
+                    if (lane == 0 && !dead) atomicExch(p.err, 1);
+                    dead = true;
+                    break;
+                }
+                if (!(p.tune & 1)) __builtin_amdgcn_s_sleep(1);
 #pragma unroll
                 for (int ks = 0; ks < NKS; ++ks)
                     if (pend & (1u << ks))
@@ -431,42 +479,30 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_fused_kernel(LstmFusedArgs 
                         if (!__any((orv & SENTINEL_MASK) != 0)) pend &= ~(1u << ks);
                     }
                 ++rounds;
-                if (pend == 0) break;
-                if (++spins > p.max_spins) {
-                    if (lane == 0 && !dead) atomicExch(p.err, 1);
-                    dead = true;
-                    break;
-                }
-                if (!(p.tune & 1)) __builtin_amdgcn_s_sleep(1);
             }
-            if (p.tune & 4) { st_poll += __builtin_readcyclecounter() - pc0; st_rounds += rounds; st_first_ok += (rounds == 1); }
+            if (p.tune & 4) {
+                const long long now = __builtin_readcyclecounter();
+                st_poll += now - pc0; st_rounds += rounds; st_first_ok += (rounds == 1);
+                st_x += pc1 - pc0; st_re += now - pc2;
+                st_hist += 1ll << (16 * (rounds > 3 ? 3 : rounds - 1));     // 4 x 16-bit histogram: 1,2,3,>=4 rounds
+            }
         }
-        // ---- 2. input projection of this step (x_t was fetched during the previous step) ------------------
-        half8_t xb[NKS];
-#pragma unroll
-        for (int ks = 0; ks < NKS; ++ks) xb[ks] = __builtin_bit_cast(half8_t, xf[ks]);
-        // ---- 3. fetch x of the next step: a whole step (exchange + compute) to land -----------------------
+        const long long pc3 = (p.tune & 4) ? __builtin_readcyclecounter() : 0;
+        // ---- 4. fetch x of the next step (behind the poll loads in the queue; lands during the recurrent phase) --
         {
             const int tn = (step + 1 < p.T) ? t + dt : t;
 #pragma unroll
             for (int ks = 0; ks < NKS; ++ks) xf[ks] = *(const uint4_t*)(xptr + (long)tn * x_row + ks * 32);
         }
-#pragma unroll
-        for (int ks = 0; ks < NKS; ++ks) {
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const half8_t a = *(const half8_t*)(wl + (g * NKS + ks) * 1024);
-                acc[g] = mfma16(a, xb[ks], acc[g]);
-            }
-        }
-        // ---- 4. recurrent part ------------------------------------------------------------------------------
+        // ---- 5. recurrent part ------------------------------------------------------------------------------
         if (step > 0) {
 #pragma unroll
             for (int ks = 0; ks < NKS; ++ks) {
                 half8_t b = __builtin_bit_cast(half8_t, hf[ks]);
 #pragma unroll
-                for (int g = 0; g < 4; ++g) acc[g] = mfma16(w[g][ks], b, acc[g]);
+                for (int g = 0; g < 4; ++g) mfma16_a(w[g][ks], b, acc[g]);
             }
+            mfma_settle(acc[0], acc[1], acc[2], acc[3]);
         }
         half4_t ho;
 #pragma unroll
@@ -480,17 +516,27 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_fused_kernel(LstmFusedArgs 
             hv = (fabsf(hv) <= 1.0f) ? hv : 0.0f;
             ho[i] = (half_t)hv;
         }
+        // x_{t+1} (requested before the recurrent phase) must have landed BEFORE h_t is published: with nothing but
+        // the h_t store ahead of them, the next step's poll loads are the only entries of the in-order memory
+        // counter the input-projection has to look at.
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) asm volatile("" : "+v"(xf[ks]));
         unsigned long long packed = __builtin_bit_cast(unsigned long long, ho);
         unsigned long long* dst = (unsigned long long*)(p.h + ((long)t * p.N + n) * H + hu0);
         if (fast) *dst = packed;
         else __hip_atomic_store(dst, packed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (p.tune & 4) st_rec += __builtin_readcyclecounter() - pc3;
     }
     if ((p.tune & 4) && lane == 0) {
-        long long* st = (long long*)((char*)p.xcc_ws + (((size_t)p.n_rings * NSL * sizeof(int) + 64 + 7) & ~(size_t)7)) + ((long)ring * NSL + slice) * 4;
+        long long* st = (long long*)((char*)p.xcc_ws + (((size_t)p.n_rings * NSL * sizeof(int) + 64 + 7) & ~(size_t)7)) + ((long)ring * NSL + slice) * 8;
         st[0] = __builtin_readcyclecounter() - st_t0;
         st[1] = st_poll;
         st[2] = st_rounds;
         st[3] = st_first_ok;
+        st[4] = st_x;
+        st[5] = st_re;
+        st[6] = st_rec;
+        st[7] = st_hist;
     }
 }
 
@@ -507,9 +553,9 @@ __global__ void fill_u16_kernel(uint16_t* dst, uint16_t v, size_t count) {
 
 size_t bh_k_lstm_packed_bytes(int H) { return (size_t)4 * H * H * 2; }
 size_t bh_k_lstm_ws_bytes(int N, int H) {
-    // XCD agreement slots + (tune bit 4) per-wave statistics: 4 x int64 per (ring, slice)
+    // XCD agreement slots + (tune bit 4) per-wave statistics: 8 x int64 per (ring, slice)
     const size_t waves = (size_t)((N + 15) / 16) * (H / 16);
-    return waves * sizeof(int) + 64 + waves * 4 * sizeof(long long) + 64;
+    return waves * sizeof(int) + 64 + waves * 8 * sizeof(long long) + 64;
 }
 
 int bh_k_fill_u16(void* dst, uint16_t value, size_t count, hipStream_t stream) {
