@@ -87,6 +87,25 @@ extern "C" int bh_lstm_pack_whh(const float* whh, int H, uint16_t* packed) {
     return 0;
 }
 
+// Tile packing for the workgroup-shared LSTM kernel: [slice][tile m][kstep][lane][8] with U = 4*MT units per slice;
+// row r of tile m is (unit slice*U + (r>>2)*MT + m, gate r&3), so the MFMA result leaves all four gate
+// pre-activations of MT consecutive units in one lane. w is [4H][H] in torch gate order (W_hh, or W_ih when
+// insize == H).
+static int lstm_pack_tiles(const float* w, int H, int MT, uint16_t* packed) {
+    const int U = 4 * MT, nks = H / 32, nsl = H / U;
+    for (int s = 0; s < nsl; ++s)
+        for (int m = 0; m < MT; ++m)
+            for (int ks = 0; ks < nks; ++ks)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int j = 0; j < 8; ++j) {
+                        const int r = lane & 15;
+                        const int row = (r & 3) * H + s * U + (r >> 2) * MT + m;
+                        const int col = ks * 32 + (lane >> 4) * 8 + j;
+                        packed[((((size_t)s * MT + m) * nks + ks) * 64 + lane) * 8 + j] = f2h(w[(size_t)row * H + col]);
+                    }
+    return 0;
+}
+
 // ------------------------------------------------------------------------------------------------
 namespace {
 
@@ -155,7 +174,8 @@ struct bh_encoder {
     int rot_len = 0;
     int out_features = 0;
     int lstm_force_slow = 0;
-    int lstm_fused = 1;          // compute the input projection inside the recurrence kernel when insize == hidden
+    int lstm_fused = 2;          // insize == hidden: 2 = workgroup-shared fused kernel where it covers H, 1 = per-wave fused
+                                 // kernel (input projection inside the recurrence), 0 = projection by a GEMM beforehand
     // optional per-kernel-class timing with HIP events on the caller's stream (bench.py roofline leg)
     bool profiling = false;
     struct Span { int cls; hipEvent_t a, b; };
@@ -344,6 +364,14 @@ extern "C" int bh_encoder_create(const bh_layer_t* layers, int n_layers, int dev
                     std::vector<uint16_t> pk((size_t)4 * H * H);
                     rc = bh_lstm_pack_whh(d.w0, H, pk.data());
                     if (!rc) rc = upload(L.w2, pk.data(), pk.size() * 2);
+                }
+                if (!rc && I == H && bh_k_lstm_wg_units(H) != 0) {    // tile-packed pair for the workgroup-shared kernel
+                    const int MT = bh_k_lstm_wg_units(H) / 4;
+                    std::vector<uint16_t> pk((size_t)4 * H * H);
+                    rc = lstm_pack_tiles(d.w1, H, MT, pk.data());
+                    if (!rc) rc = upload(L.w3, pk.data(), pk.size() * 2);
+                    if (!rc) rc = lstm_pack_tiles(d.w0, H, MT, pk.data());
+                    if (!rc) rc = upload(L.w4, pk.data(), pk.size() * 2);
                 }
                 break;
             }
@@ -590,6 +618,7 @@ extern "C" int bh_encoder_forward(bh_encoder_t* e, const void* signal, int N, in
                 void* dst = e->act[which].p;
                 const bool reg_path = H <= 512 && H % 32 == 0;
                 const bool fused = reg_path && e->lstm_fused && d.in_size == H && l.w2.p != nullptr;
+                const bool wg = fused && e->lstm_fused >= 2 && l.w3.p != nullptr && l.w4.p != nullptr;
                 if (!fused) {
                     ProfSpan span(e, st, BH_PROF_LSTM_GEMM);
                     rc = bh_k_linear(cur, l.w0.p, (const float*)l.b0.p, e->gates.p, M, 4 * H, d.in_size, d.in_size,
@@ -604,14 +633,19 @@ extern "C" int bh_encoder_forward(bh_encoder_t* e, const void* signal, int N, in
                 ProfSpan span(e, st, BH_PROF_LSTM_REC);
                 // co-residency: one launch serves at most (CUs / (8 * H/16)) * 32 rings
                 const int nsl = H / 16;
-                const int groups_fit = reg_path ? e->n_cus / (8 * nsl) : e->n_cus / (8 * (nsl / 4));
+                const int wg_wpr = wg ? (H / bh_k_lstm_wg_units(H)) / 4 : 1;     // workgroups per ring (wg variant)
+                const int groups_fit = wg ? e->n_cus / (8 * wg_wpr) : reg_path ? e->n_cus / (8 * nsl) : e->n_cus / (8 * (nsl / 4));
                 BH_REQUIRE(groups_fit >= 1, "encoder_forward: device has too few CUs (%d) for hidden size %d", e->n_cus, H);
-                const int rings_per_launch = reg_path ? groups_fit * 32 : groups_fit * 8;
+                const int rings_per_launch = wg ? groups_fit * 8 : reg_path ? groups_fit * 32 : groups_fit * 8;
                 const int n_rings = Np / 16;
                 for (int r0 = 0; r0 < n_rings; r0 += rings_per_launch) {
                     const int nr = std::min(rings_per_launch, n_rings - r0);
                     const size_t col = (size_t)r0 * 16;
-                    if (fused)
+                    if (wg)
+                        rc = bh_k_lstm_layer_wg((const char*)cur + col * H * 2, l.w4.p, (const float*)l.b0.p, l.w3.p,
+                                                (char*)dst + col * H * 2, len, Np, H, d.reverse, (int*)e->err.p, st, nr,
+                                                (int*)e->lstm_ws.p, e->lstm_force_slow);
+                    else if (fused)
                         rc = bh_k_lstm_layer_fused((const char*)cur + col * H * 2, l.w2.p, (const float*)l.b0.p, l.w1.p,
                                                    (char*)dst + col * H * 2, len, Np, H, d.reverse, (int*)e->err.p, st, nr,
                                                    (int*)e->lstm_ws.p, e->lstm_force_slow);

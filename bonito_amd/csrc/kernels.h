@@ -33,6 +33,9 @@ int bh_k_lstm_layer_fused(const void* x, const void* wih_packed, const float* bi
                           int force_slow);
 int bh_k_fill_u16(void* dst, uint16_t value, size_t count, hipStream_t stream);
 size_t bh_k_lstm_packed_bytes(int H);
+int bh_k_lstm_wg_units(int H);
+int bh_k_lstm_layer_wg(const void* x, const void* wih_tiles, const float* bias, const void* whh_tiles, void* h_out, int T, int N,
+                       int H, int reverse, int* err_flag, hipStream_t stream, int n_rings, int* xcc_ws, int force_slow);
 
 // crf.hip
 int bh_k_crf_viterbi(const void* scores, int N, int T, int state_len, int layout_5s, float blank_score,

@@ -540,6 +540,286 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_fused_kernel(LstmFusedArgs 
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Workgroup-shared exchange ("wg" variant): the four waves of a workgroup are four SLICES OF THE SAME RING.
+// Every wave owns U = 4*MT hidden units (MT M-tiles whose 16 rows are 4 units x 4 gates, so a lane ends up with all
+// four gate pre-activations of MT units), holds BOTH its W_hh and W_ih fragments in registers (H=384, U=12:
+// 2*144 registers of the 512-entry unified file) and the workgroup shares h_{t-1} and x_{t+1} through LDS:
+// each wave polls / fetches only a QUARTER of the k-steps from global memory and deposits it as ready-made B
+// fragments, one workgroup barrier per step publishes them. Compared with lstm_layer_fused_kernel this cuts the
+// L2 read traffic of the exchange and of the x stream by 4x (it was 768 waves x 12 KB x ~2.5 per step at hac
+// size, i.e. L2-bandwidth-bound polling), needs no LDS for weights and keeps all 256 CUs busy at N=512, H=384.
+// Exchange protocol (sentinel pre-fill, data-as-flag, XCD agreement, bounded spins) is unchanged.
+__device__ __forceinline__ void mfma16_av(const half8_t& a_agpr, const half8_t& b, float4_t& c) {
+    asm("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(c) : "a"(a_agpr), "v"(b));
+}
+__device__ __forceinline__ void mfma16_vv(const half8_t& a, const half8_t& b, float4_t& c) {
+    asm("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+}
+template <int MT>
+__device__ __forceinline__ void mfma_settle_v(float4_t (&c)[MT]) {
+    if constexpr (MT == 3) asm volatile("s_nop 15\n\ts_nop 7" : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]));
+    else asm volatile("s_nop 15\n\ts_nop 7" : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]));
+}
+
+template <int NKS, int MT>
+__global__ __launch_bounds__(256, 1) void lstm_layer_wg_kernel(LstmFusedArgs fp) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const LstmArgs& p = fp.a;
+    constexpr int H = NKS * 32, U = 4 * MT, NSL = H / U, WPR = NSL / 4, KQ = (NKS + 3) / 4;
+    constexpr bool EXACT = NKS % 4 == 0;     // every wave owns exactly KQ k-steps
+    static_assert(H % (4 * U) == 0, "four slices per workgroup");
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int xcd = blockIdx.x & 7;
+    const int lwg = blockIdx.x >> 3;
+    const int rl = lwg / WPR;
+    const int ring = rl * 8 + xcd;
+    const int slice = (lwg - rl * WPR) * 4 + wave;
+    if (ring >= p.n_rings) return;                      // whole workgroup (same ring) leaves together
+
+    char* hbuf = smem;                                  // [2][NKS][64 lanes][16 B]  B fragments of h_{t-1}
+    char* xbuf = smem + 2 * NKS * 1024;                 // [2][NKS][64][16]          B fragments of x_t
+    char* stage = smem + 4 * NKS * 1024 + wave * (16 * U * 2);   // per-wave [16 chunks][U] output transpose
+
+    half8_t whh[MT][NKS], wih[MT][NKS];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+            const long o = ((((long)slice * MT + m) * NKS + ks) * 64 + lane) * 8;
+            whh[m][ks] = *(const half8_t*)(p.whh + o);
+            wih[m][ks] = *(const half8_t*)(fp.wih + o);
+        }
+
+    const int c = lane & 15, q = lane >> 4;
+    const long row_bytes = (long)p.N * H * 2;
+    const unsigned voff = (unsigned)(((ring * 16 + c) * H + q * 8) * 2);
+    float cst[MT];
+    float4_t bias4[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        cst[m] = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) bias4[m][i] = fp.bias[i * H + slice * U + q * MT + m];
+    }
+    bool dead = false;
+
+    bool fast = false;
+    {
+        int* slot = p.xcc_ws + (long)ring * NSL;
+        const int mine = xcc_id();
+        if (lane == 0) __hip_atomic_store(slot + slice, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned spins = 0;
+        bool ok = false;
+        while (true) {
+            int v = (lane < NSL) ? __hip_atomic_load(slot + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : mine;
+            if (!__any(v < 0)) { ok = !__any(v != mine); break; }
+            if (++spins > p.max_spins) break;
+            __builtin_amdgcn_s_sleep(4);
+        }
+        fast = ok && !p.force_slow;
+    }
+
+    int t = p.reverse ? p.T - 1 : 0;
+    const int dt = p.reverse ? -1 : 1;
+    const half_t* xptr = fp.x + ((long)(ring * 16 + c) * H + q * 8);
+    const long x_row = (long)p.N * H;
+    const int lo = lane * 16;
+
+    // this wave's quarter of the k-steps: ks = wave + 4*kk
+    uint4_t xq[KQ], hq[KQ];
+    float4_t xacc[MT];
+
+    auto x_phase = [&](const char* xb) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m) xacc[m] = bias4[m];
+        half8_t b_cur = *(const half8_t*)(xb + lo), b_nxt = b_cur;
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+            if (ks + 1 < NKS) b_nxt = *(const half8_t*)(xb + (ks + 1) * 1024 + lo);
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                if (m < MT - 1) mfma16_av(wih[m][ks], b_cur, xacc[m]);
+                else mfma16_vv(wih[m][ks], b_cur, xacc[m]);
+            }
+            b_cur = b_nxt;
+        }
+        mfma_settle_v<MT>(xacc);
+    };
+
+    // ---- prologue: x_0 -> LDS -> input projection of step 0; x_1 quarter on its way ---------------------
+#pragma unroll
+    for (int kk = 0; kk < KQ; ++kk) {
+        const int ks = wave + 4 * kk;
+        if (EXACT || ks < NKS) *(uint4_t*)(xbuf + ks * 1024 + lo) = *(const uint4_t*)(xptr + (long)t * x_row + ks * 32);
+    }
+    {
+        const int t1 = p.T > 1 ? t + dt : t;
+#pragma unroll
+        for (int kk = 0; kk < KQ; ++kk) {
+            const int ks = wave + 4 * kk;
+            if (EXACT || ks < NKS) xq[kk] = *(const uint4_t*)(xptr + (long)t1 * x_row + ks * 32);
+        }
+    }
+    __syncthreads();
+    x_phase(xbuf);
+#pragma unroll
+    for (int kk = 0; kk < KQ; ++kk) hq[kk] = uint4_t{0, 0, 0, 0};
+
+    long long st_poll = 0, st_rounds = 0, st_first_ok = 0, st_x = 0, st_rec = 0, st_bar = 0, st_hist = 0;
+    const long long st_t0 = __builtin_readcyclecounter();
+
+    for (int step = 0; step < p.T; ++step, t += dt) {
+        const int par = step & 1;
+        float4_t acc[MT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) acc[m] = xacc[m];
+        // ---- A. x_{t+1} quarter (requested one step ago) -> LDS --------------------------------------------
+#pragma unroll
+        for (int kk = 0; kk < KQ; ++kk) {
+            const int ks = wave + 4 * kk;
+            if (EXACT || ks < NKS) *(uint4_t*)(xbuf + ((par ^ 1) * NKS + ks) * 1024 + lo) = xq[kk];
+        }
+        // ---- B. my quarter of h_{t-1}: round one was issued right after the previous store ------------------
+        const long long pc0 = (p.tune & 4) ? __builtin_readcyclecounter() : 0;
+        if (step > 0) {
+            const char* base = (const char*)p.h + (long)(t - dt) * row_bytes;
+            __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)row_bytes, 0x00020000);
+            unsigned spins = dead ? p.max_spins : 0u;
+            unsigned pend = 0;
+#pragma unroll
+            for (int kk = 0; kk < KQ; ++kk) {
+                const int ks = wave + 4 * kk;
+                if (EXACT || ks < NKS) {
+                    unsigned orv = hq[kk].x | hq[kk].y | hq[kk].z | hq[kk].w;
+                    if (__any((orv & SENTINEL_MASK) != 0)) pend |= (1u << kk);
+                }
+            }
+            unsigned rounds = 1;
+            while (pend != 0) {
+                if (++spins > p.max_spins) {
+                    if (lane == 0 && !dead) atomicExch(p.err, 1);
+                    dead = true;
+                    break;
+                }
+                if (!(p.tune & 1)) __builtin_amdgcn_s_sleep(1);
+#pragma unroll
+                for (int kk = 0; kk < KQ; ++kk)
+                    if (pend & (1u << kk))
+                        hq[kk] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff + (wave + 4 * kk) * 64, 0, (int)0x80000010);
+#pragma unroll
+                for (int kk = 0; kk < KQ; ++kk)
+                    if (pend & (1u << kk)) {
+                        unsigned orv = hq[kk].x | hq[kk].y | hq[kk].z | hq[kk].w;
+                        if (!__any((orv & SENTINEL_MASK) != 0)) pend &= ~(1u << kk);
+                    }
+                ++rounds;
+            }
+#pragma unroll
+            for (int kk = 0; kk < KQ; ++kk) {
+                const int ks = wave + 4 * kk;
+                if (EXACT || ks < NKS) *(uint4_t*)(hbuf + (par * NKS + ks) * 1024 + lo) = hq[kk];
+            }
+            if (p.tune & 4) {
+                st_poll += __builtin_readcyclecounter() - pc0; st_rounds += rounds; st_first_ok += (rounds == 1);
+                st_hist += 1ll << (16 * (rounds > 3 ? 3 : rounds - 1));
+            }
+        }
+        // ---- C. request the x quarter of step t+2 (behind the polls in the memory queue) --------------------
+        {
+            const int t2 = (step + 2 < p.T) ? t + 2 * dt : t;
+#pragma unroll
+            for (int kk = 0; kk < KQ; ++kk) {
+                const int ks = wave + 4 * kk;
+                if (EXACT || ks < NKS) xq[kk] = *(const uint4_t*)(xptr + (long)t2 * x_row + ks * 32);
+            }
+        }
+        // ---- D. publish both tiles to the workgroup ----------------------------------------------------------
+        const long long pc1 = (p.tune & 4) ? __builtin_readcyclecounter() : 0;
+        __syncthreads();
+        const long long pc2 = (p.tune & 4) ? __builtin_readcyclecounter() : 0;
+        // ---- E. recurrent part, gates, publish h_t ------------------------------------------------------------
+        if (step > 0) {
+            const char* hb = hbuf + par * NKS * 1024 + lo;
+            half8_t b_cur = *(const half8_t*)hb, b_nxt = b_cur;
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) {
+                if (ks + 1 < NKS) b_nxt = *(const half8_t*)(hb + (ks + 1) * 1024);
+#pragma unroll
+                for (int m = 0; m < MT; ++m) mfma16_av(whh[m][ks], b_cur, acc[m]);
+                b_cur = b_nxt;
+            }
+            mfma_settle_v<MT>(acc);
+        }
+        half_t ho[MT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            float ig = sigmoidf_(acc[m][0]);
+            float fg = sigmoidf_(acc[m][1]);
+            float gg = tanh_gate(acc[m][2]);
+            float og = sigmoidf_(acc[m][3]);
+            cst[m] = fg * cst[m] + ig * gg;
+            float hv = og * tanh_gate(cst[m]);
+            hv = (fabsf(hv) <= 1.0f) ? hv : 0.0f;      // keep the sentinel space clean
+            ho[m] = (half_t)hv;
+        }
+        // x_{t+2} must have landed before h_t is published (keeps the vm counter of the next step clean)
+#pragma unroll
+        for (int kk = 0; kk < KQ; ++kk) asm volatile("" : "+v"(xq[kk]));
+        if constexpr (MT == 4) {
+            half4_t h4 = {ho[0], ho[1], ho[2], ho[3]};
+            unsigned long long packed = __builtin_bit_cast(unsigned long long, h4);
+            unsigned long long* dst = (unsigned long long*)(p.h + ((long)t * p.N + ring * 16 + c) * H + slice * U + q * 4);
+            if (fast) *dst = packed;
+            else __hip_atomic_store(dst, packed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            // lane (q, c) holds units q*MT..q*MT+MT-1 of chunk c: transpose through the wave's LDS patch so that the
+            // global store is 8 bytes per lane (U/4 lanes per chunk)
+            half_t* sg = (half_t*)stage + c * U + q * MT;
+#pragma unroll
+            for (int m = 0; m < MT; ++m) sg[m] = ho[m];
+            constexpr int PARTS = U / 4;
+            if (lane < 16 * PARTS) {
+                const int cc = lane / PARTS, part = lane - cc * PARTS;
+                const unsigned long long packed = *(const unsigned long long*)((half_t*)stage + cc * U + part * 4);
+                unsigned long long* dst =
+                    (unsigned long long*)(p.h + ((long)t * p.N + ring * 16 + cc) * H + slice * U + part * 4);
+                if (fast) *dst = packed;
+                else __hip_atomic_store(dst, packed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        // ---- F. first poll round for h_t goes out now; it is checked after the input projection -------------
+        if (step + 1 < p.T) {
+            const char* base = (const char*)p.h + (long)t * row_bytes;
+            __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)row_bytes, 0x00020000);
+#pragma unroll
+            for (int kk = 0; kk < KQ; ++kk) {
+                const int ks = wave + 4 * kk;
+                if (EXACT || ks < NKS) hq[kk] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff + ks * 64, 0, (int)0x80000010);
+            }
+        }
+        const long long pc3 = (p.tune & 4) ? __builtin_readcyclecounter() : 0;
+        // ---- G. input projection of step t+1 from the LDS tile published at D --------------------------------
+        x_phase(xbuf + (par ^ 1) * NKS * 1024);
+        if (p.tune & 4) {
+            const long long now = __builtin_readcyclecounter();
+            st_bar += pc2 - pc1; st_rec += pc3 - pc2; st_x += now - pc3;
+        }
+    }
+    if ((p.tune & 4) && lane == 0) {
+        long long* st = (long long*)((char*)p.xcc_ws + (((size_t)p.n_rings * NSL * sizeof(int) + 64 + 7) & ~(size_t)7)) + ((long)ring * NSL + slice) * 8;
+        st[0] = __builtin_readcyclecounter() - st_t0;
+        st[1] = st_poll;
+        st[2] = st_rounds;
+        st[3] = st_first_ok;
+        st[4] = st_x;
+        st[5] = st_bar;
+        st[6] = st_rec;
+        st[7] = st_hist;
+    }
+}
+
 __global__ void fill_u16_kernel(uint16_t* dst, uint16_t v, size_t count) {
     size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 8;
     const size_t stride = (size_t)gridDim.x * blockDim.x * 8;
@@ -554,7 +834,7 @@ __global__ void fill_u16_kernel(uint16_t* dst, uint16_t v, size_t count) {
 size_t bh_k_lstm_packed_bytes(int H) { return (size_t)4 * H * H * 2; }
 size_t bh_k_lstm_ws_bytes(int N, int H) {
     // XCD agreement slots + (tune bit 4) per-wave statistics: 8 x int64 per (ring, slice)
-    const size_t waves = (size_t)((N + 15) / 16) * (H / 16);
+    const size_t waves = (size_t)((N + 15) / 16) * ((H + 11) / 12);      // up to H/12 slices per ring (wg variant)
     return waves * sizeof(int) + 64 + waves * 8 * sizeof(long long) + 64;
 }
 
@@ -673,6 +953,54 @@ int bh_k_lstm_layer_fused(const void* x, const void* wih_packed, const float* bi
         default: BH_REQUIRE(false, "lstm: unsupported H=%d", H);
     }
 #undef BH_LSTM_CASE
+    BH_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// Workgroup-shared variant: usable when 4*U | H (U = 12 or 16 units per wave) and both weight sets fit the
+// register file. Returns the units-per-wave it would use, 0 if the shape is not covered.
+int bh_k_lstm_wg_units(int H) {
+    if (H % 32 != 0) return 0;
+    const int nks = H / 32;
+    if (H % 48 == 0 && nks <= 12) return 12;
+    if (H % 64 == 0 && nks <= 8) return 16;
+    return 0;
+}
+
+int bh_k_lstm_layer_wg(const void* x, const void* wih_packed, const float* bias, const void* whh_packed, void* h_out,
+                       int T, int N, int H, int reverse, int* err_flag, hipStream_t stream, int n_rings, int* xcc_ws,
+                       int force_slow) {
+    using namespace bh;
+    BH_REQUIRE(N % 16 == 0, "lstm: batch must be padded to a multiple of 16 (N=%d)", N);
+    const int U = bh_k_lstm_wg_units(H);
+    BH_REQUIRE(U != 0, "lstm: workgroup-shared kernel does not cover H=%d", H);
+    BH_REQUIRE(x != h_out, "lstm: fused layer cannot run in place");
+    int dev = 0, cus = 0;
+    BH_CHECK_HIP(hipGetDevice(&dev));
+    BH_CHECK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    const int nsl = H / U, wpr = nsl / 4;
+    BH_REQUIRE(n_rings > 0 && n_rings <= N / 16, "lstm: n_rings=%d outside 1..%d", n_rings, N / 16);
+    const int rl = (n_rings + 7) / 8;
+    const int grid = 8 * rl * wpr;
+    BH_REQUIRE(grid <= cus, "lstm: %d workgroups must be co-resident but the device has %d CUs; split the batch", grid, cus);
+    BH_REQUIRE(xcc_ws != nullptr, "lstm: missing XCD agreement workspace");
+    BH_CHECK_HIP(hipMemsetAsync(xcc_ws, 0xFF, (size_t)n_rings * nsl * sizeof(int), stream));
+    LstmFusedArgs a{(const half_t*)x, (const half_t*)wih_packed, bias,
+                    LstmArgs{nullptr, (const half_t*)whh_packed, (half_t*)h_out, T, N, H, n_rings, reverse, err_flag, 1000000u,
+                             xcc_ws, force_slow & 1, force_slow >> 8}};
+    const int nks = H / 32;
+    const size_t lds = (size_t)4 * nks * 1024 + 4 * 16 * U * 2;
+#define BH_LSTM_WG(NKS, MT)                                                                                      \
+    if (nks == NKS && U == 4 * MT) {                                                                             \
+        if (lds > 64 * 1024)                                                                                     \
+            BH_CHECK_HIP(hipFuncSetAttribute((const void*)lstm_layer_wg_kernel<NKS, MT>,                         \
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));            \
+        hipLaunchKernelGGL((lstm_layer_wg_kernel<NKS, MT>), dim3(grid), dim3(256), lds, stream, a);               \
+    } else
+    BH_LSTM_WG(3, 3) BH_LSTM_WG(6, 3) BH_LSTM_WG(9, 3) BH_LSTM_WG(12, 3)
+    BH_LSTM_WG(2, 4) BH_LSTM_WG(4, 4) BH_LSTM_WG(8, 4)
+    { BH_REQUIRE(false, "lstm: workgroup-shared kernel has no instance for H=%d", H); }
+#undef BH_LSTM_WG
     BH_CHECK_HIP(hipGetLastError());
     return 0;
 }

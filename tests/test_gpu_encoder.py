@@ -110,25 +110,51 @@ def test_transformer_encoder_matches_reference_fixture(name):
 
 
 def test_fused_and_unfused_lstm_paths_agree():
-    """The fused kernel (input projection inside the recurrence) and the GEMM + recurrence pair are two
-    implementations of the same layer: both must match the reference fixture; they differ only by the fp16
-    rounding of the intermediate gate tensor."""
+    """The workgroup-shared fused kernel (2), the per-wave fused kernel (1) and the GEMM + recurrence pair (0) are three
+    implementations of the same layer: all must match the reference fixture; 0 differs from the fused ones only by
+    the fp16 rounding of the intermediate gate tensor."""
     cfg, sd, x, y = load_nn_fixture("lstm96_sl3")
     model = build_model(cfg, sd)
     want = ref_scores_to_koi(y)
     outs = {}
-    for fused in (1, 0):
+    for fused in (2, 1, 0):
         enc = HipEncoder(model, batchsize=x.shape[0], chunksize=x.shape[-1])
         enc.set_option("lstm_fused", fused)
         outs[fused] = enc(x.half().cuda()).cpu().float()
         enc.check()
-        assert (outs[fused] - want).abs().max().item() < TOL_MAX
+        assert (outs[fused] - want).abs().max().item() < TOL_MAX, fused
     assert (outs[0] - outs[1]).abs().max().item() < 2e-2
-    enc = HipEncoder(model, batchsize=x.shape[0], chunksize=x.shape[-1])
-    enc.set_option("lstm_force_slow", 1)
-    slow = enc(x.half().cuda()).cpu().float()
-    enc.check()
-    assert torch.equal(slow, outs[1])               # exchange policy never changes the bytes
+    assert (outs[2] - outs[1]).abs().max().item() < 2e-2
+    for fused in (2, 1):
+        enc = HipEncoder(model, batchsize=x.shape[0], chunksize=x.shape[-1])
+        enc.set_option("lstm_fused", fused)
+        enc.set_option("lstm_force_slow", 1)
+        slow = enc(x.half().cuda()).cpu().float()
+        enc.check()
+        assert torch.equal(slow, outs[fused])               # exchange policy never changes the bytes
+
+
+@pytest.mark.parametrize("H,sl", [(384, 4), (256, 3), (128, 2), (192, 3), (64, 2)])
+def test_workgroup_shared_lstm_kernel_widths(H, sl):
+    """Every hidden size the workgroup-shared kernel instantiates (U = 12: 96/192/288/384, U = 16: 64/128/256),
+    forward and reverse layers, batch not a multiple of 16, against the fp32 oracle of the reference modules."""
+    from bonito_amd import nn as bnn, synthetic
+    torch.manual_seed(H)
+    cfg = synthetic.lstm_crf_encoder_config(H, sl, n_lstm=3)
+    model = bnn.from_dict(cfg)
+    synthetic.randomise_batchnorm_(model)
+    nn_ref.round_params_to_half_(model)
+    x = torch.randn(21, 1, 900).half()
+    with torch.no_grad():
+        want = nn_ref.forward(model, x.float(), expand_blanks=False).permute(1, 0, 2)
+    outs = {}
+    for fused in (2, 1):
+        enc = HipEncoder(model, batchsize=21, chunksize=900)
+        enc.set_option("lstm_fused", fused)
+        outs[fused] = enc(x.cuda()).cpu().float()
+        enc.check()
+        assert (outs[fused] - want).abs().max().item() < TOL_MAX, fused
+    assert (outs[2] - outs[1]).abs().max().item() < 2e-2
 
 
 def test_wide_lstm_model_runs_through_streaming_kernel():

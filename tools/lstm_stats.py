@@ -10,9 +10,11 @@ model = model.half().cuda()
 sig = torch.randn(512, 1, 10000, device="cuda").half()
 model(sig)
 enc = model._hip
+mode = int(sys.argv[1]) if len(sys.argv) > 1 else 2        # lstm_fused option: 2 = workgroup-shared, 1 = per-wave
+enc.set_option("lstm_fused", mode)
 enc.set_option("lstm_tune", 4)
 model(sig); torch.cuda.synchronize(); enc.check()
-rings, nsl, T = 32, 24, 1667
+rings, nsl, T = 32, (32 if mode == 2 else 24), 1667
 xcc = np.zeros(rings * nsl, np.int32)
 _lib.check(_lib.lib().bh_encoder_debug_read(enc._handle, xcc.ctypes.data_as(C.c_void_p), xcc.nbytes, 0))
 off = (rings * nsl * 4 + 64 + 7) & ~7
@@ -25,7 +27,10 @@ print("cycles/step total  mean %.0f  (min %.0f max %.0f)" % (tot.mean() / T, tot
 print("cycles/step in poll mean %.0f  -> %.0f%% of the step" % (poll.mean() / T, 100 * poll.mean() / tot.mean()))
 print("poll rounds/step mean %.2f; first round already complete in %.1f%% of steps" % (rounds.mean() / T, 100 * first.mean() / T))
 xph, re, rec = [st[..., i].astype(float).mean() / T for i in (4, 5, 6)]
-print("cycles/step: issue polls + input projection %.0f | re-poll rounds %.0f | x fetch + recurrent + gates + store %.0f" % (xph, re, rec))
+if mode == 2:
+    print("cycles/step: input projection %.0f | workgroup barrier %.0f | recurrent + gates + store + poll issue %.0f" % (xph, re, rec))
+else:
+    print("cycles/step: issue polls + input projection %.0f | re-poll rounds %.0f | x fetch + recurrent + gates + store %.0f" % (xph, re, rec))
 hist = st[..., 7].astype(np.uint64)
 h = [((hist >> np.uint64(16 * i)) & np.uint64(0xffff)).astype(float).mean() / T for i in range(4)]
 print("rounds histogram (1,2,3,>=4): %s" % " ".join("%.3f" % v for v in h))
