@@ -70,11 +70,8 @@ def cpu_baseline_worker(name, chunk, seconds_budget=15.0):
     from oracle import crf_ref, nn_ref
     model = build_model(name, 8, chunk)
     nn_ref.round_params_to_half_(model)
-    try:
-        ncores = len(os.sched_getaffinity(0))
-    except AttributeError:
-        ncores = os.cpu_count() or 1
-    ncores = max(1, min(ncores, 32))      # small per-step matmuls stop scaling long before that
+    from bonito_amd.util import effective_cpu_count
+    ncores = max(1, min(effective_cpu_count(), 32))      # affinity capped by the cgroup quota; small matmuls stop scaling early
     torch.set_num_threads(ncores)
     n = 2 if name == "sup" else 8
     x = torch.randn(n, 1, chunk, generator=torch.Generator().manual_seed(25)).half().float()
@@ -118,6 +115,8 @@ def main():
     dev = torch.device("cuda", local)
 
     from bonito_amd import decode, synthetic
+    from bonito_amd.util import limit_host_threads
+    log("host threads: %d" % limit_host_threads(4))
     log("building model %s" % a.model)
     model = build_model(a.model, a.batch, a.chunk)
     model.use_koi(batchsize=a.batch, chunksize=a.chunk, quantize=False)
@@ -211,7 +210,10 @@ def main():
         flops_per_launch = work * a.batch / launches_per_fwd
         avg_ms = ms / spans
         achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12
-        roof = {"kernel": {"lstm_rec": "lstm_layer_fused_kernel" if prof["lstm_gemm"][1] == 0 else "lstm_layer_kernel", "lstm_gemm": "gemm_kernel", "crf_linear": "gemm_kernel",
+        lstm_h = {"fast": 96, "hac": 384}.get(a.model, 0)
+        lstm_kernel = ("lstm_layer_kernel" if prof["lstm_gemm"][1] else
+                       "lstm_layer_wg_kernel" if lstm_h and (lstm_h % 48 == 0 or lstm_h in (64, 128, 256)) else "lstm_layer_fused_kernel")
+        roof = {"kernel": {"lstm_rec": lstm_kernel, "lstm_gemm": "gemm_kernel", "crf_linear": "gemm_kernel",
                            "conv": "conv_igemm_kernel", "mlp": "gemm_kernel (fc1 gated + fc2) + rmsnorm_residual_kernel",
                            "attention": "gemm_kernel (Wqkv, out_proj) + attention_kernel + rmsnorm_residual_kernel"}[cls],
                 "bound": "mfma", "achieved": round(achieved, 2), "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",

@@ -22,6 +22,7 @@ from bonito_amd.reader import Reader
 
 def main(args):
     util.init(args.seed, args.device)
+    util.limit_host_threads(8)       # host work is small copies; never out-spin a container's CPU quota
     try:
         reader = Reader(args.reads_directory, args.recursive)
         sys.stderr.write("> reading %s\n" % args.reads_directory)

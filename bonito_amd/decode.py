@@ -61,9 +61,9 @@ class CRFDecoder:
             """(sequence, qstring, moves) CPU int8 [N, T] (copies, safe to keep)."""
             self.dec.done.synchronize()
             h = self.dec.host_out[:, : self.n]
-            # plain pageable copies: .clone() of a pinned tensor would hipHostMalloc a new pinned block (~6 ms each)
-            out = torch.empty(h.shape, dtype=h.dtype)
-            out.copy_(h)
+            # plain pageable copy, single-threaded on purpose: .clone() of a pinned tensor would hipHostMalloc a new
+            # pinned block (~6 ms), and torch's parallel CPU copy wakes the whole intra-op pool for 2.5 MB
+            out = torch.from_numpy(np.array(h.numpy(), copy=True))
             return out[0], out[1], out[2]
 
     def submit(self, scores):

@@ -91,3 +91,9 @@ def ref_scores_to_koi(y, blank_score_present=True):
     if not blank_score_present:
         return y.permute(1, 0, 2).contiguous()
     return y.view(T, N, C // 5, 5)[..., 1:].reshape(T, N, -1).permute(1, 0, 2).contiguous()
+
+
+def pytest_sessionstart(session):
+    # quota'd containers (256 visible CPUs, 16-core CFS quota): keep torch's intra-op pool from spinning into throttling
+    from bonito_amd.util import limit_host_threads
+    limit_host_threads(8)
