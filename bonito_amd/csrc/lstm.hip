@@ -57,7 +57,17 @@ constexpr unsigned SENTINEL_MASK = 0x40004000u;
 
 // Gate-math tanh: the exp form has absolute error ~1e-7 everywhere, which is all the recurrence needs
 // (h and c are consumed at fp16 / additive precision); the relative-accuracy branch of common.h's tanhf_ is skipped.
-__device__ __forceinline__ float tanh_gate(float x) { return 1.0f - 2.0f * rcpf_(__expf(2.0f * x) + 1.0f); }
+__device__ __forceinline__ float tanh_gate(float x) { return __builtin_fmaf(-2.0f, rcpf_(__expf(2.0f * x) + 1.0f), 1.0f); }
+
+// One cell update from the four gate pre-activations (torch order i, f, g, o). The contractions are spelled out so
+// that every kernel variant of this file produces the same bits for the same pre-activations; the returned h is
+// forced into [-1, 1] so that a non-finite value can never alias the exchange sentinel.
+__device__ __forceinline__ float lstm_cell(float ai, float af, float ag, float ao, float& c) {
+    const float ig = sigmoidf_(ai), fg = sigmoidf_(af), gg = tanh_gate(ag), og = sigmoidf_(ao);
+    c = __builtin_fmaf(fg, c, __fmul_rn(ig, gg));
+    const float hv = __fmul_rn(og, tanh_gate(c));
+    return (fabsf(hv) <= 1.0f) ? hv : 0.0f;
+}
 
 template <int NKS>
 __global__ __launch_bounds__(256, 1) void lstm_layer_kernel(LstmArgs p) {
@@ -164,14 +174,9 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_kernel(LstmArgs p) {
         half4_t ho;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            float ig = sigmoidf_(acc[0][i] + (float)gin[0][i]);
-            float fg = sigmoidf_(acc[1][i] + (float)gin[1][i]);
-            float gg = tanh_gate(acc[2][i] + (float)gin[2][i]);
-            float og = sigmoidf_(acc[3][i] + (float)gin[3][i]);
-            cst[i] = fg * cst[i] + ig * gg;
-            float hv = og * tanh_gate(cst[i]);
-            // keep the sentinel space clean: a non-finite or out-of-range h can never be published
-            hv = (fabsf(hv) <= 1.0f) ? hv : 0.0f;
+            // a non-finite or out-of-range h can never be published (keeps the sentinel space clean)
+            const float hv = lstm_cell(acc[0][i] + (float)gin[0][i], acc[1][i] + (float)gin[1][i],
+                                       acc[2][i] + (float)gin[2][i], acc[3][i] + (float)gin[3][i], cst[i]);
             ho[i] = (half_t)hv;
         }
         unsigned long long packed = __builtin_bit_cast(unsigned long long, ho);
@@ -290,14 +295,9 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_stream_kernel(LstmArgs p) {
         half4_t ho;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            float ig = sigmoidf_(acc[0][i] + (float)gin[0][i]);
-            float fg = sigmoidf_(acc[1][i] + (float)gin[1][i]);
-            float gg = tanh_gate(acc[2][i] + (float)gin[2][i]);
-            float og = sigmoidf_(acc[3][i] + (float)gin[3][i]);
-            cst[i] = fg * cst[i] + ig * gg;
-            float hv = og * tanh_gate(cst[i]);
-            // keep the sentinel space clean: a non-finite or out-of-range h can never be published
-            hv = (fabsf(hv) <= 1.0f) ? hv : 0.0f;
+            // a non-finite or out-of-range h can never be published (keeps the sentinel space clean)
+            const float hv = lstm_cell(acc[0][i] + (float)gin[0][i], acc[1][i] + (float)gin[1][i],
+                                       acc[2][i] + (float)gin[2][i], acc[3][i] + (float)gin[3][i], cst[i]);
             ho[i] = (half_t)hv;
         }
         unsigned long long packed = __builtin_bit_cast(unsigned long long, ho);
@@ -507,13 +507,7 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_fused_kernel(LstmFusedArgs 
         half4_t ho;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            float ig = sigmoidf_(acc[0][i]);
-            float fg = sigmoidf_(acc[1][i]);
-            float gg = tanh_gate(acc[2][i]);
-            float og = sigmoidf_(acc[3][i]);
-            cst[i] = fg * cst[i] + ig * gg;
-            float hv = og * tanh_gate(cst[i]);
-            hv = (fabsf(hv) <= 1.0f) ? hv : 0.0f;
+            const float hv = lstm_cell(acc[0][i], acc[1][i], acc[2][i], acc[3][i], cst[i]);
             ho[i] = (half_t)hv;
         }
         // x_{t+1} (requested before the recurrent phase) must have landed BEFORE h_t is published: with nothing but
@@ -628,7 +622,7 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_wg_kernel(LstmFusedArgs fp)
     const int lo = lane * 16;
 
     // this wave's quarter of the k-steps: ks = wave + 4*kk
-    uint4_t xq[KQ], hq[KQ];
+    uint4_t xq[KQ], xr[KQ], hq[KQ];     // x quarters of step+1 (landed) and step+2 (in flight), h quarter being polled
     float4_t xacc[MT];
 
     auto x_phase = [&](const char* xb) {
@@ -648,19 +642,20 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_wg_kernel(LstmFusedArgs fp)
         mfma_settle_v<MT>(xacc);
     };
 
-    // ---- prologue: x_0 -> LDS -> input projection of step 0; x_1 quarter on its way ---------------------
-#pragma unroll
-    for (int kk = 0; kk < KQ; ++kk) {
-        const int ks = wave + 4 * kk;
-        if (EXACT || ks < NKS) *(uint4_t*)(xbuf + ks * 1024 + lo) = *(const uint4_t*)(xptr + (long)t * x_row + ks * 32);
-    }
+    // ---- prologue: x_0 -> LDS -> input projection of step 0; x_1 landed, x_2 on its way -------------------------------
     {
-        const int t1 = p.T > 1 ? t + dt : t;
+        const int t1 = p.T > 1 ? t + dt : t, t2 = p.T > 2 ? t + 2 * dt : t;
 #pragma unroll
         for (int kk = 0; kk < KQ; ++kk) {
             const int ks = wave + 4 * kk;
-            if (EXACT || ks < NKS) xq[kk] = *(const uint4_t*)(xptr + (long)t1 * x_row + ks * 32);
+            if (EXACT || ks < NKS) {
+                *(uint4_t*)(xbuf + ks * 1024 + lo) = *(const uint4_t*)(xptr + (long)t * x_row + ks * 32);
+                xq[kk] = *(const uint4_t*)(xptr + (long)t1 * x_row + ks * 32);
+                xr[kk] = *(const uint4_t*)(xptr + (long)t2 * x_row + ks * 32);
+            }
         }
+#pragma unroll
+        for (int kk = 0; kk < KQ; ++kk) asm volatile("" : "+v"(xq[kk]), "+v"(xr[kk]));    // landed: clean vm counter at loop entry
     }
     __syncthreads();
     x_phase(xbuf);
@@ -668,14 +663,16 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_wg_kernel(LstmFusedArgs fp)
     for (int kk = 0; kk < KQ; ++kk) hq[kk] = uint4_t{0, 0, 0, 0};
 
     long long st_poll = 0, st_rounds = 0, st_first_ok = 0, st_x = 0, st_rec = 0, st_bar = 0, st_hist = 0;
+    long long st_a = 0, st_c = 0, st_mf = 0, st_gate = 0, st_store = 0;
     const long long st_t0 = __builtin_readcyclecounter();
 
     for (int step = 0; step < p.T; ++step, t += dt) {
+        const long long pct = (p.tune & 4) ? __builtin_readcyclecounter() : 0;
         const int par = step & 1;
         float4_t acc[MT];
 #pragma unroll
         for (int m = 0; m < MT; ++m) acc[m] = xacc[m];
-        // ---- A. x_{t+1} quarter (requested one step ago) -> LDS --------------------------------------------
+        // ---- A. x_{t+1} quarter (in registers since the previous step) -> LDS --------------------------------------
 #pragma unroll
         for (int kk = 0; kk < KQ; ++kk) {
             const int ks = wave + 4 * kk;
@@ -726,13 +723,18 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_wg_kernel(LstmFusedArgs fp)
                 st_hist += 1ll << (16 * (rounds > 3 ? 3 : rounds - 1));
             }
         }
-        // ---- C. request the x quarter of step t+2 (behind the polls in the memory queue) --------------------
+        const long long pcc = (p.tune & 4) ? __builtin_readcyclecounter() : 0;
+        // ---- C. rotate the x quarters and request step t+3, in the memory-quiet phase before the barrier. Two steps of
+        //         slack: the loads are never waited for on the store -> poll -> barrier critical path, and they stay away
+        //         from the store / poll burst (issued right after the polls they cut first-round poll success from
+        //         93 % to 53 %; one step of slack with a wait before the h_t store: 41 %) ------------------------------
         {
-            const int t2 = (step + 2 < p.T) ? t + 2 * dt : t;
+            const int t3 = (step + 3 < p.T) ? t + 3 * dt : t;
 #pragma unroll
             for (int kk = 0; kk < KQ; ++kk) {
                 const int ks = wave + 4 * kk;
-                if (EXACT || ks < NKS) xq[kk] = *(const uint4_t*)(xptr + (long)t2 * x_row + ks * 32);
+                xq[kk] = xr[kk];
+                if (EXACT || ks < NKS) xr[kk] = *(const uint4_t*)(xptr + (long)t3 * x_row + ks * 32);
             }
         }
         // ---- D. publish both tiles to the workgroup ----------------------------------------------------------
@@ -742,31 +744,24 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_wg_kernel(LstmFusedArgs fp)
         // ---- E. recurrent part, gates, publish h_t ------------------------------------------------------------
         if (step > 0) {
             const char* hb = hbuf + par * NKS * 1024 + lo;
-            half8_t b_cur = *(const half8_t*)hb, b_nxt = b_cur;
+            half8_t hb_f[NKS];                       // all B fragments up front: one LDS latency, then MFMAs back to back
 #pragma unroll
-            for (int ks = 0; ks < NKS; ++ks) {
-                if (ks + 1 < NKS) b_nxt = *(const half8_t*)(hb + (ks + 1) * 1024);
+            for (int ks = 0; ks < NKS; ++ks) hb_f[ks] = *(const half8_t*)(hb + ks * 1024);
 #pragma unroll
-                for (int m = 0; m < MT; ++m) mfma16_av(whh[m][ks], b_cur, acc[m]);
-                b_cur = b_nxt;
-            }
+            for (int ks = 0; ks < NKS; ++ks)
+#pragma unroll
+                for (int m = 0; m < MT; ++m) mfma16_av(whh[m][ks], hb_f[ks], acc[m]);
             mfma_settle_v<MT>(acc);
         }
+        const long long pcm = (p.tune & 4) ? __builtin_readcyclecounter() : 0;
         half_t ho[MT];
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
-            float ig = sigmoidf_(acc[m][0]);
-            float fg = sigmoidf_(acc[m][1]);
-            float gg = tanh_gate(acc[m][2]);
-            float og = sigmoidf_(acc[m][3]);
-            cst[m] = fg * cst[m] + ig * gg;
-            float hv = og * tanh_gate(cst[m]);
-            hv = (fabsf(hv) <= 1.0f) ? hv : 0.0f;      // keep the sentinel space clean
+            const float hv = lstm_cell(acc[m][0], acc[m][1], acc[m][2], acc[m][3], cst[m]);
             ho[m] = (half_t)hv;
         }
-        // x_{t+2} must have landed before h_t is published (keeps the vm counter of the next step clean)
-#pragma unroll
-        for (int kk = 0; kk < KQ; ++kk) asm volatile("" : "+v"(xq[kk]));
+        const long long pcg = (p.tune & 4) ? __builtin_readcyclecounter() : 0;
+
         if constexpr (MT == 4) {
             half4_t h4 = {ho[0], ho[1], ho[2], ho[3]};
             unsigned long long packed = __builtin_bit_cast(unsigned long long, h4);
@@ -805,10 +800,11 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_wg_kernel(LstmFusedArgs fp)
         if (p.tune & 4) {
             const long long now = __builtin_readcyclecounter();
             st_bar += pc2 - pc1; st_rec += pc3 - pc2; st_x += now - pc3;
+            st_a += pc0 - pct; st_c += pc1 - pcc; st_mf += pcm - pc2; st_gate += pcg - pcm; st_store += pc3 - pcg;
         }
     }
     if ((p.tune & 4) && lane == 0) {
-        long long* st = (long long*)((char*)p.xcc_ws + (((size_t)p.n_rings * NSL * sizeof(int) + 64 + 7) & ~(size_t)7)) + ((long)ring * NSL + slice) * 8;
+        long long* st = (long long*)((char*)p.xcc_ws + (((size_t)p.n_rings * NSL * sizeof(int) + 64 + 7) & ~(size_t)7)) + ((long)ring * NSL + slice) * 16;
         st[0] = __builtin_readcyclecounter() - st_t0;
         st[1] = st_poll;
         st[2] = st_rounds;
@@ -817,6 +813,11 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_wg_kernel(LstmFusedArgs fp)
         st[5] = st_bar;
         st[6] = st_rec;
         st[7] = st_hist;
+        st[8] = st_a;
+        st[9] = st_c;
+        st[10] = st_mf;
+        st[11] = st_gate;
+        st[12] = st_store;
     }
 }
 
@@ -833,9 +834,9 @@ __global__ void fill_u16_kernel(uint16_t* dst, uint16_t v, size_t count) {
 
 size_t bh_k_lstm_packed_bytes(int H) { return (size_t)4 * H * H * 2; }
 size_t bh_k_lstm_ws_bytes(int N, int H) {
-    // XCD agreement slots + (tune bit 4) per-wave statistics: 8 x int64 per (ring, slice)
+    // XCD agreement slots + (tune bit 4) per-wave statistics: up to 16 x int64 per (ring, slice)
     const size_t waves = (size_t)((N + 15) / 16) * ((H + 11) / 12);      // up to H/12 slices per ring (wg variant)
-    return waves * sizeof(int) + 64 + waves * 8 * sizeof(long long) + 64;
+    return waves * sizeof(int) + 64 + waves * 16 * sizeof(long long) + 64;
 }
 
 int bh_k_fill_u16(void* dst, uint16_t value, size_t count, hipStream_t stream) {

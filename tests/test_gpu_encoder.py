@@ -124,7 +124,7 @@ def test_fused_and_unfused_lstm_paths_agree():
         enc.check()
         assert (outs[fused] - want).abs().max().item() < TOL_MAX, fused
     assert (outs[0] - outs[1]).abs().max().item() < 2e-2
-    assert (outs[2] - outs[1]).abs().max().item() < 2e-2
+    assert torch.equal(outs[2], outs[1])      # same arithmetic in the same order: lstm_cell() pins the contractions
     for fused in (2, 1):
         enc = HipEncoder(model, batchsize=x.shape[0], chunksize=x.shape[-1])
         enc.set_option("lstm_fused", fused)
