@@ -174,7 +174,8 @@ struct bh_encoder {
     int rot_len = 0;
     int out_features = 0;
     int lstm_force_slow = 0;
-    int lstm_fused = 2;          // insize == hidden: 2 = workgroup-shared fused kernel where it covers H, 1 = per-wave fused
+    int lstm_fused = 3;          // insize == hidden: 3 = + ring-in-a-workgroup kernel for narrow layers, 2 = workgroup-shared fused
+                                 // kernel where it covers H, 1 = per-wave fused
                                  // kernel (input projection inside the recurrence), 0 = projection by a GEMM beforehand
     // optional per-kernel-class timing with HIP events on the caller's stream (bench.py roofline leg)
     bool profiling = false;
@@ -619,13 +620,14 @@ extern "C" int bh_encoder_forward(bh_encoder_t* e, const void* signal, int N, in
                 const bool reg_path = H <= 512 && H % 32 == 0;
                 const bool fused = reg_path && e->lstm_fused && d.in_size == H && l.w2.p != nullptr;
                 const bool wg = fused && e->lstm_fused >= 2 && l.w3.p != nullptr && l.w4.p != nullptr;
+                const bool cta = wg && e->lstm_fused >= 3 && bh_k_lstm_cta_units(H) != 0 && bh_k_lstm_cta_units(H) == bh_k_lstm_wg_units(H);
                 if (!fused) {
                     ProfSpan span(e, st, BH_PROF_LSTM_GEMM);
                     rc = bh_k_linear(cur, l.w0.p, (const float*)l.b0.p, e->gates.p, M, 4 * H, d.in_size, d.in_size,
                                      d.in_size, 4 * H, bh::ACT_NONE, 1.0f, -INFINITY, INFINITY, 0, 0, 0, 0, 0, st);
                     if (rc) return rc;
                 }
-                {
+                if (!cta) {      // exchange sentinel (the ring-in-a-workgroup kernel exchanges through LDS only)
                     ProfSpan span(e, st, BH_PROF_FILL);
                     rc = bh_k_fill_u16(dst, 0xFFFFu, (size_t)M * H, st);
                     if (rc) return rc;
@@ -636,12 +638,15 @@ extern "C" int bh_encoder_forward(bh_encoder_t* e, const void* signal, int N, in
                 const int wg_wpr = wg ? (H / bh_k_lstm_wg_units(H)) / 4 : 1;     // workgroups per ring (wg variant)
                 const int groups_fit = wg ? e->n_cus / (8 * wg_wpr) : reg_path ? e->n_cus / (8 * nsl) : e->n_cus / (8 * (nsl / 4));
                 BH_REQUIRE(groups_fit >= 1, "encoder_forward: device has too few CUs (%d) for hidden size %d", e->n_cus, H);
-                const int rings_per_launch = wg ? groups_fit * 8 : reg_path ? groups_fit * 32 : groups_fit * 8;
+                const int rings_per_launch = cta ? (1 << 20) : wg ? groups_fit * 8 : reg_path ? groups_fit * 32 : groups_fit * 8;
                 const int n_rings = Np / 16;
                 for (int r0 = 0; r0 < n_rings; r0 += rings_per_launch) {
                     const int nr = std::min(rings_per_launch, n_rings - r0);
                     const size_t col = (size_t)r0 * 16;
-                    if (wg)
+                    if (cta)
+                        rc = bh_k_lstm_layer_cta((const char*)cur + col * H * 2, l.w4.p, (const float*)l.b0.p, l.w3.p,
+                                                 (char*)dst + col * H * 2, len, Np, H, d.reverse, st, nr);
+                    else if (wg)
                         rc = bh_k_lstm_layer_wg((const char*)cur + col * H * 2, l.w4.p, (const float*)l.b0.p, l.w3.p,
                                                 (char*)dst + col * H * 2, len, Np, H, d.reverse, (int*)e->err.p, st, nr,
                                                 (int*)e->lstm_ws.p, e->lstm_force_slow);

@@ -821,6 +821,121 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_wg_kernel(LstmFusedArgs fp)
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Ring-in-a-workgroup variant ("cta") for narrow layers (H = 64 / 96 / 128, e.g. the `fast` models): all H/U slices
+// of a ring are waves of ONE workgroup, both weight sets are register-resident, and h never leaves the CU on its way
+// to the next step - every wave drops its MT units straight into the LDS tile in B-fragment order, one workgroup
+// barrier per step publishes it. No sentinel pre-fill, no polling, no co-residency constraint: grid = rings.
+// The h tile is written to global memory (for the next layer) from the fragments the waves read back anyway,
+// 16 bytes per lane, off the critical path.
+template <int NKS, int MT>
+__global__ __launch_bounds__(64 * (NKS * 32 / (4 * MT)), 1) void lstm_layer_cta_kernel(LstmFusedArgs fp) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const LstmArgs& p = fp.a;
+    constexpr int H = NKS * 32, U = 4 * MT, NSL = H / U;
+    static_assert(NSL >= NKS && NSL <= 16, "one workgroup per ring");
+    const int lane = threadIdx.x & 63;
+    const int slice = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // wave index == slice
+    const int ring = blockIdx.x;
+    char* hbuf = smem;                          // [2][NKS][64][16 B]
+    char* xbuf = smem + 2 * NKS * 1024;         // [2][NKS][64][16 B]
+
+    half8_t whh[MT][NKS], wih[MT][NKS];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+            const long o = ((((long)slice * MT + m) * NKS + ks) * 64 + lane) * 8;
+            whh[m][ks] = *(const half8_t*)(p.whh + o);
+            wih[m][ks] = *(const half8_t*)(fp.wih + o);
+        }
+    const int c = lane & 15, q = lane >> 4;
+    const int lo = lane * 16;
+    float cst[MT];
+    float4_t bias4[MT];
+    int hoff[MT];                               // where this lane's units live inside a B-fragment tile
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        cst[m] = 0.f;
+        const int u = slice * U + q * MT + m;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) bias4[m][i] = fp.bias[i * H + u];
+        hoff[m] = (((u >> 5) * 64 + ((u >> 3) & 3) * 16 + c) * 16) + (u & 7) * 2;
+    }
+    int t = p.reverse ? p.T - 1 : 0;
+    const int dt = p.reverse ? -1 : 1;
+    const bool loader = slice < NKS;            // waves 0..NKS-1 move k-step `slice` of the x / h tiles
+    const half_t* xptr = fp.x + ((long)(ring * 16 + c) * H + slice * 32 + q * 8);
+    half_t* hptr = p.h + ((long)(ring * 16 + c) * H + slice * 32 + q * 8);
+    const long row = (long)p.N * H;
+
+    uint4_t xq = {0, 0, 0, 0}, xr = {0, 0, 0, 0};
+    float4_t xacc[MT];
+    auto x_phase = [&](const char* xb) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m) xacc[m] = bias4[m];
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+            const half8_t b = *(const half8_t*)(xb + ks * 1024 + lo);
+#pragma unroll
+            for (int m = 0; m < MT; ++m) xacc[m] = mfma16(wih[m][ks], b, xacc[m]);
+        }
+    };
+    // x tiles are published one step EARLIER than they are consumed (slot (t+1)&1 holds x_{t+1} during step t), so the
+    // input projection of step t+1 has no barrier of its own: it is issued right behind the h-MFMAs of step t and its
+    // MFMAs run under the gate arithmetic.
+    if (loader) {
+        const int t1 = p.T > 1 ? t + dt : t, t2 = p.T > 2 ? t + 2 * dt : t, t3 = p.T > 3 ? t + 3 * dt : t;
+        *(uint4_t*)(xbuf + slice * 1024 + lo) = *(const uint4_t*)(xptr + (long)t * row);
+        *(uint4_t*)(xbuf + (NKS + slice) * 1024 + lo) = *(const uint4_t*)(xptr + (long)t1 * row);
+        xq = *(const uint4_t*)(xptr + (long)t2 * row);
+        xr = *(const uint4_t*)(xptr + (long)t3 * row);
+    }
+    __syncthreads();
+    x_phase(xbuf);
+    __syncthreads();                                    // slot 0 is rewritten by step 0: every wave must be done with x_0
+
+    for (int step = 0; step < p.T; ++step, t += dt) {
+        const int par = step & 1;
+        if (loader) {                                   // x_{t+2} -> slot par (x_t was consumed a step ago), rotate, request x_{t+4}
+            const int t4 = (step + 4 < p.T) ? t + 4 * dt : t;
+            *(uint4_t*)(xbuf + (par * NKS + slice) * 1024 + lo) = xq;
+            xq = xr;
+            xr = *(const uint4_t*)(xptr + (long)t4 * row);
+        }
+        float4_t acc[MT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) acc[m] = xacc[m];
+        if (step > 0) {
+            const char* hb = hbuf + par * NKS * 1024 + lo;
+            half8_t hb_f[NKS];
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) hb_f[ks] = *(const half8_t*)(hb + ks * 1024);
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks)
+#pragma unroll
+                for (int m = 0; m < MT; ++m) acc[m] = mfma16(whh[m][ks], hb_f[ks], acc[m]);
+            // h_{t-1} leaves for global memory from the fragment this wave just read (k-step == wave index)
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks)
+                if (ks == slice) *(uint4_t*)(hptr + (long)(t - dt) * row) = __builtin_bit_cast(uint4_t, hb_f[ks]);
+        }
+        x_phase(xbuf + (par ^ 1) * NKS * 1024);         // projection of step t+1 (tile published by the previous barrier)
+        char* hn = hbuf + (par ^ 1) * NKS * 1024;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const float hv = lstm_cell(acc[m][0], acc[m][1], acc[m][2], acc[m][3], cst[m]);
+            *(half_t*)(hn + hoff[m]) = (half_t)hv;
+        }
+        __syncthreads();                                // h_t tile and x_{t+2} tile complete
+    }
+    // last h tile
+    if (loader) {
+        const int par = p.T & 1;
+        *(uint4_t*)(hptr + (long)(t - dt) * row) = *(const uint4_t*)(hbuf + (par * NKS + slice) * 1024 + lo);
+    }
+}
+
 __global__ void fill_u16_kernel(uint16_t* dst, uint16_t v, size_t count) {
     size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 8;
     const size_t stride = (size_t)gridDim.x * blockDim.x * 8;
@@ -1002,6 +1117,32 @@ int bh_k_lstm_layer_wg(const void* x, const void* wih_packed, const float* bias,
     BH_LSTM_WG(2, 4) BH_LSTM_WG(4, 4) BH_LSTM_WG(8, 4)
     { BH_REQUIRE(false, "lstm: workgroup-shared kernel has no instance for H=%d", H); }
 #undef BH_LSTM_WG
+    BH_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// Ring-in-a-workgroup kernel: covers the narrow layers whose two weight sets fit the registers of H/U <= 16 waves.
+int bh_k_lstm_cta_units(int H) {
+    if (H == 96) return 12;
+    if (H == 64 || H == 128) return 16;
+    return 0;
+}
+
+int bh_k_lstm_layer_cta(const void* x, const void* wih_tiles, const float* bias, const void* whh_tiles, void* h_out, int T, int N,
+                        int H, int reverse, hipStream_t stream, int n_rings) {
+    using namespace bh;
+    BH_REQUIRE(N % 16 == 0, "lstm: batch must be padded to a multiple of 16 (N=%d)", N);
+    const int U = bh_k_lstm_cta_units(H);
+    BH_REQUIRE(U != 0, "lstm: ring-in-a-workgroup kernel does not cover H=%d", H);
+    BH_REQUIRE(x != h_out, "lstm: fused layer cannot run in place");
+    BH_REQUIRE(n_rings > 0 && n_rings <= N / 16, "lstm: n_rings=%d outside 1..%d", n_rings, N / 16);
+    LstmFusedArgs a{(const half_t*)x, (const half_t*)wih_tiles, bias,
+                    LstmArgs{nullptr, (const half_t*)whh_tiles, (half_t*)h_out, T, N, H, n_rings, reverse, nullptr, 0u, nullptr, 0, 0}};
+    const int nks = H / 32, nsl = H / U;
+    const size_t lds = (size_t)4 * nks * 1024;
+    if (H == 96) hipLaunchKernelGGL((lstm_layer_cta_kernel<3, 3>), dim3(n_rings), dim3(64 * nsl), lds, stream, a);
+    else if (H == 64) hipLaunchKernelGGL((lstm_layer_cta_kernel<2, 4>), dim3(n_rings), dim3(64 * nsl), lds, stream, a);
+    else hipLaunchKernelGGL((lstm_layer_cta_kernel<4, 4>), dim3(n_rings), dim3(64 * nsl), lds, stream, a);
     BH_CHECK_HIP(hipGetLastError());
     return 0;
 }

@@ -110,14 +110,14 @@ def test_transformer_encoder_matches_reference_fixture(name):
 
 
 def test_fused_and_unfused_lstm_paths_agree():
-    """The workgroup-shared fused kernel (2), the per-wave fused kernel (1) and the GEMM + recurrence pair (0) are three
+    """The ring-in-a-workgroup kernel (3, narrow layers only), the workgroup-shared fused kernel (2), the per-wave fused kernel (1) and the GEMM + recurrence pair (0) are four
     implementations of the same layer: all must match the reference fixture; 0 differs from the fused ones only by
     the fp16 rounding of the intermediate gate tensor."""
     cfg, sd, x, y = load_nn_fixture("lstm96_sl3")
     model = build_model(cfg, sd)
     want = ref_scores_to_koi(y)
     outs = {}
-    for fused in (2, 1, 0):
+    for fused in (3, 2, 1, 0):
         enc = HipEncoder(model, batchsize=x.shape[0], chunksize=x.shape[-1])
         enc.set_option("lstm_fused", fused)
         outs[fused] = enc(x.half().cuda()).cpu().float()
@@ -125,6 +125,7 @@ def test_fused_and_unfused_lstm_paths_agree():
         assert (outs[fused] - want).abs().max().item() < TOL_MAX, fused
     assert (outs[0] - outs[1]).abs().max().item() < 2e-2
     assert torch.equal(outs[2], outs[1])      # same arithmetic in the same order: lstm_cell() pins the contractions
+    assert torch.equal(outs[3], outs[2])      # ring-in-a-workgroup kernel (H = 96 here): exchange through LDS only
     for fused in (2, 1):
         enc = HipEncoder(model, batchsize=x.shape[0], chunksize=x.shape[-1])
         enc.set_option("lstm_fused", fused)
@@ -148,13 +149,13 @@ def test_workgroup_shared_lstm_kernel_widths(H, sl):
     with torch.no_grad():
         want = nn_ref.forward(model, x.float(), expand_blanks=False).permute(1, 0, 2)
     outs = {}
-    for fused in (2, 1):
+    for fused in (3, 2, 1):
         enc = HipEncoder(model, batchsize=21, chunksize=900)
         enc.set_option("lstm_fused", fused)
         outs[fused] = enc(x.cuda()).cpu().float()
         enc.check()
         assert (outs[fused] - want).abs().max().item() < TOL_MAX, fused
-    assert (outs[2] - outs[1]).abs().max().item() < 2e-2
+    assert torch.equal(outs[2], outs[1]) and torch.equal(outs[3], outs[1])
 
 
 def test_wide_lstm_model_runs_through_streaming_kernel():
