@@ -63,9 +63,22 @@ __device__ __forceinline__ float tanh_gate(float x) { return __builtin_fmaf(-2.0
 // that every kernel variant of this file produces the same bits for the same pre-activations; the returned h is
 // forced into [-1, 1] so that a non-finite value can never alias the exchange sentinel.
 __device__ __forceinline__ float lstm_cell(float ai, float af, float ag, float ao, float& c) {
-    const float ig = sigmoidf_(ai), fg = sigmoidf_(af), gg = tanh_gate(ag), og = sigmoidf_(ao);
-    c = __builtin_fmaf(fg, c, __fmul_rn(ig, gg));
-    const float hv = __fmul_rn(og, tanh_gate(c));
+    // Transcendental issue (quarter rate) is what the gate arithmetic costs, so the five activations share
+    // reciprocals: with E_x = exp(-x),
+    //     c' = c * sig(f) + sig(i) * tanh(g) = (c * Di * Dg + (1 - Eg2) * Df) / (Df * Di * Dg),   D_x = 1 + E_x, Eg2 = exp(-2g)
+    //     h  = sig(o) * tanh(c')             = (1 - Ec2) / ((1 + Ec2) * Do)
+    // i.e. 5 exp + 2 rcp instead of 5 + 5. Pre-activations are clamped to +-25 (sig(-25) = 1.4e-11, far below what h
+    // can resolve) so that no product of three (1 + E) factors leaves the fp32 range.
+    const float ei = __expf(-__builtin_amdgcn_fmed3f(ai, -25.0f, 25.0f));
+    const float ef = __expf(-__builtin_amdgcn_fmed3f(af, -25.0f, 25.0f));
+    const float eg = __expf(-2.0f * __builtin_amdgcn_fmed3f(ag, -12.5f, 12.5f));
+    const float eo = __expf(-__builtin_amdgcn_fmed3f(ao, -25.0f, 25.0f));
+    const float didg = __fmul_rn(1.0f + ei, 1.0f + eg);
+    const float df = 1.0f + ef;
+    const float num = __builtin_fmaf(c, didg, __fmul_rn(1.0f - eg, df));
+    c = __fmul_rn(num, rcpf_(__fmul_rn(df, didg)));
+    const float ec = __expf(-2.0f * __builtin_amdgcn_fmed3f(c, -12.5f, 12.5f));
+    const float hv = __fmul_rn(1.0f - ec, rcpf_(__fmul_rn(1.0f + ec, 1.0f + eo)));
     return (fabsf(hv) <= 1.0f) ? hv : 0.0f;
 }
 
