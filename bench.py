@@ -57,6 +57,19 @@ def flops(name, chunk):
     return synthetic.transformer_flops_per_chunk(chunksize=chunk) if name == "sup" else synthetic.flops_per_chunk(name, chunk)
 
 
+def pmc_traffic(kernel, a):
+    """HBM bytes per launch of the dominant kernel as measured by the committed PMC passes (profiles/pmc_traffic.json);
+    None when no measurement exists for this kernel / workload."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as fh:
+            ent = json.load(fh).get(kernel or "")
+    except (OSError, ValueError):
+        return None
+    if not ent or ent.get("workload") != "%s %dx%d" % (a.model, a.batch, a.chunk):
+        return None
+    return ent["bytes_per_launch"]
+
+
 def log(msg):
     sys.stderr.write("[bench %7.1fs] %s\n" % (time.perf_counter() - T_START, msg))
     sys.stderr.flush()
@@ -217,7 +230,7 @@ def main():
                            "conv": "conv_igemm_kernel", "mlp": "gemm_kernel (fc1 gated + fc2) + rmsnorm_residual_kernel",
                            "attention": "gemm_kernel (Wqkv, out_proj) + attention_kernel + rmsnorm_residual_kernel"}[cls],
                 "bound": "mfma", "achieved": round(achieved, 2), "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(achieved / MFMA_F16_PEAK_TFLOPS, 4), "traffic": None,
+                "frac": round(achieved / MFMA_F16_PEAK_TFLOPS, 4), "traffic": pmc_traffic(lstm_kernel if cls == "lstm_rec" else None, a),
                 "avg_launch_ms": round(avg_ms, 4), "flops_per_launch": flops_per_launch}
 
     if rank == 0:
