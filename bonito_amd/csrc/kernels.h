@@ -75,3 +75,4 @@ int bh_k_ctc_prefix_beam(const float* logp, const long* offs, int R, int C, int 
 size_t bh_k_posterior_viterbi_workspace(int N, int T, int state_len);
 int bh_k_posterior_viterbi(const void* scores, int N, int T, int state_len, float blank, void* workspace, int8_t* moves,
                            int8_t* path, hipStream_t stream);
+int bh_k_decode_set_option(const char* name, int value);

@@ -221,3 +221,8 @@ def posterior_viterbi(scores, blank_score=2.0):
         _lib.check(lib.bh_crf_posterior_viterbi(_lib.ptr(scores), N, T, sl, float(blank_score), _lib.ptr(ws),
                                                 _lib.ptr(moves), _lib.ptr(path), _lib.stream_ptr(dev)), "bh_crf_posterior_viterbi")
     return moves.cpu(), path.cpu()
+
+
+def set_option(name, value):
+    """Process-wide decoder knob (bh_decode_set_option), e.g. set_option("beam_fork", 0)."""
+    _lib.check(_lib.lib().bh_decode_set_option(name.encode(), int(value)), "bh_decode_set_option")

@@ -203,3 +203,21 @@ def test_posterior_viterbi_confident_scores_exact_and_model_api():
     assert np.array_equal(moves.numpy(), om)
     seqs = model.decode_batch(torch.from_numpy(sc).cuda())
     assert seqs == [model.seqdist.path_to_str(p) for p in op]
+
+
+def test_beam_fork_option_does_not_change_results():
+    # the posterior scan may run next to the beam kernel on a helper stream (bh_decode_set_option "beam_fork")
+    rng = np.random.default_rng(77)
+    sc = torch.from_numpy(_scores(rng, 9, 300, 256, "normal")).cuda()
+    outs = []
+    try:
+        for v in (0, 1, -1):
+            decode.set_option("beam_fork", v)
+            outs.append([x.clone() for x in decode.beam_search(sc)])
+    finally:
+        decode.set_option("beam_fork", -1)
+    for o in outs[1:]:
+        for a, b in zip(outs[0], o):
+            assert torch.equal(a, b)
+    with pytest.raises(Exception):
+        decode.set_option("no_such_option", 1)
