@@ -22,6 +22,29 @@ def stitch_results(results, length, size, overlap, stride, reverse=False):
     return stitch(results, size, overlap, length, stride, reverse=reverse)
 
 
+def stitch_planes(planes, length, size, overlap, stride, reverse=False):
+    """`stitch_results` for the three decode outputs stacked as one int8 tensor [3, n_chunks, T] (sequence, qstring,
+    moves): one set of slicing / concatenation calls per read instead of one per output. Same pieces as
+    util.stitch (tests compare the two)."""
+    if length < size:
+        return planes[:, 0, :int(np.floor(length / stride))]
+    if planes.shape[1] == 1:
+        return planes[:, 0]
+    semi = overlap // 2
+    start, end = semi // stride, (size - semi) // stride
+    stub = (length - overlap) % (size - overlap)
+    first_end = (stub + semi) // stride if stub > 0 else end
+    k = planes.shape[0]
+    if reverse:
+        return torch.cat([planes[:, -1, :-start], planes[:, 1:-1, -end:-start].flip(1).reshape(k, -1),
+                          planes[:, 0, -first_end:]], dim=1)
+    return torch.cat([planes[:, 0, :first_end], planes[:, 1:-1, start:end].reshape(k, -1), planes[:, -1, start:]], dim=1)
+
+
+def fmt_planes(stride, planes, rna=False):
+    return fmt(stride, {"sequence": planes[0], "qstring": planes[1], "moves": planes[2]}, rna)
+
+
 def compute_scores(model, batch, beam_width=32, beam_cut=100.0, scale=1.0, offset=0.0, blank_score=2.0,
                    reverse=False, decoder="beam"):
     """fp16 forward on the HIP engine followed by the HIP decoder; returns CPU int8 [N, T] tensors
@@ -64,11 +87,21 @@ class _Pipeline:
         self.device = next(model.parameters()).device
         self.enc_stream = torch.cuda.Stream(self.device)
         self.dec_stream = torch.cuda.Stream(self.device)
+        self.copy_stream = torch.cuda.Stream(self.device)
         self.decoders = {}
 
     def encode(self, batch):
+        # H2D on its own stream, waited for on the host: the (recycled, pinned) batch buffer is free again when this
+        # method returns, and the copy never queues behind the previous batch's encoder.
+        with torch.inference_mode(), torch.cuda.stream(self.copy_stream):
+            dev_batch = batch.to(torch.float16).to(self.device, non_blocking=True)
+            copied = torch.cuda.Event()
+            copied.record(self.copy_stream)
+        copied.synchronize()
         with torch.inference_mode(), torch.cuda.stream(self.enc_stream):
-            scores = self.model(batch.to(torch.float16).to(self.device, non_blocking=True))
+            self.enc_stream.wait_event(copied)
+            dev_batch.record_stream(self.enc_stream)
+            scores = self.model(dev_batch)
             if self.reverse:
                 scores = self.model.seqdist.reverse_complement(scores)
             ready = torch.cuda.Event()
@@ -86,26 +119,77 @@ class _Pipeline:
             self.dec_stream.wait_event(ready)
             scores.record_stream(self.dec_stream)
             ticket = dec.submit(scores)
-        sequence, qstring, moves = ticket.result()
+        planes = ticket.result_planes()      # [3, n, T] int8: sequence, qstring, moves
         if self.mode == "viterbi":
-            path = qstring            # plane 1 carries the path for the Viterbi decoder
-            sequence = hip_decode.path_to_sequence(path)
-            qstring = torch.where(sequence != 0, torch.tensor(33 + 20, dtype=torch.int8), torch.tensor(0, dtype=torch.int8))
-        return {"moves": moves, "qstring": qstring, "sequence": sequence}
+            path = planes[1]                 # plane 1 carries the path for the Viterbi decoder
+            planes[0] = hip_decode.path_to_sequence(path)
+            planes[1] = torch.where(planes[0] != 0, torch.tensor(33 + 20, dtype=torch.int8), torch.tensor(0, dtype=torch.int8))
+        return planes
+
+
+def chunk_batches(reads, chunksize, overlap, batchsize, pin=False, nbuf=4):
+    """Fused `chunk` + `batchify` + fp32->fp16 for the product path: yields exactly the (keys, batch) pairs of
+    ``batchify(((read, 0, T), chunk(signal, chunksize, overlap)) for read in reads)`` (tests compare the two), but
+    every chunk row is converted and written ONCE, straight from the read's signal into a reusable (optionally
+    pinned) fp16 batch buffer. The generic pair costs three passes over the samples (window copy, concat, cast) and
+    bounded the pipeline at ~1.5e8 samples/s on one host thread.
+
+    A yielded batch stays valid until `nbuf - 1` further batches have been yielded (buffers are recycled)."""
+    def new_buf():
+        b = torch.empty((batchsize, 1, chunksize), dtype=torch.float16)
+        return b.pin_memory() if pin else b
+
+    bufs = [new_buf() for _ in range(nbuf)]
+    cur, pos, keys = 0, 0, []
+    for read in reads:
+        sig = read.signal
+        sig = torch.from_numpy(sig) if isinstance(sig, np.ndarray) else sig
+        T = sig.shape[-1]
+        key = (read, 0, T)
+        if sig.ndim != 1 or chunksize == 0 or T < chunksize:
+            rows = chunk(sig, chunksize, overlap)                       # rare shapes: generic code, then copy in
+            rows = rows.reshape(rows.shape[0], -1)
+            if rows.shape[-1] != chunksize:
+                raise ValueError("chunk_batches needs fixed-size chunks (chunksize=%d, got %d)" % (chunksize, rows.shape[-1]))
+        else:
+            step = chunksize - overlap
+            stub = (T - overlap) % step
+            rows = sig[stub:].unfold(0, chunksize, step)               # [n, chunksize] overlapping view, no copy
+            if stub > 0:
+                rows = (sig[:chunksize].unsqueeze(0), rows)
+        pieces = rows if isinstance(rows, tuple) else (rows,)
+        n_total = sum(p.shape[0] for p in pieces)
+        done = 0
+        for piece in pieces:
+            lo = 0
+            while lo < piece.shape[0]:
+                take = min(piece.shape[0] - lo, batchsize - pos)
+                bufs[cur][pos:pos + take, 0].copy_(piece[lo:lo + take])  # strided gather + cast in one pass
+                # key ranges follow batchify: one (key, (lo, hi)) entry per contiguous run of a read inside a batch
+                if keys and keys[-1][0] is key and keys[-1][1][1] == pos:
+                    keys[-1] = (key, (keys[-1][1][0], pos + take))
+                else:
+                    keys.append((key, (pos, pos + take)))
+                pos += take
+                lo += take
+                done += take
+                if pos == batchsize:
+                    yield tuple(keys), bufs[cur]
+                    cur, pos, keys = (cur + 1) % nbuf, 0, []
+        assert done == n_total
+    if pos:
+        yield tuple(keys), bufs[cur][:pos]
 
 
 def basecall(model, reads, chunksize=4000, overlap=100, batchsize=32, reverse=False, rna=False, decoder="beam"):
     """Basecalls a set of reads: yields (read, {sequence, qstring, moves, stride})."""
     pipe = _Pipeline(model, decoder=decoder, reverse=reverse)
-    chunks = thread_iter(
-        ((read, 0, read.signal.shape[-1]), chunk(torch.from_numpy(read.signal), chunksize, overlap))
-        for read in reads
-    )
-    batches = thread_iter(batchify(chunks, batchsize=batchsize))
+    # up to 4 batches are in flight behind the generator (three single-slot queues + the consumer): recycle after 8
+    batches = thread_iter(chunk_batches(reads, chunksize, overlap, batchsize, pin=torch.cuda.is_available(), nbuf=8))
     encoded = thread_iter((keys, pipe.encode(batch)) for keys, batch in batches)
     scores = thread_iter((keys, pipe.decode(*enc)) for keys, enc in encoded)
     results = thread_iter(
-        (read, stitch_results(sc, end - start, chunksize, overlap, model.stride, reverse))
-        for ((read, start, end), sc) in unbatchify(scores)
+        (read, stitch_planes(sc, end - start, chunksize, overlap, model.stride, reverse))
+        for ((read, start, end), sc) in unbatchify(scores, dim=1)
     )
-    return thread_iter((read, fmt(model.stride, attrs, rna)) for read, attrs in results)
+    return thread_iter((read, fmt_planes(model.stride, planes, rna)) for read, planes in results)

@@ -57,13 +57,17 @@ class CRFDecoder:
         def __init__(self, dec, n):
             self.dec, self.n = dec, n
 
-        def result(self):
-            """(sequence, qstring, moves) CPU int8 [N, T] (copies, safe to keep)."""
+        def result_planes(self):
+            """CPU int8 [3, N, T] = (sequence, qstring, moves) stacked (a copy, safe to keep)."""
             self.dec.done.synchronize()
             h = self.dec.host_out[:, : self.n]
             # plain pageable copy, single-threaded on purpose: .clone() of a pinned tensor would hipHostMalloc a new
             # pinned block (~6 ms), and torch's parallel CPU copy wakes the whole intra-op pool for 2.5 MB
-            out = torch.from_numpy(np.array(h.numpy(), copy=True))
+            return torch.from_numpy(np.array(h.numpy(), copy=True))
+
+        def result(self):
+            """(sequence, qstring, moves) CPU int8 [N, T] (copies, safe to keep)."""
+            out = self.result_planes()
             return out[0], out[1], out[2]
 
     def submit(self, scores):

@@ -103,3 +103,67 @@ def test_load_symbol_maps_reference_packages():
     cfg = {"model": {"package": "bonito.crf"}}
     assert util.load_symbol(cfg, "Model") is Model
     assert util.load_symbol(cfg, "basecall") is basecall
+
+
+def test_chunk_batches_equals_chunk_plus_batchify():
+    """The product path's fused chunk -> batch -> fp16 generator yields exactly what the reference-shaped pair yields."""
+    import torch
+    from bonito_amd.crf.basecall import chunk_batches
+    from bonito_amd.util import batchify, chunk
+
+    class R:
+        def __init__(self, i, x):
+            self.read_id, self.signal = i, x
+
+    rng = np.random.default_rng(0)
+    for cs, ov, bs in ((1000, 100, 7), (996, 498, 16), (400, 0, 5)):
+        reads = [R(i, rng.standard_normal(int(n)).astype(np.float32)) for i, n in enumerate(rng.integers(50, 6000, 30))]
+        ref = list(batchify((((r, 0, len(r.signal)), chunk(torch.from_numpy(r.signal), cs, ov)) for r in reads), batchsize=bs))
+        got = [(k, b.clone()) for k, b in chunk_batches(reads, cs, ov, bs, nbuf=2)]
+        assert len(ref) == len(got)
+        for (rk, rb), (gk, gb) in zip(ref, got):
+            assert len(rk) == len(gk)
+            for a, b in zip(rk, gk):
+                assert a[0][0] is b[0][0] and a[0][1:] == b[0][1:] and tuple(a[1]) == tuple(b[1])
+            assert torch.equal(rb.to(torch.float16), gb)
+
+
+def test_stitch_vectorised_path_equals_slice_list():
+    import torch
+    from bonito_amd.util import concat, stitch
+    rng = np.random.default_rng(3)
+    cs, ov, stride = 996, 498, 6
+    for length in (996, 2000, 5555, 9000):
+        step = cs - ov
+        stub = (length - ov) % step
+        n = (length - stub - ov) // step + (1 if stub > 0 else 0)
+        chunks = torch.from_numpy(rng.integers(0, 100, (n, cs // stride)).astype(np.int8))
+        got = stitch(chunks, cs, ov, length, stride)
+        if n == 1:
+            want = chunks[0]
+        else:
+            semi = ov // 2
+            start, end = semi // stride, (cs - semi) // stride
+            first_end = (stub + semi) // stride if stub > 0 else end
+            want = concat([chunks[0, :first_end], *chunks[1:-1, start:end], chunks[-1, start:]])
+        assert torch.equal(got, want)
+
+
+@pytest.mark.parametrize("reverse", [False, True])
+def test_stitch_planes_equals_stitch_results(reverse):
+    import torch
+    from bonito_amd.crf.basecall import stitch_planes, stitch_results
+    rng = np.random.default_rng(4)
+    cs, ov, stride = 996, 498, 6
+    for length in (300, 996, 2000, 5555, 9000):
+        step = cs - ov
+        if length < cs:
+            n = 1
+        else:
+            stub = (length - ov) % step
+            n = (length - stub - ov) // step + (1 if stub > 0 else 0)
+        planes = torch.from_numpy(rng.integers(0, 100, (3, n, cs // stride)).astype(np.int8))
+        want = stitch_results({"sequence": planes[0], "qstring": planes[1], "moves": planes[2]}, length, cs, ov, stride, reverse=reverse)
+        got = stitch_planes(planes, length, cs, ov, stride, reverse=reverse)
+        for i, k in enumerate(("sequence", "qstring", "moves")):
+            assert torch.equal(got[i], want[k]), (length, k)
