@@ -55,7 +55,7 @@ SIGNATURES = {
     "bh_crf_viterbi": (_i, [_vp, _i, _i, _i, _i, _f, _l, _l, _vp, _vp, _vp, _vp, _vp]),
     "bh_crf_reverse_complement": (_i, [_vp, _vp, _i, _i, _i, _i, _l, _l, _vp]),
     "bh_crf_logz": (_i, [_vp, _i, _i, _i, _f, _vp, _vp, _vp]),
-    "bh_decode_set_option": (_i, [C.c_char_p, _i]),
+    "bh_set_option": (_i, [C.c_char_p, _i]),
     "bh_crf_posterior_viterbi_workspace": (_sz, [_i, _i, _i]),
     "bh_crf_posterior_viterbi": (_i, [_vp, _i, _i, _i, _f, _vp, _vp, _vp, _vp]),
     "bh_beam_search_workspace": (_sz, [_i, _i, _i]),

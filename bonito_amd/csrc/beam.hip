@@ -819,7 +819,7 @@ namespace {
 // One helper stream + fork/join events per (device, host thread): bh_beam_search is re-entrant per thread, and a decode
 // worker thread drives one device.
 struct SideStream { hipStream_t stream = nullptr; hipEvent_t fork = nullptr, join = nullptr; };
-int g_beam_fork = -1;      // -1 auto (fork for small state spaces), 0 never, 1 always; bh_decode_set_option("beam_fork", v)
+int g_beam_fork = -1;      // -1 auto (fork for small state spaces), 0 never, 1 always; bh_set_option("beam_fork", v)
 SideStream* side_stream(int S) {
     // Measured (MI355X, 512 x 1667 steps): forking shortens the decode stage 8.3 -> 6.7 ms (S=64) / 11.3 -> 9.3 ms (S=256).
     // Where the decoder is the pipeline bottleneck (fast-sized models) that is a net win (10.0 -> 9.4 ms per step); next to
@@ -888,6 +888,5 @@ int bh_k_beam_search(const void* scores, int N, int T, int state_len, int beam_w
 
 int bh_k_decode_set_option(const char* name, int value) {
     if (name && !strcmp(name, "beam_fork")) { g_beam_fork = value; return 0; }
-    BH_REQUIRE(false, "decode_set_option: unknown option '%s'", name ? name : "(null)");
-    return -1;
+    return 1;     // not a decoder option
 }

@@ -920,7 +920,13 @@ extern "C" int bh_crf_logz(const void* scores, int N, int T, int state_len, floa
     BH_REQUIRE(scores && workspace && logz, "crf_logz: null pointer");
     return bh_k_crf_logz(scores, N, T, state_len, blank_score, workspace, logz, (hipStream_t)stream);
 }
-extern "C" int bh_decode_set_option(const char* name, int value) { return bh_k_decode_set_option(name, value); }
+extern "C" int bh_set_option(const char* name, int value) {
+    BH_REQUIRE(name != nullptr, "set_option: null name");
+    if (bh_k_decode_set_option(name, value) == 0) return 0;
+    if (!strcmp(name, "gemm_path")) { bh_k_linear_force_v1(value); return 0; }
+    BH_REQUIRE(false, "set_option: unknown option '%s'", name);
+    return -1;
+}
 extern "C" size_t bh_crf_posterior_viterbi_workspace(int N, int T, int state_len) {
     return bh_k_posterior_viterbi_workspace(N, T, state_len);
 }

@@ -45,54 +45,93 @@ __device__ __forceinline__ int lds_off(int row, int chunk) {
     return row * (BK * 2) + ((chunk ^ (row & 7)) << 4);
 }
 
-template <int ACT, bool GATED>
-__device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, float4_t (&acc)[4][4], int f0, int t0, int wf, int wt,
+typedef float float8_t __attribute__((ext_vector_type(8)));
+
+// Epilogue. lane (c = r: token column, q = kg): features fbase + ft*4 + reg, ft,reg in 0..3; a wave owns NTT token tiles.
+// With short K (384..512 on this path) the epilogue is a third of a tile's instructions, so everything that is uniform
+// over the launch is branched on once (identity row map -> no integer division, no scale/clamp -> no extra VALU),
+// residuals are fetched as two 16-byte loads and the fp32 -> fp16 conversion uses the packed form (v_cvt_pk_f16_f32).
+template <int ACT, bool GATED, int NTT = 4, bool ALIGNED = false>
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, float4_t (&acc)[4][NTT], int f0, int t0, int wf, int wt,
                                               int r, int kg) {
-    // Epilogue. lane (c = r: token column, q = kg): features fbase + ft*4 + reg, ft,reg in 0..3.
     const int fbase = f0 + wf * 64 + kg * 16;
-    float bv[16];
+    // this lane's 16 features all exist, or (ALIGNED: N % 16 == 0 guaranteed by the launcher) none of them does
+    const bool full = fbase + 16 <= p.N;
+    if (ALIGNED && !full) return;
+    const bool ident = p.row_div == 1 && p.row_s_hi == 1;                   // out row == m, nothing dropped
+    const bool plain = p.scale == 1.0f && p.clamp_lo == -INFINITY && p.clamp_hi == INFINITY;
+    float8_t b0 = 0.0f, b1 = 0.0f;
+    if (p.bias != nullptr) {
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        int f = fbase + i;
-        bv[i] = (p.bias != nullptr && f < p.N) ? p.bias[f] : 0.0f;
+        for (int i = 0; i < 8; ++i) {
+            b0[i] = fbase + i < p.N ? p.bias[fbase + i] : 0.0f;
+            b1[i] = fbase + 8 + i < p.N ? p.bias[fbase + 8 + i] : 0.0f;
+        }
     }
 #pragma unroll
-    for (int tt = 0; tt < 4; ++tt) {
-        int m = t0 + wt * 64 + tt * 16 + r;
-        if (m >= p.M || (m % p.row_div) >= p.row_lim) continue;
-        long orow = (long)(m / p.row_div) * p.row_s_hi + (long)(m % p.row_div) * p.row_s_lo;
-        float v[16];
+    for (int tt = 0; tt < NTT; ++tt) {
+        const int m = t0 + wt * (NTT * 16) + tt * 16 + r;
+        if (m >= p.M) continue;
+        long orow = m;
+        if (!ident) {
+            const int hi = m / p.row_div, lo = m - hi * p.row_div;
+            if (lo >= p.row_lim) continue;
+            orow = (long)hi * p.row_s_hi + (long)lo * p.row_s_lo;
+        }
+        float8_t v0, v1;
 #pragma unroll
-        for (int ft = 0; ft < 4; ++ft)
+        for (int ft = 0; ft < 2; ++ft)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) v[ft * 4 + g] = acc[ft][tt][g] + bv[ft * 4 + g];
+            for (int g = 0; g < 4; ++g) {
+                v0[ft * 4 + g] = acc[ft][tt][g];
+                v1[ft * 4 + g] = acc[ft + 2][tt][g];
+            }
+        v0 += b0;
+        v1 += b1;
         if (p.res != nullptr) {
             const half_t* rp = p.res + (long)m * p.ldres + fbase;
+            if (ALIGNED || full) {
+                v0 += __builtin_convertvector(*(const half8_t*)rp, float8_t);
+                v1 += __builtin_convertvector(*(const half8_t*)(rp + 8), float8_t);
+            } else {
 #pragma unroll
-            for (int i = 0; i < 16; ++i)
-                if (fbase + i < p.N) v[i] += (float)rp[i];
+                for (int i = 0; i < 8; ++i) {
+                    if (fbase + i < p.N) v0[i] += (float)rp[i];
+                    if (fbase + 8 + i < p.N) v1[i] += (float)rp[8 + i];
+                }
+            }
         }
         if constexpr (GATED) {
             // W rows were interleaved on the host: feature 2j = y_j, 2j+1 = gate_j
             // (flash_attn GatedMlp semantics: y, gate = fc1(x).chunk(2); y * silu(gate)).
-            half8_t o;
+            float8_t y;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) o[i] = (half_t)(v[2 * i] * swishf_(v[2 * i + 1]));
-            int fo = fbase >> 1;
-            if (fo + 8 <= (p.N >> 1)) *(half8_t*)(p.out + orow * p.ldo + fo) = o;
+            for (int i = 0; i < 4; ++i) {
+                y[i] = v0[2 * i] * swishf_(v0[2 * i + 1]);
+                y[4 + i] = v1[2 * i] * swishf_(v1[2 * i + 1]);
+            }
+            const half8_t o = __builtin_convertvector(y, half8_t);
+            const int fo = fbase >> 1;
+            if (ALIGNED || fo + 8 <= (p.N >> 1)) *(half8_t*)(p.out + orow * p.ldo + fo) = o;
             else
                 for (int i = 0; i < 8; ++i)
                     if (fo + i < (p.N >> 1)) p.out[orow * p.ldo + fo + i] = o[i];
         } else {
-            half8_t o0, o1;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                float x = apply_act<ACT>(v[i]) * p.scale;
-                x = fminf(fmaxf(x, p.clamp_lo), p.clamp_hi);
-                if (i < 8) o0[i] = (half_t)x; else o1[i - 8] = (half_t)x;
+            for (int i = 0; i < 8; ++i) {
+                v0[i] = apply_act<ACT>(v0[i]);
+                v1[i] = apply_act<ACT>(v1[i]);
             }
+            if (!plain) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    v0[i] = fminf(fmaxf(v0[i] * p.scale, p.clamp_lo), p.clamp_hi);
+                    v1[i] = fminf(fmaxf(v1[i] * p.scale, p.clamp_lo), p.clamp_hi);
+                }
+            }
+            const half8_t o0 = __builtin_convertvector(v0, half8_t), o1 = __builtin_convertvector(v1, half8_t);
             half_t* dst = p.out + orow * p.ldo + fbase;
-            if (fbase + 16 <= p.N) {
+            if (ALIGNED || full) {
                 *(half8_t*)dst = o0;
                 *(half8_t*)(dst + 8) = o1;
             } else {
@@ -285,12 +324,133 @@ __global__ __launch_bounds__(256, 4) void gemm_glds_kernel(GemmArgs p) {
     gemm_epilogue<ACT, GATED>(p, acc, f0, t0, wf, wt, r, kg);
 }
 
-static int g_force_v1 = 0;   // test / A-B hook (bh_k_linear_force_v1)
+// ---------------------------------------------------------------------------------------------------
+// v3: 256 (features) x 256 (tokens) x 64 (K) tile, 8 waves (4 along features x 2 along tokens; a wave owns
+// 64 x 128 = 4 x 8 MFMA tiles, 128 accumulator registers), global_load_lds staging into two 64 KiB buffers with the
+// XOR swizzle applied on the source address (LDS rows are 128 B: chunk ^= row & 7, the v1 read pattern), one barrier
+// per K-tile. 2.7 MFMAs per ds_read_b128 instead of 2 and half the barriers of v2. The kernel is PERSISTENT over
+// output tiles: with K = 384..2048 a tile is only 6..32 K-tiles, so the first DMA of the next tile is issued before
+// the epilogue of the current one (LDS is idle while the accumulators drain).
+// Requires K % 64 == 0 and N % 16 == 0; used when the problem has enough 256 x 256 tiles to fill the chip.
+// Measured on the transformer shapes (M = 256000): +10..22 % over v2 (e.g. fc2 K=2048: 774 -> 946 TFLOP/s, gated fc1:
+// 734 -> 864). A three-buffer BK=32 pipeline with counted vmcnt waits (two stages in flight) was tried and dropped:
+// hipcc drains the vm counter in front of every ds_read it can see while an LDS-DMA is outstanding, and hiding the
+// reads in inline asm pushed the kernel over the register budget (spill reloads drain the counter as well).
+constexpr int BF3 = 256, BT3 = 256, BK3 = 64;
+constexpr int TILE3 = 256 * BK3 * 2;    // 32 KiB per operand tile
+
+template <int ACT, bool GATED>
+__global__ __launch_bounds__(512, 1) void gemm_big_kernel(GemmArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // [buf][A 32K | B 32K]
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wf = wave >> 1, wt = wave & 1;
+    const int r = lane & 15, kg = lane >> 4;
+    const int n_tiles = p.n_ft * p.n_tt;
+    const int nk = p.K / BK3;
+
+    // DMA assignment: an instruction covers 8 LDS rows x 128 B; wave w issues rows (w*4 + j)*8 .. +7 of each operand, j < 4
+    const int lr = lane >> 3, slot = lane & 7;
+    const int chunk = slot ^ lr;                       // row & 7 == lr (8-row groups are aligned)
+    unsigned aoff[4], boff[4];                         // element offsets of this lane's 16-byte chunk, per instruction
+    auto set_tile = [&](int work, int& f0, int& t0) {
+        const int tile_t = work / p.n_ft;
+        const int tile_f = work - tile_t * p.n_ft;
+        f0 = tile_f * BF3;
+        t0 = tile_t * BT3;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int row = (wave * 4 + j) * 8 + lr;
+            const int wfb = row >> 6, within = row & 63;
+            const int ft = within >> 4, rr = within & 15;
+            const int feat = min(f0 + wfb * 64 + (rr >> 2) * 16 + ft * 4 + (rr & 3), p.N - 1);
+            aoff[j] = (unsigned)feat * (unsigned)p.ldw + chunk * 8;
+            const int tok = min(t0 + row, p.M - 1);
+            boff[j] = (unsigned)tok * (unsigned)p.ldx + chunk * 8;
+        }
+    };
+    auto dma = [&](int kt, int buf) {
+        char* a = smem + buf * 2 * TILE3;
+        char* b = a + TILE3;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int off = (wave * 4 + j) * 1024;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p.W + aoff[j] + kt * BK3),
+                                             (__attribute__((address_space(3))) void*)(a + off), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p.X + boff[j] + kt * BK3),
+                                             (__attribute__((address_space(3))) void*)(b + off), 16, 0, 0);
+        }
+    };
+
+    int work = blockIdx.x;
+    if (work >= n_tiles) return;
+    int f0, t0;
+    set_tile(work, f0, t0);
+    dma(0, 0);
+    int buf = 0;
+    while (true) {
+        float4_t acc[4][8];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[i][j] = float4_t{0.f, 0.f, 0.f, 0.f};
+        const int next = work + gridDim.x;
+        int nf0 = 0, nt0 = 0;
+        for (int kt = 0; kt < nk; ++kt) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // K-tile kt has landed (this wave's part)
+            __syncthreads();                                    // ... everybody's; all reads of the other buffer are done
+            if (kt + 1 < nk) dma(kt + 1, buf ^ 1);
+            else if (next < n_tiles) {                          // first K-tile of the next output tile, under the epilogue
+                const int cf0 = f0, ct0 = t0;
+                set_tile(next, nf0, nt0);
+                dma(0, buf ^ 1);
+                f0 = cf0; t0 = ct0;
+            }
+            const char* a = smem + buf * 2 * TILE3;
+            const char* b = a + TILE3;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                half8_t af[4], bf[8];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) af[i] = *(const half8_t*)(a + lds_off(wf * 64 + i * 16 + r, ks * 4 + kg));
+#pragma unroll
+                for (int j = 0; j < 8; ++j) bf[j] = *(const half8_t*)(b + lds_off(wt * 128 + j * 16 + r, ks * 4 + kg));
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc[i][j] = mfma16(af[i], bf[j], acc[i][j]);
+            }
+            buf ^= 1;
+        }
+        gemm_epilogue<ACT, GATED, 8, true>(p, acc, f0, t0, wf, wt, r, kg);
+        if (next >= n_tiles) break;
+        work = next; f0 = nf0; t0 = nt0;
+    }
+}
+
+static int g_force_v1 = 0;   // test / A-B hook (bh_k_linear_force_v1): 1 = v1 only, 2 = never v3
 
 template <int ACT, bool GATED>
 static void launch(const GemmArgs& a, hipStream_t s) {
     int grid = a.n_ft * a.n_tt;
-    if (a.K % BK2 == 0 && !g_force_v1)
+    // v3 when the problem has at least ~2 waves of 256 x 256 tiles over the chip and no K tail
+    {
+        const int nf3 = (a.N + BF3 - 1) / BF3, nt3 = (a.M + BT3 - 1) / BT3;
+        if (a.K % BK3 == 0 && g_force_v1 == 0 && a.N >= 256 && a.N % 16 == 0 && (long)nf3 * nt3 >= 512 &&
+            (long)a.M * a.ldx < (1l << 31) && (long)a.N * a.ldw < (1l << 31)) {
+            int dev = 0, cus = 256;
+            if (hipGetDevice(&dev) != hipSuccess ||
+                hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+            (void)hipFuncSetAttribute((const void*)gemm_big_kernel<ACT, GATED>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE3);
+            GemmArgs b = a;
+            b.n_ft = nf3; b.n_tt = nt3;
+            const int tiles = nf3 * nt3;
+            hipLaunchKernelGGL((gemm_big_kernel<ACT, GATED>), dim3(tiles < cus ? tiles : cus), dim3(512), 4 * TILE3, s, b);
+            return;
+        }
+    }
+    if (a.K % BK2 == 0 && g_force_v1 != 1)
         hipLaunchKernelGGL((gemm_glds_kernel<ACT, GATED>), dim3(grid), dim3(256), 4 * TILE2, s, a);
     else
         hipLaunchKernelGGL((gemm_kernel<ACT, GATED>), dim3(grid), dim3(256), 4 * TILE_BYTES, s, a);

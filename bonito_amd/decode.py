@@ -228,5 +228,5 @@ def posterior_viterbi(scores, blank_score=2.0):
 
 
 def set_option(name, value):
-    """Process-wide decoder knob (bh_decode_set_option), e.g. set_option("beam_fork", 0)."""
-    _lib.check(_lib.lib().bh_decode_set_option(name.encode(), int(value)), "bh_decode_set_option")
+    """Process-wide engine knob (bh_set_option), e.g. set_option("beam_fork", 0)."""
+    _lib.check(_lib.lib().bh_set_option(name.encode(), int(value)), "bh_set_option")

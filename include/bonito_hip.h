@@ -146,10 +146,11 @@ int bh_crf_reverse_complement(const void* in, void* out, int N, int T, int state
 int bh_crf_logz(const void* scores, int N, int T, int state_len, float blank_score, void* workspace, double* logz,
                 void* stream);
 
-/* Process-wide decoder knobs (measurement / tuning hooks, no reference counterpart).
+/* Process-wide knobs (measurement / tuning hooks, no reference counterpart).
  *   "beam_fork": -1 auto (default), 0 = run the posterior scan behind the beam kernel on the caller's stream,
- *                1 = run it next to the beam kernel on an internal helper stream (joined before finalize). */
-int bh_decode_set_option(const char* name, int value);
+ *                1 = run it next to the beam kernel on an internal helper stream (joined before finalize).
+ *   "gemm_path": 0 auto (default), 1 = register-staged 128x128x64 kernel only, 2 = never the persistent 256x256x64 kernel. */
+int bh_set_option(const char* name, int value);
 
 /* Posterior decoding = SeqdistModel.decode_batch (crf/model.py:196-199): Viterbi over log(edge posteriors + 1e-8).
  * scores: contiguous koi layout [N][T][4S]; moves/path as bh_crf_viterbi.

@@ -206,7 +206,7 @@ def test_posterior_viterbi_confident_scores_exact_and_model_api():
 
 
 def test_beam_fork_option_does_not_change_results():
-    # the posterior scan may run next to the beam kernel on a helper stream (bh_decode_set_option "beam_fork")
+    # the posterior scan may run next to the beam kernel on a helper stream (bh_set_option "beam_fork")
     rng = np.random.default_rng(77)
     sc = torch.from_numpy(_scores(rng, 9, 300, 256, "normal")).cuda()
     outs = []

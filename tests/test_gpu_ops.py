@@ -267,3 +267,25 @@ def test_rmsnorm_residual(M, D):
                                               _lib.stream_ptr()), "rmsnorm")
     torch.cuda.synchronize()
     assert (out.cpu().float() - want).abs().max().item() < 4e-3
+
+
+@pytest.mark.parametrize("M,N,K,gated", [(16384 + 37, 2048, 128, 0), (40000, 1024, 384, 0), (33000, 1024, 64, 1)])
+def test_linear_persistent_big_tile_kernel(M, N, K, gated):
+    """Problems with >= 512 tiles of 256 x 256 and K % 64 == 0 run on the persistent 256x256x64 kernel: same K order
+    and epilogue as the 128-tile kernels, so the bytes must be identical (and right)."""
+    from bonito_amd import decode
+    g = torch.Generator().manual_seed(M)
+    x = (torch.randn(M, K, generator=g) * 0.5).half().to(dev())
+    w = (torch.randn(N, K, generator=g) * 0.2).half().to(dev())
+    b = torch.randn(N, generator=g).to(dev())
+    try:
+        decode.set_option("gemm_path", 0)
+        big = _linear(x, w, b, act=0 if gated else 1, gated=gated)
+        decode.set_option("gemm_path", 2)
+        small = _linear(x, w, b, act=0 if gated else 1, gated=gated)
+    finally:
+        decode.set_option("gemm_path", 0)
+    assert torch.equal(big, small)
+    z = x[-3000:].float() @ w.float().T + b
+    want = (z[:, 0::2] * z[:, 1::2] * torch.sigmoid(z[:, 1::2])) if gated else z * torch.sigmoid(z)
+    assert (big[-3000:].float() - want).abs().max().item() < 3e-2 + 3e-3 * want.abs().max().item()

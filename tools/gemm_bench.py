@@ -1,0 +1,35 @@
+#!/usr/bin/env python3
+"""Per-shape throughput of bh_linear for the transformer / CRF-head shapes: auto path vs the 128-tile kernels."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from bonito_amd import _lib, decode
+INF = float("inf")
+dev = torch.device("cuda", 0)
+shapes = [(256000, 1536, 512, 0), (256000, 512, 512, 0), (256000, 4096, 512, 1), (256000, 512, 2048, 0),
+          (256000, 1024, 512, 0), (512000, 4096, 512, 0), (853504, 1024, 384, 0)]
+if len(sys.argv) > 1:
+    shapes = [tuple(int(v) for v in a.split(",")) for a in sys.argv[1:]]
+lib = _lib.lib()
+for M, N, K, gated in shapes:
+    x = (torch.randn(M, K, device=dev) * 0.5).half()
+    w = (torch.randn(N, K, device=dev) * 0.2).half()
+    ncol = N // 2 if gated else N
+    out = torch.empty((M, ncol), dtype=torch.float16, device=dev)
+    res = {}
+    for path in (0, 2):
+        decode.set_option("gemm_path", path)
+        def run():
+            _lib.check(lib.bh_linear(_lib.ptr(x), _lib.ptr(w), None, _lib.ptr(out), M, N, K, K, K, ncol, 0, 1.0, -INF, INF,
+                                     gated, 0, 0, 0, 0, _lib.stream_ptr()), "bh_linear")
+        for _ in range(3): run()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10): run()
+        e1.record(); torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 10
+        res[path] = (ms, 2.0 * M * N * K / ms / 1e9)
+    decode.set_option("gemm_path", 0)
+    print("M=%d N=%d K=%d gated=%d: auto %.3f ms %.0f TF/s | 128-tile %.3f ms %.0f TF/s" % (M, N, K, gated, res[0][0], res[0][1], res[2][0], res[2][1]))
+    del x, w, out
