@@ -333,7 +333,7 @@ __global__ __launch_bounds__(256, 4) void gemm_glds_kernel(GemmArgs p) {
 // the epilogue of the current one (LDS is idle while the accumulators drain).
 // Requires K % 64 == 0 and N % 16 == 0; used when the problem has enough 256 x 256 tiles to fill the chip.
 // Measured on the transformer shapes (M = 256000): +10..22 % over v2 (e.g. fc2 K=2048: 774 -> 946 TFLOP/s, gated fc1:
-// 734 -> 864). A three-buffer BK=32 pipeline with counted vmcnt waits (two stages in flight) was tried and dropped:
+// 734 -> 864). A 256 x 128 tile with two workgroups per CU landed in between (~750 everywhere). A three-buffer BK=32 pipeline with counted vmcnt waits (two stages in flight) was tried and dropped:
 // hipcc drains the vm counter in front of every ds_read it can see while an LDS-DMA is outstanding, and hiding the
 // reads in inline asm pushed the kernel over the register budget (spill reloads drain the counter as well).
 constexpr int BF3 = 256, BT3 = 256, BK3 = 64;
@@ -354,7 +354,13 @@ __global__ __launch_bounds__(512, 1) void gemm_big_kernel(GemmArgs p) {
     const int lr = lane >> 3, slot = lane & 7;
     const int chunk = slot ^ lr;                       // row & 7 == lr (8-row groups are aligned)
     unsigned aoff[4], boff[4];                         // element offsets of this lane's 16-byte chunk, per instruction
-    auto set_tile = [&](int work, int& f0, int& t0) {
+    // XCD-aware bijective remap of the linear work index (block b runs on XCD b % 8, and so does b + k * gridDim when
+    // gridDim % 8 == 0): every XCD walks one contiguous eighth of the tile space, feature tiles fastest, so an X tile is
+    // fetched into ONE L2 instead of up to eight
+    const int q8 = n_tiles >> 3, r8 = n_tiles & 7;
+    auto set_tile = [&](int w, int& f0, int& t0) {
+        const int xcd = w & 7, loc = w >> 3;
+        const int work = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + loc;
         const int tile_t = work / p.n_ft;
         const int tile_f = work - tile_t * p.n_ft;
         f0 = tile_f * BF3;
