@@ -178,6 +178,182 @@ __global__ __launch_bounds__(512) void attention_kernel(AttnArgs p) {
 }
 
 // ---------------------------------------------------------------------------------------------------
+// Persistent ring-buffer variant for PRE-ROTATED inputs (rotary and the 1/sqrt(d) scale are applied by the epilogue of the
+// Wqkv GEMM, gemm.hip): a workgroup owns one (chunk, head) and walks its query blocks of 128 in order. K (row-major,
+// swizzled) and V^T live in a 512-row LDS ring indexed by key & 511, so every key/value row is fetched from HBM and
+// transposed exactly once per head (the block-per-workgroup kernel above re-stages ~3x the rows and re-applies the
+// rotation each time), and the 128 new rows of the next block travel through registers while the current block computes.
+// Block b (queries 128b..128b+127) reads keys 128b-128 .. 128b+271 (wave w: 18 tiles of 16 from 128b-128+16w), all tile
+// boundaries are multiples of 16 so a tile never straddles the ring wrap. Needs wl + wr <= 256 and wl <= 128.
+typedef float float8_t __attribute__((ext_vector_type(8)));
+constexpr int RING = 512;
+constexpr int RVS = RING + 4;                  // V^T row stride (halves): 4-bank skew between d rows
+
+struct AttnRingArgs {
+    const half_t* qkv;   // [N*T][3*D], q (rotated, scaled by log2(e)/sqrt(d)) | k (rotated) | v
+    half_t* out;         // [N*T][D]
+    int N, T, H;
+    int wl, wr;
+};
+
+__global__ __launch_bounds__(512) void attention_ring_kernel(AttnRingArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NT = 18;
+    char* kl = smem;                              // [RING][128 B] swizzled by slot & 7
+    half_t* vt = (half_t*)(smem + RING * 128);    // [64][RVS]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int D = p.H * HD;
+    const int h = blockIdx.x, n = blockIdx.y;
+    const half_t* base = p.qkv + (long)n * p.T * 3 * D;
+    const int g = lane >> 4;
+
+    // staging task: 16-byte chunk c of the key-row PAIR (first + 2*pp, first + 2*pp + 1), pp = pair index; pairs make the
+    // transposing V^T writes 4-byte stores of two adjacent keys
+    auto load_pair = [&](int first, int pp, int c, uint4_t (&kv)[2], uint4_t (&vv)[2]) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int j = first + 2 * pp + u;
+            kv[u] = uint4_t{0, 0, 0, 0};
+            vv[u] = kv[u];
+            if (j >= 0 && j < p.T) {
+                const half_t* rp = base + (long)j * 3 * D + D + h * HD + c * 8;
+                kv[u] = *(const uint4_t*)rp;
+                vv[u] = *(const uint4_t*)(rp + D);
+            }
+        }
+    };
+    auto store_pair = [&](int first, int pp, int c, const uint4_t (&kv)[2], const uint4_t (&vv)[2]) {
+        const int slot = (first + 2 * pp) & (RING - 1);          // even; the pair never straddles the wrap
+#pragma unroll
+        for (int u = 0; u < 2; ++u) *(uint4_t*)(kl + (slot + u) * 128 + ((c ^ ((slot + u) & 7)) << 4)) = kv[u];
+        const half8_t v0 = __builtin_bit_cast(half8_t, vv[0]), v1 = __builtin_bit_cast(half8_t, vv[1]);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const half2_t pr = {v0[e], v1[e]};
+            *(half2_t*)(vt + (c * 8 + e) * RVS + slot) = pr;
+        }
+    };
+
+    // ---- prologue: rows -128 .. 271 (200 pairs x 8 chunks) -------------------------------------------------------------
+    for (int t = tid; t < 200 * 8; t += 512) {
+        uint4_t kv[2], vv[2];
+        load_pair(-128, t >> 3, t & 7, kv, vv);
+        store_pair(-128, t >> 3, t & 7, kv, vv);
+    }
+    const int nblk = (p.T + QB - 1) / QB;
+    // this wave's 16 queries of a block as B fragments (already rotated and scaled); the next block's are requested one
+    // block ahead together with its new key/value rows
+    auto load_q = [&](int blk, half8_t (&q)[2]) {
+        const int qi = blk * QB + wave * 16 + (lane & 15);
+        q[0] = half8_t{0, 0, 0, 0, 0, 0, 0, 0};
+        q[1] = q[0];
+        if (qi < p.T) {
+            const half_t* qp = base + (long)qi * 3 * D + h * HD;
+            q[0] = *(const half8_t*)(qp + g * 8);
+            q[1] = *(const half8_t*)(qp + 32 + g * 8);
+        }
+    };
+    half8_t qn[2];
+    load_q(0, qn);
+    for (int b = 0; b < nblk; ++b) {
+        const int i0 = b * QB;
+        const int jb = i0 - 128;
+        const int qi = i0 + wave * 16 + (lane & 15);
+        half8_t qf[2] = {qn[0], qn[1]};
+        if (b + 1 < nblk) load_q(b + 1, qn);
+        // the 128 rows the NEXT block adds (128(b+1)+144 .. +271): requested now, stored after this block's compute
+        uint4_t nk[2], nv[2];
+        const int nfirst = i0 + QB + 144;
+        const bool more = b + 1 < nblk;
+        if (more) load_pair(nfirst, tid >> 3, tid & 7, nk, nv);        // 64 pairs x 8 chunks = 512 tasks
+        __syncthreads();                          // ring rows of this block are in place
+
+        const int rel0 = wave * 16;               // this wave's first key tile, relative to jb
+        float4_t s[NT];
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt) {
+            const int slot = (jb + rel0 + kt * 16 + (lane & 15)) & (RING - 1);
+            const char* rp = kl + slot * 128;
+            const half8_t a0 = *(const half8_t*)(rp + ((g ^ (slot & 7)) << 4));
+            const half8_t a1 = *(const half8_t*)(rp + (((g + 4) ^ (slot & 7)) << 4));
+            float4_t acc = {0.f, 0.f, 0.f, 0.f};
+            acc = mfma16(a0, qf[0], acc);
+            acc = mfma16(a1, qf[1], acc);
+            s[kt] = acc;
+        }
+        // visible keys of query qi, relative to this lane's first key (jb + rel0 + 4g): [lo, hi]. Away from the ends of the
+        // chunk only the first and the last two key tiles of a wave can hold invisible keys (tile kt spans 16kt..16kt+15 of
+        // the wave's keys, query q of the wave sees q+1-(128-wl) .. q+128+wr): the 15 interior tiles skip the mask.
+        const int kfirst = jb + rel0 + g * 4;
+        const int lo = max(qi - p.wl, 0) - kfirst, hi = min(qi + p.wr, p.T - 1) - kfirst;
+        const bool edge = jb < 0 || jb + 400 > p.T || p.wl != 127 || p.wr != 128;       // block-uniform
+        float m = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt) {
+            if (edge || kt == 0 || kt >= 16) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int rel = kt * 16 + e;
+                    s[kt][e] = (rel >= lo && rel <= hi) ? s[kt][e] : -INFINITY;
+                }
+            }
+            m = fmaxf(m, fmaxf(fmaxf(s[kt][0], s[kt][1]), fmaxf(s[kt][2], s[kt][3])));
+        }
+        m = fmaxf(m, __shfl_xor(m, 16));
+        m = fmaxf(m, __shfl_xor(m, 32));
+        const float msafe = (m == -INFINITY) ? 0.0f : m;
+        // scores are in log2 units (the Wqkv epilogue folded log2(e) into the scale of q): p = 2^(s - m), one v_exp each.
+        // P stays unnormalised (<= 1) on its way through the PV product; O is divided by the row sum at the end.
+        float sum = 0.0f;
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float pv = __builtin_amdgcn_exp2f(s[kt][e] - msafe);
+                s[kt][e] = pv;
+                sum += pv;
+            }
+        sum += __shfl_xor(sum, 16);
+        sum += __shfl_xor(sum, 32);
+        const float inv = sum > 0.0f ? 1.0f / sum : 0.0f;
+
+        float4_t o[4];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) o[mt] = float4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < NT / 2; ++c) {
+            const float8_t pf = {s[2 * c][0], s[2 * c][1], s[2 * c][2], s[2 * c][3],
+                                 s[2 * c + 1][0], s[2 * c + 1][1], s[2 * c + 1][2], s[2 * c + 1][3]};
+            const half8_t pb = __builtin_convertvector(pf, half8_t);
+            const int slot = (jb + rel0 + c * 32 + g * 4) & (RING - 1);        // 4 consecutive keys, then +16
+            const int slot2 = (slot + 16) & (RING - 1);
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                const half_t* vp = vt + (mt * 16 + (lane & 15)) * RVS;
+                const half4_t va = *(const half4_t*)(vp + slot);
+                const half4_t vb = *(const half4_t*)(vp + slot2);
+                half8_t af;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { af[e] = va[e]; af[4 + e] = vb[e]; }
+                o[mt] = mfma16(af, pb, o[mt]);
+            }
+        }
+        if (qi < p.T) {
+            half_t* op = p.out + ((long)n * p.T + qi) * D + h * HD + g * 4;
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                half4_t ov;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) ov[e] = (half_t)(o[mt][e] * inv);
+                *(half4_t*)(op + mt * 16) = ov;
+            }
+        }
+        __syncthreads();                          // everybody is done with the rows the next block overwrites
+        if (more) store_pair(nfirst, tid >> 3, tid & 7, nk, nv);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // out[m][:] = rmsnorm(a[m][:] + alpha * x[m][:]) * w     (fp32 statistics, eps inside the sqrt)
 struct NormArgs {
     const half_t* a;
@@ -252,6 +428,22 @@ int bh_k_attention(const void* qkv, void* out, const float* cos_sin, int N, int 
     else if (need <= 26) BH_ATTN(26);
     else BH_REQUIRE(false, "attention: window %d+%d is too wide for the LDS-resident kernel", win_left, win_right);
 #undef BH_ATTN
+    BH_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// q (already rotated and scaled) | k (already rotated) | v  ->  attention output; see attention_ring_kernel.
+int bh_k_attention_prerotated(const void* qkv, void* out, int N, int T, int nhead, int head_dim, int win_left, int win_right,
+                              hipStream_t stream) {
+    using namespace bh;
+    BH_REQUIRE(head_dim == 64, "attention: only head_dim 64 is implemented (got %d)", head_dim);
+    BH_REQUIRE(win_left >= 0 && win_right >= 0 && win_left <= 128 && win_left + win_right <= 256,
+               "attention (ring): window (%d, %d) outside the supported range", win_left, win_right);
+    BH_REQUIRE(N > 0 && T > 0 && nhead > 0, "attention: empty problem");
+    AttnRingArgs a{(const half_t*)qkv, (half_t*)out, N, T, nhead, win_left, win_right};
+    const size_t lds = (size_t)RING * 128 + (size_t)64 * RVS * 2;
+    BH_CHECK_HIP(hipFuncSetAttribute((const void*)attention_ring_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(attention_ring_kernel, dim3(nhead, N), dim3(512), lds, stream, a);
     BH_CHECK_HIP(hipGetLastError());
     return 0;
 }

@@ -174,6 +174,7 @@ struct bh_encoder {
     int rot_len = 0;
     int out_features = 0;
     int lstm_force_slow = 0;
+    int attn_ring = 1;           // transformer: rotary in the Wqkv epilogue + persistent ring-buffer attention kernel
     int lstm_fused = 3;          // insize == hidden: 3 = + ring-in-a-workgroup kernel for narrow layers, 2 = workgroup-shared fused
                                  // kernel where it covers H, 1 = per-wave fused
                                  // kernel (input projection inside the recurrence), 0 = projection by a GEMM beforehand
@@ -694,10 +695,20 @@ extern "C" int bh_encoder_forward(bh_encoder_t* e, const void* signal, int N, in
                 int rc;
                 {
                     ProfSpan span(e, st, BH_PROF_ATTENTION);
-                    rc = bh_k_linear(cur, l.w0.p, (const float*)l.b0.p, e->t_qkv.p, M, 3 * D, D, D, D, 3 * D, bh::ACT_NONE,
-                                     1.0f, -INFINITY, INFINITY, 0, 0, 0, 0, 0, st);
-                    if (!rc) rc = bh_k_attention(e->t_qkv.p, e->t_a.p, (const float*)e->rot.p, N, len, d.nhead, D / d.nhead,
-                                                 d.win_left, d.win_right, st);
+                    // default: rotary + softmax scale in the Wqkv epilogue, persistent ring-buffer attention kernel; the
+                    // block-per-workgroup kernel (rotation applied while staging) serves wider windows and "attn_ring" = 0
+                    const bool ring = e->attn_ring && d.win_left <= 128 && d.win_left + d.win_right <= 256;
+                    if (ring) {
+                        rc = bh_k_linear_qkv_rotary(cur, l.w0.p, (const float*)l.b0.p, e->t_qkv.p, M, D, D, (const float*)e->rot.p,
+                                                    len, 0.125f * 1.4426950408889634f, st);     // scores in log2 units
+                        if (!rc) rc = bh_k_attention_prerotated(e->t_qkv.p, e->t_a.p, N, len, d.nhead, D / d.nhead, d.win_left,
+                                                                d.win_right, st);
+                    } else {
+                        rc = bh_k_linear(cur, l.w0.p, (const float*)l.b0.p, e->t_qkv.p, M, 3 * D, D, D, D, 3 * D, bh::ACT_NONE,
+                                         1.0f, -INFINITY, INFINITY, 0, 0, 0, 0, 0, st);
+                        if (!rc) rc = bh_k_attention(e->t_qkv.p, e->t_a.p, (const float*)e->rot.p, N, len, d.nhead, D / d.nhead,
+                                                     d.win_left, d.win_right, st);
+                    }
                     if (!rc) rc = bh_k_linear(e->t_a.p, l.w1.p, (const float*)l.b1.p, e->t_b.p, M, D, D, D, D, D, bh::ACT_NONE,
                                               1.0f, -INFINITY, INFINITY, 0, 0, 0, 0, 0, st);
                     if (!rc) rc = bh_k_rmsnorm_residual(e->t_b.p, cur, (const float*)l.w4.p, e->t_a.p, M, D, d.alpha, eps, st);
@@ -898,6 +909,7 @@ extern "C" int bh_encoder_set_option(bh_encoder_t* e, const char* name, int valu
     BH_REQUIRE(e && name, "encoder_set_option: null argument");
     if (!strcmp(name, "lstm_force_slow")) { e->lstm_force_slow = (e->lstm_force_slow & ~1) | (value & 1); return 0; }
     if (!strcmp(name, "lstm_fused")) { e->lstm_fused = value; return 0; }
+    if (!strcmp(name, "attn_ring")) { e->attn_ring = value; return 0; }
     if (!strcmp(name, "gemm_v1")) { bh_k_linear_force_v1(value); return 0; }   // process-wide A/B switch
     if (!strcmp(name, "lstm_tune")) { e->lstm_force_slow = (e->lstm_force_slow & 1) | (value << 8); return 0; }
     BH_REQUIRE(false, "encoder_set_option: unknown option '%s'", name);

@@ -36,6 +36,11 @@ struct GemmArgs {
     long row_s_hi, row_s_lo;
     int row_lim;       // rows with (m % row_div) >= row_lim are not stored (batch padding)
     int n_ft, n_tt;    // tile counts
+    // optional rotary epilogue for the packed Wqkv projection (features [0, rot_nfeat) are heads of 64 rotated in place
+    // by position m % rot_T; features [0, rot_qfeat) are scaled by rot_qscale afterwards)
+    const float* rot_cs = nullptr;   // [rot_T][32][2] (cos, sin)
+    int rot_T = 1, rot_nfeat = 0, rot_qfeat = 0;
+    float rot_qscale = 1.0f;
 };
 
 constexpr int BF = 128, BT = 128, BK = 64;
@@ -98,6 +103,35 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, float4_t (&acc)
                 for (int i = 0; i < 8; ++i) {
                     if (fbase + i < p.N) v0[i] += (float)rp[i];
                     if (fbase + 8 + i < p.N) v1[i] += (float)rp[8 + i];
+                }
+            }
+        }
+        if constexpr (!GATED) {
+            // Rotary embedding fused into the Wqkv projection (bonito/transformer/model.py:72-73 applies RotaryEmbedding to
+            // q and k right after Wqkv): a wave's 64 features are one head, lane group kg holds dims 16kg..16kg+15, so the
+            // rotation partner (dim +-32) of every value sits in lane ^ 32. Done on the fp32 accumulators, before the only
+            // rounding to fp16. The head-level test is wave-uniform, so all 64 lanes take part in the exchange.
+            if (p.rot_cs != nullptr && f0 + wf * 64 < p.rot_nfeat) {
+                const int pos = m % p.rot_T;
+                const float* cs = p.rot_cs + ((long)pos * 32 + (kg & 1) * 16) * 2;
+                float8_t pa, pb;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    pa[i] = __shfl_xor(v0[i], 32);
+                    pb[i] = __shfl_xor(v1[i], 32);
+                }
+                const float sgn = kg < 2 ? -1.0f : 1.0f;        // x1' = x1 cos - x2 sin ; x2' = x1 sin + x2 cos
+                const float qs = f0 + wf * 64 < p.rot_qfeat ? p.rot_qscale : 1.0f;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const float4_t c4 = *(const float4_t*)(cs + 4 * i);      // (cos, sin) of dims 2i, 2i+1 of this quarter
+                    if (i < 4) {
+                        v0[2 * i] = (v0[2 * i] * c4[0] + sgn * pa[2 * i] * c4[1]) * qs;
+                        v0[2 * i + 1] = (v0[2 * i + 1] * c4[2] + sgn * pa[2 * i + 1] * c4[3]) * qs;
+                    } else {
+                        v1[2 * i - 8] = (v1[2 * i - 8] * c4[0] + sgn * pb[2 * i - 8] * c4[1]) * qs;
+                        v1[2 * i - 7] = (v1[2 * i - 7] * c4[2] + sgn * pb[2 * i - 7] * c4[3]) * qs;
+                    }
                 }
             }
         }
@@ -493,6 +527,26 @@ int bh_k_linear(const void* X, const void* W, const float* bias, void* out, int 
         case ACT_RELU: launch<ACT_RELU, false>(a, stream); break;
         default: BH_REQUIRE(false, "linear: unknown activation %d", act);
     }
+    BH_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// Packed Wqkv projection with the rotary embedding (and the softmax scale of q) applied in the epilogue:
+// out[m][0:D) = rot(q) * qscale, out[m][D:2D) = rot(k), out[m][2D:3D) = v; position of row m is m % T. cos_sin: [>=T][32][2].
+int bh_k_linear_qkv_rotary(const void* X, const void* W, const float* bias, void* out, int M, int D, int K, const float* cos_sin,
+                           int T, float qscale, hipStream_t stream) {
+    using namespace bh;
+    BH_REQUIRE(M > 0 && D > 0 && K > 0 && T > 0 && cos_sin != nullptr, "linear_qkv_rotary: bad arguments");
+    BH_REQUIRE(D % 64 == 0 && K % 8 == 0, "linear_qkv_rotary: d_model must be a multiple of 64 (heads of 64), K of 8");
+    GemmArgs a;
+    a.X = (const half_t*)X; a.W = (const half_t*)W; a.bias = bias; a.out = (half_t*)out;
+    a.res = nullptr; a.ldres = 0;
+    a.M = M; a.N = 3 * D; a.K = K; a.ldx = K; a.ldw = K; a.ldo = 3 * D;
+    a.scale = 1.0f; a.clamp_lo = -INFINITY; a.clamp_hi = INFINITY;
+    a.row_div = 1; a.row_s_hi = 1; a.row_s_lo = 0; a.row_lim = 0x7fffffff;
+    a.n_ft = (a.N + BF - 1) / BF; a.n_tt = (M + BT - 1) / BT;
+    a.rot_cs = cos_sin; a.rot_T = T; a.rot_nfeat = 2 * D; a.rot_qfeat = D; a.rot_qscale = qscale;
+    launch<ACT_NONE, false>(a, stream);
     BH_CHECK_HIP(hipGetLastError());
     return 0;
 }

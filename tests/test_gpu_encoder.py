@@ -109,6 +109,54 @@ def test_transformer_encoder_matches_reference_fixture(name):
     assert model.stride == 6
 
 
+@pytest.mark.parametrize("name", TF_FIXTURES)
+def test_transformer_attention_paths_agree(name):
+    """attn_ring = 1 (default: rotary + softmax scale in the Wqkv epilogue, persistent ring-buffer attention kernel) and
+    attn_ring = 0 (rotation applied while staging K/Q, one workgroup per query block) are two implementations of
+    MultiHeadAttention: both match the reference fixture, and each other to fp16 rounding (the fused rotation rounds once,
+    the staged one rounds q/k before and after rotating, as flash-attn's in-place rotary does)."""
+    cfg, sd, x, y = load_tf_fixture(name)
+    model = build_tf_model(cfg, sd)
+    want = ref_scores_to_koi(y)
+    rng = max(want.abs().max().item(), 1.0)
+    outs = {}
+    for ring in (1, 0):
+        enc = HipEncoder(model.encoder, batchsize=x.shape[0], chunksize=x.shape[-1])
+        enc.set_option("attn_ring", ring)
+        outs[ring] = enc(x.half().cuda()).cpu().float()
+        enc.check()
+        d = (outs[ring] - want).abs()
+        assert d.max().item() < 2e-2 * rng and d.mean().item() < 3e-3 * rng, (ring, d.max().item(), d.mean().item())
+    assert (outs[1] - outs[0]).abs().max().item() < 1e-2 * rng
+
+
+def test_transformer_long_chunk_ring_attention_matches_oracle():
+    """T = 700 tokens (six query blocks: the ring wraps) and a batch of 3, v5.0-style window (127, 128), against the fp32
+    oracle of the reference modules."""
+    from bonito_amd import synthetic
+    from bonito_amd.transformer import Model
+    torch.manual_seed(11)
+    cfg = synthetic.transformer_model_config(d_model=128, nhead=2, dim_ff=256, depth=2, window=(127, 128), state_len=3,
+                                             batchsize=3, chunksize=8400)
+    model = Model(cfg).eval()
+    nn_ref.round_params_to_half_(model.encoder)
+    x = torch.randn(3, 1, 8400).half()
+    outs = {}
+    for ring in (1, 0):
+        enc = HipEncoder(model.encoder, batchsize=3, chunksize=8400)
+        enc.set_option("attn_ring", ring)
+        outs[ring] = enc(x.cuda()).cpu().float()
+        enc.check()
+    with torch.no_grad():
+        want = nn_ref.forward(model.encoder, x.float(), expand_blanks=False)
+    if want.shape != outs[1].shape:
+        want = want.permute(1, 0, 2)
+    rng = max(want.abs().max().item(), 1.0)
+    for ring in (1, 0):
+        assert outs[ring].shape == want.shape
+        assert (outs[ring] - want).abs().max().item() < 2e-2 * rng, ring
+
+
 def test_fused_and_unfused_lstm_paths_agree():
     """The ring-in-a-workgroup kernel (3, narrow layers only), the workgroup-shared fused kernel (2), the per-wave fused kernel (1) and the GEMM + recurrence pair (0) are four
     implementations of the same layer: all must match the reference fixture; 0 differs from the fused ones only by
@@ -173,3 +221,24 @@ def test_wide_lstm_model_runs_through_streaming_kernel():
     with torch.no_grad():
         want = nn_ref.forward(model, x.float(), expand_blanks=False).permute(1, 0, 2)
     assert (got - want).abs().max().item() < TOL_MAX
+
+
+def test_full_size_hac_encoder_kernel_variants_bit_identical():
+    """BASELINE size (batch 512 x chunk 10000, hac widths): the workgroup-shared LSTM kernel that bench.py measures must give
+    the same bytes as the per-wave fused kernel and as the write-through exchange policy (size-independent property: all
+    variants share the accumulation order and lstm_cell()); the exchange must never time out."""
+    from bonito_amd import synthetic
+    model = synthetic.make_model("hac", batchsize=512, chunksize=10000)
+    x = torch.randn(512, 1, 10000, generator=torch.Generator().manual_seed(25)).half().cuda()
+    outs = []
+    for fused, slow in ((3, 0), (1, 0), (3, 1)):
+        enc = HipEncoder(model.encoder, batchsize=512, chunksize=10000)
+        enc.set_option("lstm_fused", fused)
+        enc.set_option("lstm_force_slow", slow)
+        outs.append(enc(x))
+        enc.check()
+        enc.close()
+    assert outs[0].shape == (512, 1667, 1024)
+    assert torch.isfinite(outs[0].float()).all()
+    assert torch.equal(outs[0], outs[1])
+    assert torch.equal(outs[0], outs[2])
