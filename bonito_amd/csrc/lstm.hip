@@ -678,6 +678,7 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_wg_kernel(LstmFusedArgs fp)
     long long st_poll = 0, st_rounds = 0, st_first_ok = 0, st_x = 0, st_rec = 0, st_bar = 0, st_hist = 0;
     long long st_a = 0, st_c = 0, st_mf = 0, st_gate = 0, st_store = 0;
     const long long st_t0 = __builtin_readcyclecounter();
+    const long long st_r0 = (p.tune & 4) ? (long long)__builtin_amdgcn_s_memrealtime() : 0;     // 100 MHz
 
     for (int step = 0; step < p.T; ++step, t += dt) {
         const long long pct = (p.tune & 4) ? __builtin_readcyclecounter() : 0;
@@ -783,7 +784,8 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_wg_kernel(LstmFusedArgs fp)
             else __hip_atomic_store(dst, packed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         } else {
             // lane (q, c) holds units q*MT..q*MT+MT-1 of chunk c: transpose through the wave's LDS patch so that the
-            // global store is 8 bytes per lane (U/4 lanes per chunk)
+            // global store is 8 bytes per lane (U/4 lanes per chunk). Measured alternative: MT direct 2-byte stores per
+            // lane without the LDS round trip are slower (hac encoder 19.2 -> 20.7 ms).
             half_t* sg = (half_t*)stage + c * U + q * MT;
 #pragma unroll
             for (int m = 0; m < MT; ++m) sg[m] = ho[m];
@@ -831,6 +833,7 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_wg_kernel(LstmFusedArgs fp)
         st[10] = st_mf;
         st[11] = st_gate;
         st[12] = st_store;
+        st[13] = (long long)__builtin_amdgcn_s_memrealtime() - st_r0;
     }
 }
 

@@ -37,4 +37,6 @@ print("rounds histogram (1,2,3,>=4): %s" % " ".join("%.3f" % v for v in h))
 if mode >= 2:
     names = ["x->LDS (A)", "x fetch issue (C)", "recurrent MFMAs", "gates", "x wait + transpose + store + poll issue"]
     print("cycles/step: " + " | ".join("%s %.0f" % (n, st[..., 8 + i].astype(float).mean() / T) for i, n in enumerate(names)))
+if mode >= 2:
+    print("shader clock during the kernel: %.2f GHz (cycle counter / 100 MHz real-time counter)" % (tot.mean() / st[..., 13].astype(float).mean() * 0.1))
 print("clock: readcyclecounter ticks; 100 MHz or shader clock depending on source")
