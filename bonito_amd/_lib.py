@@ -56,6 +56,9 @@ SIGNATURES = {
     "bh_crf_reverse_complement": (_i, [_vp, _vp, _i, _i, _i, _i, _l, _l, _vp]),
     "bh_crf_logz": (_i, [_vp, _i, _i, _i, _f, _vp, _vp, _vp]),
     "bh_set_option": (_i, [C.c_char_p, _i]),
+    "bh_signal_normalise": (_i, [_vp, _vp, _vp, _vp, _i, _i, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double,
+                            _i, _vp, _vp, _vp, _vp, _vp]),
+    "bh_signal_chunks": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp]),
     "bh_crf_posterior_viterbi_workspace": (_sz, [_i, _i, _i]),
     "bh_crf_posterior_viterbi": (_i, [_vp, _i, _i, _i, _f, _vp, _vp, _vp, _vp]),
     "bh_beam_search_workspace": (_sz, [_i, _i, _i]),

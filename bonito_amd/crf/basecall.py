@@ -91,6 +91,16 @@ class _Pipeline:
         self.decoders = {}
 
     def encode(self, batch):
+        if batch.is_cuda:                 # produced on the device (basecall_raw): no copy, just order the streams
+            with torch.inference_mode(), torch.cuda.stream(self.enc_stream):
+                self.enc_stream.wait_stream(torch.cuda.default_stream(self.device))
+                batch.record_stream(self.enc_stream)
+                scores = self.model(batch)
+                if self.reverse:
+                    scores = self.model.seqdist.reverse_complement(scores)
+                ready = torch.cuda.Event()
+                ready.record(self.enc_stream)
+            return scores, ready
         # H2D on its own stream, waited for on the host: the (recycled, pinned) batch buffer is free again when this
         # method returns, and the copy never queues behind the previous batch's encoder.
         with torch.inference_mode(), torch.cuda.stream(self.copy_stream):
@@ -186,6 +196,79 @@ def basecall(model, reads, chunksize=4000, overlap=100, batchsize=32, reverse=Fa
     pipe = _Pipeline(model, decoder=decoder, reverse=reverse)
     # up to 4 batches are in flight behind the generator (three single-slot queues + the consumer): recycle after 8
     batches = thread_iter(chunk_batches(reads, chunksize, overlap, batchsize, pin=torch.cuda.is_available(), nbuf=8))
+    encoded = thread_iter((keys, pipe.encode(batch)) for keys, batch in batches)
+    scores = thread_iter((keys, pipe.decode(*enc)) for keys, enc in encoded)
+    results = thread_iter(
+        (read, stitch_planes(sc, end - start, chunksize, overlap, model.stride, reverse))
+        for ((read, start, end), sc) in unbatchify(scores, dim=1)
+    )
+    return thread_iter((read, fmt_planes(model.stride, planes, rna)) for read, planes in results)
+
+
+def raw_chunk_batches(reads, chunksize, overlap, batchsize, device, group_samples=1 << 26, scaling_strategy=None,
+                      norm_params=None, do_trim=True):
+    """Device-side ingest for raw reads (objects with int16 `.raw`, `.scaling`, `.offset`): groups of reads are shipped as
+    int16 once, normalised / trimmed / chunked on the GPU (bonito_amd.signal) and handed to the encoder as fp16 device
+    batches. Yields the same (keys, batch) stream as `chunk_batches` over `reader.Read` objects of the same reads, and
+    fills in `shift`, `scale`, `trimmed_samples` and `signal_len` on every read (what the writers report)."""
+    from bonito_amd.signal import RawBatch
+
+    def groups():
+        cur, total = [], 0
+        for read in reads:
+            cur.append(read)
+            total += len(read.raw)
+            if total >= group_samples:
+                yield cur
+                cur, total = [], 0
+        if cur:
+            yield cur
+
+    pend_keys, pend_parts, pos = [], [], 0
+    for group in groups():
+        rb = RawBatch([r.raw for r in group], [float(r.scaling) for r in group], [float(r.offset) for r in group], device=device)
+        shift, scale, trim = rb.normalise(scaling_strategy, norm_params, do_trim)
+        for r, sh, sc, tr in zip(group, shift, scale, trim):
+            r.shift, r.scale, r.trimmed_samples = float(sh), float(sc), int(tr)
+            r.signal_len = len(r.raw) - int(tr)
+        table = rb.chunk_table(chunksize, overlap, trim)
+        n = len(table[0])
+        # contiguous runs of one read inside the chunk list
+        lo = 0
+        while lo < n:
+            take = min(n - lo, batchsize - pos)
+            part = rb.chunks(table, chunksize, lo, lo + take)
+            ridx = table[0][lo:lo + take]
+            start = 0
+            while start < take:
+                end = start
+                while end < take and ridx[end] == ridx[start]:
+                    end += 1
+                read = group[int(ridx[start])]
+                key = (read, 0, read.signal_len)
+                if pend_keys and pend_keys[-1][0][0] is read and pend_keys[-1][1][1] == pos + start:
+                    pend_keys[-1] = (key, (pend_keys[-1][1][0], pos + end))
+                else:
+                    pend_keys.append((key, (pos + start, pos + end)))
+                start = end
+            pend_parts.append(part)
+            pos += take
+            lo += take
+            if pos == batchsize:
+                yield tuple(pend_keys), (pend_parts[0] if len(pend_parts) == 1 else torch.cat(pend_parts))
+                pend_keys, pend_parts, pos = [], [], 0
+    if pos:
+        yield tuple(pend_keys), (pend_parts[0] if len(pend_parts) == 1 else torch.cat(pend_parts))
+
+
+def basecall_raw(model, reads, chunksize=4000, overlap=100, batchsize=32, reverse=False, rna=False, decoder="beam",
+                 scaling_strategy=None, norm_params=None, do_trim=True):
+    """`basecall` for raw int16 reads (`.raw`, `.scaling`, `.offset`): the signal pre-processing of reader.Read runs on the
+    device. Same results as ``basecall(model, [reader.Read(...) ...])`` on the same reads (tests compare them)."""
+    pipe = _Pipeline(model, decoder=decoder, reverse=reverse)
+    device = next(model.parameters()).device
+    batches = thread_iter(raw_chunk_batches(reads, chunksize, overlap, batchsize, device, scaling_strategy=scaling_strategy,
+                                            norm_params=norm_params, do_trim=do_trim))
     encoded = thread_iter((keys, pipe.encode(batch)) for keys, batch in batches)
     scores = thread_iter((keys, pipe.decode(*enc)) for keys, enc in encoded)
     results = thread_iter(

@@ -932,6 +932,22 @@ extern "C" int bh_crf_logz(const void* scores, int N, int T, int state_len, floa
     BH_REQUIRE(scores && workspace && logz, "crf_logz: null pointer");
     return bh_k_crf_logz(scores, N, T, state_len, blank_score, workspace, logz, (hipStream_t)stream);
 }
+extern "C" int bh_signal_normalise(const int16_t* raw, const long* offsets, const float* cal_scale, const float* cal_offset, int n_reads,
+                                   int strategy, double quantile_a, double quantile_b, double shift_mult, double scale_mult,
+                                   double fixed_shift, double fixed_scale, int do_trim, double* shift, double* scale, int* weak,
+                                   int* trim, void* stream) {
+    return bh_k_signal_normalise(raw, offsets, cal_scale, cal_offset, n_reads, strategy, quantile_a, quantile_b, shift_mult,
+                                 scale_mult, fixed_shift, fixed_scale, do_trim, shift, scale, weak, trim, (hipStream_t)stream);
+}
+extern "C" int bh_signal_chunks(const int16_t* raw, const long* offsets, const float* cal_scale, const float* cal_offset,
+                                const double* shift, const double* scale, const int* weak, const int* chunk_read,
+                                const long* chunk_start, const long* chunk_len, int n_chunks, int chunk_samples, void* out,
+                                void* stream) {
+    BH_REQUIRE(raw && offsets && cal_scale && cal_offset && shift && scale && weak && chunk_read && chunk_start && chunk_len && out,
+               "signal_chunks: null pointer");
+    return bh_k_signal_chunks(raw, offsets, cal_scale, cal_offset, shift, scale, weak, chunk_read, chunk_start, chunk_len,
+                              n_chunks, chunk_samples, out, (hipStream_t)stream);
+}
 extern "C" int bh_set_option(const char* name, int value) {
     BH_REQUIRE(name != nullptr, "set_option: null name");
     if (bh_k_decode_set_option(name, value) == 0) return 0;

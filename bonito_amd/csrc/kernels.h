@@ -80,3 +80,10 @@ int bh_k_linear_qkv_rotary(const void* X, const void* W, const float* bias, void
                            int T, float qscale, hipStream_t stream);
 int bh_k_attention_prerotated(const void* qkv, void* out, int N, int T, int nhead, int head_dim, int win_left, int win_right,
                               hipStream_t stream);
+// signal.hip
+int bh_k_signal_normalise(const int16_t* raw, const long* offs, const float* cal_scale, const float* cal_offset, int R,
+                          int strategy, double qa, double qb, double shift_mult, double scale_mult, double fixed_shift,
+                          double fixed_scale, int do_trim, double* shift, double* scale, int* weak, int* trim, hipStream_t stream);
+int bh_k_signal_chunks(const int16_t* raw, const long* offs, const float* cal_scale, const float* cal_offset, const double* shift,
+                       const double* scale, const int* weak, const int* chunk_read, const long* chunk_start, const long* chunk_len,
+                       int n_chunks, int L, void* out, hipStream_t stream);

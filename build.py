@@ -19,6 +19,9 @@ LIB = os.path.join(ROOT, "bonito_amd", "libbonito_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
          "-I" + os.path.join(ROOT, "include")]
+# signal.hip reproduces NumPy's arithmetic operation by operation: no fused multiply-adds there (hipcc's default
+# -ffp-contract=fast ignores the in-source pragma)
+EXTRA_FLAGS = {"signal.hip": ["-ffp-contract=off"]}
 
 
 def _newer(dst, srcs):
@@ -39,7 +42,7 @@ def build_hip(force=False):
         obj = os.path.join(OBJ, s + ".o")
         objs.append(obj)
         if force or _newer(obj, [src] + hdrs):
-            cmd = [HIPCC] + FLAGS + (["-x", "hip"] if s.endswith(".cpp") else []) + ["-c", src, "-o", obj]
+            cmd = [HIPCC] + FLAGS + EXTRA_FLAGS.get(s, []) + (["-x", "hip"] if s.endswith(".cpp") else []) + ["-c", src, "-o", obj]
             jobs.append(cmd)
 
     def run(cmd):

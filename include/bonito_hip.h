@@ -146,6 +146,23 @@ int bh_crf_reverse_complement(const void* in, void* out, int N, int T, int state
 int bh_crf_logz(const void* scores, int N, int T, int state_len, float blank_score, void* workspace, double* logz,
                 void* stream);
 
+/* Signal ingest on the device: replaces Read.__init__'s numpy work (bonito/reader.py:122-166 normalisation + trim, the pA
+ * scaling of bonito/pod5.py:52-67) and util.chunk + the fp16 cast (bonito/util.py:142-161, crf/basecall.py:31) for raw
+ * int16 reads, with the reference's arithmetic reproduced bit for bit. All pointers are device pointers.
+ *   raw: concatenated int16 samples of n_reads reads, offsets[n_reads + 1]; cal_scale / cal_offset: per-read calibration
+ *   (pA = cal_scale * (raw + cal_offset)); strategy 0 = quantile scaling with (quantile_a, quantile_b, shift_mult,
+ *   scale_mult), 1 = fixed (fixed_shift, fixed_scale). Outputs per read: shift, scale (fp64), weak (bit0: shift is the
+ *   literal 10, bit1: scale is the literal 1.0 -- NumPy's promotion then differs), trim (first sample of the read proper).
+ * bh_signal_chunks writes normalised fp16 rows [n_chunks][chunk_samples]: row i = read chunk_read[i], samples
+ *   chunk_start[i] .. (chunk_len[i] >= chunk_samples) or the chunk_len[i] available samples tiled (short reads). */
+int bh_signal_normalise(const int16_t* raw, const long* offsets, const float* cal_scale, const float* cal_offset, int n_reads,
+                        int strategy, double quantile_a, double quantile_b, double shift_mult, double scale_mult,
+                        double fixed_shift, double fixed_scale, int do_trim, double* shift, double* scale, int* weak, int* trim,
+                        void* stream);
+int bh_signal_chunks(const int16_t* raw, const long* offsets, const float* cal_scale, const float* cal_offset,
+                     const double* shift, const double* scale, const int* weak, const int* chunk_read, const long* chunk_start,
+                     const long* chunk_len, int n_chunks, int chunk_samples, void* out, void* stream);
+
 /* Process-wide knobs (measurement / tuning hooks, no reference counterpart).
  *   "beam_fork": -1 auto (default), 0 = run the posterior scan behind the beam kernel on the caller's stream,
  *                1 = run it next to the beam kernel on an internal helper stream (joined before finalize).
