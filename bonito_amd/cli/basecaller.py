@@ -44,9 +44,17 @@ def main(args):
                              scaling_strategy=model.config.get("scaling"),
                              norm_params=model.config.get("standardisation") if (model.config.get("scaling") or {}).get(
                                  "strategy") == "pa" else model.config.get("normalisation"),
-                             n_max=args.max_reads or None)
-    results = basecall(model, reads, reverse=args.revcomp, rna=args.rna, batchsize=bc["batchsize"],
-                       chunksize=bc["chunksize"], overlap=bc["overlap"])
+                             n_max=args.max_reads or None, raw=args.device_ingest)
+    if args.device_ingest:            # int16 reads: pA scaling, normalisation, trim and chunking on the GPU
+        from bonito_amd.crf.basecall import basecall_raw
+        pa = (model.config.get("scaling") or {}).get("strategy") == "pa"
+        results = basecall_raw(model, reads, reverse=args.revcomp, rna=args.rna, batchsize=bc["batchsize"],
+                               chunksize=bc["chunksize"], overlap=bc["overlap"], scaling_strategy=model.config.get("scaling"),
+                               norm_params=model.config.get("standardisation") if pa else model.config.get("normalisation"),
+                               do_trim=not args.no_trim)
+    else:
+        results = basecall(model, reads, reverse=args.revcomp, rna=args.rna, batchsize=bc["batchsize"],
+                           chunksize=bc["chunksize"], overlap=bc["overlap"])
     mode = "sam" if args.sam else ("fasta" if args.fasta else "fastq")
     writer = Writer(mode, results, fd=sys.stdout, min_qscore=args.min_qscore,
                     summary_path=None if args.no_summary else args.summary)
@@ -77,6 +85,8 @@ def argparser():
     parser.add_argument("--revcomp", action="store_true", default=False)
     parser.add_argument("--rna", action="store_true", default=False)
     parser.add_argument("--recursive", action="store_true", default=False)
+    parser.add_argument("--device-ingest", action="store_true", default=False,
+                        help="int16 .npy reads: scale / normalise / trim / chunk on the GPU instead of in numpy")
     quant = parser.add_mutually_exclusive_group()
     quant.add_argument("--quantize", dest="quantize", action="store_true")
     quant.add_argument("--no-quantize", dest="quantize", action="store_false")

@@ -76,8 +76,37 @@ class Read:
         return "Read('%s')" % self.read_id
 
 
+class RawRead:
+    """A read whose signal is still raw int16 ADC samples: normalisation / trim / chunking happen on the device
+    (bonito_amd.signal, crf.basecall.basecall_raw), which fills in `shift`, `scale`, `trimmed_samples`. Same identity
+    fields as `Read`."""
+
+    def __init__(self, read_id, raw, filename="", run_id="", channel=0, mux=0, start=0.0, sample_rate=5000.0, scaling=1.0,
+                 offset=0.0):
+        self.read_id, self.filename, self.run_id = read_id, filename, run_id
+        self.channel, self.mux, self.start = channel, mux, start
+        self.sample_rate = sample_rate
+        self.raw = np.ascontiguousarray(raw, dtype=np.int16)
+        self.scaling, self.offset = float(scaling), float(offset)
+        self.num_samples = len(self.raw)
+        self.duration = self.num_samples / sample_rate
+        self.shift, self.scale, self.trimmed_samples = 0.0, 1.0, 0
+
+    @property
+    def template_start(self):
+        return self.start + self.trimmed_samples / self.sample_rate
+
+    @property
+    def template_duration(self):
+        return self.duration - self.trimmed_samples / self.sample_rate
+
+    def __repr__(self):
+        return "RawRead('%s')" % self.read_id
+
+
 class Reader:
-    """Yields `Read`s from a directory (``*.npy``; ``*.pod5`` when the pod5 module is available)."""
+    """Yields `Read`s from a directory (``*.npy``; ``*.pod5`` when the pod5 module is available); with ``raw=True`` int16
+    reads are yielded as `RawRead`s for the device ingest instead of being normalised here."""
 
     def __init__(self, directory, recursive=False):
         pattern = "**/*" if recursive else "*"
@@ -87,7 +116,7 @@ class Reader:
             raise FileNotFoundError("no .npy or .pod5 reads found in '%s'" % directory)
 
     def get_reads(self, read_ids=None, skip=False, do_trim=True, scaling_strategy=None, norm_params=None, n_max=None,
-                  cancel=None):
+                  cancel=None, raw=False):
         count = 0
 
         def wanted(rid):
@@ -102,7 +131,19 @@ class Reader:
             rid = meta.get("read_id", os.path.splitext(os.path.basename(path))[0])
             if not wanted(rid):
                 continue
-            yield Read(rid, np.load(path), filename=os.path.basename(path), run_id=meta.get("run_id", ""),
+            data = np.load(path)
+            if raw and data.dtype == np.int16:
+                yield RawRead(rid, data, filename=os.path.basename(path), run_id=meta.get("run_id", ""),
+                              channel=meta.get("channel", 0), mux=meta.get("mux", 0), start=meta.get("start", 0.0),
+                              sample_rate=meta.get("sample_rate", 5000.0), scaling=meta.get("scale", 1.0),
+                              offset=meta.get("offset", 0.0))
+                count += 1
+                if (n_max and count >= n_max) or (cancel is not None and cancel.is_set()):
+                    return
+                continue
+            if raw:
+                raise ValueError("%s: device ingest needs int16 raw samples (got %s)" % (path, data.dtype))
+            yield Read(rid, data, filename=os.path.basename(path), run_id=meta.get("run_id", ""),
                        channel=meta.get("channel", 0), mux=meta.get("mux", 0), start=meta.get("start", 0.0),
                        sample_rate=meta.get("sample_rate", 5000.0), scaling=meta.get("scale", 1.0),
                        offset=meta.get("offset", 0.0), do_trim=do_trim, scaling_strategy=scaling_strategy,

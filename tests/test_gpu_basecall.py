@@ -174,3 +174,47 @@ def test_cli_basecaller_end_to_end(tmp_path, capsys):
     assert len(recs) == 12 and recs[0].startswith("@read0") and "mv:B:c,6," in recs[0]
     assert set(recs[1]) <= set("ACGT") and len(recs[1]) == len(recs[3])
     assert len((tmp_path / "summary.tsv").read_text().splitlines()) == 4
+
+
+def test_cli_device_ingest_equals_host_ingest(tmp_path, capsys):
+    """`--device-ingest` on int16 .npy reads (+ calibration side-cars) writes exactly the FASTQ the numpy ingest writes."""
+    import json
+    from conftest import load_nn_fixture
+    from bonito_amd.__main__ import main
+    cfg, sd, _, _ = load_nn_fixture("lstm64_sl3")
+
+    def tv(v):
+        if isinstance(v, bool):
+            return "true" if v else "false"
+        if isinstance(v, str):
+            return json.dumps(v)
+        if isinstance(v, list):
+            return "[" + ", ".join(tv(i) for i in v) + "]"
+        return repr(v)
+
+    mdir, rdir = tmp_path / "model", tmp_path / "reads"
+    mdir.mkdir(); rdir.mkdir()
+    lines = ['[model]', 'package = "bonito.crf"', '[labels]', 'labels = ["N", "A", "C", "G", "T"]', '[input]',
+             'features = 1', '[global_norm]', 'state_len = 3', '[basecaller]', 'batchsize = 8', 'chunksize = 1200',
+             'overlap = 120', '[encoder]', 'type = "serial"']
+    for sub in cfg["sublayers"]:
+        lines.append("[[encoder.sublayers]]")
+        lines += ["%s = %s" % (k, tv(v)) for k, v in sub.items()]
+    (mdir / "config.toml").write_text("\n".join(lines) + "\n")
+    sd = {k: (v * 30.0 if k.endswith("linear.weight") else v) for k, v in sd.items()}
+    torch.save(sd, str(mdir / "weights_1.tar"))
+    rng = np.random.default_rng(5)
+    for i, n in enumerate([6000, 13000, 900, 2500]):
+        x = rng.normal(480, 60, n)
+        x[60:260] += 400
+        np.save(rdir / ("read%d.npy" % i), np.clip(np.round(x), -32768, 32767).astype(np.int16))
+        (rdir / ("read%d.json" % i)).write_text(json.dumps({"scale": 0.1755, "offset": -243.0 + i, "sample_rate": 4000.0}))
+    outs = []
+    for extra in ([], ["--device-ingest"]):
+        rc = main(["basecaller", str(mdir), str(rdir), "--summary", str(tmp_path / "summary.tsv"), "--batchsize", "8"] + extra)
+        out, err = capsys.readouterr()
+        assert rc == 0 and "completed reads: 4" in err
+        outs.append(out)
+        outs.append((tmp_path / "summary.tsv").read_text())
+    assert outs[0] == outs[2] and len(outs[0].strip().split("\n")) == 16
+    assert outs[1] == outs[3]
