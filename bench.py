@@ -34,14 +34,14 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--model", default="hac", choices=["hac", "fast", "sup"])
+    ap.add_argument("--model", default="hac", choices=["hac", "fast", "sup", "sup_lstm"])
     ap.add_argument("--batch", type=int, default=0, help="default: 512 (hac/fast), 256 (sup)")
     ap.add_argument("--chunk", type=int, default=0, help="default: 10000 (hac/fast), 12000 (sup)")
     ap.add_argument("--decoder", default="beam", choices=["viterbi", "beam"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     a = ap.parse_args()
-    a.batch = a.batch or (256 if a.model == "sup" else 512)
-    a.chunk = a.chunk or (12000 if a.model == "sup" else 10000)
+    a.batch = a.batch or (256 if a.model in ("sup", "sup_lstm") else 512)
+    a.chunk = a.chunk or (12000 if a.model == "sup" else 20000 if a.model == "sup_lstm" else 10000)
     return a
 
 
@@ -223,8 +223,8 @@ def main():
         flops_per_launch = work * a.batch / launches_per_fwd
         avg_ms = ms / spans
         achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12
-        lstm_h = {"fast": 96, "hac": 384}.get(a.model, 0)
-        lstm_kernel = ("lstm_layer_kernel" if prof["lstm_gemm"][1] else
+        lstm_h = {"fast": 96, "hac": 384, "sup_lstm": 1024}.get(a.model, 0)
+        lstm_kernel = ("lstm_layer_wide_kernel" if lstm_h > 512 else "lstm_layer_kernel" if prof["lstm_gemm"][1] else
                        "lstm_layer_wg_kernel" if lstm_h and (lstm_h % 48 == 0 or lstm_h in (64, 128, 256)) else "lstm_layer_fused_kernel")
         roof = {"kernel": {"lstm_rec": lstm_kernel, "lstm_gemm": "gemm_kernel", "crf_linear": "gemm_kernel",
                            "conv": "conv_igemm_kernel", "mlp": "gemm_kernel (fc1 gated + fc2) + rmsnorm_residual_kernel",

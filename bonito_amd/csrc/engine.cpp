@@ -174,6 +174,8 @@ struct bh_encoder {
     int rot_len = 0;
     int out_features = 0;
     int lstm_force_slow = 0;
+    int batch_pad = 16;          // chunks per LSTM ring: 16, or 32 when a wide (H > 512) layer uses two column tiles per ring
+    int lstm_wide = 1;           // H > 512: stationary-W_hh kernel with 32-chunk rings (0: weight-streaming kernel)
     int attn_ring = 1;           // transformer: rotary in the Wqkv epilogue + persistent ring-buffer attention kernel
     int lstm_fused = 3;          // insize == hidden: 3 = + ring-in-a-workgroup kernel for narrow layers, 2 = workgroup-shared fused
                                  // kernel where it covers H, 1 = per-wave fused
@@ -367,6 +369,25 @@ extern "C" int bh_encoder_create(const bh_layer_t* layers, int n_layers, int dev
                     rc = bh_lstm_pack_whh(d.w0, H, pk.data());
                     if (!rc) rc = upload(L.w2, pk.data(), pk.size() * 2);
                 }
+                if (!rc && bh_k_lstm_wide_ok(H)) {   // wide layer: W_hh tiles of 8 units + W_ih / bias with permuted rows, so that
+                    const int MT = 2;                  // the GEMM writes G[t][n][(slice*4 + q)*8 + gate*2 + m]
+                    std::vector<uint16_t> pk((size_t)4 * H * H);
+                    rc = lstm_pack_tiles(d.w1, H, MT, pk.data());
+                    if (!rc) rc = upload(L.w3, pk.data(), pk.size() * 2);
+                    std::vector<float> wp((size_t)4 * H * I), bp((size_t)4 * H);
+                    for (int s8 = 0; s8 < H / 8; ++s8)
+                        for (int q = 0; q < 4; ++q)
+                            for (int g = 0; g < 4; ++g)
+                                for (int m = 0; m < MT; ++m) {
+                                    const size_t dst = (((size_t)s8 * 4 + q) * 4 + g) * MT + m;
+                                    const size_t src = (size_t)g * H + s8 * 8 + q * MT + m;
+                                    memcpy(&wp[dst * I], d.w0 + src * I, sizeof(float) * I);
+                                    bp[dst] = (d.b0 ? d.b0[src] : 0.0f) + (d.b1 ? d.b1[src] : 0.0f);
+                                }
+                    if (!rc) rc = upload_f16(L.w4, wp.data(), wp.size());
+                    if (!rc) rc = upload_f32(L.b1, bp.data(), bp.size());
+                    e->batch_pad = 32;
+                }
                 if (!rc && I == H && bh_k_lstm_wg_units(H) != 0) {    // tile-packed pair for the workgroup-shared kernel
                     const int MT = bh_k_lstm_wg_units(H) / 4;
                     std::vector<uint16_t> pk((size_t)4 * H * H);
@@ -482,7 +503,7 @@ extern "C" int bh_encoder_create(const bh_layer_t* layers, int n_layers, int dev
     }
     int T = 0, C = 0;
     size_t ab = 0, gb = 0;
-    const int Np = pad16(max_batch);
+    const int Np = (max_batch + e->batch_pad - 1) / e->batch_pad * e->batch_pad;
     if (walk(e, Np, max_chunk, &T, &C, &ab, &gb)) return fail(-2);
     bool has_res = false;
     for (const auto& l : e->layers) has_res |= l.d.kind == BH_LAYER_RESIDUAL_PROJ;
@@ -564,7 +585,7 @@ extern "C" int bh_encoder_forward(bh_encoder_t* e, const void* signal, int N, in
         ~Restore() { if (prev != dev) (void)hipSetDevice(prev); }
     } restore{prev, e->device};
 
-    const int Np = pad16(N);
+    const int Np = (N + e->batch_pad - 1) / e->batch_pad * e->batch_pad;
     // stage the batch into an engine-owned [Np][L] buffer whose padding rows are zero
     if (Np != N) BH_CHECK_HIP(hipMemsetAsync((char*)e->sig.p + (size_t)N * L * 2, 0, (size_t)(Np - N) * L * 2, st));
     BH_CHECK_HIP(hipMemcpyAsync(e->sig.p, signal, (size_t)N * L * 2, hipMemcpyDeviceToDevice, st));
@@ -619,13 +640,14 @@ extern "C" int bh_encoder_forward(bh_encoder_t* e, const void* signal, int N, in
                 int rc;
                 void* dst = e->act[which].p;
                 const bool reg_path = H <= 512 && H % 32 == 0;
+                const bool wide = !reg_path && e->lstm_wide && bh_k_lstm_wide_ok(H) && l.w3.p != nullptr && l.w4.p != nullptr;
                 const bool fused = reg_path && e->lstm_fused && d.in_size == H && l.w2.p != nullptr;
                 const bool wg = fused && e->lstm_fused >= 2 && l.w3.p != nullptr && l.w4.p != nullptr;
                 const bool cta = wg && e->lstm_fused >= 3 && bh_k_lstm_cta_units(H) != 0 && bh_k_lstm_cta_units(H) == bh_k_lstm_wg_units(H);
                 if (!fused) {
                     ProfSpan span(e, st, BH_PROF_LSTM_GEMM);
-                    rc = bh_k_linear(cur, l.w0.p, (const float*)l.b0.p, e->gates.p, M, 4 * H, d.in_size, d.in_size,
-                                     d.in_size, 4 * H, bh::ACT_NONE, 1.0f, -INFINITY, INFINITY, 0, 0, 0, 0, 0, st);
+                    rc = bh_k_linear(cur, wide ? l.w4.p : l.w0.p, (const float*)(wide ? l.b1.p : l.b0.p), e->gates.p, M, 4 * H,
+                                     d.in_size, d.in_size, d.in_size, 4 * H, bh::ACT_NONE, 1.0f, -INFINITY, INFINITY, 0, 0, 0, 0, 0, st);
                     if (rc) return rc;
                 }
                 if (!cta) {      // exchange sentinel (the ring-in-a-workgroup kernel exchanges through LDS only)
@@ -639,12 +661,18 @@ extern "C" int bh_encoder_forward(bh_encoder_t* e, const void* signal, int N, in
                 const int wg_wpr = wg ? (H / bh_k_lstm_wg_units(H)) / 4 : 1;     // workgroups per ring (wg variant)
                 const int groups_fit = wg ? e->n_cus / (8 * wg_wpr) : reg_path ? e->n_cus / (8 * nsl) : e->n_cus / (8 * (nsl / 4));
                 BH_REQUIRE(groups_fit >= 1, "encoder_forward: device has too few CUs (%d) for hidden size %d", e->n_cus, H);
-                const int rings_per_launch = cta ? (1 << 20) : wg ? groups_fit * 8 : reg_path ? groups_fit * 32 : groups_fit * 8;
-                const int n_rings = Np / 16;
+                const int wide_fit = wide ? e->n_cus / (8 * (H / 32)) : 0;          // ring groups (of 8 rings) that are co-resident
+                BH_REQUIRE(!wide || wide_fit >= 1, "encoder_forward: device has too few CUs (%d) for hidden size %d", e->n_cus, H);
+                const int rings_per_launch = wide ? wide_fit * 8 : cta ? (1 << 20) : wg ? groups_fit * 8 : reg_path ? groups_fit * 32 : groups_fit * 8;
+                const int ring_chunks = wide ? 32 : 16;
+                const int n_rings = Np / ring_chunks;
                 for (int r0 = 0; r0 < n_rings; r0 += rings_per_launch) {
                     const int nr = std::min(rings_per_launch, n_rings - r0);
-                    const size_t col = (size_t)r0 * 16;
-                    if (cta)
+                    const size_t col = (size_t)r0 * ring_chunks;
+                    if (wide)
+                        rc = bh_k_lstm_layer_wide((const char*)e->gates.p + col * 4 * H * 2, l.w3.p, (char*)dst + col * H * 2, len, Np, H,
+                                                  d.reverse, (int*)e->err.p, st, nr, (int*)e->lstm_ws.p, e->lstm_force_slow);
+                    else if (cta)
                         rc = bh_k_lstm_layer_cta((const char*)cur + col * H * 2, l.w4.p, (const float*)l.b0.p, l.w3.p,
                                                  (char*)dst + col * H * 2, len, Np, H, d.reverse, st, nr);
                     else if (wg)
@@ -910,6 +938,7 @@ extern "C" int bh_encoder_set_option(bh_encoder_t* e, const char* name, int valu
     if (!strcmp(name, "lstm_force_slow")) { e->lstm_force_slow = (e->lstm_force_slow & ~1) | (value & 1); return 0; }
     if (!strcmp(name, "lstm_fused")) { e->lstm_fused = value; return 0; }
     if (!strcmp(name, "attn_ring")) { e->attn_ring = value; return 0; }
+    if (!strcmp(name, "lstm_wide")) { e->lstm_wide = value; return 0; }
     if (!strcmp(name, "gemm_v1")) { bh_k_linear_force_v1(value); return 0; }   // process-wide A/B switch
     if (!strcmp(name, "lstm_tune")) { e->lstm_force_slow = (e->lstm_force_slow & 1) | (value << 8); return 0; }
     BH_REQUIRE(false, "encoder_set_option: unknown option '%s'", name);

@@ -87,3 +87,6 @@ int bh_k_signal_normalise(const int16_t* raw, const long* offs, const float* cal
 int bh_k_signal_chunks(const int16_t* raw, const long* offs, const float* cal_scale, const float* cal_offset, const double* shift,
                        const double* scale, const int* weak, const int* chunk_read, const long* chunk_start, const long* chunk_len,
                        int n_chunks, int L, void* out, hipStream_t stream);
+int bh_k_lstm_wide_ok(int H);
+int bh_k_lstm_layer_wide(const void* gates_perm, const void* whh_tiles, void* h_out, int T, int N, int H, int reverse,
+                         int* err_flag, hipStream_t stream, int n_rings, int* xcc_ws, int force_slow);

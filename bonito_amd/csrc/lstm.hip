@@ -789,6 +789,7 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_wg_kernel(LstmFusedArgs fp)
             half_t* sg = (half_t*)stage + c * U + q * MT;
 #pragma unroll
             for (int m = 0; m < MT; ++m) sg[m] = ho[m];
+            asm volatile("" ::: "memory");       // the 8-byte reads below alias these 2-byte writes (different types: no TBAA reordering)
             constexpr int PARTS = U / 4;
             if (lane < 16 * PARTS) {
                 const int cc = lane / PARTS, part = lane - cc * PARTS;
@@ -952,6 +953,204 @@ __global__ __launch_bounds__(64 * (NKS * 32 / (4 * MT)), 1) void lstm_layer_cta_
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Wide layers (512 < H <= 1024: the 768-wide old-style r9.4.1 models, the 1024-wide v4.3 `sup`): W_hh alone is 4.7 / 8.4 MB,
+// so one copy per 16-chunk ring does not fit the chip's registers. Here a ring is NB = 2 column tiles (32 chunks) sharing one
+// set of register-resident W_hh tiles: a wave owns U = 8 units (MT = 2 tiles, 64 fragments = all 256 accumulation
+// registers at H = 1024), a workgroup is four slices of one ring, a ring spans H/32 workgroups (32 at H = 1024 = one whole XCD),
+// and batch 256 fills 256 CUs. The input projection comes from a GEMM whose output columns are permuted so that a lane's
+// eight pre-activations (4 gates x 2 units) are one 16-byte load: G[t][n][(slice*4 + q)*8 + gate*2 + m].
+// Exchange protocol and workgroup sharing of the h tile through LDS as in lstm_layer_wg_kernel (each wave polls a quarter).
+// Replaces the weight-streaming kernel on these shapes: 139 -> 14.4 ms per layer launch at H=1024, N=256, T=3334.
+struct LstmWideArgs {
+    const half_t* G;      // [T][N][4H], columns permuted as above, bias included
+    LstmArgs a;
+};
+
+template <int NKS>
+__global__ __launch_bounds__(256, 1) void lstm_layer_wide_kernel(LstmWideArgs wp) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const LstmArgs& p = wp.a;
+    constexpr int MT = 2, NB = 2, H = NKS * 32, U = 4 * MT, NSL = H / U, WPR = NSL / 4;
+    constexpr int NF = NB * NKS;                 // B fragments of a ring's h tile
+    constexpr int KQ = (NF + 3) / 4;
+    constexpr bool EXACT = NF % 4 == 0;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int xcd = blockIdx.x & 7;
+    const int lwg = blockIdx.x >> 3;
+    const int rl = lwg / WPR;
+    const int ring = rl * 8 + xcd;
+    const int slice = (lwg - rl * WPR) * 4 + wave;
+    if (ring >= p.n_rings) return;
+
+    char* hbuf = smem;                                          // [2][NB][NKS][64 lanes][16 B]
+    char* stage = smem + 2 * NF * 1024 + wave * (16 * U * 2);   // per-wave [16 chunks][U] output transpose
+
+    half8_t whh[MT][NKS];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks)
+            whh[m][ks] = *(const half8_t*)(p.whh + ((((long)slice * MT + m) * NKS + ks) * 64 + lane) * 8);
+
+    const int c = lane & 15, q = lane >> 4;
+    const int lo = lane * 16;
+    const long row_bytes = (long)p.N * H * 2;
+    float cst[MT][NB];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) cst[m][nb] = 0.f;
+    bool dead = false;
+    bool fast = false;
+    {
+        int* slot = p.xcc_ws + (long)ring * NSL;
+        const int mine = xcc_id();
+        if (lane == 0) __hip_atomic_store(slot + slice, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned spins = 0;
+        bool ok = false;
+        while (true) {
+            bool any_unset = false, any_other = false;
+            for (int i = lane; i < NSL; i += 64) {
+                const int v = __hip_atomic_load(slot + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                any_unset |= v < 0;
+                any_other |= v != mine;
+            }
+            if (!__any(any_unset)) { ok = !__any(any_other); break; }
+            if (++spins > p.max_spins) break;
+            __builtin_amdgcn_s_sleep(4);
+        }
+        fast = ok && !p.force_slow;
+    }
+
+    int t = p.reverse ? p.T - 1 : 0;
+    const int dt = p.reverse ? -1 : 1;
+    // fragment f = nb*NKS + ks of the ring tile: chunk = ring*32 + nb*16 + c, units ks*32 + q*8 ..
+    auto frag_voff = [&](int f) -> unsigned {
+        const int nb = f / NKS, ks = f - nb * NKS;
+        return (unsigned)((((ring * NB + nb) * 16 + c) * H + ks * 32 + q * 8) * 2);
+    };
+    // gate pre-activations of this lane: 16 bytes per column tile
+    const half_t* gptr = wp.G + ((long)(ring * NB * 16 + c) * 4 * H + (slice * 4 + q) * 8);
+    const long g_row = (long)p.N * 4 * H;
+    uint4_t gq[NB], gr[NB], hq[KQ];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        const int t1 = p.T > 1 ? t + dt : t;
+        gq[nb] = *(const uint4_t*)(gptr + (long)t * g_row + (long)nb * 16 * 4 * H);
+        gr[nb] = *(const uint4_t*)(gptr + (long)t1 * g_row + (long)nb * 16 * 4 * H);
+    }
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) asm volatile("" : "+v"(gq[nb]), "+v"(gr[nb]));
+#pragma unroll
+    for (int kk = 0; kk < KQ; ++kk) hq[kk] = uint4_t{0, 0, 0, 0};
+
+    for (int step = 0; step < p.T; ++step, t += dt) {
+        const int par = step & 1;
+        // ---- B. my quarter of the ring's h_{t-1} tile (round one went out right after the previous store) --------
+        if (step > 0) {
+            const char* base = (const char*)p.h + (long)(t - dt) * row_bytes;
+            __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)row_bytes, 0x00020000);
+            unsigned spins = dead ? p.max_spins : 0u;
+            unsigned pend = 0;
+#pragma unroll
+            for (int kk = 0; kk < KQ; ++kk) {
+                const int f = wave + 4 * kk;
+                if (EXACT || f < NF) {
+                    unsigned orv = hq[kk].x | hq[kk].y | hq[kk].z | hq[kk].w;
+                    if (__any((orv & SENTINEL_MASK) != 0)) pend |= (1u << kk);
+                }
+            }
+            while (pend != 0) {
+                if (++spins > p.max_spins) {
+                    if (lane == 0 && !dead) atomicExch(p.err, 1);
+                    dead = true;
+                    break;
+                }
+                if (!(p.tune & 1)) __builtin_amdgcn_s_sleep(1);
+#pragma unroll
+                for (int kk = 0; kk < KQ; ++kk)
+                    if (pend & (1u << kk))
+                        hq[kk] = __builtin_amdgcn_raw_buffer_load_b128(rs, frag_voff(wave + 4 * kk), 0, (int)0x80000010);
+#pragma unroll
+                for (int kk = 0; kk < KQ; ++kk)
+                    if (pend & (1u << kk)) {
+                        unsigned orv = hq[kk].x | hq[kk].y | hq[kk].z | hq[kk].w;
+                        if (!__any((orv & SENTINEL_MASK) != 0)) pend &= ~(1u << kk);
+                    }
+            }
+#pragma unroll
+            for (int kk = 0; kk < KQ; ++kk) {
+                const int f = wave + 4 * kk;
+                if (EXACT || f < NF) *(uint4_t*)(hbuf + (par * NF + f) * 1024 + lo) = hq[kk];
+            }
+        }
+        // ---- C. gate pre-activations: this step's are in gq; rotate and request step t+2 (memory-quiet phase) -------
+        float4_t acc[MT][NB];
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            const half8_t g8 = __builtin_bit_cast(half8_t, gq[nb]);
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[m][nb][i] = (float)g8[i * MT + m];
+        }
+        {
+            const int t2 = (step + 2 < p.T) ? t + 2 * dt : t;
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+                gq[nb] = gr[nb];
+                gr[nb] = *(const uint4_t*)(gptr + (long)t2 * g_row + (long)nb * 16 * 4 * H);
+            }
+        }
+        __syncthreads();
+        // ---- E. recurrent part, gates, publish h_t ------------------------------------------------------------
+        if (step > 0) {
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+                const char* hb = hbuf + (par * NF + nb * NKS) * 1024 + lo;
+                half8_t b_cur = *(const half8_t*)hb, b_nxt = b_cur;
+#pragma unroll
+                for (int ks = 0; ks < NKS; ++ks) {
+                    if (ks + 1 < NKS) b_nxt = *(const half8_t*)(hb + (ks + 1) * 1024);
+#pragma unroll
+                    for (int m = 0; m < MT; ++m) mfma16_av(whh[m][ks], b_cur, acc[m][nb]);
+                    b_cur = b_nxt;
+                }
+            }
+            asm volatile("s_nop 15\n\ts_nop 7" : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[1][0]), "+v"(acc[1][1]));
+        }
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            half_t* sg = (half_t*)stage + c * U + q * MT;
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+                sg[m] = (half_t)lstm_cell(acc[m][nb][0], acc[m][nb][1], acc[m][nb][2], acc[m][nb][3], cst[m][nb]);
+            asm volatile("" ::: "memory");       // the 8-byte reads below alias these 2-byte writes (and the next tile's writes them)
+            if (lane < 32) {                    // 16 chunks x 2 parts of 4 units: 8-byte stores
+                const int cc = lane >> 1, part = lane & 1;
+                const unsigned long long packed = *(const unsigned long long*)((half_t*)stage + cc * U + part * 4);
+                unsigned long long* dst =
+                    (unsigned long long*)(p.h + ((long)t * p.N + (ring * NB + nb) * 16 + cc) * H + slice * U + part * 4);
+                if (fast) *dst = packed;
+                else __hip_atomic_store(dst, packed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            asm volatile("" ::: "memory");
+        }
+        // ---- F. first poll round for h_t ---------------------------------------------------------------------------
+        if (step + 1 < p.T) {
+            const char* base = (const char*)p.h + (long)t * row_bytes;
+            __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)row_bytes, 0x00020000);
+#pragma unroll
+            for (int kk = 0; kk < KQ; ++kk) {
+                const int f = wave + 4 * kk;
+                if (EXACT || f < NF) hq[kk] = __builtin_amdgcn_raw_buffer_load_b128(rs, frag_voff(f), 0, (int)0x80000010);
+            }
+        }
+    }
+}
+
 __global__ void fill_u16_kernel(uint16_t* dst, uint16_t v, size_t count) {
     size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 8;
     const size_t stride = (size_t)gridDim.x * blockDim.x * 8;
@@ -966,7 +1165,7 @@ __global__ void fill_u16_kernel(uint16_t* dst, uint16_t v, size_t count) {
 size_t bh_k_lstm_packed_bytes(int H) { return (size_t)4 * H * H * 2; }
 size_t bh_k_lstm_ws_bytes(int N, int H) {
     // XCD agreement slots + (tune bit 4) per-wave statistics: up to 16 x int64 per (ring, slice)
-    const size_t waves = (size_t)((N + 15) / 16) * ((H + 11) / 12);      // up to H/12 slices per ring (wg variant)
+    const size_t waves = (size_t)((N + 15) / 16) * ((H + 7) / 8);        // up to H/8 slices per ring (wide variant)
     return waves * sizeof(int) + 64 + waves * 16 * sizeof(long long) + 64;
 }
 
@@ -1159,6 +1358,42 @@ int bh_k_lstm_layer_cta(const void* x, const void* wih_tiles, const float* bias,
     if (H == 96) hipLaunchKernelGGL((lstm_layer_cta_kernel<3, 3>), dim3(n_rings), dim3(64 * nsl), lds, stream, a);
     else if (H == 64) hipLaunchKernelGGL((lstm_layer_cta_kernel<2, 4>), dim3(n_rings), dim3(64 * nsl), lds, stream, a);
     else hipLaunchKernelGGL((lstm_layer_cta_kernel<4, 4>), dim3(n_rings), dim3(64 * nsl), lds, stream, a);
+    BH_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// Wide layers: stationary W_hh, rings of 32 chunks; the caller provides G with permuted columns (bh_k_lstm_wide_permute).
+int bh_k_lstm_wide_ok(int H) { return H > 512 && H <= 1024 && H % 128 == 0; }
+
+int bh_k_lstm_layer_wide(const void* gates_perm, const void* whh_tiles, void* h_out, int T, int N, int H, int reverse,
+                         int* err_flag, hipStream_t stream, int n_rings, int* xcc_ws, int force_slow) {
+    using namespace bh;
+    BH_REQUIRE(bh_k_lstm_wide_ok(H), "lstm: wide kernel does not cover H=%d", H);
+    BH_REQUIRE(N % 32 == 0, "lstm: wide kernel needs the batch padded to a multiple of 32 (N=%d)", N);
+    int dev = 0, cus = 0;
+    BH_CHECK_HIP(hipGetDevice(&dev));
+    BH_CHECK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    const int nsl = H / 8, wpr = nsl / 4;
+    BH_REQUIRE(n_rings > 0 && n_rings <= N / 32, "lstm: n_rings=%d outside 1..%d", n_rings, N / 32);
+    const int rl = (n_rings + 7) / 8;
+    const int grid = 8 * rl * wpr;
+    BH_REQUIRE(grid <= cus, "lstm: %d workgroups must be co-resident but the device has %d CUs; split the batch", grid, cus);
+    BH_REQUIRE(xcc_ws != nullptr, "lstm: missing XCD agreement workspace");
+    BH_CHECK_HIP(hipMemsetAsync(xcc_ws, 0xFF, (size_t)n_rings * nsl * sizeof(int), stream));
+    LstmWideArgs a{(const half_t*)gates_perm,
+                   LstmArgs{nullptr, (const half_t*)whh_tiles, (half_t*)h_out, T, N, H, n_rings, reverse, err_flag, 1000000u, xcc_ws,
+                            force_slow & 1, force_slow >> 8}};
+    const int nks = H / 32;
+    const size_t lds = (size_t)2 * 2 * nks * 1024 + 4 * 16 * 8 * 2;
+#define BH_LSTM_WIDE(NKS)                                                                                               \
+    if (nks == NKS) {                                                                                                   \
+        BH_CHECK_HIP(hipFuncSetAttribute((const void*)lstm_layer_wide_kernel<NKS>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                         (int)lds));                                                                    \
+        hipLaunchKernelGGL((lstm_layer_wide_kernel<NKS>), dim3(grid), dim3(256), lds, stream, a);                        \
+    } else
+    BH_LSTM_WIDE(20) BH_LSTM_WIDE(24) BH_LSTM_WIDE(28) BH_LSTM_WIDE(32)
+    { BH_REQUIRE(false, "lstm: wide kernel has no instance for H=%d", H); }
+#undef BH_LSTM_WIDE
     BH_CHECK_HIP(hipGetLastError());
     return 0;
 }
