@@ -55,6 +55,12 @@ __device__ __forceinline__ int xcc_id() {
 
 constexpr unsigned SENTINEL_MASK = 0x40004000u;
 
+// LDS output transpose: 2-byte writes, 8-byte reads of the same bytes. Plain half_t / unsigned long long accesses are
+// different types for the compiler's alias analysis and were reordered (a wave then published stale LDS contents, which may
+// look like the exchange sentinel): both sides go through may_alias types.
+typedef unsigned short __attribute__((may_alias)) u16_alias_t;
+typedef unsigned long long __attribute__((may_alias)) u64_alias_t;
+
 // Gate-math tanh: the exp form has absolute error ~1e-7 everywhere, which is all the recurrence needs
 // (h and c are consumed at fp16 / additive precision); the relative-accuracy branch of common.h's tanhf_ is skipped.
 __device__ __forceinline__ float tanh_gate(float x) { return __builtin_fmaf(-2.0f, rcpf_(__expf(2.0f * x) + 1.0f), 1.0f); }
@@ -786,14 +792,13 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_wg_kernel(LstmFusedArgs fp)
             // lane (q, c) holds units q*MT..q*MT+MT-1 of chunk c: transpose through the wave's LDS patch so that the
             // global store is 8 bytes per lane (U/4 lanes per chunk). Measured alternative: MT direct 2-byte stores per
             // lane without the LDS round trip are slower (hac encoder 19.2 -> 20.7 ms).
-            half_t* sg = (half_t*)stage + c * U + q * MT;
+            u16_alias_t* sg = (u16_alias_t*)stage + c * U + q * MT;
 #pragma unroll
-            for (int m = 0; m < MT; ++m) sg[m] = ho[m];
-            asm volatile("" ::: "memory");       // the 8-byte reads below alias these 2-byte writes (different types: no TBAA reordering)
+            for (int m = 0; m < MT; ++m) sg[m] = __builtin_bit_cast(unsigned short, ho[m]);
             constexpr int PARTS = U / 4;
             if (lane < 16 * PARTS) {
                 const int cc = lane / PARTS, part = lane - cc * PARTS;
-                const unsigned long long packed = *(const unsigned long long*)((half_t*)stage + cc * U + part * 4);
+                const unsigned long long packed = *(const u64_alias_t*)((half_t*)stage + cc * U + part * 4);
                 unsigned long long* dst =
                     (unsigned long long*)(p.h + ((long)t * p.N + ring * 16 + cc) * H + slice * U + part * 4);
                 if (fast) *dst = packed;
@@ -1123,20 +1128,18 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_wide_kernel(LstmWideArgs wp
         }
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
-            half_t* sg = (half_t*)stage + c * U + q * MT;
+            u16_alias_t* sg = (u16_alias_t*)stage + c * U + q * MT;
 #pragma unroll
             for (int m = 0; m < MT; ++m)
-                sg[m] = (half_t)lstm_cell(acc[m][nb][0], acc[m][nb][1], acc[m][nb][2], acc[m][nb][3], cst[m][nb]);
-            asm volatile("" ::: "memory");       // the 8-byte reads below alias these 2-byte writes (and the next tile's writes them)
+                sg[m] = __builtin_bit_cast(unsigned short, (half_t)lstm_cell(acc[m][nb][0], acc[m][nb][1], acc[m][nb][2], acc[m][nb][3], cst[m][nb]));
             if (lane < 32) {                    // 16 chunks x 2 parts of 4 units: 8-byte stores
                 const int cc = lane >> 1, part = lane & 1;
-                const unsigned long long packed = *(const unsigned long long*)((half_t*)stage + cc * U + part * 4);
+                const unsigned long long packed = *(const u64_alias_t*)((half_t*)stage + cc * U + part * 4);
                 unsigned long long* dst =
                     (unsigned long long*)(p.h + ((long)t * p.N + (ring * NB + nb) * 16 + cc) * H + slice * U + part * 4);
                 if (fast) *dst = packed;
                 else __hip_atomic_store(dst, packed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
-            asm volatile("" ::: "memory");
         }
         // ---- F. first poll round for h_t ---------------------------------------------------------------------------
         if (step + 1 < p.T) {
