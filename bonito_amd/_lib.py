@@ -94,6 +94,10 @@ def lib():
                 "%s not found: the MI355X engine is not built (run `python build.py`). "
                 "bonito_amd has no CPU fallback." % LIB_PATH
             )
+        # Load torch (and with it the HIP runtime its wheel bundles, SONAME libamdhip64.so.7) BEFORE this library: whichever
+        # libamdhip64.so.7 is mapped first serves the whole process. Loaded the other way round (this library pulling
+        # /opt/rocm's runtime first, torch imported later) the two disagree and hipGetDeviceCount reports no device.
+        import torch  # noqa: F401
         handle = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(handle, name)  # AttributeError if the symbol is missing -> loud
