@@ -38,10 +38,15 @@ def parse():
     ap.add_argument("--batch", type=int, default=0, help="default: 512 (hac/fast), 256 (sup)")
     ap.add_argument("--chunk", type=int, default=0, help="default: 10000 (hac/fast), 12000 (sup)")
     ap.add_argument("--decoder", default="beam", choices=["viterbi", "beam"])
+    ap.add_argument("--lanes", type=int, default=0,
+                    help="independent batches in flight (each lane: own engine replica, encoder stream, decoder stream); "
+                         "default 1; 2 for the narrow `fast` model whose kernels leave most CUs idle (measured 8.96 -> 8.07 ms/step; "
+                         "3+ lanes lose again: more streams than hardware queues)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     a = ap.parse_args()
     a.batch = a.batch or (256 if a.model in ("sup", "sup_lstm") else 512)
     a.chunk = a.chunk or (12000 if a.model == "sup" else 20000 if a.model == "sup_lstm" else 10000)
+    a.lanes = a.lanes or (2 if a.model == "fast" else 1)
     return a
 
 
@@ -137,39 +142,64 @@ def main():
     gen = torch.Generator(device=dev).manual_seed(25 + rank)
     signal = torch.randn(a.batch, 1, a.chunk, generator=gen, device=dev).half()
 
-    enc_stream, dec_stream = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
-    T_out, C_out = None, None
+    # A lane = one engine replica (same seeded weights) + its encoder stream + its decoder stream + two decode contexts.
+    # Within a lane the decode of batch i overlaps the encoder of batch i+1; lanes overlap whole batches with each other.
+    class Lane:
+        pass
 
-    def encode():
-        with torch.cuda.stream(enc_stream):
-            sc = model(signal)
+    lanes = []
+    for li in range(a.lanes):
+        ln = Lane()
+        if li == 0:
+            ln.model = model
+        else:
+            ln.model = build_model(a.model, a.batch, a.chunk)
+            ln.model.use_koi(batchsize=a.batch, chunksize=a.chunk, quantize=False)
+            ln.model = ln.model.half().to(dev)
+        ln.enc_stream, ln.dec_stream = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+        ln.tickets = [None, None]
+        ln.count = 0
+        lanes.append(ln)
+
+    def encode(ln):
+        with torch.cuda.stream(ln.enc_stream):
+            sc = ln.model(signal)
             ev = torch.cuda.Event()
-            ev.record(enc_stream)
+            ev.record(ln.enc_stream)
         return sc, ev
 
-    # probe output geometry, build two decode contexts (double buffered pinned outputs)
-    sc0, ev0 = encode()
-    ev0.synchronize()
-    T_out, C_out = sc0.shape[1], sc0.shape[2]
-    decs = [decode.CRFDecoder(a.batch, T_out, C_out, dev, mode=a.decoder) for _ in range(2)]
-    del sc0
+    # probe output geometry, build two decode contexts per lane (double buffered pinned outputs)
+    for ln in lanes:
+        sc0, ev0 = encode(ln)
+        ev0.synchronize()
+        T_out, C_out = sc0.shape[1], sc0.shape[2]
+        ln.decs = [decode.CRFDecoder(a.batch, T_out, C_out, dev, mode=a.decoder) for _ in range(2)]
+        del sc0
+    decs = lanes[0].decs
 
     def run(steps):
-        """`steps` passes of the hot path, software-pipelined over two HIP streams: encoder(i+1) overlaps
-        decode(i). Every step's int8 outputs are on the host when this returns."""
-        tickets = [None, None]
+        """`steps` passes of the hot path over one batch each, software-pipelined: inside a lane encoder(i+1) overlaps
+        decode(i) on two HIP streams, and the lanes run round-robin. Every step's int8 outputs are on the host when this
+        returns."""
+        for ln in lanes:
+            ln.tickets = [None, None]
+            ln.count = 0
         for i in range(steps):
-            sc, ev = encode()
-            if tickets[i & 1] is not None:
-                tickets[i & 1].result()            # its pinned buffers are about to be reused
-            with torch.cuda.stream(dec_stream):
-                dec_stream.wait_event(ev)
-                sc.record_stream(dec_stream)
-                tickets[i & 1] = decs[i & 1].submit(sc)
+            ln = lanes[i % len(lanes)]
+            sc, ev = encode(ln)
+            k = ln.count & 1
+            if ln.tickets[k] is not None:
+                ln.tickets[k].result()             # its pinned buffers are about to be reused
+            with torch.cuda.stream(ln.dec_stream):
+                ln.dec_stream.wait_event(ev)
+                sc.record_stream(ln.dec_stream)
+                ln.tickets[k] = ln.decs[k].submit(sc)
+            ln.count += 1
         out = None
-        for tk in tickets:
-            if tk is not None:
-                out = tk.result()
+        for ln in lanes:
+            for tk in ln.tickets:
+                if tk is not None:
+                    out = tk.result()
         return out
 
     def barrier():
@@ -180,7 +210,8 @@ def main():
 
     log("warmup")
     run(a.warmup)
-    model._hip.check()
+    for ln in lanes:
+        ln.model._hip.check()
     barrier()
     log("timed region")
     t0 = time.perf_counter()
@@ -188,7 +219,8 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     elapsed = parallel.max_over_ranks(elapsed, device=dev)
-    model._hip.check()
+    for ln in lanes:
+        ln.model._hip.check()
     log("timed region done: %.1f ms/step" % (1e3 * elapsed / a.steps))
 
     # ---- roofline leg: per-kernel-class HIP-event timings on the engine's stream (after the timed region)
@@ -250,8 +282,8 @@ def main():
             "dtype": "f16",
             "data": "synthetic",
             "config": {"workload": "dna_r10.4.1_e8.2_400bps_%s@v5.0.0-shaped model (seeded random weights), "
-                                   "batch %d x chunk %d, %s decode, encoder/decoder software-pipelined on 2 HIP streams, 1 replica per GPU" %
-                                   (a.model, a.batch, a.chunk, a.decoder),
+                                   "batch %d x chunk %d, %s decode, encoder/decoder software-pipelined on 2 HIP streams x %d batch lane(s) per GPU" %
+                                   (a.model, a.batch, a.chunk, a.decoder, a.lanes),
                        "parallelism": "replicas x%d (shard-by-read, no collective)" % world},
             "per_gpu": samples / elapsed / world,
             "roofline": roof,
