@@ -369,7 +369,10 @@ __global__ __launch_bounds__(256, 4) void gemm_glds_kernel(GemmArgs p) {
 // Measured on the transformer shapes (M = 256000): +10..22 % over v2 (e.g. fc2 K=2048: 774 -> 946 TFLOP/s, gated fc1:
 // 734 -> 864). A 256 x 128 tile with two workgroups per CU landed in between (~750 everywhere). A three-buffer BK=32 pipeline with counted vmcnt waits (two stages in flight) was tried and dropped:
 // hipcc drains the vm counter in front of every ds_read it can see while an LDS-DMA is outstanding, and hiding the
-// reads in inline asm pushed the kernel over the register budget (spill reloads drain the counter as well).
+// reads in inline asm pushed the persistent kernel over the register budget. A non-persistent four-buffer version (prefetch
+// distance 3, builtin s_waitcnt, asm fragment reads, no spurious waits left) was measured too: 631-991 TFLOP/s on the same
+// shapes, no better than this kernel -- the DMA latency is not what bounds it; with a barrier per stage both waves of a SIMD
+// read LDS at the same time and issue MFMAs at the same time (the fix is a phase-staggered schedule, not more buffers).
 constexpr int BF3 = 256, BT3 = 256, BK3 = 64;
 constexpr int TILE3 = 256 * BK3 * 2;    // 32 KiB per operand tile
 
