@@ -15,6 +15,27 @@ from bonito_amd import _lib
 from bonito_amd.reader import __default_norm_params__
 
 
+def chunk_table(lengths, trims, chunksize, overlap):
+    """Chunk origins of `util.chunk` (bonito/util.py:142-161) for reads of `lengths` samples whose first `trims` samples are
+    cut: arrays (read index, first sample, samples available). A read shorter than the chunk yields one row with
+    available < chunksize (the kernel tiles it); otherwise windows advance by chunksize - overlap from offset `stub`, with
+    an extra first chunk at 0 when stub > 0. Reads with nothing left after the trim yield no rows."""
+    reads, starts, avail = [], [], []
+    for r, (n, t0) in enumerate(zip(lengths, trims)):
+        t0 = int(t0)
+        T = int(n) - t0
+        if T <= 0:
+            continue
+        if T < chunksize:
+            reads.append(r); starts.append(t0); avail.append(T)
+            continue
+        step = chunksize - overlap
+        stub = (T - overlap) % step
+        for s in ([t0] if stub > 0 else []) + list(range(t0 + stub, t0 + T - chunksize + 1, step)):
+            reads.append(r); starts.append(s); avail.append(chunksize)
+    return (np.asarray(reads, dtype=np.int32), np.asarray(starts, dtype=np.int64), np.asarray(avail, dtype=np.int64))
+
+
 class RawBatch:
     """Raw reads resident on the device: concatenated int16 samples + per-read calibration."""
 
@@ -64,22 +85,7 @@ class RawBatch:
     def chunk_table(self, chunksize, overlap, trims=None):
         """(read, start, available) per chunk in util.chunk order (stub chunk first, short reads tiled), host side."""
         trims = self.trim.cpu().numpy() if trims is None else np.asarray(trims)
-        reads, starts, avail = [], [], []
-        for r in range(self.R):
-            t0 = int(trims[r])
-            T = int(self.lengths[r]) - t0
-            if T <= 0:
-                continue
-            if T < chunksize:
-                reads.append(r); starts.append(t0); avail.append(T)
-                continue
-            step = chunksize - overlap
-            stub = (T - overlap) % step
-            first = [t0] if stub > 0 else []
-            rest = list(range(t0 + stub, t0 + T - chunksize + 1, step))
-            for s in first + rest:
-                reads.append(r); starts.append(s); avail.append(chunksize)
-        return (np.asarray(reads, dtype=np.int32), np.asarray(starts, dtype=np.int64), np.asarray(avail, dtype=np.int64))
+        return chunk_table(self.lengths, trims, chunksize, overlap)
 
     def chunks(self, table, chunksize, lo=0, hi=None):
         """fp16 [n, 1, chunksize] device tensor of table rows lo:hi (call `normalise` first)."""

@@ -167,3 +167,29 @@ def test_stitch_planes_equals_stitch_results(reverse):
         got = stitch_planes(planes, length, cs, ov, stride, reverse=reverse)
         for i, k in enumerate(("sequence", "qstring", "moves")):
             assert torch.equal(got[i], want[k]), (length, k)
+
+
+def test_signal_chunk_table_equals_util_chunk():
+    """Host half of the device ingest: chunk origins must be util.chunk's (checked on an index ramp as the signal)."""
+    import torch
+    from bonito_amd.signal import chunk_table
+    from bonito_amd.util import chunk
+    lengths = [12000, 4000, 3999, 700, 8001, 4500, 10]
+    trims = [250, 0, 10, 10, 1, 500, 10]
+    for cs, ov in ((4000, 500), (996, 498), (1000, 0)):
+        reads, starts, avail = chunk_table(lengths, trims, cs, ov)
+        row = 0
+        for r, (n, t0) in enumerate(zip(lengths, trims)):
+            sig = torch.arange(t0, n, dtype=torch.float32)
+            if len(sig) == 0:
+                continue
+            want = chunk(sig, cs, ov)[:, 0]
+            for w in want:
+                assert reads[row] == r
+                if avail[row] >= cs:
+                    assert starts[row] == int(w[0]) and int(w[-1]) == starts[row] + cs - 1
+                else:                       # tiled short read
+                    assert starts[row] == t0 and avail[row] == n - t0
+                    assert torch.equal(w, torch.arange(cs, dtype=torch.float32) % avail[row] + t0)
+                row += 1
+        assert row == len(reads)
