@@ -777,6 +777,7 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_wg_kernel(LstmFusedArgs fp)
         half_t ho[MT];
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
+            // (timing experiment: replacing lstm_cell by a clamp saves 645 cycles per step = 13 % of the kernel)
             const float hv = lstm_cell(acc[m][0], acc[m][1], acc[m][2], acc[m][3], cst[m]);
             ho[m] = (half_t)hv;
         }
