@@ -21,6 +21,10 @@ import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
+# HIP maps streams onto 4 hardware queues by default; with several batch lanes (2 streams each, plus the copy / helper
+# streams) streams would share queues and serialise (fast model, 3 lanes: 9.1 ms/step with 4 queues, 4.5 with 8). Must
+# be set before the HIP runtime initialises.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 sys.path.insert(0, ROOT)
 
 import torch  # noqa: E402
@@ -40,13 +44,13 @@ def parse():
     ap.add_argument("--decoder", default="beam", choices=["viterbi", "beam"])
     ap.add_argument("--lanes", type=int, default=0,
                     help="independent batches in flight (each lane: own engine replica, encoder stream, decoder stream); "
-                         "default 1; 2 for the narrow `fast` model whose kernels leave most CUs idle (measured 8.96 -> 8.07 ms/step; "
-                         "3+ lanes lose again: more streams than hardware queues)")
+                         "default 1; 3 for the narrow `fast` model whose kernels leave most CUs idle (1 lane 8.9 ms/step, "
+                         "3 lanes 4.5 with GPU_MAX_HW_QUEUES=8); hac / sup kernels fill the chip and gain nothing")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     a = ap.parse_args()
     a.batch = a.batch or (256 if a.model in ("sup", "sup_lstm") else 512)
     a.chunk = a.chunk or (12000 if a.model == "sup" else 20000 if a.model == "sup_lstm" else 10000)
-    a.lanes = a.lanes or (2 if a.model == "fast" else 1)
+    a.lanes = a.lanes or (3 if a.model == "fast" else 1)
     return a
 
 
