@@ -218,3 +218,42 @@ def test_cli_device_ingest_equals_host_ingest(tmp_path, capsys):
         outs.append((tmp_path / "summary.tsv").read_text())
     assert outs[0] == outs[2] and len(outs[0].strip().split("\n")) == 16
     assert outs[1] == outs[3]
+
+
+def test_full_size_pipelined_steps_equal_serial_execution():
+    """BASELINE size (hac, 512 x 10000, beam decode): the two-stream software pipeline of bench.py / basecall (encoder of batch
+    i+1 next to the decode of batch i, persistent LSTM workgroups sharing CUs with the decode kernels) must produce exactly
+    the bytes of a serial run, step after step, and the exchange must never time out under that contention."""
+    from bonito_amd import decode, synthetic
+    dev = torch.device("cuda", 0)
+    model = synthetic.make_model("hac", batchsize=512, chunksize=10000)
+    model.use_koi(batchsize=512, chunksize=10000, quantize=False)
+    model = model.half().to(dev)
+    gen = torch.Generator(device=dev).manual_seed(3)
+    signals = [torch.randn(512, 1, 10000, generator=gen, device=dev).half() for _ in range(2)]
+    serial = []
+    for sig in signals:
+        sc = model(sig)
+        serial.append(torch.stack(decode.beam_search(sc)))
+    model._hip.check()
+    enc_stream, dec_stream = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+    decs = [decode.CRFDecoder(512, 1667, 1024, dev, mode="beam") for _ in range(2)]
+    tickets, outs = [None, None], []
+    for i in range(6):
+        with torch.cuda.stream(enc_stream):
+            sc = model(signals[i & 1])
+            ev = torch.cuda.Event()
+            ev.record(enc_stream)
+        if tickets[i & 1] is not None:
+            outs.append(tickets[i & 1].result_planes())
+        with torch.cuda.stream(dec_stream):
+            dec_stream.wait_event(ev)
+            sc.record_stream(dec_stream)
+            tickets[i & 1] = decs[i & 1].submit(sc)
+    for k in (0, 1):                       # steps 4 and 5, in order
+        outs.append(tickets[k].result_planes())
+    torch.cuda.synchronize()
+    model._hip.check()
+    assert len(outs) == 6
+    for i, got in enumerate(outs):
+        assert torch.equal(got, serial[i & 1]), "pipelined step %d differs from the serial run" % i
