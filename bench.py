@@ -22,9 +22,23 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 # HIP maps streams onto 4 hardware queues by default; with several batch lanes (2 streams each, plus the copy / helper
-# streams) streams would share queues and serialise (fast model, 3 lanes: 9.1 ms/step with 4 queues, 4.5 with 8). Must
-# be set before the HIP runtime initialises.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# streams) streams would share queues and serialise (fast model, 3 lanes: 9.1 ms/step with 4 queues, 4.5 with 8). With one
+# lane the default is marginally better (hac: 25.5 vs 25.8 ms/step), so only multi-lane runs ask for more. Has to be in
+# the environment before the HIP runtime is loaded, hence the look at argv ahead of `import torch`.
+def _multi_lane(argv):
+    lanes = None
+    for i, tok in enumerate(argv):
+        if tok == "--lanes" and i + 1 < len(argv):
+            lanes = argv[i + 1]
+        elif tok.startswith("--lanes="):
+            lanes = tok.split("=", 1)[1]
+    if lanes is not None:
+        return lanes.isdigit() and int(lanes) > 1
+    return any(tok == "fast" or tok == "--model=fast" for tok in argv)       # the fast model defaults to 3 lanes
+
+
+if _multi_lane(sys.argv[1:]):
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 sys.path.insert(0, ROOT)
 
 import torch  # noqa: E402
