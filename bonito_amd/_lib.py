@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libbonito_hip.so")
+LIB_PATH = os.environ.get("BONITO_HIP_LIB") or os.path.join(_HERE, "libbonito_hip.so")     # override: A/B builds
 
 
 class HipEngineError(RuntimeError):
