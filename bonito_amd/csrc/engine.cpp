@@ -168,7 +168,13 @@ struct bh_encoder {
     int max_batch = 0, max_chunk = 0;
     int n_cus = 0;
     std::vector<Layer> layers;
-    DevBuf act[2], gates, sig, err, lstm_ws;
+    DevBuf act[3], gates, sig, err, lstm_ws;
+    int n_act = 2;               // activation buffers in rotation: 3 when recurrent layers pre-fill their exchange sentinel
+    // sentinel pre-fill of the NEXT recurrent layer's output buffer, on a side stream under the current layer's kernel
+    hipStream_t fill_stream = nullptr;
+    hipEvent_t fill_ready = nullptr, fill_done = nullptr;
+    void* prefilled = nullptr;
+    int lstm_prefill = 1;
     DevBuf res;                            // pending residual projection of a QuartzNet block
     DevBuf t_qkv, t_mid, t_a, t_b, rot;   // transformer workspace + rotary cos/sin table [Tmax][32][2]
     int rot_len = 0;
@@ -186,11 +192,14 @@ struct bh_encoder {
     std::vector<Span> spans;
     ~bh_encoder() {
         for (auto& s : spans) { (void)hipEventDestroy(s.a); (void)hipEventDestroy(s.b); }
+        if (fill_ready) (void)hipEventDestroy(fill_ready);
+        if (fill_done) (void)hipEventDestroy(fill_done);
+        if (fill_stream) (void)hipStreamDestroy(fill_stream);
         for (auto& l : layers) {
             l.w0.release(); l.w1.release(); l.w2.release(); l.w3.release();
             l.w4.release(); l.w5.release(); l.b0.release(); l.b1.release();
         }
-        act[0].release(); act[1].release(); gates.release(); sig.release(); err.release(); lstm_ws.release();
+        act[0].release(); act[1].release(); act[2].release(); gates.release(); sig.release(); err.release(); lstm_ws.release();
         res.release(); t_qkv.release(); t_mid.release(); t_a.release(); t_b.release(); rot.release();
     }
 };
@@ -508,6 +517,24 @@ extern "C" int bh_encoder_create(const bh_layer_t* layers, int n_layers, int dev
     bool has_res = false;
     for (const auto& l : e->layers) has_res |= l.d.kind == BH_LAYER_RESIDUAL_PROJ;
     if (has_res && e->res.alloc(ab + 256)) return fail(-1);
+    {   // two consecutive recurrent layers that exchange through sentinel-filled output: rotate three buffers so the
+        // next layer's sentinel fill can run beside the current layer's kernel
+        int prev_kind = 0;
+        for (const auto& l : e->layers) {
+            if (l.d.kind == BH_LAYER_CLAMP) continue;
+            if (l.d.kind == BH_LAYER_LSTM && prev_kind == BH_LAYER_LSTM) e->n_act = 3;
+            prev_kind = l.d.kind;
+        }
+        if (e->n_act == 3) {
+            if (e->act[2].alloc(ab + 256) || hipMemset(e->act[2].p, 0, e->act[2].bytes) != hipSuccess ||
+                hipStreamCreateWithFlags(&e->fill_stream, hipStreamNonBlocking) != hipSuccess ||
+                hipEventCreateWithFlags(&e->fill_ready, hipEventDisableTiming) != hipSuccess ||
+                hipEventCreateWithFlags(&e->fill_done, hipEventDisableTiming) != hipSuccess) {
+                bh_set_error("encoder_create: sentinel pre-fill resources");
+                return fail(-1);
+            }
+        }
+    }
     if (e->act[0].alloc(ab + 256) || e->act[1].alloc(ab + 256) || e->gates.alloc(gb + 256) ||
         e->sig.alloc((size_t)Np * max_chunk * 2) || e->err.alloc(sizeof(int)) || e->lstm_ws.alloc(bh_k_lstm_ws_bytes(Np, 1024)))
         return fail(-1);
@@ -572,6 +599,21 @@ extern "C" int bh_encoder_output_shape(const bh_encoder_t* enc, int L, int* T, i
     return 0;
 }
 
+namespace {
+// which recurrence kernel serves a layer (see lstm.hip)
+struct LstmPath { bool reg_path, wide, fused, wg, cta; };
+static LstmPath lstm_path(const bh_encoder* e, const Layer& l) {
+    const int H = l.d.out_size;
+    LstmPath p;
+    p.reg_path = H <= 512 && H % 32 == 0;
+    p.wide = !p.reg_path && e->lstm_wide && bh_k_lstm_wide_ok(H) && l.w3.p != nullptr && l.w4.p != nullptr;
+    p.fused = p.reg_path && e->lstm_fused && l.d.in_size == H && l.w2.p != nullptr;
+    p.wg = p.fused && e->lstm_fused >= 2 && l.w3.p != nullptr && l.w4.p != nullptr;
+    p.cta = p.wg && e->lstm_fused >= 3 && bh_k_lstm_cta_units(H) != 0 && bh_k_lstm_cta_units(H) == bh_k_lstm_wg_units(H);
+    return p;
+}
+}  // namespace
+
 extern "C" int bh_encoder_forward(bh_encoder_t* e, const void* signal, int N, int L, void* scores, void* stream_) {
     BH_REQUIRE(e && signal && scores, "encoder_forward: null argument");
     BH_REQUIRE(N > 0 && N <= e->max_batch, "encoder_forward: batch %d outside 1..%d", N, e->max_batch);
@@ -590,6 +632,7 @@ extern "C" int bh_encoder_forward(bh_encoder_t* e, const void* signal, int N, in
     if (Np != N) BH_CHECK_HIP(hipMemsetAsync((char*)e->sig.p + (size_t)N * L * 2, 0, (size_t)(Np - N) * L * 2, st));
     BH_CHECK_HIP(hipMemcpyAsync(e->sig.p, signal, (size_t)N * L * 2, hipMemcpyDeviceToDevice, st));
 
+    e->prefilled = nullptr;
     const void* cur = e->sig.p;
     Layout lay = L_SIGNAL;
     int len = L, C = 1, which = 0;
@@ -629,7 +672,7 @@ extern "C" int bh_encoder_forward(bh_encoder_t* e, const void* signal, int N, in
                     rc = bh_k_conv_igemm(cur, l.w0.p, (const float*)l.b0.p, dst, Np, len, lout, l.cin_eff,
                                          co, d.winlen, d.stride, d.padding, d.activation, lo, hi, os_n, os_t, st);
                 if (rc) return rc;
-                cur = dst; which ^= 1; len = lout; C = d.out_size; lay = tnc ? L_TNC : L_NLC;
+                cur = dst; which = (which + 1) % e->n_act; len = lout; C = d.out_size; lay = tnc ? L_TNC : L_NLC;
                 break;
             }
             case BH_LAYER_LSTM: {
@@ -639,11 +682,8 @@ extern "C" int bh_encoder_forward(bh_encoder_t* e, const void* signal, int N, in
                 const int M = len * Np;
                 int rc;
                 void* dst = e->act[which].p;
-                const bool reg_path = H <= 512 && H % 32 == 0;
-                const bool wide = !reg_path && e->lstm_wide && bh_k_lstm_wide_ok(H) && l.w3.p != nullptr && l.w4.p != nullptr;
-                const bool fused = reg_path && e->lstm_fused && d.in_size == H && l.w2.p != nullptr;
-                const bool wg = fused && e->lstm_fused >= 2 && l.w3.p != nullptr && l.w4.p != nullptr;
-                const bool cta = wg && e->lstm_fused >= 3 && bh_k_lstm_cta_units(H) != 0 && bh_k_lstm_cta_units(H) == bh_k_lstm_wg_units(H);
+                const LstmPath lp = lstm_path(e, l);
+                const bool reg_path = lp.reg_path, wide = lp.wide, fused = lp.fused, wg = lp.wg, cta = lp.cta;
                 if (!fused) {
                     ProfSpan span(e, st, BH_PROF_LSTM_GEMM);
                     rc = bh_k_linear(cur, wide ? l.w4.p : l.w0.p, (const float*)(wide ? l.b1.p : l.b0.p), e->gates.p, M, 4 * H,
@@ -651,9 +691,30 @@ extern "C" int bh_encoder_forward(bh_encoder_t* e, const void* signal, int N, in
                     if (rc) return rc;
                 }
                 if (!cta) {      // exchange sentinel (the ring-in-a-workgroup kernel exchanges through LDS only)
-                    ProfSpan span(e, st, BH_PROF_FILL);
-                    rc = bh_k_fill_u16(dst, 0xFFFFu, (size_t)M * H, st);
-                    if (rc) return rc;
+                    if (e->prefilled == dst) {          // filled beside the previous layer's kernel
+                        BH_CHECK_HIP(hipStreamWaitEvent(st, e->fill_done, 0));
+                    } else {
+                        ProfSpan span(e, st, BH_PROF_FILL);
+                        rc = bh_k_fill_u16(dst, 0xFFFFu, (size_t)M * H, st);
+                        if (rc) return rc;
+                    }
+                }
+                e->prefilled = nullptr;
+                if (e->n_act == 3 && e->lstm_prefill && !e->profiling && next_kind == BH_LAYER_LSTM) {
+                    // The buffer after dst in the rotation was the previous layer's input: free once everything queued so
+                    // far has run. The next layer writes H_next features per (t, n) row into it.
+                    const Layer* nx = nullptr;
+                    for (size_t j = i + 1; j < nl && !nx; ++j)
+                        if (e->layers[j].d.kind == BH_LAYER_LSTM) nx = &e->layers[j];
+                    if (nx && !lstm_path(e, *nx).cta) {
+                        void* spare = e->act[(which + 1) % 3].p;
+                        BH_CHECK_HIP(hipEventRecord(e->fill_ready, st));
+                        BH_CHECK_HIP(hipStreamWaitEvent(e->fill_stream, e->fill_ready, 0));
+                        rc = bh_k_fill_u16(spare, 0xFFFFu, (size_t)M * nx->d.out_size, e->fill_stream);
+                        if (rc) return rc;
+                        BH_CHECK_HIP(hipEventRecord(e->fill_done, e->fill_stream));
+                        e->prefilled = spare;
+                    }
                 }
                 ProfSpan span(e, st, BH_PROF_LSTM_REC);
                 // co-residency: one launch serves at most (CUs / (8 * H/16)) * 32 rings
@@ -693,7 +754,7 @@ extern "C" int bh_encoder_forward(bh_encoder_t* e, const void* signal, int N, in
                                                     (int*)e->lstm_ws.p, e->lstm_force_slow);
                     if (rc) return rc;
                 }
-                cur = dst; which ^= 1; C = H;
+                cur = dst; which = (which + 1) % e->n_act; C = H;
                 break;
             }
             case BH_LAYER_LINEAR_CRF: {
@@ -752,7 +813,7 @@ extern "C" int bh_encoder_forward(bh_encoder_t* e, const void* signal, int N, in
                     if (!rc) rc = bh_k_rmsnorm_residual(e->t_b.p, e->t_a.p, (const float*)l.w5.p, dst, M, D, d.alpha, eps, st);
                     if (rc) return rc;
                 }
-                cur = dst; which ^= 1;
+                cur = dst; which = (which + 1) % e->n_act;
                 break;
             }
             case BH_LAYER_DWCONV: {
@@ -762,7 +823,7 @@ extern "C" int bh_encoder_forward(bh_encoder_t* e, const void* signal, int N, in
                 ProfSpan span(e, st, BH_PROF_CONV);
                 int rc = bh_k_dwconv(cur, (const float*)l.w0.p, dst, Np, len, lout, C, d.winlen, d.stride, d.padding, st);
                 if (rc) return rc;
-                cur = dst; which ^= 1; len = lout;
+                cur = dst; which = (which + 1) % e->n_act; len = lout;
                 break;
             }
             case BH_LAYER_RESIDUAL_PROJ: {
@@ -791,7 +852,7 @@ extern "C" int bh_encoder_forward(bh_encoder_t* e, const void* signal, int N, in
                 int rc = bh_k_linear(cur, l.w0.p, (const float*)l.b0.p, dst, N * len, sf * D, D, D, D, sf * D, bh::ACT_NONE,
                                      1.0f, -INFINITY, INFINITY, 0, 0, 0, 0, 0, st);
                 if (rc) return rc;
-                cur = dst; which ^= 1; len *= sf;     // [N][T][s*D] viewed as [N][s*T][D]
+                cur = dst; which = (which + 1) % e->n_act; len *= sf;     // [N][T][s*D] viewed as [N][s*T][D]
                 break;
             }
             default:
@@ -939,6 +1000,7 @@ extern "C" int bh_encoder_set_option(bh_encoder_t* e, const char* name, int valu
     if (!strcmp(name, "lstm_fused")) { e->lstm_fused = value; return 0; }
     if (!strcmp(name, "attn_ring")) { e->attn_ring = value; return 0; }
     if (!strcmp(name, "lstm_wide")) { e->lstm_wide = value; return 0; }
+    if (!strcmp(name, "lstm_prefill")) { e->lstm_prefill = value; return 0; }
     if (!strcmp(name, "gemm_v1")) { bh_k_linear_force_v1(value); return 0; }   // process-wide A/B switch
     if (!strcmp(name, "lstm_tune")) { e->lstm_force_slow = (e->lstm_force_slow & 1) | (value << 8); return 0; }
     BH_REQUIRE(false, "encoder_set_option: unknown option '%s'", name);

@@ -197,13 +197,15 @@ def test_workgroup_shared_lstm_kernel_widths(H, sl):
     with torch.no_grad():
         want = nn_ref.forward(model, x.float(), expand_blanks=False).permute(1, 0, 2)
     outs = {}
-    for fused in (3, 2, 1):
+    for fused in (3, 2, 1, -2):
         enc = HipEncoder(model, batchsize=21, chunksize=900)
-        enc.set_option("lstm_fused", fused)
+        enc.set_option("lstm_fused", abs(fused))
+        if fused < 0:
+            enc.set_option("lstm_prefill", 0)
         outs[fused] = enc(x.cuda()).cpu().float()
         enc.check()
         assert (outs[fused] - want).abs().max().item() < TOL_MAX, fused
-    assert torch.equal(outs[2], outs[1]) and torch.equal(outs[3], outs[1])
+    assert torch.equal(outs[2], outs[1]) and torch.equal(outs[3], outs[1]) and torch.equal(outs[-2], outs[2])
 
 
 @pytest.mark.parametrize("H,batch", [(768, 3), (1024, 37), (640, 33)])
@@ -242,14 +244,18 @@ def test_full_size_hac_encoder_kernel_variants_bit_identical():
     model = synthetic.make_model("hac", batchsize=512, chunksize=10000)
     x = torch.randn(512, 1, 10000, generator=torch.Generator().manual_seed(25)).half().cuda()
     outs = []
-    for fused, slow in ((3, 0), (1, 0), (3, 1)):
+    for fused, slow, prefill in ((3, 0, 1), (1, 0, 1), (3, 1, 1), (3, 0, 0)):
         enc = HipEncoder(model.encoder, batchsize=512, chunksize=10000)
         enc.set_option("lstm_fused", fused)
         enc.set_option("lstm_force_slow", slow)
-        outs.append(enc(x))
+        enc.set_option("lstm_prefill", prefill)     # 0: sentinel fill inline instead of beside the previous layer's kernel
+        for _ in range(2):                             # twice: the side-stream fill must also be ordered across calls
+            out = enc(x)
+        outs.append(out)
         enc.check()
         enc.close()
     assert outs[0].shape == (512, 1667, 1024)
     assert torch.isfinite(outs[0].float()).all()
     assert torch.equal(outs[0], outs[1])
     assert torch.equal(outs[0], outs[2])
+    assert torch.equal(outs[0], outs[3])

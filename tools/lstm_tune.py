@@ -9,15 +9,16 @@ model.use_koi(batchsize=512, chunksize=10000, quantize=False)
 model = model.half().cuda()
 sig = torch.randn(512, 1, 10000, device="cuda").half()
 ref = model(sig)
-for tune in (0, 1, 0):
-    model._hip.set_option("lstm_tune", tune)
+opt = os.environ.get("OPT", "lstm_tune")           # any encoder option taking 0 / 1, e.g. OPT=lstm_prefill
+for tune in [int(v) for v in os.environ.get("VALS", "0,1,0,1").split(",")]:
+    model._hip.set_option(opt, tune)
     for _ in range(2):
         out = model(sig)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(4):
+    for _ in range(8):
         out = model(sig)
     torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / 4
+    dt = (time.perf_counter() - t0) / 8
     model._hip.check()
-    print("tune=%d  encoder %.2f ms  identical=%s" % (tune, dt * 1e3, bool(torch.equal(out, ref))))
+    print(opt + "=%d  encoder %.2f ms  identical=%s" % (tune, dt * 1e3, bool(torch.equal(out, ref))))
