@@ -325,6 +325,8 @@ struct BeamArgs {
     uint8_t* bp;           // [N][T][32]  parent | move << 5 | base << 6
     int* final_slot;       // [N]
     long long* dbg;        // optional [N][8] per-section cycle counters (BH_BEAM_DEBUG)
+    float inv_bin;         // 64 / cut: selection histogram bins per unit of key
+    int select;            // 0 histogram selection, 1 radix search (bh_set_option("beam_select"))
 };
 
 constexpr int BTB = 8;     // steps staged per LDS block
@@ -416,7 +418,145 @@ __device__ __forceinline__ float wave_max_f32(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 
-constexpr int HT = 256;   // open-addressing table of stay elements keyed by sequence hash
+template <int CTRL>
+__device__ __forceinline__ int dpp_i0(int v) {       // DPP move; lanes whose source falls outside the row read 0
+    return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true);
+}
+// inclusive prefix sum over the 64 lanes: Hillis-Steele inside each row of 16 (row_shr), then the three row totals
+__device__ __forceinline__ int wave_scan_add(int v, int lane) {
+    v += dpp_i0<0x111>(v);     // row_shr:1
+    v += dpp_i0<0x112>(v);     // row_shr:2
+    v += dpp_i0<0x114>(v);     // row_shr:4
+    v += dpp_i0<0x118>(v);     // row_shr:8
+    const int t0 = __builtin_amdgcn_readlane(v, 15), t1 = __builtin_amdgcn_readlane(v, 31), t2 = __builtin_amdgcn_readlane(v, 47);
+    const int row = lane >> 4;
+    return v + (row >= 1 ? t0 : 0) + (row >= 2 ? t1 : 0) + (row >= 3 ? t2 : 0);
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ unsigned dpp_u(unsigned v) {
+    return (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, ROW_MASK, 0xF, false);
+}
+__device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
+    v = max(v, dpp_u<0xB1, 0xF>(v));
+    v = max(v, dpp_u<0x4E, 0xF>(v));
+    v = max(v, dpp_u<0x124, 0xF>(v));
+    v = max(v, dpp_u<0x128, 0xF>(v));
+    v = max(v, dpp_u<0x142, 0xA>(v));
+    v = max(v, dpp_u<0x143, 0xC>(v));
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+
+// Same contract as radix_select (the `want` largest keys, ties by ascending candidate index), for keys known to lie
+// in [thr, thr + 64 / inv_bin]: one 64-bin histogram pass (LDS atomics + a wave prefix sum) finds the bin that holds
+// the want-th key; the few candidates in that bin are ranked exactly by repeated wave maxima. A crowded boundary bin
+// (many equal or near-equal keys) falls back to the radix search on that bin alone.
+__device__ __forceinline__ int hist_select(const float (&key)[3], const unsigned (&uk)[3], int want, int lane, float thr,
+                                           float inv_bin, int* hist, bool (&sel)[3], int (&slot)[3], unsigned ulo, unsigned uhi) {
+    unsigned long long selm[3];
+    int n_alive = 0;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { selm[i] = __ballot(uk[i] != 0u); n_alive += popc64(selm[i]); }
+    if (n_alive > want) {
+        hist[lane] = 0;
+        int bin[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            bin[i] = min(63, (int)((key[i] - thr) * inv_bin));
+            if (uk[i] != 0u) atomicAdd(&hist[63 - bin[i]], 1);
+        }
+        __syncthreads();
+        const int h = hist[lane];                       // lane l holds bin 63 - l
+        const int pre = wave_scan_add(h, lane);         // candidates in bins >= 63 - l
+        const unsigned long long ge = __ballot(pre >= want);
+        const int ls = __ffsll((long long)ge) - 1;      // exists: pre[63] = n_alive > want
+        const int n_hi = ls > 0 ? __builtin_amdgcn_readlane(pre, ls - 1) : 0;
+        const int m = __builtin_amdgcn_readlane(h, ls);
+        const int need = want - n_hi;                   // 1 <= need <= m
+        const int bstar = 63 - ls;
+        bool hi[3], bnd[3], selb[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            hi[i] = uk[i] != 0u && bin[i] > bstar;
+            bnd[i] = uk[i] != 0u && bin[i] == bstar;
+            selb[i] = bnd[i];
+        }
+        if (m > need) {
+            if (m <= 8) {
+#pragma unroll
+                for (int i = 0; i < 3; ++i) selb[i] = false;
+                int taken = 0;
+                while (taken < need) {
+                    unsigned mine = 0u;
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) mine = max(mine, (bnd[i] && !selb[i]) ? uk[i] : 0u);
+                    const unsigned top = wave_max_u32(mine);
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) {
+                        const unsigned long long mm = __ballot(bnd[i] && !selb[i] && uk[i] == top);
+                        const int room = need - taken;
+                        const bool take = ((mm >> lane) & 1ull) && popc64(mm & lanemask_lt(lane)) < room;
+                        selb[i] = selb[i] || take;
+                        taken += min(popc64(mm), room);
+                    }
+                }
+            } else {
+                unsigned ukb[3];
+                int dummy[3];
+#pragma unroll
+                for (int i = 0; i < 3; ++i) ukb[i] = bnd[i] ? uk[i] : 0u;
+                radix_select(ukb, need, lane, selb, dummy, ulo, uhi);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 3; ++i) selm[i] = __ballot(hi[i] || selb[i]);
+    }
+    int before = 0;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        sel[i] = (selm[i] >> lane) & 1ull;
+        slot[i] = before + popc64(selm[i] & lanemask_lt(lane));
+        before += popc64(selm[i]);
+    }
+    return before;
+}
+
+// Stay elements keyed by sequence hash: NBK buckets of 4 (hash, state << 5 | slot) entries, filled with one LDS atomic per
+// element as the beam is written; a move candidate reads its whole bucket with two 16-byte loads and compares in
+// registers - one LDS round trip and no divergent probe loop. A fifth element in a bucket (rare) goes to an overflow
+// list that every lookup then scans. Ties between equal (hash, state) stays resolve to the lowest slot, like the
+// oracle's first-match scan.
+constexpr int NBK = 128;
+
+struct BeamTable {
+    int* cnt;          // [NBK] elements hashed to the bucket (may exceed 4)
+    uint2_t* ent;      // [NBK][4]
+    int* ov_cnt;       // [1] (+3 pad)
+    uint2_t* ov;       // [MAXW]
+};
+__device__ __forceinline__ void table_insert(const BeamTable& tb, bool on, unsigned hash, int state, int slot) {
+    int pos = 0;
+    const int b = (int)(hash & (NBK - 1));
+    if (on) pos = atomicAdd(&tb.cnt[b], 1);
+    if (on) {
+        const uint2_t e{hash, ((unsigned)state << 5) | (unsigned)slot};
+        if (pos < 4) tb.ent[b * 4 + pos] = e;
+        else tb.ov[atomicAdd(tb.ov_cnt, 1)] = e;
+    }
+}
+
+// lse2_tab without control flow (same arithmetic): safe for garbage `b` as long as the result is discarded
+__device__ __forceinline__ float lse2_tab_nb(float a, float b, const float* tab) {
+    const float m = fmaxf(a, b);
+    const float d = fabsf(a - b);
+    const bool plain = !(d < BH_LSE_RANGE) || m == -INFINITY;
+    const float x = d * BH_LSE_SCALE;
+    int i = plain ? 0 : (int)x;
+    i = min(max(i, 0), BH_LSE_TABLE_SIZE - 2);
+    const float f = x - (float)i;
+    const float t0 = tab[i];
+    const float sp = __fmaf_rn(f, tab[i + 1] - t0, t0);
+    return plain ? m : m + sp;
+}
 
 __global__ __launch_bounds__(64) void beam_kernel(BeamArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -427,24 +567,33 @@ __global__ __launch_bounds__(64) void beam_kernel(BeamArgs p) {
     float* tab = (float*)smem;                           // lse table
     half_t* st_sc = (half_t*)(tab + BH_LSE_TABLE_SIZE + 2);   // [BTB][4S]
     float* st_b = (float*)(st_sc + BTB * 4 * S);         // [BTB][S]
-    int* b_state = (int*)(st_b + BTB * S);               // [32]
+    BeamTable tb;
+    tb.ent = (uint2_t*)(st_b + BTB * S);                 // [NBK][4], 16-byte aligned
+    tb.ov = tb.ent + NBK * 4;                            // [32]
+    tb.cnt = (int*)(tb.ov + MAXW);                       // [NBK]
+    tb.ov_cnt = tb.cnt + NBK;                            // [4]
+    int* hist = tb.ov_cnt + 4;                           // [64] selection histogram
+    int* b_state = hist + 64;                            // [32]
     unsigned* b_hash = (unsigned*)(b_state + MAXW);      // [32]
     float* b_score = (float*)(b_hash + MAXW);            // [32]
     float* m_score = b_score + MAXW;                     // [32] merged-in move score
     int* m_info = (int*)(m_score + MAXW);                // [32] merged-in move info or -1
-    int* htab = m_info + MAXW;                           // [HT]
-    uint8_t* st_bp = (uint8_t*)(htab + HT);              // [BTB][32]
+    uint8_t* st_bp = (uint8_t*)(m_info + MAXW);          // [BTB][32]
     for (int i = lane; i < BH_LSE_TABLE_SIZE; i += 64) tab[i] = g_lse_tab[i];
 
     const half_t* sc = p.scores + (long)n * T * 4 * S;
     const float* bn = p.beta + (long)n * (T + 1) * S;
     uint8_t* bpn = p.bp + (long)n * T * MAXW;
 
-    long long dsec[5] = {0, 0, 0, 0, 0};
+    long long dsec[6] = {0, 0, 0, 0, 0, 0};
     // candidate decomposition is time-invariant: c = lane + 64*i = e*5 + j
-    int ce[3], cj[3];
+    int ce[3], cj[3], cer[3];
 #pragma unroll
-    for (int i = 0; i < 3; ++i) { const int c = lane + 64 * i; ce[i] = c / 5; cj[i] = c - ce[i] * 5; }
+    for (int i = 0; i < 3; ++i) {
+        const int c = lane + 64 * i;
+        ce[i] = c / 5; cj[i] = c - ce[i] * 5;
+        cer[i] = ce[i] < MAXW ? ce[i] : 0;             // in-range element index for unconditional reads
+    }
 
     // ---- init: top-W states by beta~_0 (ties: lower state), slots in state order ------------------
     int nb;
@@ -489,108 +638,122 @@ __global__ __launch_bounds__(64) void beam_kernel(BeamArgs p) {
         nb = before;
     }
 #pragma unroll
-    for (int i = 0; i < HT / 64; ++i) htab[lane + 64 * i] = -1;
+    for (int i = 0; i < NBK / 64; ++i) tb.cnt[lane + 64 * i] = 0;
+    if (lane < 4) tb.ov_cnt[lane] = 0;
     if (lane < MAXW) m_info[lane] = -1;
     __syncthreads();
-    if (lane < nb) {
-        int hs = (int)(b_hash[lane] & (HT - 1));
-        while (atomicCAS(&htab[hs], -1, lane) != -1) hs = (hs + 1) & (HT - 1);
-    }
+    table_insert(tb, lane < nb, lane < nb ? b_hash[lane] : 0u, lane < nb ? b_state[lane] : 0, lane);
     __syncthreads();
 
-    for (int tb = 0; tb < T; tb += BTB) {
-        const int nsteps = min(BTB, T - tb);
-        // ---- stage score rows tb..tb+nsteps-1 and guide rows tb+1..tb+nsteps ------------------------
-        {
-            const int halves = nsteps * 4 * S;     // multiple of 16
-            const uint4_t* src = (const uint4_t*)(sc + (long)tb * 4 * S);
-            uint4_t* dst = (uint4_t*)st_sc;
-            for (int i = lane; i < halves / 8; i += 64) dst[i] = src[i];
-            const int floats = nsteps * S;          // multiple of 4
-            const uint4_t* bs = (const uint4_t*)(bn + (long)(tb + 1) * S);
-            uint4_t* bd = (uint4_t*)st_b;
-            for (int i = lane; i < floats / 4; i += 64) bd[i] = bs[i];
+    for (int tb0 = 0; tb0 < T; tb0 += BTB) {
+        const int nsteps = min(BTB, T - tb0);
+        // ---- stage score rows tb0..tb0+nsteps-1 and guide rows tb0+1..tb0+nsteps --------------------
+        {   // global -> LDS DMA, 1 KiB per instruction, all of them in flight before the single wait (a register round trip
+            // per 1 KiB serialises on the memory latency: there is only this one wave to hide it)
+            long long ts0 = 0;
+            if (p.dbg) ts0 = __builtin_readcyclecounter();
+            const int n_sc = nsteps * S / 2;        // 16-byte units of score rows (4S halves per step)
+            const char* src = (const char*)(sc + (long)tb0 * 4 * S);
+            for (int i0 = 0; i0 < n_sc; i0 += 64)
+                if (i0 + lane < n_sc)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (long)(i0 + lane) * 16),
+                                                     (__attribute__((address_space(3))) void*)((char*)st_sc + i0 * 16), 16, 0, 0);
+            const int n_b = nsteps * S / 4;         // 16-byte units of guide rows (S floats per step)
+            const char* bs = (const char*)(bn + (long)(tb0 + 1) * S);
+            for (int i0 = 0; i0 < n_b; i0 += 64)
+                if (i0 + lane < n_b)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(bs + (long)(i0 + lane) * 16),
+                                                     (__attribute__((address_space(3))) void*)((char*)st_b + i0 * 16), 16, 0, 0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (p.dbg) dsec[5] += __builtin_readcyclecounter() - ts0;
         }
         __syncthreads();
         for (int u = 0; u < nsteps; ++u) {
             const half_t* row = st_sc + u * 4 * S;
             const float* b1 = st_b + u * S;
-            // (the hash table of the current beam was built when the beam was written)
             long long tc0 = 0;
             if (p.dbg) tc0 = __builtin_readcyclecounter();
             // ---- (b) candidates; a move that spells the same sequence as a stay is folded into it ---
+            // Every LDS level is issued for all three candidates before it is consumed, and nothing is conditional on
+            // loaded data: level 1 = parent element, level 2 = transition score + guide + hash bucket.
             float cs[3];
             unsigned ch[3];
-            int cst[3], cinfo[3], pslot[3], d0[3];
-            bool alive[3];
-            // branch-free generation: every LDS level is issued for all three candidates before it is consumed
+            int cst[3], cinfo[3];
+            bool alive[3], mover[3];
             int es[3];
             unsigned eh[3];
             float esc[3];
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
                 alive[i] = ce[i] < nb;
-                const int e = alive[i] ? ce[i] : 0;
-                es[i] = b_state[e];
-                eh[i] = b_hash[e];
-                esc[i] = b_score[e];
+                es[i] = b_state[cer[i]];
+                eh[i] = b_hash[cer[i]];
+                esc[i] = b_score[cer[i]];
             }
-            float mv[3];
+            float mv[3], bg[3];
+            int bcnt[3];
+            uint4_t ent0[3], ent1[3];
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
                 const int x = cj[i] > 0 ? cj[i] - 1 : 0;
                 const int s2 = ((es[i] << 2) | x) & (S - 1);
                 cst[i] = cj[i] == 0 ? es[i] : s2;
-                mv[i] = (float)row[s2 * 4 + (es[i] >> sh)];
                 ch[i] = cj[i] == 0 ? eh[i] : bs_mix(eh[i], x);
                 cinfo[i] = cj[i] == 0 ? ce[i] : (ce[i] | (1 << 5) | (x << 6));
-                pslot[i] = (int)(ch[i] & (HT - 1));
-                d0[i] = -1;
+                mover[i] = alive[i] && cj[i] != 0;
+                const int bk = (int)(ch[i] & (NBK - 1));
+                mv[i] = (float)row[s2 * 4 + (es[i] >> sh)];
+                bg[i] = b1[cst[i]];
+                bcnt[i] = tb.cnt[bk];
+                ent0[i] = *(const uint4_t*)(tb.ent + bk * 4);
+                ent1[i] = *(const uint4_t*)(tb.ent + bk * 4 + 2);
             }
+            const int n_ov = tb.ov_cnt[0];
+            int dhit[3];
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
                 cs[i] = esc[i] + (cj[i] == 0 ? p.blank : mv[i]);
                 if (!alive[i]) { cs[i] = -INFINITY; ch[i] = 0u; cst[i] = 0; cinfo[i] = 0; }
+                const unsigned want_hi = (unsigned)cst[i];
+                int d = MAXW;
+                if (bcnt[i] > 0 && ent0[i].x == ch[i] && (ent0[i].y >> 5) == want_hi) d = min(d, (int)(ent0[i].y & 31u));
+                if (bcnt[i] > 1 && ent0[i].z == ch[i] && (ent0[i].w >> 5) == want_hi) d = min(d, (int)(ent0[i].w & 31u));
+                if (bcnt[i] > 2 && ent1[i].x == ch[i] && (ent1[i].y >> 5) == want_hi) d = min(d, (int)(ent1[i].y & 31u));
+                if (bcnt[i] > 3 && ent1[i].z == ch[i] && (ent1[i].w >> 5) == want_hi) d = min(d, (int)(ent1[i].w & 31u));
+                dhit[i] = d;
             }
-            // probes: level 1 (table slot) and level 2 (hash/state of the occupant) are issued for all three
-            // candidates before anything is compared -> two dependent LDS latencies instead of six
+            if (n_ov > 0) {                              // rare: some bucket held more than four elements
+                for (int k = 0; k < n_ov; ++k) {
+                    const uint2_t e = tb.ov[k];
 #pragma unroll
-            for (int i = 0; i < 3; ++i)
-                if (alive[i] && cj[i] != 0) d0[i] = htab[pslot[i]];
-            unsigned oh[3];
-            int os[3];
-#pragma unroll
-            for (int i = 0; i < 3; ++i) {
-                const int d = d0[i] < 0 ? 0 : d0[i];
-                oh[i] = b_hash[d];
-                os[i] = b_state[d];
-            }
-#pragma unroll
-            for (int i = 0; i < 3; ++i) {
-                if (d0[i] >= 0) {
-                    int d = d0[i], slot = pslot[i];
-                    bool hit = oh[i] == ch[i] && os[i] == cst[i];
-                    while (!hit) {                       // rare: another sequence occupies the slot
-                        slot = (slot + 1) & (HT - 1);
-                        d = htab[slot];
-                        if (d < 0) break;
-                        hit = b_hash[d] == ch[i] && b_state[d] == cst[i];
-                    }
-                    if (hit) {
-                        m_score[d] = cs[i];
-                        m_info[d] = cinfo[i];
-                        alive[i] = false;
-                    }
+                    for (int i = 0; i < 3; ++i)
+                        if (e.x == ch[i] && (e.y >> 5) == (unsigned)cst[i]) dhit[i] = min(dhit[i], (int)(e.y & 31u));
                 }
             }
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+                if (mover[i] && dhit[i] < MAXW) {
+                    m_score[dhit[i]] = cs[i];
+                    m_info[dhit[i]] = cinfo[i];
+                    alive[i] = false;
+                }
+            // the lookups of this step are done (one wave: LDS operations complete in issue order): reset the table
+#pragma unroll
+            for (int i = 0; i < NBK / 64; ++i) tb.cnt[lane + 64 * i] = 0;
+            if (lane < 4) tb.ov_cnt[lane] = 0;
             if (p.dbg) { const long long t1 = __builtin_readcyclecounter(); dsec[0] += t1 - tc0; tc0 = t1; }
             __syncthreads();
+            {
+                int mi[3];
+                float ms[3];
 #pragma unroll
-            for (int i = 0; i < 3; ++i) {
-                if (alive[i] && cj[i] == 0 && m_info[ce[i]] >= 0) {
-                    const float ms = m_score[ce[i]];
-                    if (ms > cs[i]) cinfo[i] = m_info[ce[i]];
-                    cs[i] = lse2_tab(cs[i], ms, tab);
+                for (int i = 0; i < 3; ++i) { mi[i] = m_info[cer[i]]; ms[i] = m_score[cer[i]]; }
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    const bool merged = alive[i] && cj[i] == 0 && mi[i] >= 0;
+                    const float lse = lse2_tab_nb(cs[i], ms[i], tab);
+                    if (merged && ms[i] > cs[i]) cinfo[i] = mi[i];
+                    if (merged) cs[i] = lse;
                 }
             }
             // ---- (c) keys, cut ---------------------------------------------------------------------
@@ -598,7 +761,7 @@ __global__ __launch_bounds__(64) void beam_kernel(BeamArgs p) {
             float best = -INFINITY;
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
-                key[i] = alive[i] ? cs[i] + b1[cst[i]] : -INFINITY;
+                key[i] = alive[i] ? cs[i] + bg[i] : -INFINITY;
                 best = fmaxf(best, key[i]);
             }
             best = wave_max_f32(best);
@@ -613,7 +776,8 @@ __global__ __launch_bounds__(64) void beam_kernel(BeamArgs p) {
             // ---- (d) top-W, slots in candidate order -----------------------------------------------
             bool sel[3];
             int slot[3];
-            const int nnew = radix_select(uk, W, lane, sel, slot, bs_ukey(thr), bs_ukey(best));
+            const int nnew = p.select == 1 ? radix_select(uk, W, lane, sel, slot, bs_ukey(thr), bs_ukey(best))
+                                           : hist_select(key, uk, W, lane, thr, p.inv_bin, hist, sel, slot, bs_ukey(thr), bs_ukey(best));
             if (p.dbg) { const long long t1 = __builtin_readcyclecounter(); dsec[2] += t1 - tc0; tc0 = t1; }
             // best selected candidate (max key, lowest index) gives the renormalisation shift
             const unsigned ubest = bs_ukey(best);
@@ -630,30 +794,35 @@ __global__ __launch_bounds__(64) void beam_kernel(BeamArgs p) {
                     }
                 }
             }
-            __syncthreads();   // everyone has finished reading the old beam and its hash table
+            __syncthreads();   // everyone has finished reading the old beam
+            // new beam + its hash table (atomics of the three candidates in flight together)
+            int pos[3];
 #pragma unroll
-            for (int i = 0; i < 3; ++i)
+            for (int i = 0; i < 3; ++i) {
+                pos[i] = 0;
                 if (sel[i]) {
                     b_state[slot[i]] = cst[i];
                     b_hash[slot[i]] = ch[i];
                     b_score[slot[i]] = cs[i] - shift;
                     st_bp[u * MAXW + slot[i]] = (uint8_t)cinfo[i];
+                    pos[i] = atomicAdd(&tb.cnt[ch[i] & (NBK - 1)], 1);
                 }
-#pragma unroll
-            for (int i = 0; i < HT / 64; ++i) htab[lane + 64 * i] = -1;
-            if (lane < MAXW) m_info[lane] = -1;
-            nb = nnew;
-            __syncthreads();
-            if (lane < nb) {   // table of the new beam's sequence hashes, used by the next step's probes
-                int hs = (int)(b_hash[lane] & (HT - 1));
-                while (atomicCAS(&htab[hs], -1, lane) != -1) hs = (hs + 1) & (HT - 1);
             }
+            if (lane < MAXW) m_info[lane] = -1;
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+                if (sel[i]) {
+                    const uint2_t e{ch[i], ((unsigned)cst[i] << 5) | (unsigned)slot[i]};
+                    if (pos[i] < 4) tb.ent[(ch[i] & (NBK - 1)) * 4 + pos[i]] = e;
+                    else tb.ov[atomicAdd(tb.ov_cnt, 1)] = e;
+                }
+            nb = nnew;
             __syncthreads();
             if (p.dbg) { const long long t1 = __builtin_readcyclecounter(); dsec[3] += t1 - tc0; dsec[4] += nb; }
         }
         // ---- flush back-pointers of this block ------------------------------------------------------
         for (int i = lane; i < nsteps * MAXW / 4; i += 64)
-            ((unsigned*)(bpn + (long)tb * MAXW))[i] = ((const unsigned*)st_bp)[i];
+            ((unsigned*)(bpn + (long)tb0 * MAXW))[i] = ((const unsigned*)st_bp)[i];
         __syncthreads();
     }
     // ---- best final element: max score (beta~_T = 0), ties -> lower slot ---------------------------
@@ -666,7 +835,7 @@ __global__ __launch_bounds__(64) void beam_kernel(BeamArgs p) {
         if (lane == 0) p.final_slot[n] = __ffsll((long long)mm) - 1;
     }
     if (p.dbg && lane == 0)
-        for (int i = 0; i < 5; ++i) p.dbg[(long)n * 8 + i] = dsec[i];
+        for (int i = 0; i < 6; ++i) p.dbg[(long)n * 8 + i] = dsec[i];
 }
 
 struct FinArgs {
@@ -819,6 +988,7 @@ namespace {
 // One helper stream + fork/join events per (device, host thread): bh_beam_search is re-entrant per thread, and a decode
 // worker thread drives one device.
 struct SideStream { hipStream_t stream = nullptr; hipEvent_t fork = nullptr, join = nullptr; };
+int g_beam_select = 0;     // 0 histogram top-W selection, 1 radix search (A/B and regression tests)
 int g_beam_fork = -1;      // -1 auto (fork for small state spaces), 0 never, 1 always; bh_set_option("beam_fork", v)
 SideStream* side_stream(int S) {
     // Measured (MI355X, 512 x 1667 steps): forking shortens the decode stage 8.3 -> 6.7 ms (S=64) / 11.3 -> 9.3 ms (S=256).
@@ -874,8 +1044,9 @@ int bh_k_beam_search(const void* scores, int N, int T, int state_len, int beam_w
     }
     hipLaunchKernelGGL(crf_forward_post_kernel, dim3(N), dim3(threads), lds_scan, fork ? side->stream : stream, sa);
     if (fork) BH_CHECK_HIP(hipEventRecord(side->join, side->stream));
-    BeamArgs ba{(const half_t*)scores, beta, N, T, S, state_len, beam_width, blank, logf(beam_cut), bp, fin, dbg};
-    const size_t lds_beam = (size_t)(BH_LSE_TABLE_SIZE + 2) * 4 + (size_t)BTB * 4 * S * 2 + (size_t)BTB * S * 4 + MAXW * 4 * 5 + HT * 4 + BTB * MAXW + 64;
+    BeamArgs ba{(const half_t*)scores, beta, N, T, S, state_len, beam_width, blank, logf(beam_cut), bp, fin, dbg,
+                64.0f / fmaxf(logf(beam_cut), 1e-6f), g_beam_select};
+    const size_t lds_beam = (size_t)(BH_LSE_TABLE_SIZE + 2) * 4 + (size_t)BTB * 4 * S * 2 + (size_t)BTB * S * 4 + MAXW * 4 * 5 + (NBK * 4 + MAXW) * 8 + (NBK + 4 + 64) * 4 + BTB * MAXW + 64;
     if (lds_beam > 64 * 1024)
         BH_CHECK_HIP(hipFuncSetAttribute((const void*)beam_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_beam));
     hipLaunchKernelGGL(beam_kernel, dim3(N), dim3(64), lds_beam, stream, ba);
@@ -888,5 +1059,6 @@ int bh_k_beam_search(const void* scores, int N, int T, int state_len, int beam_w
 
 int bh_k_decode_set_option(const char* name, int value) {
     if (name && !strcmp(name, "beam_fork")) { g_beam_fork = value; return 0; }
+    if (name && !strcmp(name, "beam_select")) { g_beam_select = value; return 0; }
     return 1;     // not a decoder option
 }

@@ -221,3 +221,20 @@ def test_beam_fork_option_does_not_change_results():
             assert torch.equal(a, b)
     with pytest.raises(Exception):
         decode.set_option("no_such_option", 1)
+
+
+@pytest.mark.parametrize("kind", ["normal", "ties", "zeros"])
+def test_beam_selection_variants_agree_with_oracle(kind):
+    # top-W selection by histogram + exact boundary ranking (default) or by radix search (bh_set_option "beam_select"):
+    # same beams, including when many keys tie (crowded boundary bin -> radix fallback inside the histogram path)
+    rng = np.random.default_rng(91)
+    sc = np.zeros((6, 160, 256), np.float16) if kind == "zeros" else _scores(rng, 6, 160, 256, kind)
+    oseq, oqs, omv, oqf = crf_ref.beam_search(sc, 3)
+    try:
+        for v in (0, 1):
+            decode.set_option("beam_select", v)
+            seq, qs, mv = decode.beam_search(torch.from_numpy(sc).cuda())
+            assert np.array_equal(mv.numpy(), omv), (kind, v)
+            assert np.array_equal(seq.numpy(), oseq), (kind, v)
+    finally:
+        decode.set_option("beam_select", 0)

@@ -17,5 +17,5 @@ for name, gain in (("flat random (bench-like)", 2.5), ("peaked", 6.0)):
     off = al(N * (T + 1) * S * 4) + al(N * (T + 1) * 8) + al(N * 8) + al(N * T * 4 * 4) + al(N * T * 32) + al(N * 4)
     st = np.frombuffer(ws[off: off + N * 64].tobytes(), dtype=np.int64).reshape(N, 8)
     sec = st[:, :4].astype(float).mean(0) / T
-    print("%-26s cycles/step: gen+probe %.0f | merge+keys+max %.0f | select %.0f | shift+write+table %.0f | total %.0f | mean beam %.1f" % (
-        name, sec[0], sec[1], sec[2], sec[3], sec.sum(), st[:, 4].mean() / T))
+    print("%-26s cycles/step: gen+probe %.0f | merge+keys+max %.0f | select %.0f | shift+write+table %.0f | staging %.0f | total %.0f | mean beam %.1f" % (
+        name, sec[0], sec[1], sec[2], sec[3], st[:, 5].mean() / T, sec.sum() + st[:, 5].mean() / T, st[:, 4].mean() / T))
