@@ -325,8 +325,8 @@ struct BeamArgs {
     uint8_t* bp;           // [N][T][32]  parent | move << 5 | base << 6
     int* final_slot;       // [N]
     long long* dbg;        // optional [N][8] per-section cycle counters (BH_BEAM_DEBUG)
-    float inv_bin;         // 64 / cut: selection histogram bins per unit of key
-    int select;            // 0 histogram selection, 1 radix search (bh_set_option("beam_select"))
+    float inv_bin;         // 256 / cut: selection histogram bins per unit of key; 0 puts every key into one bin, which
+                           // turns the selection into the plain radix search (bh_set_option("beam_select", 1))
 };
 
 constexpr int BTB = 8;     // steps staged per LDS block
@@ -447,9 +447,11 @@ __device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
 }
 
 // Same contract as radix_select (the `want` largest keys, ties by ascending candidate index), for keys known to lie
-// in [thr, thr + 64 / inv_bin]: one 64-bin histogram pass (LDS atomics + a wave prefix sum) finds the bin that holds
-// the want-th key; the few candidates in that bin are ranked exactly by repeated wave maxima. A crowded boundary bin
-// (many equal or near-equal keys) falls back to the radix search on that bin alone.
+// in [thr, thr + 256 / inv_bin]: one 256-bin histogram pass (LDS atomics, four bins per lane, a wave prefix sum) finds
+// the bin that holds the want-th key; the few candidates in that bin are ranked exactly by repeated wave maxima. A
+// crowded boundary bin (many equal or near-equal keys) falls back to the radix search on that bin alone.
+// One wave per workgroup: LDS operations complete in issue order, no barrier is needed between the phases.
+constexpr int HBINS = 256;
 __device__ __forceinline__ int hist_select(const float (&key)[3], const unsigned (&uk)[3], int want, int lane, float thr,
                                            float inv_bin, int* hist, bool (&sel)[3], int (&slot)[3], unsigned ulo, unsigned uhi) {
     unsigned long long selm[3];
@@ -457,22 +459,28 @@ __device__ __forceinline__ int hist_select(const float (&key)[3], const unsigned
 #pragma unroll
     for (int i = 0; i < 3; ++i) { selm[i] = __ballot(uk[i] != 0u); n_alive += popc64(selm[i]); }
     if (n_alive > want) {
-        hist[lane] = 0;
+        *(uint4_t*)(hist + 4 * lane) = uint4_t{0u, 0u, 0u, 0u};
         int bin[3];
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
-            bin[i] = min(63, (int)((key[i] - thr) * inv_bin));
-            if (uk[i] != 0u) atomicAdd(&hist[63 - bin[i]], 1);
+            bin[i] = min(HBINS - 1, (int)((key[i] - thr) * inv_bin));
+            if (uk[i] != 0u) atomicAdd(&hist[HBINS - 1 - bin[i]], 1);
         }
-        __syncthreads();
-        const int h = hist[lane];                       // lane l holds bin 63 - l
-        const int pre = wave_scan_add(h, lane);         // candidates in bins >= 63 - l
-        const unsigned long long ge = __ballot(pre >= want);
-        const int ls = __ffsll((long long)ge) - 1;      // exists: pre[63] = n_alive > want
-        const int n_hi = ls > 0 ? __builtin_amdgcn_readlane(pre, ls - 1) : 0;
-        const int m = __builtin_amdgcn_readlane(h, ls);
+        const uint4_t h4 = *(const uint4_t*)(hist + 4 * lane);    // lane l: bins 255-4l, 254-4l, 253-4l, 252-4l
+        const int c0 = (int)h4.x, c1 = c0 + (int)h4.y, c2 = c1 + (int)h4.z, c3 = c2 + (int)h4.w;
+        const int inc = wave_scan_add(c3, lane);        // candidates in bins >= 252 - 4l
+        const unsigned long long ge = __ballot(inc >= want);
+        const int ls = __ffsll((long long)ge) - 1;      // exists: inc[63] = n_alive > want
+        const int e = __builtin_amdgcn_readlane(inc - c3, ls);     // candidates in the bins above lane ls's four
+        const int g0 = __builtin_amdgcn_readlane((int)h4.x, ls), g1 = __builtin_amdgcn_readlane((int)h4.y, ls);
+        const int g2 = __builtin_amdgcn_readlane((int)h4.z, ls), g3 = __builtin_amdgcn_readlane((int)h4.w, ls);
+        int k, n_hi, m;
+        if (e + g0 >= want) { k = 0; n_hi = e; m = g0; }
+        else if (e + g0 + g1 >= want) { k = 1; n_hi = e + g0; m = g1; }
+        else if (e + g0 + g1 + g2 >= want) { k = 2; n_hi = e + g0 + g1; m = g2; }
+        else { k = 3; n_hi = e + g0 + g1 + g2; m = g3; }
         const int need = want - n_hi;                   // 1 <= need <= m
-        const int bstar = 63 - ls;
+        const int bstar = HBINS - 1 - (4 * ls + k);
         bool hi[3], bnd[3], selb[3];
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
@@ -520,28 +528,30 @@ __device__ __forceinline__ int hist_select(const float (&key)[3], const unsigned
     return before;
 }
 
-// Stay elements keyed by sequence hash: NBK buckets of 4 (hash, state << 5 | slot) entries, filled with one LDS atomic per
-// element as the beam is written; a move candidate reads its whole bucket with two 16-byte loads and compares in
-// registers - one LDS round trip and no divergent probe loop. A fifth element in a bucket (rare) goes to an overflow
-// list that every lookup then scans. Ties between equal (hash, state) stays resolve to the lowest slot, like the
-// oracle's first-match scan.
+// Stay elements keyed by sequence hash: NBK buckets of 4 entries (hash, step tag << 15 | state << 5 | slot), filled with
+// one LDS atomic per element as the beam is written; a move candidate reads its whole bucket with two 16-byte loads and
+// compares in registers - one LDS round trip and no divergent probe loop. Entries of earlier steps carry another tag and
+// never match, so nothing is cleared but the bucket fill counters. A fifth element in a bucket (rare) goes to an
+// overflow list that every lookup then scans. Ties between equal (hash, state) stays resolve to the lowest slot, like
+// the oracle's first-match scan.
 constexpr int NBK = 128;
+constexpr unsigned TAG_MASK = 0x1ffffu;     // 17 tag bits above 10 state bits and 5 slot bits
 
 struct BeamTable {
-    int* cnt;          // [NBK] elements hashed to the bucket (may exceed 4)
+    int* cnt;          // [NBK] elements hashed to the bucket this step (may exceed 4)
     uint2_t* ent;      // [NBK][4]
     int* ov_cnt;       // [1] (+3 pad)
     uint2_t* ov;       // [MAXW]
 };
-__device__ __forceinline__ void table_insert(const BeamTable& tb, bool on, unsigned hash, int state, int slot) {
-    int pos = 0;
-    const int b = (int)(hash & (NBK - 1));
-    if (on) pos = atomicAdd(&tb.cnt[b], 1);
-    if (on) {
-        const uint2_t e{hash, ((unsigned)state << 5) | (unsigned)slot};
-        if (pos < 4) tb.ent[b * 4 + pos] = e;
-        else tb.ov[atomicAdd(tb.ov_cnt, 1)] = e;
-    }
+
+// slot (0..31) of the lowest stay element matching (hash, want = tag | state << 5), or >= 32
+__device__ __forceinline__ unsigned bucket_match(const uint4_t& e0, const uint4_t& e1, unsigned hash, unsigned want) {
+    unsigned d = 32u;
+    d = min(d, e0.x == hash ? e0.y - want : 32u);
+    d = min(d, e0.z == hash ? e0.w - want : 32u);
+    d = min(d, e1.x == hash ? e1.y - want : 32u);
+    d = min(d, e1.z == hash ? e1.w - want : 32u);
+    return d;
 }
 
 // lse2_tab without control flow (same arithmetic): safe for garbage `b` as long as the result is discarded
@@ -558,27 +568,28 @@ __device__ __forceinline__ float lse2_tab_nb(float a, float b, const float* tab)
     return plain ? m : m + sp;
 }
 
+// STATE_LEN is a template parameter so that every LDS region sits at a constant offset (immediate DS offsets, no address
+// arithmetic or scalar registers spent on them); DBG compiles the per-section cycle counters in.
+template <int STATE_LEN, bool DBG>
 __global__ __launch_bounds__(64) void beam_kernel(BeamArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int S = p.S, T = p.T, W = p.W;
+    constexpr int S = 1 << (2 * STATE_LEN);
+    constexpr int sh = 2 * (STATE_LEN - 1);
+    const int T = p.T, W = p.W;
     const int lane = threadIdx.x, n = blockIdx.x;
-    const int sh = 2 * (p.state_len - 1);
     // LDS carve
     float* tab = (float*)smem;                           // lse table
     half_t* st_sc = (half_t*)(tab + BH_LSE_TABLE_SIZE + 2);   // [BTB][4S]
     float* st_b = (float*)(st_sc + BTB * 4 * S);         // [BTB][S]
     BeamTable tb;
     tb.ent = (uint2_t*)(st_b + BTB * S);                 // [NBK][4], 16-byte aligned
-    tb.ov = tb.ent + NBK * 4;                            // [32]
+    uint4_t* b_elem = (uint4_t*)(tb.ent + NBK * 4);      // [32] beam element: state, hash, score bits, -
+    uint2_t* m_pair = (uint2_t*)(b_elem + MAXW);         // [32] merged-in move: score bits, info (or -1)
+    tb.ov = m_pair + MAXW;                               // [32]
     tb.cnt = (int*)(tb.ov + MAXW);                       // [NBK]
     tb.ov_cnt = tb.cnt + NBK;                            // [4]
-    int* hist = tb.ov_cnt + 4;                           // [64] selection histogram
-    int* b_state = hist + 64;                            // [32]
-    unsigned* b_hash = (unsigned*)(b_state + MAXW);      // [32]
-    float* b_score = (float*)(b_hash + MAXW);            // [32]
-    float* m_score = b_score + MAXW;                     // [32] merged-in move score
-    int* m_info = (int*)(m_score + MAXW);                // [32] merged-in move info or -1
-    uint8_t* st_bp = (uint8_t*)(m_info + MAXW);          // [BTB][32]
+    int* hist = tb.ov_cnt + 4;                           // [HBINS] selection histogram (16-byte aligned)
+    uint8_t* st_bp = (uint8_t*)(hist + HBINS);           // [BTB][32]
     for (int i = lane; i < BH_LSE_TABLE_SIZE; i += 64) tab[i] = g_lse_tab[i];
 
     const half_t* sc = p.scores + (long)n * T * 4 * S;
@@ -597,6 +608,14 @@ __global__ __launch_bounds__(64) void beam_kernel(BeamArgs p) {
 
     // ---- init: top-W states by beta~_0 (ties: lower state), slots in state order ------------------
     int nb;
+#pragma unroll
+    for (int i = 0; i < NBK * 4 / 64; ++i) tb.ent[lane + 64 * i] = uint2_t{0u, 0xffffffffu};     // matches no tag
+    if (lane < MAXW) tb.ov[lane] = uint2_t{0u, 0xffffffffu};
+#pragma unroll
+    for (int i = 0; i < NBK / 64; ++i) tb.cnt[lane + 64 * i] = 0;
+    if (lane < 4) tb.ov_cnt[lane] = 0;
+    if (lane < MAXW) m_pair[lane] = uint2_t{0u, 0xffffffffu};
+    if (lane < MAXW) b_elem[lane] = uint4_t{0u, 0u, 0u, 0u};
     {
         const int per = (S + 63) / 64;
         unsigned prefix = 0u;
@@ -626,23 +645,21 @@ __global__ __launch_bounds__(64) void beam_kernel(BeamArgs p) {
             const bool tie_ok = ((eq >> lane) & 1ull) && (tie_before + popc64(eq & lanemask_lt(lane))) < need;
             const bool take = (s < S && u > prefix) || tie_ok;
             const unsigned long long tm = __ballot(take);
-            if (take) {
+            if (take) {          // step tag 0
                 const int slot = before + popc64(tm & lanemask_lt(lane));
-                b_state[slot] = s;
-                b_hash[slot] = bs_hash0(s);
-                b_score[slot] = 0.0f;
+                const unsigned h = bs_hash0(s);
+                b_elem[slot] = uint4_t{(unsigned)s, h, 0u /* score 0.0f */, 0u};
+                const int bk = (int)(h & (NBK - 1));
+                const int pos = atomicAdd(&tb.cnt[bk], 1);
+                const uint2_t e{h, ((unsigned)s << 5) | (unsigned)slot};
+                if (pos < 4) tb.ent[bk * 4 + pos] = e;
+                else tb.ov[atomicAdd(tb.ov_cnt, 1)] = e;
             }
             tie_before += popc64(eq);
             before += popc64(tm);
         }
         nb = before;
     }
-#pragma unroll
-    for (int i = 0; i < NBK / 64; ++i) tb.cnt[lane + 64 * i] = 0;
-    if (lane < 4) tb.ov_cnt[lane] = 0;
-    if (lane < MAXW) m_info[lane] = -1;
-    __syncthreads();
-    table_insert(tb, lane < nb, lane < nb ? b_hash[lane] : 0u, lane < nb ? b_state[lane] : 0, lane);
     __syncthreads();
 
     for (int tb0 = 0; tb0 < T; tb0 += BTB) {
@@ -651,7 +668,7 @@ __global__ __launch_bounds__(64) void beam_kernel(BeamArgs p) {
         {   // global -> LDS DMA, 1 KiB per instruction, all of them in flight before the single wait (a register round trip
             // per 1 KiB serialises on the memory latency: there is only this one wave to hide it)
             long long ts0 = 0;
-            if (p.dbg) ts0 = __builtin_readcyclecounter();
+            if (DBG) ts0 = __builtin_readcyclecounter();
             const int n_sc = nsteps * S / 2;        // 16-byte units of score rows (4S halves per step)
             const char* src = (const char*)(sc + (long)tb0 * 4 * S);
             for (int i0 = 0; i0 < n_sc; i0 += 64)
@@ -665,94 +682,78 @@ __global__ __launch_bounds__(64) void beam_kernel(BeamArgs p) {
                     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(bs + (long)(i0 + lane) * 16),
                                                      (__attribute__((address_space(3))) void*)((char*)st_b + i0 * 16), 16, 0, 0);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (p.dbg) dsec[5] += __builtin_readcyclecounter() - ts0;
+            if (DBG) dsec[5] += __builtin_readcyclecounter() - ts0;
         }
         __syncthreads();
         for (int u = 0; u < nsteps; ++u) {
             const half_t* row = st_sc + u * 4 * S;
             const float* b1 = st_b + u * S;
+            const unsigned tag = ((unsigned)(tb0 + u) & TAG_MASK) << 15;            // of the table built for this step
+            const unsigned tag_next = ((unsigned)(tb0 + u + 1) & TAG_MASK) << 15;
             long long tc0 = 0;
-            if (p.dbg) tc0 = __builtin_readcyclecounter();
+            if (DBG) tc0 = __builtin_readcyclecounter();
             // ---- (b) candidates; a move that spells the same sequence as a stay is folded into it ---
             // Every LDS level is issued for all three candidates before it is consumed, and nothing is conditional on
             // loaded data: level 1 = parent element, level 2 = transition score + guide + hash bucket.
+            // A candidate that does not exist (beyond the beam) or was folded into a stay carries score -inf.
             float cs[3];
             unsigned ch[3];
             int cst[3], cinfo[3];
-            bool alive[3], mover[3];
-            int es[3];
-            unsigned eh[3];
-            float esc[3];
+            uint4_t el[3];
 #pragma unroll
-            for (int i = 0; i < 3; ++i) {
-                alive[i] = ce[i] < nb;
-                es[i] = b_state[cer[i]];
-                eh[i] = b_hash[cer[i]];
-                esc[i] = b_score[cer[i]];
-            }
+            for (int i = 0; i < 3; ++i) el[i] = b_elem[cer[i]];
             float mv[3], bg[3];
-            int bcnt[3];
             uint4_t ent0[3], ent1[3];
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
+                const int es = (int)(el[i].x & (unsigned)(S - 1));      // (stale slots beyond the beam stay in range)
                 const int x = cj[i] > 0 ? cj[i] - 1 : 0;
-                const int s2 = ((es[i] << 2) | x) & (S - 1);
-                cst[i] = cj[i] == 0 ? es[i] : s2;
-                ch[i] = cj[i] == 0 ? eh[i] : bs_mix(eh[i], x);
+                const int s2 = ((es << 2) | x) & (S - 1);
+                cst[i] = cj[i] == 0 ? es : s2;
+                ch[i] = cj[i] == 0 ? el[i].y : bs_mix(el[i].y, x);
                 cinfo[i] = cj[i] == 0 ? ce[i] : (ce[i] | (1 << 5) | (x << 6));
-                mover[i] = alive[i] && cj[i] != 0;
                 const int bk = (int)(ch[i] & (NBK - 1));
-                mv[i] = (float)row[s2 * 4 + (es[i] >> sh)];
+                mv[i] = (float)row[s2 * 4 + (es >> sh)];
                 bg[i] = b1[cst[i]];
-                bcnt[i] = tb.cnt[bk];
                 ent0[i] = *(const uint4_t*)(tb.ent + bk * 4);
                 ent1[i] = *(const uint4_t*)(tb.ent + bk * 4 + 2);
             }
             const int n_ov = tb.ov_cnt[0];
-            int dhit[3];
+            unsigned dhit[3];
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
-                cs[i] = esc[i] + (cj[i] == 0 ? p.blank : mv[i]);
-                if (!alive[i]) { cs[i] = -INFINITY; ch[i] = 0u; cst[i] = 0; cinfo[i] = 0; }
-                const unsigned want_hi = (unsigned)cst[i];
-                int d = MAXW;
-                if (bcnt[i] > 0 && ent0[i].x == ch[i] && (ent0[i].y >> 5) == want_hi) d = min(d, (int)(ent0[i].y & 31u));
-                if (bcnt[i] > 1 && ent0[i].z == ch[i] && (ent0[i].w >> 5) == want_hi) d = min(d, (int)(ent0[i].w & 31u));
-                if (bcnt[i] > 2 && ent1[i].x == ch[i] && (ent1[i].y >> 5) == want_hi) d = min(d, (int)(ent1[i].y & 31u));
-                if (bcnt[i] > 3 && ent1[i].z == ch[i] && (ent1[i].w >> 5) == want_hi) d = min(d, (int)(ent1[i].w & 31u));
-                dhit[i] = d;
+                cs[i] = ce[i] < nb ? __uint_as_float(el[i].z) + (cj[i] == 0 ? p.blank : mv[i]) : -INFINITY;
+                dhit[i] = bucket_match(ent0[i], ent1[i], ch[i], tag | ((unsigned)cst[i] << 5));
             }
             if (n_ov > 0) {                              // rare: some bucket held more than four elements
                 for (int k = 0; k < n_ov; ++k) {
                     const uint2_t e = tb.ov[k];
 #pragma unroll
                     for (int i = 0; i < 3; ++i)
-                        if (e.x == ch[i] && (e.y >> 5) == (unsigned)cst[i]) dhit[i] = min(dhit[i], (int)(e.y & 31u));
+                        dhit[i] = min(dhit[i], e.x == ch[i] ? e.y - (tag | ((unsigned)cst[i] << 5)) : 32u);
                 }
             }
 #pragma unroll
             for (int i = 0; i < 3; ++i)
-                if (mover[i] && dhit[i] < MAXW) {
-                    m_score[dhit[i]] = cs[i];
-                    m_info[dhit[i]] = cinfo[i];
-                    alive[i] = false;
+                if (cj[i] != 0 && ce[i] < nb && dhit[i] < 32u) {
+                    m_pair[dhit[i]] = uint2_t{__float_as_uint(cs[i]), (unsigned)cinfo[i]};
+                    cs[i] = -INFINITY;
                 }
-            // the lookups of this step are done (one wave: LDS operations complete in issue order): reset the table
+            // the lookups of this step are done (one wave: LDS operations complete in issue order): reset the fill counters
 #pragma unroll
             for (int i = 0; i < NBK / 64; ++i) tb.cnt[lane + 64 * i] = 0;
             if (lane < 4) tb.ov_cnt[lane] = 0;
-            if (p.dbg) { const long long t1 = __builtin_readcyclecounter(); dsec[0] += t1 - tc0; tc0 = t1; }
-            __syncthreads();
-            {
-                int mi[3];
-                float ms[3];
+            if (DBG) { const long long t1 = __builtin_readcyclecounter(); dsec[0] += t1 - tc0; tc0 = t1; }
+            {   // (no barriers inside a step: one wave per workgroup, and LDS operations complete in issue order)
+                uint2_t mp[3];
 #pragma unroll
-                for (int i = 0; i < 3; ++i) { mi[i] = m_info[cer[i]]; ms[i] = m_score[cer[i]]; }
+                for (int i = 0; i < 3; ++i) mp[i] = m_pair[cer[i]];
 #pragma unroll
                 for (int i = 0; i < 3; ++i) {
-                    const bool merged = alive[i] && cj[i] == 0 && mi[i] >= 0;
-                    const float lse = lse2_tab_nb(cs[i], ms[i], tab);
-                    if (merged && ms[i] > cs[i]) cinfo[i] = mi[i];
+                    const bool merged = cj[i] == 0 && ce[i] < nb && (int)mp[i].y >= 0;
+                    const float ms = __uint_as_float(mp[i].x);
+                    const float lse = lse2_tab_nb(cs[i], ms, tab);
+                    if (merged && ms > cs[i]) cinfo[i] = (int)mp[i].y;
                     if (merged) cs[i] = lse;
                 }
             }
@@ -761,24 +762,20 @@ __global__ __launch_bounds__(64) void beam_kernel(BeamArgs p) {
             float best = -INFINITY;
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
-                key[i] = alive[i] ? cs[i] + bg[i] : -INFINITY;
+                key[i] = cs[i] + bg[i];                  // -inf for absent / folded candidates
                 best = fmaxf(best, key[i]);
             }
             best = wave_max_f32(best);
             const float thr = best - p.cut;
             unsigned uk[3];
 #pragma unroll
-            for (int i = 0; i < 3; ++i) {
-                if (alive[i] && key[i] < thr) alive[i] = false;
-                uk[i] = alive[i] ? bs_ukey(key[i]) : 0u;
-            }
-            if (p.dbg) { const long long t1 = __builtin_readcyclecounter(); dsec[1] += t1 - tc0; tc0 = t1; }
+            for (int i = 0; i < 3; ++i) uk[i] = key[i] >= thr ? bs_ukey(key[i]) : 0u;
+            if (DBG) { const long long t1 = __builtin_readcyclecounter(); dsec[1] += t1 - tc0; tc0 = t1; }
             // ---- (d) top-W, slots in candidate order -----------------------------------------------
             bool sel[3];
             int slot[3];
-            const int nnew = p.select == 1 ? radix_select(uk, W, lane, sel, slot, bs_ukey(thr), bs_ukey(best))
-                                           : hist_select(key, uk, W, lane, thr, p.inv_bin, hist, sel, slot, bs_ukey(thr), bs_ukey(best));
-            if (p.dbg) { const long long t1 = __builtin_readcyclecounter(); dsec[2] += t1 - tc0; tc0 = t1; }
+            const int nnew = hist_select(key, uk, W, lane, thr, p.inv_bin, hist, sel, slot, bs_ukey(thr), bs_ukey(best));
+            if (DBG) { const long long t1 = __builtin_readcyclecounter(); dsec[2] += t1 - tc0; tc0 = t1; }
             // best selected candidate (max key, lowest index) gives the renormalisation shift
             const unsigned ubest = bs_ukey(best);
             float shift = 0.0f;
@@ -789,36 +786,32 @@ __global__ __launch_bounds__(64) void beam_kernel(BeamArgs p) {
                     const unsigned long long mm = __ballot(sel[i] && uk[i] == ubest);
                     if (!found && mm) {
                         const int src = __ffsll((long long)mm) - 1;
-                        shift = __shfl(cs[i], src);
+                        shift = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(cs[i]), src));
                         found = 1;
                     }
                 }
             }
-            __syncthreads();   // everyone has finished reading the old beam
             // new beam + its hash table (atomics of the three candidates in flight together)
             int pos[3];
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
                 pos[i] = 0;
                 if (sel[i]) {
-                    b_state[slot[i]] = cst[i];
-                    b_hash[slot[i]] = ch[i];
-                    b_score[slot[i]] = cs[i] - shift;
+                    b_elem[slot[i]] = uint4_t{(unsigned)cst[i], ch[i], __float_as_uint(cs[i] - shift), 0u};
                     st_bp[u * MAXW + slot[i]] = (uint8_t)cinfo[i];
                     pos[i] = atomicAdd(&tb.cnt[ch[i] & (NBK - 1)], 1);
                 }
             }
-            if (lane < MAXW) m_info[lane] = -1;
+            if (lane < MAXW) m_pair[lane] = uint2_t{0u, 0xffffffffu};
 #pragma unroll
             for (int i = 0; i < 3; ++i)
                 if (sel[i]) {
-                    const uint2_t e{ch[i], ((unsigned)cst[i] << 5) | (unsigned)slot[i]};
+                    const uint2_t e{ch[i], tag_next | ((unsigned)cst[i] << 5) | (unsigned)slot[i]};
                     if (pos[i] < 4) tb.ent[(ch[i] & (NBK - 1)) * 4 + pos[i]] = e;
                     else tb.ov[atomicAdd(tb.ov_cnt, 1)] = e;
                 }
             nb = nnew;
-            __syncthreads();
-            if (p.dbg) { const long long t1 = __builtin_readcyclecounter(); dsec[3] += t1 - tc0; dsec[4] += nb; }
+            if (DBG) { const long long t1 = __builtin_readcyclecounter(); dsec[3] += t1 - tc0; dsec[4] += nb; }
         }
         // ---- flush back-pointers of this block ------------------------------------------------------
         for (int i = lane; i < nsteps * MAXW / 4; i += 64)
@@ -827,14 +820,14 @@ __global__ __launch_bounds__(64) void beam_kernel(BeamArgs p) {
     }
     // ---- best final element: max score (beta~_T = 0), ties -> lower slot ---------------------------
     {
-        const unsigned u = lane < nb ? bs_ukey(b_score[lane]) : 0u;
+        const unsigned u = lane < nb ? bs_ukey(__uint_as_float(b_elem[lane].z)) : 0u;
         unsigned m = u;
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, off));
         const unsigned long long mm = __ballot(u == m && lane < nb);
         if (lane == 0) p.final_slot[n] = __ffsll((long long)mm) - 1;
     }
-    if (p.dbg && lane == 0)
+    if (DBG && lane == 0)
         for (int i = 0; i < 6; ++i) p.dbg[(long)n * 8 + i] = dsec[i];
 }
 
@@ -1017,6 +1010,7 @@ int bh_k_beam_search(const void* scores, int N, int T, int state_len, int beam_w
     BH_REQUIRE(N > 0 && T > 0, "beam_search: empty problem N=%d T=%d", N, T);
     BH_REQUIRE(beam_width >= 1 && beam_width <= 32, "beam_search: beam_width must be in 1..32 (got %d)", beam_width);
     BH_REQUIRE(beam_cut >= 1.0f, "beam_search: beam_cut must be >= 1");
+    BH_REQUIRE(T < (1 << 17), "beam_search: at most 131071 steps per chunk (got %d)", T);
     int S = 1;
     for (int i = 0; i < state_len; ++i) S *= 4;
     auto align = [](size_t x) { return (x + 255) / 256 * 256; };
@@ -1045,11 +1039,28 @@ int bh_k_beam_search(const void* scores, int N, int T, int state_len, int beam_w
     hipLaunchKernelGGL(crf_forward_post_kernel, dim3(N), dim3(threads), lds_scan, fork ? side->stream : stream, sa);
     if (fork) BH_CHECK_HIP(hipEventRecord(side->join, side->stream));
     BeamArgs ba{(const half_t*)scores, beta, N, T, S, state_len, beam_width, blank, logf(beam_cut), bp, fin, dbg,
-                64.0f / fmaxf(logf(beam_cut), 1e-6f), g_beam_select};
-    const size_t lds_beam = (size_t)(BH_LSE_TABLE_SIZE + 2) * 4 + (size_t)BTB * 4 * S * 2 + (size_t)BTB * S * 4 + MAXW * 4 * 5 + (NBK * 4 + MAXW) * 8 + (NBK + 4 + 64) * 4 + BTB * MAXW + 64;
-    if (lds_beam > 64 * 1024)
-        BH_CHECK_HIP(hipFuncSetAttribute((const void*)beam_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_beam));
-    hipLaunchKernelGGL(beam_kernel, dim3(N), dim3(64), lds_beam, stream, ba);
+                g_beam_select ? 0.0f : 256.0f / fmaxf(logf(beam_cut), 1e-6f)};
+    const size_t lds_beam = (size_t)(BH_LSE_TABLE_SIZE + 2) * 4 + (size_t)BTB * 4 * S * 2 + (size_t)BTB * S * 4 + NBK * 4 * 8 + MAXW * (16 + 8 + 8) + (NBK + 4 + HBINS) * 4 + BTB * MAXW + 64;
+    auto launch_beam = [&](auto kern) -> int {
+        if (lds_beam > 64 * 1024)
+            BH_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_beam));
+        hipLaunchKernelGGL(kern, dim3(N), dim3(64), lds_beam, stream, ba);
+        return 0;
+    };
+    int lrc = -2;
+    switch (state_len * 2 + (dbg ? 1 : 0)) {
+        case 2: lrc = launch_beam(beam_kernel<1, false>); break;
+        case 3: lrc = launch_beam(beam_kernel<1, true>); break;
+        case 4: lrc = launch_beam(beam_kernel<2, false>); break;
+        case 5: lrc = launch_beam(beam_kernel<2, true>); break;
+        case 6: lrc = launch_beam(beam_kernel<3, false>); break;
+        case 7: lrc = launch_beam(beam_kernel<3, true>); break;
+        case 8: lrc = launch_beam(beam_kernel<4, false>); break;
+        case 9: lrc = launch_beam(beam_kernel<4, true>); break;
+        case 10: lrc = launch_beam(beam_kernel<5, false>); break;
+        case 11: lrc = launch_beam(beam_kernel<5, true>); break;
+    }
+    if (lrc) return lrc;
     if (fork) BH_CHECK_HIP(hipStreamWaitEvent(stream, side->join, 0));
     FinArgs fa{bp, fin, P, N, T, q_scale, q_offset, sequence, qstring, moves, qfloat};
     hipLaunchKernelGGL(beam_finalize_kernel, dim3(N), dim3(64), 0, stream, fa);
