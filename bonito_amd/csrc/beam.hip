@@ -459,14 +459,14 @@ __device__ __forceinline__ int hist_select(const float (&key)[3], const unsigned
 #pragma unroll
     for (int i = 0; i < 3; ++i) { selm[i] = __ballot(uk[i] != 0u); n_alive += popc64(selm[i]); }
     if (n_alive > want) {
-        *(uint4_t*)(hist + 4 * lane) = uint4_t{0u, 0u, 0u, 0u};
-        int bin[3];
+        int bin[3];                                     // (the histogram arrives zeroed and is handed back zeroed)
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
             bin[i] = min(HBINS - 1, (int)((key[i] - thr) * inv_bin));
             if (uk[i] != 0u) atomicAdd(&hist[HBINS - 1 - bin[i]], 1);
         }
         const uint4_t h4 = *(const uint4_t*)(hist + 4 * lane);    // lane l: bins 255-4l, 254-4l, 253-4l, 252-4l
+        *(uint4_t*)(hist + 4 * lane) = uint4_t{0u, 0u, 0u, 0u};
         const int c0 = (int)h4.x, c1 = c0 + (int)h4.y, c2 = c1 + (int)h4.z, c3 = c2 + (int)h4.w;
         const int inc = wave_scan_add(c3, lane);        // candidates in bins >= 252 - 4l
         const unsigned long long ge = __ballot(inc >= want);
@@ -528,29 +528,28 @@ __device__ __forceinline__ int hist_select(const float (&key)[3], const unsigned
     return before;
 }
 
-// Stay elements keyed by sequence hash: NBK buckets of 4 entries (hash, step tag << 15 | state << 5 | slot), filled with
-// one LDS atomic per element as the beam is written; a move candidate reads its whole bucket with two 16-byte loads and
-// compares in registers - one LDS round trip and no divergent probe loop. Entries of earlier steps carry another tag and
-// never match, so nothing is cleared but the bucket fill counters. A fifth element in a bucket (rare) goes to an
-// overflow list that every lookup then scans. Ties between equal (hash, state) stays resolve to the lowest slot, like
+// Stay elements keyed by sequence hash: NBK buckets of BKE entries (hash, step tag << 15 | state << 5 | slot), filled
+// with one LDS atomic per element as the beam is written; a move candidate reads its whole bucket with one 16-byte load
+// and compares in registers - one LDS round trip and no divergent probe loop. Entries of earlier steps carry another
+// tag and never match, so nothing is cleared but the bucket fill counters. A third element in a bucket (a few percent
+// of the steps) goes to an overflow list that every lookup then scans. Ties between equal (hash, state) stays resolve to the lowest slot, like
 // the oracle's first-match scan.
-constexpr int NBK = 128;
+constexpr int NBK = 256;
+constexpr int BKE = 2;      // entries per bucket
 constexpr unsigned TAG_MASK = 0x1ffffu;     // 17 tag bits above 10 state bits and 5 slot bits
 
 struct BeamTable {
     int* cnt;          // [NBK] elements hashed to the bucket this step (may exceed 4)
-    uint2_t* ent;      // [NBK][4]
+    uint2_t* ent;      // [NBK][BKE]
     int* ov_cnt;       // [1] (+3 pad)
     uint2_t* ov;       // [MAXW]
 };
 
 // slot (0..31) of the lowest stay element matching (hash, want = tag | state << 5), or >= 32
-__device__ __forceinline__ unsigned bucket_match(const uint4_t& e0, const uint4_t& e1, unsigned hash, unsigned want) {
+__device__ __forceinline__ unsigned bucket_match(const uint4_t& e0, unsigned hash, unsigned want) {
     unsigned d = 32u;
     d = min(d, e0.x == hash ? e0.y - want : 32u);
     d = min(d, e0.z == hash ? e0.w - want : 32u);
-    d = min(d, e1.x == hash ? e1.y - want : 32u);
-    d = min(d, e1.z == hash ? e1.w - want : 32u);
     return d;
 }
 
@@ -570,27 +569,44 @@ __device__ __forceinline__ float lse2_tab_nb(float a, float b, const float* tab)
 
 // STATE_LEN is a template parameter so that every LDS region sits at a constant offset (immediate DS offsets, no address
 // arithmetic or scalar registers spent on them); DBG compiles the per-section cycle counters in.
-template <int STATE_LEN, bool DBG>
-__global__ __launch_bounds__(64) void beam_kernel(BeamArgs p) {
+// One wave per chunk, CPW chunks (waves) per workgroup: the waves share nothing but the 16 KiB lse table - each has its own
+// staging buffers, beam and hash table, and they never synchronise after the table is loaded. (Sharing the table is what
+// keeps the LDS footprint per chunk low enough for several decode kernels and a recurrent layer to be co-resident.)
+template <int STATE_LEN>
+__host__ __device__ constexpr int beam_wave_lds() {
+    constexpr int S = 1 << (2 * STATE_LEN);
+    return BTB * 4 * S * 2 + BTB * S * 4 + NBK * BKE * 8 + MAXW * (16 + 8 + 8) + (NBK + 4) * 4 + BTB * MAXW;
+}
+constexpr int BEAM_TAB_LDS = (BH_LSE_TABLE_SIZE + 2) * 4;
+
+template <int STATE_LEN, int CPW, bool DBG>
+__global__ __launch_bounds__(64 * CPW) __attribute__((amdgpu_waves_per_eu(1, 8))) void beam_kernel(BeamArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int S = 1 << (2 * STATE_LEN);
     constexpr int sh = 2 * (STATE_LEN - 1);
+    static_assert(NBK == HBINS, "the selection histogram reuses the bucket fill counters");
+    static_assert(beam_wave_lds<STATE_LEN>() % 16 == 0 && BEAM_TAB_LDS % 16 == 0, "LDS regions must stay 16-byte aligned");
     const int T = p.T, W = p.W;
-    const int lane = threadIdx.x, n = blockIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int n = blockIdx.x * CPW + wave;
     // LDS carve
-    float* tab = (float*)smem;                           // lse table
-    half_t* st_sc = (half_t*)(tab + BH_LSE_TABLE_SIZE + 2);   // [BTB][4S]
+    float* tab = (float*)smem;                           // lse table (shared by the waves)
+    for (int i = threadIdx.x; i < BH_LSE_TABLE_SIZE; i += 64 * CPW) tab[i] = g_lse_tab[i];
+    __syncthreads();
+    if (n >= p.N) return;
+    char* mine = smem + BEAM_TAB_LDS + wave * beam_wave_lds<STATE_LEN>();
+    half_t* st_sc = (half_t*)mine;                       // [BTB][4S]
     float* st_b = (float*)(st_sc + BTB * 4 * S);         // [BTB][S]
     BeamTable tb;
-    tb.ent = (uint2_t*)(st_b + BTB * S);                 // [NBK][4], 16-byte aligned
-    uint4_t* b_elem = (uint4_t*)(tb.ent + NBK * 4);      // [32] beam element: state, hash, score bits, -
+    tb.ent = (uint2_t*)(st_b + BTB * S);                 // [NBK][BKE], 16-byte aligned
+    uint4_t* b_elem = (uint4_t*)(tb.ent + NBK * BKE);    // [32] beam element: state, hash, score bits, -
     uint2_t* m_pair = (uint2_t*)(b_elem + MAXW);         // [32] merged-in move: score bits, info (or -1)
     tb.ov = m_pair + MAXW;                               // [32]
-    tb.cnt = (int*)(tb.ov + MAXW);                       // [NBK]
+    tb.cnt = (int*)(tb.ov + MAXW);                       // [NBK]; doubles as the selection histogram (zero between uses)
     tb.ov_cnt = tb.cnt + NBK;                            // [4]
-    int* hist = tb.ov_cnt + 4;                           // [HBINS] selection histogram (16-byte aligned)
-    uint8_t* st_bp = (uint8_t*)(hist + HBINS);           // [BTB][32]
-    for (int i = lane; i < BH_LSE_TABLE_SIZE; i += 64) tab[i] = g_lse_tab[i];
+    int* hist = tb.cnt;
+    uint8_t* st_bp = (uint8_t*)(tb.ov_cnt + 4);          // [BTB][32]
 
     const half_t* sc = p.scores + (long)n * T * 4 * S;
     const float* bn = p.beta + (long)n * (T + 1) * S;
@@ -609,10 +625,9 @@ __global__ __launch_bounds__(64) void beam_kernel(BeamArgs p) {
     // ---- init: top-W states by beta~_0 (ties: lower state), slots in state order ------------------
     int nb;
 #pragma unroll
-    for (int i = 0; i < NBK * 4 / 64; ++i) tb.ent[lane + 64 * i] = uint2_t{0u, 0xffffffffu};     // matches no tag
+    for (int i = 0; i < NBK * BKE / 64; ++i) tb.ent[lane + 64 * i] = uint2_t{0u, 0xffffffffu};     // matches no tag
     if (lane < MAXW) tb.ov[lane] = uint2_t{0u, 0xffffffffu};
-#pragma unroll
-    for (int i = 0; i < NBK / 64; ++i) tb.cnt[lane + 64 * i] = 0;
+    *(uint4_t*)(tb.cnt + 4 * lane) = uint4_t{0u, 0u, 0u, 0u};
     if (lane < 4) tb.ov_cnt[lane] = 0;
     if (lane < MAXW) m_pair[lane] = uint2_t{0u, 0xffffffffu};
     if (lane < MAXW) b_elem[lane] = uint4_t{0u, 0u, 0u, 0u};
@@ -652,7 +667,7 @@ __global__ __launch_bounds__(64) void beam_kernel(BeamArgs p) {
                 const int bk = (int)(h & (NBK - 1));
                 const int pos = atomicAdd(&tb.cnt[bk], 1);
                 const uint2_t e{h, ((unsigned)s << 5) | (unsigned)slot};
-                if (pos < 4) tb.ent[bk * 4 + pos] = e;
+                if (pos < BKE) tb.ent[bk * BKE + pos] = e;
                 else tb.ov[atomicAdd(tb.ov_cnt, 1)] = e;
             }
             tie_before += popc64(eq);
@@ -660,7 +675,6 @@ __global__ __launch_bounds__(64) void beam_kernel(BeamArgs p) {
         }
         nb = before;
     }
-    __syncthreads();
 
     for (int tb0 = 0; tb0 < T; tb0 += BTB) {
         const int nsteps = min(BTB, T - tb0);
@@ -681,10 +695,9 @@ __global__ __launch_bounds__(64) void beam_kernel(BeamArgs p) {
                 if (i0 + lane < n_b)
                     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(bs + (long)(i0 + lane) * 16),
                                                      (__attribute__((address_space(3))) void*)((char*)st_b + i0 * 16), 16, 0, 0);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // wave-private buffers: no workgroup barrier
             if (DBG) dsec[5] += __builtin_readcyclecounter() - ts0;
         }
-        __syncthreads();
         for (int u = 0; u < nsteps; ++u) {
             const half_t* row = st_sc + u * 4 * S;
             const float* b1 = st_b + u * S;
@@ -703,7 +716,7 @@ __global__ __launch_bounds__(64) void beam_kernel(BeamArgs p) {
 #pragma unroll
             for (int i = 0; i < 3; ++i) el[i] = b_elem[cer[i]];
             float mv[3], bg[3];
-            uint4_t ent0[3], ent1[3];
+            uint4_t ent0[3];
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
                 const int es = (int)(el[i].x & (unsigned)(S - 1));      // (stale slots beyond the beam stay in range)
@@ -715,15 +728,14 @@ __global__ __launch_bounds__(64) void beam_kernel(BeamArgs p) {
                 const int bk = (int)(ch[i] & (NBK - 1));
                 mv[i] = (float)row[s2 * 4 + (es >> sh)];
                 bg[i] = b1[cst[i]];
-                ent0[i] = *(const uint4_t*)(tb.ent + bk * 4);
-                ent1[i] = *(const uint4_t*)(tb.ent + bk * 4 + 2);
+                ent0[i] = *(const uint4_t*)(tb.ent + bk * BKE);
             }
             const int n_ov = tb.ov_cnt[0];
             unsigned dhit[3];
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
                 cs[i] = ce[i] < nb ? __uint_as_float(el[i].z) + (cj[i] == 0 ? p.blank : mv[i]) : -INFINITY;
-                dhit[i] = bucket_match(ent0[i], ent1[i], ch[i], tag | ((unsigned)cst[i] << 5));
+                dhit[i] = bucket_match(ent0[i], ch[i], tag | ((unsigned)cst[i] << 5));
             }
             if (n_ov > 0) {                              // rare: some bucket held more than four elements
                 for (int k = 0; k < n_ov; ++k) {
@@ -740,8 +752,7 @@ __global__ __launch_bounds__(64) void beam_kernel(BeamArgs p) {
                     cs[i] = -INFINITY;
                 }
             // the lookups of this step are done (one wave: LDS operations complete in issue order): reset the fill counters
-#pragma unroll
-            for (int i = 0; i < NBK / 64; ++i) tb.cnt[lane + 64 * i] = 0;
+            *(uint4_t*)(tb.cnt + 4 * lane) = uint4_t{0u, 0u, 0u, 0u};
             if (lane < 4) tb.ov_cnt[lane] = 0;
             if (DBG) { const long long t1 = __builtin_readcyclecounter(); dsec[0] += t1 - tc0; tc0 = t1; }
             {   // (no barriers inside a step: one wave per workgroup, and LDS operations complete in issue order)
@@ -807,7 +818,7 @@ __global__ __launch_bounds__(64) void beam_kernel(BeamArgs p) {
             for (int i = 0; i < 3; ++i)
                 if (sel[i]) {
                     const uint2_t e{ch[i], tag_next | ((unsigned)cst[i] << 5) | (unsigned)slot[i]};
-                    if (pos[i] < 4) tb.ent[(ch[i] & (NBK - 1)) * 4 + pos[i]] = e;
+                    if (pos[i] < BKE) tb.ent[(ch[i] & (NBK - 1)) * BKE + pos[i]] = e;
                     else tb.ov[atomicAdd(tb.ov_cnt, 1)] = e;
                 }
             nb = nnew;
@@ -816,7 +827,6 @@ __global__ __launch_bounds__(64) void beam_kernel(BeamArgs p) {
         // ---- flush back-pointers of this block ------------------------------------------------------
         for (int i = lane; i < nsteps * MAXW / 4; i += 64)
             ((unsigned*)(bpn + (long)tb0 * MAXW))[i] = ((const unsigned*)st_bp)[i];
-        __syncthreads();
     }
     // ---- best final element: max score (beta~_T = 0), ties -> lower slot ---------------------------
     {
@@ -1040,25 +1050,28 @@ int bh_k_beam_search(const void* scores, int N, int T, int state_len, int beam_w
     if (fork) BH_CHECK_HIP(hipEventRecord(side->join, side->stream));
     BeamArgs ba{(const half_t*)scores, beta, N, T, S, state_len, beam_width, blank, logf(beam_cut), bp, fin, dbg,
                 g_beam_select ? 0.0f : 256.0f / fmaxf(logf(beam_cut), 1e-6f)};
-    const size_t lds_beam = (size_t)(BH_LSE_TABLE_SIZE + 2) * 4 + (size_t)BTB * 4 * S * 2 + (size_t)BTB * S * 4 + NBK * 4 * 8 + MAXW * (16 + 8 + 8) + (NBK + 4 + HBINS) * 4 + BTB * MAXW + 64;
-    auto launch_beam = [&](auto kern) -> int {
+    // Chunks (waves) per workgroup, measured on MI355X next to the encoder of the same model: four for the narrow state
+    // spaces (fast-sized models, three lanes: 1.20e9 -> 1.26e9 samples/s); one for 256 states - two waves per workgroup
+    // there cost the hac pipeline 6 % (the 78 KiB workgroups find room beside the recurrent layer's workgroups later).
+    auto launch_beam = [&](auto kern, int cpw, size_t wave_lds) -> int {
+        const size_t lds_beam = (size_t)BEAM_TAB_LDS + cpw * wave_lds;
         if (lds_beam > 64 * 1024)
             BH_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_beam));
-        hipLaunchKernelGGL(kern, dim3(N), dim3(64), lds_beam, stream, ba);
+        hipLaunchKernelGGL(kern, dim3((N + cpw - 1) / cpw), dim3(64 * cpw), lds_beam, stream, ba);
         return 0;
     };
     int lrc = -2;
     switch (state_len * 2 + (dbg ? 1 : 0)) {
-        case 2: lrc = launch_beam(beam_kernel<1, false>); break;
-        case 3: lrc = launch_beam(beam_kernel<1, true>); break;
-        case 4: lrc = launch_beam(beam_kernel<2, false>); break;
-        case 5: lrc = launch_beam(beam_kernel<2, true>); break;
-        case 6: lrc = launch_beam(beam_kernel<3, false>); break;
-        case 7: lrc = launch_beam(beam_kernel<3, true>); break;
-        case 8: lrc = launch_beam(beam_kernel<4, false>); break;
-        case 9: lrc = launch_beam(beam_kernel<4, true>); break;
-        case 10: lrc = launch_beam(beam_kernel<5, false>); break;
-        case 11: lrc = launch_beam(beam_kernel<5, true>); break;
+        case 2: lrc = launch_beam(beam_kernel<1, 4, false>, 4, beam_wave_lds<1>()); break;
+        case 3: lrc = launch_beam(beam_kernel<1, 4, true>, 4, beam_wave_lds<1>()); break;
+        case 4: lrc = launch_beam(beam_kernel<2, 4, false>, 4, beam_wave_lds<2>()); break;
+        case 5: lrc = launch_beam(beam_kernel<2, 4, true>, 4, beam_wave_lds<2>()); break;
+        case 6: lrc = launch_beam(beam_kernel<3, 4, false>, 4, beam_wave_lds<3>()); break;
+        case 7: lrc = launch_beam(beam_kernel<3, 4, true>, 4, beam_wave_lds<3>()); break;
+        case 8: lrc = launch_beam(beam_kernel<4, 1, false>, 1, beam_wave_lds<4>()); break;
+        case 9: lrc = launch_beam(beam_kernel<4, 1, true>, 1, beam_wave_lds<4>()); break;
+        case 10: lrc = launch_beam(beam_kernel<5, 1, false>, 1, beam_wave_lds<5>()); break;
+        case 11: lrc = launch_beam(beam_kernel<5, 1, true>, 1, beam_wave_lds<5>()); break;
     }
     if (lrc) return lrc;
     if (fork) BH_CHECK_HIP(hipStreamWaitEvent(stream, side->join, 0));

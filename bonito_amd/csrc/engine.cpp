@@ -526,8 +526,9 @@ extern "C" int bh_encoder_create(const bh_layer_t* layers, int n_layers, int dev
             prev_kind = l.d.kind;
         }
         if (e->n_act == 3) {
+            // (the side stream itself is created on first use: a stream that exists but idles still takes a slot in the
+            // round-robin mapping of streams onto hardware queues, which multi-lane runs of narrow models notice)
             if (e->act[2].alloc(ab + 256) || hipMemset(e->act[2].p, 0, e->act[2].bytes) != hipSuccess ||
-                hipStreamCreateWithFlags(&e->fill_stream, hipStreamNonBlocking) != hipSuccess ||
                 hipEventCreateWithFlags(&e->fill_ready, hipEventDisableTiming) != hipSuccess ||
                 hipEventCreateWithFlags(&e->fill_done, hipEventDisableTiming) != hipSuccess) {
                 bh_set_error("encoder_create: sentinel pre-fill resources");
@@ -707,6 +708,7 @@ extern "C" int bh_encoder_forward(bh_encoder_t* e, const void* signal, int N, in
                     for (size_t j = i + 1; j < nl && !nx; ++j)
                         if (e->layers[j].d.kind == BH_LAYER_LSTM) nx = &e->layers[j];
                     if (nx && !lstm_path(e, *nx).cta) {
+                        if (!e->fill_stream) BH_CHECK_HIP(hipStreamCreateWithFlags(&e->fill_stream, hipStreamNonBlocking));
                         void* spare = e->act[(which + 1) % 3].p;
                         BH_CHECK_HIP(hipEventRecord(e->fill_ready, st));
                         BH_CHECK_HIP(hipStreamWaitEvent(e->fill_stream, e->fill_ready, 0));
