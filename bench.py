@@ -61,6 +61,8 @@ def parse():
                          "default 1; 3 for the narrow `fast` model whose kernels leave most CUs idle (1 lane 8.9 ms/step, "
                          "3 lanes 4.5 with GPU_MAX_HW_QUEUES=8); hac / sup kernels fill the chip and gain nothing")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--set", action="append", default=[], metavar="NAME=VALUE",
+                    help="library tuning option (bh_set_option), e.g. beam_fork=1; for A/B runs, not part of the contract")
     a = ap.parse_args()
     a.batch = a.batch or (256 if a.model in ("sup", "sup_lstm") else 512)
     a.chunk = a.chunk or (12000 if a.model == "sup" else 20000 if a.model == "sup_lstm" else 10000)
@@ -153,6 +155,9 @@ def main():
     from bonito_amd import decode, synthetic
     from bonito_amd.util import limit_host_threads
     log("host threads: %d" % limit_host_threads(4))
+    for kv in a.set:
+        name, _, value = kv.partition("=")
+        decode.set_option(name, int(value))
     log("building model %s" % a.model)
     model = build_model(a.model, a.batch, a.chunk)
     model.use_koi(batchsize=a.batch, chunksize=a.chunk, quantize=False)

@@ -110,7 +110,9 @@ int bh_encoder_output_shape(const bh_encoder_t* enc, int L, int* T, int* C, int*
 /* signal: device fp16 [N][L] (the reference's [N,1,L] batch, bonito/crf/basecall.py:33).
  * scores: device fp16, contiguous [N][T][C] (the layout koi.decode.beam_search consumes). */
 int bh_encoder_forward(bh_encoder_t* enc, const void* signal, int N, int L, void* scores, void* stream);
-/* tuning / test options: "lstm_force_slow" (0/1), "lstm_fused" (0/1, default 1: input projection inside the recurrence) */
+/* tuning / test options (results never change): "lstm_fused" (3 default: narrowest applicable fused kernel; 2, 1, 0 = older
+ * variants down to projection-by-GEMM), "lstm_force_slow" (0/1: write-through exchange), "lstm_wide" (1/0), "lstm_prefill"
+ * (1 default: sentinel fill of the next recurrent layer's buffer on a side stream), "attn_ring" (1/0), "lstm_tune" (bit mask) */
 int bh_encoder_set_option(bh_encoder_t* enc, const char* name, int value);
 /* debug: read back the LSTM workspace (XCD agreement slots, per-wave cycle statistics when lstm_tune bit 2 is set) */
 int bh_encoder_debug_read(bh_encoder_t* enc, void* host, size_t bytes, size_t offset);
@@ -166,6 +168,8 @@ int bh_signal_chunks(const int16_t* raw, const long* offsets, const float* cal_s
 /* Process-wide knobs (measurement / tuning hooks, no reference counterpart).
  *   "beam_fork": -1 auto (default), 0 = run the posterior scan behind the beam kernel on the caller's stream,
  *                1 = run it next to the beam kernel on an internal helper stream (joined before finalize).
+ *   "beam_select": 0 (default) = top-W selection by histogram + exact boundary ranking, 1 = MSB-first radix search
+ *                (the same beams either way; kept for regression tests and A/B timing).
  *   "gemm_path": 0 auto (default), 1 = register-staged 128x128x64 kernel only, 2 = never the persistent 256x256x64 kernel. */
 int bh_set_option(const char* name, int value);
 
