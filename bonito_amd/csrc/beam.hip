@@ -329,7 +329,7 @@ struct BeamArgs {
                            // turns the selection into the plain radix search (bh_set_option("beam_select", 1))
 };
 
-constexpr int BTB = 8;     // steps staged per LDS block
+constexpr int BTB = 4;     // steps per staged block; two blocks are resident (the next one streams in under the current one)
 constexpr int MAXW = 32;
 
 __device__ __forceinline__ unsigned bs_hash0(int s) { return ((unsigned)s + 1u) * 2654435761u; }
@@ -553,6 +553,12 @@ __device__ __forceinline__ unsigned bucket_match(const uint4_t& e0, unsigned has
     return d;
 }
 
+// One 1 KiB global -> LDS DMA: lane l moves 16 bytes from g (per lane) to lds + 16 l (lds is wave-uniform).
+__device__ __forceinline__ void dma16(const char* g, char* lds) {
+    const unsigned l = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)(__attribute__((address_space(3))) char*)lds);
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(l), "v"(g) : "memory");
+}
+
 // lse2_tab without control flow (same arithmetic): safe for garbage `b` as long as the result is discarded
 __device__ __forceinline__ float lse2_tab_nb(float a, float b, const float* tab) {
     const float m = fmaxf(a, b);
@@ -575,7 +581,7 @@ __device__ __forceinline__ float lse2_tab_nb(float a, float b, const float* tab)
 template <int STATE_LEN>
 __host__ __device__ constexpr int beam_wave_lds() {
     constexpr int S = 1 << (2 * STATE_LEN);
-    return BTB * 4 * S * 2 + BTB * S * 4 + NBK * BKE * 8 + MAXW * (16 + 8 + 8) + (NBK + 4) * 4 + BTB * MAXW;
+    return 2 * (BTB * 4 * S * 2 + BTB * S * 4) + NBK * BKE * 8 + MAXW * (16 + 8 + 8) + (NBK + 4) * 4 + BTB * MAXW;
 }
 constexpr int BEAM_TAB_LDS = (BH_LSE_TABLE_SIZE + 2) * 4;
 
@@ -596,10 +602,10 @@ __global__ __launch_bounds__(64 * CPW) __attribute__((amdgpu_waves_per_eu(1, 8))
     __syncthreads();
     if (n >= p.N) return;
     char* mine = smem + BEAM_TAB_LDS + wave * beam_wave_lds<STATE_LEN>();
-    half_t* st_sc = (half_t*)mine;                       // [BTB][4S]
-    float* st_b = (float*)(st_sc + BTB * 4 * S);         // [BTB][S]
+    half_t* st_sc = (half_t*)mine;                       // [2][BTB][4S]
+    float* st_b = (float*)(st_sc + 2 * BTB * 4 * S);     // [2][BTB][S]
     BeamTable tb;
-    tb.ent = (uint2_t*)(st_b + BTB * S);                 // [NBK][BKE], 16-byte aligned
+    tb.ent = (uint2_t*)(st_b + 2 * BTB * S);             // [NBK][BKE], 16-byte aligned
     uint4_t* b_elem = (uint4_t*)(tb.ent + NBK * BKE);    // [32] beam element: state, hash, score bits, -
     uint2_t* m_pair = (uint2_t*)(b_elem + MAXW);         // [32] merged-in move: score bits, info (or -1)
     tb.ov = m_pair + MAXW;                               // [32]
@@ -676,31 +682,38 @@ __global__ __launch_bounds__(64 * CPW) __attribute__((amdgpu_waves_per_eu(1, 8))
         nb = before;
     }
 
-    for (int tb0 = 0; tb0 < T; tb0 += BTB) {
+    // Staging: score rows tb0..tb0+nsteps-1 and guide rows tb0+1..tb0+nsteps of a block go global -> LDS by DMA, 1 KiB per
+    // instruction, into the buffer the previous block is not using; the block after the current one is requested before
+    // the current one is processed, so its latency hides under four beam steps. The DMA is issued from inline assembly:
+    // the compiler then does not know of an outstanding LDS write and does not drain the memory queue before every LDS read.
+    auto stage = [&](int tb0, int which) {
         const int nsteps = min(BTB, T - tb0);
-        // ---- stage score rows tb0..tb0+nsteps-1 and guide rows tb0+1..tb0+nsteps --------------------
-        {   // global -> LDS DMA, 1 KiB per instruction, all of them in flight before the single wait (a register round trip
-            // per 1 KiB serialises on the memory latency: there is only this one wave to hide it)
+        const int n_sc = nsteps * S / 2;        // 16-byte units of score rows (4S halves per step)
+        const char* src = (const char*)(sc + (long)tb0 * 4 * S);
+        char* dsc = (char*)(st_sc + which * BTB * 4 * S);
+        for (int i0 = 0; i0 < n_sc; i0 += 64)
+            if (i0 + lane < n_sc) dma16(src + (long)(i0 + lane) * 16, dsc + i0 * 16);
+        const int n_b = nsteps * S / 4;         // 16-byte units of guide rows (S floats per step)
+        const char* bs = (const char*)(bn + (long)(tb0 + 1) * S);
+        char* dbt = (char*)(st_b + which * BTB * S);
+        for (int i0 = 0; i0 < n_b; i0 += 64)
+            if (i0 + lane < n_b) dma16(bs + (long)(i0 + lane) * 16, dbt + i0 * 16);
+    };
+    if (T > 0) stage(0, 0);
+    for (int tb0 = 0, blk = 0; tb0 < T; tb0 += BTB, ++blk) {
+        const int nsteps = min(BTB, T - tb0);
+        {
             long long ts0 = 0;
             if (DBG) ts0 = __builtin_readcyclecounter();
-            const int n_sc = nsteps * S / 2;        // 16-byte units of score rows (4S halves per step)
-            const char* src = (const char*)(sc + (long)tb0 * 4 * S);
-            for (int i0 = 0; i0 < n_sc; i0 += 64)
-                if (i0 + lane < n_sc)
-                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (long)(i0 + lane) * 16),
-                                                     (__attribute__((address_space(3))) void*)((char*)st_sc + i0 * 16), 16, 0, 0);
-            const int n_b = nsteps * S / 4;         // 16-byte units of guide rows (S floats per step)
-            const char* bs = (const char*)(bn + (long)(tb0 + 1) * S);
-            for (int i0 = 0; i0 < n_b; i0 += 64)
-                if (i0 + lane < n_b)
-                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(bs + (long)(i0 + lane) * 16),
-                                                     (__attribute__((address_space(3))) void*)((char*)st_b + i0 * 16), 16, 0, 0);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // wave-private buffers: no workgroup barrier
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this block has landed (wave-private buffers: no barrier)
             if (DBG) dsec[5] += __builtin_readcyclecounter() - ts0;
+            if (tb0 + BTB < T) stage(tb0 + BTB, (blk + 1) & 1);  // (everything read from that buffer was consumed a block ago)
         }
+        const half_t* blk_sc = st_sc + (blk & 1) * BTB * 4 * S;
+        const float* blk_b = st_b + (blk & 1) * BTB * S;
         for (int u = 0; u < nsteps; ++u) {
-            const half_t* row = st_sc + u * 4 * S;
-            const float* b1 = st_b + u * S;
+            const half_t* row = blk_sc + u * 4 * S;
+            const float* b1 = blk_b + u * S;
             const unsigned tag = ((unsigned)(tb0 + u) & TAG_MASK) << 15;            // of the table built for this step
             const unsigned tag_next = ((unsigned)(tb0 + u + 1) & TAG_MASK) << 15;
             long long tc0 = 0;
