@@ -41,6 +41,14 @@ __device__ __forceinline__ float lse2_tab(float a, float b, const float* tab) {
     return m + sp;
 }
 
+// wave-wide max without LDS traffic: DPP butterflies inside each row of 16 lanes, then row broadcasts;
+// the total ends up in lane 63 (classic GCN reduction, valid on the gfx9 family incl. gfx950).
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_f(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v),
+                                                                CTRL, ROW_MASK, 0xF, false));
+}
+
 // ------------------------------------------------------------------------------------------------
 struct ScanArgs {
     const half_t* scores;  // [N][T][4S]
@@ -132,11 +140,14 @@ __global__ void crf_backward_kernel(ScanArgs p) {
     }
 }
 
+// PB: prefetch the guide offsets B_t with the scores (8 more registers per SU; at 1024 threads per workgroup that crosses the
+// 64-register line below which two workgroups share a CU, so the 1024-state instantiation reads B_t inside the step).
+template <bool PB>
 __global__ void crf_forward_post_kernel(ScanArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* tab = (float*)smem;
     float* buf = tab + BH_LSE_TABLE_SIZE + 2;   // [2][S]
-    float* part = buf + 2 * p.S;                // [2][waves][4] class partial sums
+    float* part = buf + 2 * p.S;                // [2][4 classes][16 waves] class partial sums (16-byte aligned: S % 4 == 0)
     const int S = p.S, T = p.T, q = S >> 2;
     const int n = blockIdx.x, j = threadIdx.x;
     const bool active = j < S;
@@ -150,23 +161,27 @@ __global__ void crf_forward_post_kernel(ScanArgs p) {
     float* Pn = p.P + (long)n * T * 4;
     __syncthreads();
 
+    // everything a step needs from global memory is requested SU steps ahead: the score quad, the guide value and the
+    // running guide offset B_t (one fp64 per step; read inside the step it put an L2 round trip on the critical path)
     half4_t cur[SU], nxt[SU];
     float bcur[SU], bnxt[SU];
-    auto load = [&](half4_t (&dst)[SU], float (&bd)[SU], int t0) {
+    double Bcur[PB ? SU : 1], Bnxt[PB ? SU : 1];
+    auto load = [&](half4_t (&dst)[SU], float (&bd)[SU], double (&Bd)[PB ? SU : 1], int t0) {
 #pragma unroll
         for (int u = 0; u < SU; ++u) {
             int t = t0 + u;
             if (active && t < T) {
                 dst[u] = *(const half4_t*)(sc + (long)t * 4 * S);
                 bd[u] = bn[(long)(t + 1) * S + j];
+                if (PB) Bd[u] = Bn[t];
             }
         }
     };
     double A = 0.0;
     int cb = 0;
-    load(cur, bcur, 0);
+    load(cur, bcur, Bcur, 0);
     for (int t0 = 0; t0 < T; t0 += SU) {
-        load(nxt, bnxt, t0 + SU);
+        load(nxt, bnxt, Bnxt, t0 + SU);
 #pragma unroll
         for (int u = 0; u < SU; ++u) {
             const int t = t0 + u;
@@ -189,26 +204,36 @@ __global__ void crf_forward_post_kernel(ScanArgs p) {
                 const float now0 = now[0];
                 float pv = 0.0f;
                 if (active) {
-                    const double norm = lz - (A + (double)now0) - Bn[t];
+                    const double norm = lz - (A + (double)now0) - (PB ? Bcur[u] : Bn[t]);
                     pv = __expf((float)((double)(acc - now0) + (double)bcur[u] - norm));
                 }
-                // class sums: lanes with equal (lane & 3) are one class
-                pv += __shfl_xor(pv, 4);
-                pv += __shfl_xor(pv, 8);
+                // class sums: lanes with equal (lane & 3) are one class. Inside a row of 16 lanes two DPP rotations add the
+                // four lanes of a class, two shuffles add the four rows; the per-wave totals go to LDS class-major so that
+                // the four finishing threads read their waves' values as 16-byte vectors.
+                pv += dpp_f<0x124, 0xF>(pv);     // row_ror:4
+                pv += dpp_f<0x128, 0xF>(pv);     // row_ror:8
                 pv += __shfl_xor(pv, 16);
                 pv += __shfl_xor(pv, 32);
-                float* slot = part + ((t & 1) * nwaves + wave) * 4;
-                if (lane < 4) slot[lane] = pv;
+                float* slot = part + (t & 1) * 64;            // [4 classes][16 waves]
+                if (lane < 4) slot[lane * 16 + wave] = pv;
                 __syncthreads();
                 if (threadIdx.x < 4) {
+                    const float* mine = slot + threadIdx.x * 16;
                     float tot = 0.0f;
-                    for (int w = 0; w < nwaves; ++w) tot += part[((t & 1) * nwaves + w) * 4 + threadIdx.x];
+                    if (nwaves >= 4) {
+                        for (int w = 0; w < nwaves; w += 4) {
+                            const float4_t v = *(const float4_t*)(mine + w);
+                            tot += (v.x + v.y) + (v.z + v.w);
+                        }
+                    } else {
+                        for (int w = 0; w < nwaves; ++w) tot += mine[w];
+                    }
                     Pn[(long)t * 4 + threadIdx.x] = tot;
                 }
             }
         }
 #pragma unroll
-        for (int u = 0; u < SU; ++u) { cur[u] = nxt[u]; bcur[u] = bnxt[u]; }
+        for (int u = 0; u < SU; ++u) { cur[u] = nxt[u]; bcur[u] = bnxt[u]; if (PB) Bcur[u] = Bnxt[u]; }
     }
 }
 
@@ -401,13 +426,6 @@ __device__ __forceinline__ int radix_select(const unsigned (&uk)[3], int want, i
     return before;
 }
 
-// wave-wide max without LDS traffic: DPP butterflies inside each row of 16 lanes, then row broadcasts;
-// the total ends up in lane 63 (classic GCN reduction, valid on the gfx9 family incl. gfx950).
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ float dpp_f(float v) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v),
-                                                                CTRL, ROW_MASK, 0xF, false));
-}
 __device__ __forceinline__ float wave_max_f32(float v) {
     v = fmaxf(v, dpp_f<0xB1, 0xF>(v));     // quad_perm [1,0,3,2]
     v = fmaxf(v, dpp_f<0x4E, 0xF>(v));     // quad_perm [2,3,0,1]
@@ -964,7 +982,7 @@ int bh_k_crf_logz(const void* scores, int N, int T, int state_len, float blank, 
     double* Bcum = (double*)w;
     ScanArgs sa{(const half_t*)scores, N, T, S, state_len, blank, beta, Bcum, logz_out, nullptr};
     const int threads = S < 64 ? 64 : S;
-    const size_t lds_scan = (size_t)(BH_LSE_TABLE_SIZE + 2 + 2 * S + 2 * 16 * 4 + 8) * sizeof(float) + (size_t)2 * 4 * S * 2;
+    const size_t lds_scan = (size_t)(BH_LSE_TABLE_SIZE + 2 + 2 * S + 2 * 16 * 16 + 8) * sizeof(float) + (size_t)2 * 4 * S * 2;
     hipLaunchKernelGGL(crf_backward_kernel, dim3(N), dim3(threads), lds_scan, stream, sa);
     BH_CHECK_HIP(hipGetLastError());
     return 0;
@@ -990,7 +1008,7 @@ int bh_k_posterior_viterbi(const void* scores, int N, int T, int state_len, floa
     uint8_t* bp = (uint8_t*)workspace + bh_k_beam_workspace(N, T, state_len);
     ScanArgs sa{(const half_t*)scores, N, T, S, state_len, blank, beta, Bcum, logZ, nullptr};
     const int threads = S < 64 ? 64 : S;
-    const size_t lds_scan = (size_t)(BH_LSE_TABLE_SIZE + 2 + 2 * S + 2 * 16 * 4 + 8) * sizeof(float) + (size_t)2 * 4 * S * 2;
+    const size_t lds_scan = (size_t)(BH_LSE_TABLE_SIZE + 2 + 2 * S + 2 * 16 * 16 + 8) * sizeof(float) + (size_t)2 * 4 * S * 2;
     hipLaunchKernelGGL(crf_backward_kernel, dim3(N), dim3(threads), lds_scan, stream, sa);
     PostVitArgs pa{sa, bp, moves, path};
     int TB = (32 * 1024) / S; if (TB > 512) TB = 512; if (TB < 1) TB = 1;
@@ -1048,7 +1066,7 @@ int bh_k_beam_search(const void* scores, int N, int T, int state_len, int beam_w
 
     ScanArgs sa{(const half_t*)scores, N, T, S, state_len, blank, beta, Bcum, logZ, P};
     const int threads = S < 64 ? 64 : S;
-    const size_t lds_scan = (size_t)(BH_LSE_TABLE_SIZE + 2 + 2 * S + 2 * 16 * 4 + 8) * sizeof(float) + (size_t)2 * 4 * S * 2;
+    const size_t lds_scan = (size_t)(BH_LSE_TABLE_SIZE + 2 + 2 * S + 2 * 16 * 16 + 8) * sizeof(float) + (size_t)2 * 4 * S * 2;
     hipLaunchKernelGGL(crf_backward_kernel, dim3(N), dim3(threads), lds_scan, stream, sa);
     // The forward/posterior scan and the beam kernel both depend only on the backward scan and both are latency chains over T
     // (one workgroup / one wave per chunk): run them side by side - the posterior scan on a per-device helper stream forked
@@ -1059,7 +1077,10 @@ int bh_k_beam_search(const void* scores, int N, int T, int state_len, int beam_w
         BH_CHECK_HIP(hipEventRecord(side->fork, stream));
         BH_CHECK_HIP(hipStreamWaitEvent(side->stream, side->fork, 0));
     }
-    hipLaunchKernelGGL(crf_forward_post_kernel, dim3(N), dim3(threads), lds_scan, fork ? side->stream : stream, sa);
+    if (S <= 256)
+        hipLaunchKernelGGL(crf_forward_post_kernel<true>, dim3(N), dim3(threads), lds_scan, fork ? side->stream : stream, sa);
+    else
+        hipLaunchKernelGGL(crf_forward_post_kernel<false>, dim3(N), dim3(threads), lds_scan, fork ? side->stream : stream, sa);
     if (fork) BH_CHECK_HIP(hipEventRecord(side->join, side->stream));
     BeamArgs ba{(const half_t*)scores, beta, N, T, S, state_len, beam_width, blank, logf(beam_cut), bp, fin, dbg,
                 g_beam_select ? 0.0f : 256.0f / fmaxf(logf(beam_cut), 1e-6f)};
