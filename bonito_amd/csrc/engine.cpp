@@ -639,6 +639,25 @@ extern "C" int bh_encoder_forward(bh_encoder_t* e, const void* signal, int N, in
     int len = L, C = 1, which = 0;
     bool res_ready = false;
     const size_t nl = e->layers.size();
+    // Sentinel pre-fill for the recurrent layer that follows layer i (whose output buffer is act[which]): the buffer after
+    // it in the rotation is free once everything queued so far has run, so it is filled on the side stream while layer i's
+    // own kernels run. The next layer writes H_next features per (t, n) row into it.
+    auto prefill_next = [&](size_t i, int which, size_t rows) -> int {
+        if (e->n_act != 3 || !e->lstm_prefill || e->profiling) return 0;
+        const Layer* nx = nullptr;
+        for (size_t j = i + 1; j < nl && !nx; ++j)
+            if (e->layers[j].d.kind == BH_LAYER_LSTM) nx = &e->layers[j];
+        if (!nx || lstm_path(e, *nx).cta) return 0;
+        if (!e->fill_stream) BH_CHECK_HIP(hipStreamCreateWithFlags(&e->fill_stream, hipStreamNonBlocking));
+        void* spare = e->act[(which + 1) % 3].p;
+        BH_CHECK_HIP(hipEventRecord(e->fill_ready, st));
+        BH_CHECK_HIP(hipStreamWaitEvent(e->fill_stream, e->fill_ready, 0));
+        const int rc = bh_k_fill_u16(spare, 0xFFFFu, rows * nx->d.out_size, e->fill_stream);
+        if (rc) return rc;
+        BH_CHECK_HIP(hipEventRecord(e->fill_done, e->fill_stream));
+        e->prefilled = spare;
+        return 0;
+    };
     for (size_t i = 0; i < nl; ++i) {
         Layer& l = e->layers[i];
         const bh_layer_t& d = l.d;
@@ -659,6 +678,7 @@ extern "C" int bh_encoder_forward(bh_encoder_t* e, const void* signal, int N, in
                 const long os_n = tnc ? co : (long)lout * co;
                 const long os_t = tnc ? (long)Np * co : co;
                 int rc;
+                if (tnc) { rc = prefill_next(i, which, (size_t)lout * Np); if (rc) return rc; }
                 ProfSpan span(e, st, BH_PROF_CONV);
                 if (l.pointwise && !tnc) {
                     const void* rsd = d.add_residual ? e->res.p : nullptr;
@@ -701,23 +721,7 @@ extern "C" int bh_encoder_forward(bh_encoder_t* e, const void* signal, int N, in
                     }
                 }
                 e->prefilled = nullptr;
-                if (e->n_act == 3 && e->lstm_prefill && !e->profiling && next_kind == BH_LAYER_LSTM) {
-                    // The buffer after dst in the rotation was the previous layer's input: free once everything queued so
-                    // far has run. The next layer writes H_next features per (t, n) row into it.
-                    const Layer* nx = nullptr;
-                    for (size_t j = i + 1; j < nl && !nx; ++j)
-                        if (e->layers[j].d.kind == BH_LAYER_LSTM) nx = &e->layers[j];
-                    if (nx && !lstm_path(e, *nx).cta) {
-                        if (!e->fill_stream) BH_CHECK_HIP(hipStreamCreateWithFlags(&e->fill_stream, hipStreamNonBlocking));
-                        void* spare = e->act[(which + 1) % 3].p;
-                        BH_CHECK_HIP(hipEventRecord(e->fill_ready, st));
-                        BH_CHECK_HIP(hipStreamWaitEvent(e->fill_stream, e->fill_ready, 0));
-                        rc = bh_k_fill_u16(spare, 0xFFFFu, (size_t)M * nx->d.out_size, e->fill_stream);
-                        if (rc) return rc;
-                        BH_CHECK_HIP(hipEventRecord(e->fill_done, e->fill_stream));
-                        e->prefilled = spare;
-                    }
-                }
+                if (next_kind == BH_LAYER_LSTM) { rc = prefill_next(i, which, (size_t)M); if (rc) return rc; }
                 ProfSpan span(e, st, BH_PROF_LSTM_REC);
                 // co-residency: one launch serves at most (CUs / (8 * H/16)) * 32 rings
                 const int nsl = H / 16;
