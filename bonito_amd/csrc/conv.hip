@@ -15,6 +15,7 @@
 //    this folds nn.Permute([2,0,1]), nn.py:331-338, into the store).
 #include "common.h"
 #include "kernels.h"
+#include <cstring>
 
 namespace bh {
 
@@ -152,6 +153,105 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
     }
 }
 
+// Weight-stationary variant for wide output layers (hac conv3: 16 -> 384 channels, 19 taps): the eight waves of a
+// workgroup split the feature tiles (FPW each) and keep their weight fragments in registers for the whole block of 256
+// output positions; every wave walks the 16 position tiles, reading each tile's NKS input fragments from LDS once and
+// using them for FPW MFMAs each. There is no global load inside the loop, so nothing ever waits on `vmcnt` and the output
+// stores stream out behind the arithmetic (in conv_igemm_kernel the wait for the next tile's weights also drains the
+// previous tile's stores: loads and stores share one in-order counter on gfx950). Same accumulation order as
+// conv_igemm_kernel (k-steps ascending into one accumulator), so the two kernels give identical bytes.
+template <int FPW, int NKS>
+__global__ __launch_bounds__(512) void conv_ws_kernel(ConvArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    half_t* xin = (half_t*)smem;
+    constexpr int PB = 256;                    // positions per workgroup = 16 tiles of 16
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 15, kg = lane >> 4;
+    const int n = blockIdx.y;
+    const int t0 = blockIdx.x * PB;
+
+    // this wave's weight fragments: FPW feature tiles x NKS k-steps (requested first, they land during the staging)
+    half8_t afr[FPW][NKS];
+#pragma unroll
+    for (int f = 0; f < FPW; ++f) {
+        const half_t* wrow = p.wpk + (long)((wave * FPW + f) * 16 + r) * p.Kp + kg * 8;
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) afr[f][ks] = *(const half8_t*)(wrow + ks * 32);
+    }
+    float4_t bv[FPW];
+#pragma unroll
+    for (int f = 0; f < FPW; ++f) {
+        bv[f] = float4_t{0.f, 0.f, 0.f, 0.f};
+        if (p.bias) bv[f] = *(const float4_t*)(p.bias + (wave * FPW + f) * 16 + kg * 4);
+    }
+
+    // ---- stage the contiguous input span (zero outside [0, Lin)), as conv_igemm_kernel ----------
+    const int span_pos = (PB - 1) * p.stride + p.K;
+    const int span_halves = span_pos * p.Cin + 32 + 8;
+    const int p_start = t0 * p.stride - p.pad;
+    const half_t* src = p.in + (long)n * p.Lin * p.Cin;
+    for (int e = tid * 8; e < span_halves; e += 512 * 8) {
+        int pos = p_start + e / p.Cin;
+        uint4_t v = {0, 0, 0, 0};
+        if (pos >= 0 && pos < p.Lin && e < span_pos * p.Cin)
+            v = *(const uint4_t*)(src + (long)pos * p.Cin + (e % p.Cin));
+        *(uint4_t*)(xin + e) = v;
+    }
+    __syncthreads();
+
+    const int RS = p.stride * p.Cin;
+    for (int pt = 0; pt < PB / 16; ++pt) {
+        const int t = t0 + pt * 16 + r;
+        if (t0 + pt * 16 >= p.Lout) break;
+        const half_t* xrow = xin + (pt * 16 + r) * RS + kg * 8;
+        half8_t b[NKS];
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) b[ks] = *(const half8_t*)(xrow + ks * 32);
+        float4_t acc[FPW];
+#pragma unroll
+        for (int f = 0; f < FPW; ++f) acc[f] = float4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks)
+#pragma unroll
+            for (int f = 0; f < FPW; ++f) acc[f] = mfma16(afr[f][ks], b[ks], acc[f]);
+#pragma unroll
+        for (int f = 0; f < FPW; ++f)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) acc[f][g] += bv[f][g];
+        switch (p.act) {
+            case ACT_SWISH:
+#pragma unroll
+                for (int f = 0; f < FPW; ++f)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) acc[f][g] = swishf_(acc[f][g]);
+                break;
+            case ACT_TANH:
+#pragma unroll
+                for (int f = 0; f < FPW; ++f)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) acc[f][g] = tanhf_(acc[f][g]);
+                break;
+            case ACT_RELU:
+#pragma unroll
+                for (int f = 0; f < FPW; ++f)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) acc[f][g] = fmaxf(acc[f][g], 0.0f);
+                break;
+            default: break;
+        }
+        if (t < p.Lout) {
+            half_t* drow = p.out + (long)n * p.os_n + (long)t * p.os_t + kg * 4;
+#pragma unroll
+            for (int f = 0; f < FPW; ++f) {
+                half4_t o;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) o[g] = (half_t)fminf(fmaxf(acc[f][g], p.clamp_lo), p.clamp_hi);
+                *(half4_t*)(drow + (wave * FPW + f) * 16) = o;
+            }
+        }
+    }
+}
+
 }  // namespace bh
 
 int bh_k_conv_first(const void* signal, const float* w, const float* bias, void* out, int N, int Lin,
@@ -168,6 +268,12 @@ int bh_k_conv_first(const void* signal, const float* w, const float* bias, void*
     return 0;
 }
 
+int g_conv_ws = 1;      // bh_set_option("conv_ws", 0): always the generic implicit-GEMM kernel (A/B, regression tests)
+int bh_k_conv_set_option(const char* name, int value) {
+    if (name && !strcmp(name, "conv_ws")) { g_conv_ws = value; return 0; }
+    return 1;
+}
+
 int bh_k_conv_igemm(const void* in, const void* wpk, const float* bias, void* out, int N, int Lin,
                     int Lout, int Cin, int Cout, int K, int stride, int pad, int act, float clamp_lo,
                     float clamp_hi, long os_n, long os_t, hipStream_t stream) {
@@ -177,6 +283,12 @@ int bh_k_conv_igemm(const void* in, const void* wpk, const float* bias, void* ou
     ConvArgs a{(const half_t*)in, (const half_t*)wpk, bias, (half_t*)out, N, Lin, Lout, Cin, Cout, K,
                stride, pad, act, ((K * Cin + 31) / 32) * 32, clamp_lo, clamp_hi, os_n, os_t};
     auto lds_for = [&](int pw) { return (size_t)(((4 * pw - 1) * stride + K) * Cin + 40) * 2 + 16; };
+    // wide output layer with the k-step count of the bonito conv3 (19 taps x 16 channels): weight-stationary kernel
+    if (g_conv_ws && Cout == 384 && a.Kp == 320 && lds_for(64) <= 64 * 1024) {
+        hipLaunchKernelGGL((conv_ws_kernel<3, 10>), dim3((Lout + 255) / 256, N), dim3(512), lds_for(64), stream, a);
+        BH_CHECK_HIP(hipGetLastError());
+        return 0;
+    }
     int pw = 64;
     while (pw > 16 && lds_for(pw) > 64 * 1024) pw >>= 1;
     size_t lds = lds_for(pw);

@@ -1048,6 +1048,7 @@ extern "C" int bh_signal_chunks(const int16_t* raw, const long* offsets, const f
 extern "C" int bh_set_option(const char* name, int value) {
     BH_REQUIRE(name != nullptr, "set_option: null name");
     if (bh_k_decode_set_option(name, value) == 0) return 0;
+    if (bh_k_conv_set_option(name, value) == 0) return 0;
     if (!strcmp(name, "gemm_path")) { bh_k_linear_force_v1(value); return 0; }
     BH_REQUIRE(false, "set_option: unknown option '%s'", name);
     return -1;

@@ -76,6 +76,7 @@ size_t bh_k_posterior_viterbi_workspace(int N, int T, int state_len);
 int bh_k_posterior_viterbi(const void* scores, int N, int T, int state_len, float blank, void* workspace, int8_t* moves,
                            int8_t* path, hipStream_t stream);
 int bh_k_decode_set_option(const char* name, int value);
+int bh_k_conv_set_option(const char* name, int value);     // "conv_ws"
 int bh_k_linear_qkv_rotary(const void* X, const void* W, const float* bias, void* out, int M, int D, int K, const float* cos_sin,
                            int T, float qscale, hipStream_t stream);
 int bh_k_attention_prerotated(const void* qkv, void* out, int N, int T, int nhead, int head_dim, int win_left, int win_right,

@@ -170,6 +170,7 @@ int bh_signal_chunks(const int16_t* raw, const long* offsets, const float* cal_s
  *                1 = run it next to the beam kernel on an internal helper stream (joined before finalize).
  *   "beam_select": 0 (default) = top-W selection by histogram + exact boundary ranking, 1 = MSB-first radix search
  *                (the same beams either way; kept for regression tests and A/B timing).
+ *   "conv_ws": 1 (default) = weight-stationary kernel for the 384-channel / 19-tap convolution, 0 = generic implicit GEMM.
  *   "gemm_path": 0 auto (default), 1 = register-staged 128x128x64 kernel only, 2 = never the persistent 256x256x64 kernel. */
 int bh_set_option(const char* name, int value);
 

@@ -151,6 +151,33 @@ def test_conv_igemm(Cin, Cout, K, stride, L, tnc):
     assert (out.cpu().float() - want).abs().max().item() < 1.5e-2
 
 
+@pytest.mark.parametrize("tnc", [True, False])
+def test_conv_weight_stationary_kernel_equals_generic(tnc):
+    """hac conv3 shape (16 -> 384 channels, 19 taps, stride 6): the weight-stationary kernel (default) and the generic
+    implicit-GEMM kernel (bh_set_option "conv_ws" = 0) accumulate in the same order -> identical bytes; ragged last block."""
+    from bonito_amd import decode
+    g = torch.Generator().manual_seed(5)
+    N, Cin, Cout, K, stride, L = 5, 16, 384, 19, 6, 4000
+    x = (torch.randn(N, L, Cin, generator=g) * 0.7).half().to(dev())
+    w = (torch.randn(Cout, Cin, K, generator=g) * 0.06).half().float()
+    wpk, bd = _pack_conv(w), (torch.randn(Cout, generator=g) * 0.1).to(dev())
+    Lout = (L + 2 * (K // 2) - K) // stride + 1
+    os_n, os_t = (Cout, N * Cout) if tnc else (Lout * Cout, Cout)
+    outs = []
+    try:
+        for ws in (1, 0):
+            decode.set_option("conv_ws", ws)
+            out = torch.zeros(N * Lout * Cout, dtype=torch.float16, device=dev())
+            _lib.check(_lib.lib().bh_conv1d(_lib.ptr(x), _lib.ptr(wpk), _lib.ptr(bd), _lib.ptr(out), N, L, Cin, Cout, K, stride,
+                                            K // 2, 1, -0.5, 3.5, os_n, os_t, _lib.stream_ptr()), "conv1d")
+            torch.cuda.synchronize()
+            outs.append(out.cpu())
+    finally:
+        decode.set_option("conv_ws", 1)
+    assert torch.equal(outs[0], outs[1])
+    assert outs[0].float().abs().max().item() > 0.1
+
+
 def _lstm_ref(G, Whh, reverse):
     T, N, H4 = G.shape
     H = H4 // 4
