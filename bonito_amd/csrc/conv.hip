@@ -153,15 +153,15 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
     }
 }
 
-// Weight-stationary variant for wide output layers (hac conv3: 16 -> 384 channels, 19 taps): the eight waves of a
-// workgroup split the feature tiles (FPW each) and keep their weight fragments in registers for the whole block of 256
+// Weight-stationary variant for the layer that feeds the recurrent stack (conv3: 16 -> 384 channels in hac-sized models,
+// 16 -> 96 in fast-sized ones; 19 taps): the WAVES waves of a workgroup split the feature tiles (FPW each) and keep their weight fragments in registers for the whole block of 256
 // output positions; every wave walks the 16 position tiles, reading each tile's NKS input fragments from LDS once and
 // using them for FPW MFMAs each. There is no global load inside the loop, so nothing ever waits on `vmcnt` and the output
 // stores stream out behind the arithmetic (in conv_igemm_kernel the wait for the next tile's weights also drains the
 // previous tile's stores: loads and stores share one in-order counter on gfx950). Same accumulation order as
 // conv_igemm_kernel (k-steps ascending into one accumulator), so the two kernels give identical bytes.
-template <int FPW, int NKS>
-__global__ __launch_bounds__(512) void conv_ws_kernel(ConvArgs p) {
+template <int FPW, int NKS, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void conv_ws_kernel(ConvArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     half_t* xin = (half_t*)smem;
     constexpr int PB = 256;                    // positions per workgroup = 16 tiles of 16
@@ -190,7 +190,7 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(ConvArgs p) {
     const int span_halves = span_pos * p.Cin + 32 + 8;
     const int p_start = t0 * p.stride - p.pad;
     const half_t* src = p.in + (long)n * p.Lin * p.Cin;
-    for (int e = tid * 8; e < span_halves; e += 512 * 8) {
+    for (int e = tid * 8; e < span_halves; e += 64 * WAVES * 8) {
         int pos = p_start + e / p.Cin;
         uint4_t v = {0, 0, 0, 0};
         if (pos >= 0 && pos < p.Lin && e < span_pos * p.Cin)
@@ -284,8 +284,10 @@ int bh_k_conv_igemm(const void* in, const void* wpk, const float* bias, void* ou
                stride, pad, act, ((K * Cin + 31) / 32) * 32, clamp_lo, clamp_hi, os_n, os_t};
     auto lds_for = [&](int pw) { return (size_t)(((4 * pw - 1) * stride + K) * Cin + 40) * 2 + 16; };
     // wide output layer with the k-step count of the bonito conv3 (19 taps x 16 channels): weight-stationary kernel
-    if (g_conv_ws && Cout == 384 && a.Kp == 320 && lds_for(64) <= 64 * 1024) {
-        hipLaunchKernelGGL((conv_ws_kernel<3, 10>), dim3((Lout + 255) / 256, N), dim3(512), lds_for(64), stream, a);
+    if (g_conv_ws && (Cout == 384 || Cout == 96) && a.Kp == 320 && lds_for(64) <= 64 * 1024) {
+        const dim3 wgrid((Lout + 255) / 256, N);
+        if (Cout == 384) hipLaunchKernelGGL((conv_ws_kernel<3, 10, 8>), wgrid, dim3(512), lds_for(64), stream, a);
+        else hipLaunchKernelGGL((conv_ws_kernel<1, 10, 6>), wgrid, dim3(384), lds_for(64), stream, a);
         BH_CHECK_HIP(hipGetLastError());
         return 0;
     }

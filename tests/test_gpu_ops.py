@@ -151,13 +151,13 @@ def test_conv_igemm(Cin, Cout, K, stride, L, tnc):
     assert (out.cpu().float() - want).abs().max().item() < 1.5e-2
 
 
-@pytest.mark.parametrize("tnc", [True, False])
-def test_conv_weight_stationary_kernel_equals_generic(tnc):
-    """hac conv3 shape (16 -> 384 channels, 19 taps, stride 6): the weight-stationary kernel (default) and the generic
+@pytest.mark.parametrize("tnc,Cout", [(True, 384), (False, 384), (True, 96)])
+def test_conv_weight_stationary_kernel_equals_generic(tnc, Cout):
+    """conv3 shapes (16 -> 384 / 96 channels, 19 taps, stride 6): the weight-stationary kernel (default) and the generic
     implicit-GEMM kernel (bh_set_option "conv_ws" = 0) accumulate in the same order -> identical bytes; ragged last block."""
     from bonito_amd import decode
     g = torch.Generator().manual_seed(5)
-    N, Cin, Cout, K, stride, L = 5, 16, 384, 19, 6, 4000
+    N, Cin, K, stride, L = 5, 16, 19, 6, 4000
     x = (torch.randn(N, L, Cin, generator=g) * 0.7).half().to(dev())
     w = (torch.randn(Cout, Cin, K, generator=g) * 0.06).half().float()
     wpk, bd = _pack_conv(w), (torch.randn(Cout, generator=g) * 0.1).to(dev())
