@@ -157,7 +157,6 @@ struct ProfSpan {
     ~ProfSpan();
 };
 
-static inline int pad16(int n) { return (n + 15) / 16 * 16; }
 static inline int pad8(int n) { return (n + 7) / 8 * 8; }
 static inline int conv_out_len(int L, int K, int stride, int pad) { return (L + 2 * pad - K) / stride + 1; }
 
