@@ -42,7 +42,18 @@ def stitch_planes(planes, length, size, overlap, stride, reverse=False):
 
 
 def fmt_planes(stride, planes, rna=False):
-    return fmt(stride, {"sequence": planes[0], "qstring": planes[1], "moves": planes[2]}, rna)
+    """`fmt` for the stacked planes (sequence, qstring, moves) of one read. The decoders emit a base and a quality
+    exactly at the steps where moves == 1, so one index list serves both strings (a gather each instead of a mask
+    + compress each); anything else falls back to the generic per-plane `fmt` - same result either way."""
+    a = planes.numpy() if isinstance(planes, torch.Tensor) else np.asarray(planes)
+    idx = np.flatnonzero(a[2])
+    seq, qs = a[0][idx], a[1][idx]
+    if np.count_nonzero(a[0]) != idx.size or np.count_nonzero(a[1]) != idx.size or not seq.all() or not qs.all():
+        return fmt(stride, {"sequence": planes[0], "qstring": planes[1], "moves": planes[2]}, rna)
+    seq, qs = seq.view(np.uint8).tobytes().decode("ascii"), qs.view(np.uint8).tobytes().decode("ascii")
+    if rna:
+        seq, qs = seq[::-1], qs[::-1]
+    return {"stride": stride, "moves": a[2], "qstring": qs, "sequence": seq}
 
 
 def compute_scores(model, batch, beam_width=32, beam_cut=100.0, scale=1.0, offset=0.0, blank_score=2.0,

@@ -193,3 +193,23 @@ def test_signal_chunk_table_equals_util_chunk():
                     assert torch.equal(w, torch.arange(cs, dtype=torch.float32) % avail[row] + t0)
                 row += 1
         assert row == len(reads)
+
+
+@pytest.mark.parametrize("rna", [False, True])
+def test_fmt_planes_equals_fmt(rna):
+    # shared-index fast path (decoder outputs: base and quality exactly where moves == 1) and the generic fallback
+    from bonito_amd.crf.basecall import fmt, fmt_planes
+    rng = np.random.default_rng(3)
+    L = 5000
+    m = (rng.random(L) < 0.55).astype(np.int8)
+    seq = rng.choice(np.frombuffer(b"ACGT", np.int8), L) * m
+    qs = rng.integers(34, 83, L).astype(np.int8) * m
+    consistent = torch.from_numpy(np.stack([seq, qs, m]))
+    odd = consistent.clone()
+    odd[0, 17] = 0 if odd[0, 17] != 0 else 65          # a base without a move / a move without a base
+    empty = torch.zeros((3, 40), dtype=torch.int8)
+    for planes in (consistent, odd, empty):
+        want = fmt(6, {"sequence": planes[0], "qstring": planes[1], "moves": planes[2]}, rna)
+        got = fmt_planes(6, planes, rna)
+        assert got["sequence"] == want["sequence"] and got["qstring"] == want["qstring"] and got["stride"] == 6
+        assert np.array_equal(got["moves"], want["moves"])
