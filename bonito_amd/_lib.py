@@ -76,6 +76,8 @@ SIGNATURES = {
     "bh_attention": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "bh_rmsnorm_residual": (_i, [_vp, _vp, _vp, _vp, _l, _i, _f, _f, _vp]),
     "bh_lstm_pack_whh": (_i, [_vp, _i, _vp]),
+    "bh_host_compact": (_l, [_vp, _l, _vp]),
+    "bh_host_chunk_rows": (_l, [_vp, _l, _i, _i, _l, _l, _vp]),
     "bh_lstm_workspace": (_sz, [_i, _i]),
     "bh_lstm_layer": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _vp]),
     "bh_encoder_debug_read": (_i, [_vp, _vp, _sz, _sz]),

@@ -7,7 +7,7 @@ bonito/crf/basecall.py (stitch_results 13-24, compute_scores 27-45, fmt 48-55, b
 import numpy as np
 import torch
 
-from bonito_amd import decode as hip_decode
+from bonito_amd import _lib, decode as hip_decode
 from bonito_amd.decode import to_str
 from bonito_amd.multiprocessing import thread_iter
 from bonito_amd.util import chunk, stitch, batchify, unbatchify
@@ -42,15 +42,17 @@ def stitch_planes(planes, length, size, overlap, stride, reverse=False):
 
 
 def fmt_planes(stride, planes, rna=False):
-    """`fmt` for the stacked planes (sequence, qstring, moves) of one read. The decoders emit a base and a quality
-    exactly at the steps where moves == 1, so one index list serves both strings (a gather each instead of a mask
-    + compress each); anything else falls back to the generic per-plane `fmt` - same result either way."""
+    """`fmt` for the stacked planes (sequence, qstring, moves) of one read: the two strings are compacted by the
+    library's host helper (`bh_host_compact`, one pass each) instead of a numpy mask + compress + cast per string."""
     a = planes.numpy() if isinstance(planes, torch.Tensor) else np.asarray(planes)
-    idx = np.flatnonzero(a[2])
-    seq, qs = a[0][idx], a[1][idx]
-    if np.count_nonzero(a[0]) != idx.size or np.count_nonzero(a[1]) != idx.size or not seq.all() or not qs.all():
-        return fmt(stride, {"sequence": planes[0], "qstring": planes[1], "moves": planes[2]}, rna)
-    seq, qs = seq.view(np.uint8).tobytes().decode("ascii"), qs.view(np.uint8).tobytes().decode("ascii")
+    if a.dtype != np.int8 or not a.flags.c_contiguous:
+        a = np.ascontiguousarray(a, dtype=np.int8)
+    n = a.shape[1]
+    buf = np.empty((2, n), np.uint8)
+    src, dst = a.ctypes.data, buf.ctypes.data
+    compact = _lib.lib().bh_host_compact
+    n_seq, n_qs = compact(src, n, dst), compact(src + n, n, dst + n)
+    seq, qs = buf[0, :n_seq].tobytes().decode("ascii"), buf[1, :n_qs].tobytes().decode("ascii")
     if rna:
         seq, qs = seq[::-1], qs[::-1]
     return {"stride": stride, "moves": a[2], "qstring": qs, "sequence": seq}
@@ -161,9 +163,35 @@ def chunk_batches(reads, chunksize, overlap, batchsize, pin=False, nbuf=4):
         return b.pin_memory() if pin else b
 
     bufs = [new_buf() for _ in range(nbuf)]
+    buf_ptrs = [b.data_ptr() for b in bufs]
+    gather = _lib.lib().bh_host_chunk_rows
     cur, pos, keys = 0, 0, []
     for read in reads:
         sig = read.signal
+        if (isinstance(sig, np.ndarray) and sig.ndim == 1 and sig.dtype == np.float32 and sig.flags.c_contiguous
+                and 0 <= overlap < chunksize <= sig.shape[0]):
+            # the common case, in the library (one call per run of rows; ctypes drops the interpreter lock meanwhile):
+            # same rows as util.chunk, same round-to-nearest-even cast as .to(float16)
+            T = sig.shape[0]
+            key = (read, 0, T)
+            step = chunksize - overlap
+            stub = (T - overlap) % step
+            n_total = (T - stub - chunksize) // step + 1 + (1 if stub > 0 else 0)
+            src, lo = sig.ctypes.data, 0
+            while lo < n_total:
+                take = min(n_total - lo, batchsize - pos)
+                if gather(src, T, chunksize, overlap, lo, take, buf_ptrs[cur] + pos * chunksize * 2) != take:
+                    raise RuntimeError("bh_host_chunk_rows failed")
+                if keys and keys[-1][0] is key and keys[-1][1][1] == pos:
+                    keys[-1] = (key, (keys[-1][1][0], pos + take))
+                else:
+                    keys.append((key, (pos, pos + take)))
+                pos += take
+                lo += take
+                if pos == batchsize:
+                    yield tuple(keys), bufs[cur]
+                    cur, pos, keys = (cur + 1) % nbuf, 0, []
+            continue
         sig = torch.from_numpy(sig) if isinstance(sig, np.ndarray) else sig
         T = sig.shape[-1]
         key = (read, 0, T)
@@ -209,11 +237,13 @@ def basecall(model, reads, chunksize=4000, overlap=100, batchsize=32, reverse=Fa
     batches = thread_iter(chunk_batches(reads, chunksize, overlap, batchsize, pin=torch.cuda.is_available(), nbuf=8))
     encoded = thread_iter((keys, pipe.encode(batch)) for keys, batch in batches)
     scores = thread_iter((keys, pipe.decode(*enc)) for keys, enc in encoded)
-    results = thread_iter(
-        (read, stitch_planes(sc, end - start, chunksize, overlap, model.stride, reverse))
+    # Stitching and formatting run in the consumer's thread (the CLI's Writer thread): they cost ~40 us per read now, and
+    # every additional Python-heavy thread slows the others through the interpreter lock more than it adds (host-only
+    # ceiling of this pipeline, device stages stubbed: 1.6e8 samples/s with two more threads, 2.0e8 without).
+    return (
+        (read, fmt_planes(model.stride, stitch_planes(sc, end - start, chunksize, overlap, model.stride, reverse), rna))
         for ((read, start, end), sc) in unbatchify(scores, dim=1)
     )
-    return thread_iter((read, fmt_planes(model.stride, planes, rna)) for read, planes in results)
 
 
 def raw_chunk_batches(reads, chunksize, overlap, batchsize, device, group_samples=1 << 26, scaling_strategy=None,
@@ -282,8 +312,10 @@ def basecall_raw(model, reads, chunksize=4000, overlap=100, batchsize=32, revers
                                             norm_params=norm_params, do_trim=do_trim))
     encoded = thread_iter((keys, pipe.encode(batch)) for keys, batch in batches)
     scores = thread_iter((keys, pipe.decode(*enc)) for keys, enc in encoded)
-    results = thread_iter(
-        (read, stitch_planes(sc, end - start, chunksize, overlap, model.stride, reverse))
+    # Stitching and formatting run in the consumer's thread (the CLI's Writer thread): they cost ~40 us per read now, and
+    # every additional Python-heavy thread slows the others through the interpreter lock more than it adds (host-only
+    # ceiling of this pipeline, device stages stubbed: 1.6e8 samples/s with two more threads, 2.0e8 without).
+    return (
+        (read, fmt_planes(model.stride, stitch_planes(sc, end - start, chunksize, overlap, model.stride, reverse), rna))
         for ((read, start, end), sc) in unbatchify(scores, dim=1)
     )
-    return thread_iter((read, fmt_planes(model.stride, planes, rna)) for read, planes in results)

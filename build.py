@@ -42,7 +42,10 @@ def build_hip(force=False):
         obj = os.path.join(OBJ, s + ".o")
         objs.append(obj)
         if force or _newer(obj, [src] + hdrs):
-            cmd = [HIPCC] + FLAGS + EXTRA_FLAGS.get(s, []) + (["-x", "hip"] if s.endswith(".cpp") else []) + ["-c", src, "-o", obj]
+            # host*.cpp: plain C++ (host-only helpers with x86 intrinsics); other .cpp files carry HIP runtime calls
+            as_hip = s.endswith(".cpp") and not s.startswith("host")
+            flags = [f for f in FLAGS if as_hip or s.endswith(".hip") or not f.startswith("--offload-arch")]
+            cmd = [HIPCC] + flags + EXTRA_FLAGS.get(s, []) + (["-x", "hip"] if as_hip else []) + ["-c", src, "-o", obj]
             jobs.append(cmd)
 
     def run(cmd):

@@ -240,6 +240,13 @@ int bh_rmsnorm_residual(const void* a, const void* x, const float* w, void* out,
                         float eps, void* stream);
 /* recurrent weights: torch W_hh [4H][H] fp32 (host) -> MFMA-fragment order fp16 (host, 4*H*H halves) */
 int bh_lstm_pack_whh(const float* whh, int H, uint16_t* packed);
+/* host helper of the formatting stage = koi.decode.to_str before the text decode (bonito/crf/basecall.py:48-55): copies the
+ * non-zero bytes of src[0..n) to dst (capacity n) in order and returns how many there were. No device work. */
+long bh_host_compact(const int8_t* src, long n, char* dst);
+/* host helper of the chunking stage: rows [row0, row0 + nrows) of util.chunk(signal[0..T), chunksize, overlap)
+ * (bonito/util.py:142-161; T >= chunksize) cast to fp16 (round to nearest even) into dst[nrows][chunksize].
+ * Returns nrows, or < 0 on bad arguments. No device work. */
+long bh_host_chunk_rows(const float* signal, long T, int chunksize, int overlap, long row0, long nrows, uint16_t* dst);
 /* one LSTM layer over gates_in = x W_ih^T + b (fp16 [T][N][4H], torch gate order); h_out fp16 [T][N][H].
  * N % 16 == 0.  workspace: bh_lstm_workspace(N, H) device bytes.  err_flag: device int, set non-zero on a
  * device-side timeout.  flags bit 0: force the placement-independent write-through exchange policy;

@@ -213,3 +213,23 @@ def test_fmt_planes_equals_fmt(rna):
         got = fmt_planes(6, planes, rna)
         assert got["sequence"] == want["sequence"] and got["qstring"] == want["qstring"] and got["stride"] == 6
         assert np.array_equal(got["moves"], want["moves"])
+
+
+def test_host_chunk_rows_cast_equals_torch_half():
+    # the library's chunk gather: same rows as util.chunk, same fp32 -> fp16 rounding as torch (ties, subnormals, overflow)
+    import ctypes as C
+    from bonito_amd import _lib
+    rng = np.random.default_rng(11)
+    special = np.array([0.0, -0.0, 1.0, 65504.0, 65519.9, 65520.0, 1e6, -1e6, np.inf, -np.inf, 6.1e-5, 6.0e-5, 5.96e-8, 2.98e-8,
+                        2.9802322e-8, 3e-8, 1e-10, 1.00048828125, 1.0009765625 + 2 ** -12, 0.1, -0.3333333], np.float32)
+    sig = np.concatenate([special, (rng.standard_normal(5000) * np.exp(rng.uniform(-12, 12, 5000))).astype(np.float32)])
+    T, chunksize, overlap = sig.shape[0], 700, 130
+    want = util.chunk(torch.from_numpy(sig), chunksize, overlap).reshape(-1, chunksize).to(torch.float16)
+    got = np.empty((want.shape[0], chunksize), np.float16)
+    n = _lib.lib().bh_host_chunk_rows(sig.ctypes.data, T, chunksize, overlap, 0, want.shape[0], got.ctypes.data)
+    assert n == want.shape[0]
+    assert np.array_equal(got.view(np.uint16), want.numpy().view(np.uint16))
+    part = np.empty((3, chunksize), np.float16)
+    assert _lib.lib().bh_host_chunk_rows(sig.ctypes.data, T, chunksize, overlap, 2, 3, part.ctypes.data) == 3
+    assert np.array_equal(part.view(np.uint16), want[2:5].numpy().view(np.uint16))
+    assert _lib.lib().bh_host_chunk_rows(sig.ctypes.data, T, chunksize, overlap, want.shape[0] - 1, 2, part.ctypes.data) < 0
