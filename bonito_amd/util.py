@@ -64,7 +64,11 @@ def limit_host_threads(max_threads=4):
     On a CPU-quota'd container that spinning exhausts the quota and stalls the process for the rest of the 100 ms
     CFS period (measured on the MI355X boxes: 128 OpenMP threads against a 16-core quota -> every third decode wait
     took 80 ms instead of 9). Returns the thread count now in force."""
-    n = max(1, min(torch.get_num_threads(), max_threads, effective_cpu_count()))
+    try:                      # one process per GPU (torchrun): the ranks of a host share its CPU budget
+        local_world = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1")))
+    except ValueError:
+        local_world = 1
+    n = max(1, min(torch.get_num_threads(), max_threads, effective_cpu_count() // local_world))
     torch.set_num_threads(n)
     return n
 

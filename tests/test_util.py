@@ -233,3 +233,16 @@ def test_host_chunk_rows_cast_equals_torch_half():
     assert _lib.lib().bh_host_chunk_rows(sig.ctypes.data, T, chunksize, overlap, 2, 3, part.ctypes.data) == 3
     assert np.array_equal(part.view(np.uint16), want[2:5].numpy().view(np.uint16))
     assert _lib.lib().bh_host_chunk_rows(sig.ctypes.data, T, chunksize, overlap, want.shape[0] - 1, 2, part.ctypes.data) < 0
+
+
+def test_limit_host_threads_shares_the_budget_between_local_ranks(monkeypatch):
+    before = torch.get_num_threads()
+    try:
+        torch.set_num_threads(max(before, 4))
+        monkeypatch.setattr(util, "effective_cpu_count", lambda: 16)
+        monkeypatch.setenv("LOCAL_WORLD_SIZE", "8")
+        assert util.limit_host_threads(4) == min(2, torch.get_num_threads())
+        monkeypatch.setenv("LOCAL_WORLD_SIZE", "64")
+        assert util.limit_host_threads(4) == 1
+    finally:
+        torch.set_num_threads(before)
