@@ -246,3 +246,23 @@ def test_limit_host_threads_shares_the_budget_between_local_ranks(monkeypatch):
         assert util.limit_host_threads(4) == 1
     finally:
         torch.set_num_threads(before)
+
+
+def test_host_compact_and_chunk_rows_edge_cases():
+    from bonito_amd import _lib
+    lib = _lib.lib()
+    for src in (np.zeros(17, np.int8), np.full(9, 65, np.int8), np.array([0, 71, 0, 0, 84, 65, 0], np.int8), np.zeros(0, np.int8)):
+        dst = np.zeros(max(1, src.size), np.uint8)
+        n = lib.bh_host_compact(src.ctypes.data if src.size else None, src.size, dst.ctypes.data)
+        assert n == np.count_nonzero(src) and bytes(dst[:n]) == src[src != 0].astype(np.uint8).tobytes()
+    # no stub (T - overlap divisible by the step), a single chunk (T == chunksize), and the rejected shapes
+    for T, cs, ov in ((100 + 4 * 900, 1000, 100), (1000, 1000, 100), (2500, 1000, 0)):
+        sig = np.arange(T, dtype=np.float32) * 0.25
+        want = util.chunk(torch.from_numpy(sig), cs, ov).reshape(-1, cs).to(torch.float16).numpy()
+        got = np.empty_like(want)
+        assert lib.bh_host_chunk_rows(sig.ctypes.data, T, cs, ov, 0, want.shape[0], got.ctypes.data) == want.shape[0]
+        assert np.array_equal(got.view(np.uint16), want.view(np.uint16))
+    sig = np.zeros(500, np.float32)
+    out = np.empty((1, 1000), np.float16)
+    assert lib.bh_host_chunk_rows(sig.ctypes.data, 500, 1000, 100, 0, 1, out.ctypes.data) < 0     # T < chunksize: Python path
+    assert lib.bh_host_chunk_rows(sig.ctypes.data, 500, 100, 100, 0, 1, out.ctypes.data) < 0      # overlap >= chunksize
