@@ -1,0 +1,45 @@
+"""Host-only checks of bench.py's argument handling (the measurement itself needs an MI355X)."""
+import importlib
+import json
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def bench():
+    sys.path.insert(0, ROOT)
+    saved = sys.argv
+    sys.argv = ["bench.py"]
+    try:
+        return importlib.import_module("bench")
+    finally:
+        sys.argv = saved
+
+
+def test_multi_lane_detection_decides_the_hardware_queue_request(bench):
+    assert not bench._multi_lane([])
+    assert not bench._multi_lane(["--model", "hac", "--lanes", "1"])
+    assert bench._multi_lane(["--lanes", "3"])
+    assert bench._multi_lane(["--lanes=2"])
+    assert bench._multi_lane(["--model", "fast"])                 # the fast model defaults to three lanes
+    assert not bench._multi_lane(["--model", "fast", "--lanes", "1"])
+
+
+def test_defaults_follow_the_contract(bench, monkeypatch):
+    monkeypatch.setattr(sys, "argv", ["bench.py"])
+    a = bench.parse()
+    assert (a.gpus, a.model, a.decoder, a.batch, a.chunk, a.lanes) == (1, "hac", "beam", 512, 10000, 1)
+    assert a.steps >= 1 and a.warmup >= 0 and a.set == []
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--model", "sup_lstm", "--set", "beam_fork=1", "--set", "conv_ws=0"])
+    a = bench.parse()
+    assert (a.batch, a.chunk, a.lanes, a.set) == (256, 20000, 1, ["beam_fork=1", "conv_ws=0"])
+
+
+def test_pmc_traffic_table_names_the_roofline_kernel(bench):
+    table = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+    entry = table["lstm_layer_wg_kernel"]
+    assert entry["bytes_per_launch"] > 1e9 and os.path.exists(os.path.join(ROOT, entry["source"]))
