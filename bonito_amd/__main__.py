@@ -18,6 +18,7 @@ def main(argv=None):
         p = sub.add_parser(name, parents=[mod.argparser()])
         p.set_defaults(func=mod.main)
     args = parser.parse_args(argv)
+    args._argv = list(sys.argv[1:] if argv is None else argv)[1:]      # the sub-command's own arguments (multi-GPU re-launch)
     return args.func(args)
 
 

@@ -33,7 +33,7 @@ class bh_layer_t(C.Structure):
 BH_ACT = {None: 0, "none": 0, "swish": 1, "tanh": 2, "relu": 3}
 BH_LAYER_CONV, BH_LAYER_LSTM, BH_LAYER_LINEAR_CRF, BH_LAYER_CLAMP = 1, 2, 3, 4
 BH_LAYER_TRANSFORMER, BH_LAYER_UPSAMPLE, BH_LAYER_TCS_BLOCK, BH_LAYER_CTC_DECODER = 5, 6, 7, 8
-BH_LAYER_DWCONV, BH_LAYER_RESIDUAL_PROJ = 9, 10
+BH_LAYER_DWCONV, BH_LAYER_RESIDUAL_PROJ, BH_LAYER_LINEAR = 9, 10, 11
 
 _vp, _i, _f, _l, _sz = C.c_void_p, C.c_int, C.c_float, C.c_long, C.c_size_t
 
@@ -49,6 +49,7 @@ SIGNATURES = {
     "bh_encoder_output_shape": (_i, [_vp, _i, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)]),
     "bh_encoder_forward": (_i, [_vp, _vp, _i, _i, _vp, _vp]),
     "bh_encoder_check": (_i, [_vp, _vp]),
+    "bh_encoder_error_flag": (_i, [_vp]),
     "bh_encoder_profile": (_i, [_vp, _i]),
     "bh_encoder_profile_read": (_i, [_vp, C.POINTER(C.c_float), C.POINTER(_i)]),
     "bh_crf_viterbi_workspace": (_sz, [_i, _i, _i]),

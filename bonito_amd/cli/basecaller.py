@@ -20,16 +20,78 @@ from bonito_amd.nn import fuse_bn_
 from bonito_amd.reader import Reader
 
 
-def main(args):
+def parse_devices(spec):
+    """"0-7" / "0,2,5" / "0-3,6" -> list of device indices (duplicates allowed: two ranks may share a GPU)."""
+    out = []
+    for part in str(spec).split(","):
+        part = part.strip()
+        if not part:
+            continue
+        if "-" in part:
+            lo, hi = part.split("-", 1)
+            out.extend(range(int(lo), int(hi) + 1))
+        else:
+            out.append(int(part))
+    if not out:
+        raise ValueError("--devices: no device in %r" % (spec,))
+    return out
+
+
+def launch(args, argv):
+    """``--devices``: one worker process per listed GPU (the reference is single-device; SURVEY 8e: shard by read, no
+    collective). Each worker sees only its GPU (HIP_VISIBLE_DEVICES), takes the reads whose index is congruent to its rank,
+    formats its own records, and rank 0 merges the streams in input order and writes (bonito_amd/parallel.py)."""
+    import socket
+    import subprocess
+    devices = parse_devices(args.devices)
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    child_argv, skip = [], False
+    for tok in argv:                       # the workers get the same command line minus --devices
+        if skip:
+            skip = False
+        elif tok == "--devices":
+            skip = True
+        elif not tok.startswith("--devices="):
+            child_argv.append(tok)
+    procs = []
+    for rank, dev in enumerate(devices):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(len(devices)), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HIP_VISIBLE_DEVICES=str(dev), BONITO_AMD_SPAWNED="1")
+        env.pop("CUDA_VISIBLE_DEVICES", None)
+        pkg_root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        env["PYTHONPATH"] = pkg_root + (os.pathsep + env["PYTHONPATH"] if env.get("PYTHONPATH") else "")
+        procs.append(subprocess.Popen([sys.executable, "-m", "bonito_amd", "basecaller", *child_argv], env=env,
+                                      stdout=None if rank == 0 else subprocess.DEVNULL))
+    rcs = [p.wait() for p in procs]
+    bad = [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
+    if bad:
+        sys.stderr.write("> error: worker(s) failed: %s\n" % ", ".join("rank %d rc %d" % b for b in bad))
+        return 1
+    return 0
+
+
+def main(args, argv=None):
+    from bonito_amd import parallel
+    if getattr(args, "devices", None) and "RANK" not in os.environ:
+        return launch(args, list(argv if argv is not None else getattr(args, "_argv", sys.argv[2:])))
+    rank, world, local = parallel.env_rank_world()
+    if world > 1:
+        # one process per GPU: spawned by `launch` (sees one device) or by torchrun (device = LOCAL_RANK)
+        if not os.environ.get("BONITO_AMD_SPAWNED") and args.device == "cuda":
+            args.device = "cuda:%d" % local
+        parallel.init("gloo")              # host objects only: there is no device collective on this path
     util.init(args.seed, args.device)
     util.limit_host_threads(8)       # host work is small copies; never out-spin a container's CPU quota
+    log = sys.stderr.write if rank == 0 else (lambda _msg: None)
     try:
         reader = Reader(args.reads_directory, args.recursive)
-        sys.stderr.write("> reading %s\n" % args.reads_directory)
+        log("> reading %s\n" % args.reads_directory)
     except FileNotFoundError as exc:
         sys.stderr.write("> error: %s\n" % exc)
         return 1
-    sys.stderr.write("> loading model %s\n" % args.model_directory)
+    log("> loading model %s\n" % args.model_directory)
     model = util.load_model(args.model_directory, args.device, weights=args.weights if args.weights > 0 else None,
                             chunksize=args.chunksize, overlap=args.overlap, batchsize=args.batchsize,
                             quantize=args.quantize, use_koi=True)
@@ -44,7 +106,7 @@ def main(args):
                              scaling_strategy=model.config.get("scaling"),
                              norm_params=model.config.get("standardisation") if (model.config.get("scaling") or {}).get(
                                  "strategy") == "pa" else model.config.get("normalisation"),
-                             n_max=args.max_reads or None, raw=args.device_ingest)
+                             n_max=args.max_reads or None, raw=args.device_ingest, rank=rank, world=world)
     if args.device_ingest:            # int16 reads: pA scaling, normalisation, trim and chunking on the GPU
         from bonito_amd.crf.basecall import basecall_raw
         pa = (model.config.get("scaling") or {}).get("strategy") == "pa"
@@ -56,18 +118,36 @@ def main(args):
         results = basecall(model, reads, reverse=args.revcomp, rna=args.rna, batchsize=bc["batchsize"],
                            chunksize=bc["chunksize"], overlap=bc["overlap"])
     mode = "sam" if args.sam else ("fasta" if args.fasta else "fastq")
-    writer = Writer(mode, results, fd=sys.stdout, min_qscore=args.min_qscore,
-                    summary_path=None if args.no_summary else args.summary)
     t0 = perf_counter()
+    if world > 1:
+        # every rank formats its own records; rank 0 merges the streams in input order and is the only writer
+        records = parallel.ordered_records(parallel.format_stream(results, mode, args.min_qscore), rank, world)
+        if rank != 0:
+            import torch.distributed as dist
+            dist.barrier(group=parallel.host_group())
+            dist.destroy_process_group()
+            return 0
+        writer = Writer(mode, records, fd=sys.stdout, summary_path=None if args.no_summary else args.summary,
+                        preformatted=True)
+    else:
+        writer = Writer(mode, results, fd=sys.stdout, min_qscore=args.min_qscore,
+                        summary_path=None if args.no_summary else args.summary)
     writer.start()
     writer.join()
     duration = perf_counter() - t0
+    if world > 1:
+        import torch.distributed as dist
+        if writer.error is None:
+            dist.barrier(group=parallel.host_group())
+            dist.destroy_process_group()
     if writer.error is not None:
         raise writer.error
     num_samples = sum(n for _, n in writer.log)
     sys.stderr.write("> completed reads: %s\n" % len(writer.log))
     sys.stderr.write("> duration: %s\n" % timedelta(seconds=np.round(duration)))
     sys.stderr.write("> samples per second %.1E\n" % (num_samples / max(duration, 1e-9)))
+    if world > 1:
+        sys.stderr.write("> devices: %d (one process per GPU, reads sharded round-robin)\n" % world)
     sys.stderr.write("> done\n")
     return 0
 
@@ -77,6 +157,9 @@ def argparser():
     parser.add_argument("model_directory")
     parser.add_argument("reads_directory")
     parser.add_argument("--device", default="cuda")
+    parser.add_argument("--devices", default=None,
+                        help="multi-GPU: device list such as 0-7 or 0,2,5; one worker process per GPU, reads sharded "
+                             "round-robin, rank 0 writes all records in input order")
     parser.add_argument("--seed", default=25, type=int)
     parser.add_argument("--weights", default=0, type=int)
     parser.add_argument("--read-ids")

@@ -76,6 +76,9 @@ def compute_scores(model, batch, beam_width=32, beam_cut=100.0, scale=1.0, offse
                 sequence, qstring, moves = hip_decode.beam_search(
                     scores, beam_width=beam_width, beam_cut=beam_cut, scale=scale, offset=offset,
                     blank_score=blank_score)
+        eng = getattr(model, "_hip", None)
+        if eng is not None:      # the decoders returned CPU tensors: the forward is complete, its timeout flag is on the host
+            eng.poll()
         return {"moves": moves, "qstring": qstring, "sequence": sequence}
 
 
@@ -102,6 +105,11 @@ class _Pipeline:
         self.dec_stream = torch.cuda.Stream(self.device)
         self.copy_stream = torch.cuda.Stream(self.device)
         self.decoders = {}
+
+    def check_engine(self):
+        eng = getattr(self.model, "_hip", None)
+        if eng is not None:
+            eng.poll()
 
     def encode(self, batch):
         if batch.is_cuda:                 # produced on the device (basecall_raw): no copy, just order the streams
@@ -143,6 +151,10 @@ class _Pipeline:
             scores.record_stream(self.dec_stream)
             ticket = dec.submit(scores)
         planes = ticket.result_planes()      # [3, n, T] int8: sequence, qstring, moves
+        # the decode outputs are on the host, so the encoder forward that produced `scores` (and the 4-byte copy of the
+        # engine's timeout flag behind it) has completed: a spin timeout in a persistent kernel means these planes were
+        # decoded from invalid scores -> raise, never yield them (reference seam: crf/basecall.py:27-45)
+        self.check_engine()
         if self.mode == "viterbi":
             path = planes[1]                 # plane 1 carries the path for the Viterbi decoder
             planes[0] = hip_decode.path_to_sequence(path)

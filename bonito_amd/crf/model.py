@@ -138,6 +138,23 @@ class SeqdistModel(Module):
 
     use_koi = use_hip
 
+    # The engine snapshots the weights when it is built (first forward). Anything that changes parameters afterwards --
+    # load_state_dict, .half() / .to() / .float() (Module._apply), apply(fuse_bn_) -- drops it, so the next forward lowers
+    # the current weights again instead of silently running stale ones.
+    def _drop_engine(self):
+        eng = self.__dict__.get("_hip")
+        if eng is not None:
+            eng.close()
+        self.__dict__["_hip"] = None
+
+    def load_state_dict(self, *args, **kwargs):
+        self._drop_engine()
+        return super().load_state_dict(*args, **kwargs)
+
+    def _apply(self, fn, *args, **kwargs):
+        self._drop_engine()
+        return super()._apply(fn, *args, **kwargs)
+
     def _engine(self, x):
         N, L = x.shape[0], x.shape[-1]
         if self._hip is not None and (N > self._hip.max_batch or L > self._hip.max_chunk

@@ -168,6 +168,7 @@ struct bh_encoder {
     int n_cus = 0;
     std::vector<Layer> layers;
     DevBuf act[3], gates, sig, err, lstm_ws;
+    int* err_host = nullptr;     // pinned mirror of `err`, refreshed by a 4-byte copy at the end of every forward
     int n_act = 2;               // activation buffers in rotation: 3 when recurrent layers pre-fill their exchange sentinel
     // sentinel pre-fill of the NEXT recurrent layer's output buffer, on a side stream under the current layer's kernel
     hipStream_t fill_stream = nullptr;
@@ -194,6 +195,7 @@ struct bh_encoder {
         if (fill_ready) (void)hipEventDestroy(fill_ready);
         if (fill_done) (void)hipEventDestroy(fill_done);
         if (fill_stream) (void)hipStreamDestroy(fill_stream);
+        if (err_host) (void)hipHostFree(err_host);
         for (auto& l : layers) {
             l.w0.release(); l.w1.release(); l.w2.release(); l.w3.release();
             l.w4.release(); l.w5.release(); l.b0.release(); l.b1.release();
@@ -237,6 +239,10 @@ static int walk(const bh_encoder* e, int N, int L, int* T_out, int* C_out, size_
                 break;
             case BH_LAYER_LINEAR_CRF:
                 C = l.d.out_size;
+                break;
+            case BH_LAYER_LINEAR:
+                C = l.d.out_size;
+                amax = std::max(amax, (size_t)N * len * C * 2);
                 break;
             case BH_LAYER_CLAMP:
                 break;
@@ -404,6 +410,7 @@ extern "C" int bh_encoder_create(const bh_layer_t* layers, int n_layers, int dev
                     if (!rc) rc = lstm_pack_tiles(d.w0, H, MT, pk.data());
                     if (!rc) rc = upload(L.w4, pk.data(), pk.size() * 2);
                 }
+                cur_channels = cur_channels_eff = H;
                 break;
             }
             case BH_LAYER_LINEAR_CRF: {
@@ -414,6 +421,17 @@ extern "C" int bh_encoder_create(const bh_layer_t* layers, int n_layers, int dev
                 rc = upload_f16(L.w0, d.w0, (size_t)d.out_size * d.in_size);
                 if (!rc && d.b0) rc = upload_f32(L.b0, d.b0, d.out_size);
                 e->out_features = d.out_size;
+                break;
+            }
+            case BH_LAYER_LINEAR: {
+                if (!(d.w0 && d.in_size > 0 && d.out_size > 0 && d.in_size % 8 == 0 && d.out_size % 8 == 0) || cur_channels != d.in_size) {
+                    bh_set_error("encoder_create: layer %d: linear needs in/out features %% 8 == 0 and %d input features (chain provides %d)",
+                                 i, d.in_size, cur_channels);
+                    return fail(-2);
+                }
+                rc = upload_f16(L.w0, d.w0, (size_t)d.out_size * d.in_size);
+                if (!rc && d.b0) rc = upload_f32(L.b0, d.b0, d.out_size);
+                cur_channels = cur_channels_eff = d.out_size;
                 break;
             }
             case BH_LAYER_TRANSFORMER: {
@@ -487,7 +505,8 @@ extern "C" int bh_encoder_create(const bh_layer_t* layers, int n_layers, int dev
             case BH_LAYER_CLAMP: {
                 // fold into the producing layer's epilogue
                 int j = i - 1;
-                if (j < 0 || (e->layers[j].d.kind != BH_LAYER_CONV && e->layers[j].d.kind != BH_LAYER_LINEAR_CRF)) {
+                if (j < 0 || (e->layers[j].d.kind != BH_LAYER_CONV && e->layers[j].d.kind != BH_LAYER_LINEAR_CRF &&
+                              e->layers[j].d.kind != BH_LAYER_LINEAR)) {
                     bh_set_error("encoder_create: layer %d: clamp must follow a convolution or linear layer", i);
                     return fail(-2);
                 }
@@ -563,6 +582,11 @@ extern "C" int bh_encoder_create(const bh_layer_t* layers, int n_layers, int dev
             e->rot_len = tmax;
         }
     }
+    if (hipHostMalloc((void**)&e->err_host, sizeof(int), hipHostMallocDefault) != hipSuccess) {
+        bh_set_error("encoder_create: hipHostMalloc failed");
+        return fail(-1);
+    }
+    *e->err_host = 0;
     if (hipMemset(e->err.p, 0, sizeof(int)) != hipSuccess || hipMemset(e->act[0].p, 0, e->act[0].bytes) != hipSuccess ||
         hipMemset(e->act[1].p, 0, e->act[1].bytes) != hipSuccess) {
         bh_set_error("encoder_create: hipMemset failed");
@@ -779,6 +803,17 @@ extern "C" int bh_encoder_forward(bh_encoder_t* e, const void* signal, int N, in
                 C = d.out_size;
                 break;
             }
+            case BH_LAYER_LINEAR: {     // feature-axis linear layer; rows keep their layout ((t, n) or (n, t))
+                BH_REQUIRE(lay == L_TNC || lay == L_NLC, "encoder_forward: linear needs encoded input");
+                BH_REQUIRE(C == d.in_size, "encoder_forward: layer %zu expects %d features, got %d", i, d.in_size, C);
+                void* dst = e->act[which].p;
+                ProfSpan span(e, st, BH_PROF_OTHER);
+                int rc = bh_k_linear(cur, l.w0.p, (const float*)l.b0.p, dst, len * Np, d.out_size, d.in_size, d.in_size, d.in_size,
+                                     d.out_size, bh::ACT_NONE, 1.0f, lo, hi, 0, 0, 0, 0, 0, st);
+                if (rc) return rc;
+                cur = dst; which = (which + 1) % e->n_act; C = d.out_size;
+                break;
+            }
             case BH_LAYER_TRANSFORMER: {
                 BH_REQUIRE(lay == L_NLC, "encoder_forward: transformer layer needs [N][T][D] input");
                 BH_REQUIRE(C == d.in_size, "encoder_forward: layer %zu expects d_model %d, got %d", i, d.in_size, C);
@@ -864,7 +899,18 @@ extern "C" int bh_encoder_forward(bh_encoder_t* e, const void* signal, int N, in
                 BH_REQUIRE(false, "encoder_forward: unsupported layer kind %d", d.kind);
         }
     }
+    // The persistent recurrent kernels raise `err` on a spin timeout and then finish with invalid output. Mirror the (sticky)
+    // flag into pinned host memory behind this forward: whoever has observed the completion of this call on `st` (an event,
+    // a D2H copy of decoded outputs, a synchronise) reads it without another round trip -- bh_encoder_error_flag().
+    BH_CHECK_HIP(hipMemcpyAsync(e->err_host, e->err.p, sizeof(int), hipMemcpyDeviceToHost, st));
     return 0;
+}
+
+extern "C" int bh_encoder_error_flag(const bh_encoder_t* e) {
+    if (!e || !e->err_host) return 0;
+    const int flag = *(volatile const int*)e->err_host;
+    if (flag) bh_set_error("device-side timeout in a persistent kernel (flag=%d): the scores of that forward are invalid", flag);
+    return flag;
 }
 
 extern "C" int bh_encoder_check(bh_encoder_t* e, void* stream_) {
@@ -876,6 +922,7 @@ extern "C" int bh_encoder_check(bh_encoder_t* e, void* stream_) {
         BH_CHECK_HIP(hipMemsetAsync(e->err.p, 0, sizeof(int), (hipStream_t)stream_));
         bh_set_error("device-side timeout in a persistent kernel (flag=%d)", flag);
     }
+    if (e->err_host) *e->err_host = 0;
     return flag;
 }
 
@@ -1048,6 +1095,7 @@ extern "C" int bh_set_option(const char* name, int value) {
     BH_REQUIRE(name != nullptr, "set_option: null name");
     if (bh_k_decode_set_option(name, value) == 0) return 0;
     if (bh_k_conv_set_option(name, value) == 0) return 0;
+    if (bh_k_lstm_set_option(name, value) == 0) return 0;
     if (!strcmp(name, "gemm_path")) { bh_k_linear_force_v1(value); return 0; }
     BH_REQUIRE(false, "set_option: unknown option '%s'", name);
     return -1;

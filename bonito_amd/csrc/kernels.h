@@ -32,6 +32,7 @@ int bh_k_lstm_layer_fused(const void* x, const void* wih_packed, const float* bi
                           int T, int N, int H, int reverse, int* err_flag, hipStream_t stream, int n_rings, int* xcc_ws,
                           int force_slow);
 int bh_k_fill_u16(void* dst, uint16_t value, size_t count, hipStream_t stream);
+int bh_k_lstm_set_option(const char* name, int value);     // "lstm_max_spins"
 size_t bh_k_lstm_packed_bytes(int H);
 int bh_k_lstm_wg_units(int H);
 int bh_k_lstm_cta_units(int H);

@@ -30,6 +30,8 @@
 //     holds i,f,g,o for 4 consecutive hidden units of one chunk -> lane-local gate math, c_t kept in
 //     fp32 registers for the whole layer, 8-byte packed h stores.
 // All spins are bounded; on timeout the kernel raises *err_flag and keeps going (never hangs).
+#include <string.h>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -1166,6 +1168,14 @@ __global__ void fill_u16_kernel(uint16_t* dst, uint16_t v, size_t count) {
 
 }  // namespace bh
 
+// Bound of every exchange spin loop (poll rounds). Process-wide; lowered by tests to provoke the timeout path.
+static unsigned g_max_spins = 1000000u;
+int bh_k_lstm_set_option(const char* name, int value) {
+    if (strcmp(name, "lstm_max_spins") != 0) return -1;
+    g_max_spins = value >= 0 ? (unsigned)value : 1000000u;     // 0: the first incomplete poll round is a timeout
+    return 0;
+}
+
 size_t bh_k_lstm_packed_bytes(int H) { return (size_t)4 * H * H * 2; }
 size_t bh_k_lstm_ws_bytes(int N, int H) {
     // XCD agreement slots + (tune bit 4) per-wave statistics: up to 16 x int64 per (ring, slice)
@@ -1205,7 +1215,7 @@ int bh_k_lstm_layer(const void* gates_in, const void* whh_packed, void* h_out, i
     BH_REQUIRE(xcc_ws != nullptr, "lstm: missing XCD agreement workspace");
     BH_CHECK_HIP(hipMemsetAsync(xcc_ws, 0xFF, (size_t)n_rings * nsl * sizeof(int), stream));
     LstmArgs a{(const half_t*)gates_in, (const half_t*)whh_packed, (half_t*)h_out, T, N, H, n_rings,
-               reverse, err_flag, 1000000u, xcc_ws, force_slow & 1, force_slow >> 8};
+               reverse, err_flag, g_max_spins, xcc_ws, force_slow & 1, force_slow >> 8};
 #define BH_LSTM_CASE(NKS) \
     case NKS: hipLaunchKernelGGL(lstm_layer_kernel<NKS>, dim3(grid), dim3(256), 0, stream, a); break;
     switch (H / 32) {
@@ -1235,7 +1245,7 @@ int bh_k_lstm_layer_stream(const void* gates_in, const void* whh_packed, void* h
     BH_REQUIRE(xcc_ws != nullptr, "lstm: missing XCD agreement workspace");
     BH_CHECK_HIP(hipMemsetAsync(xcc_ws, 0xFF, (size_t)n_rings * nsl * sizeof(int), stream));
     LstmArgs a{(const half_t*)gates_in, (const half_t*)whh_packed, (half_t*)h_out, T, N, H, n_rings,
-               reverse, err_flag, 1000000u, xcc_ws, force_slow & 1, force_slow >> 8};
+               reverse, err_flag, g_max_spins, xcc_ws, force_slow & 1, force_slow >> 8};
     switch (H / 32) {
         case 2: hipLaunchKernelGGL(lstm_layer_stream_kernel<2>, dim3(grid), dim3(256), 0, stream, a); break;
         case 4: hipLaunchKernelGGL(lstm_layer_stream_kernel<4>, dim3(grid), dim3(256), 0, stream, a); break;
@@ -1271,7 +1281,7 @@ int bh_k_lstm_layer_fused(const void* x, const void* wih_packed, const float* bi
     BH_REQUIRE(xcc_ws != nullptr, "lstm: missing XCD agreement workspace");
     BH_CHECK_HIP(hipMemsetAsync(xcc_ws, 0xFF, (size_t)n_rings * nsl * sizeof(int), stream));
     LstmFusedArgs a{(const half_t*)x, (const half_t*)wih_packed, bias,
-                    LstmArgs{nullptr, (const half_t*)whh_packed, (half_t*)h_out, T, N, H, n_rings, reverse, err_flag, 1000000u,
+                    LstmArgs{nullptr, (const half_t*)whh_packed, (half_t*)h_out, T, N, H, n_rings, reverse, err_flag, g_max_spins,
                              xcc_ws, force_slow & 1, force_slow >> 8}};
     const size_t lds = (size_t)(H / 32) * 4096;
 #define BH_LSTM_CASE(NKS)                                                                                        \
@@ -1321,7 +1331,7 @@ int bh_k_lstm_layer_wg(const void* x, const void* wih_packed, const float* bias,
     BH_REQUIRE(xcc_ws != nullptr, "lstm: missing XCD agreement workspace");
     BH_CHECK_HIP(hipMemsetAsync(xcc_ws, 0xFF, (size_t)n_rings * nsl * sizeof(int), stream));
     LstmFusedArgs a{(const half_t*)x, (const half_t*)wih_packed, bias,
-                    LstmArgs{nullptr, (const half_t*)whh_packed, (half_t*)h_out, T, N, H, n_rings, reverse, err_flag, 1000000u,
+                    LstmArgs{nullptr, (const half_t*)whh_packed, (half_t*)h_out, T, N, H, n_rings, reverse, err_flag, g_max_spins,
                              xcc_ws, force_slow & 1, force_slow >> 8}};
     const int nks = H / 32;
     const size_t lds = (size_t)4 * nks * 1024 + 4 * 16 * U * 2;
@@ -1385,7 +1395,7 @@ int bh_k_lstm_layer_wide(const void* gates_perm, const void* whh_tiles, void* h_
     BH_REQUIRE(xcc_ws != nullptr, "lstm: missing XCD agreement workspace");
     BH_CHECK_HIP(hipMemsetAsync(xcc_ws, 0xFF, (size_t)n_rings * nsl * sizeof(int), stream));
     LstmWideArgs a{(const half_t*)gates_perm,
-                   LstmArgs{nullptr, (const half_t*)whh_tiles, (half_t*)h_out, T, N, H, n_rings, reverse, err_flag, 1000000u, xcc_ws,
+                   LstmArgs{nullptr, (const half_t*)whh_tiles, (half_t*)h_out, T, N, H, n_rings, reverse, err_flag, g_max_spins, xcc_ws,
                             force_slow & 1, force_slow >> 8}};
     const int nks = H / 32;
     const size_t lds = (size_t)2 * 2 * nks * 1024 + 4 * 16 * 8 * 2;

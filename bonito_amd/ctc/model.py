@@ -115,6 +115,21 @@ class Model(Module):
 
     use_koi = use_hip     # the reference CLI calls use_koi unconditionally (cli/basecaller.py:59, util.py:292-296)
 
+    # the engine snapshots the weights at its first forward: parameter changes afterwards drop it (see crf/model.py)
+    def _drop_engine(self):
+        eng = self.__dict__.get("_hip")
+        if eng is not None:
+            eng.close()
+        self.__dict__["_hip"] = None
+
+    def load_state_dict(self, *args, **kwargs):
+        self._drop_engine()
+        return super().load_state_dict(*args, **kwargs)
+
+    def _apply(self, fn, *args, **kwargs):
+        self._drop_engine()
+        return super()._apply(fn, *args, **kwargs)
+
     def forward(self, x):
         """x: cuda fp16 [N,1,L] -> log-probabilities fp16 [T, N, n_labels] (reference layout, a view)."""
         if not x.is_cuda:

@@ -84,12 +84,14 @@ class CRFDecoder:
                 _lib.check(lib.bh_beam_search(_lib.ptr(scores), N, T, self.sl, bw, cut, blank, scale, offset,
                                               _lib.ptr(self.ws), _lib.ptr(out[0]), _lib.ptr(out[1]), _lib.ptr(out[2]),
                                               None, st), "bh_beam_search")
-                self.host_out[:, :N].copy_(out[:, :N], non_blocking=True)
+                for pl in range(3):      # one dense copy per plane: a [3, :N] slice is strided when N < max_batch
+                    self.host_out[pl, :N].copy_(out[pl, :N], non_blocking=True)
             else:
                 # viterbi: plane 2 = moves, plane 1 = path (0..4); sequence/qstring are derived on the host
                 _lib.check(lib.bh_crf_viterbi(_lib.ptr(scores), N, T, self.sl, 0, blank, T * Cc, Cc, _lib.ptr(self.ws),
                                               _lib.ptr(out[2]), _lib.ptr(out[1]), None, st), "bh_crf_viterbi")
-                self.host_out[1:, :N].copy_(out[1:, :N], non_blocking=True)
+                for pl in (1, 2):
+                    self.host_out[pl, :N].copy_(out[pl, :N], non_blocking=True)
             self.done.record(torch.cuda.current_stream(self.device))
         return CRFDecoder.Ticket(self, N)
 

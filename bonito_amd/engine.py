@@ -126,6 +126,10 @@ def lower(encoder):
                 raise LoweringError("linearupsample with batch_first=False is not lowered")
             low.add(kind=_lib.BH_LAYER_UPSAMPLE, in_size=m.d_model, scale_factor=m.scale_factor,
                     w0=_f32(m.linear.weight), b0=_f32(m.linear.bias))
+        elif isinstance(m, bnn.Linear):
+            lin = m.linear
+            low.add(kind=_lib.BH_LAYER_LINEAR, in_size=lin.in_features, out_size=lin.out_features,
+                    w0=_f32(lin.weight), b0=_f32(lin.bias) if lin.bias is not None else 0)
         elif isinstance(m, bnn.Clamp):
             low.add(kind=_lib.BH_LAYER_CLAMP, clamp_lo=float(m.min), clamp_hi=float(m.max))
         else:
@@ -247,6 +251,12 @@ class HipEncoder:
             rc = _lib.lib().bh_encoder_check(self._handle, _lib.stream_ptr(self.device))
         if rc:
             raise _lib.HipEngineError("bh_encoder_check: %s" % _lib.last_error())
+
+    def poll(self):
+        """Raise if a forward whose completion the caller has already observed (event / decoded outputs / synchronise)
+        hit the spin bound of a persistent kernel: its scores are invalid. No device round trip (bh_encoder_error_flag)."""
+        if self._handle is not None and _lib.lib().bh_encoder_error_flag(self._handle):
+            raise _lib.HipEngineError("bh_encoder_error_flag: %s" % _lib.last_error())
 
     def close(self):
         if self._handle is not None:

@@ -65,15 +65,51 @@ def summary_row(read, seqlen, qscore):
             read.template_start, read.template_duration, seqlen, qscore]
 
 
-class Writer(Thread):
-    """Consumes the basecall iterator (this drives the whole pipeline) and writes records to `fd`."""
+def signal_samples(read):
+    """Post-trim samples of a read: what the reference logs as ``len(read.signal)`` (io.py:437-440) and the CLI divides
+    by the wall time for its `samples per second` line (cli/basecaller.py:156-164)."""
+    sig = getattr(read, "signal", None)
+    if sig is not None:
+        return len(sig)
+    n = getattr(read, "signal_len", None)                 # RawRead: filled in by the device ingest
+    return int(n) if n is not None else int(read.num_samples) - int(getattr(read, "trimmed_samples", 0))
 
-    def __init__(self, mode, iterator, fd=sys.stdout, min_qscore=0.0, summary_path=None, groups=()):
+
+def format_record(read, res, mode, min_qscore=0.0):
+    """One basecalled read -> (text to write or None, summary row or None, (read_id, post-trim samples)).
+
+    The single place that turns a (read, result) pair into output bytes: the in-process `Writer` and the per-rank workers of
+    the multi-GPU path (bonito_amd/parallel.py) both call it, so N-rank output is byte-identical to 1-rank output by
+    construction. The log entry is produced for EVERY read, before the q-score / empty-sequence filters, like the reference
+    (io.py:437-442)."""
+    seq, qstring = res["sequence"], res.get("qstring", "*")
+    mean_q = mean_qscore_from_qstring(qstring) if qstring and qstring != "*" else 0.0
+    log = (read.read_id, signal_samples(read))
+    if mean_q < min_qscore or not len(seq):
+        return None, None, log
+    if mode == "fasta":
+        text = ">%s\n%s\n" % (read.read_id, seq)
+    elif mode == "fastq":
+        tags = read_tags(read, res, mean_q)
+        text = "@%s %s\n%s\n+\n%s\n" % (read.read_id, "\t".join(tags), seq, qstring if qstring != "*" else "!" * len(seq))
+    else:
+        text = sam_record(read.read_id, seq, qstring, tags=read_tags(read, res, mean_q)) + "\n"
+    return text, summary_row(read, len(seq), mean_q), log
+
+
+class Writer(Thread):
+    """Consumes the basecall iterator (this drives the whole pipeline) and writes records to `fd`.
+
+    `iterator` yields (read, result) pairs, or -- `preformatted=True`, the multi-GPU merge of bonito_amd/parallel.py --
+    the (text, summary_row, log) triples `format_record` made of them on the rank that basecalled the read."""
+
+    def __init__(self, mode, iterator, fd=sys.stdout, min_qscore=0.0, summary_path=None, groups=(), preformatted=False):
         super().__init__()
         assert mode in ("fastq", "fasta", "sam")
         self.mode, self.iterator, self.fd = mode, iterator, fd
         self.min_qscore, self.summary_path, self.groups = min_qscore, summary_path, groups
-        self.log = []            # (read_id, samples) of written reads: feeds the samples/s report
+        self.preformatted = preformatted
+        self.log = []            # (read_id, post-trim samples) of every basecalled read: feeds the samples/s report
         self.error = None
 
     def run(self):
@@ -84,21 +120,14 @@ class Writer(Thread):
                 tsv.writerow(summary_field_names)
             if self.mode == "sam":
                 self.fd.write(sam_header(self.groups))
-            for read, res in self.iterator:
-                seq, qstring = res["sequence"], res.get("qstring", "*")
-                mean_q = mean_qscore_from_qstring(qstring) if qstring and qstring != "*" else 0.0
-                if mean_q < self.min_qscore or not len(seq):
+            for item in self.iterator:
+                text, row, log = item if self.preformatted else format_record(item[0], item[1], self.mode, self.min_qscore)
+                self.log.append(log)
+                if text is None:
                     continue
-                if self.mode == "fasta":
-                    write_fasta(read.read_id, seq, self.fd)
-                elif self.mode == "fastq":
-                    write_fastq(read.read_id, seq, qstring if qstring != "*" else "!" * len(seq), self.fd,
-                                tags=read_tags(read, res, mean_q))
-                else:
-                    self.fd.write(sam_record(read.read_id, seq, qstring, tags=read_tags(read, res, mean_q)) + "\n")
+                self.fd.write(text)
                 if tsv:
-                    tsv.writerow(summary_row(read, len(seq), mean_q))
-                self.log.append((read.read_id, read.num_samples))
+                    tsv.writerow(row)
             self.fd.flush()
             if summary:
                 summary.close()

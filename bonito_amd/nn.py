@@ -397,6 +397,8 @@ def fuse_bn_(m):
     """``model.apply(fuse_bn_)``: eval mode, and fold a Convolution's BatchNorm into its conv
     (reference nn.py:447-454, called at cli/basecaller.py:61). Folded in fp32 whatever the parameter dtype."""
     m.training = False
+    if hasattr(m, "_drop_engine"):      # a model object: its lowered HIP engine holds a snapshot of the old weights
+        m._drop_engine()
     if isinstance(m, Convolution) and isinstance(m.norm, BatchNorm):
         w, b = m.folded()
         dtype, device = m.conv.weight.dtype, m.conv.weight.device

@@ -2,12 +2,24 @@
 Multi-GPU execution of the hot path: replicas, shard-by-read, no data-path collective.
 
 Read chunks are independent (/root/reference bonito/crf/basecall.py:70-72) and the models are small
-(0.4-70 M parameters), so every GPU runs its own engine replica on its own process
-(``torchrun --nproc-per-node N``; ``torch.distributed`` backend "nccl" = RCCL on ROCm, "gloo" on CPU).
-The only communication is (a) the final gather of basecalls to rank 0, which restores the input order the
-reference's writer expects, and (b) barriers / a MAX-reduce for timing. Both are off the per-batch path.
+(0.4-70 M parameters), so every GPU runs its own engine replica in its own process
+(``python -m bonito_amd basecaller --devices 0-7`` spawns them; ``torchrun --nproc-per-node N`` works too;
+``torch.distributed`` backend "nccl" = RCCL on ROCm for the bench barrier, "gloo" for host objects).
+
+* Reads are sharded round-robin at the RECORD level (`Reader.get_reads(rank=, world=)`): a rank only loads, normalises and
+  chunks its own reads.
+* Every rank formats its own records (`io.format_record`: the FASTQ / SAM text, the summary row, the log entry), so the host
+  work of writing scales with the ranks.
+* Rank 0 merges the ranks' record streams back into input order and is the only writer (`ordered_records`): record i comes
+  from rank i % world, every rank emits its records in order, so the merge pulls from per-rank FIFO streams in turn -- a
+  bounded reorder window (a sender blocks once `window` of its messages are unconsumed), nothing is held until the end.
+  The reference gets its ordering from a single process (bonito/io.py:400-469 consumes one iterator); this is the same
+  contract across processes.
+* The only collectives are barriers / a MAX-reduce for timing (bench.py). Nothing per batch.
 """
+import io
 import os
+import pickle
 
 import torch
 import torch.distributed as dist
@@ -40,24 +52,6 @@ def shard(items, rank, world):
             yield i, item
 
 
-def gather_in_order(indexed_results, rank=None, world=None, dst=0):
-    """`indexed_results`: iterable of (global_index, payload) produced by this rank. Returns the payloads
-    of ALL ranks in global order on rank `dst` (None elsewhere). Payloads must be picklable."""
-    if rank is None or world is None:
-        rank, world, _ = env_rank_world()
-    mine = list(indexed_results)
-    if world == 1:
-        return [p for _, p in sorted(mine, key=lambda kv: kv[0])]
-    gathered = [None] * world if rank == dst else None
-    dist.gather_object(mine, gathered, dst=dst)
-    if rank != dst:
-        return None
-    merged = sorted((kv for part in gathered for kv in part), key=lambda kv: kv[0])
-    idx = [k for k, _ in merged]
-    assert idx == list(range(len(idx))), "shards do not cover the input exactly once"
-    return [p for _, p in merged]
-
-
 def max_over_ranks(value, device=None):
     """MAX-reduce a python float over all ranks (wall-clock of the slowest replica)."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
@@ -67,12 +61,123 @@ def max_over_ranks(value, device=None):
     return float(t.item())
 
 
+# ---- host-object point-to-point (gloo): length-prefixed pickles ------------------------------------------------
+def _send_obj(obj, dst, group):
+    buf = pickle.dumps(obj, protocol=pickle.HIGHEST_PROTOCOL)
+    dist.send(torch.tensor([len(buf)], dtype=torch.int64), dst=dst, group=group)
+    if buf:
+        dist.send(torch.frombuffer(bytearray(buf), dtype=torch.uint8), dst=dst, group=group)
+
+
+def _recv_obj(src, group):
+    n = torch.zeros(1, dtype=torch.int64)
+    dist.recv(n, src=src, group=group)
+    data = torch.empty(int(n.item()), dtype=torch.uint8)
+    if data.numel():
+        dist.recv(data, src=src, group=group)
+    return pickle.load(io.BytesIO(data.numpy().tobytes()))
+
+
+_HOST_GROUP = None
+
+
+def host_group():
+    """A gloo group for host objects (the default group may be RCCL, which only moves device tensors)."""
+    global _HOST_GROUP
+    if _HOST_GROUP is None:
+        _HOST_GROUP = dist.new_group(backend="gloo") if dist.get_backend() != "gloo" else dist.group.WORLD
+    return _HOST_GROUP
+
+
+def ordered_records(local_records, rank=None, world=None, batch=64, group=None):
+    """Merge the per-rank record streams into global input order on rank 0.
+
+    `local_records`: this rank's records in ITS order; its k-th record is global record ``rank + k * world`` (what
+    `Reader.get_reads(rank=, world=)` / `shard` produce). Records must be picklable.
+
+    Rank 0: returns a generator over ALL records in global order (record i is pulled from rank i % world's stream; the
+    stream of a rank is a sequence of messages of up to `batch` records, the last one flagged). Other ranks: the call
+    sends this rank's records to rank 0 as they are produced, blocks while rank 0 is behind (bounded window: gloo's
+    send completes when the matching recv is posted), and returns an empty iterator when done."""
+    if rank is None or world is None:
+        rank, world, _ = env_rank_world()
+    if world == 1:
+        return iter(local_records)
+    group = group or host_group()
+    if rank != 0:
+        pending = []
+        for rec in local_records:
+            pending.append(rec)
+            if len(pending) == batch:
+                _send_obj((pending, False), 0, group)
+                pending = []
+        _send_obj((pending, True), 0, group)
+        return iter(())
+
+    def merged():
+        local = iter(local_records)
+        bufs = [[] for _ in range(world)]        # records received from rank r and not yet emitted
+        done = [False] * world
+        i = 0
+        while True:
+            src = i % world
+            if src == 0:
+                try:
+                    yield next(local)
+                except StopIteration:
+                    break
+            else:
+                while not bufs[src] and not done[src]:
+                    recs, last = _recv_obj(src, group)
+                    bufs[src] = recs
+                    done[src] = last
+                if not bufs[src]:
+                    break                        # rank src is exhausted: indices are dense, so nothing follows i
+                yield bufs[src].pop(0)
+            i += 1
+        for r in range(1, world):                # drain the final (possibly empty) messages so no sender is left blocked
+            while not done[r]:
+                recs, last = _recv_obj(r, group)
+                assert not recs or last, "rank %d holds records beyond the end of the stream" % r
+                assert not recs, "rank %d holds records beyond the end of the stream" % r
+                done[r] = last
+        assert not any(bufs), "records left over after the merge"
+
+    return merged()
+
+
+def format_stream(results, mode, min_qscore=0.0):
+    """(read, result) pairs of this rank -> the picklable (text, summary_row, log) triples rank 0 writes."""
+    from bonito_amd.io import format_record
+    for read, res in results:
+        yield format_record(read, res, mode, min_qscore)
+
+
+def gather_in_order(indexed_results, rank=None, world=None, dst=0):
+    """`indexed_results`: iterable of (global_index, payload) produced by this rank. Returns the payloads of ALL
+    ranks in global order on rank `dst` (None elsewhere). Small results only (everything is held in memory): the
+    product path streams through `ordered_records` instead."""
+    if rank is None or world is None:
+        rank, world, _ = env_rank_world()
+    mine = list(indexed_results)
+    if world == 1:
+        return [p for _, p in sorted(mine, key=lambda kv: kv[0])]
+    gathered = [None] * world if rank == dst else None
+    dist.gather_object(mine, gathered, dst=dst, group=host_group())
+    if rank != dst:
+        return None
+    merged = sorted((kv for part in gathered for kv in part), key=lambda kv: kv[0])
+    idx = [k for k, _ in merged]
+    assert idx == list(range(len(idx))), "shards do not cover the input exactly once"
+    return [p for _, p in merged]
+
+
 def basecall_sharded(basecall_fn, model, reads, **kwargs):
-    """Run `basecall_fn(model, reads_of_this_rank, **kwargs)` on every rank and return all
-    (read_id, result) pairs in input order on rank 0."""
+    """Run `basecall_fn(model, reads_of_this_rank, **kwargs)` on every rank and return a generator over all
+    (read_id, result) pairs in input order on rank 0 (an empty iterator elsewhere). `reads` is the FULL read iterable
+    (sharded here, lazily); callers that can shard at the source (`Reader.get_reads(rank=, world=)`) should do that and use
+    `ordered_records` directly."""
     rank, world, _ = env_rank_world()
-    mine = list(shard(reads, rank, world))
-    index_of = {id(read): i for i, read in mine}
-    out = ((index_of[id(read)], (getattr(read, "read_id", None), res))
-           for read, res in basecall_fn(model, (r for _, r in mine), **kwargs))
-    return gather_in_order(out, rank, world)
+    mine = (read for _, read in shard(reads, rank, world))
+    out = ((getattr(read, "read_id", None), res) for read, res in basecall_fn(model, mine, **kwargs))
+    return ordered_records(out, rank, world)

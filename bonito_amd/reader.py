@@ -116,11 +116,17 @@ class Reader:
             raise FileNotFoundError("no .npy or .pod5 reads found in '%s'" % directory)
 
     def get_reads(self, read_ids=None, skip=False, do_trim=True, scaling_strategy=None, norm_params=None, n_max=None,
-                  cancel=None, raw=False):
-        count = 0
+                  cancel=None, raw=False, rank=0, world=1):
+        """Reads in directory order. `rank` / `world`: record-level round-robin shard for one-process-per-GPU runs -- the
+        i-th selected read (after `read_ids` / `skip` / `n_max`) belongs to rank i % world, and a rank loads, scales,
+        normalises and trims ONLY its own reads (the other files are never opened beyond their side-car)."""
+        index = -1        # global index of the selected read (same on every rank)
 
         def wanted(rid):
             return read_ids is None or ((rid in read_ids) ^ skip)
+
+        def stop():
+            return (n_max and index + 1 >= n_max) or (cancel is not None and cancel.is_set())
 
         for path in self.npy:
             meta = {}
@@ -131,25 +137,19 @@ class Reader:
             rid = meta.get("read_id", os.path.splitext(os.path.basename(path))[0])
             if not wanted(rid):
                 continue
-            data = np.load(path)
-            if raw and data.dtype == np.int16:
-                yield RawRead(rid, data, filename=os.path.basename(path), run_id=meta.get("run_id", ""),
-                              channel=meta.get("channel", 0), mux=meta.get("mux", 0), start=meta.get("start", 0.0),
-                              sample_rate=meta.get("sample_rate", 5000.0), scaling=meta.get("scale", 1.0),
-                              offset=meta.get("offset", 0.0))
-                count += 1
-                if (n_max and count >= n_max) or (cancel is not None and cancel.is_set()):
-                    return
-                continue
-            if raw:
-                raise ValueError("%s: device ingest needs int16 raw samples (got %s)" % (path, data.dtype))
-            yield Read(rid, data, filename=os.path.basename(path), run_id=meta.get("run_id", ""),
-                       channel=meta.get("channel", 0), mux=meta.get("mux", 0), start=meta.get("start", 0.0),
-                       sample_rate=meta.get("sample_rate", 5000.0), scaling=meta.get("scale", 1.0),
-                       offset=meta.get("offset", 0.0), do_trim=do_trim, scaling_strategy=scaling_strategy,
-                       norm_params=norm_params)
-            count += 1
-            if (n_max and count >= n_max) or (cancel is not None and cancel.is_set()):
+            index += 1
+            if index % world == rank:
+                data = np.load(path)
+                common = dict(filename=os.path.basename(path), run_id=meta.get("run_id", ""), channel=meta.get("channel", 0),
+                              mux=meta.get("mux", 0), start=meta.get("start", 0.0), sample_rate=meta.get("sample_rate", 5000.0),
+                              scaling=meta.get("scale", 1.0), offset=meta.get("offset", 0.0))
+                if raw:
+                    if data.dtype != np.int16:
+                        raise ValueError("%s: device ingest needs int16 raw samples (got %s)" % (path, data.dtype))
+                    yield RawRead(rid, data, **common)
+                else:
+                    yield Read(rid, data, do_trim=do_trim, scaling_strategy=scaling_strategy, norm_params=norm_params, **common)
+            if stop():
                 return
         if self.pod5:
             try:
@@ -162,11 +162,13 @@ class Reader:
                         rid = str(rec.read_id)
                         if not wanted(rid):
                             continue
-                        cal = rec.calibration
-                        yield Read(rid, rec.signal, filename=os.path.basename(path), run_id=rec.run_info.acquisition_id,
-                                   channel=rec.pore.channel, mux=rec.pore.well, start=rec.start_sample / rec.run_info.sample_rate,
-                                   sample_rate=rec.run_info.sample_rate, scaling=cal.scale, offset=cal.offset, do_trim=do_trim,
-                                   scaling_strategy=scaling_strategy, norm_params=norm_params)
-                        count += 1
-                        if (n_max and count >= n_max) or (cancel is not None and cancel.is_set()):
+                        index += 1
+                        if index % world == rank:
+                            cal = rec.calibration
+                            yield Read(rid, rec.signal, filename=os.path.basename(path), run_id=rec.run_info.acquisition_id,
+                                       channel=rec.pore.channel, mux=rec.pore.well,
+                                       start=rec.start_sample / rec.run_info.sample_rate, sample_rate=rec.run_info.sample_rate,
+                                       scaling=cal.scale, offset=cal.offset, do_trim=do_trim, scaling_strategy=scaling_strategy,
+                                       norm_params=norm_params)
+                        if stop():
                             return

@@ -56,8 +56,10 @@ enum {
     BH_LAYER_TCS_BLOCK = 7,   /* reserved */
     BH_LAYER_CTC_DECODER = 8, /* bonito.ctc Decoder: 1x1 conv + log_softmax (ctc/model.py:195-207); final layer */
     BH_LAYER_DWCONV = 9,      /* depthwise half of TCSConv1d (ctc/model.py:99-103): groups = channels, no bias */
-    BH_LAYER_RESIDUAL_PROJ = 10 /* Block.residual (ctc/model.py:166-167): 1x1 conv + folded BN of the block input,
-                                 * kept aside and added by the next BH_LAYER_CONV whose `add_residual` is set */
+    BH_LAYER_RESIDUAL_PROJ = 10, /* Block.residual (ctc/model.py:166-167): 1x1 conv + folded BN of the block input,
+                                  * kept aside and added by the next BH_LAYER_CONV whose `add_residual` is set */
+    BH_LAYER_LINEAR = 11      /* linear (nn.py:27-52): y = x W^T + b on the feature axis, any layout
+                               * (dna_r10.4.1@v4.0.toml:101-104: 1024 -> 256 between the LSTM stack and the CRF head) */
 };
 
 /* One layer of an encoder.  All weight pointers are HOST fp32 arrays in torch's native layout; the
@@ -118,6 +120,11 @@ int bh_encoder_set_option(bh_encoder_t* enc, const char* name, int value);
 int bh_encoder_debug_read(bh_encoder_t* enc, void* host, size_t bytes, size_t offset);
 /* non-zero if a device-side timeout was raised by a persistent kernel since the last call (synchronises stream) */
 int bh_encoder_check(bh_encoder_t* enc, void* stream);
+/* Same flag WITHOUT synchronising: every bh_encoder_forward ends with a 4-byte copy of the (sticky) device flag into pinned
+ * host memory on its stream, so once the caller has observed the completion of a forward (event, decoded outputs on the host,
+ * stream synchronise) this returns non-zero iff that forward or an earlier one timed out -- its scores are then INVALID and
+ * must not be used (bonito_amd raises). Cleared by bh_encoder_check. */
+int bh_encoder_error_flag(const bh_encoder_t* enc);
 
 /* Per-kernel-class timing with HIP events recorded on the forward's stream (measurement only).
  * After enabling, every bh_encoder_forward appends spans; profile_read synchronises on them and returns
@@ -171,7 +178,9 @@ int bh_signal_chunks(const int16_t* raw, const long* offsets, const float* cal_s
  *   "beam_select": 0 (default) = top-W selection by histogram + exact boundary ranking, 1 = MSB-first radix search
  *                (the same beams either way; kept for regression tests and A/B timing).
  *   "conv_ws": 1 (default) = weight-stationary kernel for the 384-channel / 19-tap convolution, 0 = generic implicit GEMM.
- *   "gemm_path": 0 auto (default), 1 = register-staged 128x128x64 kernel only, 2 = never the persistent 256x256x64 kernel. */
+ *   "gemm_path": 0 auto (default), 1 = register-staged 128x128x64 kernel only, 2 = never the persistent 256x256x64 kernel.
+ *   "lstm_max_spins": bound of the recurrent kernels' exchange spin loops (default 1000000; < 0 restores it). Tests lower it
+ *                to provoke the timeout path (bh_encoder_error_flag / bh_encoder_check). */
 int bh_set_option(const char* name, int value);
 
 /* Posterior decoding = SeqdistModel.decode_batch (crf/model.py:196-199): Viterbi over log(edge posteriors + 1e-8).

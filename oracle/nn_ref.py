@@ -203,6 +203,9 @@ def forward(m, x, expand_blanks=None):
         return crf_encoder_forward(m, x, expand_blanks)
     if n == "clamp":
         return torch.clamp(x, m.min, m.max)
+    if n == "linear":                     # bonito/nn.py:27-38
+        y = x @ m.linear.weight.float().T
+        return y if m.linear.bias is None else y + m.linear.bias.float()
     if n == "linearupsample":
         if not m.batch_first:
             x = x.permute(1, 0, 2)

@@ -60,7 +60,8 @@ def test_writer_filters_and_logs(tmp_path):
     buf = io.StringIO()
     w = bio.Writer("fastq", iter([(R, good), (R, bad)]), fd=buf, min_qscore=7.0, summary_path=str(tmp_path / "s.tsv"))
     w.start(); w.join()
-    assert w.error is None and w.log == [("r1", 5000)]
+    # like the reference (io.py:437-442): every read is logged BEFORE the q-score filter, with its post-trim sample count
+    assert w.error is None and w.log == [("r1", 4960), ("r1", 4960)]
     out = buf.getvalue().splitlines()
     assert out[0].startswith("@r1 RG:Z:run\tqs:f:20.00\tns:i:5000\tts:i:40\tmv:B:c,6,1,0,1,1,0,1") and out[1] == "ACGT"
     rows = (tmp_path / "s.tsv").read_text().splitlines()

@@ -1,0 +1,60 @@
+"""Every model config shipped with the reference (bonito/models/configs/*.toml, copied as TEST DATA into
+tests/golden/configs/) must build through the bonito_amd registry, lower to a bh_layer_t chain, and load a state dict
+whose keys are renamed (util.match_names, reference util.py:239-248). CPU only: no compute, no engine."""
+import glob
+import os
+from collections import OrderedDict
+
+import pytest
+import torch
+
+from conftest import GOLDEN
+from bonito_amd import _lib, engine, util
+
+CONFIGS = sorted(glob.glob(os.path.join(GOLDEN, "configs", "*.toml")))
+
+
+def build_from_config(path, seed=25):
+    cfg = util.set_config_defaults(util.load_toml(path))
+    torch.manual_seed(seed)
+    model = util.load_symbol(cfg, "Model")(cfg)
+    model.eval()
+    return cfg, model
+
+
+def test_all_seven_reference_configs_are_present():
+    assert len(CONFIGS) == 7, CONFIGS
+
+
+@pytest.mark.parametrize("path", CONFIGS, ids=[os.path.basename(p) for p in CONFIGS])
+def test_config_builds_and_lowers(path):
+    cfg, model = build_from_config(path)
+    pkg = cfg["model"]["package"]
+    if pkg == "bonito.ctc":
+        low = engine.lower_ctc(model)
+        assert low.descs[-1].kind == _lib.BH_LAYER_CTC_DECODER
+        assert model.stride == 3
+    else:
+        low = engine.lower(model.encoder)
+        kinds = [d.kind for d in low.descs]
+        assert _lib.BH_LAYER_LINEAR_CRF in kinds
+        assert model.stride == (6 if "v5.0" in path or "v4.3" in path else 5)
+        if "v4.0" in path:        # LSTM-1024 -> Linear 1024->256 -> CRF head (toml lines 101-104)
+            i = kinds.index(_lib.BH_LAYER_LINEAR)
+            assert (low.descs[i].in_size, low.descs[i].out_size) == (1024, 256)
+            assert kinds[i + 1] == _lib.BH_LAYER_LINEAR_CRF and low.descs[i + 1].in_size == 256
+    assert len(low.descs) > 3
+
+
+@pytest.mark.parametrize("path", CONFIGS, ids=[os.path.basename(p) for p in CONFIGS])
+def test_config_loads_renamed_state_dict(path):
+    """A checkpoint with foreign key names but the same shape sequence loads through match_names and lands on the
+    same parameters (what util._load_model does for every weights_N.tar)."""
+    cfg, model = build_from_config(path, seed=1)
+    _, donor = build_from_config(path, seed=2)
+    renamed = OrderedDict(("module.w%03d" % i, v.clone()) for i, (k, v) in enumerate(donor.state_dict().items()))
+    remap = util.match_names(renamed, model)
+    state = {k2: renamed[k1] for k1, k2 in remap.items()}
+    model.load_state_dict(state)
+    for (k, v), (k2, v2) in zip(model.state_dict().items(), donor.state_dict().items()):
+        assert k == k2 and torch.equal(v, v2), k

@@ -257,3 +257,138 @@ def test_full_size_pipelined_steps_equal_serial_execution():
     assert len(outs) == 6
     for i, got in enumerate(outs):
         assert torch.equal(got, serial[i & 1]), "pipelined step %d differs from the serial run" % i
+
+
+def _write_model_dir(mdir, fixture="lstm64_sl3", state_len=3, batchsize=8, chunksize=1200, overlap=120):
+    import json
+    from conftest import load_nn_fixture
+    cfg, sd, _, _ = load_nn_fixture(fixture)
+
+    def tv(v):
+        if isinstance(v, bool):
+            return "true" if v else "false"
+        if isinstance(v, str):
+            return json.dumps(v)
+        if isinstance(v, list):
+            return "[" + ", ".join(tv(i) for i in v) + "]"
+        return repr(v)
+
+    lines = ['[model]', 'package = "bonito.crf"', '[labels]', 'labels = ["N", "A", "C", "G", "T"]', '[input]',
+             'features = 1', '[global_norm]', 'state_len = %d' % state_len, '[basecaller]', 'batchsize = %d' % batchsize,
+             'chunksize = %d' % chunksize, 'overlap = %d' % overlap, '[encoder]', 'type = "serial"']
+    for sub in cfg["sublayers"]:
+        lines.append("[[encoder.sublayers]]")
+        lines += ["%s = %s" % (k, tv(v)) for k, v in sub.items()]
+    (mdir / "config.toml").write_text("\n".join(lines) + "\n")
+    sd = {k: (v * 30.0 if k.endswith("linear.weight") else v) for k, v in sd.items()}
+    torch.save(sd, str(mdir / "weights_1.tar"))
+
+
+def test_cli_multi_process_devices_equals_single_device(tmp_path):
+    """`--devices 0,0`: two worker processes (here both on GPU 0: the launcher, the record-level shard, the per-rank
+    formatting and rank 0's ordered streaming writer are what is under test) write exactly the bytes of the one-process run.
+    lstm96 fixture: the ring-in-a-workgroup LSTM kernel has no co-residency requirement, so two processes may share a GPU."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    mdir, rdir = tmp_path / "model", tmp_path / "reads"
+    mdir.mkdir(); rdir.mkdir()
+    _write_model_dir(mdir, fixture="lstm96_sl3")
+    rng = np.random.default_rng(8)
+    for i in range(9):
+        np.save(rdir / ("read%d.npy" % i), (rng.standard_normal(int(rng.integers(700, 9000))) * 12 + 90).astype(np.float32))
+    outs = []
+    for extra in ([], ["--devices", "0,0"], ["--devices", "0,0,0", "--sam"], ["--sam"]):
+        summ = tmp_path / ("summary%d.tsv" % len(outs))
+        r = subprocess.run([sys.executable, "-m", "bonito_amd", "basecaller", str(mdir), str(rdir), "--summary", str(summ),
+                            "--batchsize", "8"] + extra, capture_output=True, text=True, cwd=ROOT, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        assert "completed reads: 9" in r.stderr and "samples per second" in r.stderr
+        outs.append(("\n".join(l for l in r.stdout.split("\n") if not l.startswith("@PG")), summ.read_text()))
+    assert outs[0] == outs[1] and len(outs[0][0].strip().split("\n")) == 36
+    assert outs[2] == outs[3] and outs[2][0].startswith("@HD")
+
+
+def test_exchange_timeout_surfaces_as_an_exception_never_as_output():
+    """The persistent LSTM kernels bound every spin; on a timeout they raise a device flag and finish with INVALID output.
+    The product path must turn that into an exception: `basecall` reads the flag (mirrored to pinned host memory behind every
+    forward) after each batch's decode and raises instead of yielding. Provoked here by lowering the spin bound to 0 (the first incomplete poll round is a timeout)."""
+    from bonito_amd import _lib, synthetic
+    dev = torch.device("cuda", 0)
+    model = synthetic.make_model("hac", batchsize=64, chunksize=3000)
+    model.use_koi(batchsize=64, chunksize=3000, quantize=False)
+    model = model.half().to(dev)
+    rng = np.random.default_rng(1)
+    reads = _reads(rng, [9000] * 40)
+    good = list(crf_basecall_fn(model, iter(reads), chunksize=3000, overlap=300, batchsize=64))
+    assert len(good) == 40
+    try:
+        decode.set_option("lstm_max_spins", 0)
+        with pytest.raises(_lib.HipEngineError):
+            list(crf_basecall_fn(model, iter(reads), chunksize=3000, overlap=300, batchsize=64))
+    finally:
+        decode.set_option("lstm_max_spins", -1)      # back to the default bound
+    with pytest.raises(_lib.HipEngineError):         # sticky until bh_encoder_check clears it
+        model._hip.check()
+    again = list(crf_basecall_fn(model, iter(reads), chunksize=3000, overlap=300, batchsize=64))
+    assert [(r.read_id, res["sequence"]) for r, res in again] == [(r.read_id, res["sequence"]) for r, res in good]
+
+
+def test_concurrent_engines_never_yield_wrong_calls():
+    """Three engine replicas of a model whose recurrent kernel needs all of its workgroups co-resident (hac, 512-chunk batches
+    = 256 workgroups each), driven concurrently from three streams next to decode work, with a low spin bound: whenever the
+    dispatcher interleaves their workgroups a ring starves and times out. Every batch must either raise or equal the serial
+    result -- a timeout may never surface as output."""
+    from bonito_amd import _lib, synthetic
+    dev = torch.device("cuda", 0)
+    models = []
+    for _ in range(3):
+        m = synthetic.make_model("hac", batchsize=512, chunksize=2400)
+        m.use_koi(batchsize=512, chunksize=2400, quantize=False)
+        models.append(m.half().to(dev))
+    x = torch.randn(512, 1, 2400, generator=torch.Generator().manual_seed(3)).half().to(dev)
+    want = models[0](x).clone()
+    models[0]._hip.check()
+    streams = [torch.cuda.Stream(dev) for _ in range(3)]
+    ok = bad = 0
+    try:
+        decode.set_option("lstm_max_spins", 20000)
+        for it in range(4):
+            outs = []
+            for m, st in zip(models, streams):
+                with torch.cuda.stream(st):
+                    outs.append(m(x))
+            with torch.cuda.stream(streams[0]):
+                decode.beam_search(want[:64].contiguous())          # decode kernels competing for the CUs
+            torch.cuda.synchronize(dev)
+            for m, sc in zip(models, outs):
+                try:
+                    m._hip.poll()
+                except _lib.HipEngineError:
+                    bad += 1
+                    with pytest.raises(_lib.HipEngineError):
+                        m._hip.check()                              # synchronising variant agrees, and clears the flag
+                    continue
+                ok += 1
+                assert torch.equal(sc, want), "a batch that reported no timeout differs from the serial result"
+    finally:
+        decode.set_option("lstm_max_spins", -1)
+    assert ok + bad == 12
+    for m in models:
+        m._hip.check()
+        assert torch.equal(m(x), want)
+
+
+def test_engine_is_rebuilt_after_weights_change():
+    """load_state_dict / .half() / apply(fuse_bn_) after a forward must not leave the engine on stale weights."""
+    from bonito_amd.nn import fuse_bn_
+    model = _model(996, 4)
+    x = torch.randn(2, 1, 996, generator=torch.Generator().manual_seed(0)).half().cuda()
+    a = model(x).clone()
+    sd = {k: (v * 0.5 if "rnn.weight_hh" in k else v) for k, v in model.state_dict().items()}
+    model.load_state_dict(sd)
+    b = model(x).clone()
+    assert not torch.equal(a, b)
+    model = model.apply(fuse_bn_)
+    c = model(x)
+    assert (c.float() - b.float()).abs().max().item() < 2e-2        # folding changes rounding only

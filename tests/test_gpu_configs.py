@@ -1,0 +1,193 @@
+"""Parity at the sizes and architectures BASELINE.json names (-m gpu).
+
+1. every reference config (tests/golden/configs/*.toml = bonito/models/configs/*.toml, test data) runs on the HIP engine and
+   matches the fp32 oracle (oracle/nn_ref.py, pinned to the reference's bonito/nn.py by tests/golden/nn_*.npz) on a small batch;
+2. the four BASELINE configurations at FULL batch x chunk size: >= 4 chunks of the full batch are compared with the fp32
+   oracle (scores) and the HIP decode of the HIP scores with oracle/crf_oracle.c (sequence / moves bit-exact, q < 1e-3).
+
+The measured errors are written to gpurun_out/parity_<name>.json; the bounds below are <= 5x what was measured on MI355X.
+"""
+import copy
+import glob
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, ROOT
+from bonito_amd import decode, synthetic, util
+from bonito_amd.crf.basecall import fmt
+from oracle import crf_ref, nn_ref
+
+pytestmark = pytest.mark.gpu
+CONFIGS = sorted(glob.glob(os.path.join(GOLDEN, "configs", "*.toml")))
+
+
+def _record(name, **vals):
+    out = os.path.join(ROOT, "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    with open(os.path.join(out, "parity_%s.json" % name), "w") as fh:
+        json.dump(vals, fh)
+
+
+def _head_gain_(model, gain):
+    """A freshly initialised CRF head never beats the blank score: scale it so that decoding emits bases."""
+    from bonito_amd.nn import LinearCRFEncoder
+    with torch.no_grad():
+        for m in model.modules():
+            if isinstance(m, LinearCRFEncoder):
+                m.linear.weight.mul_(gain)
+
+
+def _gpu_copy(model, batch, chunk):
+    g = copy.deepcopy(model)
+    g.use_koi(batchsize=batch, chunksize=chunk, quantize=False)
+    return g.half().to("cuda")
+
+
+def _oracle_scores(model, rows):
+    """fp32 oracle scores of `rows` [n,1,L] in the engine's layout [n,T,C] (koi layout when a blank score is fixed)."""
+    with torch.no_grad():
+        y = nn_ref.forward(model.encoder, rows.float(), expand_blanks=False)
+    enc = model.encoder
+    last = [m for m in enc.modules() if type(m).__name__ == "LinearCRFEncoder"][-1]
+    if last.permute is None:          # TNC out of the recurrent stacks; the transformer head permutes to TNC as well
+        y = y.permute(1, 0, 2)
+    elif list(last.permute) == [1, 0, 2]:
+        y = y.permute(1, 0, 2)
+    return y.contiguous()
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# 1. every in-tree config of the reference, small batch
+SMALL = {   # chunk samples (multiple of the stride), oracle tolerance (max, mean) on scores in [-5, 5]
+    "dna_r10.4.1@v4.0.toml": (1500, 3e-2, 3e-3),
+    "dna_r10.4.1@v4.3.toml": (1800, 3e-2, 3e-3),
+    "dna_r10.4.1@v5.0.toml": (2400, 1e-1, 1e-2),
+    "dna_r9.4.1@v3.1.toml": (1500, 3e-2, 3e-3),
+    "dna_r9.4.1@v3.toml": (1500, 3e-2, 3e-3),
+}
+
+
+@pytest.mark.parametrize("path", CONFIGS, ids=[os.path.basename(p) for p in CONFIGS])
+def test_reference_config_matches_oracle_small(path):
+    name = os.path.basename(path)
+    cfg = util.set_config_defaults(util.load_toml(path))
+    torch.manual_seed(25)
+    model = util.load_symbol(cfg, "Model")(cfg).eval()
+    synthetic.randomise_batchnorm_(model)
+    nn_ref.round_params_to_half_(model)
+    if cfg["model"]["package"] == "bonito.ctc":
+        x = torch.randn(3, 1, 1200, generator=torch.Generator().manual_seed(1)).half()
+        g = _gpu_copy(model, 3, 1200)
+        got = g(x.cuda()).cpu().float()
+        g._hip.check()
+        with torch.no_grad():
+            want = nn_ref.ctc_forward(model, x.float())
+        assert got.shape == want.shape
+        d = (got - want).abs()
+        _record("small_" + name, max=d.max().item(), mean=d.mean().item())
+        assert d.max().item() < 5e-2 and d.mean().item() < 5e-3, (d.max().item(), d.mean().item())
+        return
+    L, tol_max, tol_mean = SMALL[name]
+    _head_gain_(model, 8.0)
+    nn_ref.round_params_to_half_(model)
+    x = torch.randn(3, 1, L, generator=torch.Generator().manual_seed(1)).half()
+    g = _gpu_copy(model, 3, L)
+    got = g(x.cuda())
+    g._hip.check()
+    want = _oracle_scores(model, x)
+    assert tuple(got.shape) == tuple(want.shape), (got.shape, want.shape)
+    d = (got.cpu().float() - want).abs()
+    rng = max(1.0, want.abs().max().item() / 5.0)
+    _record("small_" + name, max=d.max().item(), mean=d.mean().item(), range=want.abs().max().item())
+    assert d.max().item() < tol_max * rng and d.mean().item() < tol_mean * rng, (d.max().item(), d.mean().item(), rng)
+    # decode of the engine's scores == oracle decode of the same scores
+    S = 4 ** model.seqdist.state_len
+    if got.shape[-1] == 4 * S:
+        mv, path = decode.viterbi(got)
+        om, op, _ = crf_ref.viterbi(got.cpu().numpy(), model.seqdist.state_len, blank=2.0)
+    else:                              # learned blank column (dna_r9.4.1@v3: no blank_score): reference 5S layout
+        N, T, C = got.shape
+        tnc = got.permute(1, 0, 2).contiguous()
+        mv, path = decode.viterbi_5s(tnc, model.seqdist.state_len)
+        om, op, _ = crf_ref.viterbi(tnc.cpu().numpy(), model.seqdist.state_len, layout_5s=True, time_major=True)
+    assert np.array_equal(path.numpy(), op) and np.array_equal(mv.numpy(), om)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# 2. BASELINE configurations at full size
+ROWS = [0, 17, 255, -1]
+
+
+def _full_size(name, model, batch, chunk, tol_max, tol_mean, rna=False):
+    sl = model.seqdist.state_len
+    nn_ref.round_params_to_half_(model)
+    x = torch.randn(batch, 1, chunk, generator=torch.Generator().manual_seed(25)).half()
+    g = _gpu_copy(model, batch, chunk)
+    scores = g(x.cuda())
+    g._hip.check()
+    rows = [r % batch for r in ROWS]
+    want = _oracle_scores(model, x[rows])
+    got = scores[rows].cpu().float()
+    assert got.shape == want.shape, (got.shape, want.shape)
+    d = (got - want).abs()
+    rng = max(1.0, want.abs().max().item() / 5.0)
+    # HIP decode of the whole batch vs the C oracle on the same fp16 scores, selected rows
+    seq, qs, mv, qf = decode.beam_search(scores, return_qfloat=True)
+    sub = scores[rows].cpu().numpy()
+    oseq, oqs, omv, oqf = crf_ref.beam_search(sub, sl)
+    vm, vp = decode.viterbi(scores)
+    om, op, _ = crf_ref.viterbi(sub, sl, blank=2.0)
+    qd = float(np.abs(qf.numpy()[rows] - oqf).max())
+    _record("full_" + name, max=d.max().item(), mean=d.mean().item(), range=want.abs().max().item(), q_max=qd,
+            bases=int((omv != 0).sum()), T=int(scores.shape[1]), C=int(scores.shape[2]))
+    assert np.array_equal(mv.numpy()[rows], omv) and np.array_equal(seq.numpy()[rows], oseq)
+    assert np.array_equal(vp.numpy()[rows], op) and np.array_equal(vm.numpy()[rows], om)
+    assert qd < 1e-3
+    assert (qs.numpy()[rows] != oqs).mean() < 1e-3
+    assert int((omv != 0).sum()) > 100            # the synthetic head does emit bases
+    assert d.max().item() < tol_max * rng and d.mean().item() < tol_mean * rng, (d.max().item(), d.mean().item(), rng)
+    # the strings the basecaller would write for these chunks (rna = reversed, crf/basecall.py:48-55)
+    for i, r in enumerate(rows):
+        res = fmt(g.stride, {"moves": mv[r], "qstring": qs[r], "sequence": seq[r]}, rna=rna)
+        want_seq = decode.to_str(torch.from_numpy(oseq[i]))
+        assert res["sequence"] == (want_seq[::-1] if rna else want_seq)
+        assert len(res["qstring"]) == len(res["sequence"])
+    return scores
+
+
+def test_full_size_fast_512x10000():
+    model = synthetic.make_model("fast", batchsize=512, chunksize=10000)
+    sc = _full_size("fast", model, 512, 10000, 3e-2, 3e-3)
+    assert sc.shape == (512, 1667, 256)
+
+
+def test_full_size_hac_512x10000():
+    model = synthetic.make_model("hac", batchsize=512, chunksize=10000)
+    sc = _full_size("hac", model, 512, 10000, 3e-2, 3e-3)
+    assert sc.shape == (512, 1667, 1024)
+
+
+def test_full_size_sup_v5_transformer_256x12000():
+    """Exactly the graph of bonito/models/configs/dna_r10.4.1@v5.0.toml (d=512, 8 heads, 18 layers, window 127/128, C=4096)."""
+    cfg = util.set_config_defaults(util.load_toml(os.path.join(GOLDEN, "configs", "dna_r10.4.1@v5.0.toml")))
+    torch.manual_seed(25)
+    model = util.load_symbol(cfg, "Model")(cfg).eval()
+    synthetic.randomise_batchnorm_(model)
+    _head_gain_(model, 4.0)
+    sc = _full_size("sup_v5", model, 256, 12000, 1e-1, 1e-2)
+    assert sc.shape == (256, 2000, 4096)
+
+
+def test_full_size_sup_lstm_v43_256x20000_rna():
+    """bonito/models/configs/dna_r10.4.1@v4.3.toml (LSTM-1024, state_len 5) at BASELINE config 5's shape, rna=True."""
+    cfg = util.set_config_defaults(util.load_toml(os.path.join(GOLDEN, "configs", "dna_r10.4.1@v4.3.toml")))
+    torch.manual_seed(25)
+    model = util.load_symbol(cfg, "Model")(cfg).eval()
+    synthetic.randomise_batchnorm_(model)
+    _head_gain_(model, 24.0)
+    sc = _full_size("sup_lstm_v43", model, 256, 20000, 3e-2, 3e-3, rna=True)
+    assert sc.shape == (256, 3334, 4096)

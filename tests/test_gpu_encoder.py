@@ -85,7 +85,7 @@ def test_engine_fails_loudly_on_unsupported_layers():
     from bonito_amd import nn as bnn
     from bonito_amd.engine import LoweringError
     with pytest.raises(LoweringError):
-        HipEncoder(bnn.Serial([bnn.Linear(8, 8)]), 1, 100)
+        HipEncoder(bnn.Serial([bnn.Reverse(bnn.Linear(8, 8))]), 1, 100)
 
 
 # ---- transformer encoder ----------------------------------------------------------------------------

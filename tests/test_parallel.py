@@ -1,14 +1,19 @@
-"""N > 1 path on CPU: world_size-2 gloo processes shard reads, process them independently (no collective on
-the data path) and gather in input order; the timing MAX-reduce used by bench.py."""
+"""N > 1 path on CPU: world_size-2 (and 3) gloo processes shard reads at the record level, basecall them independently
+(no collective on the data path), format their own records, and rank 0's REAL Writer streams the merged records in input
+order -- byte-identical to the single-process output. Plus the timing MAX-reduce used by bench.py."""
+import io
+import json
 import os
 import socket
 
+import numpy as np
 import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from bonito_amd import parallel
+from bonito_amd import io as bio
+from bonito_amd import parallel, reader
 
 
 def _free_port():
@@ -17,49 +22,111 @@ def _free_port():
         return s.getsockname()[1]
 
 
-class FakeRead:
-    def __init__(self, i, n):
-        self.read_id, self.signal = "read_%d" % i, torch.arange(n, dtype=torch.float32).numpy() + i
+N_READS = 23
 
 
-def fake_basecall(model, reads, scale=1):
-    """Stands in for bonito_amd.crf.basecall on CPU: same (read, dict) protocol, deterministic payload."""
+def make_reads_dir(path):
+    rng = np.random.default_rng(7)
+    for i in range(N_READS):
+        n = int(rng.integers(900, 6000))
+        np.save(os.path.join(path, "read%02d.npy" % i), (rng.standard_normal(n) * 12 + 90).astype(np.float32))
+        with open(os.path.join(path, "read%02d.json" % i), "w") as fh:
+            json.dump({"read_id": "rid-%02d" % i, "run_id": "run%d" % (i % 2), "channel": i}, fh)
+
+
+def fake_basecall(model, reads, stride=6):
+    """Stands in for bonito_amd.crf.basecall on CPU: same (read, dict) protocol, deterministic, content depends on the
+    read's signal; some reads are empty / low quality so that the writer's filters are exercised."""
     for read in reads:
-        yield read, {"sequence": "ACGT"[int(read.signal[0]) % 4] * (len(read.signal) // 100), "n": int(len(read.signal)) * scale}
+        T = len(read.signal) // stride
+        h = int(np.abs(read.signal[:50]).sum() * 1000) % 9973
+        rng = np.random.default_rng(h)
+        moves = (rng.random(T) < 0.4).astype(np.int8)
+        if h % 7 == 0:
+            moves[:] = 0                                   # empty sequence -> skipped by the writer, still logged
+        n = int(moves.sum())
+        seq = "".join("ACGT"[b] for b in rng.integers(0, 4, n))
+        q = 33 + (3 if h % 5 == 0 else 25)                 # q 3 reads fall under --min-qscore
+        yield read, {"sequence": seq, "qstring": chr(q) * n, "moves": moves, "stride": stride}
 
 
-def _worker(rank, world, port, q):
+def _run_writer(records_or_results, mode, preformatted, summary_path):
+    buf = io.StringIO()
+    w = bio.Writer(mode, records_or_results, fd=buf, min_qscore=7.0, summary_path=summary_path, preformatted=preformatted)
+    w.start()
+    w.join()
+    if w.error is not None:
+        raise w.error
+    with open(summary_path) as fh:
+        return buf.getvalue(), fh.read(), w.log
+
+
+def _worker(rank, world, port, rdir, mode, batch, q):
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
                       MASTER_PORT=str(port))
     r, w, _ = parallel.init("gloo")
     assert (r, w) == (rank, world)
-    reads = [FakeRead(i, 300 + 100 * (i % 5)) for i in range(11)]
-    got = parallel.basecall_sharded(fake_basecall, None, reads, scale=2)
+    reads = reader.Reader(rdir).get_reads(rank=rank, world=world)           # record-level shard: only my files are loaded
+    records = parallel.ordered_records(parallel.format_stream(fake_basecall(None, reads), mode, 7.0), rank, world, batch=batch)
+    out = None
+    if rank == 0:
+        out = _run_writer(records, mode, True, os.path.join(rdir, "summary_w%d.tsv" % world))
+    else:
+        assert list(records) == []
     slow = parallel.max_over_ranks(1.0 + rank)
     dist.barrier()
-    q.put((rank, got, slow))
+    q.put((rank, out, slow))
     dist.destroy_process_group()
 
 
-def test_two_process_shard_and_ordered_gather():
-    world, port = 2, _free_port()
+@pytest.mark.parametrize("world,mode,batch", [(2, "fastq", 4), (3, "sam", 64), (2, "fasta", 1)])
+def test_multi_rank_streaming_writer_is_byte_identical(tmp_path, world, mode, batch):
+    rdir = str(tmp_path)
+    make_reads_dir(rdir)
+    want = _run_writer(fake_basecall(None, reader.Reader(rdir).get_reads()), mode, False, os.path.join(rdir, "summary_1.tsv"))
+    port = _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, rdir, mode, batch, q)) for r in range(world)]
     for p in procs:
         p.start()
     outs = dict()
     for _ in range(world):
-        rank, got, slow = q.get(timeout=120)
-        outs[rank] = (got, slow)
+        rank, out, slow = q.get(timeout=180)
+        outs[rank] = (out, slow)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    assert outs[1][0] is None                      # only rank 0 holds the result
-    got = outs[0][0]
-    want = [(r.read_id, res) for r, res in fake_basecall(None, [FakeRead(i, 300 + 100 * (i % 5)) for i in range(11)], scale=2)]
-    assert got == want                              # identical to the single-process run, in input order
-    assert outs[0][1] == outs[1][1] == 2.0          # MAX over ranks
+    text, summary, log = outs[0][0]
+    if mode == "sam":       # the @PG line quotes the command line of the writing process
+        strip = lambda s: "\n".join(l for l in s.split("\n") if not l.startswith("@PG"))
+        assert strip(text) == strip(want[0])
+    else:
+        assert text == want[0]                               # same bytes as the single-process run, in input order
+    assert summary == want[1]
+    assert log == want[2] and len(log) == N_READS            # every read logged once (filtered ones too), post-trim samples
+    assert len(text) > 1000
+    assert all(outs[r][1] == float(world) for r in range(world))     # MAX over ranks
+
+
+def test_reader_shard_is_a_partition_and_loads_only_its_own(tmp_path, monkeypatch):
+    rdir = str(tmp_path)
+    make_reads_dir(rdir)
+    full = [r.read_id for r in reader.Reader(rdir).get_reads()]
+    loaded = []
+    real_load = np.load
+    monkeypatch.setattr(np, "load", lambda p, *a, **k: (loaded.append(os.path.basename(p)), real_load(p, *a, **k))[1])
+    parts = [[r.read_id for r in reader.Reader(rdir).get_reads(rank=k, world=4)] for k in range(4)]
+    assert sorted(sum(parts, [])) == sorted(full) and len(loaded) == len(full)      # each file opened by exactly one rank
+    for k in range(4):
+        assert parts[k] == full[k::4]
+    # n_max and read_ids are applied before sharding: the union over ranks equals the unsharded selection
+    sel = [r.read_id for r in reader.Reader(rdir).get_reads(n_max=10, read_ids={"rid-03"}, skip=True)]
+    got = [[r.read_id for r in reader.Reader(rdir).get_reads(n_max=10, read_ids={"rid-03"}, skip=True, rank=k, world=3)]
+           for k in range(3)]
+    assert len(sel) == 10 and "rid-03" not in sel
+    for k in range(3):
+        assert got[k] == sel[k::3]
 
 
 def test_shard_is_a_partition():
@@ -70,6 +137,14 @@ def test_shard_is_a_partition():
     assert max(len(p) for p in parts) - min(len(p) for p in parts) <= 1
 
 
-def test_single_process_gather_is_identity():
+def test_single_process_paths_are_identity():
     assert parallel.gather_in_order([(2, "c"), (0, "a"), (1, "b")], 0, 1) == ["a", "b", "c"]
+    assert list(parallel.ordered_records(iter("abc"), 0, 1)) == ["a", "b", "c"]
     assert parallel.max_over_ranks(3.5) == 3.5
+
+
+def test_parse_devices():
+    from bonito_amd.cli.basecaller import parse_devices
+    assert parse_devices("0-7") == list(range(8)) and parse_devices("0,2,5") == [0, 2, 5] and parse_devices("1-2,0") == [1, 2, 0]
+    with pytest.raises(ValueError):
+        parse_devices("")
