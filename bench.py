@@ -2,21 +2,30 @@
 """
 Headline benchmark: signal samples/sec/GPU at chunk=10000, batch=512 (BASELINE.json `metric`).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--model hac|fast] [--decoder viterbi|beam]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--model hac|fast|sup|sup_lstm] [--decoder viterbi|beam] [--quantize]
 
-One "step" = one pass of the hot path over one resident synthetic batch: fp16 signal [512, 10000] in HBM
--> HIP encoder (conv x3, LSTM x5, LinearCRFEncoder) -> HIP CRF decode -> int8 moves/sequence/qstring on
-the host.  Weights are seeded random-init tensors of the named architecture (no checkpoints offline).
-For N > 1 launch with torch.distributed.run; each rank owns one GPU and the same per-GPU workload
-(read chunks shard embarrassingly, no data-path collective) -> "scaling": "weak".
+One "step" = one pass of the hot path over one synthetic batch: fp16 signal [512, 10000] -> HIP encoder (conv x3,
+LSTM x5, LinearCRFEncoder) -> HIP CRF decode -> int8 moves / sequence / qstring on the host. THREE distinct batches rotate
+through the steps. Weights are seeded random-init tensors of the named architecture (no checkpoints offline).
+
+Two timed regions of K steps each (both bracketed by barrier + synchronize, MAX over ranks):
+  * `value` / `ms_per_step`: input batches already resident in HBM when the region starts (the bench contract);
+  * `with_h2d`: the same steps with each batch copied pinned-host -> device on a copy stream inside the step
+    ("H2D of fp16 signal included"). The copy overlaps the previous step's kernels.
+`ms_per_step` is elapsed / K; `ms_per_step_median` is the median distance between consecutive steps' decode-done events.
+
+N > 1: `python bench.py --gpus N` spawns N ranks itself (one process per GPU, RCCL for the barrier and the MAX-reduce only);
+under `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N` the ranks come from the environment. Read
+chunks shard embarrassingly, every rank runs the same per-GPU workload, no data-path collective -> "scaling": "weak".
 
 The JSON line also carries
-  roofline     -- dominant kernel's algorithmic FLOP/s from HIP-event timings on the engine stream
-  cpu_baseline -- the CPU oracle (PyTorch-CPU fp32 restatement of bonito/nn.py + C Viterbi) on a bounded sample
+  roofline     -- dominant kernel's algorithmic FLOP/s from HIP-event timings on the engine stream (kernels running alone)
+  cpu_baseline -- the CPU oracle (PyTorch-CPU fp32 restatement of bonito/nn.py + C Viterbi) on a bounded sample (rank 0, N=1)
 """
 import argparse
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -41,29 +50,32 @@ if _multi_lane(sys.argv[1:]):
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 sys.path.insert(0, ROOT)
 
-import torch  # noqa: E402
-
 MFMA_F16_PEAK_TFLOPS = 2500.0     # MI355X dense fp16/bf16 (MI355X_MICROARCH.md)
+MFMA_I8_PEAK_TOPS = 5000.0        # dense int8 (2x the fp16 rate: v_mfma_i32_16x16x64_i8)
 HBM_PEAK_GBS = 8000.0
+N_BATCHES = 3                     # distinct input batches rotating through the steps
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--model", default="hac", choices=["hac", "fast", "sup", "sup_lstm"])
     ap.add_argument("--batch", type=int, default=0, help="default: 512 (hac/fast), 256 (sup)")
     ap.add_argument("--chunk", type=int, default=0, help="default: 10000 (hac/fast), 12000 (sup)")
     ap.add_argument("--decoder", default="beam", choices=["viterbi", "beam"])
+    ap.add_argument("--quantize", action="store_true",
+                    help="int8 recurrent path (the reference's --quantize, cli/basecaller.py:186-189): Q8-1 kernels; NOT the default")
     ap.add_argument("--lanes", type=int, default=0,
                     help="independent batches in flight (each lane: own engine replica, encoder stream, decoder stream); "
                          "default 1; 3 for the narrow `fast` model whose kernels leave most CUs idle (1 lane 8.9 ms/step, "
                          "3 lanes 4.5 with GPU_MAX_HW_QUEUES=8); hac / sup kernels fill the chip and gain nothing")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-h2d-leg", action="store_true", help="skip the second timed region (H2D inside the step)")
     ap.add_argument("--set", action="append", default=[], metavar="NAME=VALUE",
                     help="library tuning option (bh_set_option), e.g. beam_fork=1; for A/B runs, not part of the contract")
-    a = ap.parse_args()
+    a = ap.parse_args(argv)
     a.batch = a.batch or (256 if a.model in ("sup", "sup_lstm") else 512)
     a.chunk = a.chunk or (12000 if a.model == "sup" else 20000 if a.model == "sup_lstm" else 10000)
     a.lanes = a.lanes or (3 if a.model == "fast" else 1)
@@ -83,16 +95,19 @@ def flops(name, chunk):
 
 
 def pmc_traffic(kernel, a):
-    """HBM bytes per launch of the dominant kernel as measured by the committed PMC passes (profiles/pmc_traffic.json);
-    None when no measurement exists for this kernel / workload."""
+    """(HBM bytes per launch, source file) of the dominant kernel from the committed PMC passes (profiles/pmc_traffic.json:
+    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, gfx950 FETCH_SIZE x2 correction); (None, None) when no
+    measurement exists for this kernel / workload. PMC counters cannot be read from inside this process."""
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as fh:
-            ent = json.load(fh).get(kernel or "")
+            table = json.load(fh)
     except (OSError, ValueError):
-        return None
+        return None, None
+    base = (kernel or "").split("<")[0]
+    ent = table.get(kernel or "") or table.get(base)
     if not ent or ent.get("workload") != "%s %dx%d" % (a.model, a.batch, a.chunk):
-        return None
-    return ent["bytes_per_launch"]
+        return None, None
+    return ent["bytes_per_launch"], ent.get("source")
 
 
 def log(msg):
@@ -105,6 +120,7 @@ T_START = time.perf_counter()
 
 def cpu_baseline_worker(name, chunk, seconds_budget=15.0):
     """CPU oracle timed on this host: oracle/nn_ref.py forward (fp32) + oracle/crf_oracle.c Viterbi."""
+    import torch
     from oracle import crf_ref, nn_ref
     model = build_model(name, 8, chunk)
     nn_ref.round_params_to_half_(model)
@@ -143,27 +159,60 @@ def cpu_baseline(name, chunk, hard_timeout=90.0):
     return None
 
 
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start N copies of this command, one per GPU, wired up like
+    torch.distributed.run does (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT); rank 0 prints the JSON line."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    procs = []
+    for rank in range(n):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if rank == 0 else subprocess.DEVNULL))
+    rcs = [p.wait() for p in procs]
+    if any(rcs):
+        sys.stderr.write("bench.py: rank exit codes %s\n" % rcs)
+    return 1 if any(rcs) else 0
+
+
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(a.gpus))
+    import torch
     import torch.distributed as dist
     from bonito_amd import parallel
     assert torch.cuda.is_available(), "bench.py needs a HIP device; there is no CPU fallback"
-    rank, world, local = parallel.init("nccl")     # one process per GPU; RCCL only for barrier + MAX-reduce
+    ndev = torch.cuda.device_count()
+    # one process per GPU; RCCL only for barrier + MAX-reduce. More ranks than GPUs (a 1-GPU test box running `--gpus 2`):
+    # ranks share devices and the two collectives go over gloo, since RCCL refuses two ranks on one device.
+    oversubscribed = int(os.environ.get("WORLD_SIZE", "1")) > ndev
+    rank, world, local = parallel.init("gloo" if oversubscribed else "nccl")
+    if world != a.gpus:
+        raise SystemExit("bench.py: --gpus %d but the launcher started %d rank(s)" % (a.gpus, world))
+    local %= ndev
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
-    from bonito_amd import decode, synthetic
+    from bonito_amd import decode
     from bonito_amd.util import limit_host_threads
     log("host threads: %d" % limit_host_threads(4))
     for kv in a.set:
         name, _, value = kv.partition("=")
         decode.set_option(name, int(value))
-    log("building model %s" % a.model)
+    log("building model %s%s" % (a.model, " (quantize)" if a.quantize else ""))
     model = build_model(a.model, a.batch, a.chunk)
-    model.use_koi(batchsize=a.batch, chunksize=a.chunk, quantize=False)
+    model.use_koi(batchsize=a.batch, chunksize=a.chunk, quantize=a.quantize)
     model = model.half().to(dev)
     gen = torch.Generator(device=dev).manual_seed(25 + rank)
-    signal = torch.randn(a.batch, 1, a.chunk, generator=gen, device=dev).half()
+    signals = [torch.randn(a.batch, 1, a.chunk, generator=gen, device=dev).half() for _ in range(N_BATCHES)]
+    host_signals = [s.cpu().pin_memory() for s in signals]
+    copy_stream = torch.cuda.Stream(dev)
 
     # A lane = one engine replica (same seeded weights) + its encoder stream + its decoder stream + two decode contexts.
     # Within a lane the decode of batch i overlaps the encoder of batch i+1; lanes overlap whole batches with each other.
@@ -177,39 +226,56 @@ def main():
             ln.model = model
         else:
             ln.model = build_model(a.model, a.batch, a.chunk)
-            ln.model.use_koi(batchsize=a.batch, chunksize=a.chunk, quantize=False)
+            ln.model.use_koi(batchsize=a.batch, chunksize=a.chunk, quantize=a.quantize)
             ln.model = ln.model.half().to(dev)
         ln.enc_stream, ln.dec_stream = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+        ln.stage = [torch.empty_like(signals[0]) for _ in range(2)]      # H2D landing buffers (double buffered)
+        ln.stage_free = [None, None]
         ln.tickets = [None, None]
         ln.count = 0
         lanes.append(ln)
 
-    def encode(ln):
+    def encode(ln, b, h2d):
+        k = ln.count & 1
+        if h2d:
+            with torch.cuda.stream(copy_stream):
+                if ln.stage_free[k] is not None:
+                    copy_stream.wait_event(ln.stage_free[k])      # the forward that read this buffer has finished
+                ln.stage[k].copy_(host_signals[b], non_blocking=True)
+                copied = torch.cuda.Event()
+                copied.record(copy_stream)
+            x = ln.stage[k]
+        else:
+            x = signals[b]
         with torch.cuda.stream(ln.enc_stream):
-            sc = ln.model(signal)
+            if h2d:
+                ln.enc_stream.wait_event(copied)
+            sc = ln.model(x)
             ev = torch.cuda.Event()
             ev.record(ln.enc_stream)
+            if h2d:
+                ln.stage_free[k] = ev
         return sc, ev
 
     # probe output geometry, build two decode contexts per lane (double buffered pinned outputs)
     for ln in lanes:
-        sc0, ev0 = encode(ln)
+        sc0, ev0 = encode(ln, 0, False)
         ev0.synchronize()
         T_out, C_out = sc0.shape[1], sc0.shape[2]
         ln.decs = [decode.CRFDecoder(a.batch, T_out, C_out, dev, mode=a.decoder) for _ in range(2)]
         del sc0
     decs = lanes[0].decs
 
-    def run(steps):
+    def run(steps, h2d=False, marks=None):
         """`steps` passes of the hot path over one batch each, software-pipelined: inside a lane encoder(i+1) overlaps
         decode(i) on two HIP streams, and the lanes run round-robin. Every step's int8 outputs are on the host when this
-        returns."""
+        returns. `marks`: list that receives one timing event per step, recorded behind the step's decode + D2H."""
         for ln in lanes:
             ln.tickets = [None, None]
             ln.count = 0
         for i in range(steps):
             ln = lanes[i % len(lanes)]
-            sc, ev = encode(ln)
+            sc, ev = encode(ln, i % N_BATCHES, h2d)
             k = ln.count & 1
             if ln.tickets[k] is not None:
                 ln.tickets[k].result()             # its pinned buffers are about to be reused
@@ -217,6 +283,10 @@ def main():
                 ln.dec_stream.wait_event(ev)
                 sc.record_stream(ln.dec_stream)
                 ln.tickets[k] = ln.decs[k].submit(sc)
+                if marks is not None:
+                    m = torch.cuda.Event(enable_timing=True)
+                    m.record(ln.dec_stream)
+                    marks.append(m)
             ln.count += 1
         out = None
         for ln in lanes:
@@ -228,35 +298,52 @@ def main():
     def barrier():
         torch.cuda.synchronize(dev)
         if world > 1:
-            dist.barrier(device_ids=[local])
+            dist.barrier() if oversubscribed else dist.barrier(device_ids=[local])
         torch.cuda.synchronize(dev)
+
+    def check_engines():
+        for ln in lanes:
+            ln.model._hip.check()
+
+    def timed(h2d):
+        barrier()
+        marks = []
+        t0 = time.perf_counter()
+        run(a.steps, h2d, marks)
+        barrier()
+        el = time.perf_counter() - t0
+        el = parallel.max_over_ranks(el, device="cpu" if oversubscribed else dev)
+        check_engines()
+        gaps = [marks[i].elapsed_time(marks[i + 1]) for i in range(len(marks) - 1)]
+        return el, (statistics.median(gaps) if gaps else 1e3 * el / a.steps)
 
     log("warmup")
     run(a.warmup)
-    for ln in lanes:
-        ln.model._hip.check()
-    barrier()
-    log("timed region")
-    t0 = time.perf_counter()
-    run(a.steps)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    elapsed = parallel.max_over_ranks(elapsed, device=dev)
-    for ln in lanes:
-        ln.model._hip.check()
-    log("timed region done: %.1f ms/step" % (1e3 * elapsed / a.steps))
+    check_engines()
+    log("timed region (inputs resident in HBM)")
+    elapsed, med = timed(False)
+    log("timed region done: %.2f ms/step (median step %.2f ms)" % (1e3 * elapsed / a.steps, med))
+    h2d = None
+    if not a.no_h2d_leg:
+        run(min(a.warmup, 2), True)
+        el2, med2 = timed(True)
+        samples = a.batch * a.chunk * a.steps * world
+        h2d = {"value": samples / el2, "ms_per_step": 1e3 * el2 / a.steps, "ms_per_step_median": med2,
+               "note": "same K steps with the fp16 batch copied pinned host -> device on a copy stream inside every step"}
+        log("with H2D: %.2f ms/step (median %.2f)" % (1e3 * el2 / a.steps, med2))
 
     # ---- roofline leg: per-kernel-class HIP-event timings on the engine's stream (after the timed region)
     roof = None
     breakdown = None
     if rank == 0:
         enc = model._hip
+        layout = enc.describe()
         enc.profile(True)
         nprof = 3
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(2 * nprof)]
         dec_ms = 0.0
         for i in range(nprof):
-            scores = model(signal)
+            scores = model(signals[i % N_BATCHES])
             ev[2 * i].record()
             decs[0].submit(scores).result()
             ev[2 * i + 1].record()
@@ -278,15 +365,18 @@ def main():
         flops_per_launch = work * a.batch / launches_per_fwd
         avg_ms = ms / spans
         achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12
-        lstm_h = {"fast": 96, "hac": 384, "sup_lstm": 1024}.get(a.model, 0)
-        lstm_kernel = ("lstm_layer_wide_kernel" if lstm_h > 512 else "lstm_layer_kernel" if prof["lstm_gemm"][1] else
-                       "lstm_layer_wg_kernel" if lstm_h and (lstm_h % 48 == 0 or lstm_h in (64, 128, 256)) else "lstm_layer_fused_kernel")
-        roof = {"kernel": {"lstm_rec": lstm_kernel, "lstm_gemm": "gemm_kernel", "crf_linear": "gemm_kernel",
-                           "conv": "conv_igemm_kernel", "mlp": "gemm_kernel (fc1 gated + fc2) + rmsnorm_residual_kernel",
-                           "attention": "gemm_kernel (Wqkv, out_proj) + attention_kernel + rmsnorm_residual_kernel"}[cls],
-                "bound": "mfma", "achieved": round(achieved, 2), "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(achieved / MFMA_F16_PEAK_TFLOPS, 4), "traffic": pmc_traffic(lstm_kernel if cls == "lstm_rec" else None, a),
-                "avg_launch_ms": round(avg_ms, 4), "flops_per_launch": flops_per_launch}
+        # the kernel names come from the engine itself (bh_encoder_describe), not from a guess about the dispatch
+        kind = {"lstm_rec": " lstm ", "lstm_gemm": " lstm ", "crf_linear": " linearcrfencoder ", "conv": " conv ",
+                "mlp": " transformer ", "attention": " transformer "}[cls]
+        names = sorted({ln.split(": ", 1)[1] for ln in layout.splitlines() if kind in ln and ": " in ln})
+        kernel = "; ".join(names)
+        lstm_kernel = kernel if cls == "lstm_rec" else None
+        q8 = "q8" in kernel
+        peak = MFMA_I8_PEAK_TOPS if q8 else MFMA_F16_PEAK_TFLOPS
+        traffic, traffic_src = pmc_traffic(lstm_kernel, a)
+        roof = {"kernel": kernel, "bound": "mfma", "achieved": round(achieved, 2), "peak": peak,
+                "unit": "TOP/s" if q8 else "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic,
+                "traffic_source": traffic_src, "avg_launch_ms": round(avg_ms, 4), "flops_per_launch": flops_per_launch}
 
     if rank == 0:
         log("roofline leg done; cpu baseline")
@@ -299,22 +389,27 @@ def main():
             "steps": a.steps,
             "warmup": a.warmup,
             "ms_per_step": 1e3 * elapsed / a.steps,
+            "ms_per_step_median": med,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f16",
+            "dtype": "i8 recurrence (Q8-1) / f16" if a.quantize else "f16",
             "data": "synthetic",
             "config": {"workload": "dna_r10.4.1_e8.2_400bps_%s@v5.0.0-shaped model (seeded random weights), "
-                                   "batch %d x chunk %d, %s decode, encoder/decoder software-pipelined on 2 HIP streams x %d batch lane(s) per GPU" %
-                                   (a.model, a.batch, a.chunk, a.decoder, a.lanes),
-                       "parallelism": "replicas x%d (shard-by-read, no collective)" % world},
+                                   "batch %d x chunk %d, %d distinct batches rotating, %s decode, encoder/decoder "
+                                   "software-pipelined on 2 HIP streams x %d batch lane(s) per GPU%s" %
+                                   (a.model, a.batch, a.chunk, N_BATCHES, a.decoder, a.lanes, ", --quantize" if a.quantize else ""),
+                       "parallelism": "replicas x%d (shard-by-read, no collective)%s" % (world, " -- ranks SHARE devices (test mode)" if oversubscribed else "")},
             "per_gpu": samples / elapsed / world,
+            "with_h2d": h2d,
             "roofline": roof,
             "kernel_ms_per_step": breakdown,
             "cpu_baseline": None if (a.no_cpu_baseline or world > 1) else cpu_baseline(a.model, a.chunk),
         }
         print(json.dumps(out))
+        sys.stdout.flush()
     if world > 1:
+        dist.barrier() if oversubscribed else dist.barrier(device_ids=[local])
         dist.destroy_process_group()
 
 

@@ -625,7 +625,7 @@ extern "C" int bh_encoder_output_shape(const bh_encoder_t* enc, int L, int* T, i
 
 namespace {
 // which recurrence kernel serves a layer (see lstm.hip)
-struct LstmPath { bool reg_path, wide, fused, wg, cta; };
+struct LstmPath { bool reg_path, wide, fused, wg, cta, q8; };
 static LstmPath lstm_path(const bh_encoder* e, const Layer& l) {
     const int H = l.d.out_size;
     LstmPath p;
@@ -634,9 +634,55 @@ static LstmPath lstm_path(const bh_encoder* e, const Layer& l) {
     p.fused = p.reg_path && e->lstm_fused && l.d.in_size == H && l.w2.p != nullptr;
     p.wg = p.fused && e->lstm_fused >= 2 && l.w3.p != nullptr && l.w4.p != nullptr;
     p.cta = p.wg && e->lstm_fused >= 3 && bh_k_lstm_cta_units(H) != 0 && bh_k_lstm_cta_units(H) == bh_k_lstm_wg_units(H);
+    p.q8 = false;
     return p;
 }
 }  // namespace
+
+// Human-readable list of the kernels the engine will launch per layer (one line each), e.g. for bench.py's roofline label.
+extern "C" int bh_encoder_describe(const bh_encoder_t* e, char* buf, size_t n) {
+    BH_REQUIRE(e && buf && n > 0, "encoder_describe: bad arguments");
+    std::string out;
+    char line[256];
+    int li = 0;
+    for (const auto& l : e->layers) {
+        const bh_layer_t& d = l.d;
+        switch (d.kind) {
+            case BH_LAYER_CONV:
+                snprintf(line, sizeof(line), "%d conv %d->%d k%d s%d: %s\n", li, d.in_size, d.out_size, d.winlen, d.stride,
+                         l.pointwise ? "gemm (pointwise)" : d.in_size == 1 ? "conv_first_kernel" : "conv_igemm_kernel / conv_ws_kernel");
+                break;
+            case BH_LAYER_LSTM: {
+                const LstmPath p = lstm_path(e, l);
+                const int H = d.out_size, U = bh_k_lstm_wg_units(H);
+                if (p.q8) snprintf(line, sizeof(line), "%d lstm %d%s: lstm_layer_q8_kernel<%d,%d> (int8 W/x/h, i32 MFMA 16x16x64)\n", li, H, d.reverse ? " rev" : "", H / 64, U / 4);
+                else if (p.cta) snprintf(line, sizeof(line), "%d lstm %d%s: lstm_layer_cta_kernel<%d,%d>\n", li, H, d.reverse ? " rev" : "", H / 32, U / 4);
+                else if (p.wg) snprintf(line, sizeof(line), "%d lstm %d%s: lstm_layer_wg_kernel<%d,%d>\n", li, H, d.reverse ? " rev" : "", H / 32, U / 4);
+                else if (p.fused) snprintf(line, sizeof(line), "%d lstm %d%s: lstm_layer_fused_kernel<%d>\n", li, H, d.reverse ? " rev" : "", H / 32);
+                else if (p.wide) snprintf(line, sizeof(line), "%d lstm %d%s: gemm + lstm_layer_wide_kernel<%d>\n", li, H, d.reverse ? " rev" : "", H / 32);
+                else if (p.reg_path) snprintf(line, sizeof(line), "%d lstm %d%s: gemm + lstm_layer_kernel<%d>\n", li, H, d.reverse ? " rev" : "", H / 32);
+                else snprintf(line, sizeof(line), "%d lstm %d%s: gemm + lstm_layer_stream_kernel<%d>\n", li, H, d.reverse ? " rev" : "", H / 32);
+                break;
+            }
+            case BH_LAYER_LINEAR_CRF: snprintf(line, sizeof(line), "%d linearcrfencoder %d->%d: gemm\n", li, d.in_size, d.out_size); break;
+            case BH_LAYER_LINEAR: snprintf(line, sizeof(line), "%d linear %d->%d: gemm\n", li, d.in_size, d.out_size); break;
+            case BH_LAYER_TRANSFORMER:
+                snprintf(line, sizeof(line), "%d transformer d%d h%d ff%d: gemm (Wqkv%s, out_proj, fc1 SwiGLU, fc2) + %s + rmsnorm_residual_kernel\n",
+                         li, d.in_size, d.nhead, d.dim_ff, e->attn_ring ? " + rotary" : "", e->attn_ring ? "attention_ring_kernel" : "attention_kernel");
+                break;
+            case BH_LAYER_UPSAMPLE: snprintf(line, sizeof(line), "%d linearupsample x%d: gemm\n", li, d.scale_factor); break;
+            case BH_LAYER_CLAMP: snprintf(line, sizeof(line), "%d clamp: fused into the previous layer's epilogue\n", li); break;
+            case BH_LAYER_DWCONV: snprintf(line, sizeof(line), "%d dwconv k%d: dwconv_kernel\n", li, d.winlen); break;
+            case BH_LAYER_RESIDUAL_PROJ: snprintf(line, sizeof(line), "%d residual projection: gemm\n", li); break;
+            case BH_LAYER_CTC_DECODER: snprintf(line, sizeof(line), "%d ctc decoder: ctc_head_kernel\n", li); break;
+            default: snprintf(line, sizeof(line), "%d kind %d\n", li, d.kind);
+        }
+        out += line;
+        ++li;
+    }
+    snprintf(buf, n, "%s", out.c_str());
+    return 0;
+}
 
 extern "C" int bh_encoder_forward(bh_encoder_t* e, const void* signal, int N, int L, void* scores, void* stream_) {
     BH_REQUIRE(e && signal && scores, "encoder_forward: null argument");

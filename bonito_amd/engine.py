@@ -252,6 +252,12 @@ class HipEncoder:
         if rc:
             raise _lib.HipEngineError("bh_encoder_check: %s" % _lib.last_error())
 
+    def describe(self):
+        """One line per layer: which kernels the engine launches for it."""
+        buf = C.create_string_buffer(1 << 14)
+        _lib.check(_lib.lib().bh_encoder_describe(self._handle, buf, len(buf)), "bh_encoder_describe")
+        return buf.value.decode()
+
     def poll(self):
         """Raise if a forward whose completion the caller has already observed (event / decoded outputs / synchronise)
         hit the spin bound of a persistent kernel: its scores are invalid. No device round trip (bh_encoder_error_flag)."""

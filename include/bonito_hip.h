@@ -112,6 +112,8 @@ int bh_encoder_output_shape(const bh_encoder_t* enc, int L, int* T, int* C, int*
 /* signal: device fp16 [N][L] (the reference's [N,1,L] batch, bonito/crf/basecall.py:33).
  * scores: device fp16, contiguous [N][T][C] (the layout koi.decode.beam_search consumes). */
 int bh_encoder_forward(bh_encoder_t* enc, const void* signal, int N, int L, void* scores, void* stream);
+/* one text line per layer naming the kernels the engine launches for it (measurement / logging) */
+int bh_encoder_describe(const bh_encoder_t* enc, char* buf, size_t bytes);
 /* tuning / test options (results never change): "lstm_fused" (3 default: narrowest applicable fused kernel; 2, 1, 0 = older
  * variants down to projection-by-GEMM), "lstm_force_slow" (0/1: write-through exchange), "lstm_wide" (1/0), "lstm_prefill"
  * (1 default: sentinel fill of the next recurrent layer's buffer on a side stream), "attn_ring" (1/0), "lstm_tune" (bit mask) */

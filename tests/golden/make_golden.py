@@ -8,7 +8,11 @@ Generate the golden fixtures under tests/golden/ by EXECUTING THE REFERENCE (rea
 What is produced (all seeded, fp32 CPU):
   nn_<name>.npz      reference bonito/nn.py encoder forward: config (json), state_dict, input x, output y
   util_cases.json    reference bonito/util.py chunk / stitch / batchify / unbatchify on integer ramps
-  crf_rc.npz         reference CTC_CRF.reverse_complement (crf/model.py:84-96) on a random tensor
+  crf_rc.npz         reference CTC_CRF.reverse_complement (crf/model.py:84-96) on seeded tensors          (make_crf_rc_fixture)
+  crf_decode.npz     reference CTC_CRF.logZ / viterbi / path_to_str and SeqdistModel.decode_batch, executed with a torch
+                     restatement of the four koi.ctc names they call (koi is closed source)                (make_crf_decode_fixture)
+  reader_cases.npz   reference bonito/reader.py normalisation + trim in the order of bonito/pod5.py:61-62 (make_reader_fixture)
+  tf_<name>.npz / ctc_<name>.npz   reference transformer / QuartzNet forward
 Every fixture is also checked here against the oracle restatements (oracle/nn_ref.py), so a committed
 fixture certifies "oracle == reference" at generation time; tests/ re-check the oracle against the files.
 
@@ -319,6 +323,155 @@ def make_ctc_fixture(name, blocks, N, L, seed=25):
           (name, tuple(y.shape), err, os.path.basename(path), os.path.getsize(path) // 1024))
 
 
+def ref_reader():
+    """The reference's bonito/reader.py (trim 122-143, normalisation 146-172): imports torch / numpy only at module level."""
+    return load_by_path("ref_bonito_reader", os.path.join(REF, "bonito", "reader.py"))
+
+
+def reader_case_signal(rng, i):
+    """Synthetic pA-like trace; even cases carry an open-pore / adapter peak near the start (what `trim` looks for).
+    tests/test_cli_cpu.py::_regen replays exactly this sequence of draws."""
+    m = int(rng.integers(500, 20000))
+    sig = rng.standard_normal(m).astype(np.float32)
+    if i % 2 == 0:
+        a = int(rng.integers(50, 400))
+        b = a + int(rng.integers(60, 600))
+        sig[a:b] += 4.0
+    return (sig * 12.0 + 90.0).astype(np.float32)
+
+
+def make_reader_fixture(n_cases=8):
+    """reader_cases.npz: shift / scale / trim as computed by the REFERENCE functions in the order bonito/pod5.py:61-62 calls
+    them (quantile normalisation of the pA signal, then trim with threshold = scale * 2.4 + shift)."""
+    rd = ref_reader()
+    rng = np.random.default_rng(5)
+    meta = []
+    for i in range(n_cases):
+        raw = reader_case_signal(rng, i)
+        shift, scale = rd.normalisation(raw, None, None)
+        trim = rd.trim(raw, threshold=scale * 2.4 + shift)
+        meta.append({"seed": i, "n": int(len(raw)), "shift": float(shift), "scale": float(scale), "trim": int(trim),
+                     "peak": i % 2 == 0})
+    np.savez_compressed(os.path.join(HERE, "reader_cases.npz"), meta=np.array(json.dumps(meta)))
+    print("reader_cases.npz: %d cases, trims %s" % (len(meta), [m["trim"] for m in meta]))
+
+
+def koi_ctc_stub():
+    """A torch restatement of the four names of `koi.ctc` that bonito/crf/model.py:9-10 needs for CTC_CRF.logZ / posteriors /
+    viterbi, so that the REFERENCE's own class body runs here. koi (ont-koi 0.5.4, requirements.txt:19) is closed binary +
+    a thin Python layer; what is assumed of it [EXT]:
+      * semirings `Log` / `Max` with `.one == 0.0` and sum = logsumexp / max, mul = +;
+      * `logZ_cu_sparse(Ms, idx, alpha_0, beta_T, S)`: alpha_{t+1}[n, j] = S.sum_k(Ms[t, n, j, k] (x) alpha_t[n, idx[j, k]]),
+        result S.sum_j(alpha_T[n, j] (x) beta_T[n, j]), differentiable w.r.t. Ms;
+      * `SequenceDist.posteriors(scores, S)` = d logZ(scores, S).sum() / d scores (edge marginals; one-hot for Max).
+    These are the definitions SURVEY.md section 8(a) D1 and appendix B.1 give; everything downstream of them in the fixture
+    (reshape, argmax, `% len(alphabet)`, `// len(alphabet) % n_base`, path_to_str, decode_batch's `+ 1e-8`, `.log()`) is
+    the reference's code, executed."""
+    mod = types.ModuleType("koi.ctc")
+
+    class Log:
+        one = 0.0
+        zero = -float("inf")
+
+        @staticmethod
+        def sum(x, dim):
+            return torch.logsumexp(x, dim=dim)
+
+    class Max:
+        one = 0.0
+        zero = -float("inf")
+
+        @staticmethod
+        def sum(x, dim):
+            return torch.max(x, dim=dim).values
+
+    def logZ_cu_sparse(Ms, idx, alpha_0, beta_T, S):
+        T = Ms.shape[0]
+        alpha = alpha_0
+        ix = idx.to(torch.int64)
+        for t in range(T):
+            alpha = S.sum(Ms[t] + alpha[:, ix], dim=-1)
+        return S.sum(alpha + beta_T, dim=-1)
+
+    class SequenceDist:
+        def __init__(self):
+            pass
+
+        def posteriors(self, scores, S=Log):
+            with torch.enable_grad():
+                x = scores.detach().clone().requires_grad_(True)
+                lz = self.logZ(x, S)
+                (g,) = torch.autograd.grad(lz.sum(), x)
+            return g
+
+    mod.Log, mod.Max, mod.semiring = Log, Max, object
+    mod.SequenceDist, mod.logZ_cu_sparse = SequenceDist, logZ_cu_sparse
+    for n in ("logZ_cu", "viterbi_alignments", "bwd_scores_cu_sparse", "fwd_scores_cu_sparse"):
+        setattr(mod, n, None)
+    return mod
+
+
+def ref_crf_model():
+    """bonito/crf/model.py itself, with `koi` replaced by koi_ctc_stub() and bonito.nn the real file."""
+    pkg = types.ModuleType("bonito")
+    pkg.__path__ = [os.path.join(REF, "bonito")]
+    sys.modules["bonito"] = pkg
+    for name in ("koi", "koi.lstm"):
+        sys.modules[name] = types.ModuleType(name)
+    sys.modules["koi.ctc"] = koi_ctc_stub()
+    sys.modules.pop("bonito.crf.model", None)
+    sys.modules.pop("bonito.crf", None)
+    crf_pkg = types.ModuleType("bonito.crf")          # skip bonito/crf/__init__.py (it pulls basecall -> koi.decode)
+    crf_pkg.__path__ = [os.path.join(REF, "bonito", "crf")]
+    sys.modules["bonito.crf"] = crf_pkg
+    import importlib
+    return importlib.import_module("bonito.crf.model")
+
+
+def make_crf_rc_fixture():
+    """crf_rc.npz: the reference's CTC_CRF.reverse_complement (crf/model.py:84-96) on seeded [T, N, 5S] tensors."""
+    cm = ref_crf_model()
+    out = {}
+    gen = torch.Generator().manual_seed(25)
+    for sl in (1, 2, 3):
+        sd = cm.CTC_CRF(sl, ["N", "A", "C", "G", "T"])
+        x = torch.randn(7, 2, 5 * 4 ** sl, generator=gen).half().float()
+        out["x%d" % sl] = x.numpy()
+        out["y%d" % sl] = sd.reverse_complement(x).numpy()
+    np.savez_compressed(os.path.join(HERE, "crf_rc.npz"), **out)
+    print("crf_rc.npz: state_len 1..3, shapes %s" % [out["x%d" % s].shape for s in (1, 2, 3)])
+
+
+def make_crf_decode_fixture():
+    """crf_decode.npz: outputs of the REFERENCE's CTC_CRF.logZ / viterbi / path_to_str (crf/model.py:47-52,98-108) and
+    SeqdistModel.decode_batch (:196-199) executed here with koi_ctc_stub() supplying the scan, on seeded fp16-valued scores in
+    the reference layout [T, N, 5S]. Scores are drawn on a grid of 1/8 so that every partial sum is exact in fp32 and fp64
+    alike: the Viterbi paths are then independent of the accumulation precision and bit-comparable."""
+    cm = ref_crf_model()
+    out = {}
+    gen = torch.Generator().manual_seed(26)
+    for sl, T, N in ((1, 40, 3), (2, 60, 4), (3, 120, 3), (4, 90, 2)):
+        sd = cm.CTC_CRF(sl, ["N", "A", "C", "G", "T"])
+        S = 4 ** sl
+        x4 = (torch.randn(T, N, 4 * S, generator=gen) * 2.0).clamp(-5, 5)
+        x4 = torch.round(x4 * 8) / 8                      # exact in fp16; sums of <= 120 of them exact in fp32
+        x5 = torch.nn.functional.pad(x4.view(T, N, S, 4), (1, 0), value=2.0).view(T, N, 5 * S)      # nn.py:291-297
+        paths = sd.viterbi(x5.double())                   # [T, N] in {0..4}: the reference's lines, fp64 scan
+        logz = sd.logZ(x5.double())
+        strs = [sd.path_to_str(p) for p in paths.T.numpy()]
+        model = cm.SeqdistModel.__new__(cm.SeqdistModel)
+        torch.nn.Module.__init__(model)
+        model.seqdist = sd
+        post_strs = cm.SeqdistModel.decode_batch(model, x5.double())
+        out["x%d" % sl] = x4.permute(1, 0, 2).contiguous().half().numpy()        # engine layout [N, T, 4S], blank fixed at 2.0
+        out["viterbi%d" % sl] = paths.T.contiguous().numpy().astype(np.int8)     # [N, T]
+        out["logz%d" % sl] = logz.numpy()
+        out["str%d" % sl] = np.array(json.dumps(strs))
+        out["post_str%d" % sl] = np.array(json.dumps(post_strs))
+        print("crf_decode sl=%d: T=%d N=%d bases %s, posterior-decoded %s" % (sl, T, N, [len(s) for s in strs], [len(s) for s in post_strs]))
+    np.savez_compressed(os.path.join(HERE, "crf_decode.npz"), **out)
+
+
 CTC_BLOCKS_SMALL = [(32, 1, 9, 3, False, False), (48, 2, 33, 1, True, True), (48, 3, 5, 1, True, True),
                     (64, 1, 29, 1, False, True), (40, 1, 15, 1, False, False)]
 
@@ -326,6 +479,11 @@ CTC_BLOCKS_SMALL = [(32, 1, 9, 3, False, False), (48, 2, 33, 1, True, True), (48
 def main():
     if "--ctc-only" in sys.argv:
         make_ctc_fixture("quartz_small", CTC_BLOCKS_SMALL, N=3, L=600)
+        return
+    if "--crf-only" in sys.argv:
+        make_crf_rc_fixture()
+        make_crf_decode_fixture()
+        make_reader_fixture()
         return
     if "--transformer-only" in sys.argv:
         make_transformer_fixture("d128_w31_32", 128, 2, 256, 2, (31, 32), 3, N=2, L=1200)
@@ -348,6 +506,9 @@ def main():
     make_transformer_fixture("d128_w31_32", 128, 2, 256, 2, (31, 32), 3, N=2, L=1200)
     make_transformer_fixture("d64_w127_128", 64, 1, 128, 1, (127, 128), 2, N=2, L=2400)
     make_ctc_fixture("quartz_small", CTC_BLOCKS_SMALL, N=3, L=600)
+    make_crf_rc_fixture()
+    make_crf_decode_fixture()
+    make_reader_fixture()
 
 
 if __name__ == "__main__":

@@ -238,3 +238,22 @@ def test_beam_selection_variants_agree_with_oracle(kind):
             assert np.array_equal(seq.numpy(), oseq), (kind, v)
     finally:
         decode.set_option("beam_select", 0)
+
+
+def test_hip_decoders_match_reference_ctc_crf_fixture():
+    """HIP Viterbi / logZ / posterior decoding vs tests/golden/crf_decode.npz = the reference's own CTC_CRF.viterbi / logZ /
+    decode_batch lines executed with a torch scan in place of koi's kernels (tests/golden/make_golden.py)."""
+    import json
+    import os
+    from conftest import GOLDEN
+    from bonito_amd.crf.model import CTC_CRF
+    z = np.load(os.path.join(GOLDEN, "crf_decode.npz"))
+    for sl in (1, 2, 3, 4):
+        x = torch.from_numpy(z["x%d" % sl]).cuda()
+        moves, path = decode.viterbi(x)
+        assert np.array_equal(path.numpy(), z["viterbi%d" % sl]), sl
+        sd = CTC_CRF(sl, ["N", "A", "C", "G", "T"])
+        assert [sd.path_to_str(p) for p in path.numpy()] == json.loads(str(z["str%d" % sl]))
+        assert np.abs(decode.logz(x).numpy() - z["logz%d" % sl]).max() < 2e-3
+        pm, pp = decode.posterior_viterbi(x)
+        assert [sd.path_to_str(p) for p in pp.numpy()] == json.loads(str(z["post_str%d" % sl]))

@@ -179,3 +179,24 @@ def test_posterior_viterbi_equals_viterbi_on_peaked_scores():
     _, p1 = crf_ref.posterior_viterbi(sc, state_len)
     _, p2, _ = crf_ref.viterbi(sc, state_len, layout_5s=False, blank=2.0)
     assert np.array_equal(p1, p2)
+
+
+def test_oracle_matches_reference_ctc_crf_executed_with_stubbed_koi():
+    """tests/golden/crf_decode.npz holds the outputs of the REFERENCE's own CTC_CRF.viterbi / logZ / path_to_str and
+    SeqdistModel.decode_batch lines (bonito/crf/model.py:47-52,98-108,196-199), run by tests/golden/make_golden.py with a torch
+    scan standing in for the four koi.ctc names. The C oracle must reproduce them: paths bit for bit, logZ to fp32 accuracy,
+    decoded strings exactly."""
+    import json
+    import os
+    from conftest import GOLDEN
+    z = np.load(os.path.join(GOLDEN, "crf_decode.npz"))
+    alphabet = np.frombuffer(b"NACGT", dtype="u1")
+    for sl in (1, 2, 3, 4):
+        x = z["x%d" % sl]
+        mv, path, best = crf_ref.viterbi(x, sl, blank=2.0)
+        assert np.array_equal(path, z["viterbi%d" % sl]), sl
+        assert np.array_equal(mv, (z["viterbi%d" % sl] != 0).astype(np.int8))
+        assert [alphabet[p[p != 0]].tobytes().decode() for p in path] == json.loads(str(z["str%d" % sl]))
+        assert np.abs(crf_ref.logz(x, sl) - z["logz%d" % sl]).max() < 1e-4
+        pm, pp = crf_ref.posterior_viterbi(x, sl)
+        assert [alphabet[p[p != 0]].tobytes().decode() for p in pp] == json.loads(str(z["post_str%d" % sl]))

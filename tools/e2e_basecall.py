@@ -1,34 +1,110 @@
 #!/usr/bin/env python3
-"""End-to-end throughput of bonito_amd.crf.basecall (host chunking/batching/stitching included) on synthetic reads.
-    python tools/e2e_basecall.py [hac|fast] [n_reads] [mean_len]"""
-import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import numpy as np, torch
-from bonito_amd import synthetic, util
-from bonito_amd.crf import basecall
+"""End-to-end throughput of the product path on synthetic reads, host work included: chunking, batching, H2D, encoder,
+decode, D2H, stitching, formatting (FASTQ with move tables) and -- with several ranks -- the record merge on rank 0.
 
-name = sys.argv[1] if len(sys.argv) > 1 else "hac"
-n_reads = int(sys.argv[2]) if len(sys.argv) > 2 else 1500
-mean_len = int(sys.argv[3]) if len(sys.argv) > 3 else 100000
-util.limit_host_threads(8)
-model = synthetic.make_model(name, batchsize=512, chunksize=10000)
-model.use_koi(batchsize=512, chunksize=9996, quantize=False)
-model = model.half().cuda()
+    python tools/e2e_basecall.py [--model hac|fast] [--reads 1500] [--mean-len 100000] [--devices 0-7] [--reps 2]
+
+`--devices`: one process per listed GPU (a device may be listed twice), reads sharded round-robin, every rank formats
+its own records, rank 0 merges them in input order and writes them (to /dev/null) -- the same code path as
+`python -m bonito_amd basecaller --devices ...`, so host-feed and writer limits of an N-GPU node show up here
+(bench.py keeps its batches resident on the device and cannot see them).
+"""
+import argparse
+import os
+import subprocess
+import socket
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
 
 
-class Read:
-    def __init__(self, i, sig):
-        self.read_id, self.signal = "read_%d" % i, sig
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--model", default="hac", choices=["hac", "fast"])
+    ap.add_argument("--reads", type=int, default=1500)
+    ap.add_argument("--mean-len", type=int, default=100000)
+    ap.add_argument("--devices", default=None)
+    ap.add_argument("--reps", type=int, default=2)
+    return ap.parse_args()
 
 
-rng = np.random.default_rng(1)
-lens = np.clip(rng.normal(mean_len, mean_len / 3, n_reads), 5000, None).astype(int)
-reads = [Read(i, rng.standard_normal(int(n)).astype(np.float32)) for i, n in enumerate(lens)]
-total = int(lens.sum())
-for rep in range(2):
-    t0 = time.perf_counter()
-    nb = 0
-    for read, res in basecall(model, reads, chunksize=9996, overlap=498, batchsize=512):
-        nb += len(res["sequence"])
-    dt = time.perf_counter() - t0
-    print("%s: %d reads, %.3e samples, %.2f s -> %.3e samples/s end to end (%d bases)" % (name, n_reads, total, dt, total / dt, nb))
+def launch(a):
+    from bonito_amd.cli.basecaller import parse_devices
+    devices = parse_devices(a.devices)
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    argv, skip = [], False
+    for tok in sys.argv[1:]:
+        if skip:
+            skip = False
+        elif tok == "--devices":
+            skip = True
+        elif not tok.startswith("--devices="):
+            argv.append(tok)
+    procs = []
+    for rank, dev in enumerate(devices):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(len(devices)), LOCAL_RANK=str(rank), LOCAL_WORLD_SIZE=str(len(devices)),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HIP_VISIBLE_DEVICES=str(dev))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env))
+    return 1 if any(p.wait() for p in procs) else 0
+
+
+def main():
+    a = parse()
+    if a.devices and "RANK" not in os.environ:
+        sys.exit(launch(a))
+    import numpy as np
+    import torch.distributed as dist
+    from bonito_amd import io as bio
+    from bonito_amd import parallel, synthetic, util
+    from bonito_amd.crf import basecall
+
+    rank, world, _ = parallel.env_rank_world()
+    if world > 1:
+        parallel.init("gloo")
+    util.limit_host_threads(8)
+    model = synthetic.make_model(a.model, batchsize=512, chunksize=10000)
+    model.use_koi(batchsize=512, chunksize=9996, quantize=False)
+    model = model.half().cuda()
+
+    class Read:
+        run_id, filename, channel, mux, start, duration, template_start, template_duration, trimmed_samples = "run", "f", 0, 0, 0.0, 0.0, 0.0, 0.0, 0
+
+        def __init__(self, i, sig):
+            self.read_id, self.signal, self.num_samples = "read_%d" % i, sig, len(sig)
+
+    rng = np.random.default_rng(1)
+    lens = np.clip(rng.normal(a.mean_len, a.mean_len / 3, a.reads), 5000, None).astype(int)
+    mine = [Read(i, np.random.default_rng(i).standard_normal(int(n)).astype(np.float32))
+            for i, n in enumerate(lens) if i % world == rank]
+    total = int(lens.sum())
+    for rep in range(a.reps):
+        if world > 1:
+            dist.barrier(group=parallel.host_group())
+        t0 = time.perf_counter()
+        results = basecall(model, iter(mine), chunksize=9996, overlap=498, batchsize=512)
+        records = parallel.ordered_records(parallel.format_stream(results, "fastq"), rank, world)
+        if rank == 0:
+            with open(os.devnull, "w") as sink:
+                w = bio.Writer("fastq", records, fd=sink, preformatted=True)
+                w.start()
+                w.join()
+            if w.error is not None:
+                raise w.error
+            done = sum(n for _, n in w.log)
+        if world > 1:
+            dist.barrier(group=parallel.host_group())
+        dt = time.perf_counter() - t0
+        if rank == 0:
+            assert done == total, (done, total)
+            print("%s x%d rank(s): %d reads, %.3e samples, %.2f s -> %.3e samples/s end to end (%.3e per rank)"
+                  % (a.model, world, a.reads, total, dt, total / dt, total / dt / world), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
