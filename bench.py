@@ -184,6 +184,11 @@ def main():
     a = parse()
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(a.gpus))
+    # stdout carries exactly one JSON line: keep a private handle for it and point descriptor 1 at stderr meanwhile, so
+    # that nothing a library prints on stdout (gloo announces its connections there) can precede or split the line
+    sys.stdout.flush()
+    json_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     import torch
     import torch.distributed as dist
     from bonito_amd import parallel
@@ -231,30 +236,41 @@ def main():
         ln.enc_stream, ln.dec_stream = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
         ln.stage = [torch.empty_like(signals[0]) for _ in range(2)]      # H2D landing buffers (double buffered)
         ln.stage_free = [None, None]
+        ln.staged = [None, None]
         ln.tickets = [None, None]
         ln.count = 0
         lanes.append(ln)
 
-    def encode(ln, b, h2d):
+    def stage_in(ln, k, b):
+        """Enqueue the pinned-host -> device copy of batch b into landing buffer k of this lane (copy stream)."""
+        with torch.cuda.stream(copy_stream):
+            if ln.stage_free[k] is not None:
+                copy_stream.wait_event(ln.stage_free[k])          # the forward that read this buffer has finished
+            ln.stage[k].copy_(host_signals[b], non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(copy_stream)
+        ln.staged[k] = ev
+
+    def encode(ln, b, h2d, b_next=None):
         k = ln.count & 1
-        if h2d:
-            with torch.cuda.stream(copy_stream):
-                if ln.stage_free[k] is not None:
-                    copy_stream.wait_event(ln.stage_free[k])      # the forward that read this buffer has finished
-                ln.stage[k].copy_(host_signals[b], non_blocking=True)
-                copied = torch.cuda.Event()
-                copied.record(copy_stream)
-            x = ln.stage[k]
-        else:
-            x = signals[b]
+        if h2d and ln.staged[k] is None:
+            stage_in(ln, k, b)                                    # first step of the lane: nothing was prefetched
+        x = ln.stage[k] if h2d else signals[b]
         with torch.cuda.stream(ln.enc_stream):
             if h2d:
-                ln.enc_stream.wait_event(copied)
+                ln.enc_stream.wait_event(ln.staged[k])
+                ln.staged[k] = None
             sc = ln.model(x)
             ev = torch.cuda.Event()
             ev.record(ln.enc_stream)
             if h2d:
                 ln.stage_free[k] = ev
+        if h2d and b_next is not None:
+            # The NEXT batch of this lane goes out now, a whole step ahead, like the product pipeline's reader thread does
+            # (crf/basecall.py). Issued right before its own forward the copy costs ~5 ms per step: the runtime's copy
+            # kernel cannot become resident next to a persistent recurrent kernel that owns every CU's register file and
+            # has to wait for the gap between two layer launches.
+            stage_in(ln, k ^ 1, b_next)
         return sc, ev
 
     # probe output geometry, build two decode contexts per lane (double buffered pinned outputs)
@@ -272,10 +288,12 @@ def main():
         returns. `marks`: list that receives one timing event per step, recorded behind the step's decode + D2H."""
         for ln in lanes:
             ln.tickets = [None, None]
+            ln.staged = [None, None]
             ln.count = 0
         for i in range(steps):
             ln = lanes[i % len(lanes)]
-            sc, ev = encode(ln, i % N_BATCHES, h2d)
+            nxt = i + len(lanes)                   # this lane's next step
+            sc, ev = encode(ln, i % N_BATCHES, h2d, nxt % N_BATCHES if nxt < steps else None)
             k = ln.count & 1
             if ln.tickets[k] is not None:
                 ln.tickets[k].result()             # its pinned buffers are about to be reused
@@ -406,8 +424,8 @@ def main():
             "kernel_ms_per_step": breakdown,
             "cpu_baseline": None if (a.no_cpu_baseline or world > 1) else cpu_baseline(a.model, a.chunk),
         }
-        print(json.dumps(out))
-        sys.stdout.flush()
+        json_out.write(json.dumps(out) + "\n")
+        json_out.flush()
     if world > 1:
         dist.barrier() if oversubscribed else dist.barrier(device_ids=[local])
         dist.destroy_process_group()

@@ -22,7 +22,7 @@ class bh_layer_t(C.Structure):
         ("winlen", C.c_int32), ("stride", C.c_int32), ("padding", C.c_int32),
         ("activation", C.c_int32), ("reverse", C.c_int32),
         ("nhead", C.c_int32), ("dim_ff", C.c_int32), ("win_left", C.c_int32), ("win_right", C.c_int32),
-        ("scale_factor", C.c_int32), ("groups", C.c_int32), ("add_residual", C.c_int32), ("reserved_i", C.c_int32 * 2),
+        ("scale_factor", C.c_int32), ("groups", C.c_int32), ("add_residual", C.c_int32), ("quantize", C.c_int32), ("reserved_i", C.c_int32 * 1),
         ("scale", C.c_float), ("clamp_lo", C.c_float), ("clamp_hi", C.c_float),
         ("blank_score", C.c_float), ("alpha", C.c_float), ("eps", C.c_float), ("reserved_f", C.c_float * 2),
         ("w0", C.c_void_p), ("b0", C.c_void_p), ("w1", C.c_void_p), ("b1", C.c_void_p),
@@ -82,6 +82,7 @@ SIGNATURES = {
     "bh_host_chunk_rows": (_l, [_vp, _l, _i, _i, _l, _l, _vp]),
     "bh_lstm_workspace": (_sz, [_i, _i]),
     "bh_lstm_layer": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _vp]),
+    "bh_lstm_q8_layer": (_i, [_vp, _f, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "bh_encoder_debug_read": (_i, [_vp, _vp, _sz, _sz]),
     "bh_encoder_set_option": (_i, [_vp, C.c_char_p, _i]),
 }

@@ -77,7 +77,13 @@ def main(args, argv=None):
     if getattr(args, "devices", None) and "RANK" not in os.environ:
         return launch(args, list(argv if argv is not None else getattr(args, "_argv", sys.argv[2:])))
     rank, world, local = parallel.env_rank_world()
+    out = sys.stdout
     if world > 1:
+        # stdout carries the records: keep a private handle to it and point file descriptor 1 at stderr, so that nothing a
+        # library prints (gloo announces its connections on stdout) can end up inside the FASTQ / SAM stream
+        sys.stdout.flush()
+        out = os.fdopen(os.dup(1), "w")
+        os.dup2(2, 1)
         # one process per GPU: spawned by `launch` (sees one device) or by torchrun (device = LOCAL_RANK)
         if not os.environ.get("BONITO_AMD_SPAWNED") and args.device == "cuda":
             args.device = "cuda:%d" % local
@@ -127,10 +133,10 @@ def main(args, argv=None):
             dist.barrier(group=parallel.host_group())
             dist.destroy_process_group()
             return 0
-        writer = Writer(mode, records, fd=sys.stdout, summary_path=None if args.no_summary else args.summary,
+        writer = Writer(mode, records, fd=out, summary_path=None if args.no_summary else args.summary,
                         preformatted=True)
     else:
-        writer = Writer(mode, results, fd=sys.stdout, min_qscore=args.min_qscore,
+        writer = Writer(mode, results, fd=out, min_qscore=args.min_qscore,
                         summary_path=None if args.no_summary else args.summary)
     writer.start()
     writer.join()

@@ -125,15 +125,13 @@ class SeqdistModel(Module):
 
     # ---- accelerator swap point ---------------------------------------------------------------
     def use_hip(self, batchsize=None, chunksize=None, quantize=None, **_):
-        """Route ``forward`` through the HIP engine. Same keywords as the reference's ``use_koi``."""
-        if quantize:
-            # koi's int8 LSTM (cli/basecaller.py:186-189, crf/model.py:245) trades accuracy for speed on the small models;
-            # this engine has no int8 recurrence and runs the same layers in fp16 (its narrow-layer kernel keeps the whole
-            # ring in one workgroup instead). Accept the flag so that model directories with `quantize = true` stay drop-in.
-            import warnings
-            warnings.warn("quantize=True: the HIP engine has no int8 LSTM path, running the recurrence in fp16", stacklevel=2)
+        """Route ``forward`` through the HIP engine. Same keywords as the reference's ``use_koi``.
+        ``quantize=True`` (cli/basecaller.py:186-189, crf/model.py:245) selects the 8-bit recurrent path Q8-1 for every LSTM
+        layer the int8 kernel covers (hidden sizes that are multiples of 48 or 64 up to 512, input size == hidden size);
+        other layers keep the fp16 kernels -- ``model._hip.describe()`` lists what runs where. The default stays fp16."""
         self._hip_args = (batchsize, chunksize)
-        self._hip = None
+        self._quantize = bool(quantize)
+        self._drop_engine()
         return self
 
     use_koi = use_hip
@@ -163,7 +161,8 @@ class SeqdistModel(Module):
             self._hip = None
         if self._hip is None:
             bs, cs = self._hip_args if self._hip_args is not None else (None, None)
-            self._hip = HipEncoder(self.encoder, max(int(bs or 0), N), max(int(cs or 0), L), device=x.device)
+            self._hip = HipEncoder(self.encoder, max(int(bs or 0), N), max(int(cs or 0), L), device=x.device,
+                                   quantize=getattr(self, "_quantize", False))
         return self._hip
 
     def forward(self, x, *args):

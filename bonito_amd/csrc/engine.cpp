@@ -52,6 +52,7 @@ static inline uint16_t f2h(float f) {
 }
 
 extern "C" int bh_rotary_table(int T, int dim, float* out);
+static int g_q8_variant = 0;      // process-wide: geometry of the 8-bit recurrent kernel picked at engine creation ("lstm_q8_variant")
 extern "C" size_t bh_conv1d_packed_halves(int Cin, int Cout, int K) {
     size_t kp = ((size_t)K * Cin + 31) / 32 * 32;
     size_t c16 = ((size_t)Cout + 15) / 16 * 16;
@@ -146,6 +147,11 @@ struct Layer {
     // so e.g. the old-style 1 -> 4 -> 16 front end (crf/model.py:153-154) still runs on MFMA.
     int cin_eff = 0, cout_eff = 0;
     bool pointwise = false;     // K=1, stride 1 convolution executed by the GEMM kernel (supports the residual add)
+    // 8-bit recurrent path (Q8-1, lstm_q8.hip): int8 weight tiles, per-row scales (s_ih * bound/127, s_hh/127), bound of the input
+    bool q8 = false;
+    int q_variant = 0;
+    float q_bound = 1.0f;
+    DevBuf q_wih, q_whh, q_sx, q_sh;
 };
 
 enum Layout { L_SIGNAL, L_NLC, L_TNC };
@@ -175,6 +181,8 @@ struct bh_encoder {
     hipEvent_t fill_ready = nullptr, fill_done = nullptr;
     void* prefilled = nullptr;
     int lstm_prefill = 1;
+    DevBuf q_act[2], q_ex;                 // 8-bit recurrent path: int8 activations in fragment order, exchange ring buffer
+    int lstm_q8 = 1;                       // 0: run quantised layers through the fp16 kernels (A/B)
     DevBuf res;                            // pending residual projection of a QuartzNet block
     DevBuf t_qkv, t_mid, t_a, t_b, rot;   // transformer workspace + rotary cos/sin table [Tmax][32][2]
     int rot_len = 0;
@@ -199,7 +207,9 @@ struct bh_encoder {
         for (auto& l : layers) {
             l.w0.release(); l.w1.release(); l.w2.release(); l.w3.release();
             l.w4.release(); l.w5.release(); l.b0.release(); l.b1.release();
+            l.q_wih.release(); l.q_whh.release(); l.q_sx.release(); l.q_sh.release();
         }
+        q_act[0].release(); q_act[1].release(); q_ex.release();
         act[0].release(); act[1].release(); act[2].release(); gates.release(); sig.release(); err.release(); lstm_ws.release();
         res.release(); t_qkv.release(); t_mid.release(); t_a.release(); t_b.release(); rot.release();
     }
@@ -304,6 +314,8 @@ extern "C" int bh_encoder_create(const bh_layer_t* layers, int n_layers, int dev
     }
     e->layers.resize(n_layers);
     int cur_channels = 1, cur_channels_eff = 1;
+    float cur_bound = 4.0f;      // magnitude bound of the current activations, for the static int8 input scale of a Q8-1 layer
+    bool any_q8 = false;
     for (int i = 0; i < n_layers; ++i) {
         Layer& L = e->layers[i];
         L.d = layers[i];
@@ -357,6 +369,7 @@ extern "C" int bh_encoder_create(const bh_layer_t* layers, int n_layers, int dev
                 if (!rc) rc = upload_f32(L.b0, bpad.data(), bpad.size());
                 cur_channels = d.out_size;
                 cur_channels_eff = L.cout_eff;
+                cur_bound = d.activation == BH_ACT_TANH ? 1.0f : 4.0f;       // oracle/lstm_q8_ref.py: SWISH_BOUND = 4
                 break;
             }
             case BH_LAYER_LSTM: {
@@ -410,7 +423,26 @@ extern "C" int bh_encoder_create(const bh_layer_t* layers, int n_layers, int dev
                     if (!rc) rc = lstm_pack_tiles(d.w0, H, MT, pk.data());
                     if (!rc) rc = upload(L.w4, pk.data(), pk.size() * 2);
                 }
+                if (!rc && d.quantize && I == H && bh_k_lstm_q8_units(H, g_q8_variant) != 0) {       // Q8-1 tiles and scales
+                    const int U = bh_k_lstm_q8_units(H, g_q8_variant);
+                    const size_t tile_bytes = (size_t)4 * H * ((H + 63) / 64 * 64);
+                    std::vector<int8_t> pk(tile_bytes);
+                    std::vector<float> s_ih((size_t)4 * H), s_hh((size_t)4 * H);
+                    rc = bh_k_lstm_q8_pack(d.w0, H, U, pk.data(), s_ih.data());
+                    if (!rc) rc = upload(L.q_wih, pk.data(), pk.size());
+                    if (!rc) rc = bh_k_lstm_q8_pack(d.w1, H, U, pk.data(), s_hh.data());
+                    if (!rc) rc = upload(L.q_whh, pk.data(), pk.size());
+                    const float xs = (float)((double)cur_bound / 127.0);
+                    for (int j = 0; j < 4 * H; ++j) { s_ih[j] = s_ih[j] * xs; s_hh[j] = s_hh[j] / 127.0f; }
+                    if (!rc) rc = upload_f32(L.q_sx, s_ih.data(), s_ih.size());
+                    if (!rc) rc = upload_f32(L.q_sh, s_hh.data(), s_hh.size());
+                    L.q8 = true;
+                    L.q_variant = g_q8_variant;
+                    L.q_bound = cur_bound;
+                    any_q8 = true;
+                }
                 cur_channels = cur_channels_eff = H;
+                cur_bound = 1.0f;
                 break;
             }
             case BH_LAYER_LINEAR_CRF: {
@@ -513,6 +545,7 @@ extern "C" int bh_encoder_create(const bh_layer_t* layers, int n_layers, int dev
                 e->layers[j].fused_clamp = true;
                 e->layers[j].clamp_lo = d.clamp_lo;
                 e->layers[j].clamp_hi = d.clamp_hi;
+                cur_bound = std::max(fabsf(d.clamp_lo), fabsf(d.clamp_hi));
                 break;
             }
             default:
@@ -553,6 +586,10 @@ extern "C" int bh_encoder_create(const bh_layer_t* layers, int n_layers, int dev
                 return fail(-1);
             }
         }
+    }
+    if (any_q8) {      // int8 activations (fragment order, hidden size padded to 64) and the exchange ring buffer
+        if (e->q_act[0].alloc(ab + 256) || e->q_act[1].alloc(ab + 256) || e->q_ex.alloc((size_t)4 * (Np / 16) * 16 * 1024 + 256))
+            return fail(-1);
     }
     if (e->act[0].alloc(ab + 256) || e->act[1].alloc(ab + 256) || e->gates.alloc(gb + 256) ||
         e->sig.alloc((size_t)Np * max_chunk * 2) || e->err.alloc(sizeof(int)) || e->lstm_ws.alloc(bh_k_lstm_ws_bytes(Np, 1024)))
@@ -634,7 +671,8 @@ static LstmPath lstm_path(const bh_encoder* e, const Layer& l) {
     p.fused = p.reg_path && e->lstm_fused && l.d.in_size == H && l.w2.p != nullptr;
     p.wg = p.fused && e->lstm_fused >= 2 && l.w3.p != nullptr && l.w4.p != nullptr;
     p.cta = p.wg && e->lstm_fused >= 3 && bh_k_lstm_cta_units(H) != 0 && bh_k_lstm_cta_units(H) == bh_k_lstm_wg_units(H);
-    p.q8 = false;
+    p.q8 = l.q8 && e->lstm_q8 && l.d.in_size == H;
+    if (p.q8) p.fused = p.wg = p.cta = p.wide = false;
     return p;
 }
 }  // namespace
@@ -655,7 +693,7 @@ extern "C" int bh_encoder_describe(const bh_encoder_t* e, char* buf, size_t n) {
             case BH_LAYER_LSTM: {
                 const LstmPath p = lstm_path(e, l);
                 const int H = d.out_size, U = bh_k_lstm_wg_units(H);
-                if (p.q8) snprintf(line, sizeof(line), "%d lstm %d%s: lstm_layer_q8_kernel<%d,%d> (int8 W/x/h, i32 MFMA 16x16x64)\n", li, H, d.reverse ? " rev" : "", H / 64, U / 4);
+                if (p.q8) snprintf(line, sizeof(line), "%d lstm %d%s: lstm_layer_q8_kernel<%d,%d> (int8 W/x/h, i32 MFMA 16x16x64)\n", li, H, d.reverse ? " rev" : "", (H + 63) / 64, bh_k_lstm_q8_units(H, l.q_variant) / 4);
                 else if (p.cta) snprintf(line, sizeof(line), "%d lstm %d%s: lstm_layer_cta_kernel<%d,%d>\n", li, H, d.reverse ? " rev" : "", H / 32, U / 4);
                 else if (p.wg) snprintf(line, sizeof(line), "%d lstm %d%s: lstm_layer_wg_kernel<%d,%d>\n", li, H, d.reverse ? " rev" : "", H / 32, U / 4);
                 else if (p.fused) snprintf(line, sizeof(line), "%d lstm %d%s: lstm_layer_fused_kernel<%d>\n", li, H, d.reverse ? " rev" : "", H / 32);
@@ -703,6 +741,8 @@ extern "C" int bh_encoder_forward(bh_encoder_t* e, const void* signal, int N, in
     BH_CHECK_HIP(hipMemcpyAsync(e->sig.p, signal, (size_t)N * L * 2, hipMemcpyDeviceToDevice, st));
 
     e->prefilled = nullptr;
+    const void* cur_q = nullptr;     // output of a Q8-1 layer feeding the next one (int8, fragment order)
+    int qi = 0;
     const void* cur = e->sig.p;
     Layout lay = L_SIGNAL;
     int len = L, C = 1, which = 0;
@@ -716,7 +756,7 @@ extern "C" int bh_encoder_forward(bh_encoder_t* e, const void* signal, int N, in
         const Layer* nx = nullptr;
         for (size_t j = i + 1; j < nl && !nx; ++j)
             if (e->layers[j].d.kind == BH_LAYER_LSTM) nx = &e->layers[j];
-        if (!nx || lstm_path(e, *nx).cta) return 0;
+        if (!nx || lstm_path(e, *nx).cta || lstm_path(e, *nx).q8) return 0;      // those exchange elsewhere: nothing to pre-fill
         if (!e->fill_stream) BH_CHECK_HIP(hipStreamCreateWithFlags(&e->fill_stream, hipStreamNonBlocking));
         void* spare = e->act[(which + 1) % 3].p;
         BH_CHECK_HIP(hipEventRecord(e->fill_ready, st));
@@ -774,6 +814,46 @@ extern "C" int bh_encoder_forward(bh_encoder_t* e, const void* signal, int N, in
                 void* dst = e->act[which].p;
                 const LstmPath lp = lstm_path(e, l);
                 const bool reg_path = lp.reg_path, wide = lp.wide, fused = lp.fused, wg = lp.wg, cta = lp.cta;
+                if (lp.q8) {
+                    const int R = Np / 16;
+                    const size_t tile = bh_k_lstm_q8_tile_bytes(H);
+                    bool next_q8 = false;
+                    if (next_kind == BH_LAYER_LSTM)
+                        for (size_t j = i + 1; j < nl; ++j)
+                            if (e->layers[j].d.kind == BH_LAYER_LSTM) { next_q8 = lstm_path(e, e->layers[j]).q8; break; }
+                    const void* xq = cur_q;
+                    if (!xq) {       // first quantised layer: fp16 rows -> int8 fragments with the static input scale
+                        ProfSpan span(e, st, BH_PROF_OTHER);
+                        rc = bh_k_quantise_rows(cur, e->q_act[qi].p, len, Np, H, R, l.q_bound, st);
+                        if (rc) return rc;
+                        xq = e->q_act[qi].p;
+                        qi ^= 1;
+                    }
+                    void* hq_out = next_q8 ? e->q_act[qi].p : nullptr;
+                    void* h16_out = next_q8 ? nullptr : dst;
+                    ProfSpan span(e, st, BH_PROF_LSTM_REC);
+                    rc = bh_k_lstm_q8_arm(e->q_ex.p, R, H, st);
+                    if (rc) return rc;
+                    const int U = bh_k_lstm_q8_units(H, l.q_variant);
+                    const int wpr = (H / U) / 4, per_cu = U == 4 ? 3 : 1;
+                    const int fit = (e->n_cus * per_cu) / (8 * wpr);
+                    BH_REQUIRE(fit >= 1, "encoder_forward: device has too few CUs (%d) for hidden size %d", e->n_cus, H);
+                    for (int r0 = 0; r0 < R; r0 += fit * 8) {
+                        const int nr = std::min(fit * 8, R - r0);
+                        rc = bh_k_lstm_layer_q8((const char*)xq + (size_t)r0 * tile, l.q_wih.p, l.q_whh.p, (const float*)l.q_sx.p,
+                                                (const float*)l.q_sh.p, (const float*)l.b0.p,
+                                                hq_out ? (char*)hq_out + (size_t)r0 * tile : nullptr,
+                                                h16_out ? (char*)h16_out + (size_t)r0 * 16 * H * 2 : nullptr,
+                                                (char*)e->q_ex.p + (size_t)r0 * tile, len, Np, H, R, nr, d.reverse, (int*)e->err.p, st,
+                                                (int*)e->lstm_ws.p, e->lstm_force_slow, l.q_variant, nullptr, bh_k_lstm_max_spins());
+                        if (rc) return rc;
+                    }
+                    if (next_q8) { cur_q = hq_out; qi ^= 1; }
+                    else { cur_q = nullptr; cur = dst; which = (which + 1) % e->n_act; }
+                    C = H;
+                    break;
+                }
+                BH_REQUIRE(cur_q == nullptr, "encoder_forward: layer %zu would read int8 activations it cannot consume", i);
                 if (!fused) {
                     ProfSpan span(e, st, BH_PROF_LSTM_GEMM);
                     rc = bh_k_linear(cur, wide ? l.w4.p : l.w0.p, (const float*)(wide ? l.b1.p : l.b0.p), e->gates.p, M, 4 * H,
@@ -1086,6 +1166,53 @@ extern "C" int bh_lstm_layer(const void* gates_in, const void* whh_packed, void*
     return bh_k_lstm_layer(gates_in, whh_packed, h_out, T, N, H, reverse, err_flag, (hipStream_t)stream, N / 16,
                            (int*)workspace, flags & 1);
 }
+// Operator level (parity tests): one Q8-1 recurrent layer straight from fp32 host weights. Packs, uploads, quantises x with
+// the static scale 127 / bound, runs the 8-bit kernel and synchronises. `sums` (optional) receives the exact int32 partial sums
+// [T][N][4H][2] (input part, recurrent part) the gate arithmetic started from; `hq_frag` (optional) the int8 output in
+// fragment order [T][N/16][ceil(H/64)][64][16].
+extern "C" int bh_lstm_q8_layer(const void* x, float bound, const float* w_ih, const float* w_hh, const float* bias, int T, int N,
+                                int H, int reverse, int variant, void* h16_out, int8_t* hq_frag, int32_t* sums, void* stream_) {
+    BH_REQUIRE(x && w_ih && w_hh && h16_out && T > 0 && N > 0 && N % 16 == 0, "lstm_q8_layer: bad arguments");
+    const int U = bh_k_lstm_q8_units(H, variant);
+    BH_REQUIRE(U != 0, "lstm_q8_layer: hidden size %d is not covered by the 8-bit kernel", H);
+    hipStream_t st = (hipStream_t)stream_;
+    const int R = N / 16;
+    const size_t tile = bh_k_lstm_q8_tile_bytes(H), wbytes = (size_t)4 * H * ((H + 63) / 64 * 64);
+    std::vector<int8_t> pk(wbytes);
+    std::vector<float> s_ih((size_t)4 * H), s_hh((size_t)4 * H), b((size_t)4 * H, 0.0f);
+    DevBuf q_wih, q_whh, q_sx, q_sh, q_b, xq, ex, ws, err;
+    struct Free { std::vector<DevBuf*> v; ~Free() { for (auto* d : v) d->release(); } } guard{{&q_wih, &q_whh, &q_sx, &q_sh, &q_b, &xq, &ex, &ws, &err}};
+    if (bh_k_lstm_q8_pack(w_ih, H, U, pk.data(), s_ih.data()) || upload(q_wih, pk.data(), pk.size())) return -1;
+    if (bh_k_lstm_q8_pack(w_hh, H, U, pk.data(), s_hh.data()) || upload(q_whh, pk.data(), pk.size())) return -1;
+    const float xs = (float)((double)bound / 127.0);
+    for (int j = 0; j < 4 * H; ++j) { s_ih[j] *= xs; s_hh[j] /= 127.0f; if (bias) b[j] = bias[j]; }
+    if (upload_f32(q_sx, s_ih.data(), s_ih.size()) || upload_f32(q_sh, s_hh.data(), s_hh.size()) || upload_f32(q_b, b.data(), b.size())) return -1;
+    if (xq.alloc((size_t)T * R * tile) || ex.alloc(4 * (size_t)R * tile) || ws.alloc(bh_k_lstm_ws_bytes(N, 1024)) || err.alloc(sizeof(int))) return -1;
+    BH_CHECK_HIP(hipMemsetAsync(err.p, 0, sizeof(int), st));
+    int rc = bh_k_quantise_rows(x, xq.p, T, N, H, R, bound, st);
+    if (!rc) rc = bh_k_lstm_q8_arm(ex.p, R, H, st);
+    if (rc) return rc;
+    int dev = 0, cus = 0;
+    BH_CHECK_HIP(hipGetDevice(&dev));
+    BH_CHECK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    const int wpr = (H / U) / 4, fit = (cus * (U == 4 ? 3 : 1)) / (8 * wpr);
+    BH_REQUIRE(fit >= 1, "lstm_q8_layer: device has too few CUs for hidden size %d", H);
+    for (int r0 = 0; r0 < R; r0 += fit * 8) {
+        const int nr = std::min(fit * 8, R - r0);
+        rc = bh_k_lstm_layer_q8((const char*)xq.p + (size_t)r0 * tile, q_wih.p, q_whh.p, (const float*)q_sx.p, (const float*)q_sh.p,
+                                (const float*)q_b.p, hq_frag ? (char*)hq_frag + (size_t)r0 * tile : nullptr,
+                                (char*)h16_out + (size_t)r0 * 16 * H * 2, (char*)ex.p + (size_t)r0 * tile, T, N, H, R, nr, reverse,
+                                (int*)err.p, st, (int*)ws.p, 0, variant, sums ? sums + (size_t)r0 * 16 * 4 * H * 2 : nullptr,
+                                bh_k_lstm_max_spins());
+        if (rc) return rc;
+    }
+    int flag = 0;
+    BH_CHECK_HIP(hipMemcpyAsync(&flag, err.p, sizeof(int), hipMemcpyDeviceToHost, st));
+    BH_CHECK_HIP(hipStreamSynchronize(st));
+    BH_REQUIRE(flag == 0, "lstm_q8_layer: exchange timeout in the recurrent kernel");
+    return 0;
+}
+
 // debug: copy the LSTM statistics block (tune bit 4) of the last launch to the host
 extern "C" int bh_encoder_debug_read(bh_encoder_t* e, void* host, size_t bytes, size_t offset) {
     BH_REQUIRE(e && host && offset + bytes <= e->lstm_ws.bytes, "encoder_debug_read: out of range");
@@ -1099,6 +1226,7 @@ extern "C" int bh_encoder_set_option(bh_encoder_t* e, const char* name, int valu
     if (!strcmp(name, "attn_ring")) { e->attn_ring = value; return 0; }
     if (!strcmp(name, "lstm_wide")) { e->lstm_wide = value; return 0; }
     if (!strcmp(name, "lstm_prefill")) { e->lstm_prefill = value; return 0; }
+    if (!strcmp(name, "lstm_q8")) { e->lstm_q8 = value; return 0; }
     if (!strcmp(name, "gemm_v1")) { bh_k_linear_force_v1(value); return 0; }   // process-wide A/B switch
     if (!strcmp(name, "lstm_tune")) { e->lstm_force_slow = (e->lstm_force_slow & 1) | (value << 8); return 0; }
     BH_REQUIRE(false, "encoder_set_option: unknown option '%s'", name);
@@ -1143,6 +1271,7 @@ extern "C" int bh_set_option(const char* name, int value) {
     if (bh_k_conv_set_option(name, value) == 0) return 0;
     if (bh_k_lstm_set_option(name, value) == 0) return 0;
     if (!strcmp(name, "gemm_path")) { bh_k_linear_force_v1(value); return 0; }
+    if (!strcmp(name, "lstm_q8_variant")) { g_q8_variant = value; return 0; }
     BH_REQUIRE(false, "set_option: unknown option '%s'", name);
     return -1;
 }

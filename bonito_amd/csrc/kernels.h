@@ -92,3 +92,14 @@ int bh_k_signal_chunks(const int16_t* raw, const long* offs, const float* cal_sc
 int bh_k_lstm_wide_ok(int H);
 int bh_k_lstm_layer_wide(const void* gates_perm, const void* whh_tiles, void* h_out, int T, int N, int H, int reverse,
                          int* err_flag, hipStream_t stream, int n_rings, int* xcc_ws, int force_slow);
+
+// lstm_q8.hip: 8-bit recurrent path Q8-1
+int bh_k_lstm_q8_units(int H, int variant);
+size_t bh_k_lstm_q8_tile_bytes(int H);
+int bh_k_lstm_q8_pack(const float* w, int H, int U, int8_t* packed, float* scale);
+int bh_k_quantise_rows(const void* x, void* out, int T, int N, int H, int R, float bound, hipStream_t stream);
+int bh_k_lstm_q8_arm(void* ex, int R, int H, hipStream_t stream);
+int bh_k_lstm_layer_q8(const void* xq, const void* wih, const void* whh, const float* sx, const float* sh, const float* bias,
+                       void* hq_out, void* h16_out, void* ex, int T, int N, int H, int R, int n_rings, int reverse, int* err_flag,
+                       hipStream_t stream, int* xcc_ws, int flags, int variant, int* dbg, unsigned max_spins);
+unsigned bh_k_lstm_max_spins();

@@ -1176,6 +1176,8 @@ int bh_k_lstm_set_option(const char* name, int value) {
     return 0;
 }
 
+unsigned bh_k_lstm_max_spins() { return g_max_spins; }
+
 size_t bh_k_lstm_packed_bytes(int H) { return (size_t)4 * H * H * 2; }
 size_t bh_k_lstm_ws_bytes(int N, int H) {
     // XCD agreement slots + (tune bit 4) per-wave statistics: up to 16 x int64 per (ring, slice)

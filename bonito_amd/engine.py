@@ -71,8 +71,10 @@ def _flatten(module):
     return [module]
 
 
-def lower(encoder):
-    """Module tree -> _Lowered chain. Raises LoweringError on anything the engine cannot run."""
+def lower(encoder, quantize=False):
+    """Module tree -> _Lowered chain. Raises LoweringError on anything the engine cannot run.
+    `quantize`: mark every LSTM layer for the 8-bit recurrent path Q8-1 (koi's `quantize`, reference crf/model.py:245); the
+    engine uses it where its int8 kernel covers the layer shape and keeps the fp16 kernels elsewhere (HipEncoder.describe())."""
     low = _Lowered()
     time_major = False   # reference activations are NCL until Permute([2,0,1]) makes them TNC
     for m in _flatten(encoder):
@@ -103,7 +105,7 @@ def lower(encoder):
             if not time_major:
                 raise LoweringError("lstm must follow permute [2,0,1]")
             low.add(kind=_lib.BH_LAYER_LSTM, in_size=r.input_size, out_size=r.hidden_size,
-                    reverse=int(bool(m.reverse)), w0=_f32(r.weight_ih_l0), w1=_f32(r.weight_hh_l0),
+                    reverse=int(bool(m.reverse)), quantize=int(bool(quantize)), w0=_f32(r.weight_ih_l0), w1=_f32(r.weight_hh_l0),
                     b0=_f32(r.bias_ih_l0) if r.bias else 0, b1=_f32(r.bias_hh_l0) if r.bias else 0)
         elif isinstance(m, bnn.LinearCRFEncoder):
             lin = m.linear
@@ -190,7 +192,7 @@ def lower_ctc(model):
 class HipEncoder:
     """Callable engine handle: ``scores = enc(signal)`` with signal fp16 cuda [N,1,L] or [N,L]."""
 
-    def __init__(self, encoder, batchsize, chunksize, device=None, lowering=None):
+    def __init__(self, encoder, batchsize, chunksize, device=None, lowering=None, quantize=False):
         self._handle = None
         lib = _lib.lib()
         if not torch.cuda.is_available():
@@ -200,7 +202,8 @@ class HipEncoder:
             raise _lib.HipEngineError("the encoder engine needs a GPU device, got %s" % (dev,))
         self.device = dev
         self.max_batch, self.max_chunk = int(batchsize), int(chunksize)
-        low = (lowering or lower)(encoder)
+        low = lowering(encoder) if lowering is not None else lower(encoder, quantize=quantize)
+        self.quantize = bool(quantize)
         handle = C.c_void_p()
         _lib.check(lib.bh_encoder_create(low.array(), len(low.descs), dev.index or 0, self.max_batch,
                                          self.max_chunk, C.byref(handle)), "bh_encoder_create")

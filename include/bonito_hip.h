@@ -75,7 +75,8 @@ typedef struct bh_layer {
     int32_t scale_factor;               /* upsample */
     int32_t groups;      /* conv: 1 */
     int32_t add_residual;               /* conv (pointwise): add the pending residual projection before the activation */
-    int32_t reserved_i[2];
+    int32_t quantize;    /* lstm: 1 = 8-bit recurrent path Q8-1 where the kernel covers the shape (koi's `quantize`, crf/model.py:245) */
+    int32_t reserved_i[1];
     float scale;         /* linear_crf: multiply after activation (0 = none) */
     float clamp_lo, clamp_hi;           /* clamp */
     float blank_score;   /* linear_crf with fixed blank (scores keep the 4S koi layout) */
@@ -174,6 +175,14 @@ int bh_signal_chunks(const int16_t* raw, const long* offsets, const float* cal_s
                      const double* shift, const double* scale, const int* weak, const int* chunk_read, const long* chunk_start,
                      const long* chunk_len, int n_chunks, int chunk_samples, void* out, void* stream);
 
+/* Operator level (parity tests): one recurrent layer of the 8-bit path Q8-1 (koi's `quantize`, bonito/crf/model.py:245; the
+ * arithmetic is defined in oracle/lstm_q8_ref.py) from fp32 HOST weights W_ih, W_hh [4H][H] and bias [4H] (b_ih + b_hh, or NULL).
+ * x: device fp16 [T][N][H], N % 16 == 0, quantised with the static scale 127 / bound; h16_out: device fp16 [T][N][H];
+ * hq_frag (or NULL): device int8 output in MFMA fragment order [T][N/16][ceil(H/64)][64][16]; sums (or NULL): device int32
+ * [T][N][4H][2] = the exact integer sums (input part, recurrent part) per gate row. variant: see "lstm_q8_variant". Synchronises. */
+int bh_lstm_q8_layer(const void* x, float bound, const float* w_ih, const float* w_hh, const float* bias, int T, int N, int H,
+                     int reverse, int variant, void* h16_out, int8_t* hq_frag, int32_t* sums, void* stream);
+
 /* Process-wide knobs (measurement / tuning hooks, no reference counterpart).
  *   "beam_fork": -1 auto (default), 0 = run the posterior scan behind the beam kernel on the caller's stream,
  *                1 = run it next to the beam kernel on an internal helper stream (joined before finalize).
@@ -181,6 +190,8 @@ int bh_signal_chunks(const int16_t* raw, const long* offsets, const float* cal_s
  *                (the same beams either way; kept for regression tests and A/B timing).
  *   "conv_ws": 1 (default) = weight-stationary kernel for the 384-channel / 19-tap convolution, 0 = generic implicit GEMM.
  *   "gemm_path": 0 auto (default), 1 = register-staged 128x128x64 kernel only, 2 = never the persistent 256x256x64 kernel.
+ *   "lstm_q8_variant": geometry of the 8-bit recurrent kernel chosen at bh_encoder_create: 0 (default) = 12 / 16 units per wave,
+ *                one workgroup per CU; 1 = 4 units per wave, three workgroups per CU (hidden size 384 only).
  *   "lstm_max_spins": bound of the recurrent kernels' exchange spin loops (default 1000000; < 0 restores it). Tests lower it
  *                to provoke the timeout path (bh_encoder_error_flag / bh_encoder_check). */
 int bh_set_option(const char* name, int value);
