@@ -182,6 +182,8 @@ struct bh_encoder {
     void* prefilled = nullptr;
     int lstm_prefill = 1;
     DevBuf q_act[2], q_ex;                 // 8-bit recurrent path: int8 activations in fragment order, exchange ring buffer
+    DevBuf ex16;                           // fp16 workgroup-shared kernel: exchange ring buffer (lstm_layer_wgx_kernel)
+    int lstm_exchange = 1;                 // 1: hand-off through the ring buffer (no sentinel fill of the output tensor), 0: through the output
     int lstm_q8 = 1;                       // 0: run quantised layers through the fp16 kernels (A/B)
     DevBuf res;                            // pending residual projection of a QuartzNet block
     DevBuf t_qkv, t_mid, t_a, t_b, rot;   // transformer workspace + rotary cos/sin table [Tmax][32][2]
@@ -209,7 +211,7 @@ struct bh_encoder {
             l.w4.release(); l.w5.release(); l.b0.release(); l.b1.release();
             l.q_wih.release(); l.q_whh.release(); l.q_sx.release(); l.q_sh.release();
         }
-        q_act[0].release(); q_act[1].release(); q_ex.release();
+        q_act[0].release(); q_act[1].release(); q_ex.release(); ex16.release();
         act[0].release(); act[1].release(); act[2].release(); gates.release(); sig.release(); err.release(); lstm_ws.release();
         res.release(); t_qkv.release(); t_mid.release(); t_a.release(); t_b.release(); rot.release();
     }
@@ -591,6 +593,12 @@ extern "C" int bh_encoder_create(const bh_layer_t* layers, int n_layers, int dev
         if (e->q_act[0].alloc(ab + 256) || e->q_act[1].alloc(ab + 256) || e->q_ex.alloc((size_t)4 * (Np / 16) * 16 * 1024 + 256))
             return fail(-1);
     }
+    {   // exchange ring buffer of the fp16 workgroup-shared recurrent kernel: 4 slots x (H/32) KiB per ring
+        int hmax = 0;
+        for (const auto& l : e->layers)
+            if (l.d.kind == BH_LAYER_LSTM && l.d.in_size == l.d.out_size && bh_k_lstm_wg_units(l.d.out_size) != 0) hmax = std::max(hmax, l.d.out_size);
+        if (hmax && e->ex16.alloc(bh_k_lstm_wgx_ex_bytes(Np, hmax) + 256)) return fail(-1);
+    }
     if (e->act[0].alloc(ab + 256) || e->act[1].alloc(ab + 256) || e->gates.alloc(gb + 256) ||
         e->sig.alloc((size_t)Np * max_chunk * 2) || e->err.alloc(sizeof(int)) || e->lstm_ws.alloc(bh_k_lstm_ws_bytes(Np, 1024)))
         return fail(-1);
@@ -662,7 +670,7 @@ extern "C" int bh_encoder_output_shape(const bh_encoder_t* enc, int L, int* T, i
 
 namespace {
 // which recurrence kernel serves a layer (see lstm.hip)
-struct LstmPath { bool reg_path, wide, fused, wg, cta, q8; };
+struct LstmPath { bool reg_path, wide, fused, wg, cta, q8, wgx; };
 static LstmPath lstm_path(const bh_encoder* e, const Layer& l) {
     const int H = l.d.out_size;
     LstmPath p;
@@ -673,6 +681,7 @@ static LstmPath lstm_path(const bh_encoder* e, const Layer& l) {
     p.cta = p.wg && e->lstm_fused >= 3 && bh_k_lstm_cta_units(H) != 0 && bh_k_lstm_cta_units(H) == bh_k_lstm_wg_units(H);
     p.q8 = l.q8 && e->lstm_q8 && l.d.in_size == H;
     if (p.q8) p.fused = p.wg = p.cta = p.wide = false;
+    p.wgx = p.wg && !p.cta && e->lstm_exchange && e->ex16.p != nullptr;
     return p;
 }
 }  // namespace
@@ -695,6 +704,7 @@ extern "C" int bh_encoder_describe(const bh_encoder_t* e, char* buf, size_t n) {
                 const int H = d.out_size, U = bh_k_lstm_wg_units(H);
                 if (p.q8) snprintf(line, sizeof(line), "%d lstm %d%s: lstm_layer_q8_kernel<%d,%d> (int8 W/x/h, i32 MFMA 16x16x64)\n", li, H, d.reverse ? " rev" : "", (H + 63) / 64, bh_k_lstm_q8_units(H, l.q_variant) / 4);
                 else if (p.cta) snprintf(line, sizeof(line), "%d lstm %d%s: lstm_layer_cta_kernel<%d,%d>\n", li, H, d.reverse ? " rev" : "", H / 32, U / 4);
+                else if (p.wgx) snprintf(line, sizeof(line), "%d lstm %d%s: lstm_layer_wgx_kernel<%d,%d>\n", li, H, d.reverse ? " rev" : "", H / 32, U / 4);
                 else if (p.wg) snprintf(line, sizeof(line), "%d lstm %d%s: lstm_layer_wg_kernel<%d,%d>\n", li, H, d.reverse ? " rev" : "", H / 32, U / 4);
                 else if (p.fused) snprintf(line, sizeof(line), "%d lstm %d%s: lstm_layer_fused_kernel<%d>\n", li, H, d.reverse ? " rev" : "", H / 32);
                 else if (p.wide) snprintf(line, sizeof(line), "%d lstm %d%s: gemm + lstm_layer_wide_kernel<%d>\n", li, H, d.reverse ? " rev" : "", H / 32);
@@ -756,7 +766,7 @@ extern "C" int bh_encoder_forward(bh_encoder_t* e, const void* signal, int N, in
         const Layer* nx = nullptr;
         for (size_t j = i + 1; j < nl && !nx; ++j)
             if (e->layers[j].d.kind == BH_LAYER_LSTM) nx = &e->layers[j];
-        if (!nx || lstm_path(e, *nx).cta || lstm_path(e, *nx).q8) return 0;      // those exchange elsewhere: nothing to pre-fill
+        if (!nx || lstm_path(e, *nx).cta || lstm_path(e, *nx).q8 || lstm_path(e, *nx).wgx) return 0;   // those exchange elsewhere: nothing to pre-fill
         if (!e->fill_stream) BH_CHECK_HIP(hipStreamCreateWithFlags(&e->fill_stream, hipStreamNonBlocking));
         void* spare = e->act[(which + 1) % 3].p;
         BH_CHECK_HIP(hipEventRecord(e->fill_ready, st));
@@ -835,7 +845,7 @@ extern "C" int bh_encoder_forward(bh_encoder_t* e, const void* signal, int N, in
                     rc = bh_k_lstm_q8_arm(e->q_ex.p, R, H, st);
                     if (rc) return rc;
                     const int U = bh_k_lstm_q8_units(H, l.q_variant);
-                    const int wpr = (H / U) / 4, per_cu = U == 4 ? 3 : 1;
+                    const int wpr = (H / U) / 4, per_cu = U == 4 ? 3 : (l.q_variant == 2 && H == 384) ? 2 : 1;
                     const int fit = (e->n_cus * per_cu) / (8 * wpr);
                     BH_REQUIRE(fit >= 1, "encoder_forward: device has too few CUs (%d) for hidden size %d", e->n_cus, H);
                     for (int r0 = 0; r0 < R; r0 += fit * 8) {
@@ -860,7 +870,8 @@ extern "C" int bh_encoder_forward(bh_encoder_t* e, const void* signal, int N, in
                                      d.in_size, d.in_size, d.in_size, 4 * H, bh::ACT_NONE, 1.0f, -INFINITY, INFINITY, 0, 0, 0, 0, 0, st);
                     if (rc) return rc;
                 }
-                if (!cta) {      // exchange sentinel (the ring-in-a-workgroup kernel exchanges through LDS only)
+                if (!cta && !lp.wgx) {      // exchange sentinel in the output tensor (the ring-in-a-workgroup kernel exchanges through
+                                            // LDS only, the ring-buffer kernel through its own armed buffer)
                     if (e->prefilled == dst) {          // filled beside the previous layer's kernel
                         BH_CHECK_HIP(hipStreamWaitEvent(st, e->fill_done, 0));
                     } else {
@@ -891,6 +902,10 @@ extern "C" int bh_encoder_forward(bh_encoder_t* e, const void* signal, int N, in
                     else if (cta)
                         rc = bh_k_lstm_layer_cta((const char*)cur + col * H * 2, l.w4.p, (const float*)l.b0.p, l.w3.p,
                                                  (char*)dst + col * H * 2, len, Np, H, d.reverse, st, nr);
+                    else if (lp.wgx)
+                        rc = bh_k_lstm_layer_wgx((const char*)cur + col * H * 2, l.w4.p, (const float*)l.b0.p, l.w3.p,
+                                                 (char*)dst + col * H * 2, (char*)e->ex16.p + (size_t)r0 * (H / 32) * 1024, len, Np, H, n_rings,
+                                                 d.reverse, (int*)e->err.p, st, nr, (int*)e->lstm_ws.p, e->lstm_force_slow, r0 == 0);
                     else if (wg)
                         rc = bh_k_lstm_layer_wg((const char*)cur + col * H * 2, l.w4.p, (const float*)l.b0.p, l.w3.p,
                                                 (char*)dst + col * H * 2, len, Np, H, d.reverse, (int*)e->err.p, st, nr,
@@ -1195,7 +1210,7 @@ extern "C" int bh_lstm_q8_layer(const void* x, float bound, const float* w_ih, c
     int dev = 0, cus = 0;
     BH_CHECK_HIP(hipGetDevice(&dev));
     BH_CHECK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-    const int wpr = (H / U) / 4, fit = (cus * (U == 4 ? 3 : 1)) / (8 * wpr);
+    const int wpr = (H / U) / 4, fit = (cus * (U == 4 ? 3 : (variant == 2 && H == 384) ? 2 : 1)) / (8 * wpr);
     BH_REQUIRE(fit >= 1, "lstm_q8_layer: device has too few CUs for hidden size %d", H);
     for (int r0 = 0; r0 < R; r0 += fit * 8) {
         const int nr = std::min(fit * 8, R - r0);
@@ -1227,6 +1242,7 @@ extern "C" int bh_encoder_set_option(bh_encoder_t* e, const char* name, int valu
     if (!strcmp(name, "lstm_wide")) { e->lstm_wide = value; return 0; }
     if (!strcmp(name, "lstm_prefill")) { e->lstm_prefill = value; return 0; }
     if (!strcmp(name, "lstm_q8")) { e->lstm_q8 = value; return 0; }
+    if (!strcmp(name, "lstm_exchange")) { e->lstm_exchange = value; return 0; }
     if (!strcmp(name, "gemm_v1")) { bh_k_linear_force_v1(value); return 0; }   // process-wide A/B switch
     if (!strcmp(name, "lstm_tune")) { e->lstm_force_slow = (e->lstm_force_slow & 1) | (value << 8); return 0; }
     BH_REQUIRE(false, "encoder_set_option: unknown option '%s'", name);

@@ -103,3 +103,7 @@ int bh_k_lstm_layer_q8(const void* xq, const void* wih, const void* whh, const f
                        void* hq_out, void* h16_out, void* ex, int T, int N, int H, int R, int n_rings, int reverse, int* err_flag,
                        hipStream_t stream, int* xcc_ws, int flags, int variant, int* dbg, unsigned max_spins);
 unsigned bh_k_lstm_max_spins();
+size_t bh_k_lstm_wgx_ex_bytes(int N, int H);
+int bh_k_lstm_layer_wgx(const void* x, const void* wih_tiles, const float* bias, const void* whh_tiles, void* h_out, void* ex, int T,
+                        int N, int H, int R, int reverse, int* err_flag, hipStream_t stream, int n_rings, int* xcc_ws, int force_slow,
+                        int arm);

@@ -847,6 +847,268 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_wg_kernel(LstmFusedArgs fp)
 }
 
 // ---------------------------------------------------------------------------------------------------
+// "wgx": the workgroup-shared kernel above with the exchange and the x stream of the 8-bit kernel (lstm_q8.hip). Same
+// arithmetic, same accumulation order, same lstm_cell() -> the same bytes as every other fp16 variant (tested); what changes is
+// where the bytes travel:
+//   * the hand-off no longer goes through the layer's output tensor. h_t is published into a small RING BUFFER of four time
+//     slots per ring, laid out as ready-made MFMA B fragments ([k-step][lane][16 bytes]: a consumer's poll of a k-step is one
+//     fully coalesced KiB, 8 whole cache lines instead of 16 half lines of a row-major tensor). 4 x 12 KiB per ring, 1.5 MiB for
+//     a 512-chunk batch: it lives in the L2. Sentinel = fp16 0xFFFF as before (|h| <= 1 never has bit 14 set). A producer
+//     re-arms its own bytes of slot (t+2)%4 at step t, behind the workgroup barrier that proves every wave of the ring has
+//     published h_{t-1} (hence finished reading h_{t-2}); its vmcnt(0) ahead of the next barrier completes the re-arm before it
+//     publishes anything newer, so no consumer can find stale bytes. Consequences: no sentinel pre-fill of the output tensor
+//     (the fill kernel, 0.66 GB of writes per layer, is gone), no first-touch fetch of 0.66 GB of polled sentinel lines from
+//     HBM per layer, no third activation buffer;
+//   * the layer output is a second, plain 8-byte store of the same values into [T][N][H] (next layer's input / the linear layer);
+//   * x_{t+2} is fetched with LDS-DMA (global_load_lds_dwordx4: lane l -> LDS base + 16 l, which is the B-fragment order) by the
+//     four waves in shares, straight into a three-slot LDS ring: no registers, no compiler-placed waits on the x stream.
+__device__ __forceinline__ void dma16_wgx(const char* g, char* lds) {
+    const unsigned l = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)(__attribute__((address_space(3))) char*)lds);
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(l), "v"(g) : "memory");
+}
+
+struct LstmWgxArgs {
+    LstmFusedArgs f;
+    char* ex;             // exchange ring buffer [4][R][NKS][64][16], armed with 0xFF
+    int R;                // ring stride of `ex` (rings of the whole batch)
+};
+
+template <int NKS, int MT>
+__global__ __launch_bounds__(256, 1) void lstm_layer_wgx_kernel(LstmWgxArgs wp) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const LstmFusedArgs& fp = wp.f;
+    const LstmArgs& p = fp.a;
+    constexpr int H = NKS * 32, U = 4 * MT, NSL = H / U, WPR = NSL / 4, KQ = (NKS + 3) / 4, TILE = NKS * 1024;
+    constexpr bool EXACT = NKS % 4 == 0;
+    static_assert(H % (4 * U) == 0, "four slices per workgroup");
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int xcd = blockIdx.x & 7;
+    const int lwg = blockIdx.x >> 3;
+    const int rl = lwg / WPR;
+    const int ring = rl * 8 + xcd;
+    const int slice = (lwg - rl * WPR) * 4 + wave;
+    if (ring >= p.n_rings) return;
+
+    char* hbuf = smem;                                  // [2][NKS][64][16]  B fragments of h_{t-1}
+    char* xbuf = smem + 2 * TILE;                       // [3][NKS][64][16]  B fragments of x_t: consumed / landed / landing
+    char* stage = smem + 5 * TILE + wave * (16 * U * 2);
+
+    half8_t whh[MT][NKS], wih[MT][NKS];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+            const long o = ((((long)slice * MT + m) * NKS + ks) * 64 + lane) * 8;
+            whh[m][ks] = *(const half8_t*)(p.whh + o);
+            wih[m][ks] = *(const half8_t*)(fp.wih + o);
+        }
+    const int c = lane & 15, q = lane >> 4;
+    float cst[MT];
+    float4_t bias4[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        cst[m] = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) bias4[m][i] = fp.bias[i * H + slice * U + q * MT + m];
+    }
+    bool dead = false;
+    bool fast = false;
+    {
+        int* slot = p.xcc_ws + (long)ring * NSL;
+        const int mine = xcc_id();
+        if (lane == 0) __hip_atomic_store(slot + slice, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned spins = 0;
+        bool ok = false;
+        while (true) {
+            int v = (lane < NSL) ? __hip_atomic_load(slot + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : mine;
+            if (!__any(v < 0)) { ok = !__any(v != mine); break; }
+            if (++spins > p.max_spins) break;
+            __builtin_amdgcn_s_sleep(4);
+        }
+        fast = ok && !p.force_slow;
+    }
+
+    int t = p.reverse ? p.T - 1 : 0;
+    const int dt = p.reverse ? -1 : 1;
+    // x_t rows are row-major [T][N][H]; lane (c, q) of k-step ks needs halves [ks*32 + q*8, +8) of chunk ring*16 + c
+    const half_t* xptr = fp.x + ((long)(ring * 16 + c) * H + q * 8);
+    const long x_row = (long)p.N * H;
+    const int lo = lane * 16;
+    const long slot_stride = (long)wp.R * TILE;
+    char* exr = wp.ex + (long)ring * TILE;
+
+    // lanes that move this wave's U units out: (chunk cc, 4 consecutive units = 8 bytes)
+    constexpr int PARTS = U / 4;
+    const bool mover = lane < 16 * PARTS;
+    const int cc = lane / PARTS, part = lane - cc * PARTS;
+    const int u0 = slice * U + part * 4;
+    const int my_byte = (((u0 >> 5) * 64 + ((u0 >> 3) & 3) * 16 + cc) << 4) + (u0 & 7) * 2;      // inside a ring tile (fragment order)
+
+    uint4_t hq[KQ];
+    float4_t xacc[MT];
+    auto x_phase = [&](const char* xb) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m) xacc[m] = bias4[m];
+        half8_t b_cur = *(const half8_t*)(xb + lo), b_nxt = b_cur;
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+            if (ks + 1 < NKS) b_nxt = *(const half8_t*)(xb + (ks + 1) * 1024 + lo);
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                if (m < MT - 1) mfma16_av(wih[m][ks], b_cur, xacc[m]);
+                else mfma16_vv(wih[m][ks], b_cur, xacc[m]);
+            }
+            b_cur = b_nxt;
+        }
+        mfma_settle_v<MT>(xacc);
+    };
+    // x stream: the polls of the exchange go to k-steps w, w+4, ..; the DMA shares are 3-w, 7-w, .. (balanced over the waves)
+    auto x_dma = [&](int tt, int slot) {
+#pragma unroll
+        for (int kk = 0; kk < KQ; ++kk) {
+            const int ks = (3 - wave) + 4 * kk;
+            if (EXACT || ks < NKS) dma16_wgx((const char*)(xptr + (long)tt * x_row + ks * 32), xbuf + (slot * NKS + ks) * 1024);
+        }
+    };
+
+    x_dma(t, 0);
+    x_dma(p.T > 1 ? t + dt : t, 1);
+    __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0): the builtin (unlike inline asm) also clears the compiler's own scoreboard
+    __syncthreads();
+    x_phase(xbuf);
+#pragma unroll
+    for (int kk = 0; kk < KQ; ++kk) hq[kk] = uint4_t{0, 0, 0, 0};
+
+    long long st_poll = 0, st_rounds = 0, st_first_ok = 0, st_x = 0, st_rec = 0, st_bar = 0, st_hist = 0;
+    long long st_mf = 0, st_gate = 0, st_store = 0;
+    const long long st_t0 = __builtin_readcyclecounter();
+    const long long st_r0 = (p.tune & 4) ? (long long)__builtin_amdgcn_s_memrealtime() : 0;
+
+    for (int step = 0; step < p.T; ++step, t += dt) {
+        const int par = step & 1;
+        float4_t acc[MT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) acc[m] = xacc[m];
+        // ---- B. my quarter of h_{t-1}: round one went out right after the previous store --------------------------------
+        const long long pc0 = (p.tune & 4) ? __builtin_readcyclecounter() : 0;
+        if (step > 0) {
+            // wave-uniform descriptor, per-lane offset (a per-lane base would turn every load into a 64-trip readfirstlane loop)
+            const char* src = exr + (long)((step - 1) & 3) * slot_stride;
+            __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, TILE, 0x00020000);
+            unsigned spins = dead ? p.max_spins : 0u;
+            unsigned pend = 0;
+#pragma unroll
+            for (int kk = 0; kk < KQ; ++kk) {
+                const int ks = wave + 4 * kk;
+                if (EXACT || ks < NKS) {
+                    unsigned orv = hq[kk].x | hq[kk].y | hq[kk].z | hq[kk].w;
+                    if (__any((orv & SENTINEL_MASK) != 0)) pend |= (1u << kk);
+                }
+            }
+            unsigned rounds = 1;
+            while (pend != 0) {
+                if (++spins > p.max_spins) {
+                    if (lane == 0 && !dead) atomicExch(p.err, 1);
+                    dead = true;
+                    break;
+                }
+                if (!(p.tune & 1)) __builtin_amdgcn_s_sleep(1);
+#pragma unroll
+                for (int kk = 0; kk < KQ; ++kk)
+                    if (pend & (1u << kk))
+                        hq[kk] = __builtin_amdgcn_raw_buffer_load_b128(rs, (wave + 4 * kk) * 1024 + lo, 0, (int)0x80000010);
+#pragma unroll
+                for (int kk = 0; kk < KQ; ++kk)
+                    if (pend & (1u << kk)) {
+                        unsigned orv = hq[kk].x | hq[kk].y | hq[kk].z | hq[kk].w;
+                        if (!__any((orv & SENTINEL_MASK) != 0)) pend &= ~(1u << kk);
+                    }
+                ++rounds;
+            }
+#pragma unroll
+            for (int kk = 0; kk < KQ; ++kk) {
+                const int ks = wave + 4 * kk;
+                if (EXACT || ks < NKS) *(uint4_t*)(hbuf + (par * NKS + ks) * 1024 + lo) = hq[kk];
+            }
+            if (p.tune & 4) {
+                st_poll += __builtin_readcyclecounter() - pc0; st_rounds += rounds; st_first_ok += (rounds == 1);
+                st_hist += 1ll << (16 * (rounds > 3 ? 3 : rounds - 1));
+            }
+        }
+        // ---- D. publish h_{t-1} and x_{t+1} (DMA issued a step ago) to the workgroup; the vmcnt(0) covers this wave's DMA share
+        //         and completes its re-arm store of the previous step before it publishes anything newer ----------------------
+        const long long pc1 = (p.tune & 4) ? __builtin_readcyclecounter() : 0;
+        __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0): the builtin (unlike inline asm) also clears the compiler's own scoreboard
+        __syncthreads();
+        const long long pc2 = (p.tune & 4) ? __builtin_readcyclecounter() : 0;
+        // ---- E. recurrent part ------------------------------------------------------------------------------------------
+        if (step > 0) {
+            const char* hb = hbuf + par * TILE + lo;
+            half8_t hb_f[NKS];
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) hb_f[ks] = *(const half8_t*)(hb + ks * 1024);
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks)
+#pragma unroll
+                for (int m = 0; m < MT; ++m) mfma16_av(whh[m][ks], hb_f[ks], acc[m]);
+            mfma_settle_v<MT>(acc);
+        }
+        const long long pcm = (p.tune & 4) ? __builtin_readcyclecounter() : 0;
+        // ---- X. request x_{t+2} into the LDS slot x_{t-1} was consumed from; needed behind the NEXT barrier ----------------
+        if (step + 2 < p.T) x_dma(t + 2 * dt, (step + 2) % 3);
+        half_t ho[MT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) ho[m] = (half_t)lstm_cell(acc[m][0], acc[m][1], acc[m][2], acc[m][3], cst[m]);
+        const long long pcg = (p.tune & 4) ? __builtin_readcyclecounter() : 0;
+        {
+            u16_alias_t* sg = (u16_alias_t*)stage + c * U + q * MT;
+#pragma unroll
+            for (int m = 0; m < MT; ++m) sg[m] = __builtin_bit_cast(unsigned short, ho[m]);
+            if (mover) {
+                const unsigned long long packed = *(const u64_alias_t*)((half_t*)stage + cc * U + part * 4);
+                unsigned long long* dst = (unsigned long long*)(exr + (long)(step & 3) * slot_stride + my_byte);
+                if (fast) *dst = packed;
+                else __hip_atomic_store(dst, packed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                // re-arm my bytes of slot (step+2)&3 (it holds h_{t-2}; see the header)
+                if (step >= 2 && step + 2 < p.T) {
+                    unsigned long long* ra = (unsigned long long*)(exr + (long)((step + 2) & 3) * slot_stride + my_byte);
+                    if (fast) *ra = ~0ull;
+                    else __hip_atomic_store(ra, ~0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                // the layer output proper (next layer's x rows / the linear layer's input)
+                *(unsigned long long*)(p.h + ((long)t * p.N + ring * 16 + cc) * H + slice * U + part * 4) = packed;
+            }
+        }
+        // ---- F. first poll round for h_t ----------------------------------------------------------------------------------
+        if (step + 1 < p.T) {
+            const char* src = exr + (long)(step & 3) * slot_stride;
+            __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, TILE, 0x00020000);
+#pragma unroll
+            for (int kk = 0; kk < KQ; ++kk) {
+                const int ks = wave + 4 * kk;
+                if (EXACT || ks < NKS) hq[kk] = __builtin_amdgcn_raw_buffer_load_b128(rs, ks * 1024 + lo, 0, (int)0x80000010);
+            }
+        }
+        const long long pc3 = (p.tune & 4) ? __builtin_readcyclecounter() : 0;
+        // ---- G. input projection of step t+1 --------------------------------------------------------------------------------
+        x_phase(xbuf + ((step + 1) % 3) * TILE);
+        if (p.tune & 4) {
+            const long long now = __builtin_readcyclecounter();
+            st_bar += pc2 - pc1; st_rec += pc3 - pc2; st_x += now - pc3;
+            st_mf += pcm - pc2; st_gate += pcg - pcm; st_store += pc3 - pcg;
+        }
+    }
+    if ((p.tune & 4) && lane == 0) {
+        long long* st = (long long*)((char*)p.xcc_ws + (((size_t)p.n_rings * NSL * sizeof(int) + 64 + 7) & ~(size_t)7)) + ((long)ring * NSL + slice) * 16;
+        st[0] = __builtin_readcyclecounter() - st_t0;
+        st[1] = st_poll; st[2] = st_rounds; st[3] = st_first_ok; st[4] = st_x; st[5] = st_bar; st[6] = st_rec; st[7] = st_hist;
+        st[8] = 0; st[9] = 0; st[10] = st_mf; st[11] = st_gate; st[12] = st_store;
+        st[13] = (long long)__builtin_amdgcn_s_memrealtime() - st_r0;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // Ring-in-a-workgroup variant ("cta") for narrow layers (H = 64 / 96 / 128, e.g. the `fast` models): all H/U slices
 // of a ring are waves of ONE workgroup, both weight sets are register-resident, and h never leaves the CU on its way
 // to the next step - every wave drops its MT units straight into the LDS tile in B-fragment order, one workgroup
@@ -1348,6 +1610,49 @@ int bh_k_lstm_layer_wg(const void* x, const void* wih_packed, const float* bias,
     BH_LSTM_WG(2, 4) BH_LSTM_WG(4, 4) BH_LSTM_WG(8, 4)
     { BH_REQUIRE(false, "lstm: workgroup-shared kernel has no instance for H=%d", H); }
 #undef BH_LSTM_WG
+    BH_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// Ring-buffer exchange variant of the workgroup-shared kernel (lstm_layer_wgx_kernel). `ex`: 4 * R * (H/32) KiB, armed here
+// with 0xFF when `arm` is set (once per layer: launches of one layer share it, each with its ring offset applied by the caller).
+size_t bh_k_lstm_wgx_ex_bytes(int N, int H) { return (size_t)4 * (N / 16) * (H / 32) * 1024; }
+int bh_k_lstm_layer_wgx(const void* x, const void* wih_packed, const float* bias, const void* whh_packed, void* h_out, void* ex,
+                        int T, int N, int H, int R, int reverse, int* err_flag, hipStream_t stream, int n_rings, int* xcc_ws,
+                        int force_slow, int arm) {
+    using namespace bh;
+    BH_REQUIRE(N % 16 == 0, "lstm: batch must be padded to a multiple of 16 (N=%d)", N);
+    const int U = bh_k_lstm_wg_units(H);
+    BH_REQUIRE(U != 0, "lstm: workgroup-shared kernel does not cover H=%d", H);
+    BH_REQUIRE(x != h_out && ex != nullptr, "lstm: fused layer cannot run in place / missing exchange buffer");
+    int dev = 0, cus = 0;
+    BH_CHECK_HIP(hipGetDevice(&dev));
+    BH_CHECK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    const int nsl = H / U, wpr = nsl / 4;
+    BH_REQUIRE(n_rings > 0 && n_rings <= R, "lstm: n_rings=%d outside 1..%d", n_rings, R);
+    const int rl = (n_rings + 7) / 8;
+    const int grid = 8 * rl * wpr;
+    BH_REQUIRE(grid <= cus, "lstm: %d workgroups must be co-resident but the device has %d CUs; split the batch", grid, cus);
+    BH_REQUIRE(xcc_ws != nullptr, "lstm: missing XCD agreement workspace");
+    BH_CHECK_HIP(hipMemsetAsync(xcc_ws, 0xFF, (size_t)n_rings * nsl * sizeof(int), stream));
+    const int nks = H / 32;
+    if (arm) BH_CHECK_HIP(hipMemsetAsync(ex, 0xFF, (size_t)4 * R * nks * 1024, stream));
+    LstmWgxArgs a{LstmFusedArgs{(const half_t*)x, (const half_t*)wih_packed, bias,
+                                LstmArgs{nullptr, (const half_t*)whh_packed, (half_t*)h_out, T, N, H, n_rings, reverse, err_flag,
+                                         g_max_spins, xcc_ws, force_slow & 1, force_slow >> 8}},
+                  (char*)ex, R};
+    const size_t lds = (size_t)5 * nks * 1024 + 4 * 16 * U * 2;
+#define BH_LSTM_WGX(NKS, MT)                                                                                     \
+    if (nks == NKS && U == 4 * MT) {                                                                             \
+        if (lds > 64 * 1024)                                                                                     \
+            BH_CHECK_HIP(hipFuncSetAttribute((const void*)lstm_layer_wgx_kernel<NKS, MT>,                        \
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));            \
+        hipLaunchKernelGGL((lstm_layer_wgx_kernel<NKS, MT>), dim3(grid), dim3(256), lds, stream, a);              \
+    } else
+    BH_LSTM_WGX(3, 3) BH_LSTM_WGX(6, 3) BH_LSTM_WGX(9, 3) BH_LSTM_WGX(12, 3)
+    BH_LSTM_WGX(2, 4) BH_LSTM_WGX(4, 4) BH_LSTM_WGX(8, 4)
+    { BH_REQUIRE(false, "lstm: workgroup-shared kernel has no instance for H=%d", H); }
+#undef BH_LSTM_WGX
     BH_CHECK_HIP(hipGetLastError());
     return 0;
 }

@@ -86,10 +86,20 @@ __device__ __forceinline__ float q8_cell(float ai, float af, float ag, float ao,
     return (fabsf(hv) <= 1.0f) ? hv : 0.0f;
 }
 
+// One 1 KiB global -> LDS DMA: lane l moves 16 bytes from g (per lane) to lds + 16 l (lds is wave-uniform). The compiler
+// neither counts nor waits for it: the issuing wave covers it with its own s_waitcnt vmcnt(0) before a barrier publishes it.
+__device__ __forceinline__ void dma16_q8(const char* g, char* lds) {
+    const unsigned l = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)(__attribute__((address_space(3))) char*)lds);
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(l), "v"(g) : "memory");
+}
+
 // byte offset of unit u (0 .. 64*NK8) of chunk c inside a ring tile in fragment order
 __device__ __forceinline__ int frag_byte(int u, int c) { return (((u >> 6) * 64 + ((u >> 4) & 3) * 16 + c) << 4) + (u & 15); }
 
-template <int NK8, int MT, int WPS>
+// LAST: this layer also writes fp16 rows (the layer after it is not an 8-bit recurrent layer); DBG: dump the integer sums.
+// Template parameters rather than run-time tests so that the gate arithmetic of a wave's MT units is ONE basic block (the
+// compiler interleaves the transcendentals of the three cells; behind per-unit branches they ran one after the other).
+template <int NK8, int MT, int WPS, bool LAST, bool DBG>
 __global__ __launch_bounds__(256, WPS) void lstm_layer_q8_kernel(LstmQ8Args p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int U = 4 * MT, KQ = (NK8 + 3) / 4, TILE = NK8 * 1024;
@@ -106,8 +116,8 @@ __global__ __launch_bounds__(256, WPS) void lstm_layer_q8_kernel(LstmQ8Args p) {
     if (ring >= p.n_rings) return;                      // whole workgroup (same ring) leaves together
 
     char* hbuf = smem;                                  // [2][NK8][64][16]  B fragments of h_{t-1}
-    char* xbuf = smem + 2 * TILE;                       // [2][NK8][64][16]  B fragments of x_t
-    char* stage = smem + 4 * TILE + wave * (16 * U * 3);   // per wave: [16 chunks][U] bytes + [16][U] halves
+    char* xbuf = smem + 2 * TILE;                       // [3][NK8][64][16]  B fragments of x_t: consumed / landed / landing
+    char* stage = smem + 5 * TILE + wave * (16 * U * 3);   // per wave: [16 chunks][U] bytes + [16][U] halves
 
     int4_t whh[MT][NK8], wih[MT][NK8];
 #pragma unroll
@@ -165,7 +175,7 @@ __global__ __launch_bounds__(256, WPS) void lstm_layer_q8_kernel(LstmQ8Args p) {
     const int cc = lane / PARTS, part = lane - cc * PARTS;
     const int my_byte = frag_byte(slice * U + part * 4, cc);          // inside a ring tile
 
-    uint4_t xq[KQ], xr[KQ], hq[KQ];
+    uint4_t hq[KQ];
     int4_t xacc[MT];
 
     auto x_phase = [&](const char* xb) {
@@ -179,42 +189,39 @@ __global__ __launch_bounds__(256, WPS) void lstm_layer_q8_kernel(LstmQ8Args p) {
 #pragma unroll
             for (int m = 0; m < MT; ++m) xacc[m] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wih[m][ks], bf[ks], xacc[m], 0, 0, 0);
     };
-
-    // ---- prologue: x_0 -> LDS -> input projection of step 0; x_1 landed, x_2 on its way ---------------------------------
-    {
-        const int t1 = p.T > 1 ? t + dt : t, t2 = p.T > 2 ? t + 2 * dt : t;
+    // The x stream never touches registers: each wave moves its share of the k-steps of a tile with LDS-DMA (1 KiB per
+    // instruction, lane l -> LDS base + 16 l, which IS the fragment order), so the compiler has no destination registers to
+    // wait for and cannot put the fetch on the critical path. A wave's DMAs are covered by its own vmcnt(0) ahead of the
+    // barrier that publishes the tile. Shares: the polls of the exchange go w, w+4; the x stream goes 3-w, 7-w, so every
+    // wave moves three KiB per step at H = 384.
+    auto x_dma = [&](int tt, int slot) {
 #pragma unroll
         for (int kk = 0; kk < KQ; ++kk) {
-            const int ks = wave + 4 * kk;
-            if (EXACT || ks < NK8) {
-                *(uint4_t*)(xbuf + ks * 1024 + lo) = *(const uint4_t*)(xptr + (long)t * t_stride + ks * 1024);
-                xq[kk] = *(const uint4_t*)(xptr + (long)t1 * t_stride + ks * 1024);
-                xr[kk] = *(const uint4_t*)(xptr + (long)t2 * t_stride + ks * 1024);
-            }
+            const int ks = (3 - wave) + 4 * kk;
+            if (EXACT || ks < NK8) dma16_q8((const char*)(xptr + (long)tt * t_stride + ks * 1024), xbuf + (slot * NK8 + ks) * 1024);
         }
-#pragma unroll
-        for (int kk = 0; kk < KQ; ++kk) asm volatile("" : "+v"(xq[kk]), "+v"(xr[kk]));    // landed: clean vm counter at loop entry
-    }
+    };
+
+    // ---- prologue: x_0 and x_1 -> LDS, input projection of step 0 -------------------------------------------------------
+    x_dma(t, 0);
+    x_dma(p.T > 1 ? t + dt : t, 1);
+    __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0): the builtin (unlike inline asm) also clears the compiler's own scoreboard
     __syncthreads();
     x_phase(xbuf);
 #pragma unroll
     for (int kk = 0; kk < KQ; ++kk) hq[kk] = uint4_t{0, 0, 0, 0};
 
-    long long st_poll = 0, st_rounds = 0, st_first_ok = 0, st_bar = 0, st_rec = 0, st_x = 0;
+    long long st_poll = 0, st_rounds = 0, st_first_ok = 0, st_bar = 0, st_rec = 0, st_x = 0, st_mf = 0, st_gate = 0;
     const long long st_t0 = __builtin_readcyclecounter();
 
     for (int step = 0; step < p.T; ++step, t += dt) {
         const int par = step & 1;
-        // ---- A. x_{t+1} quarter (in registers since the previous step) -> LDS ----------------------------------------
-#pragma unroll
-        for (int kk = 0; kk < KQ; ++kk) {
-            const int ks = wave + 4 * kk;
-            if (EXACT || ks < NK8) *(uint4_t*)(xbuf + ((par ^ 1) * NK8 + ks) * 1024 + lo) = xq[kk];
-        }
         // ---- B. my quarter of h_{t-1}: round one was issued right after the previous store --------------------------
         const long long pc0 = (p.tune & 4) ? __builtin_readcyclecounter() : 0;
         if (step > 0) {
-            const char* src = exr + (long)((step - 1) & 3) * slot_stride + lo;
+            // wave-uniform descriptor (ring tile of the slot), per-lane offset: a per-lane base would make the compiler wrap
+            // every load in a 64-trip readfirstlane loop
+            const char* src = exr + (long)((step - 1) & 3) * slot_stride;
             __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, TILE, 0x00020000);
             unsigned spins = dead ? p.max_spins : 0u;
             unsigned pend = 0;
@@ -234,7 +241,7 @@ __global__ __launch_bounds__(256, WPS) void lstm_layer_q8_kernel(LstmQ8Args p) {
 #pragma unroll
                 for (int kk = 0; kk < KQ; ++kk)
                     if (pend & (1u << kk))
-                        hq[kk] = __builtin_amdgcn_raw_buffer_load_b128(rs, (wave + 4 * kk) * 1024, 0, (int)0x80000010);
+                        hq[kk] = __builtin_amdgcn_raw_buffer_load_b128(rs, (wave + 4 * kk) * 1024 + lo, 0, (int)0x80000010);
 #pragma unroll
                 for (int kk = 0; kk < KQ; ++kk)
                     if ((pend & (1u << kk)) && !__any(has_sentinel(hq[kk]))) pend &= ~(1u << kk);
@@ -247,30 +254,13 @@ __global__ __launch_bounds__(256, WPS) void lstm_layer_q8_kernel(LstmQ8Args p) {
             }
             if (p.tune & 4) { st_poll += __builtin_readcyclecounter() - pc0; st_rounds += rounds; st_first_ok += (rounds == 1); }
         }
-        // ---- C. rotate the x quarters and request step t+3 (memory-quiet phase before the barrier) -------------------
-        {
-            const int t3 = (step + 3 < p.T) ? t + 3 * dt : t;
-#pragma unroll
-            for (int kk = 0; kk < KQ; ++kk) {
-                const int ks = wave + 4 * kk;
-                xq[kk] = xr[kk];
-                if (EXACT || ks < NK8) xr[kk] = *(const uint4_t*)(xptr + (long)t3 * t_stride + ks * 1024);
-            }
-        }
-        // ---- D. publish both tiles to the workgroup ------------------------------------------------------------------
+        // ---- D. publish h_{t-1} (just written) and x_{t+1} (DMA issued a step ago) to the workgroup. The explicit vmcnt(0)
+        //         covers this wave's share of the x tile and, for the exchange protocol, the re-arm store of the previous
+        //         step: it is complete before this wave publishes anything newer ---------------------------------------
         const long long pc1 = (p.tune & 4) ? __builtin_readcyclecounter() : 0;
+        __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0): the builtin (unlike inline asm) also clears the compiler's own scoreboard
         __syncthreads();
         const long long pc2 = (p.tune & 4) ? __builtin_readcyclecounter() : 0;
-        // ---- R. re-arm my bytes of slot (step+2)&3. It holds h_{t-2}; behind the barrier the workgroup has seen every k-step
-        //         of h_{t-1}, i.e. EVERY wave of the ring has published h_{t-1} and so finished reading h_{t-2} (a wave publishes
-        //         only after its workgroup's barrier, which follows all four quarter polls). The data store into this slot
-        //         follows two steps from now, and the barrier in between waits for this store to complete (vmcnt(0)), so no
-        //         consumer can find the old bytes when it starts polling for h_{t+2} --------------------------------------
-        if (mover && step >= 2 && step + 2 < p.T) {
-            unsigned* dst = (unsigned*)(exr + (long)((step + 2) & 3) * slot_stride + my_byte);
-            if (fast) *(volatile unsigned*)dst = 0x80808080u;
-            else __hip_atomic_store(dst, 0x80808080u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
         // ---- E. recurrent part, gates, publish h_t --------------------------------------------------------------------
         int4_t acc[MT];
 #pragma unroll
@@ -285,7 +275,12 @@ __global__ __launch_bounds__(256, WPS) void lstm_layer_q8_kernel(LstmQ8Args p) {
 #pragma unroll
                 for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_i32_16x16x64_i8(whh[m][ks], bf[ks], acc[m], 0, 0, 0);
         }
-        if (p.dbg != nullptr) {
+        const long long pcm = (p.tune & 4) ? __builtin_readcyclecounter() : 0;
+        // ---- X. request x_{t+2} into the slot x_{t-1} was consumed from; it is needed behind the NEXT barrier. Issued between
+        //         the MFMAs and the gates: older than this step's stores and polls in the memory queue, and behind the
+        //         compiler's own vmcnt(0) at the head of this phase (which would otherwise wait for it) ---------------------
+        if (step + 2 < p.T) x_dma(t + 2 * dt, (step + 2) % 3);
+        if constexpr (DBG) {
 #pragma unroll
             for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -307,41 +302,54 @@ __global__ __launch_bounds__(256, WPS) void lstm_layer_q8_kernel(LstmQ8Args p) {
             const half_t h16 = (half_t)hv;
             const float hq_f = __builtin_rintf(__fmul_rn((float)h16, 127.0f));       // |h16| <= 1 -> |hq| <= 127, never the sentinel
             sg8[m] = (unsigned char)(signed char)(int)hq_f;
-            if (p.h16_out != nullptr) sg16[m] = __builtin_bit_cast(unsigned short, h16);
+            if constexpr (LAST) sg16[m] = __builtin_bit_cast(unsigned short, h16);
         }
+        const long long pcg = (p.tune & 4) ? __builtin_readcyclecounter() : 0;
         if (mover) {
             const unsigned packed = *(const u32a_t*)((const char*)stage + cc * U + part * 4);
             unsigned* dst = (unsigned*)(exr + (long)(step & 3) * slot_stride + my_byte);
-            if (fast) *(volatile unsigned*)dst = packed;                                                  // stays in this XCD's L2
+            if (fast) *dst = packed;                                                                    // stays in this XCD's L2
             else __hip_atomic_store(dst, packed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);               // sc1 write-through
-            if (p.hq_out != nullptr) *(unsigned*)(p.hq_out + (long)t * t_stride + (long)ring * TILE + my_byte) = packed;
-            if (p.h16_out != nullptr) {
+            // ---- R. re-arm my bytes of slot (step+2)&3. It holds h_{t-2}; behind this step's barrier the workgroup has seen
+            //         every k-step of h_{t-1}, i.e. EVERY wave of the ring has published h_{t-1} and so finished reading
+            //         h_{t-2} (a wave publishes only after its workgroup's barrier, which follows all four quarter polls). The
+            //         data store into this slot follows two steps from now; the vmcnt(0) ahead of the next barrier completes
+            //         the re-arm before this wave publishes h_{t+1}, and nobody polls the slot for h_{t+2} before having seen
+            //         everybody's h_{t+1}: no consumer can find the old bytes -------------------------------------------
+            if (step >= 2 && step + 2 < p.T) {
+                unsigned* ra = (unsigned*)(exr + (long)((step + 2) & 3) * slot_stride + my_byte);
+                if (fast) *ra = 0x80808080u;
+                else __hip_atomic_store(ra, 0x80808080u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if (!LAST || p.hq_out != nullptr) *(unsigned*)(p.hq_out + (long)t * t_stride + (long)ring * TILE + my_byte) = packed;
+            if constexpr (LAST) {
                 const unsigned long long h4 = *(const u64a_t*)((const char*)stage + 16 * U + (cc * U + part * 4) * 2);
                 *(unsigned long long*)(p.h16_out + ((long)t * p.N + ring * 16 + cc) * H + slice * U + part * 4) = h4;
             }
         }
         // ---- F. first poll round for h_t goes out now; it is checked after the input projection -----------------------
         if (step + 1 < p.T) {
-            const char* src = exr + (long)(step & 3) * slot_stride + lo;
+            const char* src = exr + (long)(step & 3) * slot_stride;
             __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, TILE, 0x00020000);
 #pragma unroll
             for (int kk = 0; kk < KQ; ++kk) {
                 const int ks = wave + 4 * kk;
-                if (EXACT || ks < NK8) hq[kk] = __builtin_amdgcn_raw_buffer_load_b128(rs, ks * 1024, 0, (int)0x80000010);
+                if (EXACT || ks < NK8) hq[kk] = __builtin_amdgcn_raw_buffer_load_b128(rs, ks * 1024 + lo, 0, (int)0x80000010);
             }
         }
         const long long pc3 = (p.tune & 4) ? __builtin_readcyclecounter() : 0;
-        // ---- G. input projection of step t+1 from the LDS tile published at D ------------------------------------------
-        x_phase(xbuf + (par ^ 1) * TILE);
+        // ---- G. input projection of step t+1 from the x tile published at D --------------------------------------------
+        x_phase(xbuf + ((step + 1) % 3) * TILE);
         if (p.tune & 4) {
             const long long now = __builtin_readcyclecounter();
-            st_bar += pc2 - pc1; st_rec += pc3 - pc2; st_x += now - pc3;
+            st_bar += pc2 - pc1; st_rec += pc3 - pc2; st_x += now - pc3; st_mf += pcm - pc2; st_gate += pcg - pcm;
         }
     }
     if ((p.tune & 4) && lane == 0) {
         long long* st = (long long*)((char*)p.xcc_ws + (((size_t)p.n_rings * NSL * sizeof(int) + 64 + 7) & ~(size_t)7)) + ((long)ring * NSL + slice) * 16;
         st[0] = __builtin_readcyclecounter() - st_t0;
         st[1] = st_poll; st[2] = st_rounds; st[3] = st_first_ok; st[4] = st_x; st[5] = st_bar; st[6] = st_rec;
+        st[7] = st_mf; st[8] = st_gate;
     }
 }
 
@@ -461,7 +469,7 @@ int bh_k_lstm_layer_q8(const void* xq, const void* wih, const void* whh, const f
     BH_CHECK_HIP(hipGetDevice(&dev));
     BH_CHECK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
     const int nsl = H / U, wpr = nsl / 4, nk8 = (H + 63) / 64;
-    const int per_cu = U == 4 ? 3 : 1;
+    const int per_cu = U == 4 ? 3 : (variant == 2 && H == 384) ? 2 : 1;
     const int rl = (n_rings + 7) / 8;
     const int grid = 8 * rl * wpr;
     BH_REQUIRE(grid <= cus * per_cu, "lstm_q8: %d workgroups must be co-resident but the device holds %d; split the batch", grid, cus * per_cu);
@@ -470,16 +478,25 @@ int bh_k_lstm_layer_q8(const void* xq, const void* wih, const void* whh, const f
     const size_t tile = (size_t)nk8 * 1024;
     LstmQ8Args a{(const int8_t*)xq, (int8_t*)hq_out, (half_t*)h16_out, (int8_t*)ex, (const int8_t*)wih, (const int8_t*)whh, sx, sh, bias,
                  T, N, H, R, n_rings, reverse, err_flag, max_spins, xcc_ws, flags & 1, flags >> 8, dbg};
-    const size_t lds = 4 * tile + 4 * (size_t)(16 * U * 3);
-#define BH_Q8(NK8, MT, WPS)                                                                                              \
-    if (nk8 == NK8 && U == 4 * MT) {                                                                                     \
+    const size_t lds = 5 * tile + 4 * (size_t)(16 * U * 3);
+    const bool last = h16_out != nullptr;
+    BH_REQUIRE(last || hq_out != nullptr, "lstm_q8: no output buffer");
+#define BH_Q8_LAUNCH(NK8, MT, WPS, LAST, DBG)                                                                            \
+    do {                                                                                                                 \
         if (lds > 64 * 1024)                                                                                             \
-            BH_CHECK_HIP(hipFuncSetAttribute((const void*)lstm_layer_q8_kernel<NK8, MT, WPS>,                            \
+            BH_CHECK_HIP(hipFuncSetAttribute((const void*)lstm_layer_q8_kernel<NK8, MT, WPS, LAST, DBG>,                 \
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                    \
-        hipLaunchKernelGGL((lstm_layer_q8_kernel<NK8, MT, WPS>), dim3(grid), dim3(256), lds, stream, a);                  \
+        hipLaunchKernelGGL((lstm_layer_q8_kernel<NK8, MT, WPS, LAST, DBG>), dim3(grid), dim3(256), lds, stream, a);       \
+    } while (0)
+#define BH_Q8(NK8, MT, WPS)                                                                                              \
+    if (nk8 == NK8 && U == 4 * MT && per_cu == WPS) {                                                                                  \
+        if (dbg) BH_Q8_LAUNCH(NK8, MT, WPS, true, true);                                                                 \
+        else if (last) BH_Q8_LAUNCH(NK8, MT, WPS, true, false);                                                          \
+        else BH_Q8_LAUNCH(NK8, MT, WPS, false, false);                                                                   \
     } else
-    BH_Q8(6, 3, 1) BH_Q8(6, 1, 3) BH_Q8(2, 3, 1) BH_Q8(3, 3, 1) BH_Q8(5, 3, 1) BH_Q8(1, 4, 1) BH_Q8(2, 4, 1) BH_Q8(4, 4, 1) BH_Q8(8, 4, 1)
+    BH_Q8(6, 3, 1) BH_Q8(6, 3, 2) BH_Q8(6, 1, 3) BH_Q8(2, 3, 1) BH_Q8(3, 3, 1) BH_Q8(5, 3, 1) BH_Q8(1, 4, 1) BH_Q8(2, 4, 1) BH_Q8(4, 4, 1) BH_Q8(8, 4, 1)
     { BH_REQUIRE(false, "lstm_q8: no kernel instance for H=%d", H); }
+#undef BH_Q8_LAUNCH
 #undef BH_Q8
     BH_CHECK_HIP(hipGetLastError());
     return 0;

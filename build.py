@@ -21,7 +21,9 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-u
          "-I" + os.path.join(ROOT, "include")]
 # signal.hip reproduces NumPy's arithmetic operation by operation: no fused multiply-adds there (hipcc's default
 # -ffp-contract=fast ignores the in-source pragma)
-EXTRA_FLAGS = {"signal.hip": ["-ffp-contract=off"]}
+# lstm_q8.hip: the pre-activation of the 8-bit recurrent path is DEFINED operation by operation (oracle/lstm_q8_ref.py); with
+# contraction on, the compiler fused different multiply-add pairs in different template instances
+EXTRA_FLAGS = {"signal.hip": ["-ffp-contract=off"], "lstm_q8.hip": ["-ffp-contract=off"]}
 
 
 def _newer(dst, srcs):

@@ -115,6 +115,8 @@ int bh_encoder_output_shape(const bh_encoder_t* enc, int L, int* T, int* C, int*
 int bh_encoder_forward(bh_encoder_t* enc, const void* signal, int N, int L, void* scores, void* stream);
 /* one text line per layer naming the kernels the engine launches for it (measurement / logging) */
 int bh_encoder_describe(const bh_encoder_t* enc, char* buf, size_t bytes);
+/* "lstm_exchange" (1 default: the workgroup-shared fp16 recurrent kernel hands h_t over through a small L2-resident ring
+ * buffer and writes the output tensor separately; 0: through the sentinel-filled output tensor as in round 1). */
 /* tuning / test options (results never change): "lstm_fused" (3 default: narrowest applicable fused kernel; 2, 1, 0 = older
  * variants down to projection-by-GEMM), "lstm_force_slow" (0/1: write-through exchange), "lstm_wide" (1/0), "lstm_prefill"
  * (1 default: sentinel fill of the next recurrent layer's buffer on a side stream), "attn_ring" (1/0), "lstm_tune" (bit mask) */
@@ -191,7 +193,9 @@ int bh_lstm_q8_layer(const void* x, float bound, const float* w_ih, const float*
  *   "conv_ws": 1 (default) = weight-stationary kernel for the 384-channel / 19-tap convolution, 0 = generic implicit GEMM.
  *   "gemm_path": 0 auto (default), 1 = register-staged 128x128x64 kernel only, 2 = never the persistent 256x256x64 kernel.
  *   "lstm_q8_variant": geometry of the 8-bit recurrent kernel chosen at bh_encoder_create: 0 (default) = 12 / 16 units per wave,
- *                one workgroup per CU; 1 = 4 units per wave, three workgroups per CU (hidden size 384 only).
+ *                one workgroup per CU; 1 = 4 units per wave, three workgroups per CU; 2 = 12 units per wave compiled for two
+ *                workgroups per CU, so that the recurrent kernels of two engines (two batches in flight) share every CU and each
+ *                hides the other's exchange round trip (both: hidden size 384 only).
  *   "lstm_max_spins": bound of the recurrent kernels' exchange spin loops (default 1000000; < 0 restores it). Tests lower it
  *                to provoke the timeout path (bh_encoder_error_flag / bh_encoder_check). */
 int bh_set_option(const char* name, int value);

@@ -5,7 +5,8 @@
 2. the four BASELINE configurations at FULL batch x chunk size: >= 4 chunks of the full batch are compared with the fp32
    oracle (scores) and the HIP decode of the HIP scores with oracle/crf_oracle.c (sequence / moves bit-exact, q < 1e-3).
 
-The measured errors are written to gpurun_out/parity_<name>.json; the bounds below are <= 5x what was measured on MI355X.
+The measured errors are written to gpurun_out/parity_<name>.json (copies of round 2: profiles/r02_parity.json); the bounds
+below are <= 5x what was measured on MI355X.
 """
 import copy
 import glob
@@ -62,12 +63,13 @@ def _oracle_scores(model, rows):
 
 # ---------------------------------------------------------------------------------------------------------------
 # 1. every in-tree config of the reference, small batch
-SMALL = {   # chunk samples (multiple of the stride), oracle tolerance (max, mean) on scores in [-5, 5]
-    "dna_r10.4.1@v4.0.toml": (1500, 3e-2, 3e-3),
-    "dna_r10.4.1@v4.3.toml": (1800, 3e-2, 3e-3),
-    "dna_r10.4.1@v5.0.toml": (2400, 1e-1, 1e-2),
-    "dna_r9.4.1@v3.1.toml": (1500, 3e-2, 3e-3),
-    "dna_r9.4.1@v3.toml": (1500, 3e-2, 3e-3),
+SMALL = {   # chunk samples (multiple of the stride), bound on (max, mean) |HIP - fp32 oracle| relative to max(1, range / 5):
+            # <= 5x the errors measured on MI355X (gpurun_out/parity_small_*.json of round 2, quoted behind each line)
+    "dna_r10.4.1@v4.0.toml": (1500, 6e-3, 9e-4),      # 1.3e-3, 1.7e-4
+    "dna_r10.4.1@v4.3.toml": (1800, 1.2e-2, 1.3e-3),  # 2.5e-3, 2.6e-4
+    "dna_r10.4.1@v5.0.toml": (2400, 4e-2, 6e-3),      # 8.0e-3, 1.3e-3 (0.086 / 0.0134 on a score range of 53)
+    "dna_r9.4.1@v3.1.toml": (1500, 3e-2, 4.5e-3),     # 6.3e-3, 8.9e-4
+    "dna_r9.4.1@v3.toml": (1500, 3e-2, 4.5e-3),       # 6.5e-3, 8.9e-4
 }
 
 
@@ -89,7 +91,7 @@ def test_reference_config_matches_oracle_small(path):
         assert got.shape == want.shape
         d = (got - want).abs()
         _record("small_" + name, max=d.max().item(), mean=d.mean().item())
-        assert d.max().item() < 5e-2 and d.mean().item() < 5e-3, (d.max().item(), d.mean().item())
+        assert d.max().item() < 2.5e-3 and d.mean().item() < 1.3e-3, (d.max().item(), d.mean().item())      # measured 5.1e-4, 2.5e-4
         return
     L, tol_max, tol_mean = SMALL[name]
     _head_gain_(model, 8.0)
@@ -161,13 +163,13 @@ def _full_size(name, model, batch, chunk, tol_max, tol_mean, rna=False):
 
 def test_full_size_fast_512x10000():
     model = synthetic.make_model("fast", batchsize=512, chunksize=10000)
-    sc = _full_size("fast", model, 512, 10000, 3e-2, 3e-3)
+    sc = _full_size("fast", model, 512, 10000, 2.1e-2, 3e-3)         # measured max 4.3e-3, mean 6.0e-4
     assert sc.shape == (512, 1667, 256)
 
 
 def test_full_size_hac_512x10000():
     model = synthetic.make_model("hac", batchsize=512, chunksize=10000)
-    sc = _full_size("hac", model, 512, 10000, 3e-2, 3e-3)
+    sc = _full_size("hac", model, 512, 10000, 2.4e-2, 3e-3)          # measured max 4.9e-3, mean 6.0e-4
     assert sc.shape == (512, 1667, 1024)
 
 
@@ -178,7 +180,7 @@ def test_full_size_sup_v5_transformer_256x12000():
     model = util.load_symbol(cfg, "Model")(cfg).eval()
     synthetic.randomise_batchnorm_(model)
     _head_gain_(model, 4.0)
-    sc = _full_size("sup_v5", model, 256, 12000, 1e-1, 1e-2)
+    sc = _full_size("sup_v5", model, 256, 12000, 4.5e-2, 6e-3)       # measured 0.049 / 0.0067 on a score range of 27 (x 5 / 27)
     assert sc.shape == (256, 2000, 4096)
 
 
@@ -189,5 +191,5 @@ def test_full_size_sup_lstm_v43_256x20000_rna():
     model = util.load_symbol(cfg, "Model")(cfg).eval()
     synthetic.randomise_batchnorm_(model)
     _head_gain_(model, 24.0)
-    sc = _full_size("sup_lstm_v43", model, 256, 20000, 3e-2, 3e-3, rna=True)
+    sc = _full_size("sup_lstm_v43", model, 256, 20000, 2.5e-2, 3.2e-3, rna=True)    # measured max 5.2e-3, mean 6.5e-4
     assert sc.shape == (256, 3334, 4096)

@@ -9,8 +9,10 @@ from oracle import crf_ref, nn_ref
 
 pytestmark = pytest.mark.gpu
 
-# fp16 activations / fp32 accumulation vs the fp32 CPU reference; scores live in [-5, 5] (fp16 ulp 4e-3)
-TOL_MAX, TOL_MEAN = 6e-2, 6e-3
+# fp16 activations / fp32 accumulation vs the fp32 CPU reference; scores live in [-5, 5] (fp16 ulp 4e-3).
+# <= 5x the largest error measured on MI355X over the fixtures and the full-size BASELINE runs (max 4.9e-3, mean 6.0e-4:
+# tests/test_gpu_configs.py, profiles/r02_parity.json)
+TOL_MAX, TOL_MEAN = 2.4e-2, 3e-3
 
 
 def _run(name, batch_pad=None):
@@ -197,15 +199,18 @@ def test_workgroup_shared_lstm_kernel_widths(H, sl):
     with torch.no_grad():
         want = nn_ref.forward(model, x.float(), expand_blanks=False).permute(1, 0, 2)
     outs = {}
-    for fused in (3, 2, 1, -2):
+    for fused in (3, 2, 1, -2, -3):
         enc = HipEncoder(model, batchsize=21, chunksize=900)
-        enc.set_option("lstm_fused", abs(fused))
-        if fused < 0:
+        enc.set_option("lstm_fused", 2 if fused < 0 else fused)
+        if fused == -2:
             enc.set_option("lstm_prefill", 0)
+        if fused <= -2:
+            enc.set_option("lstm_exchange", 0)         # round-1 hand-off through the sentinel-filled output tensor
         outs[fused] = enc(x.cuda()).cpu().float()
         enc.check()
         assert (outs[fused] - want).abs().max().item() < TOL_MAX, fused
     assert torch.equal(outs[2], outs[1]) and torch.equal(outs[3], outs[1]) and torch.equal(outs[-2], outs[2])
+    assert torch.equal(outs[-3], outs[2])              # ring-buffer exchange (default) == exchange through the output tensor
 
 
 @pytest.mark.parametrize("H,batch", [(768, 3), (1024, 37), (640, 33)])
@@ -244,11 +249,12 @@ def test_full_size_hac_encoder_kernel_variants_bit_identical():
     model = synthetic.make_model("hac", batchsize=512, chunksize=10000)
     x = torch.randn(512, 1, 10000, generator=torch.Generator().manual_seed(25)).half().cuda()
     outs = []
-    for fused, slow, prefill in ((3, 0, 1), (1, 0, 1), (3, 1, 1), (3, 0, 0)):
+    for fused, slow, prefill, exch in ((3, 0, 1, 1), (1, 0, 1, 1), (3, 1, 1, 1), (3, 0, 0, 0), (3, 0, 1, 0)):
         enc = HipEncoder(model.encoder, batchsize=512, chunksize=10000)
         enc.set_option("lstm_fused", fused)
         enc.set_option("lstm_force_slow", slow)
         enc.set_option("lstm_prefill", prefill)     # 0: sentinel fill inline instead of beside the previous layer's kernel
+        enc.set_option("lstm_exchange", exch)       # 1 (default): ring-buffer hand-off, 0: through the output tensor (round 1)
         for _ in range(2):                             # twice: the side-stream fill must also be ordered across calls
             out = enc(x)
         outs.append(out)
@@ -259,3 +265,4 @@ def test_full_size_hac_encoder_kernel_variants_bit_identical():
     assert torch.equal(outs[0], outs[1])
     assert torch.equal(outs[0], outs[2])
     assert torch.equal(outs[0], outs[3])
+    assert torch.equal(outs[0], outs[4])

@@ -34,4 +34,5 @@ tot, poll, rounds, first, xph, bar, rec = [st[..., i].astype(float) for i in ran
 print("cycles/step total mean %.0f (min %.0f max %.0f)" % (tot.mean() / T, tot.min() / T, tot.max() / T))
 print("cycles/step: poll check + re-poll %.0f | barrier %.0f | recurrent + gates + store + poll issue %.0f | input projection %.0f"
       % (poll.mean() / T, bar.mean() / T, rec.mean() / T, xph.mean() / T))
+print("cycles/step inside the recurrent part: LDS reads + h-MFMAs %.0f | gates + transpose %.0f" % (st[..., 7].astype(float).mean() / T, st[..., 8].astype(float).mean() / T))
 print("poll rounds/step mean %.2f; first round already complete in %.1f%% of steps" % (rounds.mean() / T, 100 * first.mean() / T))

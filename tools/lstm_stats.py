@@ -12,6 +12,9 @@ model(sig)
 enc = model._hip
 mode = int(sys.argv[1]) if len(sys.argv) > 1 else 2        # lstm_fused option: 2 = workgroup-shared, 1 = per-wave
 enc.set_option("lstm_fused", mode)
+if len(sys.argv) > 2:
+    enc.set_option("lstm_exchange", int(sys.argv[2]))         # 1 (default): ring-buffer hand-off, 0: through the output tensor
+print(enc.describe().splitlines()[4])
 enc.set_option("lstm_tune", 4)
 model(sig); torch.cuda.synchronize(); enc.check()
 rings, nsl, T = 32, (32 if mode >= 2 else 24), 1667
