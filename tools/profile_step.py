@@ -20,13 +20,14 @@ ap.add_argument("--decoder", default="beam")
 ap.add_argument("--steps", type=int, default=3)
 ap.add_argument("--batch", type=int, default=512)
 ap.add_argument("--chunk", type=int, default=10000)
+ap.add_argument("--quantize", action="store_true")
 a = ap.parse_args()
 if a.model == "sup":
     a.batch, a.chunk = (256, 12000) if (a.batch, a.chunk) == (512, 10000) else (a.batch, a.chunk)
     model = synthetic.make_transformer_model(head_gain=4.0, batchsize=a.batch, chunksize=a.chunk)
 else:
     model = synthetic.make_model(a.model, batchsize=a.batch, chunksize=a.chunk)
-model.use_koi(batchsize=a.batch, chunksize=a.chunk, quantize=False)
+model.use_koi(batchsize=a.batch, chunksize=a.chunk, quantize=a.quantize)
 model = model.half().cuda()
 sig = torch.randn(a.batch, 1, a.chunk, device="cuda").half()
 for _ in range(a.steps):
