@@ -90,6 +90,9 @@ def main(args, argv=None):
         parallel.init("gloo")              # host objects only: there is no device collective on this path
     util.init(args.seed, args.device)
     util.limit_host_threads(8)       # host work is small copies; never out-spin a container's CPU quota
+    if args.lanes > 1 and args.quantize:
+        from bonito_amd import decode as _decode
+        _decode.set_option("lstm_q8_variant", 2)       # 8-bit recurrent kernels compiled for two workgroups per CU
     log = sys.stderr.write if rank == 0 else (lambda _msg: None)
     try:
         reader = Reader(args.reads_directory, args.recursive)
@@ -119,10 +122,11 @@ def main(args, argv=None):
         results = basecall_raw(model, reads, reverse=args.revcomp, rna=args.rna, batchsize=bc["batchsize"],
                                chunksize=bc["chunksize"], overlap=bc["overlap"], scaling_strategy=model.config.get("scaling"),
                                norm_params=model.config.get("standardisation") if pa else model.config.get("normalisation"),
-                               do_trim=not args.no_trim)
+                               do_trim=not args.no_trim, lanes=args.lanes)
     else:
+        kw = {"lanes": args.lanes} if args.lanes > 1 and "lanes" in basecall.__code__.co_varnames else {}
         results = basecall(model, reads, reverse=args.revcomp, rna=args.rna, batchsize=bc["batchsize"],
-                           chunksize=bc["chunksize"], overlap=bc["overlap"])
+                           chunksize=bc["chunksize"], overlap=bc["overlap"], **kw)
     mode = "sam" if args.sam else ("fasta" if args.fasta else "fastq")
     t0 = perf_counter()
     if world > 1:
@@ -184,6 +188,9 @@ def argparser():
     parser.add_argument("--chunksize", default=None, type=int)
     parser.add_argument("--batchsize", default=None, type=int)
     parser.add_argument("--max-reads", default=0, type=int)
+    parser.add_argument("--lanes", default=1, type=int,
+                        help="batches in flight in the encoder (engine replicas per GPU); 2 pays off with --quantize, whose "
+                             "recurrent kernels of two lanes share every CU")
     parser.add_argument("--min-qscore", default=0.0, type=float)
     parser.add_argument("--sam", action="store_true", default=False, help="write unaligned SAM instead of FASTQ")
     parser.add_argument("--fasta", action="store_true", default=False)

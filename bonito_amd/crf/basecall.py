@@ -98,29 +98,46 @@ class _Pipeline:
     same overlap from its per-stage ThreadIterators (bonito/crf/basecall.py:63-82) with koi returning CPU
     tensors; here the split is explicit because both halves are ours."""
 
-    def __init__(self, model, decoder="beam", reverse=False, **decode_kw):
+    def __init__(self, model, decoder="beam", reverse=False, lanes=1, **decode_kw):
         self.model, self.mode, self.kw, self.reverse = model, decoder, decode_kw, reverse
         self.device = next(model.parameters()).device
-        self.enc_stream = torch.cuda.Stream(self.device)
+        # `lanes` batches in flight in the encoder: lane k has its own engine replica (same weights, own workspace) and its own
+        # stream, batches go round-robin. With the 8-bit recurrent kernels compiled for two workgroups per CU
+        # (bh_set_option "lstm_q8_variant" 2) the persistent kernels of two lanes share every CU and each hides the other's
+        # exchange round trip (hac-sized model: 18.8 -> 15.7 ms per batch); the fp16 kernels fill the register file and gain nothing.
+        self.lanes = max(1, int(lanes))
+        self.enc_streams = [torch.cuda.Stream(self.device) for _ in range(self.lanes)]
+        self.replicas = [None] * self.lanes            # lane 0 runs the model's own engine
+        self.n_encoded = 0
         self.dec_stream = torch.cuda.Stream(self.device)
         self.copy_stream = torch.cuda.Stream(self.device)
         self.decoders = {}
 
     def check_engine(self):
-        eng = getattr(self.model, "_hip", None)
-        if eng is not None:
-            eng.poll()
+        for eng in [getattr(self.model, "_hip", None)] + self.replicas[1:]:
+            if eng is not None:
+                eng.poll()
+
+    def _forward(self, lane, x):
+        if lane == 0:
+            return self.model(x)
+        if self.replicas[lane] is None:
+            self.replicas[lane] = self.model.engine_replica(x)
+        return self.replicas[lane](x)
 
     def encode(self, batch):
+        lane = self.n_encoded % self.lanes
+        self.n_encoded += 1
+        enc_stream = self.enc_streams[lane]
         if batch.is_cuda:                 # produced on the device (basecall_raw): no copy, just order the streams
-            with torch.inference_mode(), torch.cuda.stream(self.enc_stream):
-                self.enc_stream.wait_stream(torch.cuda.default_stream(self.device))
-                batch.record_stream(self.enc_stream)
-                scores = self.model(batch)
+            with torch.inference_mode(), torch.cuda.stream(enc_stream):
+                enc_stream.wait_stream(torch.cuda.default_stream(self.device))
+                batch.record_stream(enc_stream)
+                scores = self._forward(lane, batch)
                 if self.reverse:
                     scores = self.model.seqdist.reverse_complement(scores)
                 ready = torch.cuda.Event()
-                ready.record(self.enc_stream)
+                ready.record(enc_stream)
             return scores, ready
         # H2D on its own stream, waited for on the host: the (recycled, pinned) batch buffer is free again when this
         # method returns, and the copy never queues behind the previous batch's encoder.
@@ -129,14 +146,14 @@ class _Pipeline:
             copied = torch.cuda.Event()
             copied.record(self.copy_stream)
         copied.synchronize()
-        with torch.inference_mode(), torch.cuda.stream(self.enc_stream):
-            self.enc_stream.wait_event(copied)
-            dev_batch.record_stream(self.enc_stream)
-            scores = self.model(dev_batch)
+        with torch.inference_mode(), torch.cuda.stream(enc_stream):
+            enc_stream.wait_event(copied)
+            dev_batch.record_stream(enc_stream)
+            scores = self._forward(lane, dev_batch)
             if self.reverse:
                 scores = self.model.seqdist.reverse_complement(scores)
             ready = torch.cuda.Event()
-            ready.record(self.enc_stream)
+            ready.record(enc_stream)
         return scores, ready
 
     def decode(self, scores, ready):
@@ -242,9 +259,10 @@ def chunk_batches(reads, chunksize, overlap, batchsize, pin=False, nbuf=4):
         yield tuple(keys), bufs[cur][:pos]
 
 
-def basecall(model, reads, chunksize=4000, overlap=100, batchsize=32, reverse=False, rna=False, decoder="beam"):
-    """Basecalls a set of reads: yields (read, {sequence, qstring, moves, stride})."""
-    pipe = _Pipeline(model, decoder=decoder, reverse=reverse)
+def basecall(model, reads, chunksize=4000, overlap=100, batchsize=32, reverse=False, rna=False, decoder="beam", lanes=1):
+    """Basecalls a set of reads: yields (read, {sequence, qstring, moves, stride}). `lanes`: batches in flight in the encoder
+    (engine replicas); results are identical for any value."""
+    pipe = _Pipeline(model, decoder=decoder, reverse=reverse, lanes=lanes)
     # up to 4 batches are in flight behind the generator (three single-slot queues + the consumer): recycle after 8
     batches = thread_iter(chunk_batches(reads, chunksize, overlap, batchsize, pin=torch.cuda.is_available(), nbuf=8))
     encoded = thread_iter((keys, pipe.encode(batch)) for keys, batch in batches)
@@ -315,10 +333,10 @@ def raw_chunk_batches(reads, chunksize, overlap, batchsize, device, group_sample
 
 
 def basecall_raw(model, reads, chunksize=4000, overlap=100, batchsize=32, reverse=False, rna=False, decoder="beam",
-                 scaling_strategy=None, norm_params=None, do_trim=True):
+                 scaling_strategy=None, norm_params=None, do_trim=True, lanes=1):
     """`basecall` for raw int16 reads (`.raw`, `.scaling`, `.offset`): the signal pre-processing of reader.Read runs on the
     device. Same results as ``basecall(model, [reader.Read(...) ...])`` on the same reads (tests compare them)."""
-    pipe = _Pipeline(model, decoder=decoder, reverse=reverse)
+    pipe = _Pipeline(model, decoder=decoder, reverse=reverse, lanes=lanes)
     device = next(model.parameters()).device
     batches = thread_iter(raw_chunk_batches(reads, chunksize, overlap, batchsize, device, scaling_strategy=scaling_strategy,
                                             norm_params=norm_params, do_trim=do_trim))

@@ -165,6 +165,12 @@ class SeqdistModel(Module):
                                    quantize=getattr(self, "_quantize", False))
         return self._hip
 
+    def engine_replica(self, x):
+        """A second, independent engine over the same weights (own workspace): the basecaller keeps `lanes` batches in flight,
+        one engine each (crf/basecall.py). Built for the geometry of the model's own engine."""
+        eng = self._engine(x)
+        return HipEncoder(self.encoder, eng.max_batch, eng.max_chunk, device=eng.device, quantize=getattr(self, "_quantize", False))
+
     def forward(self, x, *args):
         """x: cuda fp16 [N,1,L] -> scores fp16 [N, T, 4^(state_len+1)] (koi layout, contiguous)."""
         if not x.is_cuda:

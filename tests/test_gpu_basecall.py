@@ -403,3 +403,20 @@ def test_engine_is_rebuilt_after_weights_change():
     model = model.apply(fuse_bn_)
     c = model(x)
     assert (c.float() - b.float()).abs().max().item() < 2e-2        # folding changes rounding only
+
+
+def test_basecall_lanes_give_identical_results():
+    """`lanes` engine replicas (batches in flight) never change what is called; with quantize=True the lanes run the 8-bit
+    recurrent kernels (here the hac-shaped model at a small batch)."""
+    from bonito_amd import synthetic
+    rng = np.random.default_rng(4)
+    reads = _reads(rng, [7000] * 30)
+    for quantize in (False, True):
+        model = synthetic.make_model("hac", batchsize=32, chunksize=3000)
+        model.use_koi(batchsize=32, chunksize=3000, quantize=quantize)
+        model = model.half().to("cuda")
+        outs = []
+        for lanes in (1, 2, 3):
+            outs.append([(r.read_id, res["sequence"], res["qstring"], res["moves"].tobytes())
+                         for r, res in crf_basecall_fn(model, iter(reads), chunksize=3000, overlap=300, batchsize=32, lanes=lanes)])
+        assert outs[0] == outs[1] == outs[2] and len(outs[0]) == 30
