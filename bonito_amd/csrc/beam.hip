@@ -352,6 +352,10 @@ struct BeamArgs {
     long long* dbg;        // optional [N][8] per-section cycle counters (BH_BEAM_DEBUG)
     float inv_bin;         // 256 / cut: selection histogram bins per unit of key; 0 puts every key into one bin, which
                            // turns the selection into the plain radix search (bh_set_option("beam_select", 1))
+    // fused forward / posterior scan (FUSE instantiations): what crf_forward_post_kernel reads and writes
+    const double* Bcum;    // [N][T+1]
+    const double* logZ;    // [N]
+    float* P;              // [N][T][4]
 };
 
 constexpr int BTB = 4;     // steps per staged block; two blocks are resident (the next one streams in under the current one)
@@ -603,25 +607,117 @@ __host__ __device__ constexpr int beam_wave_lds() {
 }
 constexpr int BEAM_TAB_LDS = (BH_LSE_TABLE_SIZE + 2) * 4;
 
-template <int STATE_LEN, int CPW, bool DBG>
-__global__ __launch_bounds__(64 * CPW) __attribute__((amdgpu_waves_per_eu(1, 8))) void beam_kernel(BeamArgs p) {
+// LDS of one fused scan wave: alpha~ ping-pong [2][S]
+template <int STATE_LEN>
+__host__ __device__ constexpr int scan_wave_lds() { return 2 * (1 << (2 * STATE_LEN)) * 4 + 64; }
+
+// The forward / posterior scan of crf_forward_post_kernel as ONE wave beside the beam wave of the same chunk (FUSE): it reads
+// the score rows and guide rows from the LDS blocks the beam wave stages anyway, so the score tensor and the guide are read
+// from HBM once for both (2.63 GB of 7.9 GB per hac batch gone, one kernel and its launch gone). Lane l owns the states
+// [l * SPL, (l + 1) * SPL), SPL = S / 64: alpha~ lives in a private LDS ping-pong (one wave: LDS operations complete in issue
+// order, no barrier inside a step), every state runs exactly the recurrence of crf_forward_post_kernel (same operations in the
+// same order -> the same alpha~), only the order of the fp32 class sums differs (q-scores are a tolerance-level output).
+template <int STATE_LEN>
+__device__ __forceinline__ void scan_step(const BeamArgs& p, const half_t* row, const float* bnext, float* ap, float* an, const float* tab,
+                                          int lane, double& A, double lz, double Bt, float* Pt) {
+    constexpr int S = 1 << (2 * STATE_LEN);
+    constexpr int SPL = S >= 64 ? S / 64 : 1, q = S >> 2;
+    const bool active = S >= 64 || lane < S;
+    const float ref = ap[0];
+    float acc[SPL];
+#pragma unroll
+    for (int k = 0; k < SPL; ++k) {
+        const int j = active ? lane * SPL + k : 0;
+        float a = p.blank + (ap[j] - ref);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) a = lse2_tab(a, (float)row[j * 4 + r] + (ap[r * q + (j >> 2)] - ref), tab);
+        acc[k] = a;
+    }
+    if (active) {
+#pragma unroll
+        for (int k = 0; k < SPL; ++k) an[lane * SPL + k] = acc[k];
+    }
+    A += (double)ref;
+    const float now0 = an[0];
+    const double norm = lz - (A + (double)now0) - Bt;
+    float cls[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < SPL; ++k) {
+        const int j = active ? lane * SPL + k : 0;
+        const float pv = active ? __expf((float)((double)(acc[k] - now0) + (double)bnext[j] - norm)) : 0.0f;
+        if (SPL >= 4) cls[k & 3] += pv;         // a lane's states cover the four classes evenly
+        else cls[0] = pv;                       // SPL == 1: the class is lane & 3
+    }
+    if (SPL >= 4) {
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+            float v = cls[x];
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+            cls[x] = v;
+        }
+        if (lane < 4) Pt[lane] = lane == 0 ? cls[0] : lane == 1 ? cls[1] : lane == 2 ? cls[2] : cls[3];
+    } else {
+        float v = cls[0];
+        v += dpp_f<0x124, 0xF>(v);     // row_ror:4
+        v += dpp_f<0x128, 0xF>(v);     // row_ror:8
+        v += __shfl_xor(v, 16);
+        v += __shfl_xor(v, 32);
+        if (lane < 4) Pt[lane] = v;
+    }
+}
+
+template <int STATE_LEN, int CPW, bool DBG, bool FUSE = false>
+__global__ __launch_bounds__(64 * CPW * (FUSE ? 2 : 1)) __attribute__((amdgpu_waves_per_eu(1, 8))) void beam_kernel(BeamArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int S = 1 << (2 * STATE_LEN);
     constexpr int sh = 2 * (STATE_LEN - 1);
+    constexpr int NTHR = 64 * CPW * (FUSE ? 2 : 1);
     static_assert(NBK == HBINS, "the selection histogram reuses the bucket fill counters");
     static_assert(beam_wave_lds<STATE_LEN>() % 16 == 0 && BEAM_TAB_LDS % 16 == 0, "LDS regions must stay 16-byte aligned");
     const int T = p.T, W = p.W;
     const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wave_all = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const bool scan_role = FUSE && wave_all >= CPW;
+    const int wave = scan_role ? wave_all - CPW : wave_all;      // chunk slot inside the workgroup
     const int n = blockIdx.x * CPW + wave;
     // LDS carve
     float* tab = (float*)smem;                           // lse table (shared by the waves)
-    for (int i = threadIdx.x; i < BH_LSE_TABLE_SIZE; i += 64 * CPW) tab[i] = g_lse_tab[i];
+    for (int i = threadIdx.x; i < BH_LSE_TABLE_SIZE; i += NTHR) tab[i] = g_lse_tab[i];
     __syncthreads();
     if (n >= p.N) return;
     char* mine = smem + BEAM_TAB_LDS + wave * beam_wave_lds<STATE_LEN>();
     half_t* st_sc = (half_t*)mine;                       // [2][BTB][4S]
     float* st_b = (float*)(st_sc + 2 * BTB * 4 * S);     // [2][BTB][S]
+    if (scan_role) {
+        // ---- forward / posterior scan over the blocks the beam wave stages ---------------------------------------------
+        float* al = (float*)(smem + BEAM_TAB_LDS + CPW * beam_wave_lds<STATE_LEN>() + wave * scan_wave_lds<STATE_LEN>());
+        constexpr int SPLz = S >= 64 ? S / 64 : 1;
+        if (S >= 64 || lane < S)
+            for (int k = 0; k < SPLz; ++k) al[lane * SPLz + k] = 0.0f;
+        const double* Bn = p.Bcum + (long)n * (T + 1);
+        const double lz = p.logZ[n];
+        float* Pn = p.P + (long)n * T * 4;
+        double A = 0.0;
+        int cb = 0;
+        for (int tb0 = 0, blk = 0; tb0 < T; tb0 += BTB, ++blk) {
+            const int nsteps = min(BTB, T - tb0);
+            const double Bmine = lane < nsteps ? Bn[tb0 + lane] : 0.0;       // one fp64 per step, fetched once per block
+            __syncthreads();                                                   // block `blk` has landed (beam wave waited for its DMA)
+            const half_t* blk_sc = st_sc + (blk & 1) * BTB * 4 * S;
+            const float* blk_b = st_b + (blk & 1) * BTB * S;
+            for (int u = 0; u < nsteps; ++u) {
+                const unsigned long long bb = (unsigned long long)__double_as_longlong(Bmine);
+                const unsigned lo32 = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)bb, u);
+                const unsigned hi32 = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(bb >> 32), u);
+                const double Bt = __longlong_as_double((long long)(((unsigned long long)hi32 << 32) | lo32));
+                scan_step<STATE_LEN>(p, blk_sc + u * 4 * S, blk_b + u * S, al + cb * S, al + (cb ^ 1) * S, tab, lane, A, lz, Bt,
+                                     Pn + (long)(tb0 + u) * 4);
+                cb ^= 1;
+            }
+        }
+        return;
+    }
     BeamTable tb;
     tb.ent = (uint2_t*)(st_b + 2 * BTB * S);             // [NBK][BKE], 16-byte aligned
     uint4_t* b_elem = (uint4_t*)(tb.ent + NBK * BKE);    // [32] beam element: state, hash, score bits, -
@@ -723,7 +819,10 @@ __global__ __launch_bounds__(64 * CPW) __attribute__((amdgpu_waves_per_eu(1, 8))
         {
             long long ts0 = 0;
             if (DBG) ts0 = __builtin_readcyclecounter();
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this block has landed (wave-private buffers: no barrier)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this block has landed
+            // unfused: wave-private buffers, no barrier. Fused: one workgroup barrier per block publishes the landed block to
+            // the scan wave and proves that it is done with the block before last, whose buffer the next DMA overwrites
+            if (FUSE) __syncthreads();
             if (DBG) dsec[5] += __builtin_readcyclecounter() - ts0;
             if (tb0 + BTB < T) stage(tb0 + BTB, (blk + 1) & 1);  // (everything read from that buffer was consumed a block ago)
         }
@@ -1024,6 +1123,9 @@ namespace {
 struct SideStream { hipStream_t stream = nullptr; hipEvent_t fork = nullptr, join = nullptr; };
 int g_beam_select = 0;     // 0 histogram top-W selection, 1 radix search (A/B and regression tests)
 int g_beam_fork = -1;      // -1 auto (fork for small state spaces), 0 never, 1 always; bh_set_option("beam_fork", v)
+int g_beam_fuse = -1;      // forward / posterior scan as a second wave of the beam kernel's workgroups: -1 auto (<= 256 states: one
+                           // scan wave keeps up with the beam wave; at 1024 states its 16 states per lane make the beam wave wait:
+                           // sup-LSTM 256 x 3334 decode 30 -> 36 ms), 0 never (own kernel), 1 always
 SideStream* side_stream(int S) {
     // Measured (MI355X, 512 x 1667 steps): forking shortens the decode stage 8.3 -> 6.7 ms (S=64) / 11.3 -> 9.3 ms (S=256).
     // Where the decoder is the pipeline bottleneck (fast-sized models) that is a net win (10.0 -> 9.4 ms per step); next to
@@ -1071,30 +1173,49 @@ int bh_k_beam_search(const void* scores, int N, int T, int state_len, int beam_w
     // The forward/posterior scan and the beam kernel both depend only on the backward scan and both are latency chains over T
     // (one workgroup / one wave per chunk): run them side by side - the posterior scan on a per-device helper stream forked
     // from and joined back into the caller's stream with events.
-    SideStream* side = side_stream(S);
+    // Default: the forward / posterior scan runs as a second wave inside the beam kernel's workgroups (FUSE), sharing the staged
+    // score / guide blocks. "beam_fuse" 0 restores the separate crf_forward_post_kernel (optionally forked onto a helper stream).
+    const bool fuse = g_beam_fuse > 0 || (g_beam_fuse < 0 && S <= 256);
+    SideStream* side = fuse ? nullptr : side_stream(S);
     const bool fork = side != nullptr;
     if (fork) {
         BH_CHECK_HIP(hipEventRecord(side->fork, stream));
         BH_CHECK_HIP(hipStreamWaitEvent(side->stream, side->fork, 0));
     }
-    if (S <= 256)
-        hipLaunchKernelGGL(crf_forward_post_kernel<true>, dim3(N), dim3(threads), lds_scan, fork ? side->stream : stream, sa);
-    else
-        hipLaunchKernelGGL(crf_forward_post_kernel<false>, dim3(N), dim3(threads), lds_scan, fork ? side->stream : stream, sa);
+    if (!fuse) {
+        if (S <= 256)
+            hipLaunchKernelGGL(crf_forward_post_kernel<true>, dim3(N), dim3(threads), lds_scan, fork ? side->stream : stream, sa);
+        else
+            hipLaunchKernelGGL(crf_forward_post_kernel<false>, dim3(N), dim3(threads), lds_scan, fork ? side->stream : stream, sa);
+    }
     if (fork) BH_CHECK_HIP(hipEventRecord(side->join, side->stream));
     BeamArgs ba{(const half_t*)scores, beta, N, T, S, state_len, beam_width, blank, logf(beam_cut), bp, fin, dbg,
-                g_beam_select ? 0.0f : 256.0f / fmaxf(logf(beam_cut), 1e-6f)};
+                g_beam_select ? 0.0f : 256.0f / fmaxf(logf(beam_cut), 1e-6f), Bcum, logZ, P};
     // Chunks (waves) per workgroup, measured on MI355X next to the encoder of the same model: four for the narrow state
     // spaces (fast-sized models, three lanes: 1.20e9 -> 1.26e9 samples/s); one for 256 states - two waves per workgroup
     // there cost the hac pipeline 6 % (the 78 KiB workgroups find room beside the recurrent layer's workgroups later).
-    auto launch_beam = [&](auto kern, int cpw, size_t wave_lds) -> int {
-        const size_t lds_beam = (size_t)BEAM_TAB_LDS + cpw * wave_lds;
+    auto launch_beam = [&](auto kern, int cpw, size_t wave_lds, size_t scan_lds = 0) -> int {
+        const size_t lds_beam = (size_t)BEAM_TAB_LDS + cpw * (wave_lds + scan_lds);
         if (lds_beam > 64 * 1024)
             BH_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_beam));
-        hipLaunchKernelGGL(kern, dim3((N + cpw - 1) / cpw), dim3(64 * cpw), lds_beam, stream, ba);
+        hipLaunchKernelGGL(kern, dim3((N + cpw - 1) / cpw), dim3(64 * cpw * (scan_lds ? 2 : 1)), lds_beam, stream, ba);
         return 0;
     };
     int lrc = -2;
+    if (fuse) {
+        switch (state_len * 2 + (dbg ? 1 : 0)) {
+            case 2: lrc = launch_beam(beam_kernel<1, 4, false, true>, 4, beam_wave_lds<1>(), scan_wave_lds<1>()); break;
+            case 3: lrc = launch_beam(beam_kernel<1, 4, true, true>, 4, beam_wave_lds<1>(), scan_wave_lds<1>()); break;
+            case 4: lrc = launch_beam(beam_kernel<2, 4, false, true>, 4, beam_wave_lds<2>(), scan_wave_lds<2>()); break;
+            case 5: lrc = launch_beam(beam_kernel<2, 4, true, true>, 4, beam_wave_lds<2>(), scan_wave_lds<2>()); break;
+            case 6: lrc = launch_beam(beam_kernel<3, 4, false, true>, 4, beam_wave_lds<3>(), scan_wave_lds<3>()); break;
+            case 7: lrc = launch_beam(beam_kernel<3, 4, true, true>, 4, beam_wave_lds<3>(), scan_wave_lds<3>()); break;
+            case 8: lrc = launch_beam(beam_kernel<4, 1, false, true>, 1, beam_wave_lds<4>(), scan_wave_lds<4>()); break;
+            case 9: lrc = launch_beam(beam_kernel<4, 1, true, true>, 1, beam_wave_lds<4>(), scan_wave_lds<4>()); break;
+            case 10: lrc = launch_beam(beam_kernel<5, 1, false, true>, 1, beam_wave_lds<5>(), scan_wave_lds<5>()); break;
+            case 11: lrc = launch_beam(beam_kernel<5, 1, true, true>, 1, beam_wave_lds<5>(), scan_wave_lds<5>()); break;
+        }
+    } else
     switch (state_len * 2 + (dbg ? 1 : 0)) {
         case 2: lrc = launch_beam(beam_kernel<1, 4, false>, 4, beam_wave_lds<1>()); break;
         case 3: lrc = launch_beam(beam_kernel<1, 4, true>, 4, beam_wave_lds<1>()); break;
@@ -1118,5 +1239,6 @@ int bh_k_beam_search(const void* scores, int N, int T, int state_len, int beam_w
 int bh_k_decode_set_option(const char* name, int value) {
     if (name && !strcmp(name, "beam_fork")) { g_beam_fork = value; return 0; }
     if (name && !strcmp(name, "beam_select")) { g_beam_select = value; return 0; }
+    if (name && !strcmp(name, "beam_fuse")) { g_beam_fuse = value; return 0; }
     return 1;     // not a decoder option
 }

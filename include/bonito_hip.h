@@ -188,6 +188,9 @@ int bh_lstm_q8_layer(const void* x, float bound, const float* w_ih, const float*
 /* Process-wide knobs (measurement / tuning hooks, no reference counterpart).
  *   "beam_fork": -1 auto (default), 0 = run the posterior scan behind the beam kernel on the caller's stream,
  *                1 = run it next to the beam kernel on an internal helper stream (joined before finalize).
+ *   "beam_fuse": -1 (default) = auto: fused for <= 256 states; 1 = the forward / posterior scan runs as a second wave inside the beam kernel's workgroups and reads
+ *                the score and guide rows from the blocks the beam wave stages in LDS (the score tensor is read from HBM once
+ *                for both); 0 = separate crf_forward_post_kernel as in round 1 (then "beam_fork" applies).
  *   "beam_select": 0 (default) = top-W selection by histogram + exact boundary ranking, 1 = MSB-first radix search
  *                (the same beams either way; kept for regression tests and A/B timing).
  *   "conv_ws": 1 (default) = weight-stationary kernel for the 384-channel / 19-tap convolution, 0 = generic implicit GEMM.

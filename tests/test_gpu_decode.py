@@ -257,3 +257,22 @@ def test_hip_decoders_match_reference_ctc_crf_fixture():
         assert np.abs(decode.logz(x).numpy() - z["logz%d" % sl]).max() < 2e-3
         pm, pp = decode.posterior_viterbi(x)
         assert [sd.path_to_str(p) for p in pp.numpy()] == json.loads(str(z["post_str%d" % sl]))
+
+
+@pytest.mark.parametrize("state_len", [1, 2, 3, 4, 5])
+def test_fused_and_separate_posterior_scan_agree(state_len):
+    """bh_set_option("beam_fuse"): the forward / posterior scan as a second wave of the beam kernel's workgroups (default) or
+    as its own kernel (round 1) -- same sequences and moves bit for bit, q-scores to summation order."""
+    rng = np.random.default_rng(300 + state_len)
+    N, T = (5, 61) if state_len == 5 else (11, 203)
+    sc = torch.from_numpy(_peaky_scores(rng, N, T, state_len)).cuda()
+    outs = []
+    try:
+        for v in (1, 0):
+            decode.set_option("beam_fuse", v)
+            outs.append(decode.beam_search(sc, return_qfloat=True))
+    finally:
+        decode.set_option("beam_fuse", -1)
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][2], outs[1][2])
+    assert (outs[0][3] - outs[1][3]).abs().max().item() < 1e-4
+    assert (outs[0][1] != outs[1][1]).float().mean().item() < 1e-3
