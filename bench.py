@@ -207,9 +207,13 @@ def main():
     from bonito_amd import decode
     from bonito_amd.util import limit_host_threads
     log("host threads: %d" % limit_host_threads(4))
+    enc_opts = {}
     for kv in a.set:
         name, _, value = kv.partition("=")
-        decode.set_option(name, int(value))
+        if name.startswith("enc:"):          # per-engine option (bh_encoder_set_option), e.g. enc:lstm_tune=16
+            enc_opts[name[4:]] = int(value)
+        else:
+            decode.set_option(name, int(value))
     log("building model %s%s" % (a.model, " (quantize)" if a.quantize else ""))
     model = build_model(a.model, a.batch, a.chunk)
     model.use_koi(batchsize=a.batch, chunksize=a.chunk, quantize=a.quantize)
@@ -233,6 +237,8 @@ def main():
             ln.model = build_model(a.model, a.batch, a.chunk)
             ln.model.use_koi(batchsize=a.batch, chunksize=a.chunk, quantize=a.quantize)
             ln.model = ln.model.half().to(dev)
+        # (measured and dropped: a higher hardware-queue priority for the encoder stream, 20.0 -> 21.1 ms per step, and
+        # s_setprio 3 inside the recurrent kernel, 20.0 -> 20.0)
         ln.enc_stream, ln.dec_stream = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
         ln.stage = [torch.empty_like(signals[0]) for _ in range(2)]      # H2D landing buffers (double buffered)
         ln.stage_free = [None, None]
@@ -277,6 +283,8 @@ def main():
     for ln in lanes:
         sc0, ev0 = encode(ln, 0, False)
         ev0.synchronize()
+        for k, v in enc_opts.items():
+            ln.model._hip.set_option(k, v)
         T_out, C_out = sc0.shape[1], sc0.shape[2]
         ln.decs = [decode.CRFDecoder(a.batch, T_out, C_out, dev, mode=a.decoder) for _ in range(2)]
         del sc0
