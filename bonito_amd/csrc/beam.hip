@@ -58,6 +58,8 @@ struct ScanArgs {
     double* Bcum;          // [N][T+1]
     double* logZ;          // [N]
     float* P;              // [N][T][4]   (forward only)
+    int nt;                // stream scores / guide with the non-temporal cache policy (they are read once; keeps the L2 for the
+                           // recurrent kernels' exchange buffers when the decoder runs beside the next batch's encoder)
 };
 
 constexpr int SU = 4;  // score prefetch depth
@@ -86,7 +88,8 @@ __global__ void crf_backward_kernel(ScanArgs p) {
 #pragma unroll
         for (int u = 0; u < SU; ++u) {
             int t = thi - 1 - u;
-            if (active && t >= 0) dst[u] = *(const half4_t*)(sc + (long)t * 4 * S);
+            if (active && t >= 0) dst[u] = p.nt ? __builtin_nontemporal_load((const half4_t*)(sc + (long)t * 4 * S))
+                                                : *(const half4_t*)(sc + (long)t * 4 * S);
         }
     };
     load(cur, T);
@@ -123,7 +126,8 @@ __global__ void crf_backward_kernel(ScanArgs p) {
                 __syncthreads();
                 if (active) {
                     const float* now = buf + cb * S;
-                    bn[(long)t * S + s] = now[s] - now[0];
+                    if (p.nt) __builtin_nontemporal_store(now[s] - now[0], bn + (long)t * S + s);
+                    else bn[(long)t * S + s] = now[s] - now[0];
                 }
             }
         }
@@ -356,6 +360,7 @@ struct BeamArgs {
     const double* Bcum;    // [N][T+1]
     const double* logZ;    // [N]
     float* P;              // [N][T][4]
+    int nt;                // non-temporal staging of scores / guide
 };
 
 constexpr int BTB = 4;     // steps per staged block; two blocks are resident (the next one streams in under the current one)
@@ -579,6 +584,10 @@ __device__ __forceinline__ unsigned bucket_match(const uint4_t& e0, unsigned has
 __device__ __forceinline__ void dma16(const char* g, char* lds) {
     const unsigned l = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)(__attribute__((address_space(3))) char*)lds);
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(l), "v"(g) : "memory");
+}
+__device__ __forceinline__ void dma16_nt(const char* g, char* lds) {      // same, non-temporal (streamed-once data)
+    const unsigned l = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)(__attribute__((address_space(3))) char*)lds);
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt" ::"s"(l), "v"(g) : "memory");
 }
 
 // lse2_tab without control flow (same arithmetic): safe for garbage `b` as long as the result is discarded
@@ -806,12 +815,12 @@ __global__ __launch_bounds__(64 * CPW * (FUSE ? 2 : 1)) __attribute__((amdgpu_wa
         const char* src = (const char*)(sc + (long)tb0 * 4 * S);
         char* dsc = (char*)(st_sc + which * BTB * 4 * S);
         for (int i0 = 0; i0 < n_sc; i0 += 64)
-            if (i0 + lane < n_sc) dma16(src + (long)(i0 + lane) * 16, dsc + i0 * 16);
+            if (i0 + lane < n_sc) { if (p.nt) dma16_nt(src + (long)(i0 + lane) * 16, dsc + i0 * 16); else dma16(src + (long)(i0 + lane) * 16, dsc + i0 * 16); }
         const int n_b = nsteps * S / 4;         // 16-byte units of guide rows (S floats per step)
         const char* bs = (const char*)(bn + (long)(tb0 + 1) * S);
         char* dbt = (char*)(st_b + which * BTB * S);
         for (int i0 = 0; i0 < n_b; i0 += 64)
-            if (i0 + lane < n_b) dma16(bs + (long)(i0 + lane) * 16, dbt + i0 * 16);
+            if (i0 + lane < n_b) { if (p.nt) dma16_nt(bs + (long)(i0 + lane) * 16, dbt + i0 * 16); else dma16(bs + (long)(i0 + lane) * 16, dbt + i0 * 16); }
     };
     if (T > 0) stage(0, 0);
     for (int tb0 = 0, blk = 0; tb0 < T; tb0 += BTB, ++blk) {
@@ -1053,6 +1062,8 @@ __global__ __launch_bounds__(64) void beam_finalize_kernel(FinArgs p) {
 
 }  // namespace bh
 
+static int g_decode_nt = 0;     // bh_set_option("decode_nt", v)
+
 size_t bh_k_beam_workspace(int N, int T, int state_len) {
     size_t S = 1;
     for (int i = 0; i < state_len; ++i) S *= 4;
@@ -1079,7 +1090,7 @@ int bh_k_crf_logz(const void* scores, int N, int T, int state_len, float blank, 
     char* w = (char*)workspace;
     float* beta = (float*)w;   w += align((size_t)N * (T + 1) * S * sizeof(float));
     double* Bcum = (double*)w;
-    ScanArgs sa{(const half_t*)scores, N, T, S, state_len, blank, beta, Bcum, logz_out, nullptr};
+    ScanArgs sa{(const half_t*)scores, N, T, S, state_len, blank, beta, Bcum, logz_out, nullptr, g_decode_nt};
     const int threads = S < 64 ? 64 : S;
     const size_t lds_scan = (size_t)(BH_LSE_TABLE_SIZE + 2 + 2 * S + 2 * 16 * 16 + 8) * sizeof(float) + (size_t)2 * 4 * S * 2;
     hipLaunchKernelGGL(crf_backward_kernel, dim3(N), dim3(threads), lds_scan, stream, sa);
@@ -1105,7 +1116,7 @@ int bh_k_posterior_viterbi(const void* scores, int N, int T, int state_len, floa
     double* Bcum = (double*)w; w += align((size_t)N * (T + 1) * sizeof(double));
     double* logZ = (double*)w;
     uint8_t* bp = (uint8_t*)workspace + bh_k_beam_workspace(N, T, state_len);
-    ScanArgs sa{(const half_t*)scores, N, T, S, state_len, blank, beta, Bcum, logZ, nullptr};
+    ScanArgs sa{(const half_t*)scores, N, T, S, state_len, blank, beta, Bcum, logZ, nullptr, g_decode_nt};
     const int threads = S < 64 ? 64 : S;
     const size_t lds_scan = (size_t)(BH_LSE_TABLE_SIZE + 2 + 2 * S + 2 * 16 * 16 + 8) * sizeof(float) + (size_t)2 * 4 * S * 2;
     hipLaunchKernelGGL(crf_backward_kernel, dim3(N), dim3(threads), lds_scan, stream, sa);
@@ -1166,7 +1177,7 @@ int bh_k_beam_search(const void* scores, int N, int T, int state_len, int beam_w
     int* fin = (int*)w;         w += align((size_t)N * sizeof(int));
     long long* dbg = getenv("BH_BEAM_DEBUG") ? (long long*)w : nullptr;
 
-    ScanArgs sa{(const half_t*)scores, N, T, S, state_len, blank, beta, Bcum, logZ, P};
+    ScanArgs sa{(const half_t*)scores, N, T, S, state_len, blank, beta, Bcum, logZ, P, g_decode_nt};
     const int threads = S < 64 ? 64 : S;
     const size_t lds_scan = (size_t)(BH_LSE_TABLE_SIZE + 2 + 2 * S + 2 * 16 * 16 + 8) * sizeof(float) + (size_t)2 * 4 * S * 2;
     hipLaunchKernelGGL(crf_backward_kernel, dim3(N), dim3(threads), lds_scan, stream, sa);
@@ -1190,7 +1201,7 @@ int bh_k_beam_search(const void* scores, int N, int T, int state_len, int beam_w
     }
     if (fork) BH_CHECK_HIP(hipEventRecord(side->join, side->stream));
     BeamArgs ba{(const half_t*)scores, beta, N, T, S, state_len, beam_width, blank, logf(beam_cut), bp, fin, dbg,
-                g_beam_select ? 0.0f : 256.0f / fmaxf(logf(beam_cut), 1e-6f), Bcum, logZ, P};
+                g_beam_select ? 0.0f : 256.0f / fmaxf(logf(beam_cut), 1e-6f), Bcum, logZ, P, g_decode_nt};
     // Chunks (waves) per workgroup, measured on MI355X next to the encoder of the same model: four for the narrow state
     // spaces (fast-sized models, three lanes: 1.20e9 -> 1.26e9 samples/s); one for 256 states - two waves per workgroup
     // there cost the hac pipeline 6 % (the 78 KiB workgroups find room beside the recurrent layer's workgroups later).
@@ -1240,5 +1251,6 @@ int bh_k_decode_set_option(const char* name, int value) {
     if (name && !strcmp(name, "beam_fork")) { g_beam_fork = value; return 0; }
     if (name && !strcmp(name, "beam_select")) { g_beam_select = value; return 0; }
     if (name && !strcmp(name, "beam_fuse")) { g_beam_fuse = value; return 0; }
+    if (name && !strcmp(name, "decode_nt")) { g_decode_nt = value; return 0; }
     return 1;     // not a decoder option
 }

@@ -708,8 +708,8 @@ extern "C" int bh_encoder_describe(const bh_encoder_t* e, char* buf, size_t n) {
                 else if (p.wg) snprintf(line, sizeof(line), "%d lstm %d%s: lstm_layer_wg_kernel<%d,%d>\n", li, H, d.reverse ? " rev" : "", H / 32, U / 4);
                 else if (p.fused) snprintf(line, sizeof(line), "%d lstm %d%s: lstm_layer_fused_kernel<%d>\n", li, H, d.reverse ? " rev" : "", H / 32);
                 else if (p.wide) snprintf(line, sizeof(line), "%d lstm %d%s: gemm + lstm_layer_wide_kernel<%d>\n", li, H, d.reverse ? " rev" : "", H / 32);
-                else if (p.reg_path) snprintf(line, sizeof(line), "%d lstm %d%s: gemm + lstm_layer_kernel<%d>\n", li, H, d.reverse ? " rev" : "", H / 32);
-                else snprintf(line, sizeof(line), "%d lstm %d%s: gemm + lstm_layer_stream_kernel<%d>\n", li, H, d.reverse ? " rev" : "", H / 32);
+                else if (p.reg_path) snprintf(line, sizeof(line), "%d lstm %d%s: gemm + lstm_layer_kernel<%d,false>\n", li, H, d.reverse ? " rev" : "", H / 32);
+                else snprintf(line, sizeof(line), "%d lstm %d%s: gemm + lstm_layer_kernel<%d,true> (weight streaming)\n", li, H, d.reverse ? " rev" : "", H / 32);
                 break;
             }
             case BH_LAYER_LINEAR_CRF: snprintf(line, sizeof(line), "%d linearcrfencoder %d->%d: gemm\n", li, d.in_size, d.out_size); break;

@@ -55,6 +55,29 @@ __device__ __forceinline__ int xcc_id() {
     return (int)(__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 0xF);   // hwreg(HW_REG_XCC_ID, 0, 4)
 }
 
+// XCD agreement of a ring: every member publishes its XCC id and reads the ring's ids; the ring uses plain stores (the lines stay
+// in that XCD's L2, the sc1 polls are L2 hits) iff all members sit on one XCD. A timeout is not an error: the write-through
+// policy is valid for any placement. Every member reads the same published ids, so the choice is identical across the ring.
+__device__ __forceinline__ bool ring_store_policy(const LstmArgs& p, int ring, int slice, int nsl, int lane) {
+    int* slot = p.xcc_ws + (long)ring * nsl;
+    const int mine = xcc_id();
+    if (lane == 0) __hip_atomic_store(slot + slice, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned spins = 0;
+    bool ok = false;
+    while (true) {
+        bool any_unset = false, any_other = false;
+        for (int i = lane; i < nsl; i += 64) {
+            const int v = __hip_atomic_load(slot + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            any_unset |= v < 0;
+            any_other |= v != mine;
+        }
+        if (!__any(any_unset)) { ok = !__any(any_other); break; }
+        if (++spins > p.max_spins) break;
+        __builtin_amdgcn_s_sleep(4);
+    }
+    return ok && !p.force_slow;
+}
+
 constexpr unsigned SENTINEL_MASK = 0x40004000u;
 
 // LDS output transpose: 2-byte writes, 8-byte reads of the same bytes. Plain half_t / unsigned long long accesses are
@@ -90,148 +113,35 @@ __device__ __forceinline__ float lstm_cell(float ai, float af, float ag, float a
     return (fabsf(hv) <= 1.0f) ? hv : 0.0f;
 }
 
-template <int NKS>
+// STREAM = false: W_hh fragments of the wave's slice are register-resident, a workgroup serves one slice of FOUR rings.
+// STREAM = true (hidden sizes the register file cannot hold, H > 512: the 768-wide old-style r9.4.1 models, the 1024-wide v4.3
+// `sup`, when the stationary wide kernel is switched off or does not cover H): the fragments are re-read from L2 / Infinity Cache
+// every step, a workgroup serves four slices of ONE ring, so a ring costs only NSL/4 workgroups and any H % 64 == 0 fits.
+template <int NKS, bool STREAM>
 __global__ __launch_bounds__(256, 1) void lstm_layer_kernel(LstmArgs p) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     constexpr int H = NKS * 32;
     constexpr int NSL = H / 16;  // slices == waves per ring
-    // block -> (xcd, ring group, slice); wave -> ring inside the group
+    // block -> (xcd, ring group, slice) and wave -> ring inside the group; streaming: block -> (xcd, ring, group of 4 slices)
     const int xcd = blockIdx.x & 7;
     const int lwg = blockIdx.x >> 3;
-    const int rg = lwg / NSL;
-    const int slice = lwg - rg * NSL;
-    const int ring = (rg * 4 + wave) * 8 + xcd;
-    if (ring >= p.n_rings) return;
-
-    // ---- recurrent weights -> registers (once per layer) -------------------------------------
-    half8_t w[4][NKS];
-#pragma unroll
-    for (int g = 0; g < 4; ++g)
-#pragma unroll
-        for (int ks = 0; ks < NKS; ++ks)
-            w[g][ks] = *(const half8_t*)(p.whh + ((((long)slice * 4 + g) * NKS + ks) * 64 + lane) * 8);
-
-    const int c = lane & 15, q = lane >> 4;
-    const int n = ring * 16 + c;
-    const int hu0 = slice * 16 + q * 4;
-    const long row_bytes = (long)p.N * H * 2;           // one time step of h
-    const unsigned voff = (unsigned)(((ring * 16 + c) * H + q * 8) * 2);
-    float cst[4] = {0.f, 0.f, 0.f, 0.f};
-    bool dead = false;
-
-    // ---- XCD agreement: publish my XCC id, read the ring's ids, fast policy iff all equal -------
-    bool fast = false;
-    {
-        int* slot = p.xcc_ws + (long)ring * NSL;
-        const int mine = xcc_id();
-        if (lane == 0) __hip_atomic_store(slot + slice, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        unsigned spins = 0;
-        bool ok = false;
-        while (true) {
-            int v = (lane < NSL) ? __hip_atomic_load(slot + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : mine;
-            if (!__any(v < 0)) { ok = !__any(v != mine); break; }
-            if (++spins > p.max_spins) break;     // not an error: fall back to the safe policy
-            __builtin_amdgcn_s_sleep(4);
-        }
-        fast = ok && !p.force_slow;
-    }
-
-    const long g_row = (long)p.N * 4 * H;
-    const half_t* gptr = p.G + (long)n * 4 * H + hu0;
-    int t = p.reverse ? p.T - 1 : 0;
-    const int dt = p.reverse ? -1 : 1;
-
-    half4_t gin[4];
-#pragma unroll
-    for (int g = 0; g < 4; ++g) gin[g] = *(const half4_t*)(gptr + (long)t * g_row + g * H);
-
-    for (int step = 0; step < p.T; ++step, t += dt) {
-        // prefetch next step's input projection (independent of the recurrence)
-        half4_t gnx[4];
-        {
-            int tn = (step + 1 < p.T) ? t + dt : t;
-#pragma unroll
-            for (int g = 0; g < 4; ++g) gnx[g] = *(const half4_t*)(gptr + (long)tn * g_row + g * H);
-        }
-        float4_t acc[4];
-#pragma unroll
-        for (int g = 0; g < 4; ++g) acc[g] = float4_t{0.f, 0.f, 0.f, 0.f};
-
-        if (step > 0) {
-            const char* base = (const char*)p.h + (long)(t - dt) * row_bytes;
-            __amdgpu_buffer_rsrc_t rs =
-                __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)row_bytes, 0x00020000);
-            uint4_t hf[NKS];
-            unsigned spins = dead ? p.max_spins : 0u;   // after one timeout never wait again
-            unsigned pend = (NKS >= 32) ? 0xffffffffu : ((1u << NKS) - 1u);   // wave-uniform
-            while (true) {
-#pragma unroll
-                for (int ks = 0; ks < NKS; ++ks)
-                    if (pend & (1u << ks))
-                        hf[ks] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff + ks * 64, 0, (int)0x80000010 /*sc1 + volatile*/);
-#pragma unroll
-                for (int ks = 0; ks < NKS; ++ks)
-                    if (pend & (1u << ks)) {
-                        unsigned orv = hf[ks].x | hf[ks].y | hf[ks].z | hf[ks].w;
-                        if (!__any((orv & SENTINEL_MASK) != 0)) pend &= ~(1u << ks);
-                    }
-                if (pend == 0) break;
-                if (++spins > p.max_spins) {
-                    if (lane == 0 && !dead) atomicExch(p.err, 1);
-                    dead = true;
-                    break;
-                }
-                __builtin_amdgcn_s_sleep(1);
-            }
-#pragma unroll
-            for (int ks = 0; ks < NKS; ++ks) {
-                half8_t b = __builtin_bit_cast(half8_t, hf[ks]);
-#pragma unroll
-                for (int g = 0; g < 4; ++g) acc[g] = mfma16(w[g][ks], b, acc[g]);
-            }
-        }
-
-        half4_t ho;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            // a non-finite or out-of-range h can never be published (keeps the sentinel space clean)
-            const float hv = lstm_cell(acc[0][i] + (float)gin[0][i], acc[1][i] + (float)gin[1][i],
-                                       acc[2][i] + (float)gin[2][i], acc[3][i] + (float)gin[3][i], cst[i]);
-            ho[i] = (half_t)hv;
-        }
-        unsigned long long packed = __builtin_bit_cast(unsigned long long, ho);
-        unsigned long long* dst =
-            (unsigned long long*)(p.h + ((long)t * p.N + n) * H + hu0);
-        if (fast) *dst = packed;                                                       // stays in this XCD's L2
-        else __hip_atomic_store(dst, packed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // sc1 write-through
-#pragma unroll
-        for (int g = 0; g < 4; ++g) gin[g] = gnx[g];
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------
-// Weight-streaming variant for hidden sizes the register file cannot hold (H > 512: the 768-wide old-style
-// r9.4.1 models, the 1024-wide v4.3 `sup`). Same ring exchange protocol; the W_hh fragments are re-read from
-// L2 / Infinity Cache every step instead of living in registers, and a workgroup serves 4 slices of ONE ring.
-// Slower per step than the register-resident kernel, but correct for any H % 64 == 0.
-template <int NKS>
-__global__ __launch_bounds__(256, 1) void lstm_layer_stream_kernel(LstmArgs p) {
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    constexpr int H = NKS * 32;
-    constexpr int NSL = H / 16;  // slices == waves per ring
-    // block -> (xcd, ring, group of 4 slices); wave -> slice inside the group. Nothing is register resident,
-    // so a ring costs only NSL/4 workgroups and any hidden size that is a multiple of 64 fits the device.
-    const int xcd = blockIdx.x & 7;
-    const int lwg = blockIdx.x >> 3;
-    constexpr int WPR = NSL / 4;          // workgroups per ring
-    const int rl = lwg / WPR;
-    const int slice = (lwg - rl * WPR) * 4 + wave;
-    const int ring = rl * 8 + xcd;
+    constexpr int WPR = NSL / 4;          // streaming: workgroups per ring
+    const int rg = STREAM ? lwg / WPR : lwg / NSL;
+    const int slice = STREAM ? (lwg - rg * WPR) * 4 + wave : lwg - rg * NSL;
+    const int ring = STREAM ? rg * 8 + xcd : (rg * 4 + wave) * 8 + xcd;
     if (ring >= p.n_rings) return;
     const half_t* wbase = p.whh + ((long)slice * 4 * NKS * 64 + lane) * 8;
 
+    // ---- recurrent weights -> registers (once per layer) -------------------------------------
+    half8_t w[STREAM ? 1 : 4][STREAM ? 1 : NKS];
+    if constexpr (!STREAM) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) w[g][ks] = *(const half8_t*)(wbase + (long)(g * NKS + ks) * 512);
+    }
+
     const int c = lane & 15, q = lane >> 4;
     const int n = ring * 16 + c;
     const int hu0 = slice * 16 + q * 4;
@@ -240,22 +150,7 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_stream_kernel(LstmArgs p) {
     float cst[4] = {0.f, 0.f, 0.f, 0.f};
     bool dead = false;
 
-    // ---- XCD agreement: publish my XCC id, read the ring's ids, fast policy iff all equal -------
-    bool fast = false;
-    {
-        int* slot = p.xcc_ws + (long)ring * NSL;
-        const int mine = xcc_id();
-        if (lane == 0) __hip_atomic_store(slot + slice, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        unsigned spins = 0;
-        bool ok = false;
-        while (true) {
-            int v = (lane < NSL) ? __hip_atomic_load(slot + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : mine;
-            if (!__any(v < 0)) { ok = !__any(v != mine); break; }
-            if (++spins > p.max_spins) break;     // not an error: fall back to the safe policy
-            __builtin_amdgcn_s_sleep(4);
-        }
-        fast = ok && !p.force_slow;
-    }
+    const bool fast = ring_store_policy(p, ring, slice, NSL, lane);
 
     const long g_row = (long)p.N * 4 * H;
     const half_t* gptr = p.G + (long)n * 4 * H + hu0;
@@ -308,8 +203,10 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_stream_kernel(LstmArgs p) {
             for (int ks = 0; ks < NKS; ++ks) {
                 half8_t b = __builtin_bit_cast(half8_t, hf[ks]);
 #pragma unroll
-                for (int g = 0; g < 4; ++g)
-                    acc[g] = mfma16(*(const half8_t*)(wbase + (long)(g * NKS + ks) * 512), b, acc[g]);
+                for (int g = 0; g < 4; ++g) {
+                    if constexpr (STREAM) acc[g] = mfma16(*(const half8_t*)(wbase + (long)(g * NKS + ks) * 512), b, acc[g]);
+                    else acc[g] = mfma16(w[g][ks], b, acc[g]);
+                }
             }
         }
 
@@ -401,21 +298,7 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_fused_kernel(LstmFusedArgs 
 #pragma unroll
         for (int i = 0; i < 4; ++i) bias4[g][i] = fp.bias[g * H + hu0 + i];
 
-    bool fast = false;
-    {
-        int* slot = p.xcc_ws + (long)ring * NSL;
-        const int mine = xcc_id();
-        if (lane == 0) __hip_atomic_store(slot + slice, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        unsigned spins = 0;
-        bool ok = false;
-        while (true) {
-            int v = (lane < NSL) ? __hip_atomic_load(slot + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : mine;
-            if (!__any(v < 0)) { ok = !__any(v != mine); break; }
-            if (++spins > p.max_spins) break;
-            __builtin_amdgcn_s_sleep(4);
-        }
-        fast = ok && !p.force_slow;
-    }
+    const bool fast = ring_store_policy(p, ring, slice, NSL, lane);
 
     int t = p.reverse ? p.T - 1 : 0;
     const int dt = p.reverse ? -1 : 1;
@@ -620,21 +503,7 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_wg_kernel(LstmFusedArgs fp)
     }
     bool dead = false;
 
-    bool fast = false;
-    {
-        int* slot = p.xcc_ws + (long)ring * NSL;
-        const int mine = xcc_id();
-        if (lane == 0) __hip_atomic_store(slot + slice, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        unsigned spins = 0;
-        bool ok = false;
-        while (true) {
-            int v = (lane < NSL) ? __hip_atomic_load(slot + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : mine;
-            if (!__any(v < 0)) { ok = !__any(v != mine); break; }
-            if (++spins > p.max_spins) break;
-            __builtin_amdgcn_s_sleep(4);
-        }
-        fast = ok && !p.force_slow;
-    }
+    const bool fast = ring_store_policy(p, ring, slice, NSL, lane);
 
     int t = p.reverse ? p.T - 1 : 0;
     const int dt = p.reverse ? -1 : 1;
@@ -913,21 +782,7 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_wgx_kernel(LstmWgxArgs wp) 
         for (int i = 0; i < 4; ++i) bias4[m][i] = fp.bias[i * H + slice * U + q * MT + m];
     }
     bool dead = false;
-    bool fast = false;
-    {
-        int* slot = p.xcc_ws + (long)ring * NSL;
-        const int mine = xcc_id();
-        if (lane == 0) __hip_atomic_store(slot + slice, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        unsigned spins = 0;
-        bool ok = false;
-        while (true) {
-            int v = (lane < NSL) ? __hip_atomic_load(slot + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : mine;
-            if (!__any(v < 0)) { ok = !__any(v != mine); break; }
-            if (++spins > p.max_spins) break;
-            __builtin_amdgcn_s_sleep(4);
-        }
-        fast = ok && !p.force_slow;
-    }
+    const bool fast = ring_store_policy(p, ring, slice, NSL, lane);
 
     int t = p.reverse ? p.T - 1 : 0;
     const int dt = p.reverse ? -1 : 1;
@@ -1273,26 +1128,7 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_wide_kernel(LstmWideArgs wp
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) cst[m][nb] = 0.f;
     bool dead = false;
-    bool fast = false;
-    {
-        int* slot = p.xcc_ws + (long)ring * NSL;
-        const int mine = xcc_id();
-        if (lane == 0) __hip_atomic_store(slot + slice, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        unsigned spins = 0;
-        bool ok = false;
-        while (true) {
-            bool any_unset = false, any_other = false;
-            for (int i = lane; i < NSL; i += 64) {
-                const int v = __hip_atomic_load(slot + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                any_unset |= v < 0;
-                any_other |= v != mine;
-            }
-            if (!__any(any_unset)) { ok = !__any(any_other); break; }
-            if (++spins > p.max_spins) break;
-            __builtin_amdgcn_s_sleep(4);
-        }
-        fast = ok && !p.force_slow;
-    }
+    const bool fast = ring_store_policy(p, ring, slice, NSL, lane);
 
     int t = p.reverse ? p.T - 1 : 0;
     const int dt = p.reverse ? -1 : 1;
@@ -1481,7 +1317,7 @@ int bh_k_lstm_layer(const void* gates_in, const void* whh_packed, void* h_out, i
     LstmArgs a{(const half_t*)gates_in, (const half_t*)whh_packed, (half_t*)h_out, T, N, H, n_rings,
                reverse, err_flag, g_max_spins, xcc_ws, force_slow & 1, force_slow >> 8};
 #define BH_LSTM_CASE(NKS) \
-    case NKS: hipLaunchKernelGGL(lstm_layer_kernel<NKS>, dim3(grid), dim3(256), 0, stream, a); break;
+    case NKS: hipLaunchKernelGGL((lstm_layer_kernel<NKS, false>), dim3(grid), dim3(256), 0, stream, a); break;
     switch (H / 32) {
         BH_LSTM_CASE(1) BH_LSTM_CASE(2) BH_LSTM_CASE(3) BH_LSTM_CASE(4) BH_LSTM_CASE(5) BH_LSTM_CASE(6)
         BH_LSTM_CASE(7) BH_LSTM_CASE(8) BH_LSTM_CASE(9) BH_LSTM_CASE(10) BH_LSTM_CASE(11) BH_LSTM_CASE(12)
@@ -1511,15 +1347,15 @@ int bh_k_lstm_layer_stream(const void* gates_in, const void* whh_packed, void* h
     LstmArgs a{(const half_t*)gates_in, (const half_t*)whh_packed, (half_t*)h_out, T, N, H, n_rings,
                reverse, err_flag, g_max_spins, xcc_ws, force_slow & 1, force_slow >> 8};
     switch (H / 32) {
-        case 2: hipLaunchKernelGGL(lstm_layer_stream_kernel<2>, dim3(grid), dim3(256), 0, stream, a); break;
-        case 4: hipLaunchKernelGGL(lstm_layer_stream_kernel<4>, dim3(grid), dim3(256), 0, stream, a); break;
-        case 8: hipLaunchKernelGGL(lstm_layer_stream_kernel<8>, dim3(grid), dim3(256), 0, stream, a); break;
-        case 12: hipLaunchKernelGGL(lstm_layer_stream_kernel<12>, dim3(grid), dim3(256), 0, stream, a); break;
-        case 16: hipLaunchKernelGGL(lstm_layer_stream_kernel<16>, dim3(grid), dim3(256), 0, stream, a); break;
-        case 20: hipLaunchKernelGGL(lstm_layer_stream_kernel<20>, dim3(grid), dim3(256), 0, stream, a); break;
-        case 24: hipLaunchKernelGGL(lstm_layer_stream_kernel<24>, dim3(grid), dim3(256), 0, stream, a); break;
-        case 28: hipLaunchKernelGGL(lstm_layer_stream_kernel<28>, dim3(grid), dim3(256), 0, stream, a); break;
-        case 32: hipLaunchKernelGGL(lstm_layer_stream_kernel<32>, dim3(grid), dim3(256), 0, stream, a); break;
+        case 2: hipLaunchKernelGGL((lstm_layer_kernel<2, true>), dim3(grid), dim3(256), 0, stream, a); break;
+        case 4: hipLaunchKernelGGL((lstm_layer_kernel<4, true>), dim3(grid), dim3(256), 0, stream, a); break;
+        case 8: hipLaunchKernelGGL((lstm_layer_kernel<8, true>), dim3(grid), dim3(256), 0, stream, a); break;
+        case 12: hipLaunchKernelGGL((lstm_layer_kernel<12, true>), dim3(grid), dim3(256), 0, stream, a); break;
+        case 16: hipLaunchKernelGGL((lstm_layer_kernel<16, true>), dim3(grid), dim3(256), 0, stream, a); break;
+        case 20: hipLaunchKernelGGL((lstm_layer_kernel<20, true>), dim3(grid), dim3(256), 0, stream, a); break;
+        case 24: hipLaunchKernelGGL((lstm_layer_kernel<24, true>), dim3(grid), dim3(256), 0, stream, a); break;
+        case 28: hipLaunchKernelGGL((lstm_layer_kernel<28, true>), dim3(grid), dim3(256), 0, stream, a); break;
+        case 32: hipLaunchKernelGGL((lstm_layer_kernel<32, true>), dim3(grid), dim3(256), 0, stream, a); break;
         default: BH_REQUIRE(false, "lstm: unsupported H=%d for the streaming kernel", H);
     }
     BH_CHECK_HIP(hipGetLastError());

@@ -177,6 +177,7 @@ __global__ __launch_bounds__(256, WPS) void lstm_layer_q8_kernel(LstmQ8Args p) {
 
     uint4_t hq[KQ];
     int4_t xacc[MT];
+    float4_t xpre[MT];          // float(input sum) * sx + b, formed right behind the input projection (inside the exchange round trip)
 
     auto x_phase = [&](const char* xb) {
 #pragma unroll
@@ -188,6 +189,12 @@ __global__ __launch_bounds__(256, WPS) void lstm_layer_q8_kernel(LstmQ8Args p) {
         for (int ks = 0; ks < NK8; ++ks)
 #pragma unroll
             for (int m = 0; m < MT; ++m) xacc[m] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wih[m][ks], bf[ks], xacc[m], 0, 0, 0);
+        if constexpr (!DBG) {
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) xpre[m][i] = __fadd_rn(__fmul_rn((float)xacc[m][i], sx4[m][i]), b4[m][i]);
+        }
     };
     // The x stream never touches registers: each wave moves its share of the k-steps of a tile with LDS-DMA (1 KiB per
     // instruction, lane l -> LDS base + 16 l, which IS the fragment order), so the compiler has no destination registers to
@@ -297,7 +304,8 @@ __global__ __launch_bounds__(256, WPS) void lstm_layer_q8_kernel(LstmQ8Args p) {
             float pre[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i)
-                pre[i] = __fadd_rn(__fadd_rn(__fmul_rn((float)xacc[m][i], sx4[m][i]), b4[m][i]), __fmul_rn((float)acc[m][i], sh4[m][i]));
+                pre[i] = __fadd_rn(DBG ? __fadd_rn(__fmul_rn((float)xacc[m][i], sx4[m][i]), b4[m][i]) : xpre[m][i],
+                                   __fmul_rn((float)acc[m][i], sh4[m][i]));
             const float hv = q8_cell(pre[0], pre[1], pre[2], pre[3], cst[m]);
             const half_t h16 = (half_t)hv;
             const float hq_f = __builtin_rintf(__fmul_rn((float)h16, 127.0f));       // |h16| <= 1 -> |hq| <= 127, never the sentinel
