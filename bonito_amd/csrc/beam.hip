@@ -1136,7 +1136,7 @@ int g_beam_select = 0;     // 0 histogram top-W selection, 1 radix search (A/B a
 int g_beam_fork = -1;      // -1 auto (fork for small state spaces), 0 never, 1 always; bh_set_option("beam_fork", v)
 int g_beam_fuse = -1;      // forward / posterior scan as a second wave of the beam kernel's workgroups: -1 auto (<= 256 states: one
                            // scan wave keeps up with the beam wave; at 1024 states its 16 states per lane make the beam wave wait:
-                           // sup-LSTM 256 x 3334 decode 30 -> 36 ms), 0 never (own kernel), 1 always
+                           // sup-LSTM 256 x 3334 decode 18 -> 36 ms), 0 never (own kernel), 1 always
 SideStream* side_stream(int S) {
     // Measured (MI355X, 512 x 1667 steps): forking shortens the decode stage 8.3 -> 6.7 ms (S=64) / 11.3 -> 9.3 ms (S=256).
     // Where the decoder is the pipeline bottleneck (fast-sized models) that is a net win (10.0 -> 9.4 ms per step); next to

@@ -597,7 +597,10 @@ extern "C" int bh_encoder_create(const bh_layer_t* layers, int n_layers, int dev
         int hmax = 0;
         for (const auto& l : e->layers)
             if (l.d.kind == BH_LAYER_LSTM && l.d.in_size == l.d.out_size && bh_k_lstm_wg_units(l.d.out_size) != 0) hmax = std::max(hmax, l.d.out_size);
-        if (hmax && e->ex16.alloc(bh_k_lstm_wgx_ex_bytes(Np, hmax) + 256)) return fail(-1);
+        size_t exb = hmax ? bh_k_lstm_wgx_ex_bytes(Np, hmax) : 0;
+        for (const auto& l : e->layers)
+            if (l.d.kind == BH_LAYER_LSTM && bh_k_lstm_wide_ok(l.d.out_size)) exb = std::max(exb, bh_k_lstm_wide_ex_bytes(Np, l.d.out_size));
+        if (exb && e->ex16.alloc(exb + 256)) return fail(-1);
     }
     if (e->act[0].alloc(ab + 256) || e->act[1].alloc(ab + 256) || e->gates.alloc(gb + 256) ||
         e->sig.alloc((size_t)Np * max_chunk * 2) || e->err.alloc(sizeof(int)) || e->lstm_ws.alloc(bh_k_lstm_ws_bytes(Np, 1024)))
@@ -670,7 +673,7 @@ extern "C" int bh_encoder_output_shape(const bh_encoder_t* enc, int L, int* T, i
 
 namespace {
 // which recurrence kernel serves a layer (see lstm.hip)
-struct LstmPath { bool reg_path, wide, fused, wg, cta, q8, wgx; };
+struct LstmPath { bool reg_path, wide, fused, wg, cta, q8, wgx, widex; };
 static LstmPath lstm_path(const bh_encoder* e, const Layer& l) {
     const int H = l.d.out_size;
     LstmPath p;
@@ -682,6 +685,7 @@ static LstmPath lstm_path(const bh_encoder* e, const Layer& l) {
     p.q8 = l.q8 && e->lstm_q8 && l.d.in_size == H;
     if (p.q8) p.fused = p.wg = p.cta = p.wide = false;
     p.wgx = p.wg && !p.cta && e->lstm_exchange && e->ex16.p != nullptr;
+    p.widex = p.wide && e->lstm_exchange && e->ex16.p != nullptr;
     return p;
 }
 }  // namespace
@@ -707,7 +711,7 @@ extern "C" int bh_encoder_describe(const bh_encoder_t* e, char* buf, size_t n) {
                 else if (p.wgx) snprintf(line, sizeof(line), "%d lstm %d%s: lstm_layer_wgx_kernel<%d,%d>\n", li, H, d.reverse ? " rev" : "", H / 32, U / 4);
                 else if (p.wg) snprintf(line, sizeof(line), "%d lstm %d%s: lstm_layer_wg_kernel<%d,%d>\n", li, H, d.reverse ? " rev" : "", H / 32, U / 4);
                 else if (p.fused) snprintf(line, sizeof(line), "%d lstm %d%s: lstm_layer_fused_kernel<%d>\n", li, H, d.reverse ? " rev" : "", H / 32);
-                else if (p.wide) snprintf(line, sizeof(line), "%d lstm %d%s: gemm + lstm_layer_wide_kernel<%d>\n", li, H, d.reverse ? " rev" : "", H / 32);
+                else if (p.wide) snprintf(line, sizeof(line), "%d lstm %d%s: gemm + lstm_layer_wide_kernel<%d,%s>\n", li, H, d.reverse ? " rev" : "", H / 32, p.widex ? "true" : "false");
                 else if (p.reg_path) snprintf(line, sizeof(line), "%d lstm %d%s: gemm + lstm_layer_kernel<%d,false>\n", li, H, d.reverse ? " rev" : "", H / 32);
                 else snprintf(line, sizeof(line), "%d lstm %d%s: gemm + lstm_layer_kernel<%d,true> (weight streaming)\n", li, H, d.reverse ? " rev" : "", H / 32);
                 break;
@@ -766,7 +770,7 @@ extern "C" int bh_encoder_forward(bh_encoder_t* e, const void* signal, int N, in
         const Layer* nx = nullptr;
         for (size_t j = i + 1; j < nl && !nx; ++j)
             if (e->layers[j].d.kind == BH_LAYER_LSTM) nx = &e->layers[j];
-        if (!nx || lstm_path(e, *nx).cta || lstm_path(e, *nx).q8 || lstm_path(e, *nx).wgx) return 0;   // those exchange elsewhere: nothing to pre-fill
+        if (!nx || lstm_path(e, *nx).cta || lstm_path(e, *nx).q8 || lstm_path(e, *nx).wgx || lstm_path(e, *nx).widex) return 0;   // those exchange elsewhere: nothing to pre-fill
         if (!e->fill_stream) BH_CHECK_HIP(hipStreamCreateWithFlags(&e->fill_stream, hipStreamNonBlocking));
         void* spare = e->act[(which + 1) % 3].p;
         BH_CHECK_HIP(hipEventRecord(e->fill_ready, st));
@@ -870,7 +874,7 @@ extern "C" int bh_encoder_forward(bh_encoder_t* e, const void* signal, int N, in
                                      d.in_size, d.in_size, d.in_size, 4 * H, bh::ACT_NONE, 1.0f, -INFINITY, INFINITY, 0, 0, 0, 0, 0, st);
                     if (rc) return rc;
                 }
-                if (!cta && !lp.wgx) {      // exchange sentinel in the output tensor (the ring-in-a-workgroup kernel exchanges through
+                if (!cta && !lp.wgx && !lp.widex) {      // exchange sentinel in the output tensor (the ring-in-a-workgroup kernel exchanges through
                                             // LDS only, the ring-buffer kernel through its own armed buffer)
                     if (e->prefilled == dst) {          // filled beside the previous layer's kernel
                         BH_CHECK_HIP(hipStreamWaitEvent(st, e->fill_done, 0));
@@ -898,7 +902,8 @@ extern "C" int bh_encoder_forward(bh_encoder_t* e, const void* signal, int N, in
                     const size_t col = (size_t)r0 * ring_chunks;
                     if (wide)
                         rc = bh_k_lstm_layer_wide((const char*)e->gates.p + col * 4 * H * 2, l.w3.p, (char*)dst + col * H * 2, len, Np, H,
-                                                  d.reverse, (int*)e->err.p, st, nr, (int*)e->lstm_ws.p, e->lstm_force_slow);
+                                                  d.reverse, (int*)e->err.p, st, nr, (int*)e->lstm_ws.p, e->lstm_force_slow,
+                                                  lp.widex ? (char*)e->ex16.p + (size_t)r0 * 2 * (H / 32) * 1024 : nullptr, n_rings, r0 == 0);
                     else if (cta)
                         rc = bh_k_lstm_layer_cta((const char*)cur + col * H * 2, l.w4.p, (const float*)l.b0.p, l.w3.p,
                                                  (char*)dst + col * H * 2, len, Np, H, d.reverse, st, nr);

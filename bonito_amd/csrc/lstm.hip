@@ -1090,9 +1090,15 @@ __global__ __launch_bounds__(64 * (NKS * 32 / (4 * MT)), 1) void lstm_layer_cta_
 struct LstmWideArgs {
     const half_t* G;      // [T][N][4H], columns permuted as above, bias included
     LstmArgs a;
+    char* ex;             // RX: exchange ring buffer [4][R][NB*NKS][64][16], armed with 0xFF
+    int R;                // RX: ring stride of `ex`
 };
 
-template <int NKS>
+// RX (round 2, default): hand-off through an L2-resident ring buffer in fragment order, exactly as lstm_layer_wgx_kernel (the
+// protocol and its argument are stated there): a workgroup's poll of its ring tile (64 KiB at H = 1024) becomes 64 coalesced KiB
+// instead of 1024 half-line pieces of a row-major tensor, the sentinel fill of the output tensor disappears, and the output
+// tensor is written by a second plain store. Same arithmetic -> same bytes as RX = false (tested).
+template <int NKS, bool RX>
 __global__ __launch_bounds__(256, 1) void lstm_layer_wide_kernel(LstmWideArgs wp) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const LstmArgs& p = wp.a;
@@ -1132,8 +1138,12 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_wide_kernel(LstmWideArgs wp
 
     int t = p.reverse ? p.T - 1 : 0;
     const int dt = p.reverse ? -1 : 1;
+    constexpr int TILE = NF * 1024;
+    const long slot_stride = RX ? (long)wp.R * TILE : 0;
+    char* exr = RX ? wp.ex + (long)ring * TILE : nullptr;
     // fragment f = nb*NKS + ks of the ring tile: chunk = ring*32 + nb*16 + c, units ks*32 + q*8 ..
     auto frag_voff = [&](int f) -> unsigned {
+        if constexpr (RX) return (unsigned)(f * 1024 + lo);
         const int nb = f / NKS, ks = f - nb * NKS;
         return (unsigned)((((ring * NB + nb) * 16 + c) * H + ks * 32 + q * 8) * 2);
     };
@@ -1156,8 +1166,8 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_wide_kernel(LstmWideArgs wp
         const int par = step & 1;
         // ---- B. my quarter of the ring's h_{t-1} tile (round one went out right after the previous store) --------
         if (step > 0) {
-            const char* base = (const char*)p.h + (long)(t - dt) * row_bytes;
-            __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)row_bytes, 0x00020000);
+            const char* base = RX ? exr + (long)((step - 1) & 3) * slot_stride : (const char*)p.h + (long)(t - dt) * row_bytes;
+            __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, RX ? TILE : (int)row_bytes, 0x00020000);
             unsigned spins = dead ? p.max_spins : 0u;
             unsigned pend = 0;
 #pragma unroll
@@ -1238,14 +1248,30 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_wide_kernel(LstmWideArgs wp
                 const unsigned long long packed = *(const u64_alias_t*)((half_t*)stage + cc * U + part * 4);
                 unsigned long long* dst =
                     (unsigned long long*)(p.h + ((long)t * p.N + (ring * NB + nb) * 16 + cc) * H + slice * U + part * 4);
-                if (fast) *dst = packed;
-                else __hip_atomic_store(dst, packed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if constexpr (RX) {
+                    const int u0 = slice * U + part * 4;
+                    const int my_byte = (((nb * NKS + (u0 >> 5)) * 64 + ((u0 >> 3) & 3) * 16 + cc) << 4) + (u0 & 7) * 2;
+                    // the re-arm store of the previous step must be complete before anything newer is published (lstm_layer_wgx_kernel)
+                    if (nb == 0) __builtin_amdgcn_s_waitcnt(0x0F70);
+                    unsigned long long* xd = (unsigned long long*)(exr + (long)(step & 3) * slot_stride + my_byte);
+                    if (fast) *xd = packed;
+                    else __hip_atomic_store(xd, packed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (step >= 2 && step + 2 < p.T) {
+                        unsigned long long* ra = (unsigned long long*)(exr + (long)((step + 2) & 3) * slot_stride + my_byte);
+                        if (fast) *ra = ~0ull;
+                        else __hip_atomic_store(ra, ~0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                    *dst = packed;              // the layer output proper
+                } else {
+                    if (fast) *dst = packed;
+                    else __hip_atomic_store(dst, packed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
             }
         }
         // ---- F. first poll round for h_t ---------------------------------------------------------------------------
         if (step + 1 < p.T) {
-            const char* base = (const char*)p.h + (long)t * row_bytes;
-            __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)row_bytes, 0x00020000);
+            const char* base = RX ? exr + (long)(step & 3) * slot_stride : (const char*)p.h + (long)t * row_bytes;
+            __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, RX ? TILE : (int)row_bytes, 0x00020000);
 #pragma unroll
             for (int kk = 0; kk < KQ; ++kk) {
                 const int f = wave + 4 * kk;
@@ -1522,8 +1548,11 @@ int bh_k_lstm_layer_cta(const void* x, const void* wih_tiles, const float* bias,
 // Wide layers: stationary W_hh, rings of 32 chunks; the caller provides G with permuted columns (bh_k_lstm_wide_permute).
 int bh_k_lstm_wide_ok(int H) { return H > 512 && H <= 1024 && H % 128 == 0; }
 
+size_t bh_k_lstm_wide_ex_bytes(int N, int H) { return (size_t)4 * (N / 32) * 2 * (H / 32) * 1024; }
+
+// ex != nullptr: ring-buffer exchange (R = rings of the whole batch, `arm` = fill it with the sentinel first: once per layer)
 int bh_k_lstm_layer_wide(const void* gates_perm, const void* whh_tiles, void* h_out, int T, int N, int H, int reverse,
-                         int* err_flag, hipStream_t stream, int n_rings, int* xcc_ws, int force_slow) {
+                         int* err_flag, hipStream_t stream, int n_rings, int* xcc_ws, int force_slow, void* ex, int R, int arm) {
     using namespace bh;
     BH_REQUIRE(bh_k_lstm_wide_ok(H), "lstm: wide kernel does not cover H=%d", H);
     BH_REQUIRE(N % 32 == 0, "lstm: wide kernel needs the batch padded to a multiple of 32 (N=%d)", N);
@@ -1539,14 +1568,20 @@ int bh_k_lstm_layer_wide(const void* gates_perm, const void* whh_tiles, void* h_
     BH_CHECK_HIP(hipMemsetAsync(xcc_ws, 0xFF, (size_t)n_rings * nsl * sizeof(int), stream));
     LstmWideArgs a{(const half_t*)gates_perm,
                    LstmArgs{nullptr, (const half_t*)whh_tiles, (half_t*)h_out, T, N, H, n_rings, reverse, err_flag, g_max_spins, xcc_ws,
-                            force_slow & 1, force_slow >> 8}};
+                            force_slow & 1, force_slow >> 8},
+                   (char*)ex, R};
     const int nks = H / 32;
+    if (ex && arm) BH_CHECK_HIP(hipMemsetAsync(ex, 0xFF, (size_t)4 * R * 2 * nks * 1024, stream));
     const size_t lds = (size_t)2 * 2 * nks * 1024 + 4 * 16 * 8 * 2;
 #define BH_LSTM_WIDE(NKS)                                                                                               \
-    if (nks == NKS) {                                                                                                   \
-        BH_CHECK_HIP(hipFuncSetAttribute((const void*)lstm_layer_wide_kernel<NKS>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+    if (nks == NKS && ex) {                                                                                             \
+        BH_CHECK_HIP(hipFuncSetAttribute((const void*)lstm_layer_wide_kernel<NKS, true>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                          (int)lds));                                                                    \
-        hipLaunchKernelGGL((lstm_layer_wide_kernel<NKS>), dim3(grid), dim3(256), lds, stream, a);                        \
+        hipLaunchKernelGGL((lstm_layer_wide_kernel<NKS, true>), dim3(grid), dim3(256), lds, stream, a);                  \
+    } else if (nks == NKS) {                                                                                            \
+        BH_CHECK_HIP(hipFuncSetAttribute((const void*)lstm_layer_wide_kernel<NKS, false>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                         (int)lds));                                                                    \
+        hipLaunchKernelGGL((lstm_layer_wide_kernel<NKS, false>), dim3(grid), dim3(256), lds, stream, a);                 \
     } else
     BH_LSTM_WIDE(20) BH_LSTM_WIDE(24) BH_LSTM_WIDE(28) BH_LSTM_WIDE(32)
     { BH_REQUIRE(false, "lstm: wide kernel has no instance for H=%d", H); }

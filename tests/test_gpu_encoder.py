@@ -228,14 +228,19 @@ def test_wide_lstm_models(H, batch):
     with torch.no_grad():
         want = nn_ref.forward(model, x.float(), expand_blanks=False).permute(1, 0, 2)
     outs = {}
-    for wide in (1, 0):
+    for wide in (1, 0, -1):
         if wide == 0 and H % 64 != 0:
             continue
         enc = HipEncoder(model, batchsize=batch, chunksize=600)
-        enc.set_option("lstm_wide", wide)
+        enc.set_option("lstm_wide", abs(wide))
+        if wide < 0:
+            enc.set_option("lstm_exchange", 0)      # round-1 hand-off through the sentinel-filled output tensor
+        else:
+            assert wide == 0 or "lstm_layer_wide_kernel<%d,true>" % (H // 32) in enc.describe()
         outs[wide] = enc(x.cuda()).cpu().float()
         enc.check()
         assert (outs[wide] - want).abs().max().item() < TOL_MAX, wide
+    assert torch.equal(outs[1], outs[-1])           # ring-buffer exchange == exchange through the output tensor
     if 0 in outs:      # the streaming kernel adds G after the recurrent product, the stationary one starts from G: fp32 order differs
         assert (outs[1] - outs[0]).abs().max().item() < 2e-3
 
