@@ -472,7 +472,9 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_wg_kernel(LstmFusedArgs fp)
     const int xcd = blockIdx.x & 7;
     const int lwg = blockIdx.x >> 3;
     const int rl = lwg / WPR;
-    const int ring = rl * 8 + xcd;
+    // test hook ("lstm_tune" bit 5): spread the workgroups of every ring over all eight XCDs, so that the placement-independent
+    // (write-through) hand-off really crosses XCDs
+    const int ring = rl * 8 + ((p.tune & 32) ? ((xcd + (lwg - rl * WPR)) & 7) : xcd);
     const int slice = (lwg - rl * WPR) * 4 + wave;
     if (ring >= p.n_rings) return;                      // whole workgroup (same ring) leaves together
 
@@ -755,7 +757,9 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_wgx_kernel(LstmWgxArgs wp) 
     const int xcd = blockIdx.x & 7;
     const int lwg = blockIdx.x >> 3;
     const int rl = lwg / WPR;
-    const int ring = rl * 8 + xcd;
+    // test hook ("lstm_tune" bit 5): spread the workgroups of every ring over all eight XCDs, so that the placement-independent
+    // (write-through) hand-off really crosses XCDs
+    const int ring = rl * 8 + ((p.tune & 32) ? ((xcd + (lwg - rl * WPR)) & 7) : xcd);
     const int slice = (lwg - rl * WPR) * 4 + wave;
     if (ring >= p.n_rings) return;
 
@@ -1111,7 +1115,9 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_wide_kernel(LstmWideArgs wp
     const int xcd = blockIdx.x & 7;
     const int lwg = blockIdx.x >> 3;
     const int rl = lwg / WPR;
-    const int ring = rl * 8 + xcd;
+    // test hook ("lstm_tune" bit 5): spread the workgroups of every ring over all eight XCDs, so that the placement-independent
+    // (write-through) hand-off really crosses XCDs
+    const int ring = rl * 8 + ((p.tune & 32) ? ((xcd + (lwg - rl * WPR)) & 7) : xcd);
     const int slice = (lwg - rl * WPR) * 4 + wave;
     if (ring >= p.n_rings) return;
 

@@ -111,7 +111,9 @@ __global__ __launch_bounds__(256, WPS) void lstm_layer_q8_kernel(LstmQ8Args p) {
     const int xcd = blockIdx.x & 7;
     const int lwg = blockIdx.x >> 3;
     const int rl = lwg / WPR;
-    const int ring = rl * 8 + xcd;
+    // test hook ("lstm_tune" bit 5): spread the workgroups of every ring over all eight XCDs, so that the placement-independent
+    // (write-through) hand-off really crosses XCDs
+    const int ring = rl * 8 + ((p.tune & 32) ? ((xcd + (lwg - rl * WPR)) & 7) : xcd);
     const int slice = (lwg - rl * WPR) * 4 + wave;
     if (ring >= p.n_rings) return;                      // whole workgroup (same ring) leaves together
 

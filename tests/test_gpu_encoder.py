@@ -271,3 +271,24 @@ def test_full_size_hac_encoder_kernel_variants_bit_identical():
     assert torch.equal(outs[0], outs[2])
     assert torch.equal(outs[0], outs[3])
     assert torch.equal(outs[0], outs[4])
+
+
+@pytest.mark.parametrize("quantize", [False, True])
+def test_ring_exchange_across_xcds_gives_the_same_bytes(quantize):
+    """The hand-off of the recurrent kernels must not depend on workgroup -> XCD placement. "lstm_tune" bit 5 spreads the
+    eight workgroups of every ring over all eight XCDs: the XCD agreement then selects the write-through policy and every poll
+    crosses XCDs (re-used ring-buffer addresses included). Same bytes as the co-located default, no timeout. hac-shaped model at
+    a batch that fills the chip, and the wide (1024) kernel."""
+    from bonito_amd import synthetic
+    cases = [("hac", 512, 2400)] + ([] if quantize else [("sup_lstm", 256, 1200)])
+    for name, N, L in cases:
+        model = synthetic.make_model(name, batchsize=N, chunksize=L)
+        x = torch.randn(N, 1, L, generator=torch.Generator().manual_seed(7)).half().cuda()
+        outs = []
+        for tune in (0, 32):
+            enc = HipEncoder(model.encoder, batchsize=N, chunksize=L, quantize=quantize)
+            enc.set_option("lstm_tune", tune)
+            outs.append(enc(x))
+            enc.check()
+            enc.close()
+        assert torch.equal(outs[0], outs[1]), name
