@@ -7,7 +7,7 @@ from bonito_amd import _lib, decode
 INF = float("inf")
 dev = torch.device("cuda", 0)
 shapes = [(256000, 1536, 512, 0), (256000, 512, 512, 0), (256000, 4096, 512, 1), (256000, 512, 2048, 0),
-          (256000, 1024, 512, 0), (512000, 4096, 512, 0), (853504, 1024, 384, 0)]
+          (256000, 1024, 512, 0), (512000, 4096, 512, 0), (853504, 1024, 384, 0), (853504, 4096, 1024, 0)]
 if len(sys.argv) > 1:
     shapes = [tuple(int(v) for v in a.split(",")) for a in sys.argv[1:]]
 lib = _lib.lib()
@@ -31,5 +31,16 @@ for M, N, K, gated in shapes:
         ms = e0.elapsed_time(e1) / 10
         res[path] = (ms, 2.0 * M * N * K / ms / 1e9)
     decode.set_option("gemm_path", 0)
-    print("M=%d N=%d K=%d gated=%d: auto %.3f ms %.0f TF/s | 128-tile %.3f ms %.0f TF/s" % (M, N, K, gated, res[0][0], res[0][1], res[2][0], res[2][1]))
+    # yardstick: the vendor library behind torch.matmul (hipBLASLt / rocBLAS), plain GEMM without the fused epilogue
+    full = torch.empty((M, N), dtype=torch.float16, device=dev)
+    for _ in range(3): torch.matmul(x, w.t(), out=full)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(10): torch.matmul(x, w.t(), out=full)
+    e1.record(); torch.cuda.synchronize()
+    lib_ms = e0.elapsed_time(e1) / 10
+    del full
+    print("M=%d N=%d K=%d gated=%d: auto %.3f ms %.0f TF/s | 128-tile %.3f ms %.0f TF/s | torch.matmul %.3f ms %.0f TF/s" % (
+        M, N, K, gated, res[0][0], res[0][1], res[2][0], res[2][1], lib_ms, 2.0 * M * N * K / lib_ms / 1e9))
     del x, w, out
