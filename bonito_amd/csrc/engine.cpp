@@ -183,6 +183,7 @@ struct bh_encoder {
     int lstm_prefill = 1;
     DevBuf q_act[2], q_ex;                 // 8-bit recurrent path: int8 activations in fragment order, exchange ring buffer
     DevBuf ex16;                           // fp16 workgroup-shared kernel: exchange ring buffer (lstm_layer_wgx_kernel)
+    int lstm_pair = 1;                     // batches of more rings than one launch holds: two rings per workgroup instead of two launches
     int lstm_exchange = 1;                 // 1: hand-off through the ring buffer (no sentinel fill of the output tensor), 0: through the output
     int lstm_q8 = 1;                       // 0: run quantised layers through the fp16 kernels (A/B)
     DevBuf res;                            // pending residual projection of a QuartzNet block
@@ -897,10 +898,16 @@ extern "C" int bh_encoder_forward(bh_encoder_t* e, const void* signal, int N, in
                 const int rings_per_launch = wide ? wide_fit * 8 : cta ? (1 << 20) : wg ? groups_fit * 8 : reg_path ? groups_fit * 32 : groups_fit * 8;
                 const int ring_chunks = wide ? 32 : 16;
                 const int n_rings = Np / ring_chunks;
-                for (int r0 = 0; r0 < n_rings; r0 += rings_per_launch) {
-                    const int nr = std::min(rings_per_launch, n_rings - r0);
+                for (int r0 = 0; r0 < n_rings;) {
+                    // more rings than one launch holds: the ring-buffer kernel carries two rings per workgroup (lstm_layer_wgx2_kernel)
+                    const bool pair = lp.wgx && e->lstm_pair && n_rings - r0 > rings_per_launch;
+                    const int nr = std::min(pair ? 2 * rings_per_launch : rings_per_launch, n_rings - r0);
                     const size_t col = (size_t)r0 * ring_chunks;
-                    if (wide)
+                    if (pair)
+                        rc = bh_k_lstm_layer_wgx2((const char*)cur + col * H * 2, l.w4.p, (const float*)l.b0.p, l.w3.p,
+                                                  (char*)dst + col * H * 2, (char*)e->ex16.p + (size_t)r0 * (H / 32) * 1024, len, Np, H, n_rings,
+                                                  d.reverse, (int*)e->err.p, st, nr, (int*)e->lstm_ws.p, e->lstm_force_slow, r0 == 0);
+                    else if (wide)
                         rc = bh_k_lstm_layer_wide((const char*)e->gates.p + col * 4 * H * 2, l.w3.p, (char*)dst + col * H * 2, len, Np, H,
                                                   d.reverse, (int*)e->err.p, st, nr, (int*)e->lstm_ws.p, e->lstm_force_slow,
                                                   lp.widex ? (char*)e->ex16.p + (size_t)r0 * 2 * (H / 32) * 1024 : nullptr, n_rings, r0 == 0);
@@ -928,6 +935,7 @@ extern "C" int bh_encoder_forward(bh_encoder_t* e, const void* signal, int N, in
                                                     (char*)dst + col * H * 2, len, Np, H, d.reverse, (int*)e->err.p, st, nr,
                                                     (int*)e->lstm_ws.p, e->lstm_force_slow);
                     if (rc) return rc;
+                    r0 += nr;
                 }
                 cur = dst; which = (which + 1) % e->n_act; C = H;
                 break;
@@ -1248,6 +1256,7 @@ extern "C" int bh_encoder_set_option(bh_encoder_t* e, const char* name, int valu
     if (!strcmp(name, "lstm_prefill")) { e->lstm_prefill = value; return 0; }
     if (!strcmp(name, "lstm_q8")) { e->lstm_q8 = value; return 0; }
     if (!strcmp(name, "lstm_exchange")) { e->lstm_exchange = value; return 0; }
+    if (!strcmp(name, "lstm_pair")) { e->lstm_pair = value; return 0; }
     if (!strcmp(name, "gemm_v1")) { bh_k_linear_force_v1(value); return 0; }   // process-wide A/B switch
     if (!strcmp(name, "lstm_tune")) { e->lstm_force_slow = (e->lstm_force_slow & 1) | (value << 8); return 0; }
     BH_REQUIRE(false, "encoder_set_option: unknown option '%s'", name);

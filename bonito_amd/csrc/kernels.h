@@ -109,3 +109,6 @@ size_t bh_k_lstm_wgx_ex_bytes(int N, int H);
 int bh_k_lstm_layer_wgx(const void* x, const void* wih_tiles, const float* bias, const void* whh_tiles, void* h_out, void* ex, int T,
                         int N, int H, int R, int reverse, int* err_flag, hipStream_t stream, int n_rings, int* xcc_ws, int force_slow,
                         int arm);
+int bh_k_lstm_layer_wgx2(const void* x, const void* wih_tiles, const float* bias, const void* whh_tiles, void* h_out, void* ex, int T,
+                        int N, int H, int R, int reverse, int* err_flag, hipStream_t stream, int n_rings, int* xcc_ws, int force_slow,
+                        int arm);      // two rings per workgroup: n_rings up to twice as many

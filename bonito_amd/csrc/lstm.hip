@@ -31,6 +31,7 @@
 //     fp32 registers for the whole layer, 8-byte packed h stores.
 // All spins are bounded; on timeout the kernel raises *err_flag and keeps going (never hangs).
 #include <string.h>
+#include <type_traits>
 
 #include "common.h"
 #include "kernels.h"
@@ -968,6 +969,410 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_wgx_kernel(LstmWgxArgs wp) 
 }
 
 // ---------------------------------------------------------------------------------------------------
+// "wgx2": lstm_layer_wgx_kernel serving TWO rings per workgroup with ONE register-resident copy of the weights. A batch of
+// more than 32 rings (N > 512 chunks at H = 384) does not fit the chip one ring per 8 workgroups; instead of a second launch
+// the workgroups of ring p also carry ring p + n_pairs and alternate between them: while the hand-off of one ring is in flight
+// (publish -> L2 -> poll) the wave runs the whole step of the other ring, so nothing waits for the exchange. Arithmetic,
+// accumulation order and lstm_cell() are those of the single-ring kernel: same bytes.
+//   * Nothing of the exchange lives in registers while in flight: the first poll round is an LDS-DMA (global_load_lds, sc0 sc1)
+//     straight into the NEXT parity of the ring's h tile; the wave later reads its quarter back to validate it. (With polls into
+//     VGPRs the compiler copies / re-uses the in-flight destination registers across the loop back edge and waits for them there.)
+//   * Every wait on the vector-memory queue is explicit: the wave counts the operations it has issued behind a ring's polls (the
+//     other ring's x-stream DMA, its three stores, its polls) and waits with exactly that vmcnt - the queue retires in order.
+//   * One workgroup barrier per ring step. LDS: 2 rings x (2 h tiles + 2 x tiles): the x slot consumed by step s is refilled
+//     (x_{s+2}) behind the ring's next barrier, two ring steps before it is needed.
+__device__ __forceinline__ void dma16_poll(const char* g, char* lds) {
+    const unsigned l = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)(__attribute__((address_space(3))) char*)lds);
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off sc0 sc1" ::"s"(l), "v"(g) : "memory");
+}
+__device__ __forceinline__ void wait_vm(int n) {       // s_waitcnt vmcnt(n), n wave-uniform; a smaller count than necessary is always safe
+    switch (n) {
+        case 0: __builtin_amdgcn_s_waitcnt(0x0F70); break;
+        case 1: __builtin_amdgcn_s_waitcnt(0x0F71); break;
+        case 2: __builtin_amdgcn_s_waitcnt(0x0F72); break;
+        case 3: __builtin_amdgcn_s_waitcnt(0x0F73); break;
+        case 4: __builtin_amdgcn_s_waitcnt(0x0F74); break;
+        case 5: __builtin_amdgcn_s_waitcnt(0x0F75); break;
+        case 6: __builtin_amdgcn_s_waitcnt(0x0F76); break;
+        case 7: __builtin_amdgcn_s_waitcnt(0x0F77); break;
+        case 8: __builtin_amdgcn_s_waitcnt(0x0F78); break;
+        case 9: __builtin_amdgcn_s_waitcnt(0x0F79); break;
+        case 10: __builtin_amdgcn_s_waitcnt(0x0F7A); break;
+        case 11: __builtin_amdgcn_s_waitcnt(0x0F7B); break;
+        default: __builtin_amdgcn_s_waitcnt(0x0F7C); break;     // 12
+    }
+    asm volatile("" ::: "memory");
+}
+
+// lstm_cell() of one unit with twelve MFMAs of the NEXT step's input projection threaded through it (H = 384: k-steps ks0..ks0+3 of the
+// three M tiles), one MFMA to about three vector instructions: a wave issues in order, so the vector ALU only works in the shadow of
+// the matrix core if the two kinds of instruction alternate in the instruction stream - which the compiler does not do for
+// inline-asm MFMAs, and not for builtin ones either. The arithmetic is lstm_cell()'s, operation for operation and rounding for
+// rounding (packed or scalar fp32 operations round identically): the same bits as the compiled function (tested against the
+// single-ring kernel). Hand-placed hazards: no use of a transcendental result in the next instruction, two wait states between
+// v_cmp and v_cndmask; the MFMA operands all come from outside the block.
+__device__ __forceinline__ void cell_mfma_a(float ai, float af, float ag, float ao, float& u0, float& u1, float& u2, float& u3, float& eo,
+                                            const half8_t& w00, const half8_t& w10, const half8_t& w20, const half8_t& w01, const half8_t& w11,
+                                            const half8_t& w21, const half8_t& b0, const half8_t& b1, float4_t& x0, float4_t& x1, float4_t& x2) {
+    float t0, t1, t2;
+    asm("v_med3_f32 %0, %9, %21, %22\n\t"
+        "v_med3_f32 %1, %10, %21, %22\n\t"
+        "v_med3_f32 %2, %11, %23, %24\n\t"
+        "v_mfma_f32_16x16x32_f16 %6, %13, %19, %6\n\t"
+        "v_mul_f32 %0, 0xbfb8aa3b, %0\n\t"
+        "v_mul_f32 %1, 0xbfb8aa3b, %1\n\t"
+        "v_mul_f32 %2, -2.0, %2\n\t"
+        "v_mfma_f32_16x16x32_f16 %7, %14, %19, %7\n\t"
+        "v_mul_f32 %2, 0x3fb8aa3b, %2\n\t"
+        "v_med3_f32 %3, %12, %21, %22\n\t"
+        "v_mul_f32 %3, 0xbfb8aa3b, %3\n\t"
+        "v_mfma_f32_16x16x32_f16 %8, %15, %19, %8\n\t"
+        "v_exp_f32 %0, %0\n\t"
+        "v_exp_f32 %1, %1\n\t"
+        "v_mfma_f32_16x16x32_f16 %6, %16, %20, %6\n\t"
+        "v_exp_f32 %2, %2\n\t"
+        "v_exp_f32 %3, %3\n\t"
+        "v_mfma_f32_16x16x32_f16 %7, %17, %20, %7\n\t"
+        "v_add_f32 %4, 1.0, %0\n\t"
+        "v_add_f32 %5, 1.0, %1\n\t"
+        "v_mfma_f32_16x16x32_f16 %8, %18, %20, %8\n\t"
+        "v_sub_f32 %1, 1.0, %2\n\t"
+        "v_add_f32 %2, 1.0, %2"
+        : "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(eo), "=&v"(u0), "=&v"(u2), "+v"(x0), "+v"(x1), "+v"(x2)
+        : "v"(ai), "v"(af), "v"(ag), "v"(ao), "a"(w00), "a"(w10), "v"(w20), "a"(w01), "a"(w11), "v"(w21), "v"(b0), "v"(b1),
+          "v"(-25.0f), "v"(25.0f), "v"(-12.5f), "v"(12.5f));
+    u3 = t1;        // 1 - eg
+    u1 = t2;        // 1 + eg
+}
+// second half: u0 = 1+ei, u1 = 1+eg, u2 = 1+ef, u3 = 1-eg, eo = exp(-o); c in/out; returns h (fp32, already forced into [-1, 1])
+// LAST: the block ends with the wait states an MFMA result needs before the vector ALU may read it (the compiler knows nothing of
+// the MFMAs inside and would copy the accumulators right behind the block)
+template <bool LAST>
+__device__ __forceinline__ float cell_mfma_b(float u0, float u1, float u2, float u3, float eo, float& c,
+                                             const half8_t& w00, const half8_t& w10, const half8_t& w20, const half8_t& w01, const half8_t& w11,
+                                             const half8_t& w21, const half8_t& b0, const half8_t& b1, float4_t& x0, float4_t& x1, float4_t& x2) {
+    asm("v_mul_f32 %0, %0, %1\n\t"                       // didg
+        "v_mul_f32 %3, %3, %2\n\t"                       // (1 - eg) * df
+        "v_mfma_f32_16x16x32_f16 %6, %9, %15, %6\n\t"
+        "v_mul_f32 %1, %2, %0\n\t"                       // df * didg
+        "v_fma_f32 %3, %5, %0, %3\n\t"                   // num = c * didg + (1 - eg) * df
+        "v_rcp_f32 %1, %1\n\t"
+        "v_mfma_f32_16x16x32_f16 %7, %10, %15, %7\n\t"
+        "v_mul_f32 %5, %3, %1\n\t"                       // c'
+        "v_med3_f32 %0, %5, %17, %18\n\t"
+        "v_mul_f32 %0, -2.0, %0\n\t"
+        "v_mfma_f32_16x16x32_f16 %8, %11, %15, %8\n\t"
+        "v_mul_f32 %0, 0x3fb8aa3b, %0\n\t"
+        "v_exp_f32 %0, %0\n\t"                           // ec
+        "v_add_f32 %4, 1.0, %4\n\t"                      // 1 + eo
+        "v_mfma_f32_16x16x32_f16 %6, %12, %16, %6\n\t"
+        "v_add_f32 %1, 1.0, %0\n\t"                      // 1 + ec
+        "v_sub_f32 %0, 1.0, %0\n\t"                      // 1 - ec
+        "v_mul_f32 %1, %1, %4\n\t"
+        "v_mfma_f32_16x16x32_f16 %7, %13, %16, %7\n\t"
+        "v_rcp_f32 %1, %1\n\t"
+        "s_nop 1\n\t"
+        "v_mul_f32 %0, %0, %1\n\t"                       // hv
+        "v_cmp_le_f32_e64 vcc, |%0|, 1.0\n\t"
+        "v_mfma_f32_16x16x32_f16 %8, %14, %16, %8\n\t"
+        "s_nop 1\n\t"
+        "v_cndmask_b32_e32 %0, 0, %0, vcc\n\t"
+        "s_nop %19"
+        : "+v"(u0), "+v"(u1), "+v"(u2), "+v"(u3), "+v"(eo), "+v"(c), "+v"(x0), "+v"(x1), "+v"(x2)
+        : "a"(w00), "a"(w10), "v"(w20), "a"(w01), "a"(w11), "v"(w21), "v"(b0), "v"(b1), "v"(-12.5f), "v"(12.5f), "n"(LAST ? 15 : 0)
+        : "vcc");
+    if (LAST) asm volatile("s_nop 7" : "+v"(x0), "+v"(x1), "+v"(x2));
+    return u0;
+}
+
+template <int NKS, int MT>
+__global__ __launch_bounds__(256, 1) void lstm_layer_wgx2_kernel(LstmWgxArgs wp) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const LstmFusedArgs& fp = wp.f;
+    const LstmArgs& p = fp.a;
+    constexpr int H = NKS * 32, U = 4 * MT, NSL = H / U, WPR = NSL / 4, KQ = (NKS + 3) / 4, TILE = NKS * 1024;
+    constexpr bool EXACT = NKS % 4 == 0;
+    static_assert(H % (4 * U) == 0, "four slices per workgroup");
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int xcd = blockIdx.x & 7;
+    const int lwg = blockIdx.x >> 3;
+    const int rl = lwg / WPR;
+    const int n_pairs = (p.n_rings + 1) >> 1;
+    const int pair = rl * 8 + ((p.tune & 32) ? ((xcd + (lwg - rl * WPR)) & 7) : xcd);          // bit 5: test hook, see lstm_layer_wgx_kernel
+    const int slice = (lwg - rl * WPR) * 4 + wave;
+    if (pair >= n_pairs) return;
+    const int ring_of[2] = {pair, pair + n_pairs};
+    const bool two = ring_of[1] < p.n_rings;            // odd ring count: the last workgroups carry one ring (uniform over the ring)
+
+    char* hbuf = smem;                                  // [2 rings][2 parities][NKS][64][16]  B fragments of h_{t-1}
+    char* xbuf = smem + 4 * TILE;                       // [2 rings][2 slots][NKS][64][16]     B fragments of x_t
+    char* stage = smem + 8 * TILE + wave * (16 * U * 2);
+
+    half8_t whh[MT][NKS], wih[MT][NKS];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+            const long o = ((((long)slice * MT + m) * NKS + ks) * 64 + lane) * 8;
+            whh[m][ks] = *(const half8_t*)(p.whh + o);
+            wih[m][ks] = *(const half8_t*)(fp.wih + o);
+        }
+    const int c = lane & 15, q = lane >> 4;
+    float4_t bias4[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) bias4[m][i] = fp.bias[i * H + slice * U + q * MT + m];
+    bool dead = false;
+    const int dt = p.reverse ? -1 : 1;
+    const int t0 = p.reverse ? p.T - 1 : 0;
+    const long x_row = (long)p.N * H;
+    const int lo = lane * 16;
+    const long slot_stride = (long)wp.R * TILE;
+    constexpr int PARTS = U / 4;
+    const int ml = lane < 16 * PARTS ? lane : lane - 16 * PARTS;      // lanes beyond the movers mirror one (see the stores)
+    const int cc = ml / PARTS, part = ml - cc * PARTS;
+    const int u0 = slice * U + part * 4;
+    const int my_byte = (((u0 >> 5) * 64 + ((u0 >> 3) & 3) * 16 + cc) << 4) + (u0 & 7) * 2;      // inside a ring tile (fragment order)
+    int n_poll = 0, n_dma = 0;                          // instructions of one poll round / one x-stream share of this wave
+#pragma unroll
+    for (int kk = 0; kk < KQ; ++kk) {
+        n_poll += (EXACT || wave + 4 * kk < NKS) ? 1 : 0;
+        n_dma += (EXACT || (3 - wave) + 4 * kk < NKS) ? 1 : 0;
+    }
+
+    // per-ring state
+    float cst[2][MT];
+    float4_t xacc[2][MT];
+    bool fast[2];
+    const half_t* xptr[2];
+    char* exr[2];
+    int since[2] = {0, 0};                              // vector-memory operations this wave has issued behind ring r's first poll round
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int ring = (r == 0 || two) ? ring_of[r] : ring_of[0];
+        fast[r] = (r == 0 || two) ? ring_store_policy(p, ring, slice, NSL, lane) : false;
+        xptr[r] = fp.x + ((long)(ring * 16 + c) * H + q * 8);
+        exr[r] = wp.ex + (long)ring * TILE;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) cst[r][m] = 0.f;
+    }
+
+    auto x_phase = [&](const char* xb, float4_t (&xa)[MT]) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m) xa[m] = bias4[m];
+        half8_t b_cur = *(const half8_t*)(xb + lo), b_nxt = b_cur;
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+            if (ks + 1 < NKS) b_nxt = *(const half8_t*)(xb + (ks + 1) * 1024 + lo);
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                if (m < MT - 1) mfma16_av(wih[m][ks], b_cur, xa[m]);
+                else mfma16_vv(wih[m][ks], b_cur, xa[m]);
+            }
+            b_cur = b_nxt;
+        }
+        mfma_settle_v<MT>(xa);
+    };
+    auto x_dma = [&](const half_t* xp, char* xb, int tt, int slot) {
+#pragma unroll
+        for (int kk = 0; kk < KQ; ++kk) {
+            const int ks = (3 - wave) + 4 * kk;
+            if (EXACT || ks < NKS) dma16_wgx((const char*)(xp + (long)tt * x_row + ks * 32), xb + (slot * NKS + ks) * 1024);
+        }
+    };
+    // first poll round of ring r for the h published into exchange slot `slot`: my k-steps, straight into parity `par` of the h tile
+    auto poll_dma = [&](const char* exbase, int slot, char* hb, unsigned mask) {
+        const char* src = exbase + (long)slot * slot_stride + lo;
+#pragma unroll
+        for (int kk = 0; kk < KQ; ++kk) {
+            const int ks = wave + 4 * kk;
+            if ((EXACT || ks < NKS) && (mask & (1u << kk))) dma16_poll(src + ks * 1024, hb + ks * 1024);
+        }
+    };
+
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+        if (r == 0 || two) {
+            x_dma(xptr[r], xbuf + r * 2 * TILE, t0, 0);
+            x_dma(xptr[r], xbuf + r * 2 * TILE, p.T > 1 ? t0 + dt : t0, 1);
+        }
+    wait_vm(0);
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+        if (r == 0 || two) x_phase(xbuf + r * 2 * TILE, xacc[r]);
+
+    long long st_poll = 0, st_bar = 0;
+    const long long st_t0 = __builtin_readcyclecounter();
+    const long long st_r0 = (p.tune & 4) ? (long long)__builtin_amdgcn_s_memrealtime() : 0;
+
+    // validation of this wave's quarter of ring rr's h tile for step `st` (published in exchange slot (st-1)&3, landing in parity
+    // st&1): begin = wait for the first poll round + read it back, end = test it, re-poll what is still armed
+    auto check_begin = [&](int rr, int st, uint4_t (&chk)[KQ]) {
+        wait_vm(since[rr]);
+        const char* hb = hbuf + (rr * 2 + (st & 1)) * TILE;
+#pragma unroll
+        for (int kk = 0; kk < KQ; ++kk) {
+            const int ks = wave + 4 * kk;
+            if (EXACT || ks < NKS) chk[kk] = *(const uint4_t*)(hb + ks * 1024 + lo);
+        }
+    };
+    auto check_end = [&](int rr, int st, uint4_t (&chk)[KQ]) {
+        char* hb = hbuf + (rr * 2 + (st & 1)) * TILE;
+        unsigned spins = dead ? p.max_spins : 0u;
+        while (true) {
+            unsigned pend = 0;
+#pragma unroll
+            for (int kk = 0; kk < KQ; ++kk) {
+                const int ks = wave + 4 * kk;
+                if ((EXACT || ks < NKS) && __any(((chk[kk].x | chk[kk].y | chk[kk].z | chk[kk].w) & SENTINEL_MASK) != 0)) pend |= (1u << kk);
+            }
+            if (pend == 0) break;
+            if (++spins > p.max_spins) {
+                if (lane == 0 && !dead) atomicExch(p.err, 1);
+                dead = true;
+                break;
+            }
+            if (!(p.tune & 1)) __builtin_amdgcn_s_sleep(1);
+            poll_dma(exr[rr], (st - 1) & 3, hb, pend);
+            wait_vm(0);
+#pragma unroll
+            for (int kk = 0; kk < KQ; ++kk) {
+                const int ks = wave + 4 * kk;
+                if (EXACT || ks < NKS) chk[kk] = *(const uint4_t*)(hb + ks * 1024 + lo);
+            }
+        }
+    };
+
+    // one time step of ring r (r and TWO are compile-time constants: the per-ring state stays in registers)
+    auto ring_step = [&](auto rc, auto two_c, int step, int t) {
+        constexpr int r = decltype(rc)::value;
+        constexpr bool TWO = decltype(two_c)::value;
+        char* hb_r = hbuf + (r * 2 + (step & 1)) * TILE;
+        char* xb_r = xbuf + r * 2 * TILE;
+        float4_t acc[MT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) acc[m] = xacc[r][m];
+        // ---- my quarter of h_{t-1}. Two rings: it was validated in the middle of the other ring's section (below); a lone ring
+        //      does it here, with the round trip of the polls exposed ---------------------------------------------------------------
+        const long long pc0 = (p.tune & 4) ? __builtin_readcyclecounter() : 0;
+        if constexpr (!TWO) {
+            if (step > 0) {
+                uint4_t chk[KQ];
+                check_begin(r, step, chk);
+                check_end(r, step, chk);
+            } else {
+                wait_vm(0);
+            }
+        }
+        const long long pc1 = (p.tune & 4) ? __builtin_readcyclecounter() : 0;
+        __syncthreads();                         // the h tile (all quarters validated) and the x tile of this step are complete
+        if constexpr (!TWO) __syncthreads();     // (a lone ring: keeps the sections of consecutive steps apart like the other ring's barrier would)
+        const long long pc2 = (p.tune & 4) ? __builtin_readcyclecounter() : 0;
+        if (p.tune & 4) { st_poll += pc1 - pc0; st_bar += pc2 - pc1; }
+        // ---- x_{t+2} into the slot whose x_t the input projection of the previous step consumed -------------------------------
+        if (step + 2 < p.T) {
+            x_dma(xptr[r], xb_r, t + 2 * dt, step & 1);
+            since[0] += n_dma; since[1] += n_dma;
+        }
+        // ---- recurrent part ---------------------------------------------------------------------------------------------------
+        if (step > 0) {
+            half8_t hb_f[NKS];
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) hb_f[ks] = *(const half8_t*)(hb_r + lo + ks * 1024);
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks)
+#pragma unroll
+                for (int m = 0; m < MT; ++m) mfma16_av(whh[m][ks], hb_f[ks], acc[m]);
+            mfma_settle_v<MT>(acc);
+        }
+        // ---- gate arithmetic of this step; at H = 384 the input projection of the next step (independent work for the matrix
+        //      core) is threaded through it instruction by instruction (cell_mfma_a / _b) -------------------------------------------
+        constexpr bool WOVEN = NKS == 12 && MT == 3;
+        half_t ho[MT];
+        if constexpr (WOVEN) {
+            const char* xb = xb_r + ((step + 1) & 1) * TILE + lo;
+            float4_t xa[MT];
+#pragma unroll
+            for (int m = 0; m < MT; ++m) xa[m] = bias4[m];
+            auto woven = [&](auto mc) {
+                constexpr int m = decltype(mc)::value;
+                const half8_t b0 = *(const half8_t*)(xb + (4 * m + 0) * 1024), b1 = *(const half8_t*)(xb + (4 * m + 1) * 1024);
+                const half8_t b2 = *(const half8_t*)(xb + (4 * m + 2) * 1024), b3 = *(const half8_t*)(xb + (4 * m + 3) * 1024);
+                float u0, u1, u2, u3, eo;
+                cell_mfma_a(acc[m][0], acc[m][1], acc[m][2], acc[m][3], u0, u1, u2, u3, eo, wih[0][4 * m], wih[1][4 * m], wih[2][4 * m],
+                            wih[0][4 * m + 1], wih[1][4 * m + 1], wih[2][4 * m + 1], b0, b1, xa[0], xa[1], xa[2]);
+                const float hv = cell_mfma_b<(m == 2)>(u0, u1, u2, u3, eo, cst[r][m], wih[0][4 * m + 2], wih[1][4 * m + 2], wih[2][4 * m + 2],
+                                                       wih[0][4 * m + 3], wih[1][4 * m + 3], wih[2][4 * m + 3], b2, b3, xa[0], xa[1], xa[2]);
+                ho[m] = (half_t)hv;
+            };
+            woven(std::integral_constant<int, 0>{});
+            woven(std::integral_constant<int, 1>{});
+            woven(std::integral_constant<int, 2>{});
+#pragma unroll
+            for (int m = 0; m < MT; ++m) xacc[r][m] = xa[m];
+        } else {
+#pragma unroll
+            for (int m = 0; m < MT; ++m) ho[m] = (half_t)lstm_cell(acc[m][0], acc[m][1], acc[m][2], acc[m][3], cst[r][m]);
+        }
+        {
+            u16_alias_t* sg = (u16_alias_t*)stage + c * U + q * MT;
+#pragma unroll
+            for (int m = 0; m < MT; ++m) sg[m] = __builtin_bit_cast(unsigned short, ho[m]);
+            // every lane stores (lanes beyond the movers repeat a mover's store: same address, same bytes) and the re-arm is
+            // unconditional (before step 2 it re-arms slots that are still armed, in the last two steps slots nobody reads any
+            // more): always three stores per section, so the operation count behind a poll round is a constant
+            const unsigned long long packed = *(const u64_alias_t*)((half_t*)stage + cc * U + part * 4);
+            unsigned long long* dst = (unsigned long long*)(exr[r] + (long)(step & 3) * slot_stride + my_byte);
+            unsigned long long* ra = (unsigned long long*)(exr[r] + (long)((step + 2) & 3) * slot_stride + my_byte);
+            if (fast[r]) { *dst = packed; *ra = ~0ull; }
+            else {
+                __hip_atomic_store(dst, packed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(ra, ~0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            *(unsigned long long*)(p.h + ((long)t * p.N + ring_of[r] * 16 + cc) * H + slice * U + part * 4) = packed;
+            since[0] += 3; since[1] += 3;
+        }
+        // ---- input projection of step t+1; around it the validation of the OTHER ring's quarter for its next section: its polls
+        //      went out more than half a section ago, and the LDS latency of reading them back hides behind these MFMAs ------------
+        constexpr int o = r ^ 1;
+        const int step_o = r == 0 ? step : step + 1;
+        const bool chk_o = TWO && step_o >= 1 && step_o < p.T;
+        uint4_t chk[KQ];
+        if (chk_o) check_begin(o, step_o, chk);
+        if constexpr (!WOVEN) x_phase(xb_r + ((step + 1) & 1) * TILE, xacc[r]);
+        if (chk_o) check_end(o, step_o, chk);
+        // ---- first poll round for h_t, last in the section: the publishes of the other workgroups are visible by now, and it is
+        //      looked at only after the other ring's section. It lands in the OTHER parity of the h tile: the waves of this
+        //      workgroup may still be reading the current one ---------------------------------------------------------------------
+        if (step + 1 < p.T) {
+            poll_dma(exr[r], step & 3, hbuf + (r * 2 + ((step + 1) & 1)) * TILE, 0xFFu);
+            since[r] = 0;
+            since[r ^ 1] += n_poll;
+        }
+    };
+
+    auto run = [&](auto two_c) {
+        int t = t0;
+        for (int step = 0; step < p.T; ++step, t += dt) {
+            ring_step(std::integral_constant<int, 0>{}, two_c, step, t);
+            if constexpr (decltype(two_c)::value) ring_step(std::integral_constant<int, 1>{}, two_c, step, t);
+        }
+    };
+    if (two) run(std::true_type{});
+    else run(std::false_type{});
+    if ((p.tune & 4) && lane == 0) {
+        long long* st = (long long*)((char*)p.xcc_ws + (((size_t)p.n_rings * NSL * sizeof(int) + 64 + 7) & ~(size_t)7)) + ((long)ring_of[0] * NSL + slice) * 16;
+        st[0] = __builtin_readcyclecounter() - st_t0;
+        st[1] = st_poll; st[2] = 0; st[3] = 0; st[4] = 0; st[5] = st_bar; st[6] = 0; st[7] = 0;
+        st[8] = 0; st[9] = 0; st[10] = 0; st[11] = 0; st[12] = 0;
+        st[13] = (long long)__builtin_amdgcn_s_memrealtime() - st_r0;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // Ring-in-a-workgroup variant ("cta") for narrow layers (H = 64 / 96 / 128, e.g. the `fast` models): all H/U slices
 // of a ring are waves of ONE workgroup, both weight sets are register-resident, and h never leaves the CU on its way
 // to the next step - every wave drops its MT units straight into the LDS tile in B-fragment order, one workgroup
@@ -1521,6 +1926,48 @@ int bh_k_lstm_layer_wgx(const void* x, const void* wih_packed, const float* bias
     BH_LSTM_WGX(2, 4) BH_LSTM_WGX(4, 4) BH_LSTM_WGX(8, 4)
     { BH_REQUIRE(false, "lstm: workgroup-shared kernel has no instance for H=%d", H); }
 #undef BH_LSTM_WGX
+    BH_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// Two rings per workgroup (lstm_layer_wgx2_kernel): n_rings may be up to twice what one ring per 8 * H/(4U) workgroups allows.
+int bh_k_lstm_layer_wgx2(const void* x, const void* wih_packed, const float* bias, const void* whh_packed, void* h_out, void* ex,
+                         int T, int N, int H, int R, int reverse, int* err_flag, hipStream_t stream, int n_rings, int* xcc_ws,
+                         int force_slow, int arm) {
+    using namespace bh;
+    BH_REQUIRE(N % 16 == 0, "lstm: batch must be padded to a multiple of 16 (N=%d)", N);
+    const int U = bh_k_lstm_wg_units(H);
+    BH_REQUIRE(U != 0, "lstm: workgroup-shared kernel does not cover H=%d", H);
+    BH_REQUIRE(x != h_out && ex != nullptr, "lstm: fused layer cannot run in place / missing exchange buffer");
+    int dev = 0, cus = 0;
+    BH_CHECK_HIP(hipGetDevice(&dev));
+    BH_CHECK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    const int nsl = H / U, wpr = nsl / 4;
+    BH_REQUIRE(n_rings > 0 && n_rings <= R, "lstm: n_rings=%d outside 1..%d", n_rings, R);
+    const int n_pairs = (n_rings + 1) / 2;
+    const int rl = (n_pairs + 7) / 8;
+    const int grid = 8 * rl * wpr;
+    BH_REQUIRE(grid <= cus, "lstm: %d workgroups must be co-resident but the device has %d CUs; split the batch", grid, cus);
+    BH_REQUIRE(xcc_ws != nullptr, "lstm: missing XCD agreement workspace");
+    BH_CHECK_HIP(hipMemsetAsync(xcc_ws, 0xFF, (size_t)n_rings * nsl * sizeof(int), stream));
+    const int nks = H / 32;
+    if (arm) BH_CHECK_HIP(hipMemsetAsync(ex, 0xFF, (size_t)4 * R * nks * 1024, stream));
+    LstmWgxArgs a{LstmFusedArgs{(const half_t*)x, (const half_t*)wih_packed, bias,
+                                LstmArgs{nullptr, (const half_t*)whh_packed, (half_t*)h_out, T, N, H, n_rings, reverse, err_flag,
+                                         g_max_spins, xcc_ws, force_slow & 1, force_slow >> 8}},
+                  (char*)ex, R};
+    const size_t lds = (size_t)8 * nks * 1024 + 4 * 16 * U * 2;
+#define BH_LSTM_WGX2(NKS, MT)                                                                                    \
+    if (nks == NKS && U == 4 * MT) {                                                                             \
+        if (lds > 64 * 1024)                                                                                     \
+            BH_CHECK_HIP(hipFuncSetAttribute((const void*)lstm_layer_wgx2_kernel<NKS, MT>,                       \
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));            \
+        hipLaunchKernelGGL((lstm_layer_wgx2_kernel<NKS, MT>), dim3(grid), dim3(256), lds, stream, a);             \
+    } else
+    BH_LSTM_WGX2(3, 3) BH_LSTM_WGX2(6, 3) BH_LSTM_WGX2(9, 3) BH_LSTM_WGX2(12, 3)
+    BH_LSTM_WGX2(2, 4) BH_LSTM_WGX2(4, 4) BH_LSTM_WGX2(8, 4)
+    { BH_REQUIRE(false, "lstm: workgroup-shared kernel has no instance for H=%d", H); }
+#undef BH_LSTM_WGX2
     BH_CHECK_HIP(hipGetLastError());
     return 0;
 }
