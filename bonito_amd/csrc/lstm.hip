@@ -1004,86 +1004,13 @@ __device__ __forceinline__ void wait_vm(int n) {       // s_waitcnt vmcnt(n), n 
     asm volatile("" ::: "memory");
 }
 
-// lstm_cell() of one unit with twelve MFMAs of the NEXT step's input projection threaded through it (H = 384: k-steps ks0..ks0+3 of the
-// three M tiles), one MFMA to about three vector instructions: a wave issues in order, so the vector ALU only works in the shadow of
-// the matrix core if the two kinds of instruction alternate in the instruction stream - which the compiler does not do for
-// inline-asm MFMAs, and not for builtin ones either. The arithmetic is lstm_cell()'s, operation for operation and rounding for
-// rounding (packed or scalar fp32 operations round identically): the same bits as the compiled function (tested against the
-// single-ring kernel). Hand-placed hazards: no use of a transcendental result in the next instruction, two wait states between
-// v_cmp and v_cndmask; the MFMA operands all come from outside the block.
-__device__ __forceinline__ void cell_mfma_a(float ai, float af, float ag, float ao, float& u0, float& u1, float& u2, float& u3, float& eo,
-                                            const half8_t& w00, const half8_t& w10, const half8_t& w20, const half8_t& w01, const half8_t& w11,
-                                            const half8_t& w21, const half8_t& b0, const half8_t& b1, float4_t& x0, float4_t& x1, float4_t& x2) {
-    float t0, t1, t2;
-    asm("v_med3_f32 %0, %9, %21, %22\n\t"
-        "v_med3_f32 %1, %10, %21, %22\n\t"
-        "v_med3_f32 %2, %11, %23, %24\n\t"
-        "v_mfma_f32_16x16x32_f16 %6, %13, %19, %6\n\t"
-        "v_mul_f32 %0, 0xbfb8aa3b, %0\n\t"
-        "v_mul_f32 %1, 0xbfb8aa3b, %1\n\t"
-        "v_mul_f32 %2, -2.0, %2\n\t"
-        "v_mfma_f32_16x16x32_f16 %7, %14, %19, %7\n\t"
-        "v_mul_f32 %2, 0x3fb8aa3b, %2\n\t"
-        "v_med3_f32 %3, %12, %21, %22\n\t"
-        "v_mul_f32 %3, 0xbfb8aa3b, %3\n\t"
-        "v_mfma_f32_16x16x32_f16 %8, %15, %19, %8\n\t"
-        "v_exp_f32 %0, %0\n\t"
-        "v_exp_f32 %1, %1\n\t"
-        "v_mfma_f32_16x16x32_f16 %6, %16, %20, %6\n\t"
-        "v_exp_f32 %2, %2\n\t"
-        "v_exp_f32 %3, %3\n\t"
-        "v_mfma_f32_16x16x32_f16 %7, %17, %20, %7\n\t"
-        "v_add_f32 %4, 1.0, %0\n\t"
-        "v_add_f32 %5, 1.0, %1\n\t"
-        "v_mfma_f32_16x16x32_f16 %8, %18, %20, %8\n\t"
-        "v_sub_f32 %1, 1.0, %2\n\t"
-        "v_add_f32 %2, 1.0, %2"
-        : "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(eo), "=&v"(u0), "=&v"(u2), "+v"(x0), "+v"(x1), "+v"(x2)
-        : "v"(ai), "v"(af), "v"(ag), "v"(ao), "a"(w00), "a"(w10), "v"(w20), "a"(w01), "a"(w11), "v"(w21), "v"(b0), "v"(b1),
-          "v"(-25.0f), "v"(25.0f), "v"(-12.5f), "v"(12.5f));
-    u3 = t1;        // 1 - eg
-    u1 = t2;        // 1 + eg
-}
-// second half: u0 = 1+ei, u1 = 1+eg, u2 = 1+ef, u3 = 1-eg, eo = exp(-o); c in/out; returns h (fp32, already forced into [-1, 1])
-// LAST: the block ends with the wait states an MFMA result needs before the vector ALU may read it (the compiler knows nothing of
-// the MFMAs inside and would copy the accumulators right behind the block)
-template <bool LAST>
-__device__ __forceinline__ float cell_mfma_b(float u0, float u1, float u2, float u3, float eo, float& c,
-                                             const half8_t& w00, const half8_t& w10, const half8_t& w20, const half8_t& w01, const half8_t& w11,
-                                             const half8_t& w21, const half8_t& b0, const half8_t& b1, float4_t& x0, float4_t& x1, float4_t& x2) {
-    asm("v_mul_f32 %0, %0, %1\n\t"                       // didg
-        "v_mul_f32 %3, %3, %2\n\t"                       // (1 - eg) * df
-        "v_mfma_f32_16x16x32_f16 %6, %9, %15, %6\n\t"
-        "v_mul_f32 %1, %2, %0\n\t"                       // df * didg
-        "v_fma_f32 %3, %5, %0, %3\n\t"                   // num = c * didg + (1 - eg) * df
-        "v_rcp_f32 %1, %1\n\t"
-        "v_mfma_f32_16x16x32_f16 %7, %10, %15, %7\n\t"
-        "v_mul_f32 %5, %3, %1\n\t"                       // c'
-        "v_med3_f32 %0, %5, %17, %18\n\t"
-        "v_mul_f32 %0, -2.0, %0\n\t"
-        "v_mfma_f32_16x16x32_f16 %8, %11, %15, %8\n\t"
-        "v_mul_f32 %0, 0x3fb8aa3b, %0\n\t"
-        "v_exp_f32 %0, %0\n\t"                           // ec
-        "v_add_f32 %4, 1.0, %4\n\t"                      // 1 + eo
-        "v_mfma_f32_16x16x32_f16 %6, %12, %16, %6\n\t"
-        "v_add_f32 %1, 1.0, %0\n\t"                      // 1 + ec
-        "v_sub_f32 %0, 1.0, %0\n\t"                      // 1 - ec
-        "v_mul_f32 %1, %1, %4\n\t"
-        "v_mfma_f32_16x16x32_f16 %7, %13, %16, %7\n\t"
-        "v_rcp_f32 %1, %1\n\t"
-        "s_nop 1\n\t"
-        "v_mul_f32 %0, %0, %1\n\t"                       // hv
-        "v_cmp_le_f32_e64 vcc, |%0|, 1.0\n\t"
-        "v_mfma_f32_16x16x32_f16 %8, %14, %16, %8\n\t"
-        "s_nop 1\n\t"
-        "v_cndmask_b32_e32 %0, 0, %0, vcc\n\t"
-        "s_nop %19"
-        : "+v"(u0), "+v"(u1), "+v"(u2), "+v"(u3), "+v"(eo), "+v"(c), "+v"(x0), "+v"(x1), "+v"(x2)
-        : "a"(w00), "a"(w10), "v"(w20), "a"(w01), "a"(w11), "v"(w21), "v"(b0), "v"(b1), "v"(-12.5f), "v"(12.5f), "n"(LAST ? 15 : 0)
-        : "vcc");
-    if (LAST) asm volatile("s_nop 7" : "+v"(x0), "+v"(x1), "+v"(x2));
-    return u0;
-}
+// lstm_cell() of the three units of a lane with the 36 MFMAs of the NEXT step's input projection threaded through it (H = 384), one MFMA
+// to about three vector instructions: a wave issues in order, so the vector ALU only works in the shadow of the matrix core if the
+// two kinds of instruction alternate in the instruction stream - which the compiler does neither for inline-asm MFMAs nor for
+// builtin ones (measured; sched_group_barrier included). The three units' dependency chains are interleaved round-robin so that no
+// instruction waits for a transcendental. Generated by tools/gen_cells3.py (named asm operands, five blocks because an asm statement
+// takes at most 30); the arithmetic is lstm_cell()'s operation for operation: the same bits (tested against the single-ring kernel).
+#include "cells3_mfma.inc"
 
 template <int NKS, int MT>
 __global__ __launch_bounds__(256, 1) void lstm_layer_wgx2_kernel(LstmWgxArgs wp) {
@@ -1289,7 +1216,7 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_wgx2_kernel(LstmWgxArgs wp)
             mfma_settle_v<MT>(acc);
         }
         // ---- gate arithmetic of this step; at H = 384 the input projection of the next step (independent work for the matrix
-        //      core) is threaded through it instruction by instruction (cell_mfma_a / _b) -------------------------------------------
+        //      core) is threaded through it instruction by instruction (cells3_mfma) -------------------------------------------
         constexpr bool WOVEN = NKS == 12 && MT == 3;
         half_t ho[MT];
         if constexpr (WOVEN) {
@@ -1297,20 +1224,13 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_wgx2_kernel(LstmWgxArgs wp)
             float4_t xa[MT];
 #pragma unroll
             for (int m = 0; m < MT; ++m) xa[m] = bias4[m];
-            auto woven = [&](auto mc) {
-                constexpr int m = decltype(mc)::value;
-                const half8_t b0 = *(const half8_t*)(xb + (4 * m + 0) * 1024), b1 = *(const half8_t*)(xb + (4 * m + 1) * 1024);
-                const half8_t b2 = *(const half8_t*)(xb + (4 * m + 2) * 1024), b3 = *(const half8_t*)(xb + (4 * m + 3) * 1024);
-                float u0, u1, u2, u3, eo;
-                cell_mfma_a(acc[m][0], acc[m][1], acc[m][2], acc[m][3], u0, u1, u2, u3, eo, wih[0][4 * m], wih[1][4 * m], wih[2][4 * m],
-                            wih[0][4 * m + 1], wih[1][4 * m + 1], wih[2][4 * m + 1], b0, b1, xa[0], xa[1], xa[2]);
-                const float hv = cell_mfma_b<(m == 2)>(u0, u1, u2, u3, eo, cst[r][m], wih[0][4 * m + 2], wih[1][4 * m + 2], wih[2][4 * m + 2],
-                                                       wih[0][4 * m + 3], wih[1][4 * m + 3], wih[2][4 * m + 3], b2, b3, xa[0], xa[1], xa[2]);
-                ho[m] = (half_t)hv;
-            };
-            woven(std::integral_constant<int, 0>{});
-            woven(std::integral_constant<int, 1>{});
-            woven(std::integral_constant<int, 2>{});
+            half8_t bf[NKS];
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) bf[ks] = *(const half8_t*)(xb + ks * 1024);
+            float hv[MT];
+            cells3_mfma(acc, cst[r], hv, wih, bf, xa);
+#pragma unroll
+            for (int m = 0; m < MT; ++m) ho[m] = (half_t)hv[m];
 #pragma unroll
             for (int m = 0; m < MT; ++m) xacc[r][m] = xa[m];
         } else {

@@ -36,7 +36,7 @@ def _newer(dst, srcs):
 def build_hip(force=False):
     os.makedirs(OBJ, exist_ok=True)
     srcs = sorted(f for f in os.listdir(CSRC) if f.endswith((".hip", ".cpp")))
-    hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".inc"))]
     hdrs.append(os.path.join(ROOT, "include", "bonito_hip.h"))
     objs, jobs = [], []
     for s in srcs:

@@ -15,5 +15,8 @@ _lib.check(_lib.lib().bh_encoder_debug_read(enc._handle, st.ctypes.data_as(C.c_v
 st = st[:32]
 print("cycles per double step %.0f (per ring step %.0f); poll check %.0f, wait + barrier %.0f per double step; clock %.2f GHz" % (
     st[..., 0].mean() / T, st[..., 0].mean() / T / 2, st[..., 1].mean() / T, st[..., 5].mean() / T, st[..., 0].mean() / st[..., 13].mean() * 0.1))
+print("per ring step: x DMA issue + recurrent MFMAs %.0f | gates woven with the input projection %.0f | read-back + transpose + stores %.0f | test + polls %.0f" % tuple(
+    st[..., i].mean() / T / 2 for i in (10, 11, 12, 8)))
+print("re-poll rounds per ring step: %.4f" % (st[..., 9].mean() / T / 2))
 PY
 cat gpurun_out/r2_pair_stats.log | tail -3

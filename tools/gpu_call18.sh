@@ -16,5 +16,6 @@ print("max abs diff %.3e, mean %.3e, fraction of differing elements %.4f, nan %d
 bad = (d > 0).nonzero()
 print("first differing indices (n, t, c):", bad[:5].tolist())
 print("differing chunks: %d of 1024; first t with a difference: %d" % (len(torch.unique(bad[:, 0])), int(bad[:, 1].min())))
+ch = torch.unique(bad[:, 0]); print("chunk ids mod 16 histogram:", torch.bincount(ch % 16, minlength=16).tolist()); print("chunk id // 16 (rings) sample:", torch.unique(ch // 16)[:20].tolist())
 PY
 cat gpurun_out/r2_pair_diff.log | tail -5
