@@ -71,6 +71,11 @@ def parse(argv=None):
                     help="independent batches in flight (each lane: own engine replica, encoder stream, decoder stream); "
                          "default 1; 3 for the narrow `fast` model whose kernels leave most CUs idle (1 lane 8.9 ms/step, "
                          "3 lanes 4.5 with GPU_MAX_HW_QUEUES=8); hac / sup kernels fill the chip and gain nothing")
+    ap.add_argument("--per-call", type=int, default=0,
+                    help="batches per engine call (a step stays ONE batch of --batch chunks). Default 2 for hac in fp16: with more "
+                         "than 32 rings in a call the recurrent kernel carries two rings per workgroup on one copy of the weights "
+                         "(lstm_layer_wgx2_kernel) and the hand-off of one hides behind the step of the other: 19.8 -> 18.3 ms per "
+                         "batch on the same box; 1 = one batch per call (lstm_layer_wgx_kernel). Needs --steps divisible by it.")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-h2d-leg", action="store_true", help="skip the second timed region (H2D inside the step)")
     ap.add_argument("--set", action="append", default=[], metavar="NAME=VALUE",
@@ -79,6 +84,11 @@ def parse(argv=None):
     a.batch = a.batch or (256 if a.model in ("sup", "sup_lstm") else 512)
     a.chunk = a.chunk or (12000 if a.model == "sup" else 20000 if a.model == "sup_lstm" else 10000)
     a.lanes = a.lanes or (3 if a.model == "fast" else 1)
+    a.per_call = a.per_call or (2 if a.model == "hac" and not a.quantize and a.lanes == 1 else 1)
+    if a.steps % a.per_call:
+        log("--steps %d is not divisible by %d batches per call: one batch per call" % (a.steps, a.per_call))
+        a.per_call = 1
+    a.call_batch = a.batch * a.per_call
     return a
 
 
@@ -105,7 +115,7 @@ def pmc_traffic(kernel, a):
         return None, None
     base = (kernel or "").split("<")[0]
     ent = table.get(kernel or "") or table.get(base)
-    if not ent or ent.get("workload") != "%s %dx%d" % (a.model, a.batch, a.chunk):
+    if not ent or ent.get("workload") != "%s %dx%d" % (a.model, a.call_batch, a.chunk):
         return None, None
     return ent["bytes_per_launch"], ent.get("source")
 
@@ -215,11 +225,11 @@ def main():
         else:
             decode.set_option(name, int(value))
     log("building model %s%s" % (a.model, " (quantize)" if a.quantize else ""))
-    model = build_model(a.model, a.batch, a.chunk)
-    model.use_koi(batchsize=a.batch, chunksize=a.chunk, quantize=a.quantize)
+    model = build_model(a.model, a.call_batch, a.chunk)
+    model.use_koi(batchsize=a.call_batch, chunksize=a.chunk, quantize=a.quantize)
     model = model.half().to(dev)
     gen = torch.Generator(device=dev).manual_seed(25 + rank)
-    signals = [torch.randn(a.batch, 1, a.chunk, generator=gen, device=dev).half() for _ in range(N_BATCHES)]
+    signals = [torch.randn(a.call_batch, 1, a.chunk, generator=gen, device=dev).half() for _ in range(N_BATCHES)]
     host_signals = [s.cpu().pin_memory() for s in signals]
     copy_stream = torch.cuda.Stream(dev)
 
@@ -234,8 +244,8 @@ def main():
         if li == 0:
             ln.model = model
         else:
-            ln.model = build_model(a.model, a.batch, a.chunk)
-            ln.model.use_koi(batchsize=a.batch, chunksize=a.chunk, quantize=a.quantize)
+            ln.model = build_model(a.model, a.call_batch, a.chunk)
+            ln.model.use_koi(batchsize=a.call_batch, chunksize=a.chunk, quantize=a.quantize)
             ln.model = ln.model.half().to(dev)
         # (measured and dropped: a higher hardware-queue priority for the encoder stream, 20.0 -> 21.1 ms per step, and
         # s_setprio 3 inside the recurrent kernel, 20.0 -> 20.0)
@@ -286,12 +296,12 @@ def main():
         for k, v in enc_opts.items():
             ln.model._hip.set_option(k, v)
         T_out, C_out = sc0.shape[1], sc0.shape[2]
-        ln.decs = [decode.CRFDecoder(a.batch, T_out, C_out, dev, mode=a.decoder) for _ in range(2)]
+        ln.decs = [decode.CRFDecoder(a.call_batch, T_out, C_out, dev, mode=a.decoder) for _ in range(2)]
         del sc0
     decs = lanes[0].decs
 
     def run(steps, h2d=False, marks=None):
-        """`steps` passes of the hot path over one batch each, software-pipelined: inside a lane encoder(i+1) overlaps
+        """`steps` engine calls (a.per_call batches each) of the hot path, software-pipelined: inside a lane encoder(i+1) overlaps
         decode(i) on two HIP streams, and the lanes run round-robin. Every step's int8 outputs are on the host when this
         returns. `marks`: list that receives one timing event per step, recorded behind the step's decode + D2H."""
         for ln in lanes:
@@ -335,23 +345,23 @@ def main():
         barrier()
         marks = []
         t0 = time.perf_counter()
-        run(a.steps, h2d, marks)
+        run(a.steps // a.per_call, h2d, marks)           # exactly a.steps batches
         barrier()
         el = time.perf_counter() - t0
         el = parallel.max_over_ranks(el, device="cpu" if oversubscribed else dev)
         check_engines()
-        gaps = [marks[i].elapsed_time(marks[i + 1]) for i in range(len(marks) - 1)]
+        gaps = [marks[i].elapsed_time(marks[i + 1]) / a.per_call for i in range(len(marks) - 1)]
         return el, (statistics.median(gaps) if gaps else 1e3 * el / a.steps)
 
     log("warmup")
-    run(a.warmup)
+    run(-(-a.warmup // a.per_call))                 # at least a.warmup batches
     check_engines()
     log("timed region (inputs resident in HBM)")
     elapsed, med = timed(False)
     log("timed region done: %.2f ms/step (median step %.2f ms)" % (1e3 * elapsed / a.steps, med))
     h2d = None
     if not a.no_h2d_leg:
-        run(min(a.warmup, 2), True)
+        run(max(1, min(a.warmup, 2) // a.per_call), True)
         el2, med2 = timed(True)
         samples = a.batch * a.chunk * a.steps * world
         h2d = {"value": samples / el2, "ms_per_step": 1e3 * el2 / a.steps, "ms_per_step_median": med2,
@@ -378,8 +388,8 @@ def main():
             dec_ms += ev[2 * i].elapsed_time(ev[2 * i + 1])
         prof = enc.profile_read()
         enc.profile(False)
-        breakdown = {k: round(v[0] / nprof, 3) for k, v in prof.items() if v[1]}
-        breakdown["decode_incl_d2h"] = round(dec_ms / nprof, 3)
+        breakdown = {k: round(v[0] / nprof / a.per_call, 3) for k, v in prof.items() if v[1]}      # per step = per batch
+        breakdown["decode_incl_d2h"] = round(dec_ms / nprof / a.per_call, 3)
         fl = flops(a.model, a.chunk)
         cls = max((k for k in ("lstm_rec", "lstm_gemm", "crf_linear", "conv", "attention", "mlp") if k in fl),
                   key=lambda k: prof[k][0])
@@ -388,7 +398,7 @@ def main():
         work = fl[cls]
         if cls == "lstm_rec" and prof["lstm_gemm"][1] == 0:
             work += fl["lstm_gemm"]          # fused kernel: the input projection runs inside the recurrence launch
-        flops_per_launch = work * a.batch / launches_per_fwd
+        flops_per_launch = work * a.call_batch / launches_per_fwd
         avg_ms = ms / spans
         achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12
         # the kernel names come from the engine itself (bh_encoder_describe), not from a guess about the dispatch
@@ -422,9 +432,11 @@ def main():
             "dtype": "i8 recurrence (Q8-1) / f16" if a.quantize else "f16",
             "data": "synthetic",
             "config": {"workload": "dna_r10.4.1_e8.2_400bps_%s@v5.0.0-shaped model (seeded random weights), "
-                                   "batch %d x chunk %d, %d distinct batches rotating, %s decode, encoder/decoder "
+                                   "batch %d x chunk %d, %s%d distinct inputs rotating, %s decode, encoder/decoder "
                                    "software-pipelined on 2 HIP streams x %d batch lane(s) per GPU%s" %
-                                   (a.model, a.batch, a.chunk, N_BATCHES, a.decoder, a.lanes, ", --quantize" if a.quantize else ""),
+                                   (a.model, a.batch, a.chunk,
+                                    "%d batches per engine call (their rings paired in the recurrent kernels), " % a.per_call if a.per_call > 1 else "",
+                                    N_BATCHES, a.decoder, a.lanes, ", --quantize" if a.quantize else ""),
                        "parallelism": "replicas x%d (shard-by-read, no collective)%s" % (world, " -- ranks SHARE devices (test mode)" if oversubscribed else "")},
             "per_gpu": samples / elapsed / world,
             "with_h2d": h2d,

@@ -709,7 +709,13 @@ extern "C" int bh_encoder_describe(const bh_encoder_t* e, char* buf, size_t n) {
                 const int H = d.out_size, U = bh_k_lstm_wg_units(H);
                 if (p.q8) snprintf(line, sizeof(line), "%d lstm %d%s: lstm_layer_q8_kernel<%d,%d> (int8 W/x/h, i32 MFMA 16x16x64)\n", li, H, d.reverse ? " rev" : "", (H + 63) / 64, bh_k_lstm_q8_units(H, l.q_variant) / 4);
                 else if (p.cta) snprintf(line, sizeof(line), "%d lstm %d%s: lstm_layer_cta_kernel<%d,%d>\n", li, H, d.reverse ? " rev" : "", H / 32, U / 4);
-                else if (p.wgx) snprintf(line, sizeof(line), "%d lstm %d%s: lstm_layer_wgx_kernel<%d,%d>\n", li, H, d.reverse ? " rev" : "", H / 32, U / 4);
+                else if (p.wgx) {
+                    // (at the batch the engine was created for: more rings than one launch holds are served two per workgroup)
+                    const int Np = (e->max_batch + e->batch_pad - 1) / e->batch_pad * e->batch_pad;
+                    const int fit = U ? (e->n_cus / (8 * ((H / U) / 4))) * 8 : 0;
+                    const bool pair = e->lstm_pair && fit > 0 && Np / 16 > fit;
+                    snprintf(line, sizeof(line), "%d lstm %d%s: lstm_layer_%s_kernel<%d,%d>\n", li, H, d.reverse ? " rev" : "", pair ? "wgx2" : "wgx", H / 32, U / 4);
+                }
                 else if (p.wg) snprintf(line, sizeof(line), "%d lstm %d%s: lstm_layer_wg_kernel<%d,%d>\n", li, H, d.reverse ? " rev" : "", H / 32, U / 4);
                 else if (p.fused) snprintf(line, sizeof(line), "%d lstm %d%s: lstm_layer_fused_kernel<%d>\n", li, H, d.reverse ? " rev" : "", H / 32);
                 else if (p.wide) snprintf(line, sizeof(line), "%d lstm %d%s: gemm + lstm_layer_wide_kernel<%d,%s>\n", li, H, d.reverse ? " rev" : "", H / 32, p.widex ? "true" : "false");

@@ -39,6 +39,20 @@ def test_defaults_follow_the_contract(bench, monkeypatch):
     assert (a.batch, a.chunk, a.lanes, a.set) == (256, 20000, 1, ["beam_fork=1", "conv_ws=0"])
 
 
+def test_batches_per_engine_call(bench, monkeypatch):
+    """A step is always one batch of --batch chunks; hac in fp16 hands the engine two of them per call (paired rings) when the
+    step count allows it, and never changes the number of timed steps."""
+    def parsed(*argv):
+        monkeypatch.setattr(sys, "argv", ["bench.py"] + list(argv))
+        return bench.parse()
+    a = parsed()
+    assert (a.per_call, a.batch, a.call_batch, a.steps % a.per_call) == (2, 512, 1024, 0)
+    assert parsed("--steps", "7").per_call == 1                      # exactly K steps: an odd K runs one batch per call
+    assert parsed("--per-call", "1").call_batch == 512
+    assert parsed("--quantize").per_call == 1 and parsed("--model", "fast").per_call == 1 and parsed("--model", "sup").per_call == 1
+    assert parsed("--lanes", "2").per_call == 1
+
+
 def test_pmc_traffic_table_names_the_roofline_kernel(bench):
     table = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
     entry = table["lstm_layer_wg_kernel"]

@@ -292,3 +292,79 @@ def test_ring_exchange_across_xcds_gives_the_same_bytes(quantize):
             enc.check()
             enc.close()
         assert torch.equal(outs[0], outs[1]), name
+
+
+def _encode(model, x, **options):
+    enc = HipEncoder(model, batchsize=x.shape[0], chunksize=x.shape[-1])
+    for name, value in options.items():
+        enc.set_option(name, value)
+    out = enc(x).clone()
+    again = enc(x).clone()
+    layout = enc.describe()
+    enc.check()
+    enc.close()
+    assert torch.equal(out, again)          # (a data race in the hand-off would show as run-to-run differences)
+    return out, layout
+
+
+@pytest.mark.parametrize("N", [1024, 528, 1008, 640])
+def test_paired_rings_same_bytes_as_two_launches(N):
+    """Batches of more than 32 rings at H = 384 (N > 512): `lstm_layer_wgx2_kernel` carries two rings per workgroup on one copy of
+    the weights, with the gate arithmetic woven into the MFMA stream by hand. Same arithmetic in the same order: the same bytes as
+    the single-ring kernel launched twice (`lstm_pair = 0`), for an even ring count, an odd one (a lone ring in the last workgroups),
+    one ring beyond a launch (528 = 33 rings) and with the rings of a pair spread over all XCDs."""
+    from bonito_amd import synthetic
+    model = synthetic.make_model("hac", batchsize=N, chunksize=2400)
+    x = torch.randn(N, 1, 2400, generator=torch.Generator().manual_seed(N)).half().cuda()
+    two, layout0 = _encode(model.encoder, x, lstm_pair=0)
+    one, layout1 = _encode(model.encoder, x)
+    assert "lstm_layer_wgx2_kernel<12,3>" in layout1 and "wgx2" not in layout0
+    assert torch.equal(one, two)
+    scattered, _ = _encode(model.encoder, x, lstm_tune=32)
+    assert torch.equal(scattered, two)
+
+
+@pytest.mark.parametrize("H,sl,N", [(288, 3, 1024), (192, 3, 1500), (256, 3, 1500)])
+def test_paired_rings_other_widths(H, sl, N):
+    """The widths whose gate arithmetic is not hand-woven (generic path of the paired kernel), against two launches and the oracle."""
+    from bonito_amd import nn as bnn, synthetic
+    torch.manual_seed(H)
+    model = bnn.from_dict(synthetic.lstm_crf_encoder_config(H, sl, n_lstm=3))
+    synthetic.randomise_batchnorm_(model)
+    nn_ref.round_params_to_half_(model)
+    x = torch.randn(N, 1, 900, generator=torch.Generator().manual_seed(H)).half()
+    one, layout = _encode(model, x.cuda())
+    two, _ = _encode(model, x.cuda(), lstm_pair=0)
+    assert "wgx2" in layout and torch.equal(one, two)
+    rows = [0, N // 2 + 3, N - 1]
+    with torch.no_grad():
+        want = nn_ref.forward(model, x[rows].float(), expand_blanks=False).permute(1, 0, 2)
+    assert (one[rows].cpu().float() - want).abs().max().item() < TOL_MAX
+
+
+def test_paired_rings_full_size_1024x10000():
+    """Two BASELINE batches in one engine call: same bytes as two launches per layer, four chunks against the fp32 oracle, no
+    exchange timeout; and with the spin bound at zero the first incomplete poll round raises the device flag (never a hang)."""
+    from bonito_amd import decode, synthetic
+    model = synthetic.make_model("hac", batchsize=1024, chunksize=10000)
+    nn_ref.round_params_to_half_(model)
+    x = torch.randn(1024, 1, 10000, generator=torch.Generator().manual_seed(25)).half()
+    one, _ = _encode(model.encoder, x.cuda())
+    two, _ = _encode(model.encoder, x.cuda(), lstm_pair=0)
+    assert one.shape == (1024, 1667, 1024) and torch.equal(one, two)
+    rows = [0, 511, 512, 1023]
+    with torch.no_grad():
+        want = nn_ref.forward(model.encoder, x[rows].float(), expand_blanks=False).permute(1, 0, 2)
+    d = (one[rows].cpu().float() - want).abs()
+    assert d.max().item() < 2.4e-2 and d.mean().item() < 3e-3, (d.max().item(), d.mean().item())
+    enc = HipEncoder(model.encoder, batchsize=1024, chunksize=10000)
+    try:
+        decode.set_option("lstm_max_spins", 0)
+        enc(x.cuda())
+        torch.cuda.synchronize()
+    finally:
+        decode.set_option("lstm_max_spins", -1)
+    from bonito_amd import _lib
+    with pytest.raises(_lib.HipEngineError):
+        enc.check()
+    enc.close()

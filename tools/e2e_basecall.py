@@ -27,6 +27,7 @@ def parse():
     ap.add_argument("--mean-len", type=int, default=100000)
     ap.add_argument("--devices", default=None)
     ap.add_argument("--reps", type=int, default=2)
+    ap.add_argument("--batchsize", type=int, default=512, help="chunks per engine call (more than 512: the recurrent kernels pair rings)")
     return ap.parse_args()
 
 
@@ -66,8 +67,8 @@ def main():
     if world > 1:
         parallel.init("gloo")
     util.limit_host_threads(8)
-    model = synthetic.make_model(a.model, batchsize=512, chunksize=10000)
-    model.use_koi(batchsize=512, chunksize=9996, quantize=False)
+    model = synthetic.make_model(a.model, batchsize=a.batchsize, chunksize=10000)
+    model.use_koi(batchsize=a.batchsize, chunksize=9996, quantize=False)
     model = model.half().cuda()
 
     class Read:
@@ -85,7 +86,7 @@ def main():
         if world > 1:
             dist.barrier(group=parallel.host_group())
         t0 = time.perf_counter()
-        results = basecall(model, iter(mine), chunksize=9996, overlap=498, batchsize=512)
+        results = basecall(model, iter(mine), chunksize=9996, overlap=498, batchsize=a.batchsize)
         records = parallel.ordered_records(parallel.format_stream(results, "fastq"), rank, world)
         if rank == 0:
             with open(os.devnull, "w") as sink:
