@@ -368,3 +368,15 @@ def test_paired_rings_full_size_1024x10000():
     with pytest.raises(_lib.HipEngineError):
         enc.check()
     enc.close()
+
+
+@pytest.mark.parametrize("L", [6, 12, 18, 30, 66])
+def test_paired_rings_very_short_chunks(L):
+    """One to eleven time steps: the prologue / epilogue of the paired kernel (x-stream prefetch two steps ahead, first poll round one
+    section ahead, re-arm two steps behind) must not run past either end. Against two launches of the single-ring kernel."""
+    from bonito_amd import synthetic
+    model = synthetic.make_model("hac", batchsize=1024, chunksize=L)
+    x = torch.randn(1024, 1, L, generator=torch.Generator().manual_seed(L)).half().cuda()
+    one, layout = _encode(model.encoder, x)
+    two, _ = _encode(model.encoder, x, lstm_pair=0)
+    assert "wgx2" in layout and one.shape[1] == (L - 1) // 6 + 1 and torch.equal(one, two)
