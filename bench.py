@@ -59,8 +59,8 @@ N_BATCHES = 3                     # distinct input batches rotating through the 
 def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--model", default="hac", choices=["hac", "fast", "sup", "sup_lstm"])
     ap.add_argument("--batch", type=int, default=0, help="default: 512 (hac/fast), 256 (sup)")
     ap.add_argument("--chunk", type=int, default=0, help="default: 10000 (hac/fast), 12000 (sup)")
@@ -72,10 +72,12 @@ def parse(argv=None):
                          "default 1; 3 for the narrow `fast` model whose kernels leave most CUs idle (1 lane 8.9 ms/step, "
                          "3 lanes 4.5 with GPU_MAX_HW_QUEUES=8); hac / sup kernels fill the chip and gain nothing")
     ap.add_argument("--per-call", type=int, default=0,
-                    help="batches per engine call (a step stays ONE batch of --batch chunks). Default 2 for hac in fp16: with more "
+                    help="batches per engine call (a step stays ONE batch of --batch chunks). Default 4 for hac in fp16: with more "
                          "than 32 rings in a call the recurrent kernel carries two rings per workgroup on one copy of the weights "
                          "(lstm_layer_wgx2_kernel) and the hand-off of one hides behind the step of the other: 19.8 -> 18.3 ms per "
-                         "batch on the same box; 1 = one batch per call (lstm_layer_wgx_kernel). Needs --steps divisible by it.")
+                         "batch with two batches per call on the same box, 17.2 with four (two paired launches per layer; the "
+                         "decode kernels of 2048 chunks pack the CUs better); 1 = one batch per call (lstm_layer_wgx_kernel). Needs "
+                         "--steps divisible by it, otherwise the largest divisor among 4, 2, 1 is used.")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-h2d-leg", action="store_true", help="skip the second timed region (H2D inside the step)")
     ap.add_argument("--set", action="append", default=[], metavar="NAME=VALUE",
@@ -84,10 +86,9 @@ def parse(argv=None):
     a.batch = a.batch or (256 if a.model in ("sup", "sup_lstm") else 512)
     a.chunk = a.chunk or (12000 if a.model == "sup" else 20000 if a.model == "sup_lstm" else 10000)
     a.lanes = a.lanes or (3 if a.model == "fast" else 1)
-    a.per_call = a.per_call or (2 if a.model == "hac" and not a.quantize and a.lanes == 1 else 1)
-    if a.steps % a.per_call:
-        log("--steps %d is not divisible by %d batches per call: one batch per call" % (a.steps, a.per_call))
-        a.per_call = 1
+    a.per_call = a.per_call or (4 if a.model == "hac" and not a.quantize and a.lanes == 1 else 1)
+    while a.steps % a.per_call:                       # exactly --steps batches are timed: fall back to a divisor
+        a.per_call //= 2
     a.call_batch = a.batch * a.per_call
     return a
 
@@ -104,7 +105,7 @@ def flops(name, chunk):
     return synthetic.transformer_flops_per_chunk(chunksize=chunk) if name == "sup" else synthetic.flops_per_chunk(name, chunk)
 
 
-def pmc_traffic(kernel, a):
+def pmc_traffic(kernel, a, launch_chunks=None):
     """(HBM bytes per launch, source file) of the dominant kernel from the committed PMC passes (profiles/pmc_traffic.json:
     rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, gfx950 FETCH_SIZE x2 correction); (None, None) when no
     measurement exists for this kernel / workload. PMC counters cannot be read from inside this process."""
@@ -115,7 +116,7 @@ def pmc_traffic(kernel, a):
         return None, None
     base = (kernel or "").split("<")[0]
     ent = table.get(kernel or "") or table.get(base)
-    if not ent or ent.get("workload") != "%s %dx%d" % (a.model, a.call_batch, a.chunk):
+    if not ent or ent.get("workload") != "%s %dx%d" % (a.model, launch_chunks or a.call_batch, a.chunk):
         return None, None
     return ent["bytes_per_launch"], ent.get("source")
 
@@ -400,6 +401,18 @@ def main():
             work += fl["lstm_gemm"]          # fused kernel: the input projection runs inside the recurrence launch
         flops_per_launch = work * a.call_batch / launches_per_fwd
         avg_ms = ms / spans
+        # a profiling span covers one layer of one call; the recurrent kernels of these widths serve at most 32 rings (64 paired) per
+        # launch, so a call of more chunks is several launches inside the span: report per kernel launch
+        per_span = 1
+        if cls == "lstm_rec":
+            rec = [ln for ln in layout.splitlines() if " lstm " in ln]
+            if rec and "lstm_layer_wgx2_kernel" in rec[0]:
+                per_span = -(-(a.call_batch // 16) // 64)
+            elif rec and "lstm_layer_wgx_kernel" in rec[0]:
+                per_span = -(-(a.call_batch // 16) // 32)
+        flops_per_launch /= per_span
+        avg_ms /= per_span
+        launch_chunks = a.call_batch // per_span
         achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12
         # the kernel names come from the engine itself (bh_encoder_describe), not from a guess about the dispatch
         kind = {"lstm_rec": " lstm ", "lstm_gemm": " lstm ", "crf_linear": " linearcrfencoder ", "conv": " conv ",
@@ -409,7 +422,7 @@ def main():
         lstm_kernel = kernel if cls == "lstm_rec" else None
         q8 = "q8" in kernel
         peak = MFMA_I8_PEAK_TOPS if q8 else MFMA_F16_PEAK_TFLOPS
-        traffic, traffic_src = pmc_traffic(lstm_kernel, a)
+        traffic, traffic_src = pmc_traffic(lstm_kernel, a, launch_chunks)
         roof = {"kernel": kernel, "bound": "mfma", "achieved": round(achieved, 2), "peak": peak,
                 "unit": "TOP/s" if q8 else "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic,
                 "traffic_source": traffic_src, "avg_launch_ms": round(avg_ms, 4), "flops_per_launch": flops_per_launch}

@@ -46,8 +46,9 @@ def test_batches_per_engine_call(bench, monkeypatch):
         monkeypatch.setattr(sys, "argv", ["bench.py"] + list(argv))
         return bench.parse()
     a = parsed()
-    assert (a.per_call, a.batch, a.call_batch, a.steps % a.per_call) == (2, 512, 1024, 0)
+    assert (a.per_call, a.batch, a.call_batch, a.steps % a.per_call) == (4, 512, 2048, 0)
     assert parsed("--steps", "7").per_call == 1                      # exactly K steps: an odd K runs one batch per call
+    assert parsed("--steps", "50").per_call == 2 and parsed("--steps", "20").per_call == 4
     assert parsed("--per-call", "1").call_batch == 512
     assert parsed("--quantize").per_call == 1 and parsed("--model", "fast").per_call == 1 and parsed("--model", "sup").per_call == 1
     assert parsed("--lanes", "2").per_call == 1
