@@ -43,7 +43,8 @@ def _multi_lane(argv):
             lanes = tok.split("=", 1)[1]
     if lanes is not None:
         return lanes.isdigit() and int(lanes) > 1
-    return any(tok == "fast" or tok == "--model=fast" for tok in argv)       # the fast model defaults to 3 lanes
+    # the fast model defaults to three lanes, the 8-bit path to two
+    return any(tok in ("fast", "--model=fast", "--quantize") for tok in argv)
 
 
 if _multi_lane(sys.argv[1:]):
@@ -85,8 +86,21 @@ def parse(argv=None):
     a = ap.parse_args(argv)
     a.batch = a.batch or (256 if a.model in ("sup", "sup_lstm") else 512)
     a.chunk = a.chunk or (12000 if a.model == "sup" else 20000 if a.model == "sup_lstm" else 10000)
-    a.lanes = a.lanes or (3 if a.model == "fast" else 1)
-    a.per_call = a.per_call or (4 if a.model == "hac" and not a.quantize and a.lanes == 1 else 1)
+    lanes_given = a.lanes > 0
+    a.lanes = a.lanes or (3 if a.model == "fast" else 2 if a.quantize and a.model == "hac" else 1)
+    if not a.per_call:
+        # measured on MI355X (profiles/r02_bench_lines.jsonl): hac fp16 - four batches per call, one lane (paired recurrent kernel);
+        # hac --quantize - two lanes (8-bit kernels compiled for two workgroups per CU) x two batches per call: 14.6 -> 13.7 ms;
+        # fast - three lanes x four batches per call (the ring-in-a-workgroup kernel of one 512-chunk batch fills an eighth of the
+        # chip): 3.57 -> 2.51 ms per batch
+        if a.model == "hac" and not a.quantize and a.lanes == 1:
+            a.per_call = 4
+        elif a.model == "hac" and a.quantize and a.lanes == 2 and not lanes_given:
+            a.per_call = 2
+        elif a.model == "fast" and not a.quantize and a.lanes == 3 and not lanes_given:
+            a.per_call = 4
+        else:
+            a.per_call = 1
     while a.steps % a.per_call:                       # exactly --steps batches are timed: fall back to a divisor
         a.per_call //= 2
     a.call_batch = a.batch * a.per_call
@@ -219,6 +233,8 @@ def main():
     from bonito_amd.util import limit_host_threads
     log("host threads: %d" % limit_host_threads(4))
     enc_opts = {}
+    if a.quantize and a.lanes > 1 and not any(kv.startswith("lstm_q8_variant=") for kv in a.set):
+        decode.set_option("lstm_q8_variant", 2)        # 8-bit recurrent kernels compiled for two workgroups per CU (as the CLI does)
     for kv in a.set:
         name, _, value = kv.partition("=")
         if name.startswith("enc:"):          # per-engine option (bh_encoder_set_option), e.g. enc:lstm_tune=16
@@ -351,11 +367,13 @@ def main():
         el = time.perf_counter() - t0
         el = parallel.max_over_ranks(el, device="cpu" if oversubscribed else dev)
         check_engines()
-        gaps = [marks[i].elapsed_time(marks[i + 1]) / a.per_call for i in range(len(marks) - 1)]
+        # marks arrive in submission order, lane after lane: the distance between a lane's consecutive calls covers one call of every lane
+        nl = len(lanes)
+        gaps = [marks[i].elapsed_time(marks[i + nl]) / (a.per_call * nl) for i in range(len(marks) - nl)]
         return el, (statistics.median(gaps) if gaps else 1e3 * el / a.steps)
 
     log("warmup")
-    run(-(-a.warmup // a.per_call))                 # at least a.warmup batches
+    run(max(-(-a.warmup // a.per_call), 2 * len(lanes)))      # at least a.warmup batches, and two calls of every lane
     check_engines()
     log("timed region (inputs resident in HBM)")
     elapsed, med = timed(False)

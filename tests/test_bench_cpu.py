@@ -26,6 +26,7 @@ def test_multi_lane_detection_decides_the_hardware_queue_request(bench):
     assert bench._multi_lane(["--lanes", "3"])
     assert bench._multi_lane(["--lanes=2"])
     assert bench._multi_lane(["--model", "fast"])                 # the fast model defaults to three lanes
+    assert bench._multi_lane(["--quantize"]) and not bench._multi_lane(["--quantize", "--lanes", "1"])
     assert not bench._multi_lane(["--model", "fast", "--lanes", "1"])
 
 
@@ -50,8 +51,11 @@ def test_batches_per_engine_call(bench, monkeypatch):
     assert parsed("--steps", "7").per_call == 1                      # exactly K steps: an odd K runs one batch per call
     assert parsed("--steps", "50").per_call == 2 and parsed("--steps", "20").per_call == 4
     assert parsed("--per-call", "1").call_batch == 512
-    assert parsed("--quantize").per_call == 1 and parsed("--model", "fast").per_call == 1 and parsed("--model", "sup").per_call == 1
-    assert parsed("--lanes", "2").per_call == 1
+    q = parsed("--quantize")                                         # 8-bit path: two lanes x two batches per call
+    assert (q.lanes, q.per_call) == (2, 2) and parsed("--quantize", "--lanes", "1").per_call == 1
+    f = parsed("--model", "fast")                                    # three lanes x four batches per call
+    assert (f.lanes, f.per_call, f.call_batch) == (3, 4, 2048) and parsed("--model", "fast", "--lanes", "1").per_call == 1
+    assert parsed("--model", "sup").per_call == 1 and parsed("--lanes", "2").per_call == 1
 
 
 def test_pmc_traffic_table_names_the_roofline_kernel(bench):
