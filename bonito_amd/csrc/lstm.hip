@@ -1008,8 +1008,8 @@ __device__ __forceinline__ void wait_vm(int n) {       // s_waitcnt vmcnt(n), n 
 // to about three vector instructions: a wave issues in order, so the vector ALU only works in the shadow of the matrix core if the
 // two kinds of instruction alternate in the instruction stream - which the compiler does neither for inline-asm MFMAs nor for
 // builtin ones (measured; sched_group_barrier included). The three units' dependency chains are interleaved round-robin so that no
-// instruction waits for a transcendental. Generated by tools/gen_cells3.py (named asm operands, five blocks because an asm statement
-// takes at most 30); the arithmetic is lstm_cell()'s operation for operation: the same bits (tested against the single-ring kernel).
+// instruction waits for a transcendental. Generated by tools/gen_cells3.py (named asm operands, five blocks of at most
+// 30 distinct operands); the arithmetic is lstm_cell()'s operation for operation: the same bits (tested against the single-ring kernel).
 #include "cells3_mfma.inc"
 
 template <int NKS, int MT>

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Generates bonito_amd/csrc/cells3_mfma.inc: lstm_cell() of THREE units, their dependency chains interleaved round-robin, with the
 36 MFMAs of the next step's input projection (H = 384: 12 k-steps x 3 M tiles) threaded through at about one MFMA to three vector
-instructions. Five asm blocks (the 30-operand limit of an asm statement), named operands. The arithmetic is lstm_cell()'s
+instructions. Five asm blocks of at most 30 distinct operands each, named operands. The arithmetic is lstm_cell()'s
 (bonito_amd/csrc/lstm.hip), operation for operation:
 
     ei = exp2(med3(ai, +-25) * -log2e), ef, eo likewise;  eg = exp2((med3(ag, +-12.5) * -2) * log2e)
