@@ -72,18 +72,6 @@ def launch(args, argv):
     return 0
 
 
-def paired_batchsize(model, batchsize, args):
-    """Twice the configured batch when nothing was asked for explicitly and the model's recurrent layers are the ones whose kernel pairs
-    rings (fp16, 192..512 wide, register-resident weights): 257..512 chunks are one launch of 17..32 rings, twice that is one
-    launch of the paired kernel."""
-    if args.batchsize is not None or args.quantize or args.lanes > 1 or not 256 < batchsize <= 512:
-        return batchsize
-    widths = [m.rnn.hidden_size for m in model.modules() if type(m).__name__ == "LSTM" and hasattr(m, "rnn")]
-    if widths and all(192 <= h <= 512 and (h % 48 == 0 or h % 64 == 0) for h in widths):
-        return 2 * batchsize
-    return batchsize
-
-
 def main(args, argv=None):
     from bonito_amd import parallel
     if getattr(args, "devices", None) and "RANK" not in os.environ:
@@ -119,14 +107,6 @@ def main(args, argv=None):
     model = model.apply(fuse_bn_)
     basecall = util.load_symbol(args.model_directory, "basecall")
     bc = model.config["basecaller"]
-    paired = paired_batchsize(model, bc["batchsize"], args)
-    if paired != bc["batchsize"]:
-        # the recurrent kernels of these widths serve two rings per workgroup once a batch has more rings than one launch holds
-        # (lstm_layer_wgx2_kernel: +10 % end to end): hand the engine two of the configured batches per call. Results per chunk
-        # do not depend on the batch they travel in; --batchsize N keeps exactly N.
-        log("> batchsize %d -> %d (two batches per engine call)\n" % (bc["batchsize"], paired))
-        bc["batchsize"] = paired
-        model.use_koi(batchsize=paired, chunksize=bc["chunksize"], quantize=bc["quantize"])
     read_ids = None
     if args.read_ids:
         with open(args.read_ids) as fh:

@@ -367,7 +367,10 @@ struct BeamArgs {
     int nt;                // non-temporal staging of scores / guide
 };
 
-constexpr int BTB = 4;     // steps per staged block; two blocks are resident (the next one streams in under the current one)
+constexpr int BTB = 2;     // steps per staged block; two blocks are resident (the next one streams in under the current one). Two steps
+                           // (9 k cycles of beam work) hide the DMA latency as well as four did and take 12 KiB less LDS per chunk at 256
+                           // states: measured on MI355X, hac: decode stage 4.35 -> 3.65 ms per batch, bench step with one batch per engine
+                           // call 19.7 -> 17.9 ms (more decode workgroups find room beside the recurrent kernel)
 constexpr int MAXW = 32;
 
 __device__ __forceinline__ unsigned bs_hash0(int s) { return ((unsigned)s + 1u) * 2654435761u; }

@@ -80,21 +80,3 @@ def test_npy_reader(tmp_path):
     with pytest.raises(FileNotFoundError):
         reader.Reader(str(tmp_path / "nope"))
 
-
-def test_default_batch_is_paired_for_the_kernels_that_pair_rings():
-    """Without --batchsize the basecaller hands the engine two configured batches per call where the recurrent kernel pairs rings
-    (fp16, hidden sizes 192..512); an explicit --batchsize, --quantize, --lanes or another architecture keep theirs."""
-    import argparse
-    from bonito_amd import synthetic
-    from bonito_amd.cli.basecaller import paired_batchsize
-    ns = lambda **kw: argparse.Namespace(**{"batchsize": None, "quantize": False, "lanes": 1, **kw})
-    hac = synthetic.make_model("hac", batchsize=512, chunksize=10000)
-    assert paired_batchsize(hac, 512, ns()) == 1024
-    assert paired_batchsize(hac, 512, ns(batchsize=512)) == 512
-    assert paired_batchsize(hac, 512, ns(quantize=True)) == 512
-    assert paired_batchsize(hac, 512, ns(lanes=2)) == 512
-    assert paired_batchsize(hac, 64, ns()) == 64 and paired_batchsize(hac, 1024, ns()) == 1024
-    fast = synthetic.make_model("fast", batchsize=512, chunksize=10000)          # 96 wide: ring-in-a-workgroup kernel
-    assert paired_batchsize(fast, 512, ns()) == 512
-    sup = synthetic.make_transformer_model(batchsize=8, chunksize=1200, depth=1)
-    assert paired_batchsize(sup, 512, ns()) == 512
