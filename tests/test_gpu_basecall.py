@@ -420,3 +420,26 @@ def test_basecall_lanes_give_identical_results():
             outs.append([(r.read_id, res["sequence"], res["qstring"], res["moves"].tobytes())
                          for r, res in crf_basecall_fn(model, iter(reads), chunksize=3000, overlap=300, batchsize=32, lanes=lanes)])
         assert outs[0] == outs[1] == outs[2] and len(outs[0]) == 30
+
+
+def test_bench_default_mode_runs_and_reports_the_contract_fields():
+    """`python bench.py` in its default mode (hac, four batches per engine call, paired recurrent kernel), shortened: one JSON line on
+    stdout with the contract's fields, the roofline of the kernel the engine says it runs, no exchange timeout."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "8", "--warmup", "4", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout[-500:]                       # ONE json line, nothing else on stdout
+    d = json.loads(lines[0])
+    assert d["steps"] == 8 and d["n_gpus"] == 1 and d["unit"] == "samples/s" and d["higher_is_better"] is True
+    assert d["value"] > 5e7 and abs(d["value"] - 512 * 10000 / (d["ms_per_step"] * 1e-3)) < 1e-3 * d["value"]
+    assert "4 batches per engine call" in d["config"]["workload"] and "batch 512 x chunk 10000" in d["config"]["workload"]
+    roof = d["roofline"]
+    assert roof["kernel"] == "lstm_layer_wgx2_kernel<12,3>" and roof["bound"] == "mfma" and 0.1 < roof["frac"] < 1.0
+    assert roof["flops_per_launch"] == pytest.approx(4.027e12, rel=1e-3) and roof["traffic"] == 2652000000
+    assert d["with_h2d"]["value"] > 5e7
