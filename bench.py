@@ -10,9 +10,17 @@ through the steps. Weights are seeded random-init tensors of the named architect
 
 Two timed regions of K steps each (both bracketed by barrier + synchronize, MAX over ranks):
   * `value` / `ms_per_step`: input batches already resident in HBM when the region starts (the bench contract);
-  * `with_h2d`: the same steps with each batch copied pinned-host -> device on a copy stream inside the step
-    ("H2D of fp16 signal included"). The copy overlaps the previous step's kernels.
+  * `with_h2d` / `value_with_h2d`: the same steps with each batch copied pinned-host -> device on a copy stream inside the step
+    ("H2D of fp16 signal included"). The copy overlaps the previous step's kernels. This leg runs FIRST.
 `ms_per_step` is elapsed / K; `ms_per_step_median` is the median distance between consecutive steps' decode-done events.
+The warm-up is W steps AND at least --warmup-seconds of engine calls (clocks, instruction caches and the allocator settle in
+about a second; a 20-step run used to be timed cold: mean 20.3 ms against a median of 16.3).
+
+More legs in the same JSON line (rank 0, N = 1 only; each bounded to a few seconds):
+  per_call_1    -- the product path's call shape: ONE batch of 512 chunks per engine call (`bonito basecaller` default batchsize),
+                   with the roofline of the kernel that serves it
+  other_configs -- the other BASELINE.json configurations (fast 512 x 10000, sup transformer 256 x 12000, sup LSTM-1024
+                   256 x 20000, hac --quantize), each a child process of this script with a short timed region
 
 N > 1: `python bench.py --gpus N` spawns N ranks itself (one process per GPU, RCCL for the barrier and the MAX-reduce only);
 under `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N` the ranks come from the environment. Read
@@ -79,7 +87,9 @@ def parse(argv=None):
                          "batch with two batches per call on the same box, 17.2 with four (two paired launches per layer; the "
                          "decode kernels of 2048 chunks pack the CUs better); 1 = one batch per call (lstm_layer_wgx_kernel). Needs "
                          "--steps divisible by it, otherwise the largest divisor among 4, 2, 1 is used.")
+    ap.add_argument("--warmup-seconds", type=float, default=1.5, help="the warm-up also lasts at least this long")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-side-legs", action="store_true", help="skip per_call_1 and other_configs (child runs use this)")
     ap.add_argument("--no-h2d-leg", action="store_true", help="skip the second timed region (H2D inside the step)")
     ap.add_argument("--set", action="append", default=[], metavar="NAME=VALUE",
                     help="library tuning option (bh_set_option), e.g. beam_fork=1; for A/B runs, not part of the contract")
@@ -143,8 +153,9 @@ def log(msg):
 T_START = time.perf_counter()
 
 
-def cpu_baseline_worker(name, chunk, seconds_budget=15.0):
-    """CPU oracle timed on this host: oracle/nn_ref.py forward (fp32) + oracle/crf_oracle.c Viterbi."""
+def cpu_baseline_worker(name, chunk, decoder="beam", seconds_budget=12.0):
+    """CPU oracle timed on this host: oracle/nn_ref.py forward (fp32) + oracle/crf_oracle.c decode. `value` is the same pipeline as
+    the GPU leg (forward + the decoder the GPU leg ran); the other decoder's rate is reported beside it."""
     import torch
     from oracle import crf_ref, nn_ref
     model = build_model(name, 8, chunk)
@@ -154,24 +165,33 @@ def cpu_baseline_worker(name, chunk, seconds_budget=15.0):
     torch.set_num_threads(ncores)
     n = 2 if name == "sup" else 8
     x = torch.randn(n, 1, chunk, generator=torch.Generator().manual_seed(25)).half().float()
-    reps, t_total = 0, 0.0
-    while t_total < seconds_budget and reps < 8:
+    sl = model.seqdist.state_len
+    reps, t_fwd, t_vit, t_beam = 0, 0.0, 0.0, 0.0
+    while t_fwd + t_vit + t_beam < seconds_budget and reps < 8:
         t0 = time.perf_counter()
         with torch.no_grad():
             y = nn_ref.forward(model.encoder, x, expand_blanks=False)
         sc = y.permute(1, 0, 2).contiguous().half().numpy()
-        crf_ref.viterbi(sc, model.seqdist.state_len, blank=2.0)
-        t_total += time.perf_counter() - t0
+        t1 = time.perf_counter()
+        crf_ref.viterbi(sc, sl, blank=2.0)
+        t2 = time.perf_counter()
+        crf_ref.beam_search(sc, sl)
+        t3 = time.perf_counter()
+        t_fwd += t1 - t0; t_vit += t2 - t1; t_beam += t3 - t2
         reps += 1
-    return {"value": n * chunk * reps / t_total, "unit": "samples/s", "cores": ncores, "kind": "port",
-            "sample": "%d reps of %d chunks x %d samples, oracle/nn_ref.py fp32 forward + C Viterbi" % (reps, n, chunk)}
+    work = n * chunk * reps
+    rate = {"viterbi": work / (t_fwd + t_vit), "beam": work / (t_fwd + t_beam)}
+    return {"value": rate[decoder], "unit": "samples/s", "cores": ncores, "kind": "port", "decoder": decoder,
+            "value_viterbi": rate["viterbi"], "value_beam": rate["beam"], "forward_only": work / t_fwd,
+            "sample": "%d reps of %d chunks x %d samples: oracle/nn_ref.py fp32 forward (torch, %d threads) + oracle/crf_oracle.c %s decode "
+                      "(one thread); the decoders were timed on the same scores" % (reps, n, chunk, ncores, decoder)}
 
 
-def cpu_baseline(name, chunk, hard_timeout=90.0):
+def cpu_baseline(name, chunk, decoder="beam", hard_timeout=120.0):
     """Run the CPU leg in a child process with a hard wall-clock bound so it can never stall the bench."""
     import subprocess
     code = ("import json,sys; sys.path.insert(0, %r); import bench; "
-            "print('CPU_BASELINE ' + json.dumps(bench.cpu_baseline_worker(%r, %d)))" % (ROOT, name, chunk))
+            "print('CPU_BASELINE ' + json.dumps(bench.cpu_baseline_worker(%r, %d, %r)))" % (ROOT, name, chunk, decoder))
     try:
         r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=hard_timeout,
                            env=dict(os.environ, HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES=""))
@@ -182,6 +202,41 @@ def cpu_baseline(name, chunk, hard_timeout=90.0):
     except subprocess.TimeoutExpired:
         log("cpu baseline exceeded %.0fs and was abandoned" % hard_timeout)
     return None
+
+
+OTHER_CONFIGS = {            # BASELINE.json configs 2, 4, 5 (+ the 8-bit path of config 3); the headline itself is config 3
+    "fast": ["--model", "fast", "--steps", "96", "--warmup", "24"],
+    "sup": ["--model", "sup", "--steps", "12", "--warmup", "3"],
+    "sup_lstm": ["--model", "sup_lstm", "--steps", "8", "--warmup", "2"],
+    "hac_quantize": ["--model", "hac", "--quantize", "--steps", "48", "--warmup", "8"],
+}
+
+
+def other_configs(a, hard_timeout=150.0):
+    """The other BASELINE configurations, each as a child process of this script (its own HIP context and queue settings) with a short
+    timed region; the parent's kernels are idle meanwhile. Returns {name: {value, ms_per_step, ms_per_step_median, config, roofline}}."""
+    import subprocess
+    out = {}
+    for name, flags in OTHER_CONFIGS.items():
+        if name == ("hac_quantize" if a.quantize else a.model) and a.model != "hac":
+            continue
+        if a.model == "hac" and a.quantize and name == "hac_quantize":
+            continue
+        cmd = [sys.executable, os.path.abspath(__file__)] + flags + ["--no-cpu-baseline", "--no-h2d-leg", "--no-side-legs",
+                                                                     "--warmup-seconds", "1.0", "--decoder", a.decoder]
+        log("other config: " + " ".join(flags))
+        try:
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=hard_timeout)
+            line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+            if r.returncode or not line:
+                out[name] = {"error": (r.stderr or "no output")[-300:]}
+                continue
+            j = json.loads(line[-1])
+            out[name] = {k: j.get(k) for k in ("value", "ms_per_step", "ms_per_step_median", "steps", "dtype", "roofline", "kernel_ms_per_step")}
+            out[name]["workload"] = j["config"]["workload"]
+        except subprocess.TimeoutExpired:
+            out[name] = {"error": "exceeded %.0f s" % hard_timeout}
+    return out
 
 
 def spawn_ranks(n):
@@ -373,42 +428,44 @@ def main():
         return el, (statistics.median(gaps) if gaps else 1e3 * el / a.steps)
 
     log("warmup")
+    t_w = time.perf_counter()
     run(max(-(-a.warmup // a.per_call), 2 * len(lanes)))      # at least a.warmup batches, and two calls of every lane
+    while time.perf_counter() - t_w < a.warmup_seconds:       # ... and at least --warmup-seconds: the first second runs 15-25 % slow
+        run(2 * len(lanes), not a.no_h2d_leg)
+    torch.cuda.synchronize(dev)
     check_engines()
-    log("timed region (inputs resident in HBM)")
-    elapsed, med = timed(False)
-    log("timed region done: %.2f ms/step (median step %.2f ms)" % (1e3 * elapsed / a.steps, med))
     h2d = None
     if not a.no_h2d_leg:
-        run(max(1, min(a.warmup, 2) // a.per_call), True)
+        log("timed region 1 (every batch copied host -> device inside its step)")
         el2, med2 = timed(True)
         samples = a.batch * a.chunk * a.steps * world
         h2d = {"value": samples / el2, "ms_per_step": 1e3 * el2 / a.steps, "ms_per_step_median": med2,
-               "note": "same K steps with the fp16 batch copied pinned host -> device on a copy stream inside every step"}
+               "note": "same K steps with the fp16 batch copied pinned host -> device on a copy stream inside every step (SURVEY 8d)"}
         log("with H2D: %.2f ms/step (median %.2f)" % (1e3 * el2 / a.steps, med2))
+    log("timed region 2 (inputs resident in HBM)")
+    elapsed, med = timed(False)
+    log("timed region done: %.2f ms/step (median step %.2f ms)" % (1e3 * elapsed / a.steps, med))
 
-    # ---- roofline leg: per-kernel-class HIP-event timings on the engine's stream (after the timed region)
-    roof = None
-    breakdown = None
-    if rank == 0:
-        enc = model._hip
+    # ---- roofline leg: per-kernel-class HIP-event timings on the engine's stream (after the timed regions)
+    def roofline_of(mdl, dec, sigs, call_batch, per_call):
+        enc = mdl._hip
         layout = enc.describe()
         enc.profile(True)
         nprof = 3
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(2 * nprof)]
         dec_ms = 0.0
         for i in range(nprof):
-            scores = model(signals[i % N_BATCHES])
+            scores = mdl(sigs[i % len(sigs)])
             ev[2 * i].record()
-            decs[0].submit(scores).result()
+            dec.submit(scores).result()
             ev[2 * i + 1].record()
         torch.cuda.synchronize(dev)
         for i in range(nprof):
             dec_ms += ev[2 * i].elapsed_time(ev[2 * i + 1])
         prof = enc.profile_read()
         enc.profile(False)
-        breakdown = {k: round(v[0] / nprof / a.per_call, 3) for k, v in prof.items() if v[1]}      # per step = per batch
-        breakdown["decode_incl_d2h"] = round(dec_ms / nprof / a.per_call, 3)
+        brk = {k: round(v[0] / nprof / per_call, 3) for k, v in prof.items() if v[1]}      # per step = per batch
+        brk["decode_incl_d2h"] = round(dec_ms / nprof / per_call, 3)
         fl = flops(a.model, a.chunk)
         cls = max((k for k in ("lstm_rec", "lstm_gemm", "crf_linear", "conv", "attention", "mlp") if k in fl),
                   key=lambda k: prof[k][0])
@@ -417,7 +474,7 @@ def main():
         work = fl[cls]
         if cls == "lstm_rec" and prof["lstm_gemm"][1] == 0:
             work += fl["lstm_gemm"]          # fused kernel: the input projection runs inside the recurrence launch
-        flops_per_launch = work * a.call_batch / launches_per_fwd
+        flops_per_launch = work * call_batch / launches_per_fwd
         avg_ms = ms / spans
         # a profiling span covers one layer of one call; the recurrent kernels of these widths serve at most 32 rings (64 paired) per
         # launch, so a call of more chunks is several launches inside the span: report per kernel launch
@@ -425,12 +482,12 @@ def main():
         if cls == "lstm_rec":
             rec = [ln for ln in layout.splitlines() if " lstm " in ln]
             if rec and "lstm_layer_wgx2_kernel" in rec[0]:
-                per_span = -(-(a.call_batch // 16) // 64)
+                per_span = -(-(call_batch // 16) // 64)
             elif rec and "lstm_layer_wgx_kernel" in rec[0]:
-                per_span = -(-(a.call_batch // 16) // 32)
+                per_span = -(-(call_batch // 16) // 32)
         flops_per_launch /= per_span
         avg_ms /= per_span
-        launch_chunks = a.call_batch // per_span
+        launch_chunks = call_batch // per_span
         achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12
         # the kernel names come from the engine itself (bh_encoder_describe), not from a guess about the dispatch
         kind = {"lstm_rec": " lstm ", "lstm_gemm": " lstm ", "crf_linear": " linearcrfencoder ", "conv": " conv ",
@@ -441,9 +498,58 @@ def main():
         q8 = "q8" in kernel
         peak = MFMA_I8_PEAK_TOPS if q8 else MFMA_F16_PEAK_TFLOPS
         traffic, traffic_src = pmc_traffic(lstm_kernel, a, launch_chunks)
-        roof = {"kernel": kernel, "bound": "mfma", "achieved": round(achieved, 2), "peak": peak,
-                "unit": "TOP/s" if q8 else "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic,
-                "traffic_source": traffic_src, "avg_launch_ms": round(avg_ms, 4), "flops_per_launch": flops_per_launch}
+        rf = {"kernel": kernel, "bound": "mfma", "achieved": round(achieved, 2), "peak": peak,
+              "unit": "TOP/s" if q8 else "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic,
+              "traffic_source": traffic_src, "avg_launch_ms": round(avg_ms, 4), "flops_per_launch": flops_per_launch,
+              "chunks_per_launch": launch_chunks}
+        return rf, brk
+
+    roof = None
+    breakdown = None
+    if rank == 0:
+        roof, breakdown = roofline_of(model, decs[0], signals, a.call_batch, a.per_call)
+
+    # ---- the product path's call shape: ONE batch per engine call (what `bonito basecaller --batchsize 512` hands the engine)
+    per_call_1 = None
+    if rank == 0 and world == 1 and not a.no_side_legs and a.per_call > 1:
+        log("per_call_1 leg")
+        lanes_main, per_call_main, call_batch_main = lanes, a.per_call, a.call_batch
+        try:
+            m1 = build_model(a.model, a.batch, a.chunk)
+            m1.use_koi(batchsize=a.batch, chunksize=a.chunk, quantize=a.quantize)
+            m1 = m1.half().to(dev)
+            ln = Lane()
+            ln.model = m1
+            ln.enc_stream, ln.dec_stream = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+            sig1 = [sg[:a.batch] for sg in signals]
+            ln.stage = [torch.empty_like(sig1[0]) for _ in range(2)]
+            ln.stage_free, ln.staged, ln.tickets, ln.count = [None, None], [None, None], [None, None], 0
+            sc0 = m1(sig1[0])
+            torch.cuda.synchronize(dev)
+            ln.decs = [decode.CRFDecoder(a.batch, sc0.shape[1], sc0.shape[2], dev, mode=a.decoder) for _ in range(2)]
+            del sc0
+            signals_main, host_main = signals, host_signals
+            signals, host_signals = sig1, [sg.cpu().pin_memory() for sg in sig1]
+            lanes, a.per_call, a.call_batch = [ln], 1, a.batch
+            run(8)
+            steps1 = max(8, min(a.steps, 40))
+            barrier()
+            marks = []
+            t0 = time.perf_counter()
+            run(steps1, False, marks)
+            barrier()
+            el1 = time.perf_counter() - t0
+            m1._hip.check()
+            gaps = [marks[i].elapsed_time(marks[i + 1]) for i in range(len(marks) - 1)]
+            rf1, brk1 = roofline_of(m1, ln.decs[0], sig1, a.batch, 1)
+            per_call_1 = {"value": a.batch * a.chunk * steps1 / el1, "ms_per_step": 1e3 * el1 / steps1, "steps": steps1,
+                          "ms_per_step_median": statistics.median(gaps), "roofline": rf1, "kernel_ms_per_step": brk1,
+                          "note": "one batch of %d chunks per engine call: the call shape of `bonito basecaller` at its default batchsize" % a.batch}
+            signals, host_signals = signals_main, host_main
+            del m1, ln
+        except Exception as exc:          # a side leg must never take the headline down with it
+            per_call_1 = {"error": repr(exc)}
+        lanes, a.per_call, a.call_batch = lanes_main, per_call_main, call_batch_main
 
     if rank == 0:
         log("roofline leg done; cpu baseline")
@@ -470,10 +576,15 @@ def main():
                                     N_BATCHES, a.decoder, a.lanes, ", --quantize" if a.quantize else ""),
                        "parallelism": "replicas x%d (shard-by-read, no collective)%s" % (world, " -- ranks SHARE devices (test mode)" if oversubscribed else "")},
             "per_gpu": samples / elapsed / world,
+            "value_with_h2d": h2d["value"] if h2d else None,
             "with_h2d": h2d,
+            "batches_per_engine_call": a.per_call,
+            "chunks_per_engine_call": a.call_batch,
             "roofline": roof,
             "kernel_ms_per_step": breakdown,
-            "cpu_baseline": None if (a.no_cpu_baseline or world > 1) else cpu_baseline(a.model, a.chunk),
+            "per_call_1": per_call_1,
+            "other_configs": None if (a.no_side_legs or world > 1) else other_configs(a),
+            "cpu_baseline": None if (a.no_cpu_baseline or world > 1) else cpu_baseline(a.model, a.chunk, a.decoder),
         }
         json_out.write(json.dumps(out) + "\n")
         json_out.flush()

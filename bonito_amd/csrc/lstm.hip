@@ -1011,6 +1011,11 @@ __device__ __forceinline__ void wait_vm(int n) {       // s_waitcnt vmcnt(n), n 
 // instruction waits for a transcendental. Generated by tools/gen_cells3.py (named asm operands, five blocks of at most
 // 30 distinct operands); the arithmetic is lstm_cell()'s operation for operation: the same bits (tested against the single-ring kernel).
 #include "cells3_mfma.inc"
+// The whole arithmetic of a ring step as one stream (round 3): recurrent MFMAs TILE-major, so that the gate arithmetic of a tile has
+// the next tile's recurrent MFMAs (and a share of the next step's input projection) to hide behind; generated by
+// tools/gen_ringstep.py, statement cuts audited on the compiled ISA by tools/audit_ringstep.py (tests/test_abi.py).
+__device__ __forceinline__ unsigned lds_addr(const char* p) { return (unsigned)(size_t)(__attribute__((address_space(3))) const char*)p; }
+#include "ringstep3_mfma.inc"
 
 template <int NKS, int MT>
 __global__ __launch_bounds__(256, 1) void lstm_layer_wgx2_kernel(LstmWgxArgs wp) {
@@ -1125,13 +1130,20 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_wgx2_kernel(LstmWgxArgs wp)
             x_dma(xptr[r], xbuf + r * 2 * TILE, t0, 0);
             x_dma(xptr[r], xbuf + r * 2 * TILE, p.T > 1 ? t0 + dt : t0, 1);
         }
+    if constexpr (NKS == 12 && MT == 3) {              // h_{-1} = 0: step 0 runs the same stream as every other step, on a zero tile
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int kk = 0; kk < KQ; ++kk)
+                *(uint4_t*)(hbuf + r * 2 * TILE + (wave + 4 * kk) * 1024 + lo) = uint4_t{0u, 0u, 0u, 0u};
+    }
     wait_vm(0);
     __syncthreads();
 #pragma unroll
     for (int r = 0; r < 2; ++r)
         if (r == 0 || two) x_phase(xbuf + r * 2 * TILE, xacc[r]);
 
-    long long st_poll = 0, st_bar = 0;
+    long long st_poll = 0, st_bar = 0, st_sec[6] = {0, 0, 0, 0, 0, 0};      // lstm_tune bit 2: cycles per section (tools/lstm_stats.py)
     const long long st_t0 = __builtin_readcyclecounter();
     const long long st_r0 = (p.tune & 4) ? (long long)__builtin_amdgcn_s_memrealtime() : 0;
 
@@ -1204,8 +1216,10 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_wgx2_kernel(LstmWgxArgs wp)
             x_dma(xptr[r], xb_r, t + 2 * dt, step & 1);
             since[0] += n_dma; since[1] += n_dma;
         }
-        // ---- recurrent part ---------------------------------------------------------------------------------------------------
-        if (step > 0) {
+        const long long pc3 = (p.tune & 4) ? __builtin_readcyclecounter() : 0;
+        constexpr bool WOVEN = NKS == 12 && MT == 3;
+        // ---- recurrent part (H = 384: part of the stream below; step 0 multiplies the zero-filled h tile) ---------------------------
+        if (!WOVEN && step > 0) {
             half8_t hb_f[NKS];
 #pragma unroll
             for (int ks = 0; ks < NKS; ++ks) hb_f[ks] = *(const half8_t*)(hb_r + lo + ks * 1024);
@@ -1215,28 +1229,21 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_wgx2_kernel(LstmWgxArgs wp)
                 for (int m = 0; m < MT; ++m) mfma16_av(whh[m][ks], hb_f[ks], acc[m]);
             mfma_settle_v<MT>(acc);
         }
-        // ---- gate arithmetic of this step; at H = 384 the input projection of the next step (independent work for the matrix
-        //      core) is threaded through it instruction by instruction (cells3_mfma) -------------------------------------------
-        constexpr bool WOVEN = NKS == 12 && MT == 3;
+        const long long pc4 = (p.tune & 4) ? __builtin_readcyclecounter() : 0;
+        // ---- gate arithmetic of this step; at H = 384 ONE hand-scheduled stream (ringstep3_mfma): the recurrent MFMAs tile by tile,
+        //      the gate arithmetic of tile m behind the recurrent MFMAs of tile m + 1, the input projection of the next step
+        //      (independent work for the matrix core) threaded through both, B fragments read from LDS inside the stream ---------
         half_t ho[MT];
         if constexpr (WOVEN) {
-            const char* xb = xb_r + ((step + 1) & 1) * TILE + lo;
-            float4_t xa[MT];
-#pragma unroll
-            for (int m = 0; m < MT; ++m) xa[m] = bias4[m];
-            half8_t bf[NKS];
-#pragma unroll
-            for (int ks = 0; ks < NKS; ++ks) bf[ks] = *(const half8_t*)(xb + ks * 1024);
             float hv[MT];
-            cells3_mfma(acc, cst[r], hv, wih, bf, xa);
+            ringstep3_mfma(xacc[r], cst[r], hv, whh, wih, bias4, lds_addr(hb_r + lo), lds_addr(xb_r + ((step + 1) & 1) * TILE + lo));
 #pragma unroll
             for (int m = 0; m < MT; ++m) ho[m] = (half_t)hv[m];
-#pragma unroll
-            for (int m = 0; m < MT; ++m) xacc[r][m] = xa[m];
         } else {
 #pragma unroll
             for (int m = 0; m < MT; ++m) ho[m] = (half_t)lstm_cell(acc[m][0], acc[m][1], acc[m][2], acc[m][3], cst[r][m]);
         }
+        const long long pc5 = (p.tune & 4) ? __builtin_readcyclecounter() : 0;
         {
             u16_alias_t* sg = (u16_alias_t*)stage + c * U + q * MT;
 #pragma unroll
@@ -1255,6 +1262,7 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_wgx2_kernel(LstmWgxArgs wp)
             *(unsigned long long*)(p.h + ((long)t * p.N + ring_of[r] * 16 + cc) * H + slice * U + part * 4) = packed;
             since[0] += 3; since[1] += 3;
         }
+        const long long pc6 = (p.tune & 4) ? __builtin_readcyclecounter() : 0;
         // ---- input projection of step t+1; around it the validation of the OTHER ring's quarter for its next section: its polls
         //      went out more than half a section ago, and the LDS latency of reading them back hides behind these MFMAs ------------
         constexpr int o = r ^ 1;
@@ -1264,6 +1272,7 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_wgx2_kernel(LstmWgxArgs wp)
         if (chk_o) check_begin(o, step_o, chk);
         if constexpr (!WOVEN) x_phase(xb_r + ((step + 1) & 1) * TILE, xacc[r]);
         if (chk_o) check_end(o, step_o, chk);
+        const long long pc7 = (p.tune & 4) ? __builtin_readcyclecounter() : 0;
         // ---- first poll round for h_t, last in the section: the publishes of the other workgroups are visible by now, and it is
         //      looked at only after the other ring's section. It lands in the OTHER parity of the h tile: the waves of this
         //      workgroup may still be reading the current one ---------------------------------------------------------------------
@@ -1271,6 +1280,10 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_wgx2_kernel(LstmWgxArgs wp)
             poll_dma(exr[r], step & 3, hbuf + (r * 2 + ((step + 1) & 1)) * TILE, 0xFFu);
             since[r] = 0;
             since[r ^ 1] += n_poll;
+        }
+        if (p.tune & 4) {
+            const long long pc8 = __builtin_readcyclecounter();
+            st_sec[0] += pc3 - pc2; st_sec[1] += pc4 - pc3; st_sec[2] += pc5 - pc4; st_sec[3] += pc6 - pc5; st_sec[4] += pc7 - pc6; st_sec[5] += pc8 - pc7;
         }
     };
 
@@ -1286,8 +1299,8 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_wgx2_kernel(LstmWgxArgs wp)
     if ((p.tune & 4) && lane == 0) {
         long long* st = (long long*)((char*)p.xcc_ws + (((size_t)p.n_rings * NSL * sizeof(int) + 64 + 7) & ~(size_t)7)) + ((long)ring_of[0] * NSL + slice) * 16;
         st[0] = __builtin_readcyclecounter() - st_t0;
-        st[1] = st_poll; st[2] = 0; st[3] = 0; st[4] = 0; st[5] = st_bar; st[6] = 0; st[7] = 0;
-        st[8] = 0; st[9] = 0; st[10] = 0; st[11] = 0; st[12] = 0;
+        st[1] = st_poll; st[2] = 0; st[3] = 0; st[4] = 0; st[5] = st_bar; st[6] = 0; st[7] = st_sec[5];
+        st[8] = st_sec[0]; st[9] = st_sec[1]; st[10] = st_sec[2]; st[11] = st_sec[3]; st[12] = st_sec[4];
         st[13] = (long long)__builtin_amdgcn_s_memrealtime() - st_r0;
     }
 }

@@ -1,0 +1,367 @@
+#!/usr/bin/env python3
+"""Generates bonito_amd/csrc/ringstep3_mfma.inc: ONE time step of a ring of the paired recurrent kernel (H = 384: 12 k-steps, three M
+tiles = three cells per lane) as a hand-scheduled instruction stream:
+
+    R[m][ks]:  acc[m] += W_hh[m][ks] * h_{t-1}[ks]       36 MFMAs (recurrent part of step t; acc[m] enters holding bias + W_ih x_t)
+    X[m][ks]:  xa[m]  += W_ih[m][ks] * x_{t+1}[ks]       36 MFMAs (input projection of step t+1; xa[m] enters holding the bias)
+    gates(m):  lstm_cell() of cell m on acc[m]           35 vector instructions each (7 transcendental)
+
+The recurrent part runs TILE-major: once the twelve R[0][*] have issued, cell 0's gate arithmetic has matrix work to hide behind
+(R[1][*] and part of X), cell 1's hides behind R[2][*] and X, cell 2's behind the rest of X - the matrix pipe never waits for the
+vector ALU and the vector ALU never runs alone (the round-2 kernel issued the 36 recurrent MFMAs bare, then wove the three cells
+into the 36 input-projection MFMAs: 1.1 k + 1.25 k cycles per ring step for 1.15 k cycles of MFMA).
+
+B fragments are read from LDS inside the stream (ds_read_b128 into a few rotating registers, explicit lgkmcnt waits): nothing but the
+fragments in flight is live. The accumulation order of every accumulator is that of lstm_layer_wgx_kernel (ks ascending), the gate
+arithmetic is lstm_cell()'s operation for operation => the same bits (tests/test_gpu_encoder.py::test_paired_rings_*).
+
+One asm statement (no operand limit on this target), so the compiler cannot place anything inside the stream. A cell's four
+pre-activations are the four registers of its accumulator tuple; an asm operand cannot name a sub-register, so the three recurrent
+accumulators are PHYSICAL registers (v[PBASE .. PBASE+11], "=&{v[a:b]}" constraints) and the gate arithmetic names their components
+literally. They are pure outputs: the first recurrent MFMA of a tile reads the projected input (xacc[m]) as its C operand and writes
+the tuple (D != C), the first input-projection MFMA reads the bias as C and overwrites xacc[m] - no register copies at either end.
+(A first version cut the stream into four statements and let the compiler rename sub-registers at the cuts: under the register
+pressure of the real kernel it moved accumulator tuples that MFMAs were still writing. tools/audit_ringstep.py is the check that
+found it; it stays as a guard for any multi-statement stream.)
+
+Hazards placed here (the compiler pads nothing inside an asm statement):
+  * MFMA D -> vector ALU read: >= 12 wait states (8-pass XDL) behind the last R[m][*] before gates(m) starts, and behind the last
+    MFMA at the end of the stream (the compiler reads the outputs right behind the statement);
+  * transcendental result -> consumer: at least one instruction in between (gfx940+ trans forwarding hazard);
+  * v_cmp (vcc) -> v_cndmask: at least one instruction in between.
+
+usage: gen_ringstep.py [--xdist a,b,c,d] [--hdepth n] [--xdepth n] [--hf-live] [--name fn] [--out path]
+"""
+import argparse
+import os
+
+L_NEG = "0xbfb8aa3b"      # -log2(e)
+L_POS = "0x3fb8aa3b"      # +log2(e)
+NKS = 12
+
+
+class Ins:
+    def __init__(self, kind, text, reads=(), writes=(), **meta):
+        self.kind = kind            # mfma | valu | trans | cmp | sel | lds | wait | nop
+        self.text = text
+        self.reads = tuple(reads)
+        self.writes = tuple(writes)
+        self.meta = meta
+
+    def states(self):
+        if self.kind == "nop":
+            return self.meta["n"] + 1
+        return 1
+
+
+def nop(n):
+    return Ins("nop", "s_nop %d" % n, n=n)
+
+
+PBASE = 232          # v[PBASE .. PBASE+11]: the three recurrent accumulator tuples (physical registers, see the module docstring)
+
+
+def gates(m):
+    """lstm_cell() of cell m, one dependency-ordered list. g{m}{i}: the four pre-activations = the registers of the accumulator tuple
+    (literal names), reused as temporaries; operands e{m}, c{m} (cell state), hi25 / hi12."""
+    g0, g1, g2, g3 = ("g%d%d" % (m, i) for i in range(4))
+    e, cs = "e%d" % m, "c%d" % m
+
+    def R(n):
+        if n[0] == "g":
+            return "v%d" % (PBASE + 4 * int(n[1]) + int(n[2]))
+        return "%[" + n + "]"
+
+    def v(kind, fmt, dst, *src):
+        names = {"d": R(dst)}
+        for i, s in enumerate(src):
+            names["s%d" % i] = R(s)
+        return Ins(kind, fmt.format(**names), reads=src, writes=(dst,), cell=m)
+
+    seq = []
+    for g, hi in ((g0, "hi25"), (g1, "hi25"), (g2, "hi12"), (g3, "hi25")):
+        seq.append(v("valu", "v_med3_f32 {d}, {s0}, {s1}, -{s1}", g, g, hi))
+    seq.append(v("valu", "v_mul_f32 {d}, " + L_NEG + ", {s0}", g0, g0))
+    seq.append(v("valu", "v_mul_f32 {d}, " + L_NEG + ", {s0}", g1, g1))
+    seq.append(v("valu", "v_mul_f32 {d}, -2.0, {s0}", g2, g2))
+    seq.append(v("valu", "v_mul_f32 {d}, " + L_NEG + ", {s0}", g3, g3))
+    seq.append(v("valu", "v_mul_f32 {d}, " + L_POS + ", {s0}", g2, g2))
+    for g in (g0, g1, g2, g3):
+        seq.append(v("trans", "v_exp_f32 {d}, {s0}", g, g))
+    seq.append(v("valu", "v_add_f32 {d}, 1.0, {s0}", g0, g0))                 # Di = 1 + ei
+    seq.append(v("valu", "v_add_f32 {d}, 1.0, {s0}", g1, g1))                 # Df = 1 + ef
+    seq.append(v("valu", "v_sub_f32 {d}, 1.0, {s0}", e, g2))                  # 1 - eg
+    seq.append(v("valu", "v_add_f32 {d}, 1.0, {s0}", g2, g2))                 # Dg = 1 + eg
+    seq.append(v("valu", "v_mul_f32 {d}, {s0}, {s1}", g0, g0, g2))            # didg
+    seq.append(v("valu", "v_mul_f32 {d}, {s0}, {s1}", e, e, g1))              # (1 - eg) df
+    seq.append(v("valu", "v_mul_f32 {d}, {s0}, {s1}", g2, g1, g0))            # df didg
+    seq.append(v("valu", "v_fma_f32 {d}, {s0}, {s1}, {s2}", e, cs, g0, e))    # num
+    seq.append(v("trans", "v_rcp_f32 {d}, {s0}", g2, g2))
+    seq.append(v("valu", "v_add_f32 {d}, 1.0, {s0}", g3, g3))                 # Do = 1 + eo (independent: sits behind the rcp)
+    seq.append(v("valu", "v_mul_f32 {d}, {s0}, {s1}", cs, e, g2))             # c'
+    seq.append(v("valu", "v_med3_f32 {d}, {s0}, {s1}, -{s1}", g0, cs, "hi12"))
+    seq.append(v("valu", "v_mul_f32 {d}, -2.0, {s0}", g0, g0))
+    seq.append(v("valu", "v_mul_f32 {d}, " + L_POS + ", {s0}", g0, g0))
+    seq.append(v("trans", "v_exp_f32 {d}, {s0}", g0, g0))                     # ec
+    seq.append(v("valu", "v_add_f32 {d}, 1.0, {s0}", g1, g0))
+    seq.append(v("valu", "v_sub_f32 {d}, 1.0, {s0}", g0, g0))
+    seq.append(v("valu", "v_mul_f32 {d}, {s0}, {s1}", g1, g1, g3))
+    seq.append(v("trans", "v_rcp_f32 {d}, {s0}", g1, g1))
+    seq.append(v("valu", "v_mul_f32 {d}, {s0}, {s1}", g0, g0, g1))            # hv
+    seq.append(Ins("cmp", "v_cmp_le_f32_e64 vcc, |%s|, 1.0" % R(g0), reads=(g0,), writes=("vcc",), cell=m))
+    seq.append(Ins("sel", "v_cndmask_b32_e32 %s, 0, %s, vcc" % (R(g0), R(g0)), reads=(g0, "vcc"), writes=(g0,), cell=m))
+    assert len(seq) == 35
+    return seq
+
+
+def merge_even(a, b):
+    """b spread evenly through a (both keep their order)."""
+    if not b:
+        return list(a)
+    if not a:
+        return list(b)
+    out, j = [], 0
+    n, m = len(a), len(b)
+    for i, x in enumerate(a):
+        out.append(x)
+        while j < m and (j + 1) * n <= (i + 1) * m:
+            out.append(b[j]); j += 1
+    out += b[j:]
+    return out
+
+
+def weave(mf, va, lead_m):
+    """va spread evenly over the MFMAs behind the first lead_m of them; leftovers trail."""
+    out = list(mf[:lead_m])
+    rest = mf[lead_m:]
+    if not rest:
+        return out + list(va)
+    n, m = len(rest), len(va)
+    j = 0
+    for i, x in enumerate(rest):
+        out.append(x)
+        want = ((i + 1) * m + n - 1) // n if i + 1 < n else m
+        while j < want:
+            out.append(va[j]); j += 1
+    return out
+
+
+def build(xdist, hdepth, xdepth, hpool, xpool, hf_live, lead, wgroup=1):
+    assert sum(xdist) == 3 * NKS and len(xdist) == 4
+    xs = [(ks, m) for ks in range(NKS) for m in range(3)]
+    xi = 0
+    spine_by_phase = []
+    for p in range(4):
+        # the first recurrent MFMA of every tile goes out at the very start: it reads xacc[m] (as C) before the input projection
+        # of the next step starts to overwrite it
+        R = ([("R", m, 0) for m in range(3)] if p == 0 else []) + ([("R", p, ks) for ks in range(1, NKS)] if p < 3 else [])
+        X = [("X", m, ks) for ks, m in xs[xi:xi + xdist[p]]]
+        xi += xdist[p]
+        spine_by_phase.append(merge_even(R, X) if len(R) >= len(X) else merge_even(X, R))
+
+    def mfma_ins(tag):
+        kind, m, ks = tag
+        if kind == "R":
+            acc, w, frag = "P%d" % m, "wh%d_%d" % (m, ks), ("H", 0 if hf_live else m, ks)
+        else:
+            acc, w, frag = "xa%d" % m, "wi%d_%d" % (m, ks), ("X", 0, ks)
+        return Ins("mfma", None, reads=(w,) if kind == "R" else (acc, w), writes=() if kind == "R" else (acc,), acc=acc, w=w, frag=frag, tag=tag)
+
+    # ---- weave the cells into the phases -----------------------------------------------------------------------------
+    seq = []
+    for p in range(4):
+        mf = [mfma_ins(t) for t in spine_by_phase[p]]
+        va = gates(p - 1) if p >= 1 else []
+        seq += weave(mf, va, lead if p >= 1 else 0)
+
+    # ---- fragment reads: `depth` MFMAs ahead of the first use, into rotating registers ---------------------------------
+    mf_pos = [i for i, x in enumerate(seq) if x.kind == "mfma"]
+    frags, first, last = [], {}, {}
+    for n, i in enumerate(mf_pos):
+        f = seq[i].meta["frag"]
+        if f not in first:
+            first[f] = n; frags.append(f)
+        last[f] = n
+    pools = {"H": [], "X": []}
+    reg_of, issue_after = {}, {}
+    for f in frags:
+        pool = pools[f[0]]
+        size = (NKS if hf_live else hpool) if f[0] == "H" else xpool
+        depth = hdepth if f[0] == "H" else xdepth
+        j = len(pool)
+        reg_of[f] = ("ht%d" if f[0] == "H" else "xt%d") % (j % size)
+        free_after = last[pool[j - size]] if j >= size else -1
+        issue_after[f] = max(first[f] - depth - 1, free_after, -1)
+        assert issue_after[f] < first[f]
+        pool.append(f)
+    reads_at = {}
+    for f in frags:
+        reads_at.setdefault(issue_after[f], []).append(f)
+
+    def lds_ins(f):
+        base, off = ("hb", f[2] * 1024) if f[0] == "H" else ("xb", f[2] * 1024)
+        return Ins("lds", "ds_read_b128 %%[%s], %%[%s] offset:%d" % (reg_of[f], base, off), reads=(base,), writes=(reg_of[f],), frag=f)
+
+    out = [lds_ins(f) for f in reads_at.get(-1, [])]
+    n = -1
+    for x in seq:
+        out.append(x)
+        if x.kind == "mfma":
+            n += 1
+            out += [lds_ins(f) for f in reads_at.get(n, [])]
+    seq = out
+    def tup(m):
+        return "v[%d:%d]" % (PBASE + 4 * m, PBASE + 4 * m + 3)
+
+    for x in seq:
+        if x.kind == "mfma":
+            b = reg_of[x.meta["frag"]]
+            x.reads = x.reads + (b,)
+            kind, m, ks = x.meta["tag"]
+            if kind == "R":
+                d, c = tup(m), ("%%[xa%d]" % m if ks == 0 else tup(m))
+                if ks == 0:
+                    x.reads = x.reads + ("xa%d" % m,)
+            else:
+                d, c = "%%[xa%d]" % m, ("%%[bi%d]" % m if ks == 0 else "%%[xa%d]" % m)
+                if ks == 0:
+                    x.reads = tuple(r for r in x.reads if r != "xa%d" % m) + ("bi%d" % m,)
+            x.text = "v_mfma_f32_16x16x32_f16 %s, %%[%s], %%[%s], %s" % (d, x.meta["w"], b, c)
+    # the first input-projection MFMA of a tile overwrites xacc[m]: the recurrent MFMA that reads it must have issued
+    pos = {x.meta["tag"]: i for i, x in enumerate(seq) if x.kind == "mfma"}
+    for m in range(3):
+        assert pos[("R", m, 0)] < pos[("X", m, 0)]
+
+    # ---- waits: LDS returns in order; wait for exactly as many as were issued behind the one needed ----------------------
+    out, issued, done = [], [], -1
+    for x in seq:
+        if x.kind == "lds":
+            issued.append(x.meta["frag"])
+        elif x.kind == "mfma":
+            r = max(i for i, f in enumerate(issued) if f == x.meta["frag"])
+            if r > done:
+                r = min(r + wgroup - 1, len(issued) - 1)          # wgroup > 1: one wait covers the next fragments too (fewer issue slots)
+                out.append(Ins("wait", "s_waitcnt lgkmcnt(%d)" % (len(issued) - 1 - r)))
+                done = r
+        out.append(x)
+    seq = out
+
+    # ---- hazards -----------------------------------------------------------------------------------------------------
+    out = []
+    last_r = {}                      # cell -> index in out of its last R MFMA
+    started = set()
+    for x in seq:
+        cell = x.meta.get("cell")
+        if cell is not None and cell not in started:
+            started.add(cell)
+            gap = sum(y.states() for y in out[last_r[cell] + 1:])
+            if gap < 12:
+                out.append(nop(12 - gap - 1))
+        if out and out[-1].kind == "trans" and set(out[-1].writes) & set(x.reads):
+            out.append(nop(0))
+        if x.kind == "sel" and out[-1].kind == "cmp":
+            out.append(nop(0))
+        out.append(x)
+        if x.kind == "mfma" and x.meta["tag"][0] == "R":
+            last_r[x.meta["tag"][1]] = len(out) - 1
+    last_m = max(i for i, y in enumerate(out) if y.kind == "mfma")
+    gap = sum(y.states() for y in out[last_m + 1:])
+    if gap < 12:
+        out.append(nop(12 - gap - 1))
+    out.append(Ins("wait", "s_waitcnt lgkmcnt(0)"))
+    return out
+
+
+def operand(name):
+    """name -> (register class, c++ expression)"""
+    if name.startswith("wh"):
+        m, ks = name[2:].split("_")
+        return "a", "whh[%s][%s]" % (m, ks)
+    if name.startswith("wi"):
+        m, ks = name[2:].split("_")
+        return ("a" if int(m) < 2 else "v"), "wih[%s][%s]" % (m, ks)
+    if name.startswith("xa"):
+        return "v", "xacc[%s]" % name[2:]
+    if name.startswith("bi"):
+        return "v", "bias[%s]" % name[2:]
+    if name.startswith("ht") or name.startswith("xt"):
+        return "v", name
+    if name[0] == "e":
+        return "v", "e[%s]" % name[1]
+    if name[0] == "c":
+        return "v", "cst[%s]" % name[1]
+    if name in ("hb", "xb"):
+        return "v", name
+    if name == "hi25":
+        return "v", "25.0f"
+    if name == "hi12":
+        return "v", "12.5f"
+    raise KeyError(name)
+
+
+def render(seq, fn, hf_live, header):
+    lines = ["// GENERATED by tools/gen_ringstep.py - do not edit. " + header,
+             "// in: xacc[m] = bias + W_ih x_t (tile m), cst; h_{t-1} fragments at LDS address hb, x_{t+1} fragments at xb (+ lane * 16 each)",
+             "// out: hv[m] = h_t of the lane's three cells, cst, xacc[m] = bias + W_ih x_{t+1}",
+             "__device__ __forceinline__ void %s(float4_t (&xacc)[3], float (&cst)[3], float (&hv)[3], const half8_t (&whh)[3][12]," % fn,
+             "        const half8_t (&wih)[3][12], const float4_t (&bias)[3], unsigned hb, unsigned xb) {",
+             "    float e[3];",
+             "    float4_t acc[3];",
+             "    half8_t " + ", ".join(["ht%d" % i for i in range(NKS if hf_live else 8)] + ["xt%d" % i for i in range(4)]) + ";"]
+    first_access, written = {}, set()
+    for x in seq:
+        for r in x.reads:
+            if r != "vcc" and r[0] not in "gP":
+                first_access.setdefault(r, "r")
+        for w in x.writes:
+            if w != "vcc" and w[0] not in "gP":
+                first_access.setdefault(w, "w"); written.add(w)
+    outs = ['"=&{v[%d:%d]}"(acc[%d])' % (PBASE + 4 * m, PBASE + 4 * m + 3, m) for m in range(3)]
+    ins = []
+    for name in first_access:
+        cls, expr = operand(name)
+        if name in written:
+            outs.append('[%s] "%s"(%s)' % (name, ("+" if first_access[name] == "r" else "=&") + cls, expr))
+        else:
+            ins.append('[%s] "%s"(%s)' % (name, cls, expr))
+    body = '\\n\\t"\n        "'.join(x.text for x in seq)
+    lines.append('    asm volatile("' + body + '"\n        : ' + ", ".join(outs) + "\n        : " + ", ".join(ins) + '\n        : "vcc");')
+    if any(x.meta.get("cell") is not None for x in seq):
+        lines += ["    hv[0] = acc[0][0]; hv[1] = acc[1][0]; hv[2] = acc[2][0];", "}", ""]
+    else:
+        lines += ["    hv[0] = acc[0][0]; hv[1] = acc[1][0]; hv[2] = acc[2][0]; (void)e;", "}", ""]
+    return "\n".join(lines)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--xdist", default="0,12,12,12")
+    ap.add_argument("--hdepth", type=int, default=5)
+    ap.add_argument("--xdepth", type=int, default=6)
+    ap.add_argument("--hpool", type=int, default=6)
+    ap.add_argument("--xpool", type=int, default=3)
+    ap.add_argument("--lead", type=int, default=2, help="MFMAs of a phase in front of its first vector instruction")
+    ap.add_argument("--wgroup", type=int, default=1, help="fragments covered by one lgkmcnt wait")
+    ap.add_argument("--strip", default="", help="timing experiments only (wrong results): 'valu' drops the gate arithmetic, 'mfma' drops MFMAs + LDS reads")
+    ap.add_argument("--hf-live", action="store_true", help="keep the twelve h fragments in registers instead of re-reading them per tile")
+    ap.add_argument("--name", default="ringstep3_mfma")
+    ap.add_argument("--out", default=os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bonito_amd", "csrc", "ringstep3_mfma.inc"))
+    a = ap.parse_args()
+    xdist = tuple(int(v) for v in a.xdist.split(","))
+    seq = build(xdist, a.hdepth, a.xdepth, a.hpool, a.xpool, a.hf_live, a.lead, a.wgroup)
+    if a.strip == "valu":
+        seq = [x for x in seq if x.kind not in ("valu", "trans", "cmp", "sel")]
+    elif a.strip == "mfma":
+        seq = [x for x in seq if x.kind not in ("mfma", "lds", "wait")]
+    counts = {}
+    for x in seq:
+        counts[x.kind] = counts.get(x.kind, 0) + 1
+    header = "xdist=%s hdepth=%d xdepth=%d hpool=%d xpool=%d lead=%d wgroup=%d hf_live=%d : %s" % (
+        a.xdist, a.hdepth, a.xdepth, a.hpool, a.xpool, a.lead, a.wgroup, a.hf_live, " ".join("%s=%d" % kv for kv in sorted(counts.items())))
+    with open(a.out, "w") as fh:
+        fh.write(render(seq, a.name, a.hf_live, header))
+    print("wrote", a.out, header)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,30 @@
+#!/usr/bin/env python3
+"""Cycle statistics of lstm_layer_wgx2_kernel (two rings per workgroup), lstm_tune bit 2: where does a ring step go?
+usage: lstm_stats2.py [batch=1024]"""
+import ctypes as C, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from bonito_amd import synthetic, _lib
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+model = synthetic.make_model("hac")
+model.use_koi(batchsize=N, chunksize=10000, quantize=False)
+model = model.half().cuda()
+sig = torch.randn(N, 1, 10000, device="cuda").half()
+model(sig)
+enc = model._hip
+print(enc.describe().splitlines()[4])
+enc.set_option("lstm_tune", 4)
+model(sig); torch.cuda.synchronize(); enc.check()
+rings, nsl, T = N // 16, 32, 1667
+pairs = (rings + 1) // 2
+off = (rings * nsl * 4 + 64 + 7) & ~7
+st = np.zeros((rings, nsl, 16), np.int64)
+_lib.check(_lib.lib().bh_encoder_debug_read(enc._handle, st.ctypes.data_as(C.c_void_p), st.nbytes, off))
+st = st[:pairs].astype(float)                      # a workgroup reports under its first ring
+tot = st[..., 0]
+print("cycles per pair step (two ring steps): mean %.0f (min %.0f max %.0f) -> %.0f per ring step" % (tot.mean() / T, tot.min() / T, tot.max() / T, tot.mean() / T / 2))
+names = ["barrier", "x-stream DMA issue", "recurrent MFMAs (or: the whole stream)", "gates + input projection", "transpose + stores", "validate other ring", "poll issue"]
+idx = [5, 8, 9, 10, 11, 12, 7]
+for n, i in zip(names, idx):
+    print("  %-42s %7.0f per ring step" % (n, st[..., i].mean() / T / 2))
+print("shader clock during the kernel: %.2f GHz" % (tot.mean() / st[..., 13].mean() * 0.1))
