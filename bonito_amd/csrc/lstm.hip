@@ -1016,8 +1016,31 @@ __device__ __forceinline__ void wait_vm(int n) {       // s_waitcnt vmcnt(n), n 
 // tools/gen_ringstep.py, statement cuts audited on the compiled ISA by tools/audit_ringstep.py (tests/test_abi.py).
 __device__ __forceinline__ unsigned lds_addr(const char* p) { return (unsigned)(size_t)(__attribute__((address_space(3))) const char*)p; }
 #include "ringstep3_mfma.inc"
-
 template <int NKS, int MT>
+__device__ __forceinline__ void ring_stream(float4_t (&xacc)[MT], float (&cst)[MT], float (&hv)[MT], const half8_t (&whh)[MT][NKS],
+                                            const half8_t (&wih)[MT][NKS], const float4_t (&bias)[MT], unsigned hb, unsigned xb) {
+    if constexpr (NKS == 12 && MT == 3) ringstep3_mfma(xacc, cst, hv, whh, wih, bias, hb, xb);      // the only generated width so far
+}
+
+// Vector-memory operations of the H = 384 fast path with SCALAR addressing: a wave-uniform 64-bit base in an SGPR pair plus a 32-bit
+// per-lane byte offset that is loop-invariant (the compiler's per-lane 64-bit address arithmetic, the generic -> LDS pointer
+// conversions in front of every M0 write and the spilled scalars behind them were ~55 instructions for the three x-stream DMAs of a
+// ring step alone). IMM: immediate byte offset (13-bit signed) - keep it 0 for LDS-DMA: the hardware adds the instruction offset to
+// the LDS address as well as to the global one. The DMA lands at LDS address lds_a + lane * 16.
+template <int IMM, bool POLL>
+__device__ __forceinline__ void dma16_s(const char* sbase, unsigned voff, unsigned lds_a) {
+    if constexpr (POLL)
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 offset:%3 sc0 sc1" ::"s"(lds_a), "v"(voff), "s"(sbase), "i"(IMM) : "memory");
+    else
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 offset:%3" ::"s"(lds_a), "v"(voff), "s"(sbase), "i"(IMM) : "memory");
+}
+template <bool SC1>
+__device__ __forceinline__ void store8_s(const char* sbase, unsigned voff, unsigned long long v) {
+    if constexpr (SC1) asm volatile("global_store_dwordx2 %0, %1, %2 sc1" ::"v"(voff), "v"(v), "s"(sbase) : "memory");
+    else asm volatile("global_store_dwordx2 %0, %1, %2" ::"v"(voff), "v"(v), "s"(sbase) : "memory");
+}
+
+template <int NKS, int MT, bool STATS = false>
 __global__ __launch_bounds__(256, 1) void lstm_layer_wgx2_kernel(LstmWgxArgs wp) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const LstmFusedArgs& fp = wp.f;
@@ -1091,6 +1114,23 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_wgx2_kernel(LstmWgxArgs wp)
         for (int m = 0; m < MT; ++m) cst[r][m] = 0.f;
     }
 
+    // H = 384 fast path (two rings): loop-invariant per-lane byte offsets for the scalar-addressed vector-memory operations
+    constexpr bool FASTPATH = NKS == 12 && MT == 3;
+    const unsigned smem_a = lds_addr(smem);             // hbuf at +0, xbuf at +4 TILE
+    unsigned vx_off[2], vh_off[2], vp_off[KQ];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int ring = (r == 0 || two) ? ring_of[r] : ring_of[0];
+        vx_off[r] = (unsigned)(((ring * 16 + c) * H + q * 8) * 2 + (3 - wave) * 64);       // x row of my chunk, my first k-step share
+        vh_off[r] = (unsigned)(((ring * 16 + cc) * H + slice * U + part * 4) * 2);        // my 8 bytes of the layer output row
+    }
+#pragma unroll
+    for (int kk = 0; kk < KQ; ++kk) vp_off[kk] = (unsigned)(lo + (wave + 4 * kk) * 1024);  // my k-steps inside an exchange slot
+    const long row_bytes = x_row * 2;
+    const char* xrow2 = (const char*)fp.x + (long)(p.T > 2 ? t0 + 2 * dt : t0) * row_bytes;   // row of x_{t+2} (uniform), advanced per step
+    const char* xrow_any = (const char*)fp.x + (long)t0 * row_bytes;
+    char* hrow = (char*)p.h + (long)t0 * row_bytes;                                          // row of h_t in the layer output
+
     auto x_phase = [&](const char* xb, float4_t (&xa)[MT]) {
 #pragma unroll
         for (int m = 0; m < MT; ++m) xa[m] = bias4[m];
@@ -1143,7 +1183,7 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_wgx2_kernel(LstmWgxArgs wp)
     for (int r = 0; r < 2; ++r)
         if (r == 0 || two) x_phase(xbuf + r * 2 * TILE, xacc[r]);
 
-    long long st_poll = 0, st_bar = 0, st_sec[6] = {0, 0, 0, 0, 0, 0};      // lstm_tune bit 2: cycles per section (tools/lstm_stats.py)
+    long long st_poll = 0, st_bar = 0, st_slow = 0, st_sec[6] = {0, 0, 0, 0, 0, 0};      // lstm_tune bit 2: cycles per section (tools/lstm_stats.py)
     const long long st_t0 = __builtin_readcyclecounter();
     const long long st_r0 = (p.tune & 4) ? (long long)__builtin_amdgcn_s_memrealtime() : 0;
 
@@ -1189,6 +1229,76 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_wgx2_kernel(LstmWgxArgs wp)
     auto ring_step = [&](auto rc, auto two_c, int step, int t) {
         constexpr int r = decltype(rc)::value;
         constexpr bool TWO = decltype(two_c)::value;
+        if constexpr (FASTPATH && TWO) {
+            // ---- H = 384, two rings: the section as straight-line code. Every vector-memory operation is scalar-addressed, their
+            //      number per section is a constant (x stream 3, polls 3, stores 3: the wait in front of the validation is a literal
+            //      vmcnt(3)), the validation's common case is one OR tree and one branch ------------------------------------------------
+            constexpr int o = r ^ 1;
+            const int par = step & 1;
+            const long long q0 = STATS ? __builtin_readcyclecounter() : 0;
+            __syncthreads();                     // the h tile (all quarters validated) and the x tile of this step are complete
+            const long long q1 = STATS ? __builtin_readcyclecounter() : 0;
+            {   // x_{t+2} into the x slot the previous step's input projection consumed (past the end: a valid row, into a slot nobody reads)
+                const char* src = (step + 2 < p.T) ? xrow2 : xrow_any;
+                const unsigned m0 = smem_a + (4 + r * 2 + par) * TILE + (3 - wave) * 1024;
+                dma16_s<0, false>(src, vx_off[r], m0);                        // (no immediate offsets: an LDS-DMA adds them to the LDS address too)
+                dma16_s<0, false>(src + 256, vx_off[r], m0 + 4096);
+                dma16_s<0, false>(src + 512, vx_off[r], m0 + 8192);
+            }
+            // ---- first poll round for the OTHER ring's h (published in its section, the one before this): its round trip passes behind
+            //      this ring's whole stream. Not earlier: a publish is visible to the other workgroups ~0.45 k cycles later, and a round
+            //      that comes back incomplete costs a second round trip on the critical path (polls right behind the own publish:
+            //      38 % of the validations needed a re-poll) ------------------------------------------------------------------------------
+            const int step_o = r == 0 ? step : step + 1;
+            const bool chk_o = step_o >= 1 && step_o < p.T;
+            if (chk_o) {
+                const char* exo = exr[o] + (long)((step_o - 1) & 3) * slot_stride;
+                const unsigned m0 = smem_a + (o * 2 + (step_o & 1)) * TILE + wave * 1024;
+                dma16_s<0, true>(exo, vp_off[0], m0);
+                dma16_s<0, true>(exo, vp_off[1], m0 + 4096);
+                dma16_s<0, true>(exo, vp_off[2], m0 + 8192);
+            }
+            const long long q2 = STATS ? __builtin_readcyclecounter() : 0;
+            float hv[MT];
+            ring_stream<NKS, MT>(xacc[r], cst[r], hv, whh, wih, bias4, smem_a + (r * 2 + par) * TILE + lo, smem_a + (4 + r * 2 + (par ^ 1)) * TILE + lo);
+            const long long q3 = STATS ? __builtin_readcyclecounter() : 0;
+            const char* exs = exr[r] + (long)(step & 3) * slot_stride;           // the exchange slot of h_t (uniform)
+            {
+                u16_alias_t* sg = (u16_alias_t*)stage + c * U + q * MT;
+#pragma unroll
+                for (int m = 0; m < MT; ++m) sg[m] = __builtin_bit_cast(unsigned short, (half_t)hv[m]);
+                const unsigned long long packed = *(const u64_alias_t*)((half_t*)stage + cc * U + part * 4);
+                const char* exa = exr[r] + (long)((step + 2) & 3) * slot_stride; // the slot re-armed for h_{t+2}
+                if (fast[r]) { store8_s<false>(exs, (unsigned)my_byte, packed); store8_s<false>(exa, (unsigned)my_byte, ~0ull); }
+                else { store8_s<true>(exs, (unsigned)my_byte, packed); store8_s<true>(exa, (unsigned)my_byte, ~0ull); }
+                store8_s<false>(hrow, vh_off[r], packed);
+            }
+            const long long q4 = STATS ? __builtin_readcyclecounter() : 0;
+            // ---- my quarter of the OTHER ring's next h tile: only the three stores above are younger than its polls -----------------
+            if (chk_o) {
+                __builtin_amdgcn_s_waitcnt(0x0F73);                              // vmcnt(3)
+                asm volatile("" ::: "memory");
+                if constexpr (STATS) st_sec[1] += __builtin_readcyclecounter() - q4;         // (time in that wait)
+                const char* hbo = hbuf + (o * 2 + (step_o & 1)) * TILE + lo;
+                uint4_t chk[KQ];
+#pragma unroll
+                for (int kk = 0; kk < KQ; ++kk) chk[kk] = *(const uint4_t*)(hbo + (wave + 4 * kk) * 1024);
+                unsigned any = 0;
+#pragma unroll
+                for (int kk = 0; kk < KQ; ++kk) any |= chk[kk].x | chk[kk].y | chk[kk].z | chk[kk].w;
+                if (__builtin_expect(__any((any & SENTINEL_MASK) != 0) || dead, 0)) {
+                    const long long s0 = STATS ? __builtin_readcyclecounter() : 0;
+                    check_end(o, step_o, chk);
+                    if constexpr (STATS) { st_poll += __builtin_readcyclecounter() - s0; ++st_slow; }
+                }
+            }
+            const long long q5 = STATS ? __builtin_readcyclecounter() : 0;
+            if constexpr (STATS) {
+                const long long q6 = __builtin_readcyclecounter();
+                st_bar += q1 - q0; st_sec[0] += q2 - q1; st_sec[2] += q3 - q2; st_sec[3] += q4 - q3; st_sec[4] += q5 - q4; st_sec[5] += q6 - q5;
+            }
+            return;
+        }
         char* hb_r = hbuf + (r * 2 + (step & 1)) * TILE;
         char* xb_r = xbuf + r * 2 * TILE;
         float4_t acc[MT];
@@ -1236,7 +1346,7 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_wgx2_kernel(LstmWgxArgs wp)
         half_t ho[MT];
         if constexpr (WOVEN) {
             float hv[MT];
-            ringstep3_mfma(xacc[r], cst[r], hv, whh, wih, bias4, lds_addr(hb_r + lo), lds_addr(xb_r + ((step + 1) & 1) * TILE + lo));
+            ring_stream<NKS, MT>(xacc[r], cst[r], hv, whh, wih, bias4, lds_addr(hb_r + lo), lds_addr(xb_r + ((step + 1) & 1) * TILE + lo));
 #pragma unroll
             for (int m = 0; m < MT; ++m) ho[m] = (half_t)hv[m];
         } else {
@@ -1289,17 +1399,21 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_wgx2_kernel(LstmWgxArgs wp)
 
     auto run = [&](auto two_c) {
         int t = t0;
+        const long drow = dt * row_bytes;
         for (int step = 0; step < p.T; ++step, t += dt) {
             ring_step(std::integral_constant<int, 0>{}, two_c, step, t);
             if constexpr (decltype(two_c)::value) ring_step(std::integral_constant<int, 1>{}, two_c, step, t);
+            xrow2 += drow;
+            hrow += drow;
         }
     };
     if (two) run(std::true_type{});
     else run(std::false_type{});
+    wait_vm(0);                                         // (the unconditional x-stream DMA of the last steps must have landed before the LDS is released)
     if ((p.tune & 4) && lane == 0) {
         long long* st = (long long*)((char*)p.xcc_ws + (((size_t)p.n_rings * NSL * sizeof(int) + 64 + 7) & ~(size_t)7)) + ((long)ring_of[0] * NSL + slice) * 16;
         st[0] = __builtin_readcyclecounter() - st_t0;
-        st[1] = st_poll; st[2] = 0; st[3] = 0; st[4] = 0; st[5] = st_bar; st[6] = 0; st[7] = st_sec[5];
+        st[1] = st_poll; st[2] = st_slow; st[3] = 0; st[4] = 0; st[5] = st_bar; st[6] = 0; st[7] = st_sec[5];
         st[8] = st_sec[0]; st[9] = st_sec[1]; st[10] = st_sec[2]; st[11] = st_sec[3]; st[12] = st_sec[4];
         st[13] = (long long)__builtin_amdgcn_s_memrealtime() - st_r0;
     }
@@ -1890,6 +2004,12 @@ int bh_k_lstm_layer_wgx2(const void* x, const void* wih_packed, const float* bia
                                          g_max_spins, xcc_ws, force_slow & 1, force_slow >> 8}},
                   (char*)ex, R};
     const size_t lds = (size_t)8 * nks * 1024 + 4 * 16 * U * 2;
+    if (nks == 12 && U == 12 && ((force_slow >> 8) & 4)) {          // lstm_tune bit 2: the instance with section stamps (tools/lstm_stats2.py)
+        BH_CHECK_HIP(hipFuncSetAttribute((const void*)lstm_layer_wgx2_kernel<12, 3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL((lstm_layer_wgx2_kernel<12, 3, true>), dim3(grid), dim3(256), lds, stream, a);
+        BH_CHECK_HIP(hipGetLastError());
+        return 0;
+    }
 #define BH_LSTM_WGX2(NKS, MT)                                                                                    \
     if (nks == NKS && U == 4 * MT) {                                                                             \
         if (lds > 64 * 1024)                                                                                     \

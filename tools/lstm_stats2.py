@@ -23,8 +23,9 @@ _lib.check(_lib.lib().bh_encoder_debug_read(enc._handle, st.ctypes.data_as(C.c_v
 st = st[:pairs].astype(float)                      # a workgroup reports under its first ring
 tot = st[..., 0]
 print("cycles per pair step (two ring steps): mean %.0f (min %.0f max %.0f) -> %.0f per ring step" % (tot.mean() / T, tot.min() / T, tot.max() / T, tot.mean() / T / 2))
-names = ["barrier", "x-stream DMA issue", "recurrent MFMAs (or: the whole stream)", "gates + input projection", "transpose + stores", "validate other ring", "poll issue"]
-idx = [5, 8, 9, 10, 11, 12, 7]
+names = ["barrier", "x-stream DMA issue", "the stream (recurrent MFMAs + gates + input projection)", "transpose + stores", "validate other ring", "  of which: vmcnt wait", "  of which: re-poll rounds", "poll issue"]
+idx = [5, 8, 10, 11, 12, 9, 1, 7]
 for n, i in zip(names, idx):
-    print("  %-42s %7.0f per ring step" % (n, st[..., i].mean() / T / 2))
+    print("  %-58s %7.0f per ring step" % (n, st[..., i].mean() / T / 2))
+print("validations that needed a re-poll: %.2f %% of the ring steps" % (100 * st[..., 2].mean() / T / 2))
 print("shader clock during the kernel: %.2f GHz" % (tot.mean() / st[..., 13].mean() * 0.1))
