@@ -1016,12 +1016,22 @@ __device__ __forceinline__ void wait_vm(int n) {       // s_waitcnt vmcnt(n), n 
 // tools/gen_ringstep.py, statement cuts audited on the compiled ISA by tools/audit_ringstep.py (tests/test_abi.py).
 __device__ __forceinline__ unsigned lds_addr(const char* p) { return (unsigned)(size_t)(__attribute__((address_space(3))) const char*)p; }
 #include "ringstep3_mfma.inc"
+// The same stream for the two-ring section of the fast path, carrying the section's vector-memory work as well (gen_ringstep.py
+// --polls-at --xdma-at --validate-at): the OTHER ring's three poll DMAs, this ring's three x-stream DMAs, and near the end the
+// read-back of my quarter of the other ring's h tile (`bad`: lanes that still found the exchange sentinel).
+#include "ringstep3p_mfma.inc"
 template <int NKS, int MT>
 __device__ __forceinline__ void ring_stream(float4_t (&xacc)[MT], float (&cst)[MT], float (&hv)[MT], const half8_t (&whh)[MT][NKS],
                                             const half8_t (&wih)[MT][NKS], const float4_t (&bias)[MT], unsigned hb, unsigned xb) {
     if constexpr (NKS == 12 && MT == 3) ringstep3_mfma(xacc, cst, hv, whh, wih, bias, hb, xb);      // the only generated width so far
 }
-
+template <int NKS, int MT, int KQ>
+__device__ __forceinline__ void ring_stream_paired(float4_t (&xacc)[MT], float (&cst)[MT], float (&hv)[MT], const half8_t (&whh)[MT][NKS],
+                                                   const half8_t (&wih)[MT][NKS], const float4_t (&bias)[MT], unsigned hb, unsigned xb,
+                                                   unsigned long long& bad, unsigned pm0, const char* exo, const unsigned (&vp)[KQ],
+                                                   unsigned xm0, const char* xsrc, unsigned vx, unsigned hbo) {
+    if constexpr (NKS == 12 && MT == 3) ringstep3p_mfma(xacc, cst, hv, whh, wih, bias, hb, xb, bad, pm0, exo, vp, xm0, xsrc, vx, hbo);
+}
 // Vector-memory operations of the H = 384 fast path with SCALAR addressing: a wave-uniform 64-bit base in an SGPR pair plus a 32-bit
 // per-lane byte offset that is loop-invariant (the compiler's per-lane 64-bit address arithmetic, the generic -> LDS pointer
 // conversions in front of every M0 write and the spilled scalars behind them were ~55 instructions for the three x-stream DMAs of a
@@ -1230,40 +1240,42 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_wgx2_kernel(LstmWgxArgs wp)
         constexpr int r = decltype(rc)::value;
         constexpr bool TWO = decltype(two_c)::value;
         if constexpr (FASTPATH && TWO) {
-            // ---- H = 384, two rings: the section as straight-line code. Every vector-memory operation is scalar-addressed, their
-            //      number per section is a constant (x stream 3, polls 3, stores 3: the wait in front of the validation is a literal
-            //      vmcnt(3)), the validation's common case is one OR tree and one branch ------------------------------------------------
+            // ---- H = 384, two rings: one barrier, one instruction stream, three stores. The stream (ringstep3p_mfma) carries the
+            //      section's other vector-memory work at chosen points of its MFMA sequence: the OTHER ring's first poll round (not
+            //      before its publishes are visible, ~0.45 k cycles behind them; early enough to be back by the end of the stream),
+            //      this ring's x-stream DMAs behind them, and at the end - behind a literal vmcnt(3): only the x stream is younger than
+            //      the polls - the read-back of my quarter of the other ring's h tile, OR-ed into `bad`. All of it scalar-addressed;
+            //      the operation count per section is a constant (polls 3, x stream 3, stores 3) ---------------------------------------
             constexpr int o = r ^ 1;
             const int par = step & 1;
             const long long q0 = STATS ? __builtin_readcyclecounter() : 0;
-            __syncthreads();                     // the h tile (all quarters validated) and the x tile of this step are complete
+            __syncthreads();                      // the h tile (all quarters validated in the other ring's section) and the x tile of step t+1 are complete
             const long long q1 = STATS ? __builtin_readcyclecounter() : 0;
-            {   // x_{t+2} into the x slot the previous step's input projection consumed (past the end: a valid row, into a slot nobody reads)
-                const char* src = (step + 2 < p.T) ? xrow2 : xrow_any;
-                const unsigned m0 = smem_a + (4 + r * 2 + par) * TILE + (3 - wave) * 1024;
-                dma16_s<0, false>(src, vx_off[r], m0);                        // (no immediate offsets: an LDS-DMA adds them to the LDS address too)
-                dma16_s<0, false>(src + 256, vx_off[r], m0 + 4096);
-                dma16_s<0, false>(src + 512, vx_off[r], m0 + 8192);
-            }
-            // ---- first poll round for the OTHER ring's h (published in its section, the one before this): its round trip passes behind
-            //      this ring's whole stream. Not earlier: a publish is visible to the other workgroups ~0.45 k cycles later, and a round
-            //      that comes back incomplete costs a second round trip on the critical path (polls right behind the own publish:
-            //      38 % of the validations needed a re-poll) ------------------------------------------------------------------------------
+            // Where there is nothing to poll (first / last section) the three DMAs land in the parity of the other ring's h tile that
+            // nobody reads and the validation's verdict is ignored: the operation count stays constant
             const int step_o = r == 0 ? step : step + 1;
             const bool chk_o = step_o >= 1 && step_o < p.T;
-            if (chk_o) {
-                const char* exo = exr[o] + (long)((step_o - 1) & 3) * slot_stride;
-                const unsigned m0 = smem_a + (o * 2 + (step_o & 1)) * TILE + wave * 1024;
-                dma16_s<0, true>(exo, vp_off[0], m0);
-                dma16_s<0, true>(exo, vp_off[1], m0 + 4096);
-                dma16_s<0, true>(exo, vp_off[2], m0 + 8192);
-            }
-            const long long q2 = STATS ? __builtin_readcyclecounter() : 0;
+            const char* exo = exr[o] + (long)((step_o - 1) & 3) * slot_stride;
+            // (readfirstlane: the expression shares its terms with the per-lane address below and would otherwise be built in a VGPR)
+            const unsigned pm0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(smem_a + (o * 2 + ((step_o & 1) ^ (chk_o ? 0 : 1))) * TILE + wave * 1024));
+            const unsigned hbo = smem_a + (o * 2 + (step_o & 1)) * TILE + wave * 1024 + lo;
+            const char* xsrc = (step + 2 < p.T) ? xrow2 : xrow_any;          // past the end: a valid row, into a slot nobody reads
+            const unsigned xm0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(smem_a + (4 + r * 2 + par) * TILE + (3 - wave) * 1024));
+            unsigned long long bad;
             float hv[MT];
-            ring_stream<NKS, MT>(xacc[r], cst[r], hv, whh, wih, bias4, smem_a + (r * 2 + par) * TILE + lo, smem_a + (4 + r * 2 + (par ^ 1)) * TILE + lo);
+            ring_stream_paired<NKS, MT, KQ>(xacc[r], cst[r], hv, whh, wih, bias4, smem_a + (r * 2 + par) * TILE + lo,
+                                            smem_a + (4 + r * 2 + (par ^ 1)) * TILE + lo, bad, pm0, exo, vp_off, xm0, xsrc, vx_off[r], hbo);
             const long long q3 = STATS ? __builtin_readcyclecounter() : 0;
-            const char* exs = exr[r] + (long)(step & 3) * slot_stride;           // the exchange slot of h_t (uniform)
+            if (__builtin_expect(chk_o && (bad != 0 || dead), 0)) {              // some element had not arrived: re-poll it, bounded
+                uint4_t chk[KQ];
+#pragma unroll
+                for (int kk = 0; kk < KQ; ++kk) chk[kk] = *(const uint4_t*)(hbuf + (o * 2 + (step_o & 1)) * TILE + (wave + 4 * kk) * 1024 + lo);
+                check_end(o, step_o, chk);
+                if constexpr (STATS) { st_poll += __builtin_readcyclecounter() - q3; ++st_slow; }
+            }
+            const long long q4 = STATS ? __builtin_readcyclecounter() : 0;
             {
+                const char* exs = exr[r] + (long)(step & 3) * slot_stride;       // the exchange slot of h_t (uniform)
                 u16_alias_t* sg = (u16_alias_t*)stage + c * U + q * MT;
 #pragma unroll
                 for (int m = 0; m < MT; ++m) sg[m] = __builtin_bit_cast(unsigned short, (half_t)hv[m]);
@@ -1273,29 +1285,9 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_wgx2_kernel(LstmWgxArgs wp)
                 else { store8_s<true>(exs, (unsigned)my_byte, packed); store8_s<true>(exa, (unsigned)my_byte, ~0ull); }
                 store8_s<false>(hrow, vh_off[r], packed);
             }
-            const long long q4 = STATS ? __builtin_readcyclecounter() : 0;
-            // ---- my quarter of the OTHER ring's next h tile: only the three stores above are younger than its polls -----------------
-            if (chk_o) {
-                __builtin_amdgcn_s_waitcnt(0x0F73);                              // vmcnt(3)
-                asm volatile("" ::: "memory");
-                if constexpr (STATS) st_sec[1] += __builtin_readcyclecounter() - q4;         // (time in that wait)
-                const char* hbo = hbuf + (o * 2 + (step_o & 1)) * TILE + lo;
-                uint4_t chk[KQ];
-#pragma unroll
-                for (int kk = 0; kk < KQ; ++kk) chk[kk] = *(const uint4_t*)(hbo + (wave + 4 * kk) * 1024);
-                unsigned any = 0;
-#pragma unroll
-                for (int kk = 0; kk < KQ; ++kk) any |= chk[kk].x | chk[kk].y | chk[kk].z | chk[kk].w;
-                if (__builtin_expect(__any((any & SENTINEL_MASK) != 0) || dead, 0)) {
-                    const long long s0 = STATS ? __builtin_readcyclecounter() : 0;
-                    check_end(o, step_o, chk);
-                    if constexpr (STATS) { st_poll += __builtin_readcyclecounter() - s0; ++st_slow; }
-                }
-            }
-            const long long q5 = STATS ? __builtin_readcyclecounter() : 0;
             if constexpr (STATS) {
-                const long long q6 = __builtin_readcyclecounter();
-                st_bar += q1 - q0; st_sec[0] += q2 - q1; st_sec[2] += q3 - q2; st_sec[3] += q4 - q3; st_sec[4] += q5 - q4; st_sec[5] += q6 - q5;
+                const long long q5 = __builtin_readcyclecounter();
+                st_bar += q1 - q0; st_sec[2] += q3 - q1; st_sec[4] += q4 - q3; st_sec[3] += q5 - q4;
             }
             return;
         }

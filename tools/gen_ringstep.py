@@ -61,7 +61,7 @@ def nop(n):
 PBASE = 232          # v[PBASE .. PBASE+11]: the three recurrent accumulator tuples (physical registers, see the module docstring)
 
 
-def gates(m):
+def gates(m, nan_check=False):
     """lstm_cell() of cell m, one dependency-ordered list. g{m}{i}: the four pre-activations = the registers of the accumulator tuple
     (literal names), reused as temporaries; operands e{m}, c{m} (cell state), hi25 / hi12."""
     g0, g1, g2, g3 = ("g%d%d" % (m, i) for i in range(4))
@@ -79,6 +79,12 @@ def gates(m):
         return Ins(kind, fmt.format(**names), reads=src, writes=(dst,), cell=m)
 
     seq = []
+    if nan_check:
+        # an element of h_{t-1} that had not arrived is the exchange sentinel 0xFFFF = an fp16 NaN: it makes every pre-activation of
+        # its chunk column NaN. The clamps below would swallow that (v_med3 returns a number), so fold the four pre-activations into
+        # one running fma first: it is NaN afterwards iff one of them was (finite values cannot overflow it)
+        seq.append(v("valu", "v_fma_f32 {d}, {s0}, {s1}, {s2}", "nan", g0, g1, "nan"))
+        seq.append(v("valu", "v_fma_f32 {d}, {s0}, {s1}, {s2}", "nan", g2, g3, "nan"))
     for g, hi in ((g0, "hi25"), (g1, "hi25"), (g2, "hi12"), (g3, "hi25")):
         seq.append(v("valu", "v_med3_f32 {d}, {s0}, {s1}, -{s1}", g, g, hi))
     seq.append(v("valu", "v_mul_f32 {d}, " + L_NEG + ", {s0}", g0, g0))
@@ -110,7 +116,7 @@ def gates(m):
     seq.append(v("valu", "v_mul_f32 {d}, {s0}, {s1}", g0, g0, g1))            # hv
     seq.append(Ins("cmp", "v_cmp_le_f32_e64 vcc, |%s|, 1.0" % R(g0), reads=(g0,), writes=("vcc",), cell=m))
     seq.append(Ins("sel", "v_cndmask_b32_e32 %s, 0, %s, vcc" % (R(g0), R(g0)), reads=(g0, "vcc"), writes=(g0,), cell=m))
-    assert len(seq) == 35
+    assert len(seq) == 35 + (2 if nan_check else 0)
     return seq
 
 
@@ -146,7 +152,10 @@ def weave(mf, va, lead_m):
     return out
 
 
-def build(xdist, hdepth, xdepth, hpool, xpool, hf_live, lead, wgroup=1):
+VBASE = 220          # v[VBASE .. VBASE+11]: the three fragments of the other ring's h tile read back for validation (physical: the OR tree names their dwords)
+
+
+def build(xdist, hdepth, xdepth, hpool, xpool, hf_live, lead, wgroup=1, nan_check=False, polls_at=-1, xdma_at=-1, validate_at=-1, spread=0):
     assert sum(xdist) == 3 * NKS and len(xdist) == 4
     xs = [(ks, m) for ks in range(NKS) for m in range(3)]
     xi = 0
@@ -171,7 +180,7 @@ def build(xdist, hdepth, xdepth, hpool, xpool, hf_live, lead, wgroup=1):
     seq = []
     for p in range(4):
         mf = [mfma_ins(t) for t in spine_by_phase[p]]
-        va = gates(p - 1) if p >= 1 else []
+        va = gates(p - 1, nan_check) if p >= 1 else []
         seq += weave(mf, va, lead if p >= 1 else 0)
 
     # ---- fragment reads: `depth` MFMAs ahead of the first use, into rotating registers ---------------------------------
@@ -232,6 +241,41 @@ def build(xdist, hdepth, xdepth, hpool, xpool, hf_live, lead, wgroup=1):
     for m in range(3):
         assert pos[("R", m, 0)] < pos[("X", m, 0)]
 
+    # ---- vector-memory work of the section issued from inside the stream, behind given MFMAs -------------------------------------------
+    def after_mfma(seq, at, extra):
+        out, n = [], -1
+        for x in seq:
+            out.append(x)
+            if x.kind == "mfma":
+                n += 1
+                if n == at:
+                    out += extra
+        assert n >= at
+        return out
+
+    # (`spread`: MFMAs between two DMA instructions of a group - a burst of three costs the issuing wave ~150 cycles in one piece and
+    #  skews the four waves of the workgroup against each other in front of the next barrier)
+    if polls_at >= 0:            # the other ring's first poll round: three LDS-DMA instructions (1 KiB each) into its h tile
+        for k in range(3):
+            ex = [Ins("salu", "s_mov_b32 m0, %[pm0]" if k == 0 else "s_add_u32 m0, %%[pm0], 0x%x" % (0x1000 * k), reads=("pm0",)), nop(0),
+                  Ins("vmem", "global_load_lds_dwordx4 %%[vp%d], %%[exo] sc0 sc1" % k, reads=("vp%d" % k, "exo"))]
+            seq = after_mfma(seq, polls_at + k * spread, ex)
+    if xdma_at >= 0:             # this ring's share of x_{t+2}: three LDS-DMA instructions into the x slot the previous step consumed
+        assert xdma_at >= polls_at + 2 * spread
+        for k in range(3):
+            ex = [Ins("salu", "s_mov_b32 m0, %[xm0]" if k == 0 else "s_add_u32 m0, %%[xm0], 0x%x" % (0x1000 * k), reads=("xm0",))]
+            if k:
+                ex.append(Ins("valu", "v_add_u32_e32 %%[xv%d], 0x%x, %%[vx]" % (k, 0x100 * k), reads=("vx",), writes=("xv%d" % k,)))
+            else:
+                ex.append(nop(0))
+            ex.append(Ins("vmem", "global_load_lds_dwordx4 %%[%s], %%[xsrc]" % ("xv%d" % k if k else "vx"), reads=(("xv%d" % k if k else "vx"), "xsrc")))
+            seq = after_mfma(seq, xdma_at + k * spread, ex)
+    if validate_at >= 0:         # my quarter of the other ring's h tile, read back: behind its polls only the x-stream DMAs above
+        assert polls_at >= 0 and xdma_at >= polls_at and validate_at > xdma_at + 2 * spread
+        vr = ["v[%d:%d]" % (VBASE + 4 * k, VBASE + 4 * k + 3) for k in range(3)]
+        ex = [Ins("wait", "s_waitcnt vmcnt(3)")]
+        ex += [Ins("lds", "ds_read_b128 %s, %%[hbo] offset:%d" % (vr[k], 4096 * k), reads=("hbo",), frag=("V", 0, k)) for k in range(3)]
+        seq = after_mfma(seq, validate_at, ex)
     # ---- waits: LDS returns in order; wait for exactly as many as were issued behind the one needed ----------------------
     out, issued, done = [], [], -1
     for x in seq:
@@ -245,6 +289,9 @@ def build(xdist, hdepth, xdepth, hpool, xpool, hf_live, lead, wgroup=1):
                 done = r
         out.append(x)
     seq = out
+
+    if nan_check:
+        seq = [Ins("valu", "v_mov_b32 %[nan], 0", writes=("nan",))] + seq
 
     # ---- hazards -----------------------------------------------------------------------------------------------------
     out = []
@@ -268,7 +315,19 @@ def build(xdist, hdepth, xdepth, hpool, xpool, hf_live, lead, wgroup=1):
     gap = sum(y.states() for y in out[last_m + 1:])
     if gap < 12:
         out.append(nop(12 - gap - 1))
+    if nan_check:
+        out.append(Ins("cmp", "v_cmp_u_f32_e64 %[bad], %[nan], %[nan]", reads=("nan",), writes=("bad",)))
     out.append(Ins("wait", "s_waitcnt lgkmcnt(0)"))
+    if validate_at >= 0:         # any of the twelve dwords still carrying the sentinel bit? (the stream's own LDS reads are all home by now)
+        d = ["v%d" % (VBASE + i) for i in range(12)]
+        out.append(Ins("valu", "v_or3_b32 %s, %s, %s, %s" % (d[0], d[0], d[1], d[2])))
+        out.append(Ins("valu", "v_or3_b32 %s, %s, %s, %s" % (d[4], d[3], d[4], d[5])))
+        out.append(Ins("valu", "v_or3_b32 %s, %s, %s, %s" % (d[8], d[6], d[7], d[8])))
+        out.append(Ins("valu", "v_or3_b32 %s, %s, %s, %s" % (d[0], d[0], d[9], d[10])))
+        out.append(Ins("valu", "v_or3_b32 %s, %s, %s, %s" % (d[4], d[4], d[8], d[11])))
+        out.append(Ins("valu", "v_or_b32_e32 %s, %s, %s" % (d[0], d[0], d[4])))
+        out.append(Ins("valu", "v_and_b32_e32 %s, 0x40004000, %s" % (d[0], d[0])))
+        out.append(Ins("cmp", "v_cmp_ne_u32_e64 %%[bad], 0, %s" % d[0], writes=("bad",)))
     return out
 
 
@@ -286,11 +345,27 @@ def operand(name):
         return "v", "bias[%s]" % name[2:]
     if name.startswith("ht") or name.startswith("xt"):
         return "v", name
-    if name[0] == "e":
+    if name[0] == "e" and name[1:].isdigit():
         return "v", "e[%s]" % name[1]
-    if name[0] == "c":
+    if name[0] == "c" and name[1:].isdigit():
         return "v", "cst[%s]" % name[1]
     if name in ("hb", "xb"):
+        return "v", name
+    if name == "nan":
+        return "v", "nanacc"
+    if name == "bad":
+        return "s", "bad"
+    if name == "pm0":
+        return "s", "pm0"
+    if name.startswith("vp"):
+        return "v", "vp[%s]" % name[2:]
+    if name == "exo":
+        return "s", "exo"
+    if name == "xsrc":
+        return "s", "xsrc"
+    if name in ("xm0", "vx", "hbo"):
+        return ("s" if name == "xm0" else "v"), name
+    if name in ("xv1", "xv2"):
         return "v", name
     if name == "hi25":
         return "v", "25.0f"
@@ -300,12 +375,24 @@ def operand(name):
 
 
 def render(seq, fn, hf_live, header):
+    names = {n for x in seq for n in x.reads + x.writes}
+    extra_args = ""
+    if "bad" in names:
+        extra_args += ", unsigned long long& bad"
+    if "exo" in names:
+        extra_args += ", unsigned pm0, const char* exo, const unsigned (&vp)[3]"
+    if "xsrc" in names:
+        extra_args += ", unsigned xm0, const char* xsrc, unsigned vx"
+    if "hbo" in names:
+        extra_args += ", unsigned hbo"
     lines = ["// GENERATED by tools/gen_ringstep.py - do not edit. " + header,
              "// in: xacc[m] = bias + W_ih x_t (tile m), cst; h_{t-1} fragments at LDS address hb, x_{t+1} fragments at xb (+ lane * 16 each)",
              "// out: hv[m] = h_t of the lane's three cells, cst, xacc[m] = bias + W_ih x_{t+1}",
              "__device__ __forceinline__ void %s(float4_t (&xacc)[3], float (&cst)[3], float (&hv)[3], const half8_t (&whh)[3][12]," % fn,
-             "        const half8_t (&wih)[3][12], const float4_t (&bias)[3], unsigned hb, unsigned xb) {",
-             "    float e[3];",
+             "        const half8_t (&wih)[3][12], const float4_t (&bias)[3], unsigned hb, unsigned xb%s) {" % extra_args,
+             "    float e[3], nanacc;",
+             "    unsigned xv1, xv2;",
+             "    uint4_t vt[3];",
              "    float4_t acc[3];",
              "    half8_t " + ", ".join(["ht%d" % i for i in range(NKS if hf_live else 8)] + ["xt%d" % i for i in range(4)]) + ";"]
     first_access, written = {}, set()
@@ -317,6 +404,8 @@ def render(seq, fn, hf_live, header):
             if w != "vcc" and w[0] not in "gP":
                 first_access.setdefault(w, "w"); written.add(w)
     outs = ['"=&{v[%d:%d]}"(acc[%d])' % (PBASE + 4 * m, PBASE + 4 * m + 3, m) for m in range(3)]
+    if "hbo" in names:
+        outs += ['"=&{v[%d:%d]}"(vt[%d])' % (VBASE + 4 * k, VBASE + 4 * k + 3, k) for k in range(3)]
     ins = []
     for name in first_access:
         cls, expr = operand(name)
@@ -325,11 +414,11 @@ def render(seq, fn, hf_live, header):
         else:
             ins.append('[%s] "%s"(%s)' % (name, cls, expr))
     body = '\\n\\t"\n        "'.join(x.text for x in seq)
-    lines.append('    asm volatile("' + body + '"\n        : ' + ", ".join(outs) + "\n        : " + ", ".join(ins) + '\n        : "vcc");')
+    lines.append('    asm volatile("' + body + '"\n        : ' + ", ".join(outs) + "\n        : " + ", ".join(ins) + ('\n        : "vcc", "scc", "memory");' if "exo" in names else '\n        : "vcc");'))
     if any(x.meta.get("cell") is not None for x in seq):
-        lines += ["    hv[0] = acc[0][0]; hv[1] = acc[1][0]; hv[2] = acc[2][0];", "}", ""]
+        lines += ["    hv[0] = acc[0][0]; hv[1] = acc[1][0]; hv[2] = acc[2][0]; (void)nanacc; (void)xv1; (void)xv2; (void)vt;", "}", ""]
     else:
-        lines += ["    hv[0] = acc[0][0]; hv[1] = acc[1][0]; hv[2] = acc[2][0]; (void)e;", "}", ""]
+        lines += ["    hv[0] = acc[0][0]; hv[1] = acc[1][0]; hv[2] = acc[2][0]; (void)e; (void)nanacc; (void)xv1; (void)xv2; (void)vt;", "}", ""]
     return "\n".join(lines)
 
 
@@ -342,13 +431,18 @@ def main():
     ap.add_argument("--xpool", type=int, default=3)
     ap.add_argument("--lead", type=int, default=2, help="MFMAs of a phase in front of its first vector instruction")
     ap.add_argument("--wgroup", type=int, default=1, help="fragments covered by one lgkmcnt wait")
+    ap.add_argument("--nan-check", action="store_true", help="fold the pre-activations into a NaN probe: `bad` = lanes that saw an element of h that had not arrived")
+    ap.add_argument("--polls-at", type=int, default=-1, help="issue the other ring's three poll DMAs behind this MFMA (0-based)")
+    ap.add_argument("--xdma-at", type=int, default=-1, help="issue this ring's three x-stream DMAs behind this MFMA")
+    ap.add_argument("--spread", type=int, default=0, help="MFMAs between two DMA instructions of the poll / x-stream groups")
+    ap.add_argument("--validate-at", type=int, default=-1, help="read back my quarter of the other ring's h tile behind this MFMA; `bad` = sentinel found")
     ap.add_argument("--strip", default="", help="timing experiments only (wrong results): 'valu' drops the gate arithmetic, 'mfma' drops MFMAs + LDS reads")
     ap.add_argument("--hf-live", action="store_true", help="keep the twelve h fragments in registers instead of re-reading them per tile")
     ap.add_argument("--name", default="ringstep3_mfma")
     ap.add_argument("--out", default=os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bonito_amd", "csrc", "ringstep3_mfma.inc"))
     a = ap.parse_args()
     xdist = tuple(int(v) for v in a.xdist.split(","))
-    seq = build(xdist, a.hdepth, a.xdepth, a.hpool, a.xpool, a.hf_live, a.lead, a.wgroup)
+    seq = build(xdist, a.hdepth, a.xdepth, a.hpool, a.xpool, a.hf_live, a.lead, a.wgroup, a.nan_check, a.polls_at, a.xdma_at, a.validate_at, a.spread)
     if a.strip == "valu":
         seq = [x for x in seq if x.kind not in ("valu", "trans", "cmp", "sel")]
     elif a.strip == "mfma":
@@ -356,8 +450,8 @@ def main():
     counts = {}
     for x in seq:
         counts[x.kind] = counts.get(x.kind, 0) + 1
-    header = "xdist=%s hdepth=%d xdepth=%d hpool=%d xpool=%d lead=%d wgroup=%d hf_live=%d : %s" % (
-        a.xdist, a.hdepth, a.xdepth, a.hpool, a.xpool, a.lead, a.wgroup, a.hf_live, " ".join("%s=%d" % kv for kv in sorted(counts.items())))
+    header = "xdist=%s hdepth=%d xdepth=%d hpool=%d xpool=%d lead=%d wgroup=%d hf_live=%d nan_check=%d polls_at=%d xdma_at=%d validate_at=%d spread=%d : %s" % (
+        a.xdist, a.hdepth, a.xdepth, a.hpool, a.xpool, a.lead, a.wgroup, a.hf_live, a.nan_check, a.polls_at, a.xdma_at, a.validate_at, a.spread, " ".join("%s=%d" % kv for kv in sorted(counts.items())))
     with open(a.out, "w") as fh:
         fh.write(render(seq, a.name, a.hf_live, header))
     print("wrote", a.out, header)

@@ -13,6 +13,16 @@ sig = torch.randn(N, 1, 10000, device="cuda").half()
 model(sig)
 enc = model._hip
 print(enc.describe().splitlines()[4])
+# the product instance (no stamps): HIP-event time of the recurrent launches
+enc.profile(True)
+for _ in range(3):
+    model(sig)
+torch.cuda.synchronize()
+prof = enc.profile_read()
+enc.profile(False)
+ms, spans = prof["lstm_rec"]
+launches = spans * max(1, -(-(N // 16) // 64))
+print("recurrent kernel without stamps: %.3f ms per launch (%d launches) = %.0f cycles per ring step at 2.4 GHz" % (ms / launches, launches, ms / launches * 1e-3 * 2.4e9 / 1667 / 2))
 enc.set_option("lstm_tune", 4)
 model(sig); torch.cuda.synchronize(); enc.check()
 rings, nsl, T = N // 16, 32, 1667
@@ -23,9 +33,9 @@ _lib.check(_lib.lib().bh_encoder_debug_read(enc._handle, st.ctypes.data_as(C.c_v
 st = st[:pairs].astype(float)                      # a workgroup reports under its first ring
 tot = st[..., 0]
 print("cycles per pair step (two ring steps): mean %.0f (min %.0f max %.0f) -> %.0f per ring step" % (tot.mean() / T, tot.min() / T, tot.max() / T, tot.mean() / T / 2))
-names = ["barrier", "x-stream DMA issue", "the stream (recurrent MFMAs + gates + input projection)", "transpose + stores", "validate other ring", "  of which: vmcnt wait", "  of which: re-poll rounds", "poll issue"]
-idx = [5, 8, 10, 11, 12, 9, 1, 7]
+names = ["barrier", "the stream (MFMAs + gates + polls + x-stream DMA + validation of the other ring's quarter)", "re-poll rounds", "transpose + stores"]
+idx = [5, 10, 12, 11]
 for n, i in zip(names, idx):
-    print("  %-58s %7.0f per ring step" % (n, st[..., i].mean() / T / 2))
+    print("  %-84s %7.0f per ring step" % (n, st[..., i].mean() / T / 2))
 print("validations that needed a re-poll: %.2f %% of the ring steps" % (100 * st[..., 2].mean() / T / 2))
 print("shader clock during the kernel: %.2f GHz" % (tot.mean() / st[..., 13].mean() * 0.1))
