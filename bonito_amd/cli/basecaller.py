@@ -90,9 +90,6 @@ def main(args, argv=None):
         parallel.init("gloo")              # host objects only: there is no device collective on this path
     util.init(args.seed, args.device)
     util.limit_host_threads(8)       # host work is small copies; never out-spin a container's CPU quota
-    if args.lanes > 1 and args.quantize:
-        from bonito_amd import decode as _decode
-        _decode.set_option("lstm_q8_variant", 2)       # 8-bit recurrent kernels compiled for two workgroups per CU
     log = sys.stderr.write if rank == 0 else (lambda _msg: None)
     try:
         reader = Reader(args.reads_directory, args.recursive)
@@ -122,9 +119,12 @@ def main(args, argv=None):
         results = basecall_raw(model, reads, reverse=args.revcomp, rna=args.rna, batchsize=bc["batchsize"],
                                chunksize=bc["chunksize"], overlap=bc["overlap"], scaling_strategy=model.config.get("scaling"),
                                norm_params=model.config.get("standardisation") if pa else model.config.get("normalisation"),
-                               do_trim=not args.no_trim, lanes=args.lanes)
+                               do_trim=not args.no_trim, lanes=args.lanes, per_call=args.per_call)
     else:
-        kw = {"lanes": args.lanes} if args.lanes > 1 and "lanes" in basecall.__code__.co_varnames else {}
+        names = basecall.__code__.co_varnames
+        kw = {"lanes": args.lanes} if args.lanes > 1 and "lanes" in names else {}
+        if "per_call" in names:
+            kw["per_call"] = args.per_call
         results = basecall(model, reads, reverse=args.revcomp, rna=args.rna, batchsize=bc["batchsize"],
                            chunksize=bc["chunksize"], overlap=bc["overlap"], **kw)
     mode = "sam" if args.sam else ("fasta" if args.fasta else "fastq")
@@ -191,6 +191,10 @@ def argparser():
     parser.add_argument("--lanes", default=1, type=int,
                         help="batches in flight in the encoder (engine replicas per GPU); 2 pays off with --quantize, whose "
                              "recurrent kernels of two lanes share every CU")
+    parser.add_argument("--per-call", default=0, type=int,
+                        help="batches of --batchsize chunks per engine call; 0 = automatic (calls of up to 1024 chunks for the "
+                             "192...512-wide fp16 models, whose recurrent kernel then pairs rings: 2.97 -> 1.9 ms per layer and 512 "
+                             "chunks at 384 hidden units; results do not depend on it)")
     parser.add_argument("--min-qscore", default=0.0, type=float)
     parser.add_argument("--sam", action="store_true", default=False, help="write unaligned SAM instead of FASTQ")
     parser.add_argument("--fasta", action="store_true", default=False)

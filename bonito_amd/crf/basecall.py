@@ -105,10 +105,14 @@ class _Pipeline:
         # stream, batches go round-robin. With the 8-bit recurrent kernels compiled for two workgroups per CU
         # (bh_set_option "lstm_q8_variant" 2) the persistent kernels of two lanes share every CU and each hides the other's
         # exchange round trip (hac-sized model: 18.8 -> 15.7 ms per batch); the fp16 kernels fill the register file and gain nothing.
-        self.lanes = max(1, int(lanes))
+        quantize = _resolved_quantize(model)
+        self.lanes = max(1, min(int(lanes), max_lanes(model, quantize)))
+        if self.lanes > 1 and quantize:
+            hip_decode.set_option("lstm_q8_variant", 2)    # the 8-bit kernels compiled for two workgroups per CU
         self.enc_streams = [torch.cuda.Stream(self.device) for _ in range(self.lanes)]
         self.replicas = [None] * self.lanes            # lane 0 runs the model's own engine
         self.n_encoded = 0
+        self.retries = 0                               # batches that were run a second time after an exchange timeout
         self.dec_stream = torch.cuda.Stream(self.device)
         self.copy_stream = torch.cuda.Stream(self.device)
         self.decoders = {}
@@ -117,6 +121,26 @@ class _Pipeline:
         for eng in [getattr(self.model, "_hip", None)] + self.replicas[1:]:
             if eng is not None:
                 eng.poll()
+
+    def _retry_serially(self, dev_batch):
+        """An exchange timeout (a persistent recurrent kernel whose peers were not co-resident in time: a second process on the GPU,
+        more lanes than the kernels can co-host) invalidates the batch, not the run: with nothing else in flight, clear the flag
+        and run encoder + decoder of this batch again; only a second failure is an error (bonito/crf/basecall.py:58-82 has
+        nothing that can time out, so a drop-in must not abort where the reference would have carried on)."""
+        torch.cuda.synchronize(self.device)
+        for eng in [getattr(self.model, "_hip", None)] + self.replicas[1:]:
+            if eng is not None:
+                eng.clear_error()
+        with torch.inference_mode():
+            scores = self.model(dev_batch)
+            if self.reverse:
+                scores = self.model.seqdist.reverse_complement(scores)
+            torch.cuda.synchronize(self.device)
+            self.model._hip.check()                   # raises HipEngineError if the serial run timed out as well
+            key = tuple(scores.shape[1:])
+            planes = self.decoders[key].submit(scores).result_planes()
+        self.retries += 1
+        return planes
 
     def _forward(self, lane, x):
         if lane == 0:
@@ -138,7 +162,7 @@ class _Pipeline:
                     scores = self.model.seqdist.reverse_complement(scores)
                 ready = torch.cuda.Event()
                 ready.record(enc_stream)
-            return scores, ready
+            return scores, ready, batch
         # H2D on its own stream, waited for on the host: the (recycled, pinned) batch buffer is free again when this
         # method returns, and the copy never queues behind the previous batch's encoder.
         with torch.inference_mode(), torch.cuda.stream(self.copy_stream):
@@ -154,9 +178,9 @@ class _Pipeline:
                 scores = self.model.seqdist.reverse_complement(scores)
             ready = torch.cuda.Event()
             ready.record(enc_stream)
-        return scores, ready
+        return scores, ready, dev_batch
 
-    def decode(self, scores, ready):
+    def decode(self, scores, ready, dev_batch=None):
         key = tuple(scores.shape[1:])
         dec = self.decoders.get(key)
         if dec is None or dec.N < scores.shape[0]:
@@ -170,13 +194,62 @@ class _Pipeline:
         planes = ticket.result_planes()      # [3, n, T] int8: sequence, qstring, moves
         # the decode outputs are on the host, so the encoder forward that produced `scores` (and the 4-byte copy of the
         # engine's timeout flag behind it) has completed: a spin timeout in a persistent kernel means these planes were
-        # decoded from invalid scores -> raise, never yield them (reference seam: crf/basecall.py:27-45)
-        self.check_engine()
+        # decoded from invalid scores -> never yield them (reference seam: crf/basecall.py:27-45): run the batch again with
+        # nothing else in flight, raise only if that fails too
+        try:
+            self.check_engine()
+        except _lib.HipEngineError:
+            if dev_batch is None:
+                raise
+            planes = self._retry_serially(dev_batch)
         if self.mode == "viterbi":
             path = planes[1]                 # plane 1 carries the path for the Viterbi decoder
             planes[0] = hip_decode.path_to_sequence(path)
             planes[1] = torch.where(planes[0] != 0, torch.tensor(33 + 20, dtype=torch.int8), torch.tensor(0, dtype=torch.int8))
         return planes
+
+
+def _resolved_quantize(model):
+    """What the engine will run: the value `use_koi` / `use_hip` stored (command line, config.toml or caller), not a flag."""
+    q = getattr(model, "_quantize", None)
+    if q is None:
+        q = ((getattr(model, "config", None) or {}).get("basecaller") or {}).get("quantize")
+    return bool(q)
+
+
+def lstm_widths(model):
+    return [m.rnn.hidden_size for m in model.modules() if hasattr(m, "rnn") and hasattr(m.rnn, "hidden_size")]
+
+
+def max_lanes(model, quantize=False):
+    """Engine replicas whose recurrent kernels can be co-resident. The kernels of 192...1024-wide layers are persistent and hand h
+    over between workgroups: every launch sizes its grid to the whole device and spins on peers, so two lanes would each end up
+    partly resident and time out (advisor finding, round 2). Exceptions: the ring-in-a-workgroup kernel of the narrow layers (64 /
+    96 / 128: no inter-workgroup exchange, any number of lanes) and the 8-bit kernel built for two workgroups per CU
+    (`lstm_q8_variant` 2, 384 wide: two lanes). Models without recurrent layers: no limit."""
+    sizes = lstm_widths(model)
+    if not sizes or all(h in (64, 96, 128) for h in sizes):
+        return 1 << 30
+    if quantize and all(h == 384 for h in sizes):
+        return 2
+    return 1
+
+
+def batches_per_call(model, batchsize, quantize=False):
+    """How many `batchsize`-chunk batches one ENGINE call should carry. The reference hands koi one batch per forward
+    (crf/basecall.py:70-72) and `batchsize` keeps that meaning for the caller: chunks are independent, so results do not depend on
+    how they are grouped (tests). For the 192...512-wide fp16 recurrent layers the engine's kernel carries two rings of 16 chunks
+    per workgroup once a call holds more than one launch of single rings (32 rings = 512 chunks at 384 hidden units), which takes a
+    512-chunk batch from 2.97 to 1.9 ms per layer: calls of up to 1024 chunks there, one batch per call everywhere else."""
+    if quantize:
+        return 1
+    sizes = lstm_widths(model)
+    if not sizes or not all(192 <= h <= 512 and (h % 48 == 0 or h % 64 == 0) for h in sizes):
+        return 1
+    wpr = max(1, (max(sizes) // (12 if max(sizes) % 48 == 0 else 16)) // 4)        # workgroups per ring
+    rings_per_launch = max(1, 256 // (8 * wpr)) * 8                                   # single rings on 256 CUs
+    target = 2 * rings_per_launch * 16                                                # chunks of one paired launch
+    return max(1, min(4, target // max(1, int(batchsize))))
 
 
 def chunk_batches(reads, chunksize, overlap, batchsize, pin=False, nbuf=4):
@@ -259,10 +332,15 @@ def chunk_batches(reads, chunksize, overlap, batchsize, pin=False, nbuf=4):
         yield tuple(keys), bufs[cur][:pos]
 
 
-def basecall(model, reads, chunksize=4000, overlap=100, batchsize=32, reverse=False, rna=False, decoder="beam", lanes=1):
+def basecall(model, reads, chunksize=4000, overlap=100, batchsize=32, reverse=False, rna=False, decoder="beam", lanes=1,
+             per_call=0):
     """Basecalls a set of reads: yields (read, {sequence, qstring, moves, stride}). `lanes`: batches in flight in the encoder
-    (engine replicas); results are identical for any value."""
+    (engine replicas); `per_call`: batches of `batchsize` chunks per engine call (0 = `batches_per_call`); results are
+    identical for any value of either."""
     pipe = _Pipeline(model, decoder=decoder, reverse=reverse, lanes=lanes)
+    if not per_call:
+        per_call = batches_per_call(model, batchsize, _resolved_quantize(model))
+    batchsize = int(batchsize) * max(1, int(per_call))
     # up to 4 batches are in flight behind the generator (three single-slot queues + the consumer): recycle after 8
     batches = thread_iter(chunk_batches(reads, chunksize, overlap, batchsize, pin=torch.cuda.is_available(), nbuf=8))
     encoded = thread_iter((keys, pipe.encode(batch)) for keys, batch in batches)
@@ -333,10 +411,13 @@ def raw_chunk_batches(reads, chunksize, overlap, batchsize, device, group_sample
 
 
 def basecall_raw(model, reads, chunksize=4000, overlap=100, batchsize=32, reverse=False, rna=False, decoder="beam",
-                 scaling_strategy=None, norm_params=None, do_trim=True, lanes=1):
+                 scaling_strategy=None, norm_params=None, do_trim=True, lanes=1, per_call=0):
     """`basecall` for raw int16 reads (`.raw`, `.scaling`, `.offset`): the signal pre-processing of reader.Read runs on the
     device. Same results as ``basecall(model, [reader.Read(...) ...])`` on the same reads (tests compare them)."""
     pipe = _Pipeline(model, decoder=decoder, reverse=reverse, lanes=lanes)
+    if not per_call:
+        per_call = batches_per_call(model, batchsize, _resolved_quantize(model))
+    batchsize = int(batchsize) * max(1, int(per_call))
     device = next(model.parameters()).device
     batches = thread_iter(raw_chunk_batches(reads, chunksize, overlap, batchsize, device, scaling_strategy=scaling_strategy,
                                             norm_params=norm_params, do_trim=do_trim))

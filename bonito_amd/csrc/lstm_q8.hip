@@ -403,11 +403,15 @@ __global__ void quantise_rows_kernel(const half_t* x, int8_t* out, long pieces, 
 
 // Units per wave of the 8-bit kernel for hidden size H (0: not covered). `variant` 1 asks for the single-tile geometry
 // (U = 4, three workgroups per CU) where it is instantiated.
+// Hidden units per wave of the 8-bit kernel, 0 = this width has no instance (the layer then keeps the fp16 kernels). Must name
+// exactly the (k-steps, M tiles) pairs instantiated in bh_k_lstm_layer_q8 below: a width this accepted without an instance
+// (48, 240, 320, 432, 448, 480) made every forward of a quantised model fail instead of falling back (advisor finding, round 2).
 int bh_k_lstm_q8_units(int H, int variant) {
-    if (H % 16 != 0 || H > 512) return 0;
+    if (H % 16 != 0 || H > 512 || H <= 0) return 0;
     if (variant == 1 && H == 384) return 4;
-    if (H % 48 == 0) return 12;
-    if (H % 64 == 0) return 16;
+    const int nk8 = (H + 63) / 64;
+    if (H % 48 == 0) return (nk8 == 2 || nk8 == 3 || nk8 == 5 || nk8 == 6) ? 12 : 0;      // 96, 144, 192, 288, 336, 384
+    if (H % 64 == 0) return (nk8 == 1 || nk8 == 2 || nk8 == 4 || nk8 == 8) ? 16 : 0;      // 64, 128, 256, 512
     return 0;
 }
 size_t bh_k_lstm_q8_tile_bytes(int H) { return (size_t)((H + 63) / 64) * 1024; }

@@ -255,6 +255,11 @@ class HipEncoder:
         if rc:
             raise _lib.HipEngineError("bh_encoder_check: %s" % _lib.last_error())
 
+    def clear_error(self):
+        """Synchronise and reset the (sticky) timeout flag without raising; returns whether it was set."""
+        with torch.cuda.device(self.device):
+            return bool(_lib.lib().bh_encoder_check(self._handle, _lib.stream_ptr(self.device)))
+
     def describe(self):
         """One line per layer: which kernels the engine launches for it."""
         buf = C.create_string_buffer(1 << 14)

@@ -105,7 +105,7 @@ def test_q8_engine_matches_oracle_and_decodes_like_fp32(name, N, L):
     d_ref = (g - ref).abs()             # rare flip of a quantisation bucket (1/127) propagates -> a loose bound on max, tight mean
     # measured on MI355X: kernel vs definition max 0.086 / mean 0.010-0.011 (the convolutions ahead of the first recurrent layer
     # run in fp16 on the GPU and in fp32 in the oracle, so ~10 % of its int8 inputs land in the neighbouring bucket)
-    assert d_def.mean().item() < 0.03 and d_def.max().item() < 0.4, (d_def.max().item(), d_def.mean().item())
+    assert d_def.mean().item() < 0.03 and d_def.max().item() < 0.3, (d_def.max().item(), d_def.mean().item())      # max: 3.5 x measured
     assert d_ref.max().item() < 0.6 and d_ref.mean().item() < 0.06, (d_ref.max().item(), d_ref.mean().item())
     sl = model.seqdist.state_len
     paths = [crf_ref.viterbi(s.contiguous().numpy().astype(np.float16), sl, blank=2.0)[1] for s in (ref, g)]
@@ -113,6 +113,29 @@ def test_q8_engine_matches_oracle_and_decodes_like_fp32(name, N, L):
     # the fp16 engine on the same model, for scale
     f16, _ = _scores(model, x, False)
     assert (f16.cpu().float() - ref).abs().max().item() < 3e-2
+
+
+@pytest.mark.parametrize("H", [64, 96, 128, 192, 256, 288, 320, 384, 448, 480, 512])
+def test_quantize_covers_or_falls_back_for_every_width(H):
+    """`quantize=True` on any hidden size the ring kernels serve: widths with an 8-bit kernel instance run it, the others keep the
+    fp16 kernels (use_hip's contract) - never a failing forward (advisor finding, round 2: the shape predicate accepted widths
+    without an instance). Either way the scores stay close to the fp32 oracle."""
+    from bonito_amd import nn as bnn
+    cfg = synthetic.lstm_crf_encoder_config(H, 3)
+    torch.manual_seed(H)
+    model = bnn.from_dict(cfg).eval()
+    nn_ref.round_params_to_half_(model)
+    x = torch.randn(32, 1, 900, generator=torch.Generator().manual_seed(H)).half()
+    enc = HipEncoder(model, batchsize=32, chunksize=900, quantize=True)
+    got = enc(x.cuda())
+    enc.check()
+    layout = enc.describe()
+    has_q8 = H in (64, 96, 128, 192, 256, 288, 384, 512)          # 320, 448, 480: accepted by the round-2 predicate, no kernel instance
+    assert ("lstm_layer_q8_kernel" in layout) == has_q8, layout
+    with torch.no_grad():
+        ref = nn_ref.forward(model, x.float(), expand_blanks=False).permute(1, 0, 2)
+    d = (got.cpu().float() - ref).abs()
+    assert d.mean().item() < (0.06 if has_q8 else 8e-3), (H, d.max().item(), d.mean().item())      # fp16 fallback measured: 3.8e-3 at 480
 
 
 def test_q8_option_off_runs_the_fp16_kernels():
