@@ -193,3 +193,39 @@ def test_full_size_sup_lstm_v43_256x20000_rna():
     _head_gain_(model, 24.0)
     sc = _full_size("sup_lstm_v43", model, 256, 20000, 2.5e-2, 3.2e-3, rna=True)    # measured max 5.2e-3, mean 6.5e-4
     assert sc.shape == (256, 3334, 4096)
+
+
+def test_bench_call_shape_hac_2048x10000():
+    """The default bench (and `basecaller` with automatic --per-call at batchsize 512 x 4... two launches of the paired recurrent
+    kernel per layer) hands the engine FOUR BASELINE batches per call and decodes them through one `CRFDecoder(2048, ...)`:
+    the timed call shape itself against the oracles - one chunk out of each 512-batch, plus the last chunk: scores vs the fp32
+    restatement, beam sequence / moves and the Viterbi path bit-exact vs oracle/crf_oracle.c, q within 1e-3 - exactly as
+    bench.py drives them (decode.CRFDecoder.submit on the engine's scores, the int8 planes on the host)."""
+    batch, chunk = 2048, 10000
+    model = synthetic.make_model("hac", batchsize=batch, chunksize=chunk)
+    sl = model.seqdist.state_len
+    nn_ref.round_params_to_half_(model)
+    x = torch.randn(batch, 1, chunk, generator=torch.Generator().manual_seed(2048)).half()
+    g = _gpu_copy(model, batch, chunk)
+    scores = g(x.cuda())
+    g._hip.check()
+    assert "lstm_layer_wgx2_kernel<12,3>" in g._hip.describe() and scores.shape == (batch, 1667, 1024)
+    rows = [17, 512 + 300, 1024 + 5, 1536 + 511, 2047]
+    want = _oracle_scores(model, x[rows])
+    d = (scores[rows].cpu().float() - want).abs()
+    dec = decode.CRFDecoder(batch, scores.shape[1], scores.shape[2], torch.device("cuda", 0), mode="beam")
+    planes = dec.submit(scores).result_planes()                 # [3, 2048, T] int8: sequence, qstring, moves
+    seq, qs, mv = planes[0].numpy(), planes[1].numpy(), planes[2].numpy()
+    vdec = decode.CRFDecoder(batch, scores.shape[1], scores.shape[2], torch.device("cuda", 0), mode="viterbi")
+    vplanes = vdec.submit(scores).result_planes()
+    sub = scores[rows].cpu().numpy()
+    oseq, oqs, omv, oqf = crf_ref.beam_search(sub, sl)
+    om, op, _ = crf_ref.viterbi(sub, sl, blank=2.0)
+    _, _, _, qf = decode.beam_search(scores, return_qfloat=True)
+    qd = float(np.abs(qf.numpy()[rows] - oqf).max())
+    _record("bench_shape_hac_2048", max=d.max().item(), mean=d.mean().item(), q_max=qd, bases=int((omv != 0).sum()))
+    assert np.array_equal(mv[rows], omv) and np.array_equal(seq[rows], oseq)
+    assert np.array_equal(vplanes[1].numpy()[rows], op) and np.array_equal(vplanes[2].numpy()[rows], om)
+    assert qd < 1e-3 and (qs[rows] != oqs).mean() < 1e-3
+    assert int((omv != 0).sum()) > 100
+    assert d.max().item() < 2.4e-2 and d.mean().item() < 3e-3, (d.max().item(), d.mean().item())      # as at 512 x 10000 (5 x measured)

@@ -10,7 +10,7 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 cd /tmp && export TMPDIR=/tmp
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
-rocprofv3 --kernel-trace --stats -d $OUT/trace -o bench -- python $R/bench.py --no-cpu-baseline --no-h2d-leg "$@" > $OUT/bench.log 2>&1
+rocprofv3 --kernel-trace --stats -d $OUT/trace -o bench -- python $R/bench.py --no-cpu-baseline --no-h2d-leg --no-side-legs "$@" > $OUT/bench.log 2>&1
 tail -1 $OUT/bench.log | cut -c1-300
 python $R/tools/rocprof_summary.py $(find $OUT/trace -name "*.db" | head -1) $OUT/bench_kernel_stats.csv | head -14
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/pmc_rd -o rd -- python $R/tools/profile_step.py --steps 1 ${PS_ARGS:-"$@"} > $OUT/pmc_rd.log 2>&1
