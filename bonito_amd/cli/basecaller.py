@@ -64,7 +64,20 @@ def launch(args, argv):
         env["PYTHONPATH"] = pkg_root + (os.pathsep + env["PYTHONPATH"] if env.get("PYTHONPATH") else "")
         procs.append(subprocess.Popen([sys.executable, "-m", "bonito_amd", "basecaller", *child_argv], env=env,
                                       stdout=None if rank == 0 else subprocess.DEVNULL))
-    rcs = [p.wait() for p in procs]
+    # a worker that dies would leave the others waiting for it in the record merge: poll, and take the rest down with it
+    import time
+    rcs = [None] * len(procs)
+    while any(rc is None for rc in rcs):
+        for i, pr in enumerate(procs):
+            if rcs[i] is None:
+                rcs[i] = pr.poll()
+        if any(rc not in (None, 0) for rc in rcs):
+            for i, pr in enumerate(procs):
+                if rcs[i] is None:
+                    pr.terminate()
+                    rcs[i] = pr.wait()
+            break
+        time.sleep(0.05)
     bad = [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
     if bad:
         sys.stderr.write("> error: worker(s) failed: %s\n" % ", ".join("rank %d rc %d" % b for b in bad))
@@ -113,35 +126,37 @@ def main(args, argv=None):
                              norm_params=model.config.get("standardisation") if (model.config.get("scaling") or {}).get(
                                  "strategy") == "pa" else model.config.get("normalisation"),
                              n_max=args.max_reads or None, raw=args.device_ingest, rank=rank, world=world)
-    if args.device_ingest:            # int16 reads: pA scaling, normalisation, trim and chunking on the GPU
-        from bonito_amd.crf.basecall import basecall_raw
-        pa = (model.config.get("scaling") or {}).get("strategy") == "pa"
-        results = basecall_raw(model, reads, reverse=args.revcomp, rna=args.rna, batchsize=bc["batchsize"],
-                               chunksize=bc["chunksize"], overlap=bc["overlap"], scaling_strategy=model.config.get("scaling"),
-                               norm_params=model.config.get("standardisation") if pa else model.config.get("normalisation"),
-                               do_trim=not args.no_trim, lanes=args.lanes, per_call=args.per_call)
+    mode = "sam" if args.sam else ("fasta" if args.fasta else "fastq")
+    pa = (model.config.get("scaling") or {}).get("strategy") == "pa"
+    raw_kw = dict(scaling_strategy=model.config.get("scaling"),
+                  norm_params=model.config.get("standardisation") if pa else model.config.get("normalisation"),
+                  do_trim=not args.no_trim) if args.device_ingest else None    # int16 reads: pA scaling, normalisation, trim, chunking on the GPU
+    import importlib
+    records_fn = getattr(importlib.import_module(basecall.__module__), "basecall_records", None)
+    if records_fn is not None:
+        # CRF family: stitching, string compaction and the record text of a read are ONE library call (crf/basecall.py
+        # records_from_planes); the triples are what io.format_record makes of basecall()'s results, byte for byte
+        records = records_fn(model, reads, mode, reverse=args.revcomp, rna=args.rna, batchsize=bc["batchsize"],
+                             chunksize=bc["chunksize"], overlap=bc["overlap"], lanes=args.lanes, per_call=args.per_call,
+                             min_qscore=args.min_qscore, raw=raw_kw)
     else:
+        if args.device_ingest:
+            raise SystemExit("> error: --device-ingest needs a CRF model")
         names = basecall.__code__.co_varnames
         kw = {"lanes": args.lanes} if args.lanes > 1 and "lanes" in names else {}
-        if "per_call" in names:
-            kw["per_call"] = args.per_call
         results = basecall(model, reads, reverse=args.revcomp, rna=args.rna, batchsize=bc["batchsize"],
                            chunksize=bc["chunksize"], overlap=bc["overlap"], **kw)
-    mode = "sam" if args.sam else ("fasta" if args.fasta else "fastq")
+        records = parallel.format_stream(results, mode, args.min_qscore)
     t0 = perf_counter()
     if world > 1:
         # every rank formats its own records; rank 0 merges the streams in input order and is the only writer
-        records = parallel.ordered_records(parallel.format_stream(results, mode, args.min_qscore), rank, world)
+        records = parallel.ordered_records(records, rank, world)
         if rank != 0:
             import torch.distributed as dist
             dist.barrier(group=parallel.host_group())
             dist.destroy_process_group()
             return 0
-        writer = Writer(mode, records, fd=out, summary_path=None if args.no_summary else args.summary,
-                        preformatted=True)
-    else:
-        writer = Writer(mode, results, fd=out, min_qscore=args.min_qscore,
-                        summary_path=None if args.no_summary else args.summary)
+    writer = Writer(mode, records, fd=out, summary_path=None if args.no_summary else args.summary, preformatted=True)
     writer.start()
     writer.join()
     duration = perf_counter() - t0

@@ -354,6 +354,84 @@ def basecall(model, reads, chunksize=4000, overlap=100, batchsize=32, reverse=Fa
     )
 
 
+_MODES = {"fastq": 0, "fasta": 1, "sam": 2}
+
+
+def records_from_planes(batches, chunksize, overlap, stride, mode, min_qscore=0.0, reverse=False, rna=False):
+    """(keys, planes [3, n, T] int8) batches -> the (text, summary_row, log) triples `io.format_record` produces for the same reads
+    (tests compare the bytes), one library call per read (`bh_host_format_read`: stitch + to_str + record text) instead of
+    unbatchify -> stitch_planes -> fmt_planes -> format_record, which cost ~1 ms of interpreter and small-tensor time per read and
+    capped a rank at ~1e8 samples/s on one host thread. A read's chunks are passed as runs of rows of the batches they sit in
+    (nothing is concatenated); the batches must arrive in order, like for `unbatchify`."""
+    import ctypes as C
+    from bonito_amd.io import signal_samples, summary_row
+    fn = _lib.lib().bh_host_format_read
+    m = _MODES[mode]
+    cap = 1 << 20
+    out = C.create_string_buffer(cap)
+    seq_len, mean_q = C.c_long(0), C.c_double(0.0)
+    K = 64
+    base, pstride, lo_a, rows_a = (C.c_void_p * K)(), (C.c_long * K)(), (C.c_long * K)(), (C.c_long * K)()
+
+    def emit(key, pieces):
+        nonlocal cap, out
+        read, start, end = key
+        n = len(pieces)
+        if n > K:
+            raise ValueError("a read spans more than %d engine calls" % K)
+        for i, (arr, lo, hi) in enumerate(pieces):
+            base[i], pstride[i], lo_a[i], rows_a[i] = arr.ctypes.data, arr.strides[0], lo, hi - lo
+        T = pieces[0][0].shape[2]
+        rid = read.read_id.encode()
+        run = (getattr(read, "run_id", None) or "").encode()
+        while True:
+            got = fn(base, pstride, lo_a, rows_a, n, T, end - start, chunksize, overlap, stride, int(bool(reverse)), int(bool(rna)), m,
+                     float(min_qscore), rid, run, int(getattr(read, "num_samples", end - start)),
+                     int(getattr(read, "trimmed_samples", 0)), out, cap, C.byref(seq_len), C.byref(mean_q))
+            if got >= -1:
+                break
+            cap = max(2 * cap, -got)
+            out = C.create_string_buffer(cap)
+        if got < 0:
+            raise RuntimeError("bh_host_format_read failed")
+        log = (read.read_id, signal_samples(read))
+        if got == 0:
+            return None, None, log
+        return C.string_at(out, got).decode("ascii"), summary_row(read, seq_len.value, mean_q.value), log
+
+    cur, pieces = None, []
+    for keys, planes in batches:
+        arr = planes.numpy() if isinstance(planes, torch.Tensor) else np.asarray(planes)
+        if arr.dtype != np.int8 or arr.strides[2] != 1 or arr.strides[1] != arr.shape[2]:
+            arr = np.ascontiguousarray(arr, dtype=np.int8)
+        for key, (lo, hi) in keys:
+            if cur is not None and key[0] is not cur[0]:
+                yield emit(cur, pieces)
+                pieces = []
+            cur = key
+            pieces.append((arr, lo, hi))
+    if cur is not None:
+        yield emit(cur, pieces)
+
+
+def basecall_records(model, reads, mode, chunksize=4000, overlap=100, batchsize=32, reverse=False, rna=False, decoder="beam",
+                     lanes=1, per_call=0, min_qscore=0.0, raw=None):
+    """`basecall` (or, with `raw` = the keyword arguments of the device-side ingest, `basecall_raw`) + `io.format_record` for the
+    writers of the product path: yields the (text, summary_row, log) triples of the reads in order - the same bytes (tests), with
+    the per-read host work in the library (`records_from_planes`)."""
+    pipe = _Pipeline(model, decoder=decoder, reverse=reverse, lanes=lanes)
+    if not per_call:
+        per_call = batches_per_call(model, batchsize, _resolved_quantize(model))
+    batchsize = int(batchsize) * max(1, int(per_call))
+    if raw is not None:
+        batches = thread_iter(raw_chunk_batches(reads, chunksize, overlap, batchsize, next(model.parameters()).device, **raw))
+    else:
+        batches = thread_iter(chunk_batches(reads, chunksize, overlap, batchsize, pin=torch.cuda.is_available(), nbuf=8))
+    encoded = thread_iter((keys, pipe.encode(batch)) for keys, batch in batches)
+    scores = thread_iter((keys, pipe.decode(*enc)) for keys, enc in encoded)
+    return records_from_planes(scores, chunksize, overlap, model.stride, mode, min_qscore, reverse, rna)
+
+
 def raw_chunk_batches(reads, chunksize, overlap, batchsize, device, group_samples=1 << 26, scaling_strategy=None,
                       norm_params=None, do_trim=True):
     """Device-side ingest for raw reads (objects with int16 `.raw`, `.scaling`, `.offset`): groups of reads are shipped as

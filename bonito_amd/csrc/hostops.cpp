@@ -76,3 +76,154 @@ extern "C" long bh_host_chunk_rows(const float* signal, long T, int chunksize, i
     }
     return nrows;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// One basecalled read -> its record text, in one call: stitch (bonito/util.py:164-183 via crf/basecall.py:13-24) + to_str
+// (crf/basecall.py:48-55) + the FASTQ / FASTA / SAM line with the tags of bonito/io.py:135-166 (RG, qs, ns, ts, mv). The Python
+// spelling of the same steps (unbatchify -> torch.cat -> reshape -> cat -> compact -> numpy -> str.join) cost ~1 ms per read on one
+// host thread, i.e. it capped a rank at ~1e8 samples/s; this is ~20 us.
+#include <cmath>
+#include <cstdio>
+
+namespace {
+
+// Python's a[lo:hi] on a sequence of length n (negative bounds count from the end; -0 is 0, exactly like the slices of
+// util.stitch / stitch_planes this mirrors, quirks included)
+inline void py_slice(long lo, long hi, long n, long& a, long& b) {
+    a = lo < 0 ? (n + lo < 0 ? 0 : n + lo) : (lo > n ? n : lo);
+    b = hi < 0 ? (n + hi < 0 ? 0 : n + hi) : (hi > n ? n : hi);
+    if (b < a) b = a;
+}
+
+struct Piece { const int8_t* base; long plane_stride, lo, rows; };
+
+inline const int8_t* chunk_row(const Piece* pc, int n_pieces, long j, int plane, long T) {
+    for (int i = 0; i < n_pieces; ++i) {
+        if (j < pc[i].rows) return pc[i].base + plane * pc[i].plane_stride + (pc[i].lo + j) * T;
+        j -= pc[i].rows;
+    }
+    return nullptr;
+}
+
+double mean_qscore(const unsigned long* hist) {
+    // util.mean_qscore_from_qstring: mean error probability of the phred characters, as a q-score (floor 1e-4 on the mean)
+    unsigned long n = 0;
+    double sum = 0.0;
+    for (int q = 0; q < 256; ++q)
+        if (hist[q]) { n += hist[q]; sum += (double)hist[q] * std::exp((double)((q - 33) & 0xff) * (-std::log(10.0) / 10.0)); }
+    if (!n) return 0.0;
+    const double mean = sum / (double)n;
+    return -10.0 * std::log10(mean > 1e-4 ? mean : 1e-4);
+}
+
+}  // namespace
+
+extern "C" double bh_host_mean_qscore(const char* qstring, long n) {
+    if (!qstring || n <= 0) return 0.0;
+    unsigned long hist[256] = {0};
+    for (long i = 0; i < n; ++i) ++hist[(unsigned char)qstring[i]];
+    return mean_qscore(hist);
+}
+
+// mode: 0 fastq, 1 fasta, 2 sam. Returns the number of bytes written to `out`; 0 = the read is filtered out (empty sequence or
+// mean q-score below min_qscore: seq_len / mean_q are still set); -1 = bad arguments; < -1 = -(bytes needed) when out_cap is short.
+extern "C" long bh_host_format_read(const int8_t* const* base, const long* plane_stride, const long* lo, const long* rows, int n_pieces,
+                                    long T, long length, int chunksize, int overlap, int stride, int reverse, int rna, int mode,
+                                    double min_qscore, const char* read_id, const char* run_id, long num_samples, long trimmed_samples,
+                                    char* out, long out_cap, long* seq_len, double* mean_q) {
+    if (!base || !plane_stride || !lo || !rows || n_pieces <= 0 || n_pieces > 64 || T <= 0 || stride <= 0 || !read_id || !out || !seq_len || !mean_q) return -1;
+    Piece pc[64];
+    long n_chunks = 0;
+    for (int i = 0; i < n_pieces; ++i) { pc[i] = Piece{base[i], plane_stride[i], lo[i], rows[i]}; n_chunks += rows[i]; }
+    if (n_chunks <= 0) return -1;
+    // ---- which [a, b) of which chunk, in output order (stitch_planes) -----------------------------------------------------------
+    struct Seg { long chunk, a, b; };
+    Seg one[3];
+    long n_edge = 0, mid_lo = 0, mid_hi = 0, mid_a = 0, mid_b = 0;         // edge segments + the run of middle chunks
+    bool mid_flip = false;
+    int mid_at = -1;                                                        // position of the middle run among the edge segments
+    const long size = chunksize;
+    if (length < size) {
+        long a, b; py_slice(0, (long)std::floor((double)length / stride), T, a, b);
+        one[n_edge++] = Seg{0, a, b};
+    } else if (n_chunks == 1) {
+        one[n_edge++] = Seg{0, 0, T};
+    } else {
+        const long semi = overlap / 2, start = semi / stride, end = (size - semi) / stride;
+        const long stub = (length - overlap) % (size - overlap);
+        const long first_end = stub > 0 ? (stub + semi) / stride : end;
+        long a, b;
+        if (reverse) {
+            py_slice(0, -start, T, a, b); one[n_edge++] = Seg{n_chunks - 1, a, b};
+            mid_at = 1; mid_lo = 1; mid_hi = n_chunks - 1; mid_flip = true; py_slice(-end, -start, T, mid_a, mid_b);
+            py_slice(-first_end, T, T, a, b); one[n_edge++] = Seg{0, a, b};
+        } else {
+            py_slice(0, first_end, T, a, b); one[n_edge++] = Seg{0, a, b};
+            mid_at = 1; mid_lo = 1; mid_hi = n_chunks - 1; py_slice(start, end, T, mid_a, mid_b);
+            py_slice(start, T, T, a, b); one[n_edge++] = Seg{n_chunks - 1, a, b};
+        }
+    }
+    long positions = 0;
+    for (long i = 0; i < n_edge; ++i) positions += one[i].b - one[i].a;
+    if (mid_at >= 0 && mid_hi > mid_lo) positions += (mid_hi - mid_lo) * (mid_b - mid_a);
+    const long id_len = (long)strlen(read_id), rg_len = run_id && *run_id ? (long)strlen(run_id) : 7;
+    // the record (at most 2 x positions for sequence + qstring, 2 x positions for the move table, the names) is assembled at the front
+    // of `out`; sequence / qstring / moves are first collected in 3 x positions of scratch at its far end
+    const long need = 4 * positions + 24 + 2 * id_len + rg_len + 160 + 3 * positions;
+    if (need > out_cap) return -need;
+    // ---- strings -----------------------------------------------------------------------------------------------------------------
+    char* seq = out + out_cap - positions;
+    char* qs = seq - positions;
+    char* mvs = qs - positions;
+    long n_seq = 0, n_qs = 0, n_mv = 0;
+    unsigned long hist[256] = {0};
+    auto emit = [&](long chunk, long a, long b) {
+        const int8_t* s = chunk_row(pc, n_pieces, chunk, 0, T);
+        const int8_t* q = chunk_row(pc, n_pieces, chunk, 1, T);
+        const int8_t* m = chunk_row(pc, n_pieces, chunk, 2, T);
+        for (long t = a; t < b; ++t) {
+            seq[n_seq] = (char)s[t]; n_seq += s[t] != 0;
+            qs[n_qs] = (char)q[t]; n_qs += q[t] != 0;
+            mvs[n_mv++] = (char)('0' + m[t]);
+        }
+    };
+    for (long i = 0; i < n_edge; ++i) {
+        if (mid_at == i && mid_hi > mid_lo) {
+            if (mid_flip) for (long c = mid_hi - 1; c >= mid_lo; --c) emit(c, mid_a, mid_b);
+            else for (long c = mid_lo; c < mid_hi; ++c) emit(c, mid_a, mid_b);
+        }
+        emit(one[i].chunk, one[i].a, one[i].b);
+    }
+    if (rna) {
+        for (long i = 0, j = n_seq - 1; i < j; ++i, --j) { const char t = seq[i]; seq[i] = seq[j]; seq[j] = t; }
+        for (long i = 0, j = n_qs - 1; i < j; ++i, --j) { const char t = qs[i]; qs[i] = qs[j]; qs[j] = t; }
+    }
+    for (long i = 0; i < n_qs; ++i) ++hist[(unsigned char)qs[i]];
+    const double mq = n_qs ? mean_qscore(hist) : 0.0;
+    *seq_len = n_seq;
+    *mean_q = mq;
+    if (mq < min_qscore || n_seq == 0) return 0;
+    // ---- the record -----------------------------------------------------------------------------------------------------------------
+    char* p = out;
+    auto put = [&](const char* s, long n) { memcpy(p, s, (size_t)n); p += n; };
+    auto tags = [&]() {
+        p += sprintf(p, "RG:Z:%s\tqs:f:%0.2f\tns:i:%ld\tts:i:%ld", run_id && *run_id ? run_id : "unknown", mq, num_samples, trimmed_samples);
+        if (n_mv) {
+            p += sprintf(p, "\tmv:B:c,%d", stride);
+            for (long i = 0; i < n_mv; ++i) { *p++ = ','; *p++ = mvs[i]; }
+        }
+    };
+    if (mode == 1) {
+        *p++ = '>'; put(read_id, id_len); *p++ = '\n'; put(seq, n_seq); *p++ = '\n';
+    } else if (mode == 0) {
+        *p++ = '@'; put(read_id, id_len); *p++ = ' '; tags(); *p++ = '\n';
+        put(seq, n_seq); put("\n+\n", 3);
+        if (n_qs) put(qs, n_qs); else { memset(p, '!', (size_t)n_seq); p += n_seq; }
+        *p++ = '\n';
+    } else {
+        put(read_id, id_len); put("\t4\t*\t0\t0\t*\t*\t0\t0\t", 17); put(seq, n_seq); *p++ = '\t';
+        if (n_qs) put(qs, n_qs); else *p++ = '*';
+        put("\tNM:i:0\t", 8); tags(); *p++ = '\n';
+    }
+    return (long)(p - out);
+}

@@ -19,6 +19,17 @@ summary_field_names = ["filename", "read_id", "run_id", "channel", "mux", "start
                        "template_duration", "sequence_length_template", "mean_qscore_template"]
 
 
+def mean_qscore(qstring):
+    """`util.mean_qscore_from_qstring` through the library's helper: the Python records and the ones `bh_host_format_read` writes
+    (crf/basecall.py `records_from_planes`) carry the same `qs:f` / summary values because they share the arithmetic."""
+    try:
+        from bonito_amd import _lib
+        raw = qstring.encode("latin-1")
+        return float(_lib.lib().bh_host_mean_qscore(raw, len(raw)))
+    except OSError:                      # library not built: the numpy restatement (differs in the last bit at most)
+        return float(mean_qscore_from_qstring(qstring))
+
+
 def encode_moves(moves, stride, sep=","):
     """np.array([0,1,0,1,1]), 5 -> '5,0,1,0,1,1' (single-digit moves only)."""
     moves = np.asarray(moves)
@@ -83,7 +94,7 @@ def format_record(read, res, mode, min_qscore=0.0):
     construction. The log entry is produced for EVERY read, before the q-score / empty-sequence filters, like the reference
     (io.py:437-442)."""
     seq, qstring = res["sequence"], res.get("qstring", "*")
-    mean_q = mean_qscore_from_qstring(qstring) if qstring and qstring != "*" else 0.0
+    mean_q = mean_qscore(qstring) if qstring and qstring != "*" else 0.0
     log = (read.read_id, signal_samples(read))
     if mean_q < min_qscore or not len(seq):
         return None, None, log

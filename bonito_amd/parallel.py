@@ -12,7 +12,8 @@ Read chunks are independent (/root/reference bonito/crf/basecall.py:70-72) and t
   work of writing scales with the ranks.
 * Rank 0 merges the ranks' record streams back into input order and is the only writer (`ordered_records`): record i comes
   from rank i % world, every rank emits its records in order, so the merge pulls from per-rank FIFO streams in turn -- a
-  bounded reorder window (a sender blocks once `window` of its messages are unconsumed), nothing is held until the end.
+  bounded reorder window (a rank produces into a queue of `window` messages that a sender thread drains; the pipeline only
+  waits once that window is full), nothing is held until the end.
   The reference gets its ordering from a single process (bonito/io.py:400-469 consumes one iterator); this is the same
   contract across processes.
 * The only collectives are barriers / a MAX-reduce for timing (bench.py). Nothing per batch.
@@ -89,7 +90,39 @@ def host_group():
     return _HOST_GROUP
 
 
-def ordered_records(local_records, rank=None, world=None, batch=64, group=None):
+class _Prefetch:
+    """Runs an iterator in a thread and hands its items over a bounded queue: the producer (a rank's basecalling pipeline) keeps
+    running while the consumer is blocked elsewhere (a send to rank 0, a receive from a slower rank), up to `depth` items ahead;
+    beyond that it waits - memory stays bounded. Exceptions of the producer surface in the consumer."""
+    _END = object()
+
+    def __init__(self, iterator, depth):
+        import queue
+        import threading
+        self.q = queue.Queue(maxsize=max(1, depth))
+        self.exc = None
+        self.t = threading.Thread(target=self._run, args=(iterator,), daemon=True)
+        self.t.start()
+
+    def _run(self, iterator):
+        try:
+            for item in iterator:
+                self.q.put(item)
+        except BaseException as exc:      # handed to the consumer
+            self.exc = exc
+        self.q.put(self._END)
+
+    def __iter__(self):
+        while True:
+            item = self.q.get()
+            if item is self._END:
+                if self.exc is not None:
+                    raise self.exc
+                return
+            yield item
+
+
+def ordered_records(local_records, rank=None, world=None, batch=64, group=None, window=32):
     """Merge the per-rank record streams into global input order on rank 0.
 
     `local_records`: this rank's records in ITS order; its k-th record is global record ``rank + k * world`` (what
@@ -97,25 +130,35 @@ def ordered_records(local_records, rank=None, world=None, batch=64, group=None):
 
     Rank 0: returns a generator over ALL records in global order (record i is pulled from rank i % world's stream; the
     stream of a rank is a sequence of messages of up to `batch` records, the last one flagged). Other ranks: the call
-    sends this rank's records to rank 0 as they are produced, blocks while rank 0 is behind (bounded window: gloo's
-    send completes when the matching recv is posted), and returns an empty iterator when done."""
+    sends this rank's records to rank 0 as they are produced and returns an empty iterator when done.
+
+    Back-pressure without stalling the GPUs: on every rank the records are produced by a thread of their own into a queue of at
+    most `window` messages (`window * batch` records), so a rank whose send is waiting for rank 0 - because an EARLIER record of a
+    slower rank is still missing - keeps basecalling until that window is full, and rank 0's own pipeline keeps running while
+    its writer waits for another rank. Nothing is ever held beyond the windows (a run with one rank ten times slower than the
+    others finishes with the same bytes, tests/test_parallel.py)."""
     if rank is None or world is None:
         rank, world, _ = env_rank_world()
     if world == 1:
         return iter(local_records)
     group = group or host_group()
-    if rank != 0:
+
+    def messages(records):
         pending = []
-        for rec in local_records:
+        for rec in records:
             pending.append(rec)
             if len(pending) == batch:
-                _send_obj((pending, False), 0, group)
+                yield pending, False
                 pending = []
-        _send_obj((pending, True), 0, group)
+        yield pending, True
+
+    if rank != 0:
+        for msg in _Prefetch(messages(local_records), window):
+            _send_obj(msg, 0, group)
         return iter(())
 
     def merged():
-        local = iter(local_records)
+        local = iter(_Prefetch(local_records, window * batch))
         bufs = [[] for _ in range(world)]        # records received from rank r and not yet emitted
         done = [False] * world
         i = 0

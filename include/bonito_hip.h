@@ -281,6 +281,20 @@ long bh_host_compact(const int8_t* src, long n, char* dst);
  * (bonito/util.py:142-161; T >= chunksize) cast to fp16 (round to nearest even) into dst[nrows][chunksize].
  * Returns nrows, or < 0 on bad arguments. No device work. */
 long bh_host_chunk_rows(const float* signal, long T, int chunksize, int overlap, long row0, long nrows, uint16_t* dst);
+
+/* One basecalled read -> its FASTQ (mode 0) / FASTA (1) / unaligned SAM (2) record, in one call: the stitching of
+ * bonito/util.py:164-183 (via crf/basecall.py:13-24: the kept window of every chunk, `reverse` included), koi's to_str
+ * (crf/basecall.py:48-55), the rna flip, the mean q-score filter and the record text with the tags of bonito/io.py:135-166
+ * (RG:Z, qs:f, ns:i, ts:i, mv:B:c). The read's chunks are n_pieces runs of consecutive rows of decoded planes: piece i = rows
+ * [lo[i], lo[i] + rows[i]) of an int8 array [3][n][T] (sequence, qstring, moves) at base[i] whose planes are plane_stride[i] bytes
+ * apart. Returns the bytes written to out; 0 = filtered out (empty sequence or mean q < min_qscore; seq_len / mean_q are set
+ * regardless); -1 = bad arguments; < -1 = -(bytes of out needed). */
+long bh_host_format_read(const int8_t* const* base, const long* plane_stride, const long* lo, const long* rows, int n_pieces,
+                         long T, long length, int chunksize, int overlap, int stride, int reverse, int rna, int mode,
+                         double min_qscore, const char* read_id, const char* run_id, long num_samples, long trimmed_samples,
+                         char* out, long out_cap, long* seq_len, double* mean_q);
+/* Mean q-score of a phred string, averaged in error-probability space (bonito/util.py mean_qscore_from_qstring). */
+double bh_host_mean_qscore(const char* qstring, long n);
 /* one LSTM layer over gates_in = x W_ih^T + b (fp16 [T][N][4H], torch gate order); h_out fp16 [T][N][H].
  * N % 16 == 0.  workspace: bh_lstm_workspace(N, H) device bytes.  err_flag: device int, set non-zero on a
  * device-side timeout.  flags bit 0: force the placement-independent write-through exchange policy;

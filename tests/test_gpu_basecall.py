@@ -485,7 +485,7 @@ def test_bench_default_mode_runs_and_reports_the_contract_fields():
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "8", "--warmup", "4", "--no-cpu-baseline"],
-                       capture_output=True, text=True, timeout=600)
+                       capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1, r.stdout[-500:]                       # ONE json line, nothing else on stdout
@@ -495,5 +495,13 @@ def test_bench_default_mode_runs_and_reports_the_contract_fields():
     assert "4 batches per engine call" in d["config"]["workload"] and "batch 512 x chunk 10000" in d["config"]["workload"]
     roof = d["roofline"]
     assert roof["kernel"] == "lstm_layer_wgx2_kernel<12,3>" and roof["bound"] == "mfma" and 0.1 < roof["frac"] < 1.0
-    assert roof["flops_per_launch"] == pytest.approx(4.027e12, rel=1e-3) and roof["traffic"] == 2652000000
-    assert d["with_h2d"]["value"] > 5e7
+    with open(os.path.join(root, "profiles", "pmc_traffic.json")) as fh:
+        pmc = json.load(fh)["lstm_layer_wgx2_kernel"]
+    assert roof["flops_per_launch"] == pytest.approx(4.027e12, rel=1e-3) and roof["traffic"] == pmc["bytes_per_launch"]
+    assert 2.6e9 < roof["traffic"] < 2.8e9 and roof["traffic_source"] == pmc["source"]      # 2.62 GB algorithmic
+    assert d["with_h2d"]["value"] > 5e7 and d["value_with_h2d"] == d["with_h2d"]["value"] and d["batches_per_engine_call"] == 4
+    one = d["per_call_1"]                                        # the product path's call shape, in the same line
+    assert one["value"] > 5e7 and "lstm_layer_wgx" in one["roofline"]["kernel"] and one["roofline"]["chunks_per_launch"] == 512
+    assert set(d["other_configs"]) == {"fast", "sup", "sup_lstm", "hac_quantize"}
+    for name, leg in d["other_configs"].items():
+        assert "error" not in leg and leg["value"] > 1e7, (name, leg)

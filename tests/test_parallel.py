@@ -109,6 +109,74 @@ def test_multi_rank_streaming_writer_is_byte_identical(tmp_path, world, mode, ba
     assert all(outs[r][1] == float(world) for r in range(world))     # MAX over ranks
 
 
+def _skew_worker(rank, world, port, n, slow_rank, q):
+    """Rank `slow_rank` produces every record ~40x slower than the others and with 10x the payload; one rank pauses for a while in
+    the middle. Tiny windows (batch 2, window 2), so every back-pressure path is taken many times."""
+    import time
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    parallel.init("gloo")
+    produced = []
+
+    def records():
+        for k, i in enumerate(range(rank, n, world)):
+            if rank == slow_rank:
+                time.sleep(0.004)
+            if rank == (slow_rank + 1) % world and k == 20:
+                time.sleep(0.5)                                    # a rank that sleeps
+            produced.append(i)
+            yield ("rec-%d" % i) * (10 if rank == slow_rank else 1), [i], ("id%d" % i, i)
+
+    out = parallel.ordered_records(records(), rank, world, batch=2, window=2)
+    got = list(out)
+    dist.barrier()
+    q.put((rank, got if rank == 0 else len(produced)))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,slow", [(3, 1), (2, 0), (4, 3)])
+def test_merge_with_a_slow_and_a_sleeping_rank_neither_deadlocks_nor_reorders(world, slow):
+    """Skewed ranks (one with 10x the bytes per record and 40x the time, one that pauses): the merged stream is still every record
+    once, in global order, and the run ends - the fast ranks wait in their bounded windows, nobody holds records to the end."""
+    n = 151
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_skew_worker, args=(r, world, port, n, slow, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    outs = dict(q.get(timeout=240) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert [r[1] for r in outs[0]] == [[i] for i in range(n)]
+    assert all(r[0] == ("rec-%d" % r[1][0]) * (10 if r[1][0] % world == slow else 1) for r in outs[0])
+    assert sum(outs[r] for r in range(1, world)) == n - len(range(0, n, world))
+
+
+def test_prefetch_propagates_producer_errors_and_bounds_the_queue():
+    def boom():
+        yield 1
+        yield 2
+        raise ValueError("producer failed")
+
+    it = iter(parallel._Prefetch(boom(), 4))
+    assert next(it) == 1 and next(it) == 2
+    with pytest.raises(ValueError):
+        next(it)
+    produced = []
+
+    def counted():
+        for i in range(100):
+            produced.append(i)
+            yield i
+
+    pf = parallel._Prefetch(counted(), 3)
+    import time
+    time.sleep(0.3)
+    assert len(produced) <= 5                       # 3 queued + one in hand (+ one being produced): the producer waits
+    assert list(pf) == list(range(100))
+
+
 def test_reader_shard_is_a_partition_and_loads_only_its_own(tmp_path, monkeypatch):
     rdir = str(tmp_path)
     make_reads_dir(rdir)

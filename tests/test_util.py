@@ -266,3 +266,69 @@ def test_host_compact_and_chunk_rows_edge_cases():
     out = np.empty((1, 1000), np.float16)
     assert lib.bh_host_chunk_rows(sig.ctypes.data, 500, 1000, 100, 0, 1, out.ctypes.data) < 0     # T < chunksize: Python path
     assert lib.bh_host_chunk_rows(sig.ctypes.data, 500, 100, 100, 0, 1, out.ctypes.data) < 0      # overlap >= chunksize
+
+
+@pytest.mark.parametrize("mode", ["fastq", "fasta", "sam"])
+@pytest.mark.parametrize("reverse,rna", [(False, False), (True, False), (False, True)])
+def test_fused_record_formatter_writes_the_bytes_of_the_python_path(mode, reverse, rna):
+    """`records_from_planes` (one `bh_host_format_read` call per read: stitch + to_str + record text in the library) against
+    unbatchify -> stitch_planes -> fmt_planes -> io.format_record on the same decoded planes: identical text, summary rows and log
+    entries - reads shorter than a chunk, exactly one chunk, many chunks, reads split over several engine calls, empty calls
+    (filtered), a q-score filter, overlap 0 and an overlap that is not a multiple of the stride."""
+    import importlib
+    from bonito_amd import io as bio
+    bc = importlib.import_module("bonito_amd.crf.basecall")
+
+    class Read:
+        filename, channel, mux, start, duration, template_start, template_duration = "f.pod5", 3, 1, 0.5, 2.0, 0.1, 1.9
+
+        def __init__(self, i, n, run):
+            self.read_id, self.num_samples, self.signal_len, self.run_id, self.trimmed_samples = "read-%d" % i, n + 7 * i, n, run, 7 * i
+        signal = None
+
+    rng = np.random.default_rng(11)
+    for chunksize, overlap, stride, batch in [(1200, 120, 6, 7), (1000, 0, 5, 5), (1210, 121, 11, 16), (600, 60, 6, 3)]:
+        T = chunksize // stride
+        lens = [chunksize // 3, chunksize, chunksize + 1, 2 * chunksize - overlap, 5 * chunksize + 17, 3 * chunksize, 11 * chunksize + 333, chunksize - 1]
+        reads = [Read(i, n, "run%d" % (i % 2) if i % 3 else None) for i, n in enumerate(lens)]
+
+        def n_chunks(n):
+            if n < chunksize:
+                return 1
+            step = chunksize - overlap
+            stub = (n - overlap) % step
+            return (n - stub - chunksize) // step + 1 + (1 if stub > 0 else 0)
+
+        def batches():
+            keys, pos, planes = [], 0, None
+            for r in reads:
+                n, lo = n_chunks(r.signal_len), 0
+                key = (r, 0, r.signal_len)
+                while lo < n:
+                    if planes is None:
+                        mv = (rng.random((batch, T)) < 0.4).astype(np.int8)
+                        if r.read_id == "read-5":
+                            mv[:] = 0                                       # a read that calls nothing: filtered out
+                        seq = np.where(mv != 0, np.array([65, 67, 71, 84], np.int8)[rng.integers(0, 4, (batch, T))], 0).astype(np.int8)
+                        qs = np.where(mv != 0, rng.integers(34, 80, (batch, T)), 0).astype(np.int8)
+                        planes = torch.from_numpy(np.stack([seq, qs, mv]))
+                    take = min(n - lo, batch - pos)
+                    keys.append((key, (pos, pos + take)))
+                    pos += take
+                    lo += take
+                    if pos == batch:
+                        yield tuple(keys), planes
+                        keys, pos, planes = [], 0, None
+            if pos:
+                yield tuple(keys), planes[:, :pos]
+
+        cached = list(batches())
+        for min_q in (0.0, 14.0):
+            want = [bio.format_record(read, bc.fmt_planes(stride, bc.stitch_planes(sc, end - start, chunksize, overlap, stride, reverse), rna), mode, min_q)
+                    for ((read, start, end), sc) in util.unbatchify(iter(cached), dim=1)]
+            got = list(bc.records_from_planes(iter(cached), chunksize, overlap, stride, mode, min_q, reverse, rna))
+            assert len(got) == len(want) == len(reads)
+            for g, w in zip(got, want):
+                assert g == w
+            assert min_q > 0 or any(t is not None for t, _, _ in got)
+        assert any(t is None for t, _, _ in got)                            # ... and the q-score filter did drop reads

@@ -2,7 +2,7 @@
 """End-to-end throughput of the product path on synthetic reads, host work included: chunking, batching, H2D, encoder,
 decode, D2H, stitching, formatting (FASTQ with move tables) and -- with several ranks -- the record merge on rank 0.
 
-    python tools/e2e_basecall.py [--model hac|fast] [--reads 1500] [--mean-len 100000] [--devices 0-7] [--reps 2]
+    python tools/e2e_basecall.py [--model hac|fast] [--reads 30000] [--mean-len 100000] [--devices 0-7] [--reps 2]
 
 `--devices`: one process per listed GPU (a device may be listed twice), reads sharded round-robin, every rank formats
 its own records, rank 0 merges them in input order and writes them (to /dev/null) -- the same code path as
@@ -23,7 +23,7 @@ sys.path.insert(0, ROOT)
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--model", default="hac", choices=["hac", "fast"])
-    ap.add_argument("--reads", type=int, default=1500)
+    ap.add_argument("--reads", type=int, default=30000)
     ap.add_argument("--mean-len", type=int, default=100000)
     ap.add_argument("--devices", default=None)
     ap.add_argument("--reps", type=int, default=2)
@@ -61,7 +61,8 @@ def main():
     import torch.distributed as dist
     from bonito_amd import io as bio
     from bonito_amd import parallel, synthetic, util
-    from bonito_amd.crf import basecall
+    import importlib
+    basecall_records = importlib.import_module("bonito_amd.crf.basecall").basecall_records
 
     rank, world, _ = parallel.env_rank_world()
     if world > 1:
@@ -79,15 +80,22 @@ def main():
 
     rng = np.random.default_rng(1)
     lens = np.clip(rng.normal(a.mean_len, a.mean_len / 3, a.reads), 5000, None).astype(int)
-    mine = [Read(i, np.random.default_rng(i).standard_normal(int(n)).astype(np.float32))
-            for i, n in enumerate(lens) if i % world == rank]
+    # a pool of distinct signals reused cyclically (30 000 reads of 1e5 samples would be 12 GB of float32): every read is a window
+    # of one of them, with its own id and length
+    pool = [np.random.default_rng(100 + k).standard_normal(int(lens.max()) + 1).astype(np.float32) for k in range(16)]
+
+    def my_reads():
+        for i, n in enumerate(lens):
+            if i % world == rank:
+                yield Read(i, pool[i % len(pool)][:int(n)])
+
     total = int(lens.sum())
     for rep in range(a.reps):
         if world > 1:
             dist.barrier(group=parallel.host_group())
         t0 = time.perf_counter()
-        results = basecall(model, iter(mine), chunksize=9996, overlap=498, batchsize=a.batchsize)
-        records = parallel.ordered_records(parallel.format_stream(results, "fastq"), rank, world)
+        records = basecall_records(model, my_reads(), "fastq", chunksize=9996, overlap=498, batchsize=a.batchsize)
+        records = parallel.ordered_records(records, rank, world)
         if rank == 0:
             with open(os.devnull, "w") as sink:
                 w = bio.Writer("fastq", records, fd=sink, preformatted=True)
@@ -101,8 +109,9 @@ def main():
         dt = time.perf_counter() - t0
         if rank == 0:
             assert done == total, (done, total)
-            print("%s x%d rank(s): %d reads, %.3e samples, %.2f s -> %.3e samples/s end to end (%.3e per rank)"
-                  % (a.model, world, a.reads, total, dt, total / dt, total / dt / world), flush=True)
+            print("%s x%d rank(s), host cpus %s: %d reads, %.3e samples, %.2f s -> %.3e samples/s end to end (%.3e per rank)"
+                  % (a.model, world, sorted(os.sched_getaffinity(0))[:4] if len(os.sched_getaffinity(0)) <= 4 else len(os.sched_getaffinity(0)),
+                     a.reads, total, dt, total / dt, total / dt / world), flush=True)
     if world > 1:
         dist.destroy_process_group()
 
