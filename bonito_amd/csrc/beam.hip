@@ -1235,6 +1235,12 @@ int g_beam_ckpt = 0;       // with the fused scan: 1 = guide checkpointed every 
                            // guide's HBM traffic to a quarter (decode stage 5.26 -> 3.94 GB per hac batch) but costs more than it saves
                            // next to the encoder: decode 5.7 -> 6.1 ms, bench step 19.6 -> 20.7 ms (fp16), 14.8 -> 15.2 (8-bit, two
                            // lanes); with the recomputation on the scan wave itself 23.4 ms. Off by default.
+int g_beam_cpw = 1;        // chunks per workgroup of the fused beam kernel at 256 states ("beam_cpw": 1, 2, 3). The 16 KiB lse table is shared
+                           // by the chunks of a workgroup: three chunks make two 78 KiB workgroups = six chunks per CU where one per
+                           // workgroup (37 KiB) gives four. Measured in round 3 (hac, 2048-chunk calls): decode 3.71 / 3.56 / 3.63 ms
+                           // per batch for 1 / 2 / 3, the bench step unchanged - with four chunks per CU the kernel is already bound by
+                           // the instructions the beam and scan waves issue (~5.5 k SIMD cycles per chunk and time step), not by the
+                           // latency of one wave's LDS round trips. Left at 1.
 int g_beam_fuse = -1;      // forward / posterior scan as a second wave of the beam kernel's workgroups: -1 auto (<= 256 states: one
                            // scan wave keeps up with the beam wave; at 1024 states its 16 states per lane make the beam wave wait:
                            // sup-LSTM 256 x 3334 decode 18 -> 36 ms), 0 never (own kernel), 1 always
@@ -1328,6 +1334,10 @@ int bh_k_beam_search(const void* scores, int N, int T, int state_len, int beam_w
             case 10: lrc = launch_beam(beam_kernel<5, 1, false, true, true>, 1, beam_wave_lds<5>(), scan_wave_lds_ckpt<5>()); break;
             case 11: lrc = launch_beam(beam_kernel<5, 1, true, true, true>, 1, beam_wave_lds<5>(), scan_wave_lds_ckpt<5>()); break;
         }
+    } else if (fuse && state_len == 4 && !dbg && g_beam_cpw == 3) {
+        lrc = launch_beam(beam_kernel<4, 3, false, true>, 3, beam_wave_lds<4>(), scan_wave_lds<4>());
+    } else if (fuse && state_len == 4 && !dbg && g_beam_cpw == 2) {
+        lrc = launch_beam(beam_kernel<4, 2, false, true>, 2, beam_wave_lds<4>(), scan_wave_lds<4>());
     } else if (fuse) {
         switch (state_len * 2 + (dbg ? 1 : 0)) {
             case 2: lrc = launch_beam(beam_kernel<1, 4, false, true>, 4, beam_wave_lds<1>(), scan_wave_lds<1>()); break;
@@ -1366,6 +1376,7 @@ int bh_k_decode_set_option(const char* name, int value) {
     if (name && !strcmp(name, "beam_fork")) { g_beam_fork = value; return 0; }
     if (name && !strcmp(name, "beam_select")) { g_beam_select = value; return 0; }
     if (name && !strcmp(name, "beam_fuse")) { g_beam_fuse = value; return 0; }
+    if (name && !strcmp(name, "beam_cpw")) { g_beam_cpw = value; return 0; }
     if (name && !strcmp(name, "decode_nt")) { g_decode_nt = value; return 0; }
     if (name && !strcmp(name, "beam_ckpt")) { g_beam_ckpt = value; return 0; }
     return 1;     // not a decoder option
