@@ -15,6 +15,7 @@ for step in "$@"; do
     bench)  timeout 600 python bench.py > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err; tail -n1 gpurun_out/${TAG}_bench.json | cut -c1-3000 ;;
     benchq) timeout 300 python bench.py --no-cpu-baseline > gpurun_out/${TAG}_benchq.json 2> gpurun_out/${TAG}_benchq.err; tail -n1 gpurun_out/${TAG}_benchq.json | cut -c1-1500 ;;
     prof)   PS_ARGS="--batch 1024" timeout 900 bash tools/prof_round.sh $TAG > gpurun_out/${TAG}_prof.log 2>&1; sed -n 1,14p gpurun_out/${TAG}_prof.log | cut -c1-180 ;;
+    sq)     timeout 900 bash tools/prof_sq.sh $TAG > gpurun_out/${TAG}_sq.log 2>&1; tail -n 40 gpurun_out/${TAG}_sq.log | cut -c1-160 ;;
     e2e)    timeout 600 python tools/e2e_basecall.py --reps 1 > gpurun_out/${TAG}_e2e.log 2>&1; tail -n 3 gpurun_out/${TAG}_e2e.log ;;
     e2e2)   timeout 600 taskset -c 0-1 python tools/e2e_basecall.py --reps 1 > gpurun_out/${TAG}_e2e_2cores.log 2>&1; tail -n 3 gpurun_out/${TAG}_e2e_2cores.log ;;
     cli)    timeout 900 python -m pytest tests/test_gpu_basecall.py -m gpu -x -q > gpurun_out/${TAG}_pytest_cli.log 2>&1; tail -n 4 gpurun_out/${TAG}_pytest_cli.log ;;
