@@ -30,7 +30,9 @@ Hazards placed here (the compiler pads nothing inside an asm statement):
   * transcendental result -> consumer: at least one instruction in between (gfx940+ trans forwarding hazard);
   * v_cmp (vcc) -> v_cndmask: at least one instruction in between.
 
-usage: gen_ringstep.py [--xdist a,b,c,d] [--hdepth n] [--xdepth n] [--hf-live] [--name fn] [--out path]
+usage: gen_ringstep.py --preset plain|paired        (the two includes of the library)
+       gen_ringstep.py [--xdist a,b,c,d] [--hdepth n] [--xdepth n] [--hf-live] [--polls-at n --xdma-at n --validate-at n --spread n]
+                       [--name fn] [--out path]         (experiments: tools/stream_bench.py, tools/gpu_variants.sh)
 """
 import argparse
 import os
@@ -422,7 +424,21 @@ def render(seq, fn, hf_live, header):
     return "\n".join(lines)
 
 
-def main():
+# The two streams the library is built from (python tools/gen_ringstep.py --preset plain|paired); the parameters are the best of the
+# sweeps of round 3 (tools/stream_bench.py for the arithmetic, tools/gpu_variants.sh + tools/lstm_stats2.py for the in-stream DMA)
+PRESETS = {
+    "plain": ["--hf-live", "--xdist", "0,10,10,16", "--xdepth", "3"],
+    "paired": ["--hf-live", "--xdist", "0,10,10,16", "--xdepth", "3", "--polls-at", "26", "--xdma-at", "42", "--spread", "2",
+               "--validate-at", "71", "--name", "ringstep3p_mfma", "--out",
+               os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bonito_amd", "csrc", "ringstep3p_mfma.inc")],
+}
+
+
+def main(argv=None):
+    import sys
+    argv = list(sys.argv[1:] if argv is None else argv)
+    if len(argv) >= 2 and argv[0] == "--preset":
+        argv = PRESETS[argv[1]] + argv[2:]
     ap = argparse.ArgumentParser()
     ap.add_argument("--xdist", default="0,12,12,12")
     ap.add_argument("--hdepth", type=int, default=5)
@@ -440,7 +456,7 @@ def main():
     ap.add_argument("--hf-live", action="store_true", help="keep the twelve h fragments in registers instead of re-reading them per tile")
     ap.add_argument("--name", default="ringstep3_mfma")
     ap.add_argument("--out", default=os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bonito_amd", "csrc", "ringstep3_mfma.inc"))
-    a = ap.parse_args()
+    a = ap.parse_args(argv)
     xdist = tuple(int(v) for v in a.xdist.split(","))
     seq = build(xdist, a.hdepth, a.xdepth, a.hpool, a.xpool, a.hf_live, a.lead, a.wgroup, a.nan_check, a.polls_at, a.xdma_at, a.validate_at, a.spread)
     if a.strip == "valu":
