@@ -32,7 +32,8 @@ __device__ const float g_lse_tab[BH_LSE_TABLE_SIZE] = {BH_LSE_TABLE_VALUES};
 __device__ __forceinline__ float lse2_tab(float a, float b, const float* tab) {
     float m = fmaxf(a, b);
     float d = fabsf(a - b);
-    if (!(d < BH_LSE_RANGE) || m == -INFINITY) return m;
+    // (m == -inf needs no test of its own: then both are -inf and d is NaN, or one is and d is +inf - neither is < RANGE)
+    if (!(d < BH_LSE_RANGE)) return m;
     float x = d * BH_LSE_SCALE;
     int i = (int)x;
     float f = x - (float)i;
@@ -601,7 +602,7 @@ __device__ __forceinline__ void dma16_nt(const char* g, char* lds) {      // sam
 __device__ __forceinline__ float lse2_tab_nb(float a, float b, const float* tab) {
     const float m = fmaxf(a, b);
     const float d = fabsf(a - b);
-    const bool plain = !(d < BH_LSE_RANGE) || m == -INFINITY;
+    const bool plain = !(d < BH_LSE_RANGE);          // covers m == -inf (d is NaN or +inf then)
     const float x = d * BH_LSE_SCALE;
     int i = plain ? 0 : (int)x;
     i = min(max(i, 0), BH_LSE_TABLE_SIZE - 2);
