@@ -1029,8 +1029,10 @@ template <int NKS, int MT, int KQ>
 __device__ __forceinline__ void ring_stream_paired(float4_t (&xacc)[MT], float (&cst)[MT], float (&hv)[MT], const half8_t (&whh)[MT][NKS],
                                                    const half8_t (&wih)[MT][NKS], const float4_t (&bias)[MT], unsigned hb, unsigned xb,
                                                    unsigned long long& bad, unsigned pm0, const char* exo, const unsigned (&vp)[KQ],
-                                                   unsigned xm0, const char* xsrc, unsigned vx, unsigned hbo) {
-    if constexpr (NKS == 12 && MT == 3) ringstep3p_mfma(xacc, cst, hv, whh, wih, bias, hb, xb, bad, pm0, exo, vp, xm0, xsrc, vx, hbo);
+                                                   unsigned xm0, const char* xsrc, unsigned vx, unsigned hbo, unsigned sga, unsigned rda,
+                                                   unsigned vmy, unsigned vh, const char* exs, const char* exa, const char* hrow, unsigned fast) {
+    if constexpr (NKS == 12 && MT == 3)
+        ringstep3p_mfma(xacc, cst, hv, whh, wih, bias, hb, xb, bad, pm0, exo, vp, xm0, xsrc, vx, hbo, sga, rda, vmy, vh, exs, exa, hrow, fast);
 }
 // Vector-memory operations of the H = 384 fast path with SCALAR addressing: a wave-uniform 64-bit base in an SGPR pair plus a 32-bit
 // per-lane byte offset that is loop-invariant (the compiler's per-lane 64-bit address arithmetic, the generic -> LDS pointer
@@ -1136,6 +1138,10 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_wgx2_kernel(LstmWgxArgs wp)
     }
 #pragma unroll
     for (int kk = 0; kk < KQ; ++kk) vp_off[kk] = (unsigned)(lo + (wave + 4 * kk) * 1024);  // my k-steps inside an exchange slot
+    const unsigned stage_a = lds_addr(stage);           // this wave's transpose row
+    unsigned fast_u[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) fast_u[r] = (unsigned)__builtin_amdgcn_readfirstlane(fast[r] ? 1 : 0);
     const long row_bytes = x_row * 2;
     const char* xrow2 = (const char*)fp.x + (long)(p.T > 2 ? t0 + 2 * dt : t0) * row_bytes;   // row of x_{t+2} (uniform), advanced per step
     const char* xrow_any = (const char*)fp.x + (long)t0 * row_bytes;
@@ -1263,8 +1269,12 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_wgx2_kernel(LstmWgxArgs wp)
             const unsigned xm0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(smem_a + (4 + r * 2 + par) * TILE + (3 - wave) * 1024));
             unsigned long long bad;
             float hv[MT];
+            const char* exs = exr[r] + (long)(step & 3) * slot_stride;           // the exchange slot of h_t (uniform)
+            const char* exa = exr[r] + (long)((step + 2) & 3) * slot_stride;     // the slot re-armed for h_{t+2}
             ring_stream_paired<NKS, MT, KQ>(xacc[r], cst[r], hv, whh, wih, bias4, smem_a + (r * 2 + par) * TILE + lo,
-                                            smem_a + (4 + r * 2 + (par ^ 1)) * TILE + lo, bad, pm0, exo, vp_off, xm0, xsrc, vx_off[r], hbo);
+                                            smem_a + (4 + r * 2 + (par ^ 1)) * TILE + lo, bad, pm0, exo, vp_off, xm0, xsrc, vx_off[r], hbo,
+                                            stage_a + (unsigned)((c * U + q * MT) * 2), stage_a + (unsigned)((cc * U + part * 4) * 2),
+                                            (unsigned)my_byte, vh_off[r], exs, exa, hrow, (unsigned)__builtin_amdgcn_readfirstlane((int)fast_u[r]));
             const long long q3 = STATS ? __builtin_readcyclecounter() : 0;
             if (__builtin_expect(chk_o && (bad != 0 || dead), 0)) {              // some element had not arrived: re-poll it, bounded
                 uint4_t chk[KQ];
@@ -1274,17 +1284,6 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_wgx2_kernel(LstmWgxArgs wp)
                 if constexpr (STATS) { st_poll += __builtin_readcyclecounter() - q3; ++st_slow; }
             }
             const long long q4 = STATS ? __builtin_readcyclecounter() : 0;
-            {
-                const char* exs = exr[r] + (long)(step & 3) * slot_stride;       // the exchange slot of h_t (uniform)
-                u16_alias_t* sg = (u16_alias_t*)stage + c * U + q * MT;
-#pragma unroll
-                for (int m = 0; m < MT; ++m) sg[m] = __builtin_bit_cast(unsigned short, (half_t)hv[m]);
-                const unsigned long long packed = *(const u64_alias_t*)((half_t*)stage + cc * U + part * 4);
-                const char* exa = exr[r] + (long)((step + 2) & 3) * slot_stride; // the slot re-armed for h_{t+2}
-                if (fast[r]) { store8_s<false>(exs, (unsigned)my_byte, packed); store8_s<false>(exa, (unsigned)my_byte, ~0ull); }
-                else { store8_s<true>(exs, (unsigned)my_byte, packed); store8_s<true>(exa, (unsigned)my_byte, ~0ull); }
-                store8_s<false>(hrow, vh_off[r], packed);
-            }
             if constexpr (STATS) {
                 const long long q5 = __builtin_readcyclecounter();
                 st_bar += q1 - q0; st_sec[2] += q3 - q1; st_sec[4] += q4 - q3; st_sec[3] += q5 - q4;

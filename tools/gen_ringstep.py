@@ -157,7 +157,7 @@ def weave(mf, va, lead_m):
 VBASE = 220          # v[VBASE .. VBASE+11]: the three fragments of the other ring's h tile read back for validation (physical: the OR tree names their dwords)
 
 
-def build(xdist, hdepth, xdepth, hpool, xpool, hf_live, lead, wgroup=1, nan_check=False, polls_at=-1, xdma_at=-1, validate_at=-1, spread=0):
+def build(xdist, hdepth, xdepth, hpool, xpool, hf_live, lead, wgroup=1, nan_check=False, polls_at=-1, xdma_at=-1, validate_at=-1, spread=0, publish=False):
     assert sum(xdist) == 3 * NKS and len(xdist) == 4
     xs = [(ks, m) for ks in range(NKS) for m in range(3)]
     xi = 0
@@ -319,7 +319,19 @@ def build(xdist, hdepth, xdepth, hpool, xpool, hf_live, lead, wgroup=1, nan_chec
         out.append(nop(12 - gap - 1))
     if nan_check:
         out.append(Ins("cmp", "v_cmp_u_f32_e64 %[bad], %[nan], %[nan]", reads=("nan",), writes=("bad",)))
-    out.append(Ins("wait", "s_waitcnt lgkmcnt(0)"))
+    if publish:
+        # h_t of the lane's three cells -> fp16 -> the wave's LDS staging row (2-byte writes) -> read back as the 8 bytes this lane
+        # moves (one wave: LDS operations complete in issue order, no wait between the writes and the read). The OR tree of the
+        # validation runs while that read is in flight.
+        assert validate_at >= 0
+        for m in range(3):
+            out.append(Ins("valu", "v_cvt_f16_f32_e32 %%[hh%d], v%d" % (m, PBASE + 4 * m), writes=("hh%d" % m,)))
+        for m in range(3):
+            out.append(Ins("lds", "ds_write_b16 %%[sga], %%[hh%d]%s" % (m, " offset:%d" % (2 * m) if m else ""), reads=("sga", "hh%d" % m)))
+        out.append(Ins("lds", "ds_read_b64 %[pk], %[rda]", reads=("rda",), writes=("pk",)))
+        out.append(Ins("wait", "s_waitcnt lgkmcnt(4)"))          # the three validation reads are home (three writes + one read younger)
+    else:
+        out.append(Ins("wait", "s_waitcnt lgkmcnt(0)"))
     if validate_at >= 0:         # any of the twelve dwords still carrying the sentinel bit? (the stream's own LDS reads are all home by now)
         d = ["v%d" % (VBASE + i) for i in range(12)]
         out.append(Ins("valu", "v_or3_b32 %s, %s, %s, %s" % (d[0], d[0], d[1], d[2])))
@@ -330,6 +342,20 @@ def build(xdist, hdepth, xdepth, hpool, xpool, hf_live, lead, wgroup=1, nan_chec
         out.append(Ins("valu", "v_or_b32_e32 %s, %s, %s" % (d[0], d[0], d[4])))
         out.append(Ins("valu", "v_and_b32_e32 %s, 0x40004000, %s" % (d[0], d[0])))
         out.append(Ins("cmp", "v_cmp_ne_u32_e64 %%[bad], 0, %s" % d[0], writes=("bad",)))
+    if publish:
+        # publish h_t into its exchange slot, re-arm the slot of h_{t+2}, write the layer output row: plain stores when the ring sits on
+        # one XCD (`fast`), write-through otherwise - the policy of the C++ sections
+        out.append(Ins("wait", "s_waitcnt lgkmcnt(0)"))
+        out.append(Ins("salu", "s_cmp_lg_u32 %[fast], 0", reads=("fast",)))
+        out.append(Ins("salu", "s_cbranch_scc1 1f"))
+        out.append(Ins("vmem", "global_store_dwordx2 %[vmy], %[pk], %[exs] sc1", reads=("vmy", "pk", "exs")))
+        out.append(Ins("vmem", "global_store_dwordx2 %[vmy], %[ones], %[exa] sc1", reads=("vmy", "ones", "exa")))
+        out.append(Ins("salu", "s_branch 2f"))
+        out.append(Ins("label", "1:"))
+        out.append(Ins("vmem", "global_store_dwordx2 %[vmy], %[pk], %[exs]", reads=("vmy", "pk", "exs")))
+        out.append(Ins("vmem", "global_store_dwordx2 %[vmy], %[ones], %[exa]", reads=("vmy", "ones", "exa")))
+        out.append(Ins("label", "2:"))
+        out.append(Ins("vmem", "global_store_dwordx2 %[vh], %[pk], %[hrow]", reads=("vh", "pk", "hrow")))
     return out
 
 
@@ -369,6 +395,18 @@ def operand(name):
         return ("s" if name == "xm0" else "v"), name
     if name in ("xv1", "xv2"):
         return "v", name
+    if name in ("hh0", "hh1", "hh2"):
+        return "v", "hh[%s]" % name[2]
+    if name == "pk":
+        return "v", "pk"
+    if name in ("sga", "rda", "vmy", "vh"):
+        return "v", name
+    if name == "ones":
+        return "v", "~0ull"
+    if name in ("exs", "exa", "hrow"):
+        return "s", name
+    if name == "fast":
+        return "s", "fast"
     if name == "hi25":
         return "v", "25.0f"
     if name == "hi12":
@@ -387,6 +425,8 @@ def render(seq, fn, hf_live, header):
         extra_args += ", unsigned xm0, const char* xsrc, unsigned vx"
     if "hbo" in names:
         extra_args += ", unsigned hbo"
+    if "pk" in names:
+        extra_args += ", unsigned sga, unsigned rda, unsigned vmy, unsigned vh, const char* exs, const char* exa, const char* hrow, unsigned fast"
     lines = ["// GENERATED by tools/gen_ringstep.py - do not edit. " + header,
              "// in: xacc[m] = bias + W_ih x_t (tile m), cst; h_{t-1} fragments at LDS address hb, x_{t+1} fragments at xb (+ lane * 16 each)",
              "// out: hv[m] = h_t of the lane's three cells, cst, xacc[m] = bias + W_ih x_{t+1}",
@@ -395,6 +435,8 @@ def render(seq, fn, hf_live, header):
              "    float e[3], nanacc;",
              "    unsigned xv1, xv2;",
              "    uint4_t vt[3];",
+             "    unsigned hh[3];",
+             "    unsigned long long pk;",
              "    float4_t acc[3];",
              "    half8_t " + ", ".join(["ht%d" % i for i in range(NKS if hf_live else 8)] + ["xt%d" % i for i in range(4)]) + ";"]
     first_access, written = {}, set()
@@ -418,9 +460,9 @@ def render(seq, fn, hf_live, header):
     body = '\\n\\t"\n        "'.join(x.text for x in seq)
     lines.append('    asm volatile("' + body + '"\n        : ' + ", ".join(outs) + "\n        : " + ", ".join(ins) + ('\n        : "vcc", "scc", "memory");' if "exo" in names else '\n        : "vcc");'))
     if any(x.meta.get("cell") is not None for x in seq):
-        lines += ["    hv[0] = acc[0][0]; hv[1] = acc[1][0]; hv[2] = acc[2][0]; (void)nanacc; (void)xv1; (void)xv2; (void)vt;", "}", ""]
+        lines += ["    hv[0] = acc[0][0]; hv[1] = acc[1][0]; hv[2] = acc[2][0]; (void)nanacc; (void)xv1; (void)xv2; (void)vt; (void)hh; (void)pk;", "}", ""]
     else:
-        lines += ["    hv[0] = acc[0][0]; hv[1] = acc[1][0]; hv[2] = acc[2][0]; (void)e; (void)nanacc; (void)xv1; (void)xv2; (void)vt;", "}", ""]
+        lines += ["    hv[0] = acc[0][0]; hv[1] = acc[1][0]; hv[2] = acc[2][0]; (void)e; (void)nanacc; (void)xv1; (void)xv2; (void)vt; (void)hh; (void)pk;", "}", ""]
     return "\n".join(lines)
 
 
@@ -429,7 +471,7 @@ def render(seq, fn, hf_live, header):
 PRESETS = {
     "plain": ["--hf-live", "--xdist", "0,10,10,16", "--xdepth", "3"],
     "paired": ["--hf-live", "--xdist", "0,10,10,16", "--xdepth", "3", "--polls-at", "26", "--xdma-at", "42", "--spread", "2",
-               "--validate-at", "71", "--name", "ringstep3p_mfma", "--out",
+               "--validate-at", "71", "--publish", "--name", "ringstep3p_mfma", "--out",
                os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bonito_amd", "csrc", "ringstep3p_mfma.inc")],
 }
 
@@ -451,6 +493,7 @@ def main(argv=None):
     ap.add_argument("--polls-at", type=int, default=-1, help="issue the other ring's three poll DMAs behind this MFMA (0-based)")
     ap.add_argument("--xdma-at", type=int, default=-1, help="issue this ring's three x-stream DMAs behind this MFMA")
     ap.add_argument("--spread", type=int, default=0, help="MFMAs between two DMA instructions of the poll / x-stream groups")
+    ap.add_argument("--publish", action="store_true", help="LDS transpose of h_t and the section's three stores at the end of the stream")
     ap.add_argument("--validate-at", type=int, default=-1, help="read back my quarter of the other ring's h tile behind this MFMA; `bad` = sentinel found")
     ap.add_argument("--strip", default="", help="timing experiments only (wrong results): 'valu' drops the gate arithmetic, 'mfma' drops MFMAs + LDS reads")
     ap.add_argument("--hf-live", action="store_true", help="keep the twelve h fragments in registers instead of re-reading them per tile")
@@ -458,7 +501,7 @@ def main(argv=None):
     ap.add_argument("--out", default=os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bonito_amd", "csrc", "ringstep3_mfma.inc"))
     a = ap.parse_args(argv)
     xdist = tuple(int(v) for v in a.xdist.split(","))
-    seq = build(xdist, a.hdepth, a.xdepth, a.hpool, a.xpool, a.hf_live, a.lead, a.wgroup, a.nan_check, a.polls_at, a.xdma_at, a.validate_at, a.spread)
+    seq = build(xdist, a.hdepth, a.xdepth, a.hpool, a.xpool, a.hf_live, a.lead, a.wgroup, a.nan_check, a.polls_at, a.xdma_at, a.validate_at, a.spread, a.publish)
     if a.strip == "valu":
         seq = [x for x in seq if x.kind not in ("valu", "trans", "cmp", "sel")]
     elif a.strip == "mfma":
@@ -466,8 +509,8 @@ def main(argv=None):
     counts = {}
     for x in seq:
         counts[x.kind] = counts.get(x.kind, 0) + 1
-    header = "xdist=%s hdepth=%d xdepth=%d hpool=%d xpool=%d lead=%d wgroup=%d hf_live=%d nan_check=%d polls_at=%d xdma_at=%d validate_at=%d spread=%d : %s" % (
-        a.xdist, a.hdepth, a.xdepth, a.hpool, a.xpool, a.lead, a.wgroup, a.hf_live, a.nan_check, a.polls_at, a.xdma_at, a.validate_at, a.spread, " ".join("%s=%d" % kv for kv in sorted(counts.items())))
+    header = "xdist=%s hdepth=%d xdepth=%d hpool=%d xpool=%d lead=%d wgroup=%d hf_live=%d nan_check=%d polls_at=%d xdma_at=%d validate_at=%d spread=%d publish=%d : %s" % (
+        a.xdist, a.hdepth, a.xdepth, a.hpool, a.xpool, a.lead, a.wgroup, a.hf_live, a.nan_check, a.polls_at, a.xdma_at, a.validate_at, a.spread, a.publish, " ".join("%s=%d" % kv for kv in sorted(counts.items())))
     with open(a.out, "w") as fh:
         fh.write(render(seq, a.name, a.hf_live, header))
     print("wrote", a.out, header)

@@ -33,8 +33,8 @@ _lib.check(_lib.lib().bh_encoder_debug_read(enc._handle, st.ctypes.data_as(C.c_v
 st = st[:pairs].astype(float)                      # a workgroup reports under its first ring
 tot = st[..., 0]
 print("cycles per pair step (two ring steps): mean %.0f (min %.0f max %.0f) -> %.0f per ring step" % (tot.mean() / T, tot.min() / T, tot.max() / T, tot.mean() / T / 2))
-names = ["barrier", "the stream (MFMAs + gates + polls + x-stream DMA + validation of the other ring's quarter)", "re-poll rounds", "transpose + stores"]
-idx = [5, 10, 12, 11]
+names = ["barrier", "the stream (MFMAs + gates + polls + x-stream DMA + validation + LDS transpose + stores)", "re-poll rounds + bookkeeping"]
+idx = [5, 10, 12]
 for n, i in zip(names, idx):
     print("  %-84s %7.0f per ring step" % (n, st[..., i].mean() / T / 2))
 print("validations that needed a re-poll: %.2f %% of the ring steps" % (100 * st[..., 2].mean() / T / 2))
