@@ -734,6 +734,38 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_wg_kernel(LstmFusedArgs fp)
 //   * the layer output is a second, plain 8-byte store of the same values into [T][N][H] (next layer's input / the linear layer);
 //   * x_{t+2} is fetched with LDS-DMA (global_load_lds_dwordx4: lane l -> LDS base + 16 l, which is the B-fragment order) by the
 //     four waves in shares, straight into a three-slot LDS ring: no registers, no compiler-placed waits on the x stream.
+#include "cells3_mfma.inc"
+// The whole arithmetic of a ring step as one stream (round 3): recurrent MFMAs TILE-major, so that the gate arithmetic of a tile has
+// the next tile's recurrent MFMAs (and a share of the next step's input projection) to hide behind; generated by
+// tools/gen_ringstep.py, statement cuts audited on the compiled ISA by tools/audit_ringstep.py (tests/test_abi.py).
+__device__ __forceinline__ unsigned lds_addr(const char* p) { return (unsigned)(size_t)(__attribute__((address_space(3))) const char*)p; }
+#include "ringstep3_mfma.inc"
+// The same stream for the two-ring section of the fast path, carrying the section's vector-memory work as well (gen_ringstep.py
+// --polls-at --xdma-at --validate-at): the OTHER ring's three poll DMAs, this ring's three x-stream DMAs, and near the end the
+// read-back of my quarter of the other ring's h tile (`bad`: lanes that still found the exchange sentinel).
+#include "ringstep3p_mfma.inc"
+template <int NKS, int MT>
+__device__ __forceinline__ void ring_stream(float4_t (&xacc)[MT], float (&cst)[MT], float (&hv)[MT], const half8_t (&whh)[MT][NKS],
+                                            const half8_t (&wih)[MT][NKS], const float4_t (&bias)[MT], unsigned hb, unsigned xb) {
+    if constexpr (NKS == 12 && MT == 3) ringstep3_mfma(xacc, cst, hv, whh, wih, bias, hb, xb);      // the only generated width so far
+}
+template <int NKS, int MT, int KQ>
+__device__ __forceinline__ void ring_stream_paired(float4_t (&xacc)[MT], float (&cst)[MT], float (&hv)[MT], const half8_t (&whh)[MT][NKS],
+                                                   const half8_t (&wih)[MT][NKS], const float4_t (&bias)[MT], unsigned hb, unsigned xb,
+                                                   unsigned long long& bad, unsigned pm0, const char* exo, const unsigned (&vp)[KQ],
+                                                   unsigned xm0, const char* xsrc, unsigned vx, unsigned hbo, unsigned sga, unsigned rda,
+                                                   unsigned vmy, unsigned vh, const char* exs, const char* exa, const char* hrow, unsigned fast) {
+    if constexpr (NKS == 12 && MT == 3)
+        ringstep3p_mfma(xacc, cst, hv, whh, wih, bias, hb, xb, bad, pm0, exo, vp, xm0, xsrc, vx, hbo, sga, rda, vmy, vh, exs, exa, hrow, fast);
+}
+// The recurrent half alone (36 MFMAs tile-major + the gate arithmetic) for the single-ring kernel, whose input projection runs behind
+// the publish: gen_ringstep.py --preset rec
+#include "ringstep3r_mfma.inc"
+template <int NKS, int MT>
+__device__ __forceinline__ void ring_stream_rec(float4_t (&xacc)[MT], float (&cst)[MT], float (&hv)[MT], const half8_t (&whh)[MT][NKS],
+                                                const half8_t (&wih)[MT][NKS], const float4_t (&bias)[MT], unsigned hb) {
+    if constexpr (NKS == 12 && MT == 3) ringstep3r_mfma(xacc, cst, hv, whh, wih, bias, hb, 0u);
+}
 __device__ __forceinline__ void dma16_wgx(const char* g, char* lds) {
     const unsigned l = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)(__attribute__((address_space(3))) char*)lds);
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(l), "v"(g) : "memory");
@@ -744,6 +776,24 @@ struct LstmWgxArgs {
     char* ex;             // exchange ring buffer [4][R][NKS][64][16], armed with 0xFF
     int R;                // ring stride of `ex` (rings of the whole batch)
 };
+
+// Vector-memory operations of the H = 384 fast path with SCALAR addressing: a wave-uniform 64-bit base in an SGPR pair plus a 32-bit
+// per-lane byte offset that is loop-invariant (the compiler's per-lane 64-bit address arithmetic, the generic -> LDS pointer
+// conversions in front of every M0 write and the spilled scalars behind them were ~55 instructions for the three x-stream DMAs of a
+// ring step alone). IMM: immediate byte offset (13-bit signed) - keep it 0 for LDS-DMA: the hardware adds the instruction offset to
+// the LDS address as well as to the global one. The DMA lands at LDS address lds_a + lane * 16.
+template <int IMM, bool POLL>
+__device__ __forceinline__ void dma16_s(const char* sbase, unsigned voff, unsigned lds_a) {
+    if constexpr (POLL)
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 offset:%3 sc0 sc1" ::"s"(lds_a), "v"(voff), "s"(sbase), "i"(IMM) : "memory");
+    else
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 offset:%3" ::"s"(lds_a), "v"(voff), "s"(sbase), "i"(IMM) : "memory");
+}
+template <bool SC1>
+__device__ __forceinline__ void store8_s(const char* sbase, unsigned voff, unsigned long long v) {
+    if constexpr (SC1) asm volatile("global_store_dwordx2 %0, %1, %2 sc1" ::"v"(voff), "v"(v), "s"(sbase) : "memory");
+    else asm volatile("global_store_dwordx2 %0, %1, %2" ::"v"(voff), "v"(v), "s"(sbase) : "memory");
+}
 
 template <int NKS, int MT>
 __global__ __launch_bounds__(256, 1) void lstm_layer_wgx_kernel(LstmWgxArgs wp) {
@@ -823,12 +873,26 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_wgx_kernel(LstmWgxArgs wp) 
         }
         mfma_settle_v<MT>(xacc);
     };
-    // x stream: the polls of the exchange go to k-steps w, w+4, ..; the DMA shares are 3-w, 7-w, .. (balanced over the waves)
+    // x stream: the polls of the exchange go to k-steps w, w+4, ..; the DMA shares are 3-w, 7-w, .. (balanced over the waves).
+    // H = 384: scalar-addressed (a wave-uniform row base + a loop-invariant 32-bit per-lane offset, LDS addresses as integers) - the
+    // per-lane 64-bit address arithmetic and the generic -> LDS pointer conversions were ~18 instructions per DMA
+    const unsigned smem_a = lds_addr(smem);
+    const unsigned vx_off = (unsigned)(((ring * 16 + c) * H + q * 8) * 2 + (3 - wave) * 64);
+    const unsigned vh_off = (unsigned)(((ring * 16 + cc) * H + slice * U + part * 4) * 2);
+    const long row_bytes = x_row * 2;
     auto x_dma = [&](int tt, int slot) {
+        if constexpr (NKS == 12 && MT == 3) {
+            const char* src = (const char*)fp.x + (long)tt * row_bytes;
+            const unsigned m0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(smem_a + (2 + slot) * TILE + (3 - wave) * 1024));
+            dma16_s<0, false>(src, vx_off, m0);
+            dma16_s<0, false>(src + 256, vx_off, m0 + 4096);
+            dma16_s<0, false>(src + 512, vx_off, m0 + 8192);
+        } else {
 #pragma unroll
-        for (int kk = 0; kk < KQ; ++kk) {
-            const int ks = (3 - wave) + 4 * kk;
-            if (EXACT || ks < NKS) dma16_wgx((const char*)(xptr + (long)tt * x_row + ks * 32), xbuf + (slot * NKS + ks) * 1024);
+            for (int kk = 0; kk < KQ; ++kk) {
+                const int ks = (3 - wave) + 4 * kk;
+                if (EXACT || ks < NKS) dma16_wgx((const char*)(xptr + (long)tt * x_row + ks * 32), xbuf + (slot * NKS + ks) * 1024);
+            }
         }
     };
 
@@ -886,14 +950,17 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_wgx_kernel(LstmWgxArgs wp) 
                     }
                 ++rounds;
             }
+            if (p.tune & 4) {
+                st_poll += __builtin_readcyclecounter() - pc0; st_rounds += rounds; st_first_ok += (rounds == 1);
+                st_hist += 1ll << (16 * (rounds > 3 ? 3 : rounds - 1));
+            }
+        }
+        constexpr bool STREAM = NKS == 12 && MT == 3;      // H = 384: the recurrent MFMAs and the gate arithmetic are one generated stream
+        if (step > 0 || STREAM) {                          // (step 0 of the stream multiplies a zero tile: hq starts as zeros)
 #pragma unroll
             for (int kk = 0; kk < KQ; ++kk) {
                 const int ks = wave + 4 * kk;
                 if (EXACT || ks < NKS) *(uint4_t*)(hbuf + (par * NKS + ks) * 1024 + lo) = hq[kk];
-            }
-            if (p.tune & 4) {
-                st_poll += __builtin_readcyclecounter() - pc0; st_rounds += rounds; st_first_ok += (rounds == 1);
-                st_hist += 1ll << (16 * (rounds > 3 ? 3 : rounds - 1));
             }
         }
         // ---- D. publish h_{t-1} and x_{t+1} (DMA issued a step ago) to the workgroup; the vmcnt(0) covers this wave's DMA share
@@ -902,24 +969,36 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_wgx_kernel(LstmWgxArgs wp) 
         __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0): the builtin (unlike inline asm) also clears the compiler's own scoreboard
         __syncthreads();
         const long long pc2 = (p.tune & 4) ? __builtin_readcyclecounter() : 0;
-        // ---- E. recurrent part ------------------------------------------------------------------------------------------
-        if (step > 0) {
-            const char* hb = hbuf + par * TILE + lo;
-            half8_t hb_f[NKS];
-#pragma unroll
-            for (int ks = 0; ks < NKS; ++ks) hb_f[ks] = *(const half8_t*)(hb + ks * 1024);
-#pragma unroll
-            for (int ks = 0; ks < NKS; ++ks)
-#pragma unroll
-                for (int m = 0; m < MT; ++m) mfma16_av(whh[m][ks], hb_f[ks], acc[m]);
-            mfma_settle_v<MT>(acc);
-        }
-        const long long pcm = (p.tune & 4) ? __builtin_readcyclecounter() : 0;
-        // ---- X. request x_{t+2} into the LDS slot x_{t-1} was consumed from; needed behind the NEXT barrier ----------------
-        if (step + 2 < p.T) x_dma(t + 2 * dt, (step + 2) % 3);
         half_t ho[MT];
+        long long pcm = 0;
+        if constexpr (STREAM) {
+            // ---- X / E. x_{t+2} requested first, then the recurrent MFMAs tile by tile with the gate arithmetic of tile m behind the
+            //      MFMAs of tile m + 1 (ringstep3r_mfma, round 3: the bare MFMA phase + the bare gate phase were 1.5 k cycles) ---------
+            if (step + 2 < p.T) x_dma(t + 2 * dt, (step + 2) % 3);
+            float hv[MT];
+            ring_stream_rec<NKS, MT>(acc, cst, hv, whh, wih, bias4, lds_addr(hbuf + par * TILE + lo));
 #pragma unroll
-        for (int m = 0; m < MT; ++m) ho[m] = (half_t)lstm_cell(acc[m][0], acc[m][1], acc[m][2], acc[m][3], cst[m]);
+            for (int m = 0; m < MT; ++m) ho[m] = (half_t)hv[m];
+            pcm = (p.tune & 4) ? __builtin_readcyclecounter() : 0;
+        } else {
+            // ---- E. recurrent part ------------------------------------------------------------------------------------------
+            if (step > 0) {
+                const char* hb = hbuf + par * TILE + lo;
+                half8_t hb_f[NKS];
+#pragma unroll
+                for (int ks = 0; ks < NKS; ++ks) hb_f[ks] = *(const half8_t*)(hb + ks * 1024);
+#pragma unroll
+                for (int ks = 0; ks < NKS; ++ks)
+#pragma unroll
+                    for (int m = 0; m < MT; ++m) mfma16_av(whh[m][ks], hb_f[ks], acc[m]);
+                mfma_settle_v<MT>(acc);
+            }
+            pcm = (p.tune & 4) ? __builtin_readcyclecounter() : 0;
+            // ---- X. request x_{t+2} into the LDS slot x_{t-1} was consumed from; needed behind the NEXT barrier ----------------
+            if (step + 2 < p.T) x_dma(t + 2 * dt, (step + 2) % 3);
+#pragma unroll
+            for (int m = 0; m < MT; ++m) ho[m] = (half_t)lstm_cell(acc[m][0], acc[m][1], acc[m][2], acc[m][3], cst[m]);
+        }
         const long long pcg = (p.tune & 4) ? __builtin_readcyclecounter() : 0;
         {
             u16_alias_t* sg = (u16_alias_t*)stage + c * U + q * MT;
@@ -927,6 +1006,15 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_wgx_kernel(LstmWgxArgs wp) 
             for (int m = 0; m < MT; ++m) sg[m] = __builtin_bit_cast(unsigned short, ho[m]);
             if (mover) {
                 const unsigned long long packed = *(const u64_alias_t*)((half_t*)stage + cc * U + part * 4);
+                if constexpr (STREAM) {                    // scalar-addressed stores (uniform slot base + my byte offset)
+                    const char* exs = exr + (long)(step & 3) * slot_stride;
+                    if (fast) store8_s<false>(exs, (unsigned)my_byte, packed); else store8_s<true>(exs, (unsigned)my_byte, packed);
+                    if (step >= 2 && step + 2 < p.T) {     // re-arm my bytes of slot (step+2)&3 (it holds h_{t-2}; see the header)
+                        const char* exa = exr + (long)((step + 2) & 3) * slot_stride;
+                        if (fast) store8_s<false>(exa, (unsigned)my_byte, ~0ull); else store8_s<true>(exa, (unsigned)my_byte, ~0ull);
+                    }
+                    store8_s<false>((const char*)p.h + (long)t * row_bytes, vh_off, packed);
+                } else {
                 unsigned long long* dst = (unsigned long long*)(exr + (long)(step & 3) * slot_stride + my_byte);
                 if (fast) *dst = packed;
                 else __hip_atomic_store(dst, packed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -938,6 +1026,7 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_wgx_kernel(LstmWgxArgs wp) 
                 }
                 // the layer output proper (next layer's x rows / the linear layer's input)
                 *(unsigned long long*)(p.h + ((long)t * p.N + ring * 16 + cc) * H + slice * U + part * 4) = packed;
+                }
             }
         }
         // ---- F. first poll round for h_t ----------------------------------------------------------------------------------
@@ -1010,48 +1099,6 @@ __device__ __forceinline__ void wait_vm(int n) {       // s_waitcnt vmcnt(n), n 
 // builtin ones (measured; sched_group_barrier included). The three units' dependency chains are interleaved round-robin so that no
 // instruction waits for a transcendental. Generated by tools/gen_cells3.py (named asm operands, five blocks of at most
 // 30 distinct operands); the arithmetic is lstm_cell()'s operation for operation: the same bits (tested against the single-ring kernel).
-#include "cells3_mfma.inc"
-// The whole arithmetic of a ring step as one stream (round 3): recurrent MFMAs TILE-major, so that the gate arithmetic of a tile has
-// the next tile's recurrent MFMAs (and a share of the next step's input projection) to hide behind; generated by
-// tools/gen_ringstep.py, statement cuts audited on the compiled ISA by tools/audit_ringstep.py (tests/test_abi.py).
-__device__ __forceinline__ unsigned lds_addr(const char* p) { return (unsigned)(size_t)(__attribute__((address_space(3))) const char*)p; }
-#include "ringstep3_mfma.inc"
-// The same stream for the two-ring section of the fast path, carrying the section's vector-memory work as well (gen_ringstep.py
-// --polls-at --xdma-at --validate-at): the OTHER ring's three poll DMAs, this ring's three x-stream DMAs, and near the end the
-// read-back of my quarter of the other ring's h tile (`bad`: lanes that still found the exchange sentinel).
-#include "ringstep3p_mfma.inc"
-template <int NKS, int MT>
-__device__ __forceinline__ void ring_stream(float4_t (&xacc)[MT], float (&cst)[MT], float (&hv)[MT], const half8_t (&whh)[MT][NKS],
-                                            const half8_t (&wih)[MT][NKS], const float4_t (&bias)[MT], unsigned hb, unsigned xb) {
-    if constexpr (NKS == 12 && MT == 3) ringstep3_mfma(xacc, cst, hv, whh, wih, bias, hb, xb);      // the only generated width so far
-}
-template <int NKS, int MT, int KQ>
-__device__ __forceinline__ void ring_stream_paired(float4_t (&xacc)[MT], float (&cst)[MT], float (&hv)[MT], const half8_t (&whh)[MT][NKS],
-                                                   const half8_t (&wih)[MT][NKS], const float4_t (&bias)[MT], unsigned hb, unsigned xb,
-                                                   unsigned long long& bad, unsigned pm0, const char* exo, const unsigned (&vp)[KQ],
-                                                   unsigned xm0, const char* xsrc, unsigned vx, unsigned hbo, unsigned sga, unsigned rda,
-                                                   unsigned vmy, unsigned vh, const char* exs, const char* exa, const char* hrow, unsigned fast) {
-    if constexpr (NKS == 12 && MT == 3)
-        ringstep3p_mfma(xacc, cst, hv, whh, wih, bias, hb, xb, bad, pm0, exo, vp, xm0, xsrc, vx, hbo, sga, rda, vmy, vh, exs, exa, hrow, fast);
-}
-// Vector-memory operations of the H = 384 fast path with SCALAR addressing: a wave-uniform 64-bit base in an SGPR pair plus a 32-bit
-// per-lane byte offset that is loop-invariant (the compiler's per-lane 64-bit address arithmetic, the generic -> LDS pointer
-// conversions in front of every M0 write and the spilled scalars behind them were ~55 instructions for the three x-stream DMAs of a
-// ring step alone). IMM: immediate byte offset (13-bit signed) - keep it 0 for LDS-DMA: the hardware adds the instruction offset to
-// the LDS address as well as to the global one. The DMA lands at LDS address lds_a + lane * 16.
-template <int IMM, bool POLL>
-__device__ __forceinline__ void dma16_s(const char* sbase, unsigned voff, unsigned lds_a) {
-    if constexpr (POLL)
-        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 offset:%3 sc0 sc1" ::"s"(lds_a), "v"(voff), "s"(sbase), "i"(IMM) : "memory");
-    else
-        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 offset:%3" ::"s"(lds_a), "v"(voff), "s"(sbase), "i"(IMM) : "memory");
-}
-template <bool SC1>
-__device__ __forceinline__ void store8_s(const char* sbase, unsigned voff, unsigned long long v) {
-    if constexpr (SC1) asm volatile("global_store_dwordx2 %0, %1, %2 sc1" ::"v"(voff), "v"(v), "s"(sbase) : "memory");
-    else asm volatile("global_store_dwordx2 %0, %1, %2" ::"v"(voff), "v"(v), "s"(sbase) : "memory");
-}
-
 template <int NKS, int MT, bool STATS = false>
 __global__ __launch_bounds__(256, 1) void lstm_layer_wgx2_kernel(LstmWgxArgs wp) {
     extern __shared__ __attribute__((aligned(16))) char smem[];

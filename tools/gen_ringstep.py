@@ -30,7 +30,7 @@ Hazards placed here (the compiler pads nothing inside an asm statement):
   * transcendental result -> consumer: at least one instruction in between (gfx940+ trans forwarding hazard);
   * v_cmp (vcc) -> v_cndmask: at least one instruction in between.
 
-usage: gen_ringstep.py --preset plain|paired        (the two includes of the library)
+usage: gen_ringstep.py --preset plain|paired|rec    (the three includes of the library)
        gen_ringstep.py [--xdist a,b,c,d] [--hdepth n] [--xdepth n] [--hf-live] [--polls-at n --xdma-at n --validate-at n --spread n]
                        [--name fn] [--out path]         (experiments: tools/stream_bench.py, tools/gpu_variants.sh)
 """
@@ -158,7 +158,9 @@ VBASE = 220          # v[VBASE .. VBASE+11]: the three fragments of the other ri
 
 
 def build(xdist, hdepth, xdepth, hpool, xpool, hf_live, lead, wgroup=1, nan_check=False, polls_at=-1, xdma_at=-1, validate_at=-1, spread=0, publish=False):
-    assert sum(xdist) == 3 * NKS and len(xdist) == 4
+    # xdist all zero: the recurrent half alone (single-ring kernel: the input projection of the next step runs BEHIND the publish there,
+    # it is what fills the hand-off's round trip)
+    assert (sum(xdist) == 3 * NKS or sum(xdist) == 0) and len(xdist) == 4
     xs = [(ks, m) for ks in range(NKS) for m in range(3)]
     xi = 0
     spine_by_phase = []
@@ -241,7 +243,7 @@ def build(xdist, hdepth, xdepth, hpool, xpool, hf_live, lead, wgroup=1, nan_chec
     # the first input-projection MFMA of a tile overwrites xacc[m]: the recurrent MFMA that reads it must have issued
     pos = {x.meta["tag"]: i for i, x in enumerate(seq) if x.kind == "mfma"}
     for m in range(3):
-        assert pos[("R", m, 0)] < pos[("X", m, 0)]
+        assert ("X", m, 0) not in pos or pos[("R", m, 0)] < pos[("X", m, 0)]
 
     # ---- vector-memory work of the section issued from inside the stream, behind given MFMAs -------------------------------------------
     def after_mfma(seq, at, extra):
@@ -470,6 +472,8 @@ def render(seq, fn, hf_live, header):
 # sweeps of round 3 (tools/stream_bench.py for the arithmetic, tools/gpu_variants.sh + tools/lstm_stats2.py for the in-stream DMA)
 PRESETS = {
     "plain": ["--hf-live", "--xdist", "0,10,10,16", "--xdepth", "3"],
+    "rec": ["--hf-live", "--xdist", "0,0,0,0", "--name", "ringstep3r_mfma", "--out",
+            os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bonito_amd", "csrc", "ringstep3r_mfma.inc")],
     "paired": ["--hf-live", "--xdist", "0,10,10,16", "--xdepth", "3", "--polls-at", "26", "--xdma-at", "42", "--spread", "2",
                "--validate-at", "71", "--publish", "--name", "ringstep3p_mfma", "--out",
                os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bonito_amd", "csrc", "ringstep3p_mfma.inc")],
