@@ -24,6 +24,8 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-u
 # lstm_q8.hip: the pre-activation of the 8-bit recurrent path is DEFINED operation by operation (oracle/lstm_q8_ref.py); with
 # contraction on, the compiler fused different multiply-add pairs in different template instances
 EXTRA_FLAGS = {"signal.hip": ["-ffp-contract=off"], "lstm_q8.hip": ["-ffp-contract=off"]}
+if os.environ.get("BH_EXTRA_LSTM_FLAGS"):          # timing experiments only (e.g. -DBH_EXPT_SHARE: wrong results on purpose)
+    EXTRA_FLAGS["lstm.hip"] = os.environ["BH_EXTRA_LSTM_FLAGS"].split()
 
 
 def _newer(dst, srcs):

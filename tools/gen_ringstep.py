@@ -60,6 +60,7 @@ def nop(n):
     return Ins("nop", "s_nop %d" % n, n=n)
 
 
+ALL_AGPR = False     # timing experiments: every weight operand in the accumulator half
 PBASE = 232          # v[PBASE .. PBASE+11]: the three recurrent accumulator tuples (physical registers, see the module docstring)
 
 
@@ -368,7 +369,7 @@ def operand(name):
         return "a", "whh[%s][%s]" % (m, ks)
     if name.startswith("wi"):
         m, ks = name[2:].split("_")
-        return ("a" if int(m) < 2 else "v"), "wih[%s][%s]" % (m, ks)
+        return ("a" if int(m) < 2 or ALL_AGPR else "v"), "wih[%s][%s]" % (m, ks)
     if name.startswith("xa"):
         return "v", "xacc[%s]" % name[2:]
     if name.startswith("bi"):
@@ -472,7 +473,9 @@ def render(seq, fn, hf_live, header):
 # sweeps of round 3 (tools/stream_bench.py for the arithmetic, tools/gpu_variants.sh + tools/lstm_stats2.py for the in-stream DMA)
 PRESETS = {
     "plain": ["--hf-live", "--xdist", "0,10,10,16", "--xdepth", "3"],
-    "rec": ["--hf-live", "--xdist", "0,0,0,0", "--name", "ringstep3r_mfma", "--out",
+    # (--pbase: the single-ring kernel otherwise needs ~190 VGPRs; with the accumulators at v[232..] its 244 + 240 registers left no room
+    #  for a decode wave beside it, and the one-batch-per-call pipeline lost the overlap it lives on: 18.0 -> 19.4 ms per batch)
+    "rec": ["--hf-live", "--xdist", "0,0,0,0", "--pbase", "144", "--name", "ringstep3r_mfma", "--out",
             os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bonito_amd", "csrc", "ringstep3r_mfma.inc")],
     "paired": ["--hf-live", "--xdist", "0,10,10,16", "--xdepth", "3", "--polls-at", "26", "--xdma-at", "42", "--spread", "2",
                "--validate-at", "71", "--publish", "--name", "ringstep3p_mfma", "--out",
@@ -499,11 +502,16 @@ def main(argv=None):
     ap.add_argument("--spread", type=int, default=0, help="MFMAs between two DMA instructions of the poll / x-stream groups")
     ap.add_argument("--publish", action="store_true", help="LDS transpose of h_t and the section's three stores at the end of the stream")
     ap.add_argument("--validate-at", type=int, default=-1, help="read back my quarter of the other ring's h tile behind this MFMA; `bad` = sentinel found")
+    ap.add_argument("--pbase", type=int, default=232, help="first of the twelve physical accumulator registers (the kernel's VGPR count is at least this + 12)")
+    ap.add_argument("--vbase", type=int, default=220, help="first of the twelve physical registers of the validation read-back")
+    ap.add_argument("--all-agpr", action="store_true", help="timing experiments: W_ih tile 2 as AGPR operands too")
     ap.add_argument("--strip", default="", help="timing experiments only (wrong results): 'valu' drops the gate arithmetic, 'mfma' drops MFMAs + LDS reads")
     ap.add_argument("--hf-live", action="store_true", help="keep the twelve h fragments in registers instead of re-reading them per tile")
     ap.add_argument("--name", default="ringstep3_mfma")
     ap.add_argument("--out", default=os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bonito_amd", "csrc", "ringstep3_mfma.inc"))
     a = ap.parse_args(argv)
+    global PBASE, VBASE, ALL_AGPR
+    PBASE, VBASE, ALL_AGPR = a.pbase, a.vbase, a.all_agpr
     xdist = tuple(int(v) for v in a.xdist.split(","))
     seq = build(xdist, a.hdepth, a.xdepth, a.hpool, a.xpool, a.hf_live, a.lead, a.wgroup, a.nan_check, a.polls_at, a.xdma_at, a.validate_at, a.spread, a.publish)
     if a.strip == "valu":
