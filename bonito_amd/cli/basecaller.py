@@ -48,15 +48,22 @@ def launch(args, argv):
         sock.bind(("127.0.0.1", 0))
         port = sock.getsockname()[1]
     child_argv, skip = [], False
-    for tok in argv:                       # the workers get the same command line minus --devices
+    for tok in argv:                       # the workers get the same command line minus --devices / --device (each sees ONE device)
         if skip:
             skip = False
-        elif tok == "--devices":
+        elif tok in ("--devices", "--device"):
             skip = True
-        elif not tok.startswith("--devices="):
+        elif not tok.startswith(("--devices=", "--device=")):
             child_argv.append(tok)
+    # indices are relative to what THIS process may see: honour a HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES mask of the parent
+    parent_mask = os.environ.get("HIP_VISIBLE_DEVICES") or os.environ.get("ROCR_VISIBLE_DEVICES")
+    visible = [d.strip() for d in parent_mask.split(",") if d.strip()] if parent_mask else None
     procs = []
     for rank, dev in enumerate(devices):
+        if visible is not None:
+            if dev >= len(visible):
+                raise SystemExit("> error: --devices names device %d but only %d are visible (%s)" % (dev, len(visible), parent_mask))
+            dev = visible[dev]
         env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(len(devices)), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), HIP_VISIBLE_DEVICES=str(dev), BONITO_AMD_SPAWNED="1")
         env.pop("CUDA_VISIBLE_DEVICES", None)
