@@ -399,6 +399,27 @@ def test_batches_per_engine_call_do_not_change_the_calls():
     assert "wgx2" in model._hip.describe()
 
 
+@pytest.mark.parametrize("mode,kw", [("fastq", {}), ("sam", {"rna": True}), ("fasta", {"reverse": True})])
+def test_records_path_equals_basecall_plus_format_record(mode, kw):
+    """The writers' path of the CLI (`basecall_records`: one library call per read behind the decoder) against the reference-shaped
+    API (`basecall` -> `io.format_record`) on the same reads through the same engine: identical record text, summary rows and log."""
+    import importlib
+    from bonito_amd import io as bio, synthetic
+    bc = importlib.import_module("bonito_amd.crf.basecall")
+    model = synthetic.make_model("hac", batchsize=64, chunksize=2400)
+    model.use_koi(batchsize=64, chunksize=2400, quantize=False)
+    model = model.half().to("cuda")
+    rng = np.random.default_rng(9)
+    reads = _reads(rng, [700, 2400, 2401, 5000, 9000, 30000, 2399, 12345])
+    for r in reads:
+        r.run_id, r.filename, r.channel, r.mux, r.start, r.duration = "runA", "x.npy", 1, 1, 0.0, 1.0
+        r.template_start, r.template_duration, r.num_samples, r.trimmed_samples = 0.0, 1.0, len(r.signal) + 5, 5
+    want = [bio.format_record(r, res, mode, 0.0)
+            for r, res in crf_basecall_fn(model, iter(reads), chunksize=2400, overlap=240, batchsize=64, **kw)]
+    got = list(bc.basecall_records(model, iter(reads), mode, chunksize=2400, overlap=240, batchsize=64, min_qscore=0.0, **kw))
+    assert got == want and len(got) == len(reads) and any(t is not None for t, _, _ in got)
+
+
 def test_concurrent_engines_never_yield_wrong_calls():
     """Three engine replicas of a model whose recurrent kernel needs all of its workgroups co-resident (hac, 512-chunk batches
     = 256 workgroups each), driven concurrently from three streams next to decode work, with a low spin bound: whenever the
