@@ -734,7 +734,8 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_wg_kernel(LstmFusedArgs fp)
 //   * the layer output is a second, plain 8-byte store of the same values into [T][N][H] (next layer's input / the linear layer);
 //   * x_{t+2} is fetched with LDS-DMA (global_load_lds_dwordx4: lane l -> LDS base + 16 l, which is the B-fragment order) by the
 //     four waves in shares, straight into a three-slot LDS ring: no registers, no compiler-placed waits on the x stream.
-#include "cells3_mfma.inc"
+// (round 2's cells3_mfma.inc - the gate arithmetic woven into the input-projection MFMAs only - is no longer part of the library; it is
+// the baseline variant of tools/stream_bench.hip)
 // The whole arithmetic of a ring step as one stream (round 3): recurrent MFMAs TILE-major, so that the gate arithmetic of a tile has
 // the next tile's recurrent MFMAs (and a share of the next step's input projection) to hide behind; generated by
 // tools/gen_ringstep.py, statement cuts audited on the compiled ISA by tools/audit_ringstep.py (tests/test_abi.py).
@@ -1093,12 +1094,6 @@ __device__ __forceinline__ void wait_vm(int n) {       // s_waitcnt vmcnt(n), n 
     asm volatile("" ::: "memory");
 }
 
-// lstm_cell() of the three units of a lane with the 36 MFMAs of the NEXT step's input projection threaded through it (H = 384), one MFMA
-// to about three vector instructions: a wave issues in order, so the vector ALU only works in the shadow of the matrix core if the
-// two kinds of instruction alternate in the instruction stream - which the compiler does neither for inline-asm MFMAs nor for
-// builtin ones (measured; sched_group_barrier included). The three units' dependency chains are interleaved round-robin so that no
-// instruction waits for a transcendental. Generated by tools/gen_cells3.py (named asm operands, five blocks of at most
-// 30 distinct operands); the arithmetic is lstm_cell()'s operation for operation: the same bits (tested against the single-ring kernel).
 template <int NKS, int MT, bool STATS = false>
 __global__ __launch_bounds__(256, 1) void lstm_layer_wgx2_kernel(LstmWgxArgs wp) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
