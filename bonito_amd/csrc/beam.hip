@@ -63,27 +63,36 @@ struct ScanArgs {
                            // recurrent kernels' exchange buffers when the decoder runs beside the next batch's encoder)
     int ckpt;              // backward scan: write only the guide rows t % ckpt == 0 (and t == T); 0 = every row. The fused
                            // beam kernel recomputes the rows in between from the staged scores (beam_kernel, CKPT)
+    int cpb;               // backward scan: chunks per workgroup (backward_geometry)
 };
 
 constexpr int SU = 4;  // score prefetch depth
 
 __global__ void crf_backward_kernel(ScanArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* tab = (float*)smem;                 // BH_LSE_TABLE_SIZE
-    float* buf = tab + BH_LSE_TABLE_SIZE + 2;  // [2][S]
-    half_t* rows = (half_t*)(buf + 2 * p.S);   // [2][4S] score rows, double buffered
+    // Several chunks per workgroup (`p.cpb`, threads = cpb * max(S, 64)) share the 16 KiB lse table: at 256 states a chunk then takes
+    // 16.4 / 2 + 6 = 14 KiB of LDS instead of 22.5, eight chunks fit a CU instead of six (the 32-wave limit), and the 2048 chunks of a
+    // bench call run in ONE round on 256 CUs instead of a full one and a third-full one. The chunks of a workgroup run the same number
+    // of steps, so they share the per-step barrier.
     const int S = p.S, T = p.T;
-    const int n = blockIdx.x, s = threadIdx.x;
-    const bool active = s < S;
+    const int tpc = S < 64 ? 64 : S;           // threads per chunk
+    const int slot = threadIdx.x / tpc, s = threadIdx.x - slot * tpc;
+    const int n = blockIdx.x * p.cpb + slot;
+    float* tab = (float*)smem;                 // BH_LSE_TABLE_SIZE
+    float* buf = (float*)(smem + ((BH_LSE_TABLE_SIZE * 4 + 15) & ~15) + (size_t)slot * 24 * S);   // [2][S], 16-byte aligned (vector reads below)
+    half_t* rows = (half_t*)(buf + 2 * S);     // [2][4S] score rows, double buffered
+    const bool active = s < S && n < p.N;
     for (int i = threadIdx.x; i < BH_LSE_TABLE_SIZE; i += blockDim.x) tab[i] = g_lse_tab[i];
     if (active) buf[s] = 0.0f;
     const int lead = s >> (2 * (p.state_len - 1));
+    const bool vec = S >= 16;                  // (S = 4: a row is 16 halves in all, the scalar gathers stay)
     const int sm = (s & ((S >> 2) - 1));       // successors of s are the states sm*4 + x
-    const half_t* sc = p.scores + (long)n * T * 4 * S + s * 4;   // this thread stages halves [4s, 4s+4) of a row
-    float* bn = p.beta + (long)n * (T + 1) * S;
-    double* Bn = p.Bcum + (long)n * (T + 1);
+    const int nn = n < p.N ? n : p.N - 1;      // (a slot beyond the batch only keeps the barriers company)
+    const half_t* sc = p.scores + (long)nn * T * 4 * S + s * 4;   // this thread stages halves [4s, 4s+4) of a row
+    float* bn = p.beta + (long)nn * (T + 1) * S;
+    double* Bn = p.Bcum + (long)nn * (T + 1);
     if (active) bn[(long)T * S + s] = 0.0f;
-    if (s == 0) Bn[T] = 0.0;
+    if (s == 0 && n < p.N) Bn[T] = 0.0;
 
     // register prefetch ring: pre[u] holds this thread's 8 bytes of row (thi - 1 - u)
     half4_t cur[SU], nxt[SU];
@@ -112,10 +121,30 @@ __global__ void crf_backward_kernel(ScanArgs p) {
                 const float ref = prev[0];
                 if (active) {
                     float acc = p.blank + (prev[s] - ref);
+                    if (vec) {
+                        // The four successors of state s are the states sm*4 .. sm*4+3: their guide values are 16 contiguous bytes
+                        // and their 16 transition scores 32 contiguous bytes of the row. Read as vectors and pick half `lead` of
+                        // each group of four in registers - the per-element gathers (prev[sm*4+x]: stride 16 bytes across lanes,
+                        // row[(sm*4+x)*4+lead]: 2-byte reads at stride 32 bytes) were 4- and 8-way bank conflicts: the kernel spent
+                        // 89 % of its CU cycles in LDS conflict cycles (SQ_LDS_BANK_CONFLICT, profiles/r03a_sq_counters.txt).
+                        // Same values, same order of operations: the same bits.
+                        const float4_t pv = *(const float4_t*)(prev + sm * 4);
+                        const uint4_t r0 = *(const uint4_t*)(row + sm * 16), r1 = *(const uint4_t*)(row + sm * 16 + 8);
+                        const bool hi = (lead & 2) != 0;
+                        const unsigned sh16 = (lead & 1) * 16;
+                        const unsigned w[4] = {hi ? r0.y : r0.x, hi ? r0.w : r0.z, hi ? r1.y : r1.x, hi ? r1.w : r1.z};
+                        const float pvx[4] = {pv.x, pv.y, pv.z, pv.w};
 #pragma unroll
-                    for (int x = 0; x < 4; ++x) {
-                        const int s2 = sm * 4 + x;
-                        acc = lse2_tab(acc, (float)row[s2 * 4 + lead] + (prev[s2] - ref), tab);
+                        for (int x = 0; x < 4; ++x) {
+                            const half_t m = __builtin_bit_cast(half_t, (unsigned short)(w[x] >> sh16));
+                            acc = lse2_tab(acc, (float)m + (pvx[x] - ref), tab);
+                        }
+                    } else {
+#pragma unroll
+                        for (int x = 0; x < 4; ++x) {
+                            const int s2 = sm * 4 + x;
+                            acc = lse2_tab(acc, (float)row[s2 * 4 + lead] + (prev[s2] - ref), tab);
+                        }
                     }
                     buf[(cb ^ 1) * S + s] = acc;
                     // stage the next (earlier) row for the following step
@@ -124,7 +153,7 @@ __global__ void crf_backward_kernel(ScanArgs p) {
                         *(half4_t*)(rows + ((t - 1) & 1) * 4 * S + s * 4) = v;
                     }
                 }
-                if (s == 0) { cum += (double)ref; Bn[t] = cum; }
+                if (s == 0 && n < p.N) { cum += (double)ref; Bn[t] = cum; }
                 cb ^= 1;
                 __syncthreads();
                 if (active) {
@@ -140,13 +169,22 @@ __global__ void crf_backward_kernel(ScanArgs p) {
         for (int u = 0; u < SU; ++u) cur[u] = nxt[u];
     }
     // logZ = B_0 + raw_0[0] + LSE_s beta~_0[s]   (alpha_0 = 0); once per chunk, serial in double
-    if (s == 0) {
+    if (s == 0 && n < p.N) {
         const float* now = buf + cb * S;
         double m = -INFINITY, sum = 0.0;
         for (int i = 0; i < S; ++i) m = fmax(m, (double)(now[i] - now[0]));
         for (int i = 0; i < S; ++i) sum += exp((double)(now[i] - now[0]) - m);
         p.logZ[n] = cum + (double)now[0] + m + log(sum);
     }
+}
+
+// chunks per workgroup / threads / LDS bytes of crf_backward_kernel for S states
+static void backward_geometry(int S, int N, int& cpb, int& threads, size_t& lds) {
+    const int tpc = S < 64 ? 64 : S;
+    cpb = tpc >= 1024 ? 1 : tpc >= 256 ? 2 : 4;          // workgroups of at most 512 threads (1024 at 1024 states)
+    if (cpb > N) cpb = N;
+    threads = cpb * tpc;
+    lds = (size_t)((BH_LSE_TABLE_SIZE * 4 + 15) & ~15) + (size_t)cpb * 24 * S + 64;
 }
 
 // PB: prefetch the guide offsets B_t with the scores (8 more registers per SU; at 1024 threads per workgroup that crosses the
@@ -1188,10 +1226,17 @@ int bh_k_crf_logz(const void* scores, int N, int T, int state_len, float blank, 
     char* w = (char*)workspace;
     float* beta = (float*)w;   w += align((size_t)N * (T + 1) * S * sizeof(float));
     double* Bcum = (double*)w;
-    ScanArgs sa{(const half_t*)scores, N, T, S, state_len, blank, beta, Bcum, logz_out, nullptr, g_decode_nt, 0};
+    ScanArgs sa{(const half_t*)scores, N, T, S, state_len, blank, beta, Bcum, logz_out, nullptr, g_decode_nt, 0, 1};
     const int threads = S < 64 ? 64 : S;
     const size_t lds_scan = (size_t)(BH_LSE_TABLE_SIZE + 2 + 2 * S + 2 * 16 * 16 + 8) * sizeof(float) + (size_t)2 * 4 * S * 2;
-    hipLaunchKernelGGL(crf_backward_kernel, dim3(N), dim3(threads), lds_scan, stream, sa);
+    {
+        int b_threads = 0;
+        size_t b_lds = 0;
+        backward_geometry(S, N, sa.cpb, b_threads, b_lds);
+        if (b_lds > 64 * 1024) BH_CHECK_HIP(hipFuncSetAttribute((const void*)crf_backward_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b_lds));
+        hipLaunchKernelGGL(crf_backward_kernel, dim3((N + sa.cpb - 1) / sa.cpb), dim3(b_threads), b_lds, stream, sa);
+        sa.cpb = 1;
+    }
     BH_CHECK_HIP(hipGetLastError());
     return 0;
 }
@@ -1214,10 +1259,17 @@ int bh_k_posterior_viterbi(const void* scores, int N, int T, int state_len, floa
     double* Bcum = (double*)w; w += align((size_t)N * (T + 1) * sizeof(double));
     double* logZ = (double*)w;
     uint8_t* bp = (uint8_t*)workspace + bh_k_beam_workspace(N, T, state_len);
-    ScanArgs sa{(const half_t*)scores, N, T, S, state_len, blank, beta, Bcum, logZ, nullptr, g_decode_nt, 0};
+    ScanArgs sa{(const half_t*)scores, N, T, S, state_len, blank, beta, Bcum, logZ, nullptr, g_decode_nt, 0, 1};
     const int threads = S < 64 ? 64 : S;
     const size_t lds_scan = (size_t)(BH_LSE_TABLE_SIZE + 2 + 2 * S + 2 * 16 * 16 + 8) * sizeof(float) + (size_t)2 * 4 * S * 2;
-    hipLaunchKernelGGL(crf_backward_kernel, dim3(N), dim3(threads), lds_scan, stream, sa);
+    {
+        int b_threads = 0;
+        size_t b_lds = 0;
+        backward_geometry(S, N, sa.cpb, b_threads, b_lds);
+        if (b_lds > 64 * 1024) BH_CHECK_HIP(hipFuncSetAttribute((const void*)crf_backward_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b_lds));
+        hipLaunchKernelGGL(crf_backward_kernel, dim3((N + sa.cpb - 1) / sa.cpb), dim3(b_threads), b_lds, stream, sa);
+        sa.cpb = 1;
+    }
     PostVitArgs pa{sa, bp, moves, path};
     int TB = (32 * 1024) / S; if (TB > 512) TB = 512; if (TB < 1) TB = 1;
     const size_t lds_pv = (size_t)(BH_LSE_TABLE_SIZE + 2 + 4 * S + 4) * sizeof(float) + (size_t)TB * S + 2 * TB + 32;
@@ -1287,10 +1339,17 @@ int bh_k_beam_search(const void* scores, int N, int T, int state_len, int beam_w
 
     const bool fuse = g_beam_fuse > 0 || (g_beam_fuse < 0 && S <= 256);
     const bool ckpt = fuse && g_beam_ckpt != 0 && S <= 256;       // (three score buffers of 1024 states do not fit the LDS)
-    ScanArgs sa{(const half_t*)scores, N, T, S, state_len, blank, beta, Bcum, logZ, P, g_decode_nt, ckpt ? BTB : 0};
+    ScanArgs sa{(const half_t*)scores, N, T, S, state_len, blank, beta, Bcum, logZ, P, g_decode_nt, ckpt ? BTB : 0, 1};
     const int threads = S < 64 ? 64 : S;
     const size_t lds_scan = (size_t)(BH_LSE_TABLE_SIZE + 2 + 2 * S + 2 * 16 * 16 + 8) * sizeof(float) + (size_t)2 * 4 * S * 2;
-    hipLaunchKernelGGL(crf_backward_kernel, dim3(N), dim3(threads), lds_scan, stream, sa);
+    {
+        int b_threads = 0;
+        size_t b_lds = 0;
+        backward_geometry(S, N, sa.cpb, b_threads, b_lds);
+        if (b_lds > 64 * 1024) BH_CHECK_HIP(hipFuncSetAttribute((const void*)crf_backward_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b_lds));
+        hipLaunchKernelGGL(crf_backward_kernel, dim3((N + sa.cpb - 1) / sa.cpb), dim3(b_threads), b_lds, stream, sa);
+        sa.cpb = 1;
+    }
     // The forward/posterior scan and the beam kernel both depend only on the backward scan and both are latency chains over T
     // (one workgroup / one wave per chunk): run them side by side - the posterior scan on a per-device helper stream forked
     // from and joined back into the caller's stream with events.
