@@ -759,6 +759,20 @@ __device__ __forceinline__ void ring_stream_paired(float4_t (&xacc)[MT], float (
     if constexpr (NKS == 12 && MT == 3)
         ringstep3p_mfma(xacc, cst, hv, whh, wih, bias, hb, xb, bad, pm0, exo, vp, xm0, xsrc, vx, hbo, sga, rda, vmy, vh, exs, exa, hrow, fast);
 }
+// The paired stream once more for the main loop of the fast path, which is unrolled over four steps (exchange slot = step & 3, tile
+// parity = step & 1): which h tile / x slot an instruction addresses is a template constant added to a loop-invariant base
+// (gen_ringstep.py --preset unrolled; the same instructions in the same order otherwise)
+#include "ringstep3u_mfma.inc"
+template <int NKS, int MT, int KQ, int HOFF, int XOFF, int VOFF, int PMO, int XMO>
+__device__ __forceinline__ void ring_stream_unrolled(float4_t (&xacc)[MT], float (&cst)[MT], float (&hv)[MT], const half8_t (&whh)[MT][NKS],
+                                                     const half8_t (&wih)[MT][NKS], const float4_t (&bias)[MT], unsigned hb, unsigned xb,
+                                                     unsigned long long& bad, unsigned pm0, const char* exo, const unsigned (&vp)[KQ],
+                                                     unsigned xm0, const char* xsrc, unsigned vx, unsigned hbo, unsigned sga, unsigned rda,
+                                                     unsigned vmy, unsigned vh, const char* exs, const char* exa, const char* hrow, unsigned fast) {
+    if constexpr (NKS == 12 && MT == 3)
+        ringstep3u_mfma<HOFF, XOFF, VOFF, PMO, XMO>(xacc, cst, hv, whh, wih, bias, hb, xb, bad, pm0, exo, vp, xm0, xsrc, vx, hbo, sga, rda, vmy, vh, exs,
+                                                    exa, hrow, fast);
+}
 // The recurrent half alone (36 MFMAs tile-major + the gate arithmetic) for the single-ring kernel, whose input projection runs behind
 // the publish: gen_ringstep.py --preset rec
 #include "ringstep3r_mfma.inc"
@@ -1183,7 +1197,8 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_wgx2_kernel(LstmWgxArgs wp)
     const unsigned stage_a = lds_addr(stage);           // this wave's transpose row
     unsigned fast_u[2];
 #pragma unroll
-    for (int r = 0; r < 2; ++r) fast_u[r] = (unsigned)__builtin_amdgcn_readfirstlane(fast[r] ? 1 : 0);
+    for (int r = 0; r < 2; ++r)              // (a scalar the compiler cannot fold back into a zero-extended bool, which it keeps in a VGPR)
+        asm("s_cmp_lg_u64 %1, 0\n\ts_cselect_b32 %0, 1, 0" : "=s"(fast_u[r]) : "s"(__builtin_amdgcn_ballot_w64(fast[r])) : "scc");
     const long row_bytes = x_row * 2;
     const char* xrow2 = (const char*)fp.x + (long)(p.T > 2 ? t0 + 2 * dt : t0) * row_bytes;   // row of x_{t+2} (uniform), advanced per step
     const char* xrow_any = (const char*)fp.x + (long)t0 * row_bytes;
@@ -1430,14 +1445,78 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_wgx2_kernel(LstmWgxArgs wp)
         }
     };
 
+    // ---- the fast path's main loop, unrolled over four steps. With step & 3 a compile-time constant every exchange slot is one of
+    //      eight loop-invariant pointers, every LDS tile a constant offset, and what is left between two streams is the barrier, one
+    //      test of `bad`, and the two row pointers moving on: ~12 instructions where the generic section code above (runtime slot
+    //      products, parity selects, the tests for the first / last steps) has ~60, each an issue slot of the only wave of its SIMD.
+    //      Valid for 1 <= step and step + 2 < T (every poll / x fetch / validation is real); the steps around run the code above -----
+    const char* ex_slot[2][4];
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) ex_slot[r][k] = exr[r] + (long)k * slot_stride;
+    const unsigned lds_h = smem_a + lo;                                  // + tile offset: a fragment row of an h tile
+    const unsigned lds_x = smem_a + 4 * TILE + lo;                       // the same for the x slots
+    const unsigned lds_v = smem_a + wave * 1024 + lo;                    // my quarter of an h tile (validation read-back)
+    const unsigned m0_poll = (unsigned)__builtin_amdgcn_readfirstlane((int)(smem_a + wave * 1024));
+    const unsigned m0_x = (unsigned)__builtin_amdgcn_readfirstlane((int)(smem_a + (3 - wave) * 1024));
+    unsigned long long dead_m = 0;                                       // (uniform) all ones once the ring is given up
+    auto fast_step = [&](auto rc, auto phc, int step) {
+        constexpr int r = decltype(rc)::value, ph = decltype(phc)::value, o = r ^ 1;
+        constexpr int par = ph & 1, par_o = r == 0 ? par : par ^ 1;     // parity of the other ring's h tile its next section reads
+        __syncthreads();
+        unsigned long long bad;
+        float hv[MT];
+        ring_stream_unrolled<NKS, MT, KQ, (r * 2 + par) * TILE, (r * 2 + (par ^ 1)) * TILE, (o * 2 + par_o) * TILE, (o * 2 + par_o) * TILE,
+                             (4 + r * 2 + par) * TILE>(
+            xacc[r], cst[r], hv, whh, wih, bias4, lds_h, lds_x, bad, m0_poll, ex_slot[o][r == 0 ? (ph + 3) & 3 : ph], vp_off, m0_x, xrow2, vx_off[r],
+            lds_v, stage_a + (unsigned)((c * U + q * MT) * 2), stage_a + (unsigned)((cc * U + part * 4) * 2), (unsigned)my_byte, vh_off[r],
+            ex_slot[r][ph], ex_slot[r][(ph + 2) & 3], hrow, fast_u[r]);
+        if (__builtin_expect((bad | dead_m) != 0, 0)) {
+            const int step_o = r == 0 ? step : step + 1;
+            uint4_t chk[KQ];
+#pragma unroll
+            for (int kk = 0; kk < KQ; ++kk) chk[kk] = *(const uint4_t*)(hbuf + (o * 2 + par_o) * TILE + (wave + 4 * kk) * 1024 + lo);
+            check_end(o, step_o, chk);
+            dead_m = __builtin_amdgcn_readfirstlane(dead ? 1 : 0) ? ~0ull : 0ull;
+            if constexpr (STATS) ++st_slow;
+        }
+    };
+
     auto run = [&](auto two_c) {
         int t = t0;
         const long drow = dt * row_bytes;
-        for (int step = 0; step < p.T; ++step, t += dt) {
-            ring_step(std::integral_constant<int, 0>{}, two_c, step, t);
-            if constexpr (decltype(two_c)::value) ring_step(std::integral_constant<int, 1>{}, two_c, step, t);
-            xrow2 += drow;
-            hrow += drow;
+        auto generic_steps = [&](int from, int to) {
+            for (int step = from; step < to; ++step, t += dt) {
+                ring_step(std::integral_constant<int, 0>{}, two_c, step, t);
+                if constexpr (decltype(two_c)::value) ring_step(std::integral_constant<int, 1>{}, two_c, step, t);
+                xrow2 += drow;
+                hrow += drow;
+            }
+        };
+        if constexpr (FASTPATH && decltype(two_c)::value) {
+            int step = p.T < 4 ? p.T : 4;
+            generic_steps(0, step);
+            if (!(p.tune & 64)) {                       // (lstm_tune bit 6: generic section code throughout - the comparison the tests make)
+                for (; step + 4 <= p.T - 2; step += 4) {
+                    fast_step(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, step);
+                    fast_step(std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{}, step);
+                    xrow2 += drow; hrow += drow;
+                    fast_step(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{}, step + 1);
+                    fast_step(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{}, step + 1);
+                    xrow2 += drow; hrow += drow;
+                    fast_step(std::integral_constant<int, 0>{}, std::integral_constant<int, 2>{}, step + 2);
+                    fast_step(std::integral_constant<int, 1>{}, std::integral_constant<int, 2>{}, step + 2);
+                    xrow2 += drow; hrow += drow;
+                    fast_step(std::integral_constant<int, 0>{}, std::integral_constant<int, 3>{}, step + 3);
+                    fast_step(std::integral_constant<int, 1>{}, std::integral_constant<int, 3>{}, step + 3);
+                    xrow2 += drow; hrow += drow;
+                }
+                t = t0 + step * dt;
+            }
+            generic_steps(step, p.T);
+        } else {
+            generic_steps(0, p.T);
         }
     };
     if (two) run(std::true_type{});

@@ -322,6 +322,24 @@ def test_paired_rings_same_bytes_as_two_launches(N):
     assert torch.equal(one, two)
     scattered, _ = _encode(model.encoder, x, lstm_tune=32)
     assert torch.equal(scattered, two)
+    generic, _ = _encode(model.encoder, x, lstm_tune=64)       # bit 6: no unrolled main loop, the generic section code for every step
+    assert torch.equal(generic, two)
+
+
+@pytest.mark.parametrize("L", [30, 48, 54, 60, 66, 72, 78, 102])
+def test_paired_rings_main_loop_boundaries(L):
+    """The main loop of the paired kernel is unrolled over four steps and runs for 4 <= step, step + 4 <= T - 2; the steps around
+    it run the generic section code. T = 5 ... 17 puts the seams everywhere (no main loop at all, exactly one pass, every length
+    of the tail): the same bytes as the single-ring kernel launched twice and as the generic code throughout."""
+    from bonito_amd import synthetic
+    model = synthetic.make_model("hac", batchsize=1024, chunksize=L)
+    x = torch.randn(1024, 1, L, generator=torch.Generator().manual_seed(L)).half().cuda()
+    two, _ = _encode(model.encoder, x, lstm_pair=0)
+    one, layout = _encode(model.encoder, x)
+    assert "lstm_layer_wgx2_kernel<12,3>" in layout and one.shape[1] == L // 6
+    assert torch.equal(one, two)
+    generic, _ = _encode(model.encoder, x, lstm_tune=64)
+    assert torch.equal(generic, two)
 
 
 @pytest.mark.parametrize("H,sl,N", [(288, 3, 1024), (192, 3, 1500), (256, 3, 1500)])

@@ -30,7 +30,7 @@ Hazards placed here (the compiler pads nothing inside an asm statement):
   * transcendental result -> consumer: at least one instruction in between (gfx940+ trans forwarding hazard);
   * v_cmp (vcc) -> v_cndmask: at least one instruction in between.
 
-usage: gen_ringstep.py --preset plain|paired|rec    (the three includes of the library)
+usage: gen_ringstep.py --preset plain|paired|unrolled|rec    (the four includes of the library)
        gen_ringstep.py [--xdist a,b,c,d] [--hdepth n] [--xdepth n] [--hf-live] [--polls-at n --xdma-at n --validate-at n --spread n]
                        [--name fn] [--out path]         (experiments: tools/stream_bench.py, tools/gpu_variants.sh)
 """
@@ -60,6 +60,7 @@ def nop(n):
     return Ins("nop", "s_nop %d" % n, n=n)
 
 
+IMM = False          # --imm: LDS tile offsets / M0 tile offsets are template constants ("n" operands) added to loop-invariant bases
 ALL_AGPR = False     # timing experiments: every weight operand in the accumulator half
 PBASE = 232          # v[PBASE .. PBASE+11]: the three recurrent accumulator tuples (physical registers, see the module docstring)
 
@@ -214,7 +215,9 @@ def build(xdist, hdepth, xdepth, hpool, xpool, hf_live, lead, wgroup=1, nan_chec
 
     def lds_ins(f):
         base, off = ("hb", f[2] * 1024) if f[0] == "H" else ("xb", f[2] * 1024)
-        return Ins("lds", "ds_read_b128 %%[%s], %%[%s] offset:%d" % (reg_of[f], base, off), reads=(base,), writes=(reg_of[f],), frag=f)
+        imm = ("%%[%s]+" % ("hoff" if f[0] == "H" else "xoff")) if IMM else ""
+        return Ins("lds", "ds_read_b128 %%[%s], %%[%s] offset:%s%d" % (reg_of[f], base, imm, off), reads=(base,) + ((("hoff" if f[0] == "H" else "xoff"),) if IMM else ()),
+                   writes=(reg_of[f],), frag=f)
 
     out = [lds_ins(f) for f in reads_at.get(-1, [])]
     n = -1
@@ -262,13 +265,20 @@ def build(xdist, hdepth, xdepth, hpool, xpool, hf_live, lead, wgroup=1, nan_chec
     #  skews the four waves of the workgroup against each other in front of the next barrier)
     if polls_at >= 0:            # the other ring's first poll round: three LDS-DMA instructions (1 KiB each) into its h tile
         for k in range(3):
-            ex = [Ins("salu", "s_mov_b32 m0, %[pm0]" if k == 0 else "s_add_u32 m0, %%[pm0], 0x%x" % (0x1000 * k), reads=("pm0",)), nop(0),
+            if IMM:
+                m0w = Ins("salu", "s_add_u32 m0, %%[pm0], %%[pmo]+0x%x" % (0x1000 * k), reads=("pm0", "pmo"))
+            else:
+                m0w = Ins("salu", "s_mov_b32 m0, %[pm0]" if k == 0 else "s_add_u32 m0, %%[pm0], 0x%x" % (0x1000 * k), reads=("pm0",))
+            ex = [m0w, nop(0),
                   Ins("vmem", "global_load_lds_dwordx4 %%[vp%d], %%[exo] sc0 sc1" % k, reads=("vp%d" % k, "exo"))]
             seq = after_mfma(seq, polls_at + k * spread, ex)
     if xdma_at >= 0:             # this ring's share of x_{t+2}: three LDS-DMA instructions into the x slot the previous step consumed
         assert xdma_at >= polls_at + 2 * spread
         for k in range(3):
-            ex = [Ins("salu", "s_mov_b32 m0, %[xm0]" if k == 0 else "s_add_u32 m0, %%[xm0], 0x%x" % (0x1000 * k), reads=("xm0",))]
+            if IMM:
+                ex = [Ins("salu", "s_add_u32 m0, %%[xm0], %%[xmo]+0x%x" % (0x1000 * k), reads=("xm0", "xmo"))]
+            else:
+                ex = [Ins("salu", "s_mov_b32 m0, %[xm0]" if k == 0 else "s_add_u32 m0, %%[xm0], 0x%x" % (0x1000 * k), reads=("xm0",))]
             if k:
                 ex.append(Ins("valu", "v_add_u32_e32 %%[xv%d], 0x%x, %%[vx]" % (k, 0x100 * k), reads=("vx",), writes=("xv%d" % k,)))
             else:
@@ -279,7 +289,8 @@ def build(xdist, hdepth, xdepth, hpool, xpool, hf_live, lead, wgroup=1, nan_chec
         assert polls_at >= 0 and xdma_at >= polls_at and validate_at > xdma_at + 2 * spread
         vr = ["v[%d:%d]" % (VBASE + 4 * k, VBASE + 4 * k + 3) for k in range(3)]
         ex = [Ins("wait", "s_waitcnt vmcnt(3)")]
-        ex += [Ins("lds", "ds_read_b128 %s, %%[hbo] offset:%d" % (vr[k], 4096 * k), reads=("hbo",), frag=("V", 0, k)) for k in range(3)]
+        ex += [Ins("lds", "ds_read_b128 %s, %%[hbo] offset:%s%d" % (vr[k], "%[voff]+" if IMM else "", 4096 * k), reads=("hbo",) + (("voff",) if IMM else ()),
+                   frag=("V", 0, k)) for k in range(3)]
         seq = after_mfma(seq, validate_at, ex)
     # ---- waits: LDS returns in order; wait for exactly as many as were issued behind the one needed ----------------------
     out, issued, done = [], [], -1
@@ -382,6 +393,8 @@ def operand(name):
         return "v", "cst[%s]" % name[1]
     if name in ("hb", "xb"):
         return "v", name
+    if name in ("hoff", "xoff", "voff", "pmo", "xmo"):
+        return "n", name.upper()
     if name == "nan":
         return "v", "nanacc"
     if name == "bad":
@@ -433,6 +446,9 @@ def render(seq, fn, hf_live, header):
     lines = ["// GENERATED by tools/gen_ringstep.py - do not edit. " + header,
              "// in: xacc[m] = bias + W_ih x_t (tile m), cst; h_{t-1} fragments at LDS address hb, x_{t+1} fragments at xb (+ lane * 16 each)",
              "// out: hv[m] = h_t of the lane's three cells, cst, xacc[m] = bias + W_ih x_{t+1}",
+             *(["// --imm: hb / xb / hbo / pm0 / xm0 are loop-invariant bases, the tile they address is the template constant added to them (HOFF: this ring's h",
+                "// tile, XOFF: its x slot of step t+1, VOFF / PMO: the other ring's h tile that is validated / polled into, XMO: the x slot the DMA fills)"] if IMM else []),
+             ("template <int HOFF, int XOFF, int VOFF, int PMO, int XMO>\n" if IMM else "") +
              "__device__ __forceinline__ void %s(float4_t (&xacc)[3], float (&cst)[3], float (&hv)[3], const half8_t (&whh)[3][12]," % fn,
              "        const half8_t (&wih)[3][12], const float4_t (&bias)[3], unsigned hb, unsigned xb%s) {" % extra_args,
              "    float e[3], nanacc;",
@@ -481,6 +497,8 @@ PRESETS = {
                "--validate-at", "71", "--publish", "--name", "ringstep3p_mfma", "--out",
                os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bonito_amd", "csrc", "ringstep3p_mfma.inc")],
 }
+# the same stream for the main loop of the paired kernel, unrolled over four steps: every tile / slot choice is a compile-time constant
+PRESETS["unrolled"] = PRESETS["paired"][:-4] + ["--imm", "--name", "ringstep3u_mfma", "--out", PRESETS["paired"][-1].replace("ringstep3p", "ringstep3u")]
 
 
 def main(argv=None):
@@ -504,14 +522,15 @@ def main(argv=None):
     ap.add_argument("--validate-at", type=int, default=-1, help="read back my quarter of the other ring's h tile behind this MFMA; `bad` = sentinel found")
     ap.add_argument("--pbase", type=int, default=232, help="first of the twelve physical accumulator registers (the kernel's VGPR count is at least this + 12)")
     ap.add_argument("--vbase", type=int, default=220, help="first of the twelve physical registers of the validation read-back")
+    ap.add_argument("--imm", action="store_true", help="tile offsets as template constants on loop-invariant bases (the unrolled main loop of the paired kernel)")
     ap.add_argument("--all-agpr", action="store_true", help="timing experiments: W_ih tile 2 as AGPR operands too")
     ap.add_argument("--strip", default="", help="timing experiments only (wrong results): 'valu' drops the gate arithmetic, 'mfma' drops MFMAs + LDS reads")
     ap.add_argument("--hf-live", action="store_true", help="keep the twelve h fragments in registers instead of re-reading them per tile")
     ap.add_argument("--name", default="ringstep3_mfma")
     ap.add_argument("--out", default=os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bonito_amd", "csrc", "ringstep3_mfma.inc"))
     a = ap.parse_args(argv)
-    global PBASE, VBASE, ALL_AGPR
-    PBASE, VBASE, ALL_AGPR = a.pbase, a.vbase, a.all_agpr
+    global PBASE, VBASE, ALL_AGPR, IMM
+    PBASE, VBASE, ALL_AGPR, IMM = a.pbase, a.vbase, a.all_agpr, a.imm
     xdist = tuple(int(v) for v in a.xdist.split(","))
     seq = build(xdist, a.hdepth, a.xdepth, a.hpool, a.xpool, a.hf_live, a.lead, a.wgroup, a.nan_check, a.polls_at, a.xdma_at, a.validate_at, a.spread, a.publish)
     if a.strip == "valu":
