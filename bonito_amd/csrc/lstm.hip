@@ -1497,7 +1497,9 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_wgx2_kernel(LstmWgxArgs wp)
         if constexpr (FASTPATH && decltype(two_c)::value) {
             int step = p.T < 4 ? p.T : 4;
             generic_steps(0, step);
-            if (!(p.tune & 64)) {                       // (lstm_tune bit 6: generic section code throughout - the comparison the tests make)
+            // (lstm_tune bit 6: generic section code throughout - the comparison the tests make; a ring spread over several XCDs - write-through
+            //  stores, see ring_store_policy - runs the generic code as well: the unrolled stream publishes with plain stores)
+            if (!(p.tune & 64) && fast_u[0] != 0 && fast_u[1] != 0) {
                 for (; step + 4 <= p.T - 2; step += 4) {
                     fast_step(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, step);
                     fast_step(std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{}, step);

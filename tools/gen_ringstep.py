@@ -60,6 +60,7 @@ def nop(n):
     return Ins("nop", "s_nop %d" % n, n=n)
 
 
+POLL_FLAGS = "sc0 sc1"  # cache policy of the poll DMAs (experiments: --poll-flags)
 IMM = False          # --imm: LDS tile offsets / M0 tile offsets are template constants ("n" operands) added to loop-invariant bases
 ALL_AGPR = False     # timing experiments: every weight operand in the accumulator half
 PBASE = 232          # v[PBASE .. PBASE+11]: the three recurrent accumulator tuples (physical registers, see the module docstring)
@@ -156,10 +157,23 @@ def weave(mf, va, lead_m):
     return out
 
 
+def publish_ops():
+    """h_t of the lane's three cells -> fp16 -> the wave's LDS staging row (2-byte writes) -> read back as the 8 bytes this lane moves (one
+    wave: LDS operations complete in issue order) -> exchange slot, re-arm of the slot of h_{t+2}, layer output row. Plain stores: the
+    unrolled main loop only runs where the ring sits on one XCD."""
+    ops = [Ins("valu", "v_cvt_f16_f32_e32 %%[hh%d], v%d" % (m, PBASE + 4 * m), writes=("hh%d" % m,)) for m in range(3)]
+    ops += [Ins("lds", "ds_write_b16 %%[sga], %%[hh%d]%s" % (m, " offset:%d" % (2 * m) if m else ""), reads=("sga", "hh%d" % m), frag=("W", 0, m)) for m in range(3)]
+    ops.append(Ins("lds", "ds_read_b64 %[pk], %[rda]", reads=("rda",), writes=("pk",), frag=("P", 0, 0)))
+    ops.append(Ins("vmem", "global_store_dwordx2 %[vmy], %[pk], %[exs]", reads=("vmy", "pk", "exs"), needs=[("P", 0, 0)]))
+    ops.append(Ins("vmem", "global_store_dwordx2 %[vmy], %[ones], %[exa]", reads=("vmy", "ones", "exa")))
+    ops.append(Ins("vmem", "global_store_dwordx2 %[vh], %[pk], %[hrow]", reads=("vh", "pk", "hrow")))
+    return ops
+
+
 VBASE = 220          # v[VBASE .. VBASE+11]: the three fragments of the other ring's h tile read back for validation (physical: the OR tree names their dwords)
 
 
-def build(xdist, hdepth, xdepth, hpool, xpool, hf_live, lead, wgroup=1, nan_check=False, polls_at=-1, xdma_at=-1, validate_at=-1, spread=0, publish=False):
+def build(xdist, hdepth, xdepth, hpool, xpool, hf_live, lead, wgroup=1, nan_check=False, polls_at=-1, xdma_at=-1, validate_at=-1, spread=0, publish=False, tail=0):
     # xdist all zero: the recurrent half alone (single-ring kernel: the input projection of the next step runs BEHIND the publish there,
     # it is what fills the hand-off's round trip)
     assert (sum(xdist) == 3 * NKS or sum(xdist) == 0) and len(xdist) == 4
@@ -187,7 +201,16 @@ def build(xdist, hdepth, xdepth, hpool, xpool, hf_live, lead, wgroup=1, nan_chec
     for p in range(4):
         mf = [mfma_ins(t) for t in spine_by_phase[p]]
         va = gates(p - 1, nan_check) if p >= 1 else []
-        seq += weave(mf, va, lead if p >= 1 else 0)
+        if p == 3 and tail:
+            # --tail K: cell 2's gate arithmetic over all but the last K MFMAs, the publish of h_t (fp16 -> LDS transpose -> three plain
+            # stores) over the last K: the peers see h_t ~150 cycles earlier and the stream's MFMA-less end shrinks to the validation
+            assert publish and 6 <= tail < len(mf)
+            ops, mb = publish_ops(), mf[-tail:]
+            # conversions + transpose right behind the cell, the stores behind the last two MFMAs: the LDS round trip of the transpose
+            # (the stores wait for it) has the MFMAs in between to hide behind
+            seq += weave(mf[:-tail], va, lead) + weave(mb[:3], ops[:7], 0) + mb[3:-2] + [mb[-2], ops[7], ops[8], mb[-1], ops[9]]
+        else:
+            seq += weave(mf, va, lead if p >= 1 else 0)
 
     # ---- fragment reads: `depth` MFMAs ahead of the first use, into rotating registers ---------------------------------
     mf_pos = [i for i, x in enumerate(seq) if x.kind == "mfma"]
@@ -270,7 +293,7 @@ def build(xdist, hdepth, xdepth, hpool, xpool, hf_live, lead, wgroup=1, nan_chec
             else:
                 m0w = Ins("salu", "s_mov_b32 m0, %[pm0]" if k == 0 else "s_add_u32 m0, %%[pm0], 0x%x" % (0x1000 * k), reads=("pm0",))
             ex = [m0w, nop(0),
-                  Ins("vmem", "global_load_lds_dwordx4 %%[vp%d], %%[exo] sc0 sc1" % k, reads=("vp%d" % k, "exo"))]
+                  Ins("vmem", "global_load_lds_dwordx4 %%[vp%d], %%[exo] %s" % (k, POLL_FLAGS), reads=("vp%d" % k, "exo"))]
             seq = after_mfma(seq, polls_at + k * spread, ex)
     if xdma_at >= 0:             # this ring's share of x_{t+2}: three LDS-DMA instructions into the x slot the previous step consumed
         assert xdma_at >= polls_at + 2 * spread
@@ -288,7 +311,7 @@ def build(xdist, hdepth, xdepth, hpool, xpool, hf_live, lead, wgroup=1, nan_chec
     if validate_at >= 0:         # my quarter of the other ring's h tile, read back: behind its polls only the x-stream DMAs above
         assert polls_at >= 0 and xdma_at >= polls_at and validate_at > xdma_at + 2 * spread
         vr = ["v[%d:%d]" % (VBASE + 4 * k, VBASE + 4 * k + 3) for k in range(3)]
-        ex = [Ins("wait", "s_waitcnt vmcnt(3)")]
+        ex = [Ins("wait", "s_waitcnt vmcnt(3)", vmwait=True)]       # (the count is resolved below: the vector-memory operations younger than the polls)
         ex += [Ins("lds", "ds_read_b128 %s, %%[hbo] offset:%s%d" % (vr[k], "%[voff]+" if IMM else "", 4096 * k), reads=("hbo",) + (("voff",) if IMM else ()),
                    frag=("V", 0, k)) for k in range(3)]
         seq = after_mfma(seq, validate_at, ex)
@@ -297,14 +320,21 @@ def build(xdist, hdepth, xdepth, hpool, xpool, hf_live, lead, wgroup=1, nan_chec
     for x in seq:
         if x.kind == "lds":
             issued.append(x.meta["frag"])
-        elif x.kind == "mfma":
-            r = max(i for i, f in enumerate(issued) if f == x.meta["frag"])
+        elif x.kind == "mfma" or x.meta.get("needs"):
+            needs = [x.meta["frag"]] if x.kind == "mfma" else x.meta["needs"]
+            r = max(i for i, f in enumerate(issued) if f in needs)
             if r > done:
-                r = min(r + wgroup - 1, len(issued) - 1)          # wgroup > 1: one wait covers the next fragments too (fewer issue slots)
+                if x.kind == "mfma":
+                    r = min(r + wgroup - 1, len(issued) - 1)      # wgroup > 1: one wait covers the next fragments too (fewer issue slots)
                 out.append(Ins("wait", "s_waitcnt lgkmcnt(%d)" % (len(issued) - 1 - r)))
                 done = r
         out.append(x)
     seq = out
+    # the validation's vmcnt: everything up to the polls must be home, i.e. all but the vector-memory operations issued behind them
+    for i, x in enumerate(seq):
+        if x.meta.get("vmwait"):
+            last_poll = max(j for j, y in enumerate(seq[:i]) if y.kind == "vmem" and "exo" in y.reads)
+            x.text = "s_waitcnt vmcnt(%d)" % sum(1 for y in seq[last_poll + 1:i] if y.kind == "vmem")
 
     if nan_check:
         seq = [Ins("valu", "v_mov_b32 %[nan], 0", writes=("nan",))] + seq
@@ -329,11 +359,14 @@ def build(xdist, hdepth, xdepth, hpool, xpool, hf_live, lead, wgroup=1, nan_chec
             last_r[x.meta["tag"][1]] = len(out) - 1
     last_m = max(i for i, y in enumerate(out) if y.kind == "mfma")
     gap = sum(y.states() for y in out[last_m + 1:])
-    if gap < 12:
+    if gap < 12 and not tail:        # (--tail: the validation below sits behind the last MFMA; checked at the end)
         out.append(nop(12 - gap - 1))
     if nan_check:
         out.append(Ins("cmp", "v_cmp_u_f32_e64 %[bad], %[nan], %[nan]", reads=("nan",), writes=("bad",)))
-    if publish:
+    if tail:
+        # the publish is inside the stream already; what is left behind the last MFMA is the validation
+        out.append(Ins("wait", "s_waitcnt lgkmcnt(0)"))
+    elif publish:
         # h_t of the lane's three cells -> fp16 -> the wave's LDS staging row (2-byte writes) -> read back as the 8 bytes this lane
         # moves (one wave: LDS operations complete in issue order, no wait between the writes and the read). The OR tree of the
         # validation runs while that read is in flight.
@@ -356,7 +389,7 @@ def build(xdist, hdepth, xdepth, hpool, xpool, hf_live, lead, wgroup=1, nan_chec
         out.append(Ins("valu", "v_or_b32_e32 %s, %s, %s" % (d[0], d[0], d[4])))
         out.append(Ins("valu", "v_and_b32_e32 %s, 0x40004000, %s" % (d[0], d[0])))
         out.append(Ins("cmp", "v_cmp_ne_u32_e64 %%[bad], 0, %s" % d[0], writes=("bad",)))
-    if publish:
+    if publish and not tail:
         # publish h_t into its exchange slot, re-arm the slot of h_{t+2}, write the layer output row: plain stores when the ring sits on
         # one XCD (`fast`), write-through otherwise - the policy of the C++ sections
         out.append(Ins("wait", "s_waitcnt lgkmcnt(0)"))
@@ -370,6 +403,10 @@ def build(xdist, hdepth, xdepth, hpool, xpool, hf_live, lead, wgroup=1, nan_chec
         out.append(Ins("vmem", "global_store_dwordx2 %[vmy], %[ones], %[exa]", reads=("vmy", "ones", "exa")))
         out.append(Ins("label", "2:"))
         out.append(Ins("vmem", "global_store_dwordx2 %[vh], %[pk], %[hrow]", reads=("vh", "pk", "hrow")))
+    if tail:
+        gap = sum(y.states() for y in out[last_m + 1:])
+        if gap < 12:
+            out.append(nop(12 - gap - 1))
     return out
 
 
@@ -479,9 +516,9 @@ def render(seq, fn, hf_live, header):
     body = '\\n\\t"\n        "'.join(x.text for x in seq)
     lines.append('    asm volatile("' + body + '"\n        : ' + ", ".join(outs) + "\n        : " + ", ".join(ins) + ('\n        : "vcc", "scc", "memory");' if "exo" in names else '\n        : "vcc");'))
     if any(x.meta.get("cell") is not None for x in seq):
-        lines += ["    hv[0] = acc[0][0]; hv[1] = acc[1][0]; hv[2] = acc[2][0]; (void)nanacc; (void)xv1; (void)xv2; (void)vt; (void)hh; (void)pk;", "}", ""]
+        lines += ["    hv[0] = acc[0][0]; hv[1] = acc[1][0]; hv[2] = acc[2][0]; (void)nanacc; (void)xv1; (void)xv2; (void)vt; (void)hh; (void)pk;" + (" (void)fast;" if "pk" in names else ""), "}", ""]
     else:
-        lines += ["    hv[0] = acc[0][0]; hv[1] = acc[1][0]; hv[2] = acc[2][0]; (void)e; (void)nanacc; (void)xv1; (void)xv2; (void)vt; (void)hh; (void)pk;", "}", ""]
+        lines += ["    hv[0] = acc[0][0]; hv[1] = acc[1][0]; hv[2] = acc[2][0]; (void)e; (void)nanacc; (void)xv1; (void)xv2; (void)vt; (void)hh; (void)pk;" + (" (void)fast;" if "pk" in names else ""), "}", ""]
     return "\n".join(lines)
 
 
@@ -498,7 +535,10 @@ PRESETS = {
                os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bonito_amd", "csrc", "ringstep3p_mfma.inc")],
 }
 # the same stream for the main loop of the paired kernel, unrolled over four steps: every tile / slot choice is a compile-time constant
-PRESETS["unrolled"] = PRESETS["paired"][:-4] + ["--imm", "--name", "ringstep3u_mfma", "--out", PRESETS["paired"][-1].replace("ringstep3p", "ringstep3u")]
+# (--tail 8: the publish inside the last eight MFMAs, plain stores - the main loop runs only where the ring sits on one XCD; polls four MFMAs
+#  later than in the generic stream: the section is ~350 cycles shorter, the peers' publishes are not visible any earlier)
+PRESETS["unrolled"] = PRESETS["paired"][:-4] + ["--imm", "--tail", "8", "--polls-at", "30", "--xdma-at", "46", "--name", "ringstep3u_mfma", "--out",
+                                                PRESETS["paired"][-1].replace("ringstep3p", "ringstep3u")]
 
 
 def main(argv=None):
@@ -523,16 +563,18 @@ def main(argv=None):
     ap.add_argument("--pbase", type=int, default=232, help="first of the twelve physical accumulator registers (the kernel's VGPR count is at least this + 12)")
     ap.add_argument("--vbase", type=int, default=220, help="first of the twelve physical registers of the validation read-back")
     ap.add_argument("--imm", action="store_true", help="tile offsets as template constants on loop-invariant bases (the unrolled main loop of the paired kernel)")
+    ap.add_argument("--tail", type=int, default=0, help="weave the publish (plain stores) into the last K MFMAs; cell 2's gate arithmetic over the ones before")
+    ap.add_argument("--poll-flags", default="sc0 sc1", help="timing experiments: cache policy bits of the poll DMAs")
     ap.add_argument("--all-agpr", action="store_true", help="timing experiments: W_ih tile 2 as AGPR operands too")
     ap.add_argument("--strip", default="", help="timing experiments only (wrong results): 'valu' drops the gate arithmetic, 'mfma' drops MFMAs + LDS reads")
     ap.add_argument("--hf-live", action="store_true", help="keep the twelve h fragments in registers instead of re-reading them per tile")
     ap.add_argument("--name", default="ringstep3_mfma")
     ap.add_argument("--out", default=os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bonito_amd", "csrc", "ringstep3_mfma.inc"))
     a = ap.parse_args(argv)
-    global PBASE, VBASE, ALL_AGPR, IMM
-    PBASE, VBASE, ALL_AGPR, IMM = a.pbase, a.vbase, a.all_agpr, a.imm
+    global PBASE, VBASE, ALL_AGPR, IMM, POLL_FLAGS
+    PBASE, VBASE, ALL_AGPR, IMM, POLL_FLAGS = a.pbase, a.vbase, a.all_agpr, a.imm, a.poll_flags
     xdist = tuple(int(v) for v in a.xdist.split(","))
-    seq = build(xdist, a.hdepth, a.xdepth, a.hpool, a.xpool, a.hf_live, a.lead, a.wgroup, a.nan_check, a.polls_at, a.xdma_at, a.validate_at, a.spread, a.publish)
+    seq = build(xdist, a.hdepth, a.xdepth, a.hpool, a.xpool, a.hf_live, a.lead, a.wgroup, a.nan_check, a.polls_at, a.xdma_at, a.validate_at, a.spread, a.publish, a.tail)
     if a.strip == "valu":
         seq = [x for x in seq if x.kind not in ("valu", "trans", "cmp", "sel")]
     elif a.strip == "mfma":
@@ -540,8 +582,10 @@ def main(argv=None):
     counts = {}
     for x in seq:
         counts[x.kind] = counts.get(x.kind, 0) + 1
-    header = "xdist=%s hdepth=%d xdepth=%d hpool=%d xpool=%d lead=%d wgroup=%d hf_live=%d nan_check=%d polls_at=%d xdma_at=%d validate_at=%d spread=%d publish=%d : %s" % (
-        a.xdist, a.hdepth, a.xdepth, a.hpool, a.xpool, a.lead, a.wgroup, a.hf_live, a.nan_check, a.polls_at, a.xdma_at, a.validate_at, a.spread, a.publish, " ".join("%s=%d" % kv for kv in sorted(counts.items())))
+    header = "xdist=%s hdepth=%d xdepth=%d hpool=%d xpool=%d lead=%d wgroup=%d hf_live=%d nan_check=%d polls_at=%d xdma_at=%d validate_at=%d spread=%d publish=%d%s : %s" % (
+        a.xdist, a.hdepth, a.xdepth, a.hpool, a.xpool, a.lead, a.wgroup, a.hf_live, a.nan_check, a.polls_at, a.xdma_at, a.validate_at, a.spread, a.publish,
+        (" imm=1" if a.imm else "") + (" tail=%d" % a.tail if a.tail else "") + (" poll_flags=%s" % a.poll_flags.replace(" ", "+") if a.poll_flags != "sc0 sc1" else ""),
+        " ".join("%s=%d" % kv for kv in sorted(counts.items())))
     with open(a.out, "w") as fh:
         fh.write(render(seq, a.name, a.hf_live, header))
     print("wrote", a.out, header)
