@@ -36,6 +36,7 @@ struct GemmArgs {
     long row_s_hi, row_s_lo;
     int row_lim;       // rows with (m % row_div) >= row_lim are not stored (batch padding)
     int n_ft, n_tt;    // tile counts
+    int stagger = 0;   // persistent kernels: workgroup b starts ((b >> 3) & 7) * stagger * 1024 cycles late (see gemm_stagger_start)
     // optional rotary epilogue for the packed Wqkv projection (features [0, rot_nfeat) are heads of 64 rotated in place
     // by position m % rot_T; features [0, rot_qfeat) are scaled by rot_qscale afterwards)
     const float* rot_cs = nullptr;   // [rot_T][32][2] (cos, sin)
@@ -373,6 +374,15 @@ __global__ __launch_bounds__(256, 4) void gemm_glds_kernel(GemmArgs p) {
 // distance 3, builtin s_waitcnt, asm fragment reads, no spurious waits left) was measured too: 631-991 TFLOP/s on the same
 // shapes, no better than this kernel -- the DMA latency is not what bounds it; with a barrier per stage both waves of a SIMD
 // read LDS at the same time and issue MFMAs at the same time (the fix is a phase-staggered schedule, not more buffers).
+// The persistent kernels run compute (K loop) and store (epilogue) phases of equal length on every CU; launched together, all 256 CUs
+// reach their epilogues together and the output tile of every one of them (128 KiB) goes to HBM in one burst while the matrix cores
+// of the whole chip idle - then nobody writes for a K loop. Starting the workgroups of an XCD in eight phase groups spreads the
+// bursts over the tile period: stores of one group overlap the K loops of the others ("gemm_stagger" option, units of 1024 cycles).
+__device__ __forceinline__ void gemm_stagger_start(int units) {
+    const int slot = (blockIdx.x >> 3) & 7;
+    for (int i = 0; i < slot * units; ++i) __builtin_amdgcn_s_sleep(16);
+}
+
 constexpr int BF3 = 256, BT3 = 256, BK3 = 64;
 constexpr int TILE3 = 256 * BK3 * 2;    // 32 KiB per operand tile
 
@@ -428,6 +438,7 @@ __global__ __launch_bounds__(512, 1) void gemm_big_kernel(GemmArgs p) {
 
     int work = blockIdx.x;
     if (work >= n_tiles) return;
+    gemm_stagger_start(p.stagger);
     int f0, t0;
     set_tile(work, f0, t0);
     dma(0, 0);
@@ -472,6 +483,15 @@ __global__ __launch_bounds__(512, 1) void gemm_big_kernel(GemmArgs p) {
     }
 }
 
+// (Round 3, measured and not kept: "v4" = this kernel with the fragment reads software-pipelined across the barrier - barrier in the
+// middle of a K-tile, the next phase's twelve fragments read during the first six MFMA groups of the current one, DMA from inline
+// assembly with scalar bases, one instruction per MFMA group; the compiled K loop was clean (no spills, one lgkmcnt wait per phase).
+// Bit-identical, and no faster: 634 vs 752 TFLOP/s at K = 512 (more per-tile overhead), 1030-1060 vs 978-985 at K = 2048, 917 vs 956
+// at K = 1024. The SQ counters say why (profiles/r03_sq_counters_other_models.txt): the waves of v3 wait 40 % of their time, and
+// SQ_WAIT_INST_LDS is 1.6 % - they wait for the global -> LDS stream (vmcnt(0) in front of the barrier: 64 KiB per K-tile and CU,
+// ~6-9 TB/s out of the L2s chip-wide at these rates), not for fragment reads. The next step is a deeper DMA pipeline (three stages
+// need BK = 32 or a 256 x 128 tile: 2 x 64 KiB is what fits beside nothing else), not a better MFMA schedule.)
+static int g_stagger = 0;    // bh_k_linear_stagger
 static int g_force_v1 = 0;   // test / A-B hook (bh_k_linear_force_v1): 1 = v1 only, 2 = never v3
 
 template <int ACT, bool GATED>
@@ -485,10 +505,11 @@ static void launch(const GemmArgs& a, hipStream_t s) {
             int dev = 0, cus = 256;
             if (hipGetDevice(&dev) != hipSuccess ||
                 hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
-            (void)hipFuncSetAttribute((const void*)gemm_big_kernel<ACT, GATED>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE3);
             GemmArgs b = a;
             b.n_ft = nf3; b.n_tt = nt3;
+            b.stagger = g_stagger;
             const int tiles = nf3 * nt3;
+            (void)hipFuncSetAttribute((const void*)gemm_big_kernel<ACT, GATED>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE3);
             hipLaunchKernelGGL((gemm_big_kernel<ACT, GATED>), dim3(tiles < cus ? tiles : cus), dim3(512), 4 * TILE3, s, b);
             return;
         }
@@ -502,6 +523,7 @@ static void launch(const GemmArgs& a, hipStream_t s) {
 }  // namespace bh
 
 void bh_k_linear_force_v1(int on) { bh::g_force_v1 = on; }
+void bh_k_linear_stagger(int units) { bh::g_stagger = units; }
 
 int bh_k_linear(const void* X, const void* W, const float* bias, void* out, int M, int N, int K,
                 int ldx, int ldw, int ldo, int act, float scale, float clamp_lo, float clamp_hi,

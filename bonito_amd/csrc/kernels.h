@@ -13,6 +13,7 @@ int bh_k_linear(const void* X, const void* W, const float* bias, void* out, int 
                 const void* residual = nullptr, int ldres = 0);
 
 void bh_k_linear_force_v1(int on);
+void bh_k_linear_stagger(int units);
 
 // conv.hip
 int bh_k_conv_first(const void* signal, const float* w, const float* bias, void* out, int N, int Lin,

@@ -296,10 +296,12 @@ def test_rmsnorm_residual(M, D):
     assert (out.cpu().float() - want).abs().max().item() < 4e-3
 
 
-@pytest.mark.parametrize("M,N,K,gated", [(16384 + 37, 2048, 128, 0), (40000, 1024, 384, 0), (33000, 1024, 64, 1)])
+@pytest.mark.parametrize("M,N,K,gated", [(16384 + 37, 2048, 128, 0), (40000, 1024, 384, 0), (33000, 1024, 64, 1), (70000, 512, 512, 0),
+                                         (36000, 1024, 192, 1), (131072 + 5, 256, 2048, 0)])
 def test_linear_persistent_big_tile_kernel(M, N, K, gated):
-    """Problems with >= 512 tiles of 256 x 256 and K % 64 == 0 run on the persistent 256x256x64 kernel: same K order
-    and epilogue as the 128-tile kernels, so the bytes must be identical (and right)."""
+    """Problems with >= 512 tiles of 256 x 256 and K % 64 == 0 run on the persistent 256x256x64 kernel: same K order and
+    epilogue as the 128-tile kernels, so the bytes must be identical (and right) - also with the staggered start ("gemm_stagger");
+    short and long K-tile streams, ragged last token tile."""
     from bonito_amd import decode
     g = torch.Generator().manual_seed(M)
     x = (torch.randn(M, K, generator=g) * 0.5).half().to(dev())
@@ -310,9 +312,14 @@ def test_linear_persistent_big_tile_kernel(M, N, K, gated):
         big = _linear(x, w, b, act=0 if gated else 1, gated=gated)
         decode.set_option("gemm_path", 2)
         small = _linear(x, w, b, act=0 if gated else 1, gated=gated)
+        decode.set_option("gemm_path", 0)
+        decode.set_option("gemm_stagger", 3)
+        again = _linear(x, w, b, act=0 if gated else 1, gated=gated)
     finally:
         decode.set_option("gemm_path", 0)
+        decode.set_option("gemm_stagger", 0)
     assert torch.equal(big, small)
+    assert torch.equal(again, big)
     z = x[-3000:].float() @ w.float().T + b
     want = (z[:, 0::2] * z[:, 1::2] * torch.sigmoid(z[:, 1::2])) if gated else z * torch.sigmoid(z)
     assert (big[-3000:].float() - want).abs().max().item() < 3e-2 + 3e-3 * want.abs().max().item()

@@ -17,8 +17,9 @@ for M, N, K, gated in shapes:
     ncol = N // 2 if gated else N
     out = torch.empty((M, ncol), dtype=torch.float16, device=dev)
     res = {}
-    for path in (0, 2):
-        decode.set_option("gemm_path", path)
+    for path in (0, 2, 1003, 1006):          # >= 1000: the auto path with gemm_stagger p % 100
+        decode.set_option("gemm_path", 0 if path >= 1000 else path)
+        decode.set_option("gemm_stagger", path % 100 if path >= 1000 else 0)
         def run():
             _lib.check(lib.bh_linear(_lib.ptr(x), _lib.ptr(w), None, _lib.ptr(out), M, N, K, K, K, ncol, 0, 1.0, -INF, INF,
                                      gated, 0, 0, 0, 0, _lib.stream_ptr()), "bh_linear")
@@ -30,7 +31,8 @@ for M, N, K, gated in shapes:
         e1.record(); torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / 10
         res[path] = (ms, 2.0 * M * N * K / ms / 1e9)
-    decode.set_option("gemm_path", 0)
+    decode.set_option("gemm_path", 0); decode.set_option("gemm_stagger", 0)
+    print("   staggered start: " + "  ".join("%d: %.3f ms %.0f TF/s" % (k % 100, v[0], v[1]) for k, v in res.items() if k >= 1000))
     # yardstick: the vendor library behind torch.matmul (hipBLASLt / rocBLAS), plain GEMM without the fused epilogue
     full = torch.empty((M, N), dtype=torch.float16, device=dev)
     for _ in range(3): torch.matmul(x, w.t(), out=full)
