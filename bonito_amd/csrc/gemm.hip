@@ -490,7 +490,11 @@ __global__ __launch_bounds__(512, 1) void gemm_big_kernel(GemmArgs p) {
 // at K = 1024. The SQ counters say why (profiles/r03_sq_counters_other_models.txt): the waves of v3 wait 40 % of their time, and
 // SQ_WAIT_INST_LDS is 1.6 % - they wait for the global -> LDS stream (vmcnt(0) in front of the barrier: 64 KiB per K-tile and CU,
 // ~6-9 TB/s out of the L2s chip-wide at these rates), not for fragment reads. The next step is a deeper DMA pipeline (three stages
-// need BK = 32 or a 256 x 128 tile: 2 x 64 KiB is what fits beside nothing else), not a better MFMA schedule.)
+// need BK = 32 or a 256 x 128 tile: 2 x 64 KiB is what fits beside nothing else), not a better MFMA schedule. Also measured: v3 with its
+// DMA issued from inline assembly (scalar base, so that the compiler inserts no vmcnt drain in front of the fragment reads) and a counted
+// vmcnt behind the epilogue (its sixteen stores are younger than the next tile's first DMA): 586 vs 758 TFLOP/s at K = 512, 728 vs 985 at
+// K = 2048 - the eight asm statements pin the DMA issue (~50 cycles each) in front of the K-tile's fragment reads, where the builtin
+// lets the scheduler spread them; the builtin form stays.)
 static int g_stagger = 0;    // bh_k_linear_stagger
 static int g_force_v1 = 0;   // test / A-B hook (bh_k_linear_force_v1): 1 = v1 only, 2 = never v3
 
