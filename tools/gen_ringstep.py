@@ -39,6 +39,8 @@ import os
 
 L_NEG = "0xbfb8aa3b"      # -log2(e)
 L_POS = "0x3fb8aa3b"      # +log2(e)
+L_M2POS = "0xc038aa3b"    # -2 log2(e)
+PACKED = False           # --packed: packed fp32 instructions + fused constants in the gate arithmetic (30 instead of 35 per cell)
 NKS = 12
 
 
@@ -92,15 +94,29 @@ def gates(m, nan_check=False):
         seq.append(v("valu", "v_fma_f32 {d}, {s0}, {s1}, {s2}", "nan", g2, g3, "nan"))
     for g, hi in ((g0, "hi25"), (g1, "hi25"), (g2, "hi12"), (g3, "hi25")):
         seq.append(v("valu", "v_med3_f32 {d}, {s0}, {s1}, -{s1}", g, g, hi))
-    seq.append(v("valu", "v_mul_f32 {d}, " + L_NEG + ", {s0}", g0, g0))
-    seq.append(v("valu", "v_mul_f32 {d}, " + L_NEG + ", {s0}", g1, g1))
-    seq.append(v("valu", "v_mul_f32 {d}, -2.0, {s0}", g2, g2))
-    seq.append(v("valu", "v_mul_f32 {d}, " + L_NEG + ", {s0}", g3, g3))
-    seq.append(v("valu", "v_mul_f32 {d}, " + L_POS + ", {s0}", g2, g2))
+
+    def pk(fmt, lo, hi, const):          # one packed fp32 instruction on the register pair (lo, hi) with a 64-bit scalar constant pair
+        pair = "v[%d:%d]" % (PBASE + 4 * m + int(lo[2]), PBASE + 4 * m + int(hi[2]))
+        return Ins("valu", fmt % (pair, pair, "%[" + const + "]"), reads=(lo, hi, const), writes=(lo, hi), cell=m)
+
+    if PACKED:
+        # v_pk_mul_f32 / v_pk_add_f32 round each half like the scalar instruction; (-2 x) * log2e == x * (-2 log2e) bit for bit (the
+        # factor 2 is exact, |x| <= 12.5): five multiplications and two additions become three packed instructions
+        seq.append(pk("v_pk_mul_f32 %s, %s, %s", g0, g1, "kneg2"))            # (-log2e, -log2e)
+        seq.append(pk("v_pk_mul_f32 %s, %s, %s", g2, g3, "kc2n"))             # (-2 log2e, -log2e)
+    else:
+        seq.append(v("valu", "v_mul_f32 {d}, " + L_NEG + ", {s0}", g0, g0))
+        seq.append(v("valu", "v_mul_f32 {d}, " + L_NEG + ", {s0}", g1, g1))
+        seq.append(v("valu", "v_mul_f32 {d}, -2.0, {s0}", g2, g2))
+        seq.append(v("valu", "v_mul_f32 {d}, " + L_NEG + ", {s0}", g3, g3))
+        seq.append(v("valu", "v_mul_f32 {d}, " + L_POS + ", {s0}", g2, g2))
     for g in (g0, g1, g2, g3):
         seq.append(v("trans", "v_exp_f32 {d}, {s0}", g, g))
-    seq.append(v("valu", "v_add_f32 {d}, 1.0, {s0}", g0, g0))                 # Di = 1 + ei
-    seq.append(v("valu", "v_add_f32 {d}, 1.0, {s0}", g1, g1))                 # Df = 1 + ef
+    if PACKED:
+        seq.append(pk("v_pk_add_f32 %s, %s, %s", g0, g1, "kone2"))            # Di = 1 + ei, Df = 1 + ef
+    else:
+        seq.append(v("valu", "v_add_f32 {d}, 1.0, {s0}", g0, g0))                 # Di = 1 + ei
+        seq.append(v("valu", "v_add_f32 {d}, 1.0, {s0}", g1, g1))                 # Df = 1 + ef
     seq.append(v("valu", "v_sub_f32 {d}, 1.0, {s0}", e, g2))                  # 1 - eg
     seq.append(v("valu", "v_add_f32 {d}, 1.0, {s0}", g2, g2))                 # Dg = 1 + eg
     seq.append(v("valu", "v_mul_f32 {d}, {s0}, {s1}", g0, g0, g2))            # didg
@@ -111,8 +127,11 @@ def gates(m, nan_check=False):
     seq.append(v("valu", "v_add_f32 {d}, 1.0, {s0}", g3, g3))                 # Do = 1 + eo (independent: sits behind the rcp)
     seq.append(v("valu", "v_mul_f32 {d}, {s0}, {s1}", cs, e, g2))             # c'
     seq.append(v("valu", "v_med3_f32 {d}, {s0}, {s1}, -{s1}", g0, cs, "hi12"))
-    seq.append(v("valu", "v_mul_f32 {d}, -2.0, {s0}", g0, g0))
-    seq.append(v("valu", "v_mul_f32 {d}, " + L_POS + ", {s0}", g0, g0))
+    if PACKED:
+        seq.append(v("valu", "v_mul_f32 {d}, " + L_M2POS + ", {s0}", g0, g0))
+    else:
+        seq.append(v("valu", "v_mul_f32 {d}, -2.0, {s0}", g0, g0))
+        seq.append(v("valu", "v_mul_f32 {d}, " + L_POS + ", {s0}", g0, g0))
     seq.append(v("trans", "v_exp_f32 {d}, {s0}", g0, g0))                     # ec
     seq.append(v("valu", "v_add_f32 {d}, 1.0, {s0}", g1, g0))
     seq.append(v("valu", "v_sub_f32 {d}, 1.0, {s0}", g0, g0))
@@ -121,7 +140,7 @@ def gates(m, nan_check=False):
     seq.append(v("valu", "v_mul_f32 {d}, {s0}, {s1}", g0, g0, g1))            # hv
     seq.append(Ins("cmp", "v_cmp_le_f32_e64 vcc, |%s|, 1.0" % R(g0), reads=(g0,), writes=("vcc",), cell=m))
     seq.append(Ins("sel", "v_cndmask_b32_e32 %s, 0, %s, vcc" % (R(g0), R(g0)), reads=(g0, "vcc"), writes=(g0,), cell=m))
-    assert len(seq) == 35 + (2 if nan_check else 0)
+    assert len(seq) == (30 if PACKED else 35) + (2 if nan_check else 0)
     return seq
 
 
@@ -430,6 +449,12 @@ def operand(name):
         return "v", "cst[%s]" % name[1]
     if name in ("hb", "xb"):
         return "v", name
+    if name == "kneg2":
+        return "s", "0xbfb8aa3bbfb8aa3bull"
+    if name == "kc2n":
+        return "s", "0xbfb8aa3bc038aa3bull"          # low half: -2 log2e (lane pair element 0 = the g gate), high half: -log2e (o gate)
+    if name == "kone2":
+        return "s", "0x3f8000003f800000ull"
     if name in ("hoff", "xoff", "voff", "pmo", "xmo"):
         return "n", name.upper()
     if name == "nan":
@@ -564,6 +589,7 @@ def main(argv=None):
     ap.add_argument("--vbase", type=int, default=220, help="first of the twelve physical registers of the validation read-back")
     ap.add_argument("--imm", action="store_true", help="tile offsets as template constants on loop-invariant bases (the unrolled main loop of the paired kernel)")
     ap.add_argument("--tail", type=int, default=0, help="weave the publish (plain stores) into the last K MFMAs; cell 2's gate arithmetic over the ones before")
+    ap.add_argument("--packed", action="store_true", help="experiment: gate arithmetic with v_pk_mul_f32 / v_pk_add_f32 and fused constants (same bits, 30 instead of 35 instructions per cell; measured SLOWER: 1965 vs 1870 cycles per ring step)")
     ap.add_argument("--poll-flags", default="sc0 sc1", help="timing experiments: cache policy bits of the poll DMAs")
     ap.add_argument("--all-agpr", action="store_true", help="timing experiments: W_ih tile 2 as AGPR operands too")
     ap.add_argument("--strip", default="", help="timing experiments only (wrong results): 'valu' drops the gate arithmetic, 'mfma' drops MFMAs + LDS reads")
@@ -571,8 +597,8 @@ def main(argv=None):
     ap.add_argument("--name", default="ringstep3_mfma")
     ap.add_argument("--out", default=os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bonito_amd", "csrc", "ringstep3_mfma.inc"))
     a = ap.parse_args(argv)
-    global PBASE, VBASE, ALL_AGPR, IMM, POLL_FLAGS
-    PBASE, VBASE, ALL_AGPR, IMM, POLL_FLAGS = a.pbase, a.vbase, a.all_agpr, a.imm, a.poll_flags
+    global PBASE, VBASE, ALL_AGPR, IMM, POLL_FLAGS, PACKED
+    PBASE, VBASE, ALL_AGPR, IMM, POLL_FLAGS, PACKED = a.pbase, a.vbase, a.all_agpr, a.imm, a.poll_flags, a.packed
     xdist = tuple(int(v) for v in a.xdist.split(","))
     seq = build(xdist, a.hdepth, a.xdepth, a.hpool, a.xpool, a.hf_live, a.lead, a.wgroup, a.nan_check, a.polls_at, a.xdma_at, a.validate_at, a.spread, a.publish, a.tail)
     if a.strip == "valu":
@@ -584,7 +610,7 @@ def main(argv=None):
         counts[x.kind] = counts.get(x.kind, 0) + 1
     header = "xdist=%s hdepth=%d xdepth=%d hpool=%d xpool=%d lead=%d wgroup=%d hf_live=%d nan_check=%d polls_at=%d xdma_at=%d validate_at=%d spread=%d publish=%d%s : %s" % (
         a.xdist, a.hdepth, a.xdepth, a.hpool, a.xpool, a.lead, a.wgroup, a.hf_live, a.nan_check, a.polls_at, a.xdma_at, a.validate_at, a.spread, a.publish,
-        (" imm=1" if a.imm else "") + (" tail=%d" % a.tail if a.tail else "") + (" poll_flags=%s" % a.poll_flags.replace(" ", "+") if a.poll_flags != "sc0 sc1" else ""),
+        (" imm=1" if a.imm else "") + (" packed=1" if a.packed else "") + (" tail=%d" % a.tail if a.tail else "") + (" poll_flags=%s" % a.poll_flags.replace(" ", "+") if a.poll_flags != "sc0 sc1" else ""),
         " ".join("%s=%d" % kv for kv in sorted(counts.items())))
     with open(a.out, "w") as fh:
         fh.write(render(seq, a.name, a.hf_live, header))
