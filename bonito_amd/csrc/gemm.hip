@@ -494,7 +494,13 @@ __global__ __launch_bounds__(512, 1) void gemm_big_kernel(GemmArgs p) {
 // DMA issued from inline assembly (scalar base, so that the compiler inserts no vmcnt drain in front of the fragment reads) and a counted
 // vmcnt behind the epilogue (its sixteen stores are younger than the next tile's first DMA): 586 vs 758 TFLOP/s at K = 512, 728 vs 985 at
 // K = 2048 - the eight asm statements pin the DMA issue (~50 cycles each) in front of the K-tile's fragment reads, where the builtin
-// lets the scheduler spread them; the builtin form stays.)
+// lets the scheduler spread them; the builtin form stays. And "deep": a FOUR-stage pipeline of 32-wide K slices (three requests in
+// flight, counted vmcnt waits, conflict-free 64-byte-row planes with chunk ^= (row >> 2) & 3, no compiler waits left in the K loop,
+// bit-identical): 674-930 TFLOP/s on the same shapes, within 3 % of v3 everywhere but Wqkv (787 vs 674) - the DMA latency is not the
+// bound either. Three schedules of the same work (v3, v4, deep) run at the same rate, like the stream variants of the recurrent kernel
+// (DESIGN.md 4a "the clock"): the kernel is most likely at the chip's power limit, and what separates it from the library's
+// 1.15-1.24 PFLOP/s at K >= 1024 is energy per MFMA - 2.7 MFMAs per 1 KiB fragment read here; a 128 x 128 wave tile gives 4, and
+// 32 x 32 x 16 MFMAs halve the operand reads again.)
 static int g_stagger = 0;    // bh_k_linear_stagger
 static int g_force_v1 = 0;   // test / A-B hook (bh_k_linear_force_v1): 1 = v1 only, 2 = never v3
 
