@@ -214,9 +214,9 @@ def argparser():
                         help="batches in flight in the encoder (engine replicas per GPU); 2 pays off with --quantize, whose "
                              "recurrent kernels of two lanes share every CU")
     parser.add_argument("--per-call", default=0, type=int,
-                        help="batches of --batchsize chunks per engine call; 0 = automatic (calls of up to 1024 chunks for the "
-                             "192...512-wide fp16 models, whose recurrent kernel then pairs rings: 2.97 -> 1.9 ms per layer and 512 "
-                             "chunks at 384 hidden units; results do not depend on it)")
+                        help="batches of --batchsize chunks per engine call; 0 = automatic (calls of up to 2048 chunks for the "
+                             "192...512-wide fp16 models: the recurrent kernel pairs rings, 2.97 -> 1.8 ms per layer and 512 chunks at "
+                             "384 hidden units, and two such launches per layer keep the pipeline full; results do not depend on it)")
     parser.add_argument("--min-qscore", default=0.0, type=float)
     parser.add_argument("--sam", action="store_true", default=False, help="write unaligned SAM instead of FASTQ")
     parser.add_argument("--fasta", action="store_true", default=False)

@@ -235,12 +235,15 @@ def max_lanes(model, quantize=False):
     return 1
 
 
-def batches_per_call(model, batchsize, quantize=False):
+def batches_per_call(model, batchsize, quantize=False, chunksize=None):
     """How many `batchsize`-chunk batches one ENGINE call should carry. The reference hands koi one batch per forward
     (crf/basecall.py:70-72) and `batchsize` keeps that meaning for the caller: chunks are independent, so results do not depend on
     how they are grouped (tests). For the 192...512-wide fp16 recurrent layers the engine's kernel carries two rings of 16 chunks
     per workgroup once a call holds more than one launch of single rings (32 rings = 512 chunks at 384 hidden units), which takes a
-    512-chunk batch from 2.97 to 1.9 ms per layer: calls of up to 1024 chunks there, one batch per call everywhere else."""
+    512-chunk batch from 2.97 to 1.8 ms per layer, and a call of TWO such launches per layer keeps the two-stream pipeline full
+    across call boundaries (hac, batches of 512: 14.9 ms per batch in calls of 1024 chunks, 13.96 in calls of 2048 - bench.py
+    --per-call 2 / 4 on one box): calls of up to 2048 chunks there, as long as the score tensor of a call stays below 8 GiB; one batch
+    per call everywhere else."""
     if quantize:
         return 1
     sizes = lstm_widths(model)
@@ -248,8 +251,14 @@ def batches_per_call(model, batchsize, quantize=False):
         return 1
     wpr = max(1, (max(sizes) // (12 if max(sizes) % 48 == 0 else 16)) // 4)        # workgroups per ring
     rings_per_launch = max(1, 256 // (8 * wpr)) * 8                                   # single rings on 256 CUs
-    target = 2 * rings_per_launch * 16                                                # chunks of one paired launch
-    return max(1, min(4, target // max(1, int(batchsize))))
+    target = 2 * 2 * rings_per_launch * 16                                            # chunks of two paired launches
+    if chunksize:
+        seqdist, stride = getattr(model, "seqdist", None), max(1, int(getattr(model, "stride", 1) or 1))
+        states = len(getattr(seqdist, "alphabet", "NACGT")) - 1 if seqdist is not None else 4
+        n_scores = (states ** int(getattr(seqdist, "state_len", 4))) * states if seqdist is not None else 1024
+        per_chunk = (int(chunksize) // stride + 1) * n_scores * 2                     # bytes of fp16 scores per chunk
+        target = min(target, max(int(batchsize), (8 << 30) // max(1, per_chunk)))
+    return max(1, min(8, target // max(1, int(batchsize))))
 
 
 def chunk_batches(reads, chunksize, overlap, batchsize, pin=False, nbuf=4):
@@ -339,7 +348,7 @@ def basecall(model, reads, chunksize=4000, overlap=100, batchsize=32, reverse=Fa
     identical for any value of either."""
     pipe = _Pipeline(model, decoder=decoder, reverse=reverse, lanes=lanes)
     if not per_call:
-        per_call = batches_per_call(model, batchsize, _resolved_quantize(model))
+        per_call = batches_per_call(model, batchsize, _resolved_quantize(model), chunksize)
     batchsize = int(batchsize) * max(1, int(per_call))
     # up to 4 batches are in flight behind the generator (three single-slot queues + the consumer): recycle after 8
     batches = thread_iter(chunk_batches(reads, chunksize, overlap, batchsize, pin=torch.cuda.is_available(), nbuf=8))
@@ -421,7 +430,7 @@ def basecall_records(model, reads, mode, chunksize=4000, overlap=100, batchsize=
     the per-read host work in the library (`records_from_planes`)."""
     pipe = _Pipeline(model, decoder=decoder, reverse=reverse, lanes=lanes)
     if not per_call:
-        per_call = batches_per_call(model, batchsize, _resolved_quantize(model))
+        per_call = batches_per_call(model, batchsize, _resolved_quantize(model), chunksize)
     batchsize = int(batchsize) * max(1, int(per_call))
     if raw is not None:
         batches = thread_iter(raw_chunk_batches(reads, chunksize, overlap, batchsize, next(model.parameters()).device, **raw))
@@ -494,7 +503,7 @@ def basecall_raw(model, reads, chunksize=4000, overlap=100, batchsize=32, revers
     device. Same results as ``basecall(model, [reader.Read(...) ...])`` on the same reads (tests compare them)."""
     pipe = _Pipeline(model, decoder=decoder, reverse=reverse, lanes=lanes)
     if not per_call:
-        per_call = batches_per_call(model, batchsize, _resolved_quantize(model))
+        per_call = batches_per_call(model, batchsize, _resolved_quantize(model), chunksize)
     batchsize = int(batchsize) * max(1, int(per_call))
     device = next(model.parameters()).device
     batches = thread_iter(raw_chunk_batches(reads, chunksize, overlap, batchsize, device, scaling_strategy=scaling_strategy,

@@ -380,14 +380,16 @@ def test_exchange_timeout_is_retried_serially_and_the_run_completes(monkeypatch)
 
 
 def test_batches_per_engine_call_do_not_change_the_calls():
-    """`per_call` (batches per engine call; automatic = calls of up to 1024 chunks for the 384-wide fp16 model, whose recurrent
+    """`per_call` (batches per engine call; automatic = calls of up to 2048 chunks for the 384-wide fp16 model, whose recurrent
     kernel then pairs rings) groups chunks differently and nothing else: identical records for 1, 2, 4 and the automatic value."""
     from bonito_amd import synthetic
     from bonito_amd.crf.basecall import batches_per_call, max_lanes
     model = synthetic.make_model("hac", batchsize=256, chunksize=2400)
     model.use_koi(batchsize=256, chunksize=2400, quantize=False)
     model = model.half().to("cuda")
-    assert batches_per_call(model, 512) == 2 and batches_per_call(model, 256) == 4 and batches_per_call(model, 2048) == 1
+    assert batches_per_call(model, 512) == 4 and batches_per_call(model, 256) == 8 and batches_per_call(model, 2048) == 1
+    assert batches_per_call(model, 512, chunksize=10000) == 4 and batches_per_call(model, 512, chunksize=20000) == 2     # (8 GiB of scores per call)
+    assert batches_per_call(model, 512, chunksize=40000) == 1
     assert batches_per_call(model, 512, quantize=True) == 1 and max_lanes(model) == 1 and max_lanes(model, True) == 2
     fast = synthetic.make_model("fast", batchsize=64, chunksize=2400)
     assert batches_per_call(fast, 512) == 1 and max_lanes(fast) > 8
