@@ -58,3 +58,18 @@ def test_config_loads_renamed_state_dict(path):
     model.load_state_dict(state)
     for (k, v), (k2, v2) in zip(model.state_dict().items(), donor.state_dict().items()):
         assert k == k2 and torch.equal(v, v2), k
+
+
+def test_engine_call_size_policy():
+    """`batches_per_call` (crf/basecall.py): the 192...512-wide fp16 recurrent models get engine calls of two paired launches per layer
+    (2048 chunks at 384 hidden units), capped by 8 GiB of scores per call; every other model, and the 8-bit path, one batch per call.
+    Pure host logic: which chunks share a call never changes a result (GPU test `test_batches_per_engine_call_do_not_change_the_calls`)."""
+    from bonito_amd import synthetic
+    from bonito_amd.crf.basecall import batches_per_call
+    hac = synthetic.make_model("hac", batchsize=64, chunksize=1200)
+    assert [batches_per_call(hac, b) for b in (128, 256, 512, 1024, 2048, 4096)] == [8, 8, 4, 2, 1, 1]
+    assert batches_per_call(hac, 512, quantize=True) == 1
+    assert [batches_per_call(hac, 512, chunksize=c) for c in (4000, 10000, 20000, 40000)] == [4, 4, 2, 1]
+    for name in ("fast", "sup_lstm"):
+        assert batches_per_call(synthetic.make_model(name, batchsize=16, chunksize=1200), 512, chunksize=10000) == 1, name
+    assert batches_per_call(synthetic.make_transformer_model(batchsize=16, chunksize=1200), 256, chunksize=12000) == 1
