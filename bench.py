@@ -17,8 +17,8 @@ The warm-up is W steps AND at least --warmup-seconds of engine calls (clocks, in
 about a second; a 20-step run used to be timed cold: mean 20.3 ms against a median of 16.3).
 
 More legs in the same JSON line (rank 0, N = 1 only; each bounded to a few seconds):
-  per_call_1    -- the product path's call shape: ONE batch of 512 chunks per engine call (`bonito basecaller` default batchsize),
-                   with the roofline of the kernel that serves it
+  per_call_1    -- the reference's call shape: ONE batch of 512 chunks per engine call (what `--per-call 1` or a short input runs; the
+                   product path groups batches into the default leg's calls of 2048 chunks), with the roofline of the kernel that serves it
   other_configs -- the other BASELINE.json configurations (fast 512 x 10000, sup transformer 256 x 12000, sup LSTM-1024
                    256 x 20000, hac --quantize), each a child process of this script with a short timed region
 
