@@ -210,9 +210,9 @@ def argparser():
     parser.add_argument("--chunksize", default=None, type=int)
     parser.add_argument("--batchsize", default=None, type=int)
     parser.add_argument("--max-reads", default=0, type=int)
-    parser.add_argument("--lanes", default=1, type=int,
-                        help="batches in flight in the encoder (engine replicas per GPU); 2 pays off with --quantize, whose "
-                             "recurrent kernels of two lanes share every CU")
+    parser.add_argument("--lanes", default=0, type=int,
+                        help="batches in flight in the encoder (engine replicas per GPU); 0 = automatic: 2 with the 8-bit recurrent "
+                             "path (--quantize at 384 hidden units: the kernels of two lanes share every CU), 1 otherwise")
     parser.add_argument("--per-call", default=0, type=int,
                         help="batches of --batchsize chunks per engine call; 0 = automatic (calls of up to 2048 chunks for the "
                              "192...512-wide fp16 models: the recurrent kernel pairs rings, 2.97 -> 1.8 ms per layer and 512 chunks at "

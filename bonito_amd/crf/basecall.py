@@ -106,6 +106,8 @@ class _Pipeline:
         # (bh_set_option "lstm_q8_variant" 2) the persistent kernels of two lanes share every CU and each hides the other's
         # exchange round trip (hac-sized model: 18.8 -> 15.7 ms per batch); the fp16 kernels fill the register file and gain nothing.
         quantize = _resolved_quantize(model)
+        if not lanes:                                  # automatic: two lanes where the kernels are built to share the CUs (8-bit path)
+            lanes = 2 if quantize and 2 <= max_lanes(model, quantize) < (1 << 20) else 1
         self.lanes = max(1, min(int(lanes), max_lanes(model, quantize)))
         if self.lanes > 1 and quantize:
             hip_decode.set_option("lstm_q8_variant", 2)    # the 8-bit kernels compiled for two workgroups per CU
@@ -235,16 +237,19 @@ def max_lanes(model, quantize=False):
     return 1
 
 
-def batches_per_call(model, batchsize, quantize=False, chunksize=None):
+def batches_per_call(model, batchsize, quantize=False, chunksize=None, lanes=1):
     """How many `batchsize`-chunk batches one ENGINE call should carry. The reference hands koi one batch per forward
     (crf/basecall.py:70-72) and `batchsize` keeps that meaning for the caller: chunks are independent, so results do not depend on
     how they are grouped (tests). For the 192...512-wide fp16 recurrent layers the engine's kernel carries two rings of 16 chunks
     per workgroup once a call holds more than one launch of single rings (32 rings = 512 chunks at 384 hidden units), which takes a
     512-chunk batch from 2.97 to 1.8 ms per layer, and a call of TWO such launches per layer keeps the two-stream pipeline full
     across call boundaries (hac, batches of 512: 14.9 ms per batch in calls of 1024 chunks, 13.96 in calls of 2048 - bench.py
-    --per-call 2 / 4 on one box): calls of up to 2048 chunks there, as long as the score tensor of a call stays below 8 GiB; one batch
-    per call everywhere else."""
+    --per-call 2 / 4 on one box): calls of up to 2048 chunks there, as long as the score tensor of a call stays below 8 GiB; the
+    8-bit path with its two lanes: calls of 1024 chunks (one launch of the two-workgroups-per-CU kernel; bench.py: 14.6 -> 13.7 ms per
+    batch); one batch per call everywhere else."""
     if quantize:
+        if lanes >= 2 and max_lanes(model, True) == 2:
+            return max(1, min(4, 1024 // max(1, int(batchsize))))
         return 1
     sizes = lstm_widths(model)
     if not sizes or not all(192 <= h <= 512 and (h % 48 == 0 or h % 64 == 0) for h in sizes):
@@ -341,14 +346,14 @@ def chunk_batches(reads, chunksize, overlap, batchsize, pin=False, nbuf=4):
         yield tuple(keys), bufs[cur][:pos]
 
 
-def basecall(model, reads, chunksize=4000, overlap=100, batchsize=32, reverse=False, rna=False, decoder="beam", lanes=1,
+def basecall(model, reads, chunksize=4000, overlap=100, batchsize=32, reverse=False, rna=False, decoder="beam", lanes=0,
              per_call=0):
     """Basecalls a set of reads: yields (read, {sequence, qstring, moves, stride}). `lanes`: batches in flight in the encoder
-    (engine replicas); `per_call`: batches of `batchsize` chunks per engine call (0 = `batches_per_call`); results are
+    (engine replicas; 0 = automatic: two for the 8-bit recurrent path at 384 hidden units, one otherwise); `per_call`: batches of `batchsize` chunks per engine call (0 = `batches_per_call`); results are
     identical for any value of either."""
     pipe = _Pipeline(model, decoder=decoder, reverse=reverse, lanes=lanes)
     if not per_call:
-        per_call = batches_per_call(model, batchsize, _resolved_quantize(model), chunksize)
+        per_call = batches_per_call(model, batchsize, _resolved_quantize(model), chunksize, pipe.lanes)
     batchsize = int(batchsize) * max(1, int(per_call))
     # up to 4 batches are in flight behind the generator (three single-slot queues + the consumer): recycle after 8
     batches = thread_iter(chunk_batches(reads, chunksize, overlap, batchsize, pin=torch.cuda.is_available(), nbuf=8))
@@ -424,13 +429,13 @@ def records_from_planes(batches, chunksize, overlap, stride, mode, min_qscore=0.
 
 
 def basecall_records(model, reads, mode, chunksize=4000, overlap=100, batchsize=32, reverse=False, rna=False, decoder="beam",
-                     lanes=1, per_call=0, min_qscore=0.0, raw=None):
+                     lanes=0, per_call=0, min_qscore=0.0, raw=None):
     """`basecall` (or, with `raw` = the keyword arguments of the device-side ingest, `basecall_raw`) + `io.format_record` for the
     writers of the product path: yields the (text, summary_row, log) triples of the reads in order - the same bytes (tests), with
     the per-read host work in the library (`records_from_planes`)."""
     pipe = _Pipeline(model, decoder=decoder, reverse=reverse, lanes=lanes)
     if not per_call:
-        per_call = batches_per_call(model, batchsize, _resolved_quantize(model), chunksize)
+        per_call = batches_per_call(model, batchsize, _resolved_quantize(model), chunksize, pipe.lanes)
     batchsize = int(batchsize) * max(1, int(per_call))
     if raw is not None:
         batches = thread_iter(raw_chunk_batches(reads, chunksize, overlap, batchsize, next(model.parameters()).device, **raw))
@@ -498,12 +503,12 @@ def raw_chunk_batches(reads, chunksize, overlap, batchsize, device, group_sample
 
 
 def basecall_raw(model, reads, chunksize=4000, overlap=100, batchsize=32, reverse=False, rna=False, decoder="beam",
-                 scaling_strategy=None, norm_params=None, do_trim=True, lanes=1, per_call=0):
+                 scaling_strategy=None, norm_params=None, do_trim=True, lanes=0, per_call=0):
     """`basecall` for raw int16 reads (`.raw`, `.scaling`, `.offset`): the signal pre-processing of reader.Read runs on the
     device. Same results as ``basecall(model, [reader.Read(...) ...])`` on the same reads (tests compare them)."""
     pipe = _Pipeline(model, decoder=decoder, reverse=reverse, lanes=lanes)
     if not per_call:
-        per_call = batches_per_call(model, batchsize, _resolved_quantize(model), chunksize)
+        per_call = batches_per_call(model, batchsize, _resolved_quantize(model), chunksize, pipe.lanes)
     batchsize = int(batchsize) * max(1, int(per_call))
     device = next(model.parameters()).device
     batches = thread_iter(raw_chunk_batches(reads, chunksize, overlap, batchsize, device, scaling_strategy=scaling_strategy,

@@ -68,7 +68,8 @@ def test_engine_call_size_policy():
     from bonito_amd.crf.basecall import batches_per_call
     hac = synthetic.make_model("hac", batchsize=64, chunksize=1200)
     assert [batches_per_call(hac, b) for b in (128, 256, 512, 1024, 2048, 4096)] == [8, 8, 4, 2, 1, 1]
-    assert batches_per_call(hac, 512, quantize=True) == 1
+    assert batches_per_call(hac, 512, quantize=True) == 1 and batches_per_call(hac, 512, quantize=True, lanes=2) == 2
+    assert batches_per_call(hac, 256, quantize=True, lanes=2) == 4 and batches_per_call(hac, 2048, quantize=True, lanes=2) == 1
     assert [batches_per_call(hac, 512, chunksize=c) for c in (4000, 10000, 20000, 40000)] == [4, 4, 2, 1]
     for name in ("fast", "sup_lstm"):
         assert batches_per_call(synthetic.make_model(name, batchsize=16, chunksize=1200), 512, chunksize=10000) == 1, name

@@ -27,6 +27,7 @@ def parse():
     ap.add_argument("--mean-len", type=int, default=100000)
     ap.add_argument("--devices", default=None)
     ap.add_argument("--reps", type=int, default=2)
+    ap.add_argument("--quantize", action="store_true", help="the 8-bit recurrent path (two lanes, calls of 1024 chunks: the automatic choice)")
     ap.add_argument("--batchsize", type=int, default=512, help="chunks per engine call (more than 512: the recurrent kernels pair rings)")
     return ap.parse_args()
 
@@ -69,7 +70,7 @@ def main():
         parallel.init("gloo")
     util.limit_host_threads(8)
     model = synthetic.make_model(a.model, batchsize=a.batchsize, chunksize=10000)
-    model.use_koi(batchsize=a.batchsize, chunksize=9996, quantize=False)
+    model.use_koi(batchsize=a.batchsize, chunksize=9996, quantize=a.quantize)
     model = model.half().cuda()
 
     class Read:
