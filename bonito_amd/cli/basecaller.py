@@ -94,6 +94,9 @@ def launch(args, argv):
 
 def main(args, argv=None):
     from bonito_amd import parallel
+    # several lanes (narrow models, the 8-bit path) need more hardware queues than the runtime's default of four, or their streams
+    # share queues and serialise; must be set before the HIP runtime starts. Measured harmless for the one-lane models.
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     if getattr(args, "devices", None) and "RANK" not in os.environ:
         return launch(args, list(argv if argv is not None else getattr(args, "_argv", sys.argv[2:])))
     rank, world, local = parallel.env_rank_world()
@@ -212,7 +215,8 @@ def argparser():
     parser.add_argument("--max-reads", default=0, type=int)
     parser.add_argument("--lanes", default=0, type=int,
                         help="batches in flight in the encoder (engine replicas per GPU); 0 = automatic: 2 with the 8-bit recurrent "
-                             "path (--quantize at 384 hidden units: the kernels of two lanes share every CU), 1 otherwise")
+                             "path (--quantize at 384 hidden units: the kernels of two lanes share every CU), 3 for the narrow (64 / 96 / 128 "
+                             "wide) models whose recurrent kernel fills an eighth of the chip, 1 otherwise")
     parser.add_argument("--per-call", default=0, type=int,
                         help="batches of --batchsize chunks per engine call; 0 = automatic (calls of up to 2048 chunks for the "
                              "192...512-wide fp16 models: the recurrent kernel pairs rings, 2.97 -> 1.8 ms per layer and 512 chunks at "

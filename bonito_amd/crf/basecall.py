@@ -106,8 +106,11 @@ class _Pipeline:
         # (bh_set_option "lstm_q8_variant" 2) the persistent kernels of two lanes share every CU and each hides the other's
         # exchange round trip (hac-sized model: 18.8 -> 15.7 ms per batch); the fp16 kernels fill the register file and gain nothing.
         quantize = _resolved_quantize(model)
-        if not lanes:                                  # automatic: two lanes where the kernels are built to share the CUs (8-bit path)
-            lanes = 2 if quantize and 2 <= max_lanes(model, quantize) < (1 << 20) else 1
+        if not lanes:
+            # automatic: two lanes where the kernels are built to share the CUs (8-bit path), three for the narrow models whose
+            # ring-in-a-workgroup kernel leaves most CUs idle (bench.py: fast, 1 lane 8.9 ms per batch, 3 lanes x 4 batches per call 2.4)
+            cap = max_lanes(model, quantize)
+            lanes = 3 if cap >= (1 << 20) and lstm_widths(model) else 2 if quantize and cap >= 2 else 1
         self.lanes = max(1, min(int(lanes), max_lanes(model, quantize)))
         if self.lanes > 1 and quantize:
             hip_decode.set_option("lstm_q8_variant", 2)    # the 8-bit kernels compiled for two workgroups per CU
@@ -246,12 +249,14 @@ def batches_per_call(model, batchsize, quantize=False, chunksize=None, lanes=1):
     across call boundaries (hac, batches of 512: 14.9 ms per batch in calls of 1024 chunks, 13.96 in calls of 2048 - bench.py
     --per-call 2 / 4 on one box): calls of up to 2048 chunks there, as long as the score tensor of a call stays below 8 GiB; the
     8-bit path with its two lanes: calls of 1024 chunks (one launch of the two-workgroups-per-CU kernel; bench.py: 14.6 -> 13.7 ms per
-    batch); one batch per call everywhere else."""
+    batch); the narrow (64 / 96 / 128 wide) models with their three lanes: calls of 2048 chunks; one batch per call everywhere else."""
+    sizes = lstm_widths(model)
+    if sizes and all(h in (64, 96, 128) for h in sizes):         # ring-in-a-workgroup kernels: a 512-chunk batch fills an eighth of the chip
+        return max(1, min(4, 2048 // max(1, int(batchsize)))) if lanes >= 2 else 1
     if quantize:
         if lanes >= 2 and max_lanes(model, True) == 2:
             return max(1, min(4, 1024 // max(1, int(batchsize))))
         return 1
-    sizes = lstm_widths(model)
     if not sizes or not all(192 <= h <= 512 and (h % 48 == 0 or h % 64 == 0) for h in sizes):
         return 1
     wpr = max(1, (max(sizes) // (12 if max(sizes) % 48 == 0 else 16)) // 4)        # workgroups per ring

@@ -11,6 +11,7 @@ its own records, rank 0 merges them in input order and writes them (to /dev/null
 """
 import argparse
 import os
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")     # as the CLI does (several lanes need more than four hardware queues)
 import subprocess
 import socket
 import sys
