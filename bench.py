@@ -205,7 +205,8 @@ def cpu_baseline(name, chunk, decoder="beam", hard_timeout=120.0):
 
 
 OTHER_CONFIGS = {            # BASELINE.json configs 2, 4, 5 (+ the 8-bit path of config 3); the headline itself is config 3
-    "fast": ["--model", "fast", "--steps", "96", "--warmup", "24"],
+    "fast": ["--model", "fast", "--steps", "384", "--warmup", "48"],        # (three lanes x four batches per call: 96 steps were 8 calls per lane,
+                                                                            #  half of them ramp-up - 2.53 ms against 2.37 over 384 steps)
     "sup": ["--model", "sup", "--steps", "12", "--warmup", "3"],
     "sup_lstm": ["--model", "sup_lstm", "--steps", "8", "--warmup", "2"],
     "hac_quantize": ["--model", "hac", "--quantize", "--steps", "48", "--warmup", "8"],
