@@ -106,12 +106,7 @@ class _Pipeline:
         # (bh_set_option "lstm_q8_variant" 2) the persistent kernels of two lanes share every CU and each hides the other's
         # exchange round trip (hac-sized model: 18.8 -> 15.7 ms per batch); the fp16 kernels fill the register file and gain nothing.
         quantize = _resolved_quantize(model)
-        if not lanes:
-            # automatic: two lanes where the kernels are built to share the CUs (8-bit path), three for the narrow models whose
-            # ring-in-a-workgroup kernel leaves most CUs idle (bench.py: fast, 1 lane 8.9 ms per batch, 3 lanes x 4 batches per call 2.4)
-            cap = max_lanes(model, quantize)
-            lanes = 3 if cap >= (1 << 20) and lstm_widths(model) else 2 if quantize and cap >= 2 else 1
-        self.lanes = max(1, min(int(lanes), max_lanes(model, quantize)))
+        self.lanes = max(1, min(int(lanes) or auto_lanes(model, quantize), max_lanes(model, quantize)))
         if self.lanes > 1 and quantize:
             hip_decode.set_option("lstm_q8_variant", 2)    # the 8-bit kernels compiled for two workgroups per CU
         self.enc_streams = [torch.cuda.Stream(self.device) for _ in range(self.lanes)]
@@ -238,6 +233,16 @@ def max_lanes(model, quantize=False):
     if quantize and all(h == 384 for h in sizes):
         return 2
     return 1
+
+
+def auto_lanes(model, quantize=False):
+    """`lanes = 0`: two lanes where the kernels are built to share the CUs (8-bit path at 384 hidden units), three for the narrow
+    models whose ring-in-a-workgroup kernel leaves most CUs idle (bench.py, fast: 1 lane 8.9 ms per batch, 3 lanes x 4 batches per
+    call 2.4), one everywhere else."""
+    cap = max_lanes(model, quantize)
+    if cap >= (1 << 20):
+        return 3 if lstm_widths(model) else 1
+    return 2 if quantize and cap >= 2 else 1
 
 
 def batches_per_call(model, batchsize, quantize=False, chunksize=None, lanes=1):

@@ -65,8 +65,12 @@ def test_engine_call_size_policy():
     (2048 chunks at 384 hidden units), capped by 8 GiB of scores per call; every other model, and the 8-bit path, one batch per call.
     Pure host logic: which chunks share a call never changes a result (GPU test `test_batches_per_engine_call_do_not_change_the_calls`)."""
     from bonito_amd import synthetic
-    from bonito_amd.crf.basecall import batches_per_call
+    from bonito_amd.crf.basecall import auto_lanes, batches_per_call
     hac = synthetic.make_model("hac", batchsize=64, chunksize=1200)
+    assert (auto_lanes(hac), auto_lanes(hac, True)) == (1, 2)
+    assert auto_lanes(synthetic.make_model("fast", batchsize=16, chunksize=1200)) == 3
+    assert auto_lanes(synthetic.make_model("sup_lstm", batchsize=16, chunksize=1200), True) == 1
+    assert auto_lanes(synthetic.make_transformer_model(batchsize=16, chunksize=1200)) == 1
     assert [batches_per_call(hac, b) for b in (128, 256, 512, 1024, 2048, 4096)] == [8, 8, 4, 2, 1, 1]
     assert batches_per_call(hac, 512, quantize=True) == 1 and batches_per_call(hac, 512, quantize=True, lanes=2) == 2
     assert batches_per_call(hac, 256, quantize=True, lanes=2) == 4 and batches_per_call(hac, 2048, quantize=True, lanes=2) == 1
