@@ -37,6 +37,24 @@ def parse_devices(spec):
     return out
 
 
+def child_device_mask(dev, environ):
+    """HIP_VISIBLE_DEVICES for the worker that gets `--devices` entry `dev`. Indices are relative to what THIS process may see.
+    HIP numbers its devices WITHIN the set ROCR_VISIBLE_DEVICES leaves (and that variable stays in the child's environment), so:
+    parent mask in HIP_VISIBLE_DEVICES (with or without a ROCR mask underneath): entry `dev` of that list - its values already
+    are indices into the ROCR set; ROCR mask only, or no mask: `dev` itself, bounds-checked against the ROCR list (advisor
+    finding, round 3: translating through a ROCR-only mask gave the children indices of the physical numbering on top of the
+    filtered set - no device)."""
+    hip = [d.strip() for d in (environ.get("HIP_VISIBLE_DEVICES") or "").split(",") if d.strip()]
+    rocr = [d.strip() for d in (environ.get("ROCR_VISIBLE_DEVICES") or "").split(",") if d.strip()]
+    if hip:
+        if dev >= len(hip):
+            raise SystemExit("> error: --devices names device %d but only %d are visible (HIP_VISIBLE_DEVICES=%s)" % (dev, len(hip), ",".join(hip)))
+        return hip[dev]
+    if rocr and dev >= len(rocr):
+        raise SystemExit("> error: --devices names device %d but only %d are visible (ROCR_VISIBLE_DEVICES=%s)" % (dev, len(rocr), ",".join(rocr)))
+    return str(dev)
+
+
 def launch(args, argv):
     """``--devices``: one worker process per listed GPU (the reference is single-device; SURVEY 8e: shard by read, no
     collective). Each worker sees only its GPU (HIP_VISIBLE_DEVICES), takes the reads whose index is congruent to its rank,
@@ -55,15 +73,9 @@ def launch(args, argv):
             skip = True
         elif not tok.startswith(("--devices=", "--device=")):
             child_argv.append(tok)
-    # indices are relative to what THIS process may see: honour a HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES mask of the parent
-    parent_mask = os.environ.get("HIP_VISIBLE_DEVICES") or os.environ.get("ROCR_VISIBLE_DEVICES")
-    visible = [d.strip() for d in parent_mask.split(",") if d.strip()] if parent_mask else None
     procs = []
     for rank, dev in enumerate(devices):
-        if visible is not None:
-            if dev >= len(visible):
-                raise SystemExit("> error: --devices names device %d but only %d are visible (%s)" % (dev, len(visible), parent_mask))
-            dev = visible[dev]
+        dev = child_device_mask(dev, os.environ)
         env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(len(devices)), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), HIP_VISIBLE_DEVICES=str(dev), BONITO_AMD_SPAWNED="1")
         env.pop("CUDA_VISIBLE_DEVICES", None)

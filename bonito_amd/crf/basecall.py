@@ -116,29 +116,38 @@ class _Pipeline:
         self.dec_stream = torch.cuda.Stream(self.device)
         self.copy_stream = torch.cuda.Stream(self.device)
         self.decoders = {}
+        import threading
+        self.enc_lock = threading.RLock()              # encoder thread vs. a serial retry from the decode thread
 
-    def check_engine(self):
-        for eng in [getattr(self.model, "_hip", None)] + self.replicas[1:]:
-            if eng is not None:
-                eng.poll()
+    def engine(self, lane):
+        return getattr(self.model, "_hip", None) if lane == 0 else self.replicas[lane]
 
-    def _retry_serially(self, dev_batch):
+    def check_forward(self, lane, ticket):
+        """Raises HipEngineError iff forward `ticket` of lane `lane`'s engine hit the spin bound of a persistent kernel. Only that
+        forward's flag is read (`bh_encoder_error_flag_at`): the batches behind it in the pipeline keep theirs (advisor finding,
+        round 3: with one sticky flag per engine, the retry of batch i erased the evidence against batches i+1 and i+2)."""
+        eng = self.engine(lane)
+        if eng is not None:
+            eng.poll_ticket(ticket)
+
+    def _retry_serially(self, dev_batch, lane=0):
         """An exchange timeout (a persistent recurrent kernel whose peers were not co-resident in time: a second process on the GPU,
-        more lanes than the kernels can co-host) invalidates the batch, not the run: with nothing else in flight, clear the flag
-        and run encoder + decoder of this batch again; only a second failure is an error (bonito/crf/basecall.py:58-82 has
-        nothing that can time out, so a drop-in must not abort where the reference would have carried on)."""
-        torch.cuda.synchronize(self.device)
-        for eng in [getattr(self.model, "_hip", None)] + self.replicas[1:]:
-            if eng is not None:
-                eng.clear_error()
-        with torch.inference_mode():
-            scores = self.model(dev_batch)
-            if self.reverse:
-                scores = self.model.seqdist.reverse_complement(scores)
+        more lanes than the kernels can co-host) invalidates the batch, not the run: keep the encoder thread from issuing anything
+        new (`enc_lock`), let what is in flight finish, and run encoder + decoder of THIS batch again on the engine that produced
+        it, alone on the device; only a second failure is an error (bonito/crf/basecall.py:58-82 has nothing that can time out, so
+        a drop-in must not abort where the reference would have carried on). The batches that were in flight meanwhile are checked
+        against their own tickets when their turn comes, and retried the same way."""
+        with self.enc_lock:
             torch.cuda.synchronize(self.device)
-            self.model._hip.check()                   # raises HipEngineError if the serial run timed out as well
-            key = tuple(scores.shape[1:])
-            planes = self.decoders[key].submit(scores).result_planes()
+            with torch.inference_mode():
+                scores = self._forward(lane, dev_batch)
+                ticket = self.engine(lane).last_ticket
+                if self.reverse:
+                    scores = self.model.seqdist.reverse_complement(scores)
+                torch.cuda.synchronize(self.device)
+                self.check_forward(lane, ticket)          # raises HipEngineError if the serial run timed out as well
+                key = tuple(scores.shape[1:])
+                planes = self.decoders[key].submit(scores).result_planes()
         self.retries += 1
         return planes
 
@@ -149,6 +158,18 @@ class _Pipeline:
             self.replicas[lane] = self.model.engine_replica(x)
         return self.replicas[lane](x)
 
+    def _encode_on(self, lane, enc_stream, x):
+        """forward (+ reverse complement) of one device batch on its lane's stream -> (scores, ready event, ticket). The lock keeps
+        a serial retry (decode thread) and this thread from driving an engine - one workspace, one flag array - at the same time."""
+        with self.enc_lock:
+            scores = self._forward(lane, x)
+            ticket = self.engine(lane).last_ticket
+            if self.reverse:
+                scores = self.model.seqdist.reverse_complement(scores)
+            ready = torch.cuda.Event()
+            ready.record(enc_stream)
+        return scores, ready, ticket
+
     def encode(self, batch):
         lane = self.n_encoded % self.lanes
         self.n_encoded += 1
@@ -157,12 +178,8 @@ class _Pipeline:
             with torch.inference_mode(), torch.cuda.stream(enc_stream):
                 enc_stream.wait_stream(torch.cuda.default_stream(self.device))
                 batch.record_stream(enc_stream)
-                scores = self._forward(lane, batch)
-                if self.reverse:
-                    scores = self.model.seqdist.reverse_complement(scores)
-                ready = torch.cuda.Event()
-                ready.record(enc_stream)
-            return scores, ready, batch
+                scores, ready, ticket = self._encode_on(lane, enc_stream, batch)
+            return scores, ready, batch, (lane, ticket)
         # H2D on its own stream, waited for on the host: the (recycled, pinned) batch buffer is free again when this
         # method returns, and the copy never queues behind the previous batch's encoder.
         with torch.inference_mode(), torch.cuda.stream(self.copy_stream):
@@ -173,14 +190,10 @@ class _Pipeline:
         with torch.inference_mode(), torch.cuda.stream(enc_stream):
             enc_stream.wait_event(copied)
             dev_batch.record_stream(enc_stream)
-            scores = self._forward(lane, dev_batch)
-            if self.reverse:
-                scores = self.model.seqdist.reverse_complement(scores)
-            ready = torch.cuda.Event()
-            ready.record(enc_stream)
-        return scores, ready, dev_batch
+            scores, ready, ticket = self._encode_on(lane, enc_stream, dev_batch)
+        return scores, ready, dev_batch, (lane, ticket)
 
-    def decode(self, scores, ready, dev_batch=None):
+    def decode(self, scores, ready, dev_batch=None, origin=None):
         key = tuple(scores.shape[1:])
         dec = self.decoders.get(key)
         if dec is None or dec.N < scores.shape[0]:
@@ -196,12 +209,13 @@ class _Pipeline:
         # engine's timeout flag behind it) has completed: a spin timeout in a persistent kernel means these planes were
         # decoded from invalid scores -> never yield them (reference seam: crf/basecall.py:27-45): run the batch again with
         # nothing else in flight, raise only if that fails too
+        lane, ticket = origin if origin is not None else (0, getattr(self.engine(0), "last_ticket", None))
         try:
-            self.check_engine()
+            self.check_forward(lane, ticket)
         except _lib.HipEngineError:
             if dev_batch is None:
                 raise
-            planes = self._retry_serially(dev_batch)
+            planes = self._retry_serially(dev_batch, lane)
         if self.mode == "viterbi":
             path = planes[1]                 # plane 1 carries the path for the Viterbi decoder
             planes[0] = hip_decode.path_to_sequence(path)
@@ -221,17 +235,30 @@ def lstm_widths(model):
     return [m.rnn.hidden_size for m in model.modules() if hasattr(m, "rnn") and hasattr(m.rnn, "hidden_size")]
 
 
+def q8_covers(h):
+    """Hidden sizes the 8-bit recurrent kernel is instantiated for (`bh_k_lstm_q8_units` in csrc/lstm_q8.hip; tests compare)."""
+    h = int(h)
+    if h <= 0 or h > 512 or h % 16:
+        return False
+    nk8 = (h + 63) // 64
+    return (h % 48 == 0 and nk8 in (2, 3, 5, 6)) or (h % 64 == 0 and nk8 in (1, 2, 4, 8))
+
+
 def max_lanes(model, quantize=False):
     """Engine replicas whose recurrent kernels can be co-resident. The kernels of 192...1024-wide layers are persistent and hand h
     over between workgroups: every launch sizes its grid to the whole device and spins on peers, so two lanes would each end up
-    partly resident and time out (advisor finding, round 2). Exceptions: the ring-in-a-workgroup kernel of the narrow layers (64 /
-    96 / 128: no inter-workgroup exchange, any number of lanes) and the 8-bit kernel built for two workgroups per CU
-    (`lstm_q8_variant` 2, 384 wide: two lanes). Models without recurrent layers: no limit."""
+    partly resident and time out (advisor finding, round 2). The 8-bit kernel is of that kind at EVERY width it covers (at 96 and
+    128 its rings span two workgroups), so `quantize` is looked at first (advisor finding, round 3: a quantised 96-wide model was
+    given the three lanes of the fp16 ring-in-a-workgroup kernel); its instance built for two workgroups per CU (`lstm_q8_variant`
+    2, 384 wide) allows two lanes. Otherwise: the ring-in-a-workgroup kernel of the narrow fp16 layers (64 / 96 / 128: no
+    inter-workgroup exchange) any number of lanes, models without recurrent layers no limit, everything else one."""
     sizes = lstm_widths(model)
-    if not sizes or all(h in (64, 96, 128) for h in sizes):
+    if not sizes:
         return 1 << 30
-    if quantize and all(h == 384 for h in sizes):
-        return 2
+    if quantize and any(q8_covers(h) for h in sizes):
+        return 2 if all(h == 384 for h in sizes) else 1
+    if all(h in (64, 96, 128) for h in sizes):
+        return 1 << 30
     return 1
 
 
@@ -256,7 +283,8 @@ def batches_per_call(model, batchsize, quantize=False, chunksize=None, lanes=1):
     8-bit path with its two lanes: calls of 1024 chunks (one launch of the two-workgroups-per-CU kernel; bench.py: 14.6 -> 13.7 ms per
     batch); the narrow (64 / 96 / 128 wide) models with their three lanes: calls of 2048 chunks; one batch per call everywhere else."""
     sizes = lstm_widths(model)
-    if sizes and all(h in (64, 96, 128) for h in sizes):         # ring-in-a-workgroup kernels: a 512-chunk batch fills an eighth of the chip
+    q8 = bool(quantize) and any(q8_covers(h) for h in sizes)
+    if sizes and all(h in (64, 96, 128) for h in sizes) and not q8:   # ring-in-a-workgroup kernels: a 512-chunk batch fills an eighth of the chip
         return max(1, min(4, 2048 // max(1, int(batchsize)))) if lanes >= 2 else 1
     if quantize:
         if lanes >= 2 and max_lanes(model, True) == 2:
@@ -398,11 +426,12 @@ def records_from_planes(batches, chunksize, overlap, stride, mode, min_qscore=0.
     base, pstride, lo_a, rows_a = (C.c_void_p * K)(), (C.c_long * K)(), (C.c_long * K)(), (C.c_long * K)()
 
     def emit(key, pieces):
-        nonlocal cap, out
+        nonlocal cap, out, K, base, pstride, lo_a, rows_a
         read, start, end = key
         n = len(pieces)
-        if n > K:
-            raise ValueError("a read spans more than %d engine calls" % K)
+        if n > K:            # a very long read / very small engine calls: as many pieces as it takes (the library has no limit either)
+            K = 2 * n
+            base, pstride, lo_a, rows_a = (C.c_void_p * K)(), (C.c_long * K)(), (C.c_long * K)(), (C.c_long * K)()
         for i, (arr, lo, hi) in enumerate(pieces):
             base[i], pstride[i], lo_a[i], rows_a[i] = arr.ctypes.data, arr.strides[0], lo, hi - lo
         T = pieces[0][0].shape[2]
@@ -421,7 +450,7 @@ def records_from_planes(batches, chunksize, overlap, stride, mode, min_qscore=0.
         log = (read.read_id, signal_samples(read))
         if got == 0:
             return None, None, log
-        return C.string_at(out, got).decode("ascii"), summary_row(read, seq_len.value, mean_q.value), log
+        return C.string_at(out, got).decode("utf-8"), summary_row(read, seq_len.value, mean_q.value), log
 
     cur, pieces = None, []
     for keys, planes in batches:

@@ -174,7 +174,19 @@ struct bh_encoder {
     int n_cus = 0;
     std::vector<Layer> layers;
     DevBuf act[3], gates, sig, err, lstm_ws;
-    int* err_host = nullptr;     // pinned mirror of `err`, refreshed by a 4-byte copy at the end of every forward
+    // Timeout flags are PER FORWARD: forward number n (its "ticket") owns slot n % ERR_SLOTS of `err`; the slot is zeroed on the
+    // stream in front of the forward, the persistent recurrent kernels raise it, and a 4-byte copy behind the forward mirrors it
+    // into the same slot of the pinned host array. A caller that has observed the completion of forward n reads ITS flag
+    // (bh_encoder_error_flag_at) - flags of other forwards in flight are neither consumed nor cleared (advisor finding, round 3:
+    // the one sticky flag made a retry of batch i erase the evidence against batches i+1, i+2). At most ERR_SLOTS forwards of an
+    // engine may be in flight. `sticky` collects the slots as they are recycled, for bh_encoder_check / bh_encoder_error_flag
+    // ("has anything timed out since the last check").
+    static constexpr int ERR_SLOTS = 64;
+    int* err_host = nullptr;     // pinned [ERR_SLOTS] mirror of `err`
+    long ticket = -1;            // number of the most recent forward
+    long checked = -1;           // forwards <= checked have been reported by bh_encoder_check
+    int sticky = 0;              // flags harvested from recycled slots (forwards in (checked, ticket - ERR_SLOTS])
+    int* cur_err = nullptr;      // device slot of the forward being issued
     int n_act = 2;               // activation buffers in rotation: 3 when recurrent layers pre-fill their exchange sentinel
     // sentinel pre-fill of the NEXT recurrent layer's output buffer, on a side stream under the current layer's kernel
     hipStream_t fill_stream = nullptr;
@@ -604,7 +616,7 @@ extern "C" int bh_encoder_create(const bh_layer_t* layers, int n_layers, int dev
         if (exb && e->ex16.alloc(exb + 256)) return fail(-1);
     }
     if (e->act[0].alloc(ab + 256) || e->act[1].alloc(ab + 256) || e->gates.alloc(gb + 256) ||
-        e->sig.alloc((size_t)Np * max_chunk * 2) || e->err.alloc(sizeof(int)) || e->lstm_ws.alloc(bh_k_lstm_ws_bytes(Np, 1024)))
+        e->sig.alloc((size_t)Np * max_chunk * 2) || e->err.alloc(sizeof(int) * bh_encoder::ERR_SLOTS) || e->lstm_ws.alloc(bh_k_lstm_ws_bytes(Np, 1024)))
         return fail(-1);
     {   // transformer workspace: sized by walking to each transformer layer's token count
         long len = max_chunk;
@@ -631,12 +643,13 @@ extern "C" int bh_encoder_create(const bh_layer_t* layers, int n_layers, int dev
             e->rot_len = tmax;
         }
     }
-    if (hipHostMalloc((void**)&e->err_host, sizeof(int), hipHostMallocDefault) != hipSuccess) {
+    if (hipHostMalloc((void**)&e->err_host, sizeof(int) * bh_encoder::ERR_SLOTS, hipHostMallocDefault) != hipSuccess) {
         bh_set_error("encoder_create: hipHostMalloc failed");
         return fail(-1);
     }
-    *e->err_host = 0;
-    if (hipMemset(e->err.p, 0, sizeof(int)) != hipSuccess || hipMemset(e->act[0].p, 0, e->act[0].bytes) != hipSuccess ||
+    for (int i = 0; i < bh_encoder::ERR_SLOTS; ++i) e->err_host[i] = 0;
+    e->cur_err = (int*)e->err.p;
+    if (hipMemset(e->err.p, 0, sizeof(int) * bh_encoder::ERR_SLOTS) != hipSuccess || hipMemset(e->act[0].p, 0, e->act[0].bytes) != hipSuccess ||
         hipMemset(e->act[1].p, 0, e->act[1].bytes) != hipSuccess) {
         bh_set_error("encoder_create: hipMemset failed");
         return fail(-1);
@@ -756,6 +769,15 @@ extern "C" int bh_encoder_forward(bh_encoder_t* e, const void* signal, int N, in
         ~Restore() { if (prev != dev) (void)hipSetDevice(prev); }
     } restore{prev, e->device};
 
+    // this forward's timeout slot (see bh_encoder::ERR_SLOTS): harvest the flag of the forward that used it last, zero it on the stream
+    {
+        const long n = ++e->ticket;
+        const int slot = (int)(n % bh_encoder::ERR_SLOTS);
+        if (n - bh_encoder::ERR_SLOTS > e->checked) e->sticky |= e->err_host[slot];
+        e->err_host[slot] = 0;
+        e->cur_err = (int*)e->err.p + slot;
+        BH_CHECK_HIP(hipMemsetAsync(e->cur_err, 0, sizeof(int), st));
+    }
     const int Np = (N + e->batch_pad - 1) / e->batch_pad * e->batch_pad;
     // stage the batch into an engine-owned [Np][L] buffer whose padding rows are zero
     if (Np != N) BH_CHECK_HIP(hipMemsetAsync((char*)e->sig.p + (size_t)N * L * 2, 0, (size_t)(Np - N) * L * 2, st));
@@ -865,7 +887,7 @@ extern "C" int bh_encoder_forward(bh_encoder_t* e, const void* signal, int N, in
                                                 (const float*)l.q_sh.p, (const float*)l.b0.p,
                                                 hq_out ? (char*)hq_out + (size_t)r0 * tile : nullptr,
                                                 h16_out ? (char*)h16_out + (size_t)r0 * 16 * H * 2 : nullptr,
-                                                (char*)e->q_ex.p + (size_t)r0 * tile, len, Np, H, R, nr, d.reverse, (int*)e->err.p, st,
+                                                (char*)e->q_ex.p + (size_t)r0 * tile, len, Np, H, R, nr, d.reverse, e->cur_err, st,
                                                 (int*)e->lstm_ws.p, e->lstm_force_slow, l.q_variant, nullptr, bh_k_lstm_max_spins());
                         if (rc) return rc;
                     }
@@ -912,10 +934,10 @@ extern "C" int bh_encoder_forward(bh_encoder_t* e, const void* signal, int N, in
                     if (pair)
                         rc = bh_k_lstm_layer_wgx2((const char*)cur + col * H * 2, l.w4.p, (const float*)l.b0.p, l.w3.p,
                                                   (char*)dst + col * H * 2, (char*)e->ex16.p + (size_t)r0 * (H / 32) * 1024, len, Np, H, n_rings,
-                                                  d.reverse, (int*)e->err.p, st, nr, (int*)e->lstm_ws.p, e->lstm_force_slow, r0 == 0);
+                                                  d.reverse, e->cur_err, st, nr, (int*)e->lstm_ws.p, e->lstm_force_slow, r0 == 0);
                     else if (wide)
                         rc = bh_k_lstm_layer_wide((const char*)e->gates.p + col * 4 * H * 2, l.w3.p, (char*)dst + col * H * 2, len, Np, H,
-                                                  d.reverse, (int*)e->err.p, st, nr, (int*)e->lstm_ws.p, e->lstm_force_slow,
+                                                  d.reverse, e->cur_err, st, nr, (int*)e->lstm_ws.p, e->lstm_force_slow,
                                                   lp.widex ? (char*)e->ex16.p + (size_t)r0 * 2 * (H / 32) * 1024 : nullptr, n_rings, r0 == 0);
                     else if (cta)
                         rc = bh_k_lstm_layer_cta((const char*)cur + col * H * 2, l.w4.p, (const float*)l.b0.p, l.w3.p,
@@ -923,22 +945,22 @@ extern "C" int bh_encoder_forward(bh_encoder_t* e, const void* signal, int N, in
                     else if (lp.wgx)
                         rc = bh_k_lstm_layer_wgx((const char*)cur + col * H * 2, l.w4.p, (const float*)l.b0.p, l.w3.p,
                                                  (char*)dst + col * H * 2, (char*)e->ex16.p + (size_t)r0 * (H / 32) * 1024, len, Np, H, n_rings,
-                                                 d.reverse, (int*)e->err.p, st, nr, (int*)e->lstm_ws.p, e->lstm_force_slow, r0 == 0);
+                                                 d.reverse, e->cur_err, st, nr, (int*)e->lstm_ws.p, e->lstm_force_slow, r0 == 0);
                     else if (wg)
                         rc = bh_k_lstm_layer_wg((const char*)cur + col * H * 2, l.w4.p, (const float*)l.b0.p, l.w3.p,
-                                                (char*)dst + col * H * 2, len, Np, H, d.reverse, (int*)e->err.p, st, nr,
+                                                (char*)dst + col * H * 2, len, Np, H, d.reverse, e->cur_err, st, nr,
                                                 (int*)e->lstm_ws.p, e->lstm_force_slow);
                     else if (fused)
                         rc = bh_k_lstm_layer_fused((const char*)cur + col * H * 2, l.w2.p, (const float*)l.b0.p, l.w1.p,
-                                                   (char*)dst + col * H * 2, len, Np, H, d.reverse, (int*)e->err.p, st, nr,
+                                                   (char*)dst + col * H * 2, len, Np, H, d.reverse, e->cur_err, st, nr,
                                                    (int*)e->lstm_ws.p, e->lstm_force_slow);
                     else if (reg_path)
                         rc = bh_k_lstm_layer((const char*)e->gates.p + col * 4 * H * 2, l.w1.p,
-                                             (char*)dst + col * H * 2, len, Np, H, d.reverse, (int*)e->err.p, st, nr,
+                                             (char*)dst + col * H * 2, len, Np, H, d.reverse, e->cur_err, st, nr,
                                              (int*)e->lstm_ws.p, e->lstm_force_slow);
                     else
                         rc = bh_k_lstm_layer_stream((const char*)e->gates.p + col * 4 * H * 2, l.w1.p,
-                                                    (char*)dst + col * H * 2, len, Np, H, d.reverse, (int*)e->err.p, st, nr,
+                                                    (char*)dst + col * H * 2, len, Np, H, d.reverse, e->cur_err, st, nr,
                                                     (int*)e->lstm_ws.p, e->lstm_force_slow);
                     if (rc) return rc;
                     r0 += nr;
@@ -1059,30 +1081,52 @@ extern "C" int bh_encoder_forward(bh_encoder_t* e, const void* signal, int N, in
                 BH_REQUIRE(false, "encoder_forward: unsupported layer kind %d", d.kind);
         }
     }
-    // The persistent recurrent kernels raise `err` on a spin timeout and then finish with invalid output. Mirror the (sticky)
-    // flag into pinned host memory behind this forward: whoever has observed the completion of this call on `st` (an event,
-    // a D2H copy of decoded outputs, a synchronise) reads it without another round trip -- bh_encoder_error_flag().
-    BH_CHECK_HIP(hipMemcpyAsync(e->err_host, e->err.p, sizeof(int), hipMemcpyDeviceToHost, st));
+    // The persistent recurrent kernels raise this forward's slot on a spin timeout and then finish with invalid output. Mirror it
+    // into pinned host memory behind this forward: whoever has observed the completion of this call on `st` (an event, a D2H copy
+    // of decoded outputs, a synchronise) reads it without another round trip -- bh_encoder_error_flag_at(ticket).
+    BH_CHECK_HIP(hipMemcpyAsync(e->err_host + (e->cur_err - (int*)e->err.p), e->cur_err, sizeof(int), hipMemcpyDeviceToHost, st));
     return 0;
+}
+
+extern "C" long bh_encoder_last_ticket(const bh_encoder_t* e) { return e ? e->ticket : -1; }
+
+extern "C" int bh_encoder_error_flag_at(const bh_encoder_t* e, long ticket) {
+    if (!e || !e->err_host || ticket < 0 || ticket > e->ticket) return 0;
+    if (e->ticket - ticket >= bh_encoder::ERR_SLOTS) {
+        bh_set_error("forward %ld is more than %d forwards old: its timeout flag has been recycled", ticket, bh_encoder::ERR_SLOTS);
+        return -1;
+    }
+    const int flag = ((volatile const int*)e->err_host)[ticket % bh_encoder::ERR_SLOTS];
+    if (flag) bh_set_error("device-side timeout in a persistent kernel (flag=%d, forward %ld): the scores of that forward are invalid", flag, ticket);
+    return flag;
+}
+
+// flags of the forwards that bh_encoder_check has not reported yet (host side only: completed forwards whose copy has landed)
+static int pending_flags(const bh_encoder_t* e) {
+    int flag = e->sticky;
+    long lo = e->checked + 1;
+    if (lo < e->ticket - bh_encoder::ERR_SLOTS + 1) lo = e->ticket - bh_encoder::ERR_SLOTS + 1;
+    if (lo < 0) lo = 0;
+    for (long n = lo; n <= e->ticket; ++n) flag |= ((volatile const int*)e->err_host)[n % bh_encoder::ERR_SLOTS];
+    return flag;
 }
 
 extern "C" int bh_encoder_error_flag(const bh_encoder_t* e) {
     if (!e || !e->err_host) return 0;
-    const int flag = *(volatile const int*)e->err_host;
+    const int flag = pending_flags(e);
     if (flag) bh_set_error("device-side timeout in a persistent kernel (flag=%d): the scores of that forward are invalid", flag);
     return flag;
 }
 
 extern "C" int bh_encoder_check(bh_encoder_t* e, void* stream_) {
     BH_REQUIRE(e, "encoder_check: null engine");
-    int flag = 0;
-    BH_CHECK_HIP(hipMemcpyAsync(&flag, e->err.p, sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream_));
     BH_CHECK_HIP(hipStreamSynchronize((hipStream_t)stream_));
-    if (flag) {
-        BH_CHECK_HIP(hipMemsetAsync(e->err.p, 0, sizeof(int), (hipStream_t)stream_));
-        bh_set_error("device-side timeout in a persistent kernel (flag=%d)", flag);
-    }
-    if (e->err_host) *e->err_host = 0;
+    const int flag = pending_flags(e);
+    // reported: forget everything up to the most recent forward. (A forward still in flight on ANOTHER stream than `stream_` is
+    // past this check; its flag stays readable through its ticket.)
+    e->sticky = 0;
+    if (flag) bh_set_error("device-side timeout in a persistent kernel (flag=%d)", flag);
+    e->checked = e->ticket;
     return flag;
 }
 

@@ -6,6 +6,7 @@
 // (which drops the lock for the duration of the call).
 #include <cstdint>
 #include <cstring>
+#include <vector>
 #include <immintrin.h>
 
 #include "bonito_hip.h"
@@ -131,8 +132,11 @@ extern "C" long bh_host_format_read(const int8_t* const* base, const long* plane
                                     long T, long length, int chunksize, int overlap, int stride, int reverse, int rna, int mode,
                                     double min_qscore, const char* read_id, const char* run_id, long num_samples, long trimmed_samples,
                                     char* out, long out_cap, long* seq_len, double* mean_q) {
-    if (!base || !plane_stride || !lo || !rows || n_pieces <= 0 || n_pieces > 64 || T <= 0 || stride <= 0 || !read_id || !out || !seq_len || !mean_q) return -1;
-    Piece pc[64];
+    if (!base || !plane_stride || !lo || !rows || n_pieces <= 0 || T <= 0 || stride <= 0 || !read_id || !out || !seq_len || !mean_q) return -1;
+    Piece pc_fixed[64];                       // a read's chunks usually sit in a handful of engine calls; any number is accepted
+    std::vector<Piece> pc_big;
+    Piece* pc = pc_fixed;
+    if (n_pieces > 64) { pc_big.resize((size_t)n_pieces); pc = pc_big.data(); }
     long n_chunks = 0;
     for (int i = 0; i < n_pieces; ++i) { pc[i] = Piece{base[i], plane_stride[i], lo[i], rows[i]}; n_chunks += rows[i]; }
     if (n_chunks <= 0) return -1;
@@ -198,8 +202,11 @@ extern "C" long bh_host_format_read(const int8_t* const* base, const long* plane
         for (long i = 0, j = n_seq - 1; i < j; ++i, --j) { const char t = seq[i]; seq[i] = seq[j]; seq[j] = t; }
         for (long i = 0, j = n_qs - 1; i < j; ++i, --j) { const char t = qs[i]; qs[i] = qs[j]; qs[j] = t; }
     }
-    for (long i = 0; i < n_qs; ++i) ++hist[(unsigned char)qs[i]];
-    const double mq = n_qs ? mean_qscore(hist) : 0.0;
+    // io.format_record's conventions, quirks included (tests fuzz the two against each other): a qstring that is exactly "*" means
+    // "no qualities" (mean 0.0; '!' per base in FASTQ, '*' in SAM); an EMPTY qstring beside a sequence is written as an empty field
+    const bool qs_missing = n_qs == 1 && qs[0] == '*';
+    if (!qs_missing) for (long i = 0; i < n_qs; ++i) ++hist[(unsigned char)qs[i]];
+    const double mq = (n_qs && !qs_missing) ? mean_qscore(hist) : 0.0;
     *seq_len = n_seq;
     *mean_q = mq;
     if (mq < min_qscore || n_seq == 0) return 0;
@@ -218,11 +225,11 @@ extern "C" long bh_host_format_read(const int8_t* const* base, const long* plane
     } else if (mode == 0) {
         *p++ = '@'; put(read_id, id_len); *p++ = ' '; tags(); *p++ = '\n';
         put(seq, n_seq); put("\n+\n", 3);
-        if (n_qs) put(qs, n_qs); else { memset(p, '!', (size_t)n_seq); p += n_seq; }
+        if (qs_missing) { memset(p, '!', (size_t)n_seq); p += n_seq; } else put(qs, n_qs);
         *p++ = '\n';
     } else {
         put(read_id, id_len); put("\t4\t*\t0\t0\t*\t*\t0\t0\t", 17); put(seq, n_seq); *p++ = '\t';
-        if (n_qs) put(qs, n_qs); else *p++ = '*';
+        put(qs, n_qs);
         put("\tNM:i:0\t", 8); tags(); *p++ = '\n';
     }
     return (long)(p - out);

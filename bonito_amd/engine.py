@@ -194,6 +194,7 @@ class HipEncoder:
 
     def __init__(self, encoder, batchsize, chunksize, device=None, lowering=None, quantize=False):
         self._handle = None
+        self.last_ticket = None
         lib = _lib.lib()
         if not torch.cuda.is_available():
             raise _lib.HipEngineError("no HIP device visible: the MI355X engine has no CPU fallback")
@@ -231,6 +232,8 @@ class HipEncoder:
         with torch.cuda.device(self.device):
             _lib.check(_lib.lib().bh_encoder_forward(self._handle, _lib.ptr(x), N, L, _lib.ptr(scores),
                                                      _lib.stream_ptr(self.device)), "bh_encoder_forward")
+        # the number of this forward: its timeout flag is kept apart from those of the forwards around it (poll_ticket)
+        self.last_ticket = int(_lib.lib().bh_encoder_last_ticket(self._handle))
         return scores
 
     PROF_CLASSES = ("conv", "lstm_gemm", "fill", "lstm_rec", "crf_linear", "attention", "mlp", "other")
@@ -271,6 +274,15 @@ class HipEncoder:
         hit the spin bound of a persistent kernel: its scores are invalid. No device round trip (bh_encoder_error_flag)."""
         if self._handle is not None and _lib.lib().bh_encoder_error_flag(self._handle):
             raise _lib.HipEngineError("bh_encoder_error_flag: %s" % _lib.last_error())
+
+    def poll_ticket(self, ticket):
+        """`poll` for ONE forward (`last_ticket` read right after the call that issued it): raises iff that forward timed out.
+        Flags of other forwards in flight on this engine are left alone (bh_encoder_error_flag_at)."""
+        if self._handle is None or ticket is None:
+            return
+        rc = _lib.lib().bh_encoder_error_flag_at(self._handle, int(ticket))
+        if rc:
+            raise _lib.HipEngineError("bh_encoder_error_flag_at: %s" % _lib.last_error())
 
     def close(self):
         if self._handle is not None:

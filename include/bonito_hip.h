@@ -125,13 +125,20 @@ int bh_encoder_describe(const bh_encoder_t* enc, char* buf, size_t bytes);
 int bh_encoder_set_option(bh_encoder_t* enc, const char* name, int value);
 /* debug: read back the LSTM workspace (XCD agreement slots, per-wave cycle statistics when lstm_tune bit 2 is set) */
 int bh_encoder_debug_read(bh_encoder_t* enc, void* host, size_t bytes, size_t offset);
-/* non-zero if a device-side timeout was raised by a persistent kernel since the last call (synchronises stream) */
+/* Device-side timeouts. The persistent recurrent kernels bound every spin; a kernel that gives up raises a flag and finishes with
+ * INVALID output. Flags are kept PER FORWARD: every bh_encoder_forward gets a ticket (0, 1, 2, ... per engine,
+ * bh_encoder_last_ticket right after the call), zeroes its own slot in front of its kernels and ends with a 4-byte copy of the slot
+ * into pinned host memory on its stream. Once the caller has observed the completion of forward `ticket` (event, decoded outputs on
+ * the host, stream synchronise), bh_encoder_error_flag_at(ticket) says - without a device round trip - whether THAT forward timed
+ * out; other forwards in flight are not consumed or cleared by the query (the product pipeline retries exactly the flagged batch).
+ * At most 64 forwards of one engine may be in flight / unqueried (-1 for a ticket whose slot has been recycled).
+ * bh_encoder_error_flag: non-zero iff any forward since the last bh_encoder_check has been SEEN to time out (host side only).
+ * bh_encoder_check: synchronises `stream`, returns the same and forgets it (reference seam: bonito/crf/basecall.py:27-45 has
+ * nothing that can time out; a drop-in must neither abort nor emit calls decoded from invalid scores). */
 int bh_encoder_check(bh_encoder_t* enc, void* stream);
-/* Same flag WITHOUT synchronising: every bh_encoder_forward ends with a 4-byte copy of the (sticky) device flag into pinned
- * host memory on its stream, so once the caller has observed the completion of a forward (event, decoded outputs on the host,
- * stream synchronise) this returns non-zero iff that forward or an earlier one timed out -- its scores are then INVALID and
- * must not be used (bonito_amd raises). Cleared by bh_encoder_check. */
 int bh_encoder_error_flag(const bh_encoder_t* enc);
+long bh_encoder_last_ticket(const bh_encoder_t* enc);
+int bh_encoder_error_flag_at(const bh_encoder_t* enc, long ticket);
 
 /* Per-kernel-class timing with HIP events recorded on the forward's stream (measurement only).
  * After enabling, every bh_encoder_forward appends spans; profile_read synchronises on them and returns

@@ -62,3 +62,21 @@ def test_pmc_traffic_table_names_the_roofline_kernel(bench):
     table = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
     entry = table["lstm_layer_wg_kernel"]
     assert entry["bytes_per_launch"] > 1e9 and os.path.exists(os.path.join(ROOT, entry["source"]))
+
+
+def test_experimental_lstm_flags_never_write_the_product_library(tmp_path):
+    """`BH_EXTRA_LSTM_FLAGS` builds (timing experiments, wrong results on purpose) go to libbonito_hip_expt.so / build/obj_expt; a
+    stray environment variable must not be able to replace bonito_amd/libbonito_hip.so (review, round 3)."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    code = ("import os, build; print(build.LIB); print(build.OBJ); print(build.EXTRA_FLAGS.get('lstm.hip'))")
+    env = dict(os.environ, BH_EXTRA_LSTM_FLAGS="-DBH_EXPT_SHARE")
+    r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=env, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    lib, obj, flags = r.stdout.strip().split("\n")
+    assert lib.endswith("libbonito_hip_expt.so") and obj.endswith("obj_expt") and "BH_EXPT_SHARE" in flags
+    env.pop("BH_EXTRA_LSTM_FLAGS")
+    r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=env, capture_output=True, text=True)
+    lib, obj, flags = r.stdout.strip().split("\n")
+    assert lib.endswith("bonito_amd/libbonito_hip.so") and obj.endswith("build/obj") and flags == "None"

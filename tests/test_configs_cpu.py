@@ -69,6 +69,13 @@ def test_engine_call_size_policy():
     hac = synthetic.make_model("hac", batchsize=64, chunksize=1200)
     assert (auto_lanes(hac), auto_lanes(hac, True)) == (1, 2)
     assert auto_lanes(synthetic.make_model("fast", batchsize=16, chunksize=1200)) == 3
+    # the 8-bit kernel exchanges between workgroups at EVERY width it covers: a quantised 96-wide model is a one-lane model
+    # (advisor finding, round 3: it was given the three lanes of the fp16 ring-in-a-workgroup kernel)
+    from bonito_amd.crf.basecall import max_lanes, q8_covers
+    fastq = synthetic.make_model("fast", batchsize=16, chunksize=1200)
+    assert (max_lanes(fastq), max_lanes(fastq, True), auto_lanes(fastq, True)) == (1 << 30, 1, 1)
+    assert batches_per_call(fastq, 512, quantize=True, chunksize=10000, lanes=3) == 1
+    assert [h for h in range(16, 529, 16) if q8_covers(h)] == [64, 96, 128, 144, 192, 256, 288, 336, 384, 512]
     assert auto_lanes(synthetic.make_model("sup_lstm", batchsize=16, chunksize=1200), True) == 1
     assert auto_lanes(synthetic.make_transformer_model(batchsize=16, chunksize=1200)) == 1
     assert [batches_per_call(hac, b) for b in (128, 256, 512, 1024, 2048, 4096)] == [8, 8, 4, 2, 1, 1]

@@ -360,23 +360,72 @@ def test_exchange_timeout_is_retried_serially_and_the_run_completes(monkeypatch)
     good = [(r.read_id, res["sequence"], res["qstring"], res["moves"].tobytes())
             for r, res in crf_basecall_fn(model, iter(reads), chunksize=3000, overlap=300, batchsize=64, per_call=1)]
     calls, retried = {"n": 0}, []
-    real_check, real_retry = bc_mod._Pipeline.check_engine, bc_mod._Pipeline._retry_serially
+    real_check, real_retry = bc_mod._Pipeline.check_forward, bc_mod._Pipeline._retry_serially
 
-    def flaky_check(self):
+    def flaky_check(self, lane, ticket):
         calls["n"] += 1
         if calls["n"] in (2, 4):
             raise _lib.HipEngineError("injected: device-side timeout in a persistent kernel")
-        return real_check(self)
+        return real_check(self, lane, ticket)
 
-    def counting_retry(self, dev_batch):
+    def counting_retry(self, dev_batch, lane=0):
         retried.append(dev_batch.shape[0])
-        return real_retry(self, dev_batch)
+        return real_retry(self, dev_batch, lane)
 
-    monkeypatch.setattr(bc_mod._Pipeline, "check_engine", flaky_check)
+    monkeypatch.setattr(bc_mod._Pipeline, "check_forward", flaky_check)
     monkeypatch.setattr(bc_mod._Pipeline, "_retry_serially", counting_retry)
     again = [(r.read_id, res["sequence"], res["qstring"], res["moves"].tobytes())
              for r, res in crf_basecall_fn(model, iter(reads), chunksize=3000, overlap=300, batchsize=64, per_call=1)]
     assert len(retried) == 2 and again == good and len(good) == 60
+
+
+def test_real_timeouts_of_consecutive_batches_are_each_retried(monkeypatch):
+    """Advisor finding (round 3): with ONE sticky flag per engine, the serial retry of batch i cleared the flag that batch i+1 -
+    already in flight behind it - had raised as well, and batch i+1 was yielded from invalid scores. Flags are per forward now
+    (bh_encoder_error_flag_at): here the forwards of two CONSECUTIVE batches really time out (spin bound 0 while exactly those two
+    are launched from the encoder thread; the retries run from the decode thread with the default bound), both must be run again,
+    and the calls must equal those of an undisturbed run."""
+    import importlib
+    import threading
+    from bonito_amd import _lib, synthetic
+    bc_mod = importlib.import_module("bonito_amd.crf.basecall")
+    dev = torch.device("cuda", 0)
+    model = synthetic.make_model("hac", batchsize=64, chunksize=3000)
+    model.use_koi(batchsize=64, chunksize=3000, quantize=False)
+    model = model.half().to(dev)
+    rng = np.random.default_rng(4)
+    reads = _reads(rng, [9000] * 80)
+    good = [(r.read_id, res["sequence"], res["qstring"], res["moves"].tobytes())
+            for r, res in crf_basecall_fn(model, iter(reads), chunksize=3000, overlap=300, batchsize=64, per_call=1)]
+    real_forward = bc_mod._Pipeline._forward
+    state = {"n": 0, "enc_thread": None, "pipes": []}
+
+    def sabotaged_forward(self, lane, x):
+        me = threading.current_thread()
+        if state["enc_thread"] is None:
+            state["enc_thread"] = me
+            state["pipes"].append(self)
+        if me is not state["enc_thread"]:                # a serial retry (decode thread): undisturbed
+            return real_forward(self, lane, x)
+        state["n"] += 1
+        if state["n"] in (2, 3):
+            decode.set_option("lstm_max_spins", 0)       # read when the kernels are launched: only this forward
+            try:
+                return real_forward(self, lane, x)
+            finally:
+                decode.set_option("lstm_max_spins", -1)
+        return real_forward(self, lane, x)
+
+    monkeypatch.setattr(bc_mod._Pipeline, "_forward", sabotaged_forward)
+    again = [(r.read_id, res["sequence"], res["qstring"], res["moves"].tobytes())
+             for r, res in crf_basecall_fn(model, iter(reads), chunksize=3000, overlap=300, batchsize=64, per_call=1)]
+    assert state["pipes"] and state["pipes"][0].retries == 2, state["pipes"][0].retries
+    assert again == good and len(good) == 80
+    torch.cuda.synchronize()
+    try:                                                 # the flags were reported per forward; forget them for later tests
+        model._hip.check()
+    except _lib.HipEngineError:
+        pass
 
 
 def test_batches_per_engine_call_do_not_change_the_calls():

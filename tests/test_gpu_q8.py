@@ -132,6 +132,8 @@ def test_quantize_covers_or_falls_back_for_every_width(H):
     layout = enc.describe()
     has_q8 = H in (64, 96, 128, 192, 256, 288, 384, 512)          # 320, 448, 480: accepted by the round-2 predicate, no kernel instance
     assert ("lstm_layer_q8_kernel" in layout) == has_q8, layout
+    from bonito_amd.crf.basecall import q8_covers
+    assert q8_covers(H) == has_q8          # the host-side lane policy (max_lanes) uses the same predicate
     with torch.no_grad():
         ref = nn_ref.forward(model, x.float(), expand_blanks=False).permute(1, 0, 2)
     d = (got.cpu().float() - ref).abs()

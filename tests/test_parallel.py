@@ -216,3 +216,18 @@ def test_parse_devices():
     assert parse_devices("0-7") == list(range(8)) and parse_devices("0,2,5") == [0, 2, 5] and parse_devices("1-2,0") == [1, 2, 0]
     with pytest.raises(ValueError):
         parse_devices("")
+
+
+def test_child_device_mask_follows_the_parent_masks():
+    """`--devices` indices are relative to what the launcher may see. HIP numbers devices inside the set ROCR_VISIBLE_DEVICES
+    leaves, and the ROCR mask stays in the child's environment (advisor finding, round 3)."""
+    from bonito_amd.cli.basecaller import child_device_mask
+    assert child_device_mask(3, {}) == "3"
+    assert child_device_mask(1, {"HIP_VISIBLE_DEVICES": "4,6,7"}) == "6"
+    # ROCR-only mask: HIP indices 0..1 address the filtered set; the physical ids 2 / 3 would see nothing
+    assert [child_device_mask(d, {"ROCR_VISIBLE_DEVICES": "2,3"}) for d in (0, 1)] == ["0", "1"]
+    # both: the HIP mask's values already are indices into the ROCR set
+    assert child_device_mask(1, {"ROCR_VISIBLE_DEVICES": "2,3,5", "HIP_VISIBLE_DEVICES": "2,0"}) == "0"
+    for env in ({"HIP_VISIBLE_DEVICES": "4,6"}, {"ROCR_VISIBLE_DEVICES": "2,3"}):
+        with pytest.raises(SystemExit):
+            child_device_mask(2, env)

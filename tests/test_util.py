@@ -332,3 +332,57 @@ def test_fused_record_formatter_writes_the_bytes_of_the_python_path(mode, revers
                 assert g == w
             assert min_q > 0 or any(t is not None for t, _, _ in got)
         assert any(t is None for t, _, _ in got)                            # ... and the q-score filter did drop reads
+
+
+@pytest.mark.parametrize("mode", ["fastq", "sam", "fasta"])
+def test_fused_record_formatter_edge_cases_follow_format_record(mode):
+    """Advisor findings (round 3) on `bh_host_format_read` vs `io.format_record`: a qstring that is exactly "*" means "no qualities"
+    (mean 0.0; '!' per base in FASTQ), an EMPTY qstring beside a sequence is written as an empty field, a read may span more than
+    64 engine calls (tiny batches / `--per-call 1` / ultra-long reads), and a non-ASCII read id is carried through as UTF-8."""
+    import importlib
+    from bonito_amd import io as bio
+    bc = importlib.import_module("bonito_amd.crf.basecall")
+
+    class Read:
+        filename, channel, mux, start, duration, template_start, template_duration = "f.pod5", 3, 1, 0.5, 2.0, 0.1, 1.9
+        signal, run_id, trimmed_samples = None, "runX", 0
+
+        def __init__(self, rid, n):
+            self.read_id, self.num_samples, self.signal_len = rid, n, n
+
+    chunksize, overlap, stride = 600, 60, 6
+    T = chunksize // stride
+
+    def planes_for(seq_row, qs_row):
+        mv = (np.asarray(seq_row) != 0).astype(np.int8)
+        return torch.from_numpy(np.stack([np.asarray(seq_row, np.int8)[None], np.asarray(qs_row, np.int8)[None], mv[None]]))
+
+    cases = []
+    one_base = np.zeros(T, np.int8); one_base[5] = 65
+    star = np.zeros(T, np.int8); star[5] = ord("*")                       # a single base with q = 9: the qstring IS "*"
+    cases.append((Read("star", chunksize), planes_for(one_base, star)))
+    three = np.zeros(T, np.int8); three[[3, 9, 40]] = [65, 67, 71]
+    cases.append((Read("noqual", chunksize), planes_for(three, np.zeros(T, np.int8))))     # sequence without any quality
+    qs3 = np.zeros(T, np.int8); qs3[[3, 9, 40]] = [40, 50, 60]
+    cases.append((Read("réad-ü", chunksize), planes_for(three, qs3)))                      # non-ASCII id
+    for read, planes in cases:
+        keys = (((read, 0, read.signal_len), (0, 1)),)
+        for min_q in (0.0, 5.0):
+            want = [bio.format_record(read, bc.fmt_planes(stride, bc.stitch_planes(planes, read.signal_len, chunksize, overlap, stride), False), mode, min_q)]
+            got = list(bc.records_from_planes(iter([(keys, planes)]), chunksize, overlap, stride, mode, min_q))
+            assert got == want, (read.read_id, min_q)
+
+    # one read of 150 chunks delivered as 150 engine calls of one chunk each (> 64 pieces)
+    rng = np.random.default_rng(5)
+    n = 150
+    length = chunksize + (n - 1) * (chunksize - overlap)
+    read = Read("long", length)
+    mv = (rng.random((n, T)) < 0.4).astype(np.int8)
+    seq = np.where(mv != 0, np.array([65, 67, 71, 84], np.int8)[rng.integers(0, 4, (n, T))], 0).astype(np.int8)
+    qs = np.where(mv != 0, rng.integers(34, 80, (n, T)), 0).astype(np.int8)
+    allp = torch.from_numpy(np.stack([seq, qs, mv]))
+    key = (read, 0, length)
+    calls = [(((key, (0, 1)),), allp[:, i:i + 1].contiguous()) for i in range(n)]
+    want = bio.format_record(read, bc.fmt_planes(stride, bc.stitch_planes(allp, length, chunksize, overlap, stride), False), mode, 0.0)
+    got = list(bc.records_from_planes(iter(calls), chunksize, overlap, stride, mode, 0.0))
+    assert got == [want] and want[0] is not None

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Generates bonito_amd/csrc/cells3_mfma.inc: lstm_cell() of THREE units, their dependency chains interleaved round-robin, with the
+"""Generates tools/cells3_mfma.inc: lstm_cell() of THREE units, their dependency chains interleaved round-robin, with the
 36 MFMAs of the next step's input projection (H = 384: 12 k-steps x 3 M tiles) threaded through at about one MFMA to three vector
 instructions. Five asm blocks of at most 30 distinct operands each, named operands. The arithmetic is lstm_cell()'s
 (bonito_amd/csrc/lstm.hip), operation for operation:
@@ -162,7 +162,7 @@ def main():
            "        for (int i = 0; i < 4; ++i) g[c][i] = acc[c][i];"]
     out += [blk for blk in blocks]
     out += ["#pragma unroll", "    for (int c = 0; c < 3; ++c) hv[c] = g[c][0];", "}", ""]
-    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bonito_amd", "csrc", "cells3_mfma.inc")
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "cells3_mfma.inc")
     with open(path, "w") as fh:
         fh.write("\n".join(out))
     print("wrote", path)
