@@ -501,16 +501,275 @@ __global__ __launch_bounds__(512, 1) void gemm_big_kernel(GemmArgs p) {
 // (DESIGN.md 4a "the clock"): the kernel is most likely at the chip's power limit, and what separates it from the library's
 // 1.15-1.24 PFLOP/s at K >= 1024 is energy per MFMA - 2.7 MFMAs per 1 KiB fragment read here; a 128 x 128 wave tile gives 4, and
 // 32 x 32 x 16 MFMAs halve the operand reads again.)
+
+// ---------------------------------------------------------------------------------------------------
+// v5 ("w4", round 4): the same 256 x 256 x 64 workgroup tile on FOUR waves - one per SIMD, each owning a 128 x 128 wave tile on
+// v_mfma_f32_32x32x16_f16 (256 accumulator registers) - with the whole K-tile as ONE generated instruction stream
+// (tools/gen_gemmstep.py -> gemm_ktile_mfma.inc): 64 MFMAs with the 32 fragment reads of the next k-steps, the wave's 16 LDS-DMA
+// pieces of the K-tiles ahead and one barrier issued from inside the stream. What that changes against v3 (8 waves, 64 x 128
+// wave tiles on 16 x 16 x 32, compiler-scheduled, everything of a K-tile - wait, barrier, DMA issue, fragment reads, MFMAs - one
+// after the other with both waves of a SIMD in the same phase: matrix pipe busy 41-50 % per cycle):
+//   * 4 MFMAs per KiB of fragment reads instead of 2.7, half the operand-register reads per FLOP, half the MFMA instructions:
+//     less energy per FLOP on a kernel that sits at the board's power cap;
+//   * DMA issue (~60-180 cycles each), fragment reads and the barrier hide behind MFMAs of the same wave instead of standing in
+//     front of them;
+//   * output tiles are written as FULL 128-byte lines: a lane's 32 consecutive features of a token go through a per-wave 8 KiB LDS
+//     scratch (XOR-swizzled, no barrier: one wave) and leave as rows of 8 lanes x 16 B. v3's stores were 64 separate 16-byte
+//     pieces per instruction - the "17 k cycles of turn-around per output tile" of round 3 were mostly that.
+// LDS: two stages of (W tile 32 KiB | X tile 32 KiB) + 4 x 8 KiB epilogue scratch = 160 KiB. Rows are 128 B = eight 16-byte chunks;
+// chunk c of row r sits at position c ^ ((r >> 1) & 7): a 32x32x16 fragment read takes rows l & 31 and chunk 2 ks + (l >> 5), so
+// every 16-lane group of the ds_read_b128 (lanes of one half, sixteen distinct rows of which eight even, eight odd) touches
+// sixteen distinct 16-byte slots of the 256-byte bank window (slot = (r & 1) * 8 + position). The DMA applies the permutation to
+// its SOURCE chunk (the LDS image of a DMA is lane-linear), a row's eight lanes still fetch one whole 128-byte line.
+// W rows are staged permuted (row rho of a 32-row MFMA tile i of a 64-feature pair holds feature 32 ((rho >> 2) & 1) + 16 (i & 1)
+// + 4 (rho >> 3) + (rho & 3)), so that lane (h = l >> 5, col = l & 31) ends up with the 32 CONSECUTIVE features 32 h .. 32 h + 31
+// of the pair for token col: the epilogue stays lane-local (bias, activation, SwiGLU pairs, the rotary partner in lane ^ 32).
+// K-tile g lives in stage g & 1; K % 128 == 0 keeps that parity across output tiles, so the streams of a tile are unrolled by
+// two with the stage as a compile-time choice of operands; the DMA cursor runs one (X) / two (W) K-tiles ahead and crosses into the
+// NEXT output tile in the last two instances (persistent kernel: the first K-tile of the next tile lands under the epilogue).
+#include "gemm_ktile_mfma.inc"
+
+constexpr int W4_STAGE = 65536, W4_B = 32768, W4_SCRATCH = 131072, W4_LDS = 163840;
+
+__device__ __forceinline__ void w4_dma(unsigned m0v, unsigned voff, const char* sbase) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(m0v), "v"(voff), "s"(sbase) : "memory");
+}
+
+// per-lane byte offsets of this wave's eight DMA pieces of each operand for the output tile (f0, t0)
+__device__ __forceinline__ void w4_offsets(const GemmArgs& p, int f0, int t0, int wave, int lane, unsigned (&va)[8], unsigned (&vb)[8]) {
+    const int lr = lane >> 3, slot = lane & 7;
+#pragma unroll
+    for (int n = 0; n < 8; ++n) {
+        const int R = wave * 64 + n * 8 + lr;                 // LDS row of this lane's chunk
+        const int chunk = slot ^ ((R >> 1) & 7);
+        const int rho = R & 31, i = (R >> 5) & 3;
+        const int feat = f0 + (R >> 7) * 128 + (i >> 1) * 64 + 32 * ((rho >> 2) & 1) + 16 * (i & 1) + 4 * (rho >> 3) + (rho & 3);
+        va[n] = (unsigned)min(feat, p.N - 1) * (unsigned)(p.ldw * 2) + chunk * 16;
+        vb[n] = (unsigned)min(t0 + R, p.M - 1) * (unsigned)(p.ldx * 2) + chunk * 16;
+    }
+}
+
+// Epilogue of one wave: acc[i][j] (i: 32-feature MFMA tiles of the wave's 128 features, j: 32-token tiles) -> bias / residual / rotary /
+// activation / scale / clamp / SwiGLU exactly as gemm_epilogue above, then through the wave's LDS scratch into full-line stores.
+template <int ACT, bool GATED>
+__device__ __forceinline__ void w4_epilogue(const GemmArgs& p, float16_t (&acc)[4][4], int f0, int t0, int wf, int wt, int lane, char* scratch) {
+    const int h = lane >> 5, col = lane & 31;
+    const bool ident = p.row_div == 1 && p.row_s_hi == 1;
+    const bool plain = p.scale == 1.0f && p.clamp_lo == -INFINITY && p.clamp_hi == INFINITY;
+    const int tl = lane >> 3, q = lane & 7;               // store side: token tl + 8 rr of the block, 16-byte piece q of its 128-byte row
+    auto drain = [&](int j, int buf, long fcol) {         // the block of token tile j in scratch buffer `buf` -> out[.][fcol + 8 q ..]
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            const int tok = tl + 8 * rr;
+            const uint4_t v = *(const uint4_t*)(scratch + buf * 4096 + tok * 128 + ((q ^ (tok & 7)) << 4));
+            const int m = t0 + wt * 128 + j * 32 + tok;
+            if (m >= p.M) continue;
+            long orow = m;
+            if (!ident) {
+                const int hi = m / p.row_div, lo = m - hi * p.row_div;
+                if (lo >= p.row_lim) continue;
+                orow = (long)hi * p.row_s_hi + (long)lo * p.row_s_lo;
+            }
+            *(uint4_t*)(p.out + orow * p.ldo + fcol + q * 8) = v;
+        }
+        __builtin_amdgcn_wave_barrier();
+    };
+    int nblk = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int m = t0 + wt * 128 + j * 32 + col;       // this lane's token in the accumulator layout
+#pragma unroll
+        for (int P = 0; P < 2; ++P) {
+            const int fb = f0 + wf * 128 + P * 64 + 32 * h;       // the lane's 32 consecutive features
+            float v[32];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { v[r] = acc[2 * P][j][r]; v[16 + r] = acc[2 * P + 1][j][r]; }
+            if (p.bias != nullptr) {
+#pragma unroll
+                for (int i = 0; i < 32; i += 4) {
+                    const float4_t b4 = *(const float4_t*)(p.bias + fb + i);
+                    v[i] += b4[0]; v[i + 1] += b4[1]; v[i + 2] += b4[2]; v[i + 3] += b4[3];
+                }
+            }
+            if (p.res != nullptr && m < p.M) {
+                const half_t* rp = p.res + (long)m * p.ldres + fb;
+#pragma unroll
+                for (int i = 0; i < 32; i += 8) {
+                    const half8_t r8 = *(const half8_t*)(rp + i);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[i + e] += (float)r8[e];
+                }
+            }
+            if constexpr (!GATED) {
+                // rotary embedding of the packed Wqkv projection (see gemm_epilogue): the pair of tiles is one head of 64, this lane
+                // holds dims 32 h .. 32 h + 31, the partner dim (+-32) of every value sits in lane ^ 32 at the same index
+                if (p.rot_cs != nullptr && f0 + wf * 128 + P * 64 < p.rot_nfeat) {
+                    const int pos = m % p.rot_T;
+                    const float* cs = p.rot_cs + (long)pos * 64;
+                    const float sgn = h == 0 ? -1.0f : 1.0f;
+                    const float qs = f0 + wf * 128 + P * 64 < p.rot_qfeat ? p.rot_qscale : 1.0f;
+#pragma unroll
+                    for (int i = 0; i < 32; i += 2) {
+                        const float4_t c4 = *(const float4_t*)(cs + 2 * i);      // (cos, sin) of dims i, i + 1
+                        const float pa = __shfl_xor(v[i], 32), pb = __shfl_xor(v[i + 1], 32);
+                        v[i] = (v[i] * c4[0] + sgn * pa * c4[1]) * qs;
+                        v[i + 1] = (v[i + 1] * c4[2] + sgn * pb * c4[3]) * qs;
+                    }
+                }
+            }
+            const int buf = nblk & 1;
+            char* row = scratch + buf * 4096 + col * 128;
+            if constexpr (GATED) {
+                // W rows interleaved on the host: feature 2 k = y_k, 2 k + 1 = gate_k; 16 outputs = two 16-byte pieces 4 P + 2 h, + 1
+                float y[16];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) y[i] = v[2 * i] * swishf_(v[2 * i + 1]);
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    float8_t f8;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) f8[e] = y[c * 8 + e];
+                    const half8_t o = __builtin_convertvector(f8, half8_t);
+                    *(half8_t*)(row + (((4 * P + 2 * h + c) ^ (col & 7)) << 4)) = o;
+                }
+                if (P == 1) { drain(j, buf, (long)((f0 + wf * 128) >> 1)); ++nblk; }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 32; ++i) v[i] = apply_act<ACT>(v[i]);
+                if (!plain) {
+#pragma unroll
+                    for (int i = 0; i < 32; ++i) v[i] = fminf(fmaxf(v[i] * p.scale, p.clamp_lo), p.clamp_hi);
+                }
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    float8_t f8;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) f8[e] = v[c * 8 + e];
+                    const half8_t o = __builtin_convertvector(f8, half8_t);
+                    *(half8_t*)(row + (((4 * h + c) ^ (col & 7)) << 4)) = o;
+                }
+                drain(j, buf, (long)(f0 + wf * 128 + P * 64));
+                ++nblk;
+            }
+        }
+    }
+}
+
+template <int ACT, bool GATED>
+__global__ __launch_bounds__(256, 1) void gemm_w4_kernel(GemmArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // [stage][W 32K | X 32K] x 2, then 4 x 8 KiB epilogue scratch
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wf = wave >> 1, wt = wave & 1;
+    const int n_tiles = p.n_ft * p.n_tt;
+    const int nk = p.K / 64;
+
+    // fragment read addresses: rows l & 31 of tile i (immediate offset i * 4096), chunk (2 ks + (l >> 5)) ^ ((row >> 1) & 7)
+    unsigned ra[2][4], rb[2][4];
+    {
+        const int row = lane & 31, hh = lane >> 5, g = (row >> 1) & 7;
+#pragma unroll
+        for (int st = 0; st < 2; ++st)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const unsigned off = (unsigned)(row * 128 + (((2 * ks + hh) ^ g) << 4));
+                ra[st][ks] = st * W4_STAGE + wf * 16384 + off;
+                rb[st][ks] = st * W4_STAGE + W4_B + wt * 16384 + off;
+            }
+    }
+    const unsigned mdA0 = wave * 8192, mdA1 = W4_STAGE + wave * 8192, mdB0 = W4_B + wave * 8192, mdB1 = W4_STAGE + W4_B + wave * 8192;
+    const char* const Wb = (const char*)p.W;
+    const char* const Xb = (const char*)p.X;
+
+    const int q8 = n_tiles >> 3, r8 = n_tiles & 7;
+    auto tile_of = [&](int w, int& f0, int& t0) {          // XCD-aware bijective remap, feature tiles fastest (as gemm_big_kernel)
+        const int xcd = w & 7, loc = w >> 3;
+        const int work = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + loc;
+        const int tile_t = work / p.n_ft;
+        f0 = (work - tile_t * p.n_ft) * 256;
+        t0 = tile_t * 256;
+    };
+
+    int work = blockIdx.x;
+    if (work >= n_tiles) return;
+    int f0, t0;
+    tile_of(work, f0, t0);
+    unsigned va[8], vb[8], van[8], vbn[8];
+    w4_offsets(p, f0, t0, wave, lane, va, vb);
+
+    // prologue: K-tile 0 (both operands) into stage 0, the W operand of K-tile 1 into stage 1; fragments of k-step 0
+#pragma unroll
+    for (int n = 0; n < 8; ++n) w4_dma(mdA0 + n * 1024, va[n], Wb);
+#pragma unroll
+    for (int n = 0; n < 8; ++n) w4_dma(mdB0 + n * 1024, vb[n], Xb);
+#pragma unroll
+    for (int n = 0; n < 8; ++n) w4_dma(mdA1 + n * 1024, va[n], Wb + 128);
+    asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
+    half8_t fa[2][4], fb[2][4];
+    asm volatile("ds_read_b128 %0, %8 offset:0\n\tds_read_b128 %1, %8 offset:4096\n\tds_read_b128 %2, %8 offset:8192\n\tds_read_b128 %3, %8 offset:12288\n\t"
+                 "ds_read_b128 %4, %9 offset:0\n\tds_read_b128 %5, %9 offset:4096\n\tds_read_b128 %6, %9 offset:8192\n\tds_read_b128 %7, %9 offset:12288\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&v"(fa[0][0]), "=&v"(fa[0][1]), "=&v"(fa[0][2]), "=&v"(fa[0][3]),
+                   "=&v"(fb[0][0]), "=&v"(fb[0][1]), "=&v"(fb[0][2]), "=&v"(fb[0][3])
+                 : "v"(ra[0][0]), "v"(rb[0][0])
+                 : "memory");
+
+    char* const scratch = smem + W4_SCRATCH + wave * 8192;
+    while (true) {
+        const int next = work + gridDim.x;
+        int nf0 = f0, nt0 = t0;
+        if (next < n_tiles) tile_of(next, nf0, nt0);       // (no next tile: the run-ahead DMAs re-fetch this one, nobody reads them)
+        w4_offsets(p, nf0, nt0, wave, lane, van, vbn);
+        float16_t acc[4][4];
+        // K-tile k: D1 = X of K-tile k + 1 into stage (k + 1) & 1, D2 = W of K-tile k + 2 into stage k & 1
+        gemm_ktile_first(acc, fa, fb, ra[0], rb[0], ra[1][0], rb[1][0], vb, va, Xb + 128, Wb + 256, mdB1, mdA0);
+        gemm_ktile(acc, fa, fb, ra[1], rb[1], ra[0][0], rb[0][0], vb, va, Xb + 256, Wb + 384, mdB0, mdA1);
+        for (int k = 2; k < nk - 2; k += 2) {
+            const char* xs = Xb + (long)(k + 1) * 128;
+            const char* ws = Wb + (long)(k + 2) * 128;
+            gemm_ktile(acc, fa, fb, ra[0], rb[0], ra[1][0], rb[1][0], vb, va, xs, ws, mdB1, mdA0);
+            gemm_ktile(acc, fa, fb, ra[1], rb[1], ra[0][0], rb[0][0], vb, va, xs + 128, ws + 128, mdB0, mdA1);
+        }
+        gemm_ktile(acc, fa, fb, ra[0], rb[0], ra[1][0], rb[1][0], vb, van, Xb + (long)(nk - 1) * 128, Wb, mdB1, mdA0);
+        gemm_ktile(acc, fa, fb, ra[1], rb[1], ra[0][0], rb[0][0], vbn, van, Xb, Wb + 128, mdB0, mdA1);
+        // MFMA result -> vector ALU: the stream ends on an MFMA and pads nothing
+        asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3"
+                     : "+a"(acc[0][0]), "+a"(acc[0][1]), "+a"(acc[0][2]), "+a"(acc[0][3]), "+a"(acc[1][0]), "+a"(acc[1][1]), "+a"(acc[1][2]),
+                       "+a"(acc[1][3]), "+a"(acc[2][0]), "+a"(acc[2][1]), "+a"(acc[2][2]), "+a"(acc[2][3]), "+a"(acc[3][0]), "+a"(acc[3][1]),
+                       "+a"(acc[3][2]), "+a"(acc[3][3]));
+        w4_epilogue<ACT, GATED>(p, acc, f0, t0, wf, wt, lane, scratch);
+        if (next >= n_tiles) break;
+        work = next; f0 = nf0; t0 = nt0;
+#pragma unroll
+        for (int n = 0; n < 8; ++n) { va[n] = van[n]; vb[n] = vbn[n]; }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the run-ahead DMAs of the tile that does not exist
+}
+
 static int g_stagger = 0;    // bh_k_linear_stagger
-static int g_force_v1 = 0;   // test / A-B hook (bh_k_linear_force_v1): 1 = v1 only, 2 = never v3
+static int g_force_v1 = 0;   // test / A-B hook (bh_k_linear_force_v1): 1 = v1 only, 2 = never v3 / v5, 3 = never v5 (v3 where it applies), 5 = v5 whenever the shape is legal (tests: small problems)
 
 template <int ACT, bool GATED>
 static void launch(const GemmArgs& a, hipStream_t s) {
     int grid = a.n_ft * a.n_tt;
-    // v3 when the problem has at least ~2 waves of 256 x 256 tiles over the chip and no K tail
+    // v5 (gemm_w4_kernel) / v3 when the problem has at least ~2 waves of 256 x 256 tiles over the chip and no K tail
     {
         const int nf3 = (a.N + BF3 - 1) / BF3, nt3 = (a.M + BT3 - 1) / BT3;
-        if (a.K % BK3 == 0 && g_force_v1 == 0 && a.N >= 256 && a.N % 16 == 0 && (long)nf3 * nt3 >= 512 &&
+        if (a.K % 128 == 0 && a.K >= 256 && (g_force_v1 == 0 || g_force_v1 == 5) && a.N % 256 == 0 && ((long)nf3 * nt3 >= 512 || g_force_v1 == 5) &&
+            (long)a.M * a.ldx < (1l << 31) && (long)a.N * a.ldw < (1l << 31)) {
+            int dev = 0, cus = 256;
+            if (hipGetDevice(&dev) != hipSuccess ||
+                hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+            GemmArgs b = a;
+            b.n_ft = nf3; b.n_tt = nt3;
+            const int tiles = nf3 * nt3;
+            (void)hipFuncSetAttribute((const void*)gemm_w4_kernel<ACT, GATED>, hipFuncAttributeMaxDynamicSharedMemorySize, W4_LDS);
+            hipLaunchKernelGGL((gemm_w4_kernel<ACT, GATED>), dim3(tiles < cus ? tiles : cus), dim3(256), W4_LDS, s, b);
+            return;
+        }
+        if (a.K % BK3 == 0 && (g_force_v1 == 0 || g_force_v1 == 3) && a.N >= 256 && a.N % 16 == 0 && (long)nf3 * nt3 >= 512 &&
             (long)a.M * a.ldx < (1l << 31) && (long)a.N * a.ldw < (1l << 31)) {
             int dev = 0, cus = 256;
             if (hipGetDevice(&dev) != hipSuccess ||

@@ -308,11 +308,11 @@ def test_linear_persistent_big_tile_kernel(M, N, K, gated):
     w = (torch.randn(N, K, generator=g) * 0.2).half().to(dev())
     b = torch.randn(N, generator=g).to(dev())
     try:
-        decode.set_option("gemm_path", 0)
+        decode.set_option("gemm_path", 3)            # (0 = automatic would pick the four-wave kernel where it applies: its own test below)
         big = _linear(x, w, b, act=0 if gated else 1, gated=gated)
         decode.set_option("gemm_path", 2)
         small = _linear(x, w, b, act=0 if gated else 1, gated=gated)
-        decode.set_option("gemm_path", 0)
+        decode.set_option("gemm_path", 3)
         decode.set_option("gemm_stagger", 3)
         again = _linear(x, w, b, act=0 if gated else 1, gated=gated)
     finally:
@@ -323,3 +323,80 @@ def test_linear_persistent_big_tile_kernel(M, N, K, gated):
     z = x[-3000:].float() @ w.float().T + b
     want = (z[:, 0::2] * z[:, 1::2] * torch.sigmoid(z[:, 1::2])) if gated else z * torch.sigmoid(z)
     assert (big[-3000:].float() - want).abs().max().item() < 3e-2 + 3e-3 * want.abs().max().item()
+
+
+def _linear_ref(x, w, b, act, gated, scale=1.0, lo=-INF, hi=INF):
+    z = x.float() @ w.float().T
+    if b is not None:
+        z = z + b.float()
+    if gated:
+        return z[:, 0::2] * z[:, 1::2] * torch.sigmoid(z[:, 1::2])
+    z = {0: z, 1: z * torch.sigmoid(z), 2: torch.tanh(z), 3: torch.relu(z)}[act] * scale
+    return z.clamp(lo, hi)
+
+
+@pytest.mark.parametrize("M,N,K,gated,act", [(300, 256, 256, 0, 0), (1000 + 7, 512, 384, 0, 1), (2048, 256, 512, 1, 0), (777, 768, 1024, 0, 2),
+                                             (40000 + 13, 1024, 384, 0, 1), (70000, 512, 512, 1, 0), (131072 + 5, 256, 2048, 0, 0)])
+def test_linear_four_wave_kernel(M, N, K, gated, act):
+    """gemm_w4_kernel (256 x 256 x 64 tile on four waves, 32x32x16 MFMAs, one generated instruction stream per K-tile, outputs
+    through an LDS scratch into full-line stores) serves K % 128 == 0, N % 256 == 0 problems of >= 512 tiles ("gemm_path" 5: any
+    legal shape). EVERY output row against the fp32 restatement on the device (it accumulates K in another order than the
+    16x16x32 kernels, so the bar is the tolerance of test_linear_plain, not bit equality with them), closeness to the 128-tile
+    kernel, and identical bytes when run twice; shortest (4) and long (32) K-tile streams, one workgroup walking several output
+    tiles, ragged last token tile, SwiGLU / swish / tanh epilogues with bias."""
+    from bonito_amd import decode
+    g = torch.Generator().manual_seed(M + K)
+    x = (torch.randn(M, K, generator=g) * 0.5).half().to(dev())
+    w = (torch.randn(N, K, generator=g) * 0.2).half().to(dev())
+    b = torch.randn(N, generator=g).to(dev())
+    try:
+        decode.set_option("gemm_path", 5)
+        got = _linear(x, w, b, act=act, gated=gated)
+        again = _linear(x, w, b, act=act, gated=gated)
+        decode.set_option("gemm_path", 2)
+        small = _linear(x, w, b, act=act, gated=gated)
+    finally:
+        decode.set_option("gemm_path", 0)
+    assert torch.equal(got, again)
+    worst = 0.0
+    for lo_ in range(0, M, 16384):                     # fp32 restatement on the device, every row
+        want = _linear_ref(x[lo_:lo_ + 16384], w, b, act, gated)
+        d = (got[lo_:lo_ + 16384].float() - want).abs().max().item()
+        worst = max(worst, d / (2e-2 + 2e-3 * want.abs().max().item()))
+    assert worst < 1.0, worst
+    assert (got.float() - small.float()).abs().max().item() < 2e-2 + 2e-3 * small.float().abs().max().item()
+
+
+def test_linear_four_wave_kernel_layouts_exactly():
+    """X = I-like (one 1.0 per row) against an asymmetric W: every output is one W element exactly, so a permuted fragment row, a
+    wrong swizzle or a transposed store shows up as a wrong value, not as noise. K = 256, several feature and token tiles."""
+    from bonito_amd import decode
+    M, N, K = 1024, 512, 256
+    x = torch.zeros(M, K)
+    x[torch.arange(M), (torch.arange(M) * 7) % K] = 1.0
+    w = ((torch.arange(N * K).reshape(N, K) * 37) % 2039 / 16.0).half()
+    want = w.float()[:, (torch.arange(M) * 7) % K].T.contiguous().half()
+    try:
+        decode.set_option("gemm_path", 5)
+        got = _linear(x.half().to(dev()), w.to(dev())).cpu()
+    finally:
+        decode.set_option("gemm_path", 0)
+    assert torch.equal(got, want)
+
+
+def test_linear_four_wave_kernel_row_remap_scale_clamp():
+    """The CRF head's call shape on the four-wave kernel: (t, n)-major rows -> [N][T][C] with the padded batch rows dropped, tanh,
+    scale 5, clamp."""
+    from bonito_amd import decode
+    T, Np, Nv, K, Cc = 70, 32, 27, 384, 1024
+    g = torch.Generator().manual_seed(8)
+    x = torch.randn(T * Np, K, generator=g).half()
+    w = (torch.randn(Cc, K, generator=g) * 0.1).half()
+    z = torch.tanh(x.float() @ w.float().T) * 5.0
+    want = z.clamp(-4.5, 4.5).view(T, Np, Cc)[:, :Nv].permute(1, 0, 2).reshape(Nv * T, Cc)
+    try:
+        decode.set_option("gemm_path", 5)
+        got = _linear(x.to(dev()), w.to(dev()), act=2, scale=5.0, lo=-4.5, hi=4.5, row=(Np, 1, T, Nv), out_rows=Nv * T).cpu().float()
+    finally:
+        decode.set_option("gemm_path", 0)
+    assert (got - want).abs().max().item() < 2e-2

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Per-shape throughput of bh_linear for the transformer / CRF-head shapes: auto path vs the 128-tile kernels."""
+"""Per-shape throughput of bh_linear for the transformer / CRF-head shapes: the automatic path (the four-wave kernel where it applies)
+vs the eight-wave 256-tile kernel ("gemm_path" 3), the 128-tile kernels and the vendor library behind torch.matmul."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -17,9 +18,8 @@ for M, N, K, gated in shapes:
     ncol = N // 2 if gated else N
     out = torch.empty((M, ncol), dtype=torch.float16, device=dev)
     res = {}
-    for path in (0, 2, 1003, 1006):          # >= 1000: the auto path with gemm_stagger p % 100
-        decode.set_option("gemm_path", 0 if path >= 1000 else path)
-        decode.set_option("gemm_stagger", path % 100 if path >= 1000 else 0)
+    for path in (0, 3, 2):
+        decode.set_option("gemm_path", path)
         def run():
             _lib.check(lib.bh_linear(_lib.ptr(x), _lib.ptr(w), None, _lib.ptr(out), M, N, K, K, K, ncol, 0, 1.0, -INF, INF,
                                      gated, 0, 0, 0, 0, _lib.stream_ptr()), "bh_linear")
@@ -32,7 +32,6 @@ for M, N, K, gated in shapes:
         ms = e0.elapsed_time(e1) / 10
         res[path] = (ms, 2.0 * M * N * K / ms / 1e9)
     decode.set_option("gemm_path", 0); decode.set_option("gemm_stagger", 0)
-    print("   staggered start: " + "  ".join("%d: %.3f ms %.0f TF/s" % (k % 100, v[0], v[1]) for k, v in res.items() if k >= 1000))
     # yardstick: the vendor library behind torch.matmul (hipBLASLt / rocBLAS), plain GEMM without the fused epilogue
     full = torch.empty((M, N), dtype=torch.float16, device=dev)
     for _ in range(3): torch.matmul(x, w.t(), out=full)
@@ -43,6 +42,7 @@ for M, N, K, gated in shapes:
     e1.record(); torch.cuda.synchronize()
     lib_ms = e0.elapsed_time(e1) / 10
     del full
-    print("M=%d N=%d K=%d gated=%d: auto %.3f ms %.0f TF/s | 128-tile %.3f ms %.0f TF/s | torch.matmul %.3f ms %.0f TF/s" % (
-        M, N, K, gated, res[0][0], res[0][1], res[2][0], res[2][1], lib_ms, 2.0 * M * N * K / lib_ms / 1e9))
+    lib_tf = 2.0 * M * N * K / lib_ms / 1e9
+    print("M=%d N=%d K=%d gated=%d: auto %.3f ms %.0f TF/s (%.2f x lib) | 8-wave 256-tile %.3f ms %.0f TF/s | 128-tile %.3f ms %.0f TF/s | torch.matmul %.3f ms %.0f TF/s" % (
+        M, N, K, gated, res[0][0], res[0][1], res[0][1] / lib_tf, res[3][0], res[3][1], res[2][0], res[2][1], lib_ms, lib_tf), flush=True)
     del x, w, out
