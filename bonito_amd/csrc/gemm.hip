@@ -16,6 +16,7 @@
 //    same conflict-free pattern for both operands.
 //  * XCD-aware block remap: blocks that land on the same XCD (blockIdx % 8) walk consecutive
 //    feature tiles of the same token tile, so the X tile is fetched into that XCD's L2 once.
+#include <type_traits>
 #include "common.h"
 #include "kernels.h"
 
@@ -42,6 +43,10 @@ struct GemmArgs {
     const float* rot_cs = nullptr;   // [rot_T][32][2] (cos, sin)
     int rot_T = 1, rot_nfeat = 0, rot_qfeat = 0;
     float rot_qscale = 1.0f;
+    int w4_gf = 4;     // gemm_w4_kernel: feature tiles per block of its work order (1, 2, 4, 8, 16 or 32; see the kernel)
+#ifdef BH_GEMM_STATS
+    unsigned long long* dbg = nullptr;   // tools/gemm_lab.hip: cycle stamps of workgroup 0 (K loops, epilogues, total, real-time ticks, tiles)
+#endif
 };
 
 constexpr int BF = 128, BT = 128, BK = 64;
@@ -527,227 +532,320 @@ __global__ __launch_bounds__(512, 1) void gemm_big_kernel(GemmArgs p) {
 // K-tile g lives in stage g & 1; K % 128 == 0 keeps that parity across output tiles, so the streams of a tile are unrolled by
 // two with the stage as a compile-time choice of operands; the DMA cursor runs one (X) / two (W) K-tiles ahead and crosses into the
 // NEXT output tile in the last two instances (persistent kernel: the first K-tile of the next tile lands under the epilogue).
-#include "gemm_ktile_mfma.inc"
+#ifndef BH_GEMM_KTILE_INC
+#define BH_GEMM_KTILE_INC "gemm_ktile_mfma.inc"      // (tools/gemm_lab.hip builds the kernel around other variants of the stream)
+#endif
+#include BH_GEMM_KTILE_INC
 
-constexpr int W4_STAGE = 65536, W4_B = 32768, W4_SCRATCH = 131072, W4_LDS = 163840;
+constexpr int W4_OP = 32768, W4_BRING = 3 * W4_OP, W4_LDS = 5 * W4_OP;     // A ring: three 32 KiB stages, B ring: two
 
 __device__ __forceinline__ void w4_dma(unsigned m0v, unsigned voff, const char* sbase) {
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(m0v), "v"(voff), "s"(sbase) : "memory");
 }
 
-// per-lane byte offsets of this wave's eight DMA pieces of each operand for the output tile (f0, t0)
+// per-lane byte offsets of this wave's eight DMA pieces of each operand for the output tile (f0, t0): va = X (tokens, MFMA A), vb = W (features, B)
 __device__ __forceinline__ void w4_offsets(const GemmArgs& p, int f0, int t0, int wave, int lane, unsigned (&va)[8], unsigned (&vb)[8]) {
     const int lr = lane >> 3, slot = lane & 7;
 #pragma unroll
     for (int n = 0; n < 8; ++n) {
         const int R = wave * 64 + n * 8 + lr;                 // LDS row of this lane's chunk
         const int chunk = slot ^ ((R >> 1) & 7);
-        const int rho = R & 31, i = (R >> 5) & 3;
-        const int feat = f0 + (R >> 7) * 128 + (i >> 1) * 64 + 32 * ((rho >> 2) & 1) + 16 * (i & 1) + 4 * (rho >> 3) + (rho & 3);
-        va[n] = (unsigned)min(feat, p.N - 1) * (unsigned)(p.ldw * 2) + chunk * 16;
-        vb[n] = (unsigned)min(t0 + R, p.M - 1) * (unsigned)(p.ldx * 2) + chunk * 16;
+        // token ring: row R = token t0 + R. Feature ring: row R = (wave half R >> 7, MFMA tile j = (R >> 5) & 3, tile row rho = R & 31) holds
+        // feature 128 (R >> 7) + 64 (j >> 1) + 32 ((rho >> 2) & 1) + 16 (j & 1) + 4 (rho >> 3) + (rho & 3): accumulator register r of lane
+        // half h is tile row (r & 3) + 8 (r >> 2) + 4 h, so the lane holds the 32 CONSECUTIVE features 32 h + 16 (j & 1) + r of the pair
+        const int rho = R & 31, j = (R >> 5) & 3;
+        const int feat = f0 + (R >> 7) * 128 + (j >> 1) * 64 + 32 * ((rho >> 2) & 1) + 16 * (j & 1) + 4 * (rho >> 3) + (rho & 3);
+        va[n] = (unsigned)min(t0 + R, p.M - 1) * (unsigned)(p.ldx * 2) + chunk * 16;
+        vb[n] = (unsigned)min(feat, p.N - 1) * (unsigned)(p.ldw * 2) + chunk * 16;
     }
 }
 
-// Epilogue of one wave: acc[i][j] (i: 32-feature MFMA tiles of the wave's 128 features, j: 32-token tiles) -> bias / residual / rotary /
-// activation / scale / clamp / SwiGLU exactly as gemm_epilogue above, then through the wave's LDS scratch into full-line stores.
+// Epilogue of one wave. acc[i][j][r] of lane (h = l >> 5, col = l & 31): token tw + 32 i + col, feature fw + 64 (j >> 1) + 32 h + 16 (j & 1)
+// + r - a lane holds 32 consecutive features of ONE token per pair of feature tiles, i.e. the tokens run along the lanes, and a store
+// straight from this layout would touch 64 different rows per instruction. What the CU's store path costs is instructions, not bytes
+// (measured: ~48 cycles per 64-lane dwordx2 store and ~74 per dwordx4 store whatever they write - 128 KiB per output tile took 12.4 k
+// cycles as 256 dwordx2 stores of whole 256-byte row slices, 9.5 k as 128 dwordx4 stores of whole 128-byte lines; the chip-wide HBM
+// rate is nowhere near its limit), so the tile leaves as the FEWEST, WIDEST stores: dwordx4, eight lanes per 128-byte line.
+// That needs a transposition, through LDS: a block of 32 tokens x 64 features goes out as fp32 straight from the accumulation registers
+// (ds_write_b128 with an AGPR data operand, no v_accvgpr_read) and comes back as lane (tl = l >> 3, q = l & 7) <- features 8 q .. 8 q + 7
+// of token tl + 8 rr, rr < 4. Everything else happens in THAT layout: bias (8 values per lane and feature pair), residual (one
+// coalesced 16-byte buffer load per row), rotary (the partner dims +-32 of a head of 64 sit in lane ^ 4), activation, scale / clamp,
+// SwiGLU (four (y, gate) pairs per lane), ONE rounding to fp16. Stores and residual loads are buffer operations (tile base in a scalar
+// resource, the lane's column in a loop-invariant voffset, the row in a scalar soffset: no vector address arithmetic); rows that are
+// not stored (ragged last token tile, dropped batch-padding rows) are predicated in a second instance of the code that only such tiles run. The row map must be
+// affine over a tile: identity, or a remap whose group size is a multiple of 256 (the launcher sends nothing else to this kernel).
+// LDS: the block is 8 KiB = this wave's slice of the A-ring stage the last K-tile just vacated (`scratch`; the next instance's DMA into
+// that slice is issued by this wave, behind its epilogue). Rows are 256 B = sixteen 16-byte pieces, piece k of token t at position
+// k ^ (t & 15): writes (8-lane groups = 8 tokens x one piece) and reads (16-lane groups = 4 tokens x 4 lanes) are conflict free. Block
+// b + 1 is written while block b's reads are in flight (the LDS operations of one wave execute in issue order).
 template <int ACT, bool GATED>
-__device__ __forceinline__ void w4_epilogue(const GemmArgs& p, float16_t (&acc)[4][4], int f0, int t0, int wf, int wt, int lane, char* scratch) {
+__device__ __forceinline__ void w4_epilogue(const GemmArgs& p, float16_t (&acc)[4][4], int f0, int t0, int wa, int wb, int lane, char* scratch) {
     const int h = lane >> 5, col = lane & 31;
+    const int tl = lane >> 3, q = lane & 7;
+    const int fw = f0 + wb * 128, tw = t0 + wa * 128;
     const bool ident = p.row_div == 1 && p.row_s_hi == 1;
     const bool plain = p.scale == 1.0f && p.clamp_lo == -INFINITY && p.clamp_hi == INFINITY;
-    const int tl = lane >> 3, q = lane & 7;               // store side: token tl + 8 rr of the block, 16-byte piece q of its 128-byte row
-    auto drain = [&](int j, int buf, long fcol) {         // the block of token tile j in scratch buffer `buf` -> out[.][fcol + 8 q ..]
-        __builtin_amdgcn_wave_barrier();
+    const int hi_u = ident ? 0 : t0 / p.row_div;
+    const int mlim = ident ? p.M : min(p.M, hi_u * p.row_div + p.row_lim);       // tokens >= mlim of this tile are not stored
+    const long o0 = ident ? (long)tw : (long)hi_u * p.row_s_hi + (long)(tw - hi_u * p.row_div) * p.row_s_lo;
+    const int rowbytes = (ident ? 1 : (int)p.row_s_lo) * p.ldo * 2;              // bytes between consecutive tokens (< 16 MiB)
+    const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(p.out + o0 * p.ldo + (GATED ? fw >> 1 : fw)), 0, 0x7ffffff0, 0x00020000);
+    const int ovoff = tl * rowbytes + (GATED ? 8 * q : 16 * q);
+    const bool has_res = p.res != nullptr;
+    const __amdgpu_buffer_rsrc_t rrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(has_res ? p.res + (long)tw * p.ldres + fw : p.out), 0, 0x7ffffff0, 0x00020000);
+    const int resbytes = p.ldres * 2;
+    const int rvoff = tl * resbytes + 16 * q;
+    float bq[2][8];
 #pragma unroll
-        for (int rr = 0; rr < 4; ++rr) {
-            const int tok = tl + 8 * rr;
-            const uint4_t v = *(const uint4_t*)(scratch + buf * 4096 + tok * 128 + ((q ^ (tok & 7)) << 4));
-            const int m = t0 + wt * 128 + j * 32 + tok;
-            if (m >= p.M) continue;
-            long orow = m;
-            if (!ident) {
-                const int hi = m / p.row_div, lo = m - hi * p.row_div;
-                if (lo >= p.row_lim) continue;
-                orow = (long)hi * p.row_s_hi + (long)lo * p.row_s_lo;
-            }
-            *(uint4_t*)(p.out + orow * p.ldo + fcol + q * 8) = v;
+    for (int P = 0; P < 2; ++P) {
+        float4_t b0 = {0.f, 0.f, 0.f, 0.f}, b1 = b0;
+        if (p.bias != nullptr) { b0 = *(const float4_t*)(p.bias + fw + P * 64 + 8 * q); b1 = *(const float4_t*)(p.bias + fw + P * 64 + 8 * q + 4); }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { bq[P][e] = b0[e]; bq[P][4 + e] = b1[e]; }
+    }
+    const bool rot = !GATED && p.rot_cs != nullptr;
+    const float rsgn = q < 4 ? -1.0f : 1.0f;
+    const int pos0 = rot ? (tw + tl) % p.rot_T : 0;                              // position of the lane's first row (rot_T >= 256: one wrap at most)
+    const float* const cs0 = p.rot_cs + (q & 3) * 16;
+    char* const wrow = scratch + col * 256;
+    const int wx = col & 15;
+    auto write_block = [&](const float16_t& a0, const float16_t& a1) {          // the lane's 32 features of one token: tiles j = 2 P, 2 P + 1
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float4_t v0 = {a0[4 * c], a0[4 * c + 1], a0[4 * c + 2], a0[4 * c + 3]};
+            const float4_t v1 = {a1[4 * c], a1[4 * c + 1], a1[4 * c + 2], a1[4 * c + 3]};
+            *(float4_t*)(wrow + (((8 * h + c) ^ wx) << 4)) = v0;
+            *(float4_t*)(wrow + (((8 * h + 4 + c) ^ wx) << 4)) = v1;
         }
-        __builtin_amdgcn_wave_barrier();
     };
-    int nblk = 0;
+    auto blocks = [&](auto masked) {
+        constexpr bool MASKED = decltype(masked)::value;
+        write_block(acc[0][0], acc[0][1]);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int m = t0 + wt * 128 + j * 32 + col;       // this lane's token in the accumulator layout
+        for (int b = 0; b < 8; ++b) {
+            const int i = b >> 1, P = b & 1;                // token tile, feature pair
+            float4_t lo[4], hi[4];
 #pragma unroll
-        for (int P = 0; P < 2; ++P) {
-            const int fb = f0 + wf * 128 + P * 64 + 32 * h;       // the lane's 32 consecutive features
-            float v[32];
+            for (int rr = 0; rr < 4; ++rr) {
+                const int tr = tl + 8 * rr;
+                lo[rr] = *(const float4_t*)(scratch + tr * 256 + (((2 * q) ^ (tr & 15)) << 4));
+                hi[rr] = *(const float4_t*)(scratch + tr * 256 + (((2 * q + 1) ^ (tr & 15)) << 4));
+            }
+            uint4_t rres[4];
+            if (has_res) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { v[r] = acc[2 * P][j][r]; v[16 + r] = acc[2 * P + 1][j][r]; }
-            if (p.bias != nullptr) {
-#pragma unroll
-                for (int i = 0; i < 32; i += 4) {
-                    const float4_t b4 = *(const float4_t*)(p.bias + fb + i);
-                    v[i] += b4[0]; v[i + 1] += b4[1]; v[i + 2] += b4[2]; v[i + 3] += b4[3];
+                for (int rr = 0; rr < 4; ++rr) {
+                    rres[rr] = uint4_t{0u, 0u, 0u, 0u};
+                    if (!MASKED || tw + 32 * i + 8 * rr + tl < mlim)
+                        rres[rr] = __builtin_amdgcn_raw_buffer_load_b128(rrsrc, rvoff + P * 128, (32 * i + 8 * rr) * resbytes, 0);
                 }
             }
-            if (p.res != nullptr && m < p.M) {
-                const half_t* rp = p.res + (long)m * p.ldres + fb;
+            if (b + 1 < 8) write_block(acc[(b + 1) >> 1][2 * ((b + 1) & 1)], acc[(b + 1) >> 1][2 * ((b + 1) & 1) + 1]);
+            const bool rot_here = rot && fw + P * 64 < p.rot_nfeat;
+            const float rqs = fw + P * 64 < p.rot_qfeat ? p.rot_qscale : 1.0f;
 #pragma unroll
-                for (int i = 0; i < 32; i += 8) {
-                    const half8_t r8 = *(const half8_t*)(rp + i);
+            for (int rr = 0; rr < 4; ++rr) {
+                float v[8] = {lo[rr][0] + bq[P][0], lo[rr][1] + bq[P][1], lo[rr][2] + bq[P][2], lo[rr][3] + bq[P][3],
+                              hi[rr][0] + bq[P][4], hi[rr][1] + bq[P][5], hi[rr][2] + bq[P][6], hi[rr][3] + bq[P][7]};
+                if (has_res) {
+                    const half8_t r8 = __builtin_bit_cast(half8_t, rres[rr]);
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) v[i + e] += (float)r8[e];
+                    for (int e = 0; e < 8; ++e) v[e] += (float)r8[e];
                 }
-            }
-            if constexpr (!GATED) {
-                // rotary embedding of the packed Wqkv projection (see gemm_epilogue): the pair of tiles is one head of 64, this lane
-                // holds dims 32 h .. 32 h + 31, the partner dim (+-32) of every value sits in lane ^ 32 at the same index
-                if (p.rot_cs != nullptr && f0 + wf * 128 + P * 64 < p.rot_nfeat) {
-                    const int pos = m % p.rot_T;
-                    const float* cs = p.rot_cs + (long)pos * 64;
-                    const float sgn = h == 0 ? -1.0f : 1.0f;
-                    const float qs = f0 + wf * 128 + P * 64 < p.rot_qfeat ? p.rot_qscale : 1.0f;
+                if constexpr (!GATED) {
+                    if (rot_here) {
+                        // rotary embedding of the packed Wqkv projection (see gemm_epilogue): the 64-feature pair is one head, lanes q < 4
+                        // hold its first half, q >= 4 the second; the partner of dim d is dim d +- 32 = lane ^ 4, same index
+                        int pos = pos0 + 32 * i + 8 * rr;
+                        pos = pos >= p.rot_T ? pos - p.rot_T : pos;
+                        const float* cs = cs0 + (long)pos * 64;
 #pragma unroll
-                    for (int i = 0; i < 32; i += 2) {
-                        const float4_t c4 = *(const float4_t*)(cs + 2 * i);      // (cos, sin) of dims i, i + 1
-                        const float pa = __shfl_xor(v[i], 32), pb = __shfl_xor(v[i + 1], 32);
-                        v[i] = (v[i] * c4[0] + sgn * pa * c4[1]) * qs;
-                        v[i + 1] = (v[i + 1] * c4[2] + sgn * pb * c4[3]) * qs;
+                        for (int e = 0; e < 8; e += 2) {
+                            const float4_t c4 = *(const float4_t*)(cs + 2 * e);      // (cos, sin) of dims e, e + 1 of this lane's eight
+                            const float pa = __shfl_xor(v[e], 4), pb = __shfl_xor(v[e + 1], 4);
+                            v[e] = (v[e] * c4[0] + rsgn * pa * c4[1]) * rqs;
+                            v[e + 1] = (v[e + 1] * c4[2] + rsgn * pb * c4[3]) * rqs;
+                        }
                     }
                 }
-            }
-            const int buf = nblk & 1;
-            char* row = scratch + buf * 4096 + col * 128;
-            if constexpr (GATED) {
-                // W rows interleaved on the host: feature 2 k = y_k, 2 k + 1 = gate_k; 16 outputs = two 16-byte pieces 4 P + 2 h, + 1
-                float y[16];
+                const bool live = !MASKED || tw + 32 * i + 8 * rr + tl < mlim;
+                const int vo = ovoff;
+                if constexpr (GATED) {
+                    // W rows interleaved on the host: feature 2 k = y_k, 2 k + 1 = gate_k: four outputs per lane, 8 bytes
+                    float4_t y;
 #pragma unroll
-                for (int i = 0; i < 16; ++i) y[i] = v[2 * i] * swishf_(v[2 * i + 1]);
-#pragma unroll
-                for (int c = 0; c < 2; ++c) {
+                    for (int k = 0; k < 4; ++k) y[k] = v[2 * k] * swishf_(v[2 * k + 1]);
+                    if (live)
+                        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(uint2_t, __builtin_convertvector(y, half4_t)), orsrc, vo + P * 64,
+                                                              (32 * i + 8 * rr) * rowbytes, 0);
+                } else {
                     float8_t f8;
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) f8[e] = y[c * 8 + e];
-                    const half8_t o = __builtin_convertvector(f8, half8_t);
-                    *(half8_t*)(row + (((4 * P + 2 * h + c) ^ (col & 7)) << 4)) = o;
+                    for (int e = 0; e < 8; ++e) f8[e] = apply_act<ACT>(v[e]);
+                    if (!plain) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) f8[e] = fminf(fmaxf(f8[e] * p.scale, p.clamp_lo), p.clamp_hi);
+                    }
+                    if (live)
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uint4_t, __builtin_convertvector(f8, half8_t)), orsrc, vo + P * 128,
+                                                               (32 * i + 8 * rr) * rowbytes, 0);
                 }
-                if (P == 1) { drain(j, buf, (long)((f0 + wf * 128) >> 1)); ++nblk; }
-            } else {
-#pragma unroll
-                for (int i = 0; i < 32; ++i) v[i] = apply_act<ACT>(v[i]);
-                if (!plain) {
-#pragma unroll
-                    for (int i = 0; i < 32; ++i) v[i] = fminf(fmaxf(v[i] * p.scale, p.clamp_lo), p.clamp_hi);
-                }
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    float8_t f8;
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) f8[e] = v[c * 8 + e];
-                    const half8_t o = __builtin_convertvector(f8, half8_t);
-                    *(half8_t*)(row + (((4 * h + c) ^ (col & 7)) << 4)) = o;
-                }
-                drain(j, buf, (long)(f0 + wf * 128 + P * 64));
-                ++nblk;
             }
         }
-    }
+    };
+    if (tw + 128 <= mlim) blocks(std::false_type{});
+    else blocks(std::true_type{});
 }
 
 template <int ACT, bool GATED>
 __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(GemmArgs p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];   // [stage][W 32K | X 32K] x 2, then 4 x 8 KiB epilogue scratch
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // [stage][X tile 32K | W tile 32K] x 2 (addressed by offset only)
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wf = wave >> 1, wt = wave & 1;
-    const int n_tiles = p.n_ft * p.n_tt;
+    const int wa = wave >> 1, wb = wave & 1;
     const int nk = p.K / 64;
 
-    // fragment read addresses: rows l & 31 of tile i (immediate offset i * 4096), chunk (2 ks + (l >> 5)) ^ ((row >> 1) & 7)
-    unsigned ra[2][4], rb[2][4];
+    // fragment read addresses: rows l & 31 of tile i (immediate offset i * 4096), chunk (2 ks + (l >> 5)) ^ ((row >> 1) & 7); the stage
+    // offsets (A ring: three stages from LDS 0, B ring: two from W4_BRING) are scalars added inside the stream
+    unsigned rab[4], rbb[4];
     {
         const int row = lane & 31, hh = lane >> 5, g = (row >> 1) & 7;
 #pragma unroll
-        for (int st = 0; st < 2; ++st)
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                const unsigned off = (unsigned)(row * 128 + (((2 * ks + hh) ^ g) << 4));
-                ra[st][ks] = st * W4_STAGE + wf * 16384 + off;
-                rb[st][ks] = st * W4_STAGE + W4_B + wt * 16384 + off;
-            }
+        for (int ks = 0; ks < 4; ++ks) {
+            const unsigned off = (unsigned)(row * 128 + (((2 * ks + hh) ^ g) << 4));
+            rab[ks] = wa * 16384 + off;
+            rbb[ks] = wb * 16384 + off;
+        }
     }
-    const unsigned mdA0 = wave * 8192, mdA1 = W4_STAGE + wave * 8192, mdB0 = W4_B + wave * 8192, mdB1 = W4_STAGE + W4_B + wave * 8192;
-    const char* const Wb = (const char*)p.W;
-    const char* const Xb = (const char*)p.X;
+    const unsigned wdma = wave * 8192;                       // this wave's eight pieces of a 32 KiB operand tile
+    const char* const Ab = (const char*)p.X;      // MFMA A operand: tokens
+    const char* const Bb = (const char*)p.W;      // MFMA B operand: features
 
-    const int q8 = n_tiles >> 3, r8 = n_tiles & 7;
-    auto tile_of = [&](int w, int& f0, int& t0) {          // XCD-aware bijective remap, feature tiles fastest (as gemm_big_kernel)
+    // Work order (persistent kernel, block b on XCD b % 8 - observed dispatch, for speed only). XCD x owns the token tiles
+    // [tlo, tlo + NT); inside its share the order is: blocks of GF feature tiles x GT token tiles (GF * GT = 32 = one sweep of the
+    // XCD's CUs: 32 workgroups share GF W tiles and GT X tiles, GF + GT L2 fills per K-tile instead of 32 + 32 / n_ft), token
+    // blocks fastest, so the GF W tiles stay in the XCD's L2 while the X tiles stream past once per group of GF feature tiles.
+    // (Feature tiles fastest over ALL of them, as gemm_big_kernel walks, puts n_ft W tiles - 4 MiB at N = 4096, K = 512: the whole
+    // L2 - in competition with the X stream: 2800-3600 cycles per K-tile at N = 4096 against 2250 at N = 512.) Slots that fall
+    // outside the problem (ragged edges of the blocking) are skipped: every tile is visited exactly once for any grid.
+    const int GF = p.w4_gf, GT = 32 / GF;
+    const int tq = p.n_tt >> 3, tr = p.n_tt & 7;
+    const int nbt = ((tq + (tr ? 1 : 0)) + GT - 1) / GT, nfg = (p.n_ft + GF - 1) / GF;
+    const int slots = 8 * nfg * nbt * 32;
+    auto tile_of = [&](int w, int& f0, int& t0) -> bool {
         const int xcd = w & 7, loc = w >> 3;
-        const int work = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + loc;
-        const int tile_t = work / p.n_ft;
-        f0 = (work - tile_t * p.n_ft) * 256;
-        t0 = tile_t * 256;
+        const int NT = tq + (xcd < tr ? 1 : 0), tlo = xcd * tq + min(xcd, tr);
+        const int blk = loc >> 5, within = loc & 31;
+        const int fg = blk / nbt, tg = blk - fg * nbt;
+        const int tf = fg * GF + within % GF, tt = tg * GT + within / GF;
+        f0 = tf * 256;
+        t0 = (tlo + tt) * 256;
+        return tf < p.n_ft && tt < NT;
+    };
+    auto next_valid = [&](int w, int& f0, int& t0) -> int {       // first slot >= w (stride gridDim) that holds a tile; `slots` if none
+        for (; w < slots; w += gridDim.x)
+            if (tile_of(w, f0, t0)) return w;
+        return slots;
     };
 
-    int work = blockIdx.x;
-    if (work >= n_tiles) return;
-    int f0, t0;
-    tile_of(work, f0, t0);
+    int f0 = 0, t0 = 0;
+    int work = next_valid(blockIdx.x, f0, t0);
+    if (work >= slots) return;
+    // Phase stagger. Every workgroup has the same work per tile, so all 256 CUs would reach their epilogues together and 32 MiB of
+    // output would head for HBM in one burst while every matrix core waits (measured: the epilogue takes 12 k cycles = 5 us = 32 MiB at
+    // 6.4 TB/s whatever its instruction count - three versions of it, 600 to 2000 instructions, all took 9.5-14 k cycles) - and then
+    // nobody writes for a K loop. The workgroups of an XCD therefore start in eight phase groups, p.stagger cycles apart (an eighth of
+    // a tile's duration): one group's stores overlap the K loops of the other seven. (gemm_big_kernel's "gemm_stagger" is the same idea.)
+    if (p.stagger > 0) {
+        const unsigned long long until = __builtin_readcyclecounter() + (unsigned long long)(((blockIdx.x >> 3) & 7) * p.stagger);
+        while (__builtin_readcyclecounter() < until) __builtin_amdgcn_s_sleep(32);
+    }
     unsigned va[8], vb[8], van[8], vbn[8];
     w4_offsets(p, f0, t0, wave, lane, va, vb);
 
-    // prologue: K-tile 0 (both operands) into stage 0, the W operand of K-tile 1 into stage 1; fragments of k-step 0
+    // prologue: K-tiles 0 and 1 of both operands; fragments of k-step 0 of K-tile 0
+    unsigned a0 = 0, a1 = W4_OP, a2 = 2 * W4_OP;             // A stage offsets of K-tiles G, G + 1, G + 2 (rotating)
+    unsigned b0 = W4_BRING, b1 = W4_BRING + W4_OP;           // B stage offsets of K-tiles G, G + 1 (alternating)
 #pragma unroll
-    for (int n = 0; n < 8; ++n) w4_dma(mdA0 + n * 1024, va[n], Wb);
+    for (int n = 0; n < 8; ++n) w4_dma(a0 + wdma + n * 1024, va[n], Ab);
 #pragma unroll
-    for (int n = 0; n < 8; ++n) w4_dma(mdB0 + n * 1024, vb[n], Xb);
+    for (int n = 0; n < 8; ++n) w4_dma(b0 + wdma + n * 1024, vb[n], Bb);
 #pragma unroll
-    for (int n = 0; n < 8; ++n) w4_dma(mdA1 + n * 1024, va[n], Wb + 128);
-    asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
+    for (int n = 0; n < 8; ++n) w4_dma(a1 + wdma + n * 1024, va[n], Ab + 128);
+#pragma unroll
+    for (int n = 0; n < 8; ++n) w4_dma(b1 + wdma + n * 1024, vb[n], Bb + 128);
+    asm volatile("s_waitcnt vmcnt(16)\n\ts_barrier" ::: "memory");
     half8_t fa[2][4], fb[2][4];
     asm volatile("ds_read_b128 %0, %8 offset:0\n\tds_read_b128 %1, %8 offset:4096\n\tds_read_b128 %2, %8 offset:8192\n\tds_read_b128 %3, %8 offset:12288\n\t"
                  "ds_read_b128 %4, %9 offset:0\n\tds_read_b128 %5, %9 offset:4096\n\tds_read_b128 %6, %9 offset:8192\n\tds_read_b128 %7, %9 offset:12288\n\t"
                  "s_waitcnt lgkmcnt(0)"
                  : "=&v"(fa[0][0]), "=&v"(fa[0][1]), "=&v"(fa[0][2]), "=&v"(fa[0][3]),
                    "=&v"(fb[0][0]), "=&v"(fb[0][1]), "=&v"(fb[0][2]), "=&v"(fb[0][3])
-                 : "v"(ra[0][0]), "v"(rb[0][0])
+                 : "v"(rab[0] + a0), "v"(rbb[0] + b0)
                  : "memory");
 
-    char* const scratch = smem + W4_SCRATCH + wave * 8192;
+#ifdef BH_GEMM_STATS
+    unsigned long long st_loop = 0, st_epi = 0, st_tiles = 0;
+    const unsigned long long st_t0 = __builtin_readcyclecounter(), st_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
     while (true) {
-        const int next = work + gridDim.x;
+#ifdef BH_GEMM_STATS
+        const unsigned long long st_a = __builtin_readcyclecounter();
+#endif
         int nf0 = f0, nt0 = t0;
-        if (next < n_tiles) tile_of(next, nf0, nt0);       // (no next tile: the run-ahead DMAs re-fetch this one, nobody reads them)
+        int tf0 = 0, tt0 = 0;
+        const int next = next_valid(work + gridDim.x, tf0, tt0);
+        if (next < slots) { nf0 = tf0; nt0 = tt0; }         // (no next tile: the run-ahead DMAs re-fetch this one, nobody reads them)
         w4_offsets(p, nf0, nt0, wave, lane, van, vbn);
         float16_t acc[4][4];
-        // K-tile k: D1 = X of K-tile k + 1 into stage (k + 1) & 1, D2 = W of K-tile k + 2 into stage k & 1
-        gemm_ktile_first(acc, fa, fb, ra[0], rb[0], ra[1][0], rb[1][0], vb, va, Xb + 128, Wb + 256, mdB1, mdA0);
-        gemm_ktile(acc, fa, fb, ra[1], rb[1], ra[0][0], rb[0][0], vb, va, Xb + 256, Wb + 384, mdB0, mdA1);
-        for (int k = 2; k < nk - 2; k += 2) {
-            const char* xs = Xb + (long)(k + 1) * 128;
-            const char* ws = Wb + (long)(k + 2) * 128;
-            gemm_ktile(acc, fa, fb, ra[0], rb[0], ra[1][0], rb[1][0], vb, va, xs, ws, mdB1, mdA0);
-            gemm_ktile(acc, fa, fb, ra[1], rb[1], ra[0][0], rb[0][0], vb, va, xs + 128, ws + 128, mdB0, mdA1);
+        // instance of K-tile k: reads A stage a0 / B stage b0 (k-step 0 of K-tile k + 1 from a1 / b1), D1 = A of K-tile k + 2 into A stage
+        // a2, D2 = B of K-tile k + 2 into B stage b0; the DMA cursor crosses into the NEXT output tile in the last two instances
+#define W4_ROTATE() do { const unsigned ta = a0; a0 = a1; a1 = a2; a2 = ta; const unsigned tb = b0; b0 = b1; b1 = tb; } while (0)
+        gemm_ktile_first(acc, fa, fb, rab, rbb, a0, b0, a1, b1, va, vb, Ab + 256, Bb + 256, a2 + wdma, b0 + wdma);
+        W4_ROTATE();
+        for (int k = 1; k < nk - 2; ++k) {
+            gemm_ktile(acc, fa, fb, rab, rbb, a0, b0, a1, b1, va, vb, Ab + (long)(k + 2) * 128, Bb + (long)(k + 2) * 128, a2 + wdma, b0 + wdma);
+            W4_ROTATE();
         }
-        gemm_ktile(acc, fa, fb, ra[0], rb[0], ra[1][0], rb[1][0], vb, van, Xb + (long)(nk - 1) * 128, Wb, mdB1, mdA0);
-        gemm_ktile(acc, fa, fb, ra[1], rb[1], ra[0][0], rb[0][0], vbn, van, Xb, Wb + 128, mdB0, mdA1);
+        gemm_ktile(acc, fa, fb, rab, rbb, a0, b0, a1, b1, van, vbn, Ab, Bb, a2 + wdma, b0 + wdma);
+        W4_ROTATE();
+        gemm_ktile(acc, fa, fb, rab, rbb, a0, b0, a1, b1, van, vbn, Ab + 128, Bb + 128, a2 + wdma, b0 + wdma);
+        W4_ROTATE();
+#undef W4_ROTATE
+#ifdef BH_GEMM_STATS
+        const unsigned long long st_b = __builtin_readcyclecounter();
+#endif
         // MFMA result -> vector ALU: the stream ends on an MFMA and pads nothing
         asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3"
                      : "+a"(acc[0][0]), "+a"(acc[0][1]), "+a"(acc[0][2]), "+a"(acc[0][3]), "+a"(acc[1][0]), "+a"(acc[1][1]), "+a"(acc[1][2]),
                        "+a"(acc[1][3]), "+a"(acc[2][0]), "+a"(acc[2][1]), "+a"(acc[2][2]), "+a"(acc[2][3]), "+a"(acc[3][0]), "+a"(acc[3][1]),
                        "+a"(acc[3][2]), "+a"(acc[3][3]));
-        w4_epilogue<ACT, GATED>(p, acc, f0, t0, wf, wt, lane, scratch);
-        if (next >= n_tiles) break;
+        // (a2: the A stage the last K-tile has just vacated - the next instance's D1 target - serves as the transposition scratch)
+        w4_epilogue<ACT, GATED>(p, acc, f0, t0, wa, wb, lane, smem + a2 + wdma);
+#ifdef BH_GEMM_STATS
+        st_loop += st_b - st_a; st_epi += __builtin_readcyclecounter() - st_b; ++st_tiles;
+#endif
+        if (next >= slots) break;
         work = next; f0 = nf0; t0 = nt0;
 #pragma unroll
         for (int n = 0; n < 8; ++n) { va[n] = van[n]; vb[n] = vbn[n]; }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the run-ahead DMAs of the tile that does not exist
+#ifdef BH_GEMM_STATS
+    if (p.dbg != nullptr && tid == 0 && (blockIdx.x == 0 || blockIdx.x == 133)) {
+        unsigned long long* d = p.dbg + (blockIdx.x == 0 ? 0 : 8);
+        d[0] = st_loop; d[1] = st_epi; d[2] = __builtin_readcyclecounter() - st_t0; d[3] = __builtin_amdgcn_s_memrealtime() - st_r0; d[4] = st_tiles;
+    }
+#endif
 }
 
+#ifdef BH_GEMM_STATS
+unsigned long long* g_gemm_dbg = nullptr;
+#endif
+int g_w4_gf = 0;             // experiments: feature tiles per block of gemm_w4_kernel's work order (0 = default)
 static int g_stagger = 0;    // bh_k_linear_stagger
 static int g_force_v1 = 0;   // test / A-B hook (bh_k_linear_force_v1): 1 = v1 only, 2 = never v3 / v5, 3 = never v5 (v3 where it applies), 5 = v5 whenever the shape is legal (tests: small problems)
 
@@ -758,15 +856,24 @@ static void launch(const GemmArgs& a, hipStream_t s) {
     {
         const int nf3 = (a.N + BF3 - 1) / BF3, nt3 = (a.M + BT3 - 1) / BT3;
         if (a.K % 128 == 0 && a.K >= 256 && (g_force_v1 == 0 || g_force_v1 == 5) && a.N % 256 == 0 && ((long)nf3 * nt3 >= 512 || g_force_v1 == 5) &&
+            ((a.row_div == 1 && a.row_s_hi == 1) || a.row_div % 256 == 0) && (a.rot_cs == nullptr || a.rot_T >= 256) &&
+            (long)a.ldo * 2 * (a.row_div == 1 ? 1 : a.row_s_lo) < (1l << 24) &&
             (long)a.M * a.ldx < (1l << 31) && (long)a.N * a.ldw < (1l << 31)) {
             int dev = 0, cus = 256;
             if (hipGetDevice(&dev) != hipSuccess ||
                 hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
             GemmArgs b = a;
             b.n_ft = nf3; b.n_tt = nt3;
-            const int tiles = nf3 * nt3;
+            int gf = g_w4_gf > 0 ? g_w4_gf : 4;
+            while (gf > nf3) gf >>= 1;
+            b.w4_gf = gf;
+            // phase groups an eighth of a tile apart (~2300 cycles per K-tile + the epilogue's issue time); "gemm_stagger" n > 0: n x 256
+            // cycles, n < 0: off
+            b.stagger = g_stagger > 0 ? g_stagger * 256 : g_stagger < 0 ? 0 : ((a.K / 64) * 2300 + 3500) / 8;
+            const int gt = 32 / gf, ntx = (nt3 >> 3) + ((nt3 & 7) ? 1 : 0);
+            const long slots = 8l * ((nf3 + gf - 1) / gf) * ((ntx + gt - 1) / gt) * 32;
             (void)hipFuncSetAttribute((const void*)gemm_w4_kernel<ACT, GATED>, hipFuncAttributeMaxDynamicSharedMemorySize, W4_LDS);
-            hipLaunchKernelGGL((gemm_w4_kernel<ACT, GATED>), dim3(tiles < cus ? tiles : cus), dim3(256), W4_LDS, s, b);
+            hipLaunchKernelGGL((gemm_w4_kernel<ACT, GATED>), dim3(slots < cus ? (int)slots : cus), dim3(256), W4_LDS, s, b);
             return;
         }
         if (a.K % BK3 == 0 && (g_force_v1 == 0 || g_force_v1 == 3) && a.N >= 256 && a.N % 16 == 0 && (long)nf3 * nt3 >= 512 &&
@@ -813,6 +920,9 @@ int bh_k_linear(const void* X, const void* W, const float* bias, void* out, int 
     a.row_s_lo = row_div > 0 ? row_s_lo : 0;
     a.row_lim = (row_div > 0 && row_lim > 0) ? row_lim : 0x7fffffff;
     a.n_ft = (N + BF - 1) / BF; a.n_tt = (M + BT - 1) / BT;
+#ifdef BH_GEMM_STATS
+    a.dbg = g_gemm_dbg;
+#endif
     if (gated) { launch<ACT_NONE, true>(a, stream); }
     else switch (act) {
         case ACT_NONE: launch<ACT_NONE, false>(a, stream); break;

@@ -23,24 +23,24 @@ for M, N, K, gated in shapes:
         def run():
             _lib.check(lib.bh_linear(_lib.ptr(x), _lib.ptr(w), None, _lib.ptr(out), M, N, K, K, K, ncol, 0, 1.0, -INF, INF,
                                      gated, 0, 0, 0, 0, _lib.stream_ptr()), "bh_linear")
-        for _ in range(3): run()
+        for _ in range(15): run()
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        for _ in range(10): run()
+        for _ in range(40): run()
         e1.record(); torch.cuda.synchronize()
-        ms = e0.elapsed_time(e1) / 10
+        ms = e0.elapsed_time(e1) / 40
         res[path] = (ms, 2.0 * M * N * K / ms / 1e9)
     decode.set_option("gemm_path", 0); decode.set_option("gemm_stagger", 0)
     # yardstick: the vendor library behind torch.matmul (hipBLASLt / rocBLAS), plain GEMM without the fused epilogue
     full = torch.empty((M, N), dtype=torch.float16, device=dev)
-    for _ in range(3): torch.matmul(x, w.t(), out=full)
+    for _ in range(15): torch.matmul(x, w.t(), out=full)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    for _ in range(10): torch.matmul(x, w.t(), out=full)
+    for _ in range(40): torch.matmul(x, w.t(), out=full)
     e1.record(); torch.cuda.synchronize()
-    lib_ms = e0.elapsed_time(e1) / 10
+    lib_ms = e0.elapsed_time(e1) / 40
     del full
     lib_tf = 2.0 * M * N * K / lib_ms / 1e9
     print("M=%d N=%d K=%d gated=%d: auto %.3f ms %.0f TF/s (%.2f x lib) | 8-wave 256-tile %.3f ms %.0f TF/s | 128-tile %.3f ms %.0f TF/s | torch.matmul %.3f ms %.0f TF/s" % (

@@ -2,20 +2,26 @@
 """Generates bonito_amd/csrc/gemm_ktile_mfma.inc: ONE K-tile (64 deep) of the 256 x 256 linear-layer GEMM `gemm_w4_kernel` (gemm.hip)
 as a hand-scheduled instruction stream for ONE wave per SIMD.
 
-    wave tile 128 (features, MFMA A operand = W rows) x 128 (tokens, B operand = X rows), v_mfma_f32_32x32x16_f16:
-    acc[i][j] += FA[i][ks] * FB[j][ks],   i, j in 0..3 (32 x 32 tiles), ks in 0..3 (16 deep)  = 64 MFMAs = 2048 matrix-pipe cycles
+    wave tile 128 tokens (X rows, LDS "A ring", fragments FA) x 128 features (W rows, "B ring", FB), v_mfma_f32_32x32x16_f16 with the W
+    fragment as the instruction's A input (features along the accumulator registers, tokens along the lanes):
+    acc[i][j] += FB[j][ks] * FA[i][ks]^T,   i, j in 0..3 (32 x 32 tiles), ks in 0..3 (16 deep)  = 64 MFMAs = 2048 matrix-pipe cycles
     per k-step 8 fragment reads (ds_read_b128, 1 KiB each) for 16 MFMAs: 4 MFMAs per KiB of LDS traffic (the 64 x 128 wave tile of
     gemm_big_kernel on 16 x 16 x 32: 2.7) and half the operand-register reads per FLOP.
 
-What one stream instance does for K-tile g of a workgroup (stage s = g & 1 of the two 64 KiB LDS stages):
+LDS: the A operand (X rows: streamed from HBM, every fetch pays memory latency) has a ring of THREE 32 KiB stages, the B operand
+(W rows: L2 resident) two. What one stream instance does for K-tile g of a workgroup (A stage g % 3, B stage g % 2; the stage
+offsets are scalar operands, the read addresses are made from them by eight v_add_u32 at the head of the stream):
     ks = 0      16 MFMAs on the fragments of ks 0 (read by the previous instance); the 8 reads of ks 1; D1: the wave's eight
-                LDS-DMA pieces of the X operand of K-tile g + 1 (into stage s ^ 1)
+                LDS-DMA pieces of the A operand of K-tile g + 2 (into A stage (g + 2) % 3, free since the barrier of K-tile g - 1)
     ks = 1, 2   16 MFMAs each; the reads of ks 2 / 3
-    ks = 3      WAIT_AT MFMAs, then: lgkmcnt(0) (all my reads of stage s are back), vmcnt(0) (my pieces of K-tile g + 1 have landed),
-                s_barrier (everybody's have; nobody reads stage s any more); behind it the 8 reads of ks 0 of K-tile g + 1 (stage s ^ 1)
-                and D2: my eight pieces of the W operand of K-tile g + 2 (into stage s)
-One barrier per K-tile; every DMA has >= 1.1 k-tiles of matrix work between issue and the wait that retires it; nothing in the
-stream waits for an instruction issued fewer than ~6 MFMAs (190 cycles) earlier. Fragment registers are double buffered by k-step
+    ks = 3      WAIT_AT MFMAs, then: lgkmcnt(0) (all my reads of K-tile g are back), vmcnt(8) (my pieces of K-tile g + 1 - A issued
+                1.75 K-tiles ago, B one K-tile ago - have landed; only D1 of this instance is younger), s_barrier (everybody's have;
+                nobody reads K-tile g any more); behind it the 8 reads of ks 0 of K-tile g + 1 and D2: my eight pieces of the B
+                operand of K-tile g + 2 (into B stage g % 2)
+One barrier per K-tile. With two stages per operand every K-tile waited for the A pieces issued ONE K-tile earlier, and the loop ran
+at the memory latency (64 KiB in flight per CU / ~1.5 us = 43 GB/s per CU = ~1.5 us per K-tile on every shape, 2100 cycles of MFMA
+in it); the third A stage doubles the lead of the operand that comes from HBM. Nothing in the stream waits for an instruction
+issued fewer than ~6 MFMAs (190 cycles) earlier. Fragment registers are double buffered by k-step
 parity; reads are waited for with COUNTED lgkmcnt (they return in order), so a late fragment never holds up the MFMAs in front of it.
 `FIRST` instances (first K-tile of an output tile) start the accumulators from the inline constant 0 instead of reading them.
 
@@ -28,12 +34,16 @@ import argparse
 import os
 
 
-def build(wait_at=2, read_at=1, d1_at=0, d1_every=2, d2_every=1, first=False, name="gemm_ktile"):
+def build(wait_at=2, read_at=1, d1_at=0, d1_every=2, d2_every=1, first=False, name="gemm_ktile", strip=(), dma_flags=""):
     lines = []          # instruction text
-    counts = {"mfma": 0, "lds": 0, "vmem": 0, "salu": 0, "wait": 0, "nop": 0}
+    counts = {"mfma": 0, "lds": 0, "vmem": 0, "salu": 0, "wait": 0, "nop": 0, "valu": 0}
     fifo = []           # fragment names with a read in flight, oldest first
 
     def emit(kind, text):
+        # --strip (timing experiments, wrong results on purpose): drop the DMA, the fragment reads and / or the barrier from the stream
+        if ("dma" in strip and (kind in ("vmem", "salu", "nop") or "vmcnt" in text)) or ("lds" in strip and kind == "lds") or \
+                ("bar" in strip and text == "s_barrier"):
+            return
         counts[kind] += 1
         lines.append(text)
 
@@ -51,12 +61,17 @@ def build(wait_at=2, read_at=1, d1_at=0, d1_every=2, d2_every=1, first=False, na
     def dma(mbase, imm, voff, sbase):
         emit("salu", "s_add_u32 m0, %%[%s], 0x%x" % (mbase, imm))
         emit("nop", "s_nop 0")
-        emit("vmem", "global_load_lds_dwordx4 %%[%s], %%[%s]" % (voff, sbase))
+        emit("vmem", "global_load_lds_dwordx4 %%[%s], %%[%s]%s" % (voff, sbase, (" " + dma_flags) if dma_flags else ""))
 
     def frag_reads(p, ra, rb):
         """the 8 reads of one k-step in the order the MFMAs need them (i-major MFMA order): A0 B0 B1 B2 B3 A1 A2 A3"""
         order = [("a", 0)] + [("b", j) for j in range(4)] + [("a", i) for i in range(1, 4)]
         return [("f%s%d%d" % (op, p, n), ra if op == "a" else rb, n * 4096) for op, n in order]
+
+    # read addresses of this instance: per-lane bases + the (scalar) stage offsets
+    head = [("ra%d" % k, "sa", "rab%d" % k) for k in (1, 2, 3)] + [("rb%d" % k, "sb", "rbb%d" % k) for k in (1, 2, 3)] + \
+           [("rao", "san", "rab0"), ("rbo", "sbn", "rbb0")]
+    head_at = {0: head[0:2], 1: head[2:6], 8: head[6:8]}      # behind MFMA m of k-step 0 (ra1 / rb1 are needed behind MFMA 1)
 
     for ks in range(4):
         p = ks & 1
@@ -78,13 +93,18 @@ def build(wait_at=2, read_at=1, d1_at=0, d1_every=2, d2_every=1, first=False, na
                     fifo_was = list(fifo)
                     emit("wait", "s_waitcnt lgkmcnt(0)")
                     del fifo[:]
-                    emit("wait", "s_waitcnt vmcnt(0)")
+                    emit("wait", "s_waitcnt vmcnt(8)")
                     emit("wait", "s_barrier")
                     assert all(f[1] == str(p) or True for f in fifo_was)
                 need("fa%d%d" % (p, i), "fb%d%d" % (p, j))
                 c = "%%[c%d%d]" % (i, j)
                 src = "0" if (first and ks == 0) else c
-                emit("mfma", "v_mfma_f32_32x32x16_f16 %s, %%[fa%d%d], %%[fb%d%d], %s" % (c, p, i, p, j, src))
+                # the B-ring operand (W rows: features) is the MFMA's A input, the A-ring operand (X rows: tokens) its B input: features
+                # run along the accumulator registers, tokens along the lanes (gemm.hip: w4_epilogue)
+                emit("mfma", "v_mfma_f32_32x32x16_f16 %s, %%[fb%d%d], %%[fa%d%d], %s" % (c, p, j, p, i, src))
+                if ks == 0:
+                    for dst, sreg, base in head_at.get(m, ()):
+                        emit("valu", "v_add_u32_e32 %%[%s], %%[%s], %%[%s]" % (dst, sreg, base))
                 # side instructions behind MFMA m of this k-step
                 if m >= start and pending and (m - start) < 8:
                     read(*pending.pop(0))
@@ -113,9 +133,13 @@ def build(wait_at=2, read_at=1, d1_at=0, d1_every=2, d2_every=1, first=False, na
         outs.append('[fa1%d] "=&v"(fa[1][%d])' % (n, n))
         outs.append('[fb1%d] "=&v"(fb[1][%d])' % (n, n))
     for ks in range(1, 4):
-        ins.append('[ra%d] "v"(ra[%d])' % (ks, ks))
-        ins.append('[rb%d] "v"(rb[%d])' % (ks, ks))
-    ins += ['[rao] "v"(rao)', '[rbo] "v"(rbo)']
+        outs.append('[ra%d] "=&v"(ra[%d])' % (ks, ks))
+        outs.append('[rb%d] "=&v"(rb[%d])' % (ks, ks))
+    outs += ['[rao] "=&v"(ra[0])', '[rbo] "=&v"(rb[0])']
+    for ks in range(4):
+        ins.append('[rab%d] "v"(rab[%d])' % (ks, ks))
+        ins.append('[rbb%d] "v"(rbb[%d])' % (ks, ks))
+    ins += ['[sa] "s"(sa)', '[sb] "s"(sb)', '[san] "s"(san)', '[sbn] "s"(sbn)']
     for n in range(8):
         ins.append('[vd1_%d] "v"(vd1[%d])' % (n, n))
     for n in range(8):
@@ -127,13 +151,15 @@ def build(wait_at=2, read_at=1, d1_at=0, d1_every=2, d2_every=1, first=False, na
     text.append("// %s<%s>: wait_at=%d read_at=%d d1_at=%d d1_every=%d d2_every=%d : %s" % (
         name, "FIRST" if first else "", wait_at, read_at, d1_at, d1_every, d2_every, stat))
     sig = ("__device__ __forceinline__ void %s%s(float16_t (&acc)[4][4], half8_t (&fa)[2][4], half8_t (&fb)[2][4], "
-           "const unsigned (&ra)[4], const unsigned (&rb)[4], unsigned rao, unsigned rbo, const unsigned (&vd1)[8], "
+           "const unsigned (&rab)[4], const unsigned (&rbb)[4], unsigned sa, unsigned sb, unsigned san, unsigned sbn, const unsigned (&vd1)[8], "
            "const unsigned (&vd2)[8], const char* sd1, const char* sd2, unsigned md1, unsigned md2) {" % (name, "_first" if first else ""))
     text.append(sig)
+    text.append("    unsigned ra[4], rb[4];")
     text.append('    asm volatile("' + body + '"\n        "' + lines[-1] + '"')
     text.append("        : " + ", ".join(outs))
     text.append("        : " + ", ".join(ins))
     text.append('        : "memory", "scc");')
+    text.append("    (void)ra; (void)rb;")
     text.append("}")
     return "\n".join(text) + "\n"
 
@@ -146,9 +172,12 @@ def main():
     ap.add_argument("--d1-every", type=int, default=2)
     ap.add_argument("--d2-every", type=int, default=1)
     ap.add_argument("--name", default="gemm_ktile")
+    ap.add_argument("--dma-flags", default="", help="cache policy bits of the LDS-DMA instructions: nt | sc0 | sc1 | sc0 sc1")
+    ap.add_argument("--strip", default="", help="comma list of dma,lds,bar: timing experiments only (wrong results)")
     ap.add_argument("--out", default=None)
     a = ap.parse_args()
-    kw = dict(wait_at=a.wait_at, read_at=a.read_at, d1_at=a.d1_at, d1_every=a.d1_every, d2_every=a.d2_every, name=a.name)
+    kw = dict(wait_at=a.wait_at, read_at=a.read_at, d1_at=a.d1_at, d1_every=a.d1_every, d2_every=a.d2_every, name=a.name,
+              strip=tuple(x for x in a.strip.split(",") if x), dma_flags=a.dma_flags)
     head = ("// GENERATED by tools/gen_gemmstep.py - do not edit. One K-tile (64 deep) of gemm_w4_kernel's 128 x 128 wave tile as one\n"
             "// instruction stream: 64 v_mfma_f32_32x32x16_f16, the 32 fragment reads of the next k-steps, the wave's 16 LDS-DMA pieces of the\n"
             "// K-tiles ahead, one barrier. See the generator's docstring for the schedule and gemm.hip for the operands.\n")
