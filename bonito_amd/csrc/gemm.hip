@@ -578,21 +578,44 @@ __device__ __forceinline__ void w4_offsets(const GemmArgs& p, int f0, int t0, in
 // that slice is issued by this wave, behind its epilogue). Rows are 256 B = sixteen 16-byte pieces, piece k of token t at position
 // k ^ (t & 15): writes (8-lane groups = 8 tokens x one piece) and reads (16-lane groups = 4 tokens x 4 lanes) are conflict free. Block
 // b + 1 is written while block b's reads are in flight (the LDS operations of one wave execute in issue order).
-template <int ACT, bool GATED>
-__device__ __forceinline__ void w4_epilogue(const GemmArgs& p, float16_t (&acc)[4][4], int f0, int t0, int wa, int wb, int lane, char* scratch) {
+// DEFERRED: the 32 finished rows of a full tile are not stored here but PARKED (park[4 b + rr], fp16, store layout) together with
+// the tile's store parameters (W4Store); the K-tile instances of the NEXT output tile issue them a few at a time behind their
+// barriers (gemm_ktile_st*: four per K-tile at K >= 512), the last tile's rows go out through w4_store_parked. The CU's store
+// path needs ~74 cycles per dwordx4 store - 9.5 k cycles per output tile, a third of a K = 512 tile when the epilogue waits for
+// it - and runs beside the matrix pipe for free when the stores are spread over the next K loop. Ragged tiles (returns false)
+// are stored here, predicated.
+struct W4Store {
+    uint4_t srd;        // buffer resource of the tile's output rows (base = first row of the wave, first feature of the wave)
+    unsigned voff;      // this lane's byte offset inside a block of 8 rows: (l >> 3) rows + (l & 7) pieces
+    unsigned rowb;      // bytes between consecutive tokens
+};
+
+// MODE (compile time, so that the block loop is straight-line code the compiler can software-pipeline; with run-time flags every
+// `if` inside it was a join with full s_waitcnt's: 9.5 k cycles per tile whatever the stores did): 1 = residual, 2 = rotary, 4 = scale / clamp
+template <int ACT, bool GATED, int MODE, typename PARK>
+__device__ __forceinline__ bool w4_epilogue(const GemmArgs& p, float16_t (&acc)[4][4], int f0, int t0, int wa, int wb, int lane, char* scratch,
+                                            PARK (&park)[W4_NPARK], W4Store& st) {
+    asm volatile("" : "+v"(lane));      // opaque: the lane constants below are recomputed per tile instead of living in registers through the K loop
     const int h = lane >> 5, col = lane & 31;
     const int tl = lane >> 3, q = lane & 7;
     const int fw = f0 + wb * 128, tw = t0 + wa * 128;
     const bool ident = p.row_div == 1 && p.row_s_hi == 1;
-    const bool plain = p.scale == 1.0f && p.clamp_lo == -INFINITY && p.clamp_hi == INFINITY;
+    constexpr bool plain = (MODE & 4) == 0;
     const int hi_u = ident ? 0 : t0 / p.row_div;
     const int mlim = ident ? p.M : min(p.M, hi_u * p.row_div + p.row_lim);       // tokens >= mlim of this tile are not stored
     const long o0 = ident ? (long)tw : (long)hi_u * p.row_s_hi + (long)(tw - hi_u * p.row_div) * p.row_s_lo;
     const int rowbytes = (ident ? 1 : (int)p.row_s_lo) * p.ldo * 2;              // bytes between consecutive tokens (< 16 MiB)
-    const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)(p.out + o0 * p.ldo + (GATED ? fw >> 1 : fw)), 0, 0x7ffffff0, 0x00020000);
+    half_t* const obase = p.out + o0 * p.ldo + (GATED ? fw >> 1 : fw);
+    const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc((void*)obase, 0, 0x7ffffff0, 0x00020000);
     const int ovoff = tl * rowbytes + (GATED ? 8 * q : 16 * q);
-    const bool has_res = p.res != nullptr;
+    {
+        const unsigned long long ob = (unsigned long long)obase;
+        st.srd = uint4_t{(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)ob),
+                         (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)(ob >> 32) & 0xffffu)), 0x7ffffff0u, 0x00020000u};
+        st.voff = (unsigned)ovoff;
+        st.rowb = (unsigned)__builtin_amdgcn_readfirstlane(rowbytes);
+    }
+    constexpr bool has_res = (MODE & 1) != 0;
     const __amdgpu_buffer_rsrc_t rrsrc = __builtin_amdgcn_make_buffer_rsrc(
         (void*)(has_res ? p.res + (long)tw * p.ldres + fw : p.out), 0, 0x7ffffff0, 0x00020000);
     const int resbytes = p.ldres * 2;
@@ -605,7 +628,7 @@ __device__ __forceinline__ void w4_epilogue(const GemmArgs& p, float16_t (&acc)[
 #pragma unroll
         for (int e = 0; e < 4; ++e) { bq[P][e] = b0[e]; bq[P][4 + e] = b1[e]; }
     }
-    const bool rot = !GATED && p.rot_cs != nullptr;
+    constexpr bool rot = !GATED && (MODE & 2) != 0;
     const float rsgn = q < 4 ? -1.0f : 1.0f;
     const int pos0 = rot ? (tw + tl) % p.rot_T : 0;                              // position of the lane's first row (rot_T >= 256: one wrap at most)
     const float* const cs0 = p.rot_cs + (q & 3) * 16;
@@ -634,7 +657,7 @@ __device__ __forceinline__ void w4_epilogue(const GemmArgs& p, float16_t (&acc)[
                 hi[rr] = *(const float4_t*)(scratch + tr * 256 + (((2 * q + 1) ^ (tr & 15)) << 4));
             }
             uint4_t rres[4];
-            if (has_res) {
+            if constexpr (has_res) {
 #pragma unroll
                 for (int rr = 0; rr < 4; ++rr) {
                     rres[rr] = uint4_t{0u, 0u, 0u, 0u};
@@ -649,12 +672,12 @@ __device__ __forceinline__ void w4_epilogue(const GemmArgs& p, float16_t (&acc)[
             for (int rr = 0; rr < 4; ++rr) {
                 float v[8] = {lo[rr][0] + bq[P][0], lo[rr][1] + bq[P][1], lo[rr][2] + bq[P][2], lo[rr][3] + bq[P][3],
                               hi[rr][0] + bq[P][4], hi[rr][1] + bq[P][5], hi[rr][2] + bq[P][6], hi[rr][3] + bq[P][7]};
-                if (has_res) {
+                if constexpr (has_res) {
                     const half8_t r8 = __builtin_bit_cast(half8_t, rres[rr]);
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] += (float)r8[e];
                 }
-                if constexpr (!GATED) {
+                if constexpr (rot) {
                     if (rot_here) {
                         // rotary embedding of the packed Wqkv projection (see gemm_epilogue): the 64-feature pair is one head, lanes q < 4
                         // hold its first half, q >= 4 the second; the partner of dim d is dim d +- 32 = lane ^ 4, same index
@@ -671,35 +694,67 @@ __device__ __forceinline__ void w4_epilogue(const GemmArgs& p, float16_t (&acc)[
                     }
                 }
                 const bool live = !MASKED || tw + 32 * i + 8 * rr + tl < mlim;
+                // (the row goes into the VECTOR offset: a buffer_store_dwordx4 with a scalar offset reads its data registers late, and
+                // the two wait states hipcc leaves before the next row's arithmetic overwrites them were not enough on gfx950 - dword 1
+                // of lanes 12-15 of every 16 came out of the NEXT row, run-to-run different; stores without a scalar offset never did)
                 const int vo = ovoff;
                 if constexpr (GATED) {
                     // W rows interleaved on the host: feature 2 k = y_k, 2 k + 1 = gate_k: four outputs per lane, 8 bytes
                     float4_t y;
 #pragma unroll
                     for (int k = 0; k < 4; ++k) y[k] = v[2 * k] * swishf_(v[2 * k + 1]);
-                    if (live)
-                        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(uint2_t, __builtin_convertvector(y, half4_t)), orsrc, vo + P * 64,
-                                                              (32 * i + 8 * rr) * rowbytes, 0);
+                    const uint2_t o2 = __builtin_bit_cast(uint2_t, __builtin_convertvector(y, half4_t));
+                    if constexpr (!MASKED) { if (4 * b + rr >= W4_NOW) park[4 * b + rr - W4_NOW] = o2; }
+                    if ((!MASKED && 4 * b + rr < W4_NOW) || (MASKED && live)) __builtin_amdgcn_raw_buffer_store_b64(o2, orsrc, vo + P * 64 + (32 * i + 8 * rr) * rowbytes, 0, 0);
                 } else {
                     float8_t f8;
 #pragma unroll
                     for (int e = 0; e < 8; ++e) f8[e] = apply_act<ACT>(v[e]);
-                    if (!plain) {
+                    if constexpr (!plain) {
 #pragma unroll
                         for (int e = 0; e < 8; ++e) f8[e] = fminf(fmaxf(f8[e] * p.scale, p.clamp_lo), p.clamp_hi);
                     }
-                    if (live)
-                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uint4_t, __builtin_convertvector(f8, half8_t)), orsrc, vo + P * 128,
-                                                               (32 * i + 8 * rr) * rowbytes, 0);
+                    const uint4_t o4 = __builtin_bit_cast(uint4_t, __builtin_convertvector(f8, half8_t));
+                    if constexpr (!MASKED) { if (4 * b + rr >= W4_NOW) park[4 * b + rr - W4_NOW] = o4; }
+                    if ((!MASKED && 4 * b + rr < W4_NOW) || (MASKED && live)) __builtin_amdgcn_raw_buffer_store_b128(o4, orsrc, vo + P * 128 + (32 * i + 8 * rr) * rowbytes, 0, 0);
                 }
             }
         }
     };
-    if (tw + 128 <= mlim) blocks(std::false_type{});
-    else blocks(std::true_type{});
+    if (tw + 128 <= mlim) { blocks(std::false_type{}); return true; }
+    blocks(std::true_type{});
+    return false;
 }
 
-template <int ACT, bool GATED>
+// the parked rows of a tile that no K loop follows
+template <bool GATED, typename PARK>
+__device__ __forceinline__ void w4_store_parked(const PARK (&park)[W4_NPARK], const W4Store& st) {
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(((unsigned long long)st.srd[1] << 32) | st.srd[0]), 0, 0x7ffffff0, 0x00020000);
+#pragma unroll
+    for (int idx = 0; idx < W4_NPARK; ++idx) {
+        if constexpr (GATED) __builtin_amdgcn_raw_buffer_store_b64(park[idx], rsrc, st.voff + w4_store_col(idx) * 64 + w4_store_row(idx) * st.rowb, 0, 0);
+        else __builtin_amdgcn_raw_buffer_store_b128(park[idx], rsrc, st.voff + w4_store_col(idx) * 128 + w4_store_row(idx) * st.rowb, 0, 0);
+    }
+}
+
+// one K-tile instance that also issues S parked rows (IDX0 .. IDX0 + S - 1, modulo W4_NPARK) of the previous tile
+template <int IDX0, int S, bool WIDE, bool FIRST, typename PARK>
+__device__ __forceinline__ void w4_inst_st(float16_t (&acc)[4][4], half8_t (&fa)[2][4], half8_t (&fb)[2][4], const unsigned (&rab)[4],
+                                           const unsigned (&rbb)[4], unsigned sa, unsigned sb, unsigned san, unsigned sbn, const unsigned (&vd1)[8],
+                                           const unsigned (&vd2)[8], const char* sd1, const char* sd2, unsigned md1, unsigned md2,
+                                           const PARK (&park)[W4_NPARK], const W4Store& st) {
+    if constexpr (S == 4 && WIDE && !FIRST) gemm_ktile_st4w<IDX0>(acc, fa, fb, rab, rbb, sa, sb, san, sbn, vd1, vd2, sd1, sd2, md1, md2, park, st.srd, st.voff, st.rowb);
+    else if constexpr (S == 4 && WIDE && FIRST) gemm_ktile_first_st4w<IDX0>(acc, fa, fb, rab, rbb, sa, sb, san, sbn, vd1, vd2, sd1, sd2, md1, md2, park, st.srd, st.voff, st.rowb);
+    else if constexpr (S == 4 && !WIDE && !FIRST) gemm_ktile_st4n<IDX0>(acc, fa, fb, rab, rbb, sa, sb, san, sbn, vd1, vd2, sd1, sd2, md1, md2, park, st.srd, st.voff, st.rowb);
+    else if constexpr (S == 4 && !WIDE && FIRST) gemm_ktile_first_st4n<IDX0>(acc, fa, fb, rab, rbb, sa, sb, san, sbn, vd1, vd2, sd1, sd2, md1, md2, park, st.srd, st.voff, st.rowb);
+    else if constexpr (S == 6 && WIDE && !FIRST) gemm_ktile_st6w<IDX0>(acc, fa, fb, rab, rbb, sa, sb, san, sbn, vd1, vd2, sd1, sd2, md1, md2, park, st.srd, st.voff, st.rowb);
+    else if constexpr (S == 6 && WIDE && FIRST) gemm_ktile_first_st6w<IDX0>(acc, fa, fb, rab, rbb, sa, sb, san, sbn, vd1, vd2, sd1, sd2, md1, md2, park, st.srd, st.voff, st.rowb);
+    else if constexpr (S == 6 && !WIDE && !FIRST) gemm_ktile_st6n<IDX0>(acc, fa, fb, rab, rbb, sa, sb, san, sbn, vd1, vd2, sd1, sd2, md1, md2, park, st.srd, st.voff, st.rowb);
+    else gemm_ktile_first_st6n<IDX0>(acc, fa, fb, rab, rbb, sa, sb, san, sbn, vd1, vd2, sd1, sd2, md1, md2, park, st.srd, st.voff, st.rowb);
+}
+
+template <int ACT, bool GATED, int S, int MODE>       // S: parked output rows per K-tile instance (4: K >= 512, 6: K = 384); MODE: w4_epilogue
 __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];   // [stage][X tile 32K | W tile 32K] x 2 (addressed by offset only)
     const int tid = threadIdx.x;
@@ -754,16 +809,14 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(GemmArgs p) {
     int f0 = 0, t0 = 0;
     int work = next_valid(blockIdx.x, f0, t0);
     if (work >= slots) return;
-    // Phase stagger. Every workgroup has the same work per tile, so all 256 CUs would reach their epilogues together and 32 MiB of
-    // output would head for HBM in one burst while every matrix core waits (measured: the epilogue takes 12 k cycles = 5 us = 32 MiB at
-    // 6.4 TB/s whatever its instruction count - three versions of it, 600 to 2000 instructions, all took 9.5-14 k cycles) - and then
-    // nobody writes for a K loop. The workgroups of an XCD therefore start in eight phase groups, p.stagger cycles apart (an eighth of
-    // a tile's duration): one group's stores overlap the K loops of the other seven. (gemm_big_kernel's "gemm_stagger" is the same idea.)
+    // Optional phase stagger ("gemm_stagger", as gemm_big_kernel's): the workgroups of an XCD start in eight groups p.stagger cycles apart.
+    // Tried because all CUs reach their epilogues together; measured without effect here (an epilogue takes 9-12 k cycles at 1.7 and at
+    // 2.4 GHz alike: it is bound by the CU's own store path - ~74 cycles per dwordx4 store instruction - not by a chip-wide burst).
     if (p.stagger > 0) {
         const unsigned long long until = __builtin_readcyclecounter() + (unsigned long long)(((blockIdx.x >> 3) & 7) * p.stagger);
         while (__builtin_readcyclecounter() < until) __builtin_amdgcn_s_sleep(32);
     }
-    unsigned va[8], vb[8], van[8], vbn[8];
+    unsigned va[8], vb[8];
     w4_offsets(p, f0, t0, wave, lane, va, vb);
 
     // prologue: K-tiles 0 and 1 of both operands; fragments of k-step 0 of K-tile 0
@@ -791,6 +844,13 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(GemmArgs p) {
     unsigned long long st_loop = 0, st_epi = 0, st_tiles = 0;
     const unsigned long long st_t0 = __builtin_readcyclecounter(), st_r0 = __builtin_amdgcn_s_memrealtime();
 #endif
+    using park_t = std::conditional_t<GATED, uint2_t, uint4_t>;
+    constexpr int NST = (W4_NPARK + S - 1) / S;              // K-tile instances that carry parked rows (nk >= NST: the launcher)
+    park_t park[W4_NPARK];
+    W4Store pst;
+    bool parked = false;
+    const char* dA = Ab + 256;                               // DMA cursor: K-tile k + 2 of the instance of K-tile k ...
+    const char* dB = Bb + 256;
     while (true) {
 #ifdef BH_GEMM_STATS
         const unsigned long long st_a = __builtin_readcyclecounter();
@@ -799,21 +859,35 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(GemmArgs p) {
         int tf0 = 0, tt0 = 0;
         const int next = next_valid(work + gridDim.x, tf0, tt0);
         if (next < slots) { nf0 = tf0; nt0 = tt0; }         // (no next tile: the run-ahead DMAs re-fetch this one, nobody reads them)
-        w4_offsets(p, nf0, nt0, wave, lane, van, vbn);
         float16_t acc[4][4];
         // instance of K-tile k: reads A stage a0 / B stage b0 (k-step 0 of K-tile k + 1 from a1 / b1), D1 = A of K-tile k + 2 into A stage
-        // a2, D2 = B of K-tile k + 2 into B stage b0; the DMA cursor crosses into the NEXT output tile in the last two instances
-#define W4_ROTATE() do { const unsigned ta = a0; a0 = a1; a1 = a2; a2 = ta; const unsigned tb = b0; b0 = b1; b1 = tb; } while (0)
-        gemm_ktile_first(acc, fa, fb, rab, rbb, a0, b0, a1, b1, va, vb, Ab + 256, Bb + 256, a2 + wdma, b0 + wdma);
-        W4_ROTATE();
-        for (int k = 1; k < nk - 2; ++k) {
-            gemm_ktile(acc, fa, fb, rab, rbb, a0, b0, a1, b1, va, vb, Ab + (long)(k + 2) * 128, Bb + (long)(k + 2) * 128, a2 + wdma, b0 + wdma);
+        // a2, D2 = B of K-tile k + 2 into B stage b0. In the last two instances the DMA cursor is in the NEXT output tile: va / vb are
+        // overwritten with its offsets in front of instance nk - 2 (nothing of this tile is fetched any more).
+#define W4_ROTATE() do { const unsigned ta = a0; a0 = a1; a1 = a2; a2 = ta; const unsigned tb = b0; b0 = b1; b1 = tb; dA += 128; dB += 128; } while (0)
+#define W4_CURSOR(k) do { if ((k) == nk - 2) { int lc = lane; asm volatile("" : "+v"(lc)); /* (opaque: nothing of it is hoisted and kept live) */ \
+                                               w4_offsets(p, nf0, nt0, wave, lc, va, vb); dA = Ab; dB = Bb; } } while (0)
+#define W4_ARGS acc, fa, fb, rab, rbb, a0, b0, a1, b1, va, vb, dA, dB, a2 + wdma, b0 + wdma
+        if (parked) {
+            // the first NST instances also issue the previous tile's parked rows
+#define W4_ST(T) if constexpr ((T) < NST) { W4_CURSOR(T); w4_inst_st<(T) * S, S, !GATED, (T) == 0>(W4_ARGS, park, pst); W4_ROTATE(); }
+            W4_ST(0) W4_ST(1) W4_ST(2) W4_ST(3) W4_ST(4) W4_ST(5) W4_ST(6) W4_ST(7)
+#undef W4_ST
+            for (int k = NST; k < nk; ++k) {
+                W4_CURSOR(k);
+                gemm_ktile(W4_ARGS);
+                W4_ROTATE();
+            }
+        } else {
+            gemm_ktile_first(W4_ARGS);
             W4_ROTATE();
+            for (int k = 1; k < nk; ++k) {
+                W4_CURSOR(k);
+                gemm_ktile(W4_ARGS);
+                W4_ROTATE();
+            }
         }
-        gemm_ktile(acc, fa, fb, rab, rbb, a0, b0, a1, b1, van, vbn, Ab, Bb, a2 + wdma, b0 + wdma);
-        W4_ROTATE();
-        gemm_ktile(acc, fa, fb, rab, rbb, a0, b0, a1, b1, van, vbn, Ab + 128, Bb + 128, a2 + wdma, b0 + wdma);
-        W4_ROTATE();
+#undef W4_ARGS
+#undef W4_CURSOR
 #undef W4_ROTATE
 #ifdef BH_GEMM_STATS
         const unsigned long long st_b = __builtin_readcyclecounter();
@@ -824,15 +898,14 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(GemmArgs p) {
                        "+a"(acc[1][3]), "+a"(acc[2][0]), "+a"(acc[2][1]), "+a"(acc[2][2]), "+a"(acc[2][3]), "+a"(acc[3][0]), "+a"(acc[3][1]),
                        "+a"(acc[3][2]), "+a"(acc[3][3]));
         // (a2: the A stage the last K-tile has just vacated - the next instance's D1 target - serves as the transposition scratch)
-        w4_epilogue<ACT, GATED>(p, acc, f0, t0, wa, wb, lane, smem + a2 + wdma);
+        parked = w4_epilogue<ACT, GATED, MODE>(p, acc, f0, t0, wa, wb, lane, smem + a2 + wdma, park, pst);
 #ifdef BH_GEMM_STATS
         st_loop += st_b - st_a; st_epi += __builtin_readcyclecounter() - st_b; ++st_tiles;
 #endif
         if (next >= slots) break;
         work = next; f0 = nf0; t0 = nt0;
-#pragma unroll
-        for (int n = 0; n < 8; ++n) { va[n] = van[n]; vb[n] = vbn[n]; }
     }
+    if (parked) w4_store_parked<GATED>(park, pst);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the run-ahead DMAs of the tile that does not exist
 #ifdef BH_GEMM_STATS
     if (p.dbg != nullptr && tid == 0 && (blockIdx.x == 0 || blockIdx.x == 133)) {
@@ -855,7 +928,7 @@ static void launch(const GemmArgs& a, hipStream_t s) {
     // v5 (gemm_w4_kernel) / v3 when the problem has at least ~2 waves of 256 x 256 tiles over the chip and no K tail
     {
         const int nf3 = (a.N + BF3 - 1) / BF3, nt3 = (a.M + BT3 - 1) / BT3;
-        if (a.K % 128 == 0 && a.K >= 256 && (g_force_v1 == 0 || g_force_v1 == 5) && a.N % 256 == 0 && ((long)nf3 * nt3 >= 512 || g_force_v1 == 5) &&
+        if (a.K % 128 == 0 && a.K >= 384 && (g_force_v1 == 0 || g_force_v1 == 5) && a.N % 256 == 0 && ((long)nf3 * nt3 >= 512 || g_force_v1 == 5) &&
             ((a.row_div == 1 && a.row_s_hi == 1) || a.row_div % 256 == 0) && (a.rot_cs == nullptr || a.rot_T >= 256) &&
             (long)a.ldo * 2 * (a.row_div == 1 ? 1 : a.row_s_lo) < (1l << 24) &&
             (long)a.M * a.ldx < (1l << 31) && (long)a.N * a.ldw < (1l << 31)) {
@@ -865,15 +938,47 @@ static void launch(const GemmArgs& a, hipStream_t s) {
             GemmArgs b = a;
             b.n_ft = nf3; b.n_tt = nt3;
             int gf = g_w4_gf > 0 ? g_w4_gf : 4;
-            while (gf > nf3) gf >>= 1;
+            while (gf > 1 && (gf > nf3 || (g_w4_gf <= 0 && nf3 % gf != 0))) gf >>= 1;      // (a group that does not divide n_ft leaves slots empty: 6 tiles in groups of 4 wasted a quarter)
             b.w4_gf = gf;
-            // phase groups an eighth of a tile apart (~2300 cycles per K-tile + the epilogue's issue time); "gemm_stagger" n > 0: n x 256
-            // cycles, n < 0: off
-            b.stagger = g_stagger > 0 ? g_stagger * 256 : g_stagger < 0 ? 0 : ((a.K / 64) * 2300 + 3500) / 8;
+            // "gemm_stagger" n > 0: phase groups n x 256 cycles apart (measured: no gain for this kernel - its epilogue is bound by the CU's
+            // store path, not by a chip-wide burst - and the last groups finish up to 7 n x 256 cycles late); default off
+            b.stagger = g_stagger > 0 ? g_stagger * 256 : 0;
             const int gt = 32 / gf, ntx = (nt3 >> 3) + ((nt3 & 7) ? 1 : 0);
             const long slots = 8l * ((nf3 + gf - 1) / gf) * ((ntx + gt - 1) / gt) * 32;
-            (void)hipFuncSetAttribute((const void*)gemm_w4_kernel<ACT, GATED>, hipFuncAttributeMaxDynamicSharedMemorySize, W4_LDS);
-            hipLaunchKernelGGL((gemm_w4_kernel<ACT, GATED>), dim3(slots < cus ? (int)slots : cus), dim3(256), W4_LDS, s, b);
+            // epilogue modes are compile-time (w4_epilogue): the combinations the engine uses are instantiated, anything else falls through
+            // to the eight-wave kernel below
+            const bool plain = a.scale == 1.0f && a.clamp_lo == -INFINITY && a.clamp_hi == INFINITY;
+            const int mode = (a.res != nullptr ? 1 : 0) | (a.rot_cs != nullptr ? 2 : 0) | (plain ? 0 : 4);
+            bool done = true;
+#define W4_LAUNCH(A_, G_, MODE_)                                                                                                    \
+    do {                                                                                                                          \
+        if (a.K >= 512) {                                                                                                         \
+            (void)hipFuncSetAttribute((const void*)gemm_w4_kernel<A_, G_, 4, MODE_>, hipFuncAttributeMaxDynamicSharedMemorySize, W4_LDS); \
+            hipLaunchKernelGGL((gemm_w4_kernel<A_, G_, 4, MODE_>), dim3(slots < cus ? (int)slots : cus), dim3(256), W4_LDS, s, b);  \
+        } else {                                                                                                                  \
+            (void)hipFuncSetAttribute((const void*)gemm_w4_kernel<A_, G_, 6, MODE_>, hipFuncAttributeMaxDynamicSharedMemorySize, W4_LDS); \
+            hipLaunchKernelGGL((gemm_w4_kernel<A_, G_, 6, MODE_>), dim3(slots < cus ? (int)slots : cus), dim3(256), W4_LDS, s, b);  \
+        }                                                                                                                         \
+    } while (0)
+            if constexpr (GATED) {
+                if (mode == 0) W4_LAUNCH(ACT_NONE, true, 0); else done = false;
+            } else if constexpr (ACT == ACT_NONE) {
+                if (mode == 0) W4_LAUNCH(ACT_NONE, false, 0);
+                else if (mode == 1) W4_LAUNCH(ACT_NONE, false, 1);
+                else if (mode == 2) W4_LAUNCH(ACT_NONE, false, 2);
+                else if (mode == 4) W4_LAUNCH(ACT_NONE, false, 4);
+                else done = false;
+            } else if constexpr (ACT == ACT_TANH) {
+                if (mode == 4) W4_LAUNCH(ACT_TANH, false, 4); else if (mode == 0) W4_LAUNCH(ACT_TANH, false, 0); else done = false;
+            } else if constexpr (ACT == ACT_SWISH) {
+                if (mode == 0) W4_LAUNCH(ACT_SWISH, false, 0); else done = false;
+            } else {
+                done = false;
+            }
+#undef W4_LAUNCH
+            if (done) return;
+        }
+        if (false) {
             return;
         }
         if (a.K % BK3 == 0 && (g_force_v1 == 0 || g_force_v1 == 3) && a.N >= 256 && a.N % 16 == 0 && (long)nf3 * nt3 >= 512 &&

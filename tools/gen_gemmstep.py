@@ -34,7 +34,7 @@ import argparse
 import os
 
 
-def build(wait_at=2, read_at=1, d1_at=0, d1_every=2, d2_every=1, first=False, name="gemm_ktile", strip=(), dma_flags=""):
+def build(wait_at=2, read_at=1, d1_at=0, d1_every=2, d2_every=1, first=False, name="gemm_ktile", strip=(), dma_flags="", stores=0, wide=True, st_at=3, st_every=2):
     lines = []          # instruction text
     counts = {"mfma": 0, "lds": 0, "vmem": 0, "salu": 0, "wait": 0, "nop": 0, "valu": 0}
     fifo = []           # fragment names with a read in flight, oldest first
@@ -86,6 +86,11 @@ def build(wait_at=2, read_at=1, d1_at=0, d1_every=2, d2_every=1, first=False, na
             d = [(d1_at + n * d1_every, ("md1", n * 1024, "vd1_%d" % n, "sd1")) for n in range(8)]
         elif ks == 3:
             d = [(wait_at + n * d2_every, ("md2", n * 1024, "vd2_%d" % n, "sd2")) for n in range(8)]
+        st = []
+        if ks == 3 and stores:
+            # the parked output rows of the PREVIOUS tile (gemm.hip: deferred epilogue): right behind the barrier, so that they have a
+            # whole K-tile to retire before the next counted vmcnt wait has to sit them out (loads and stores share the counter)
+            st = [(min(15, wait_at + st_at + (n * st_every if stores <= 6 else n)), n) for n in range(stores)]
         m = 0
         for i in range(4):
             for j in range(4):
@@ -111,6 +116,10 @@ def build(wait_at=2, read_at=1, d1_at=0, d1_every=2, d2_every=1, first=False, na
                 for at, args in d:
                     if at == m:
                         dma(*args)
+                for at, n in st:
+                    if at == m:
+                        emit("salu", "s_mul_i32 %%[stt], %%[rowb], %%[k%d]" % n)
+                        emit("vmem", "buffer_store_dwordx%d %%[pk%d], %%[stv], %%[srd], %%[stt] offen offset:%%[o%d]" % (4 if wide else 2, n, n))
                 m += 1
         # anything that did not fit behind an MFMA (late wait_at): issue it now
         while pending:
@@ -145,21 +154,34 @@ def build(wait_at=2, read_at=1, d1_at=0, d1_every=2, d2_every=1, first=False, na
     for n in range(8):
         ins.append('[vd2_%d] "v"(vd2[%d])' % (n, n))
     ins += ['[sd1] "s"(sd1)', '[sd2] "s"(sd2)', '[md1] "s"(md1)', '[md2] "s"(md2)']
+    if stores:
+        outs.append('[stt] "=&s"(stt)')
+        for n in range(stores):
+            ins.append('[pk%d] "v"(park[(IDX0 + %d) %% W4_NPARK])' % (n, n))
+            ins.append('[k%d] "n"(w4_store_row((IDX0 + %d) %% W4_NPARK))' % (n, n))
+            ins.append('[o%d] "n"(w4_store_col((IDX0 + %d) %% W4_NPARK) * %d)' % (n, n, 128 if wide else 64))
+        ins += ['[srd] "s"(srd)', '[stv] "v"(stv)', '[rowb] "s"(rowb)']
     stat = " ".join("%s=%d" % kv for kv in sorted(counts.items()))
     body = '"\n        "'.join(l + "\\n\\t" for l in lines[:-1])
     text = []
-    text.append("// %s<%s>: wait_at=%d read_at=%d d1_at=%d d1_every=%d d2_every=%d : %s" % (
-        name, "FIRST" if first else "", wait_at, read_at, d1_at, d1_every, d2_every, stat))
-    sig = ("__device__ __forceinline__ void %s%s(float16_t (&acc)[4][4], half8_t (&fa)[2][4], half8_t (&fb)[2][4], "
+    text.append("// %s<%s>: wait_at=%d read_at=%d d1_at=%d d1_every=%d d2_every=%d stores=%d%s : %s" % (
+        name, "FIRST" if first else "", wait_at, read_at, d1_at, d1_every, d2_every, stores, ("" if not stores else (" x16B" if wide else " x8B")), stat))
+    fname = name + ("_first" if first else "") + (("_st%d%s" % (stores, "w" if wide else "n")) if stores else "")
+    sig = ("__device__ __forceinline__ void %s(float16_t (&acc)[4][4], half8_t (&fa)[2][4], half8_t (&fb)[2][4], "
            "const unsigned (&rab)[4], const unsigned (&rbb)[4], unsigned sa, unsigned sb, unsigned san, unsigned sbn, const unsigned (&vd1)[8], "
-           "const unsigned (&vd2)[8], const char* sd1, const char* sd2, unsigned md1, unsigned md2) {" % (name, "_first" if first else ""))
+           "const unsigned (&vd2)[8], const char* sd1, const char* sd2, unsigned md1, unsigned md2%s) {" % (
+               fname, (", const %s (&park)[W4_NPARK], uint4_t srd, unsigned stv, unsigned rowb" % ("uint4_t" if wide else "uint2_t")) if stores else ""))
+    if stores:
+        text.append("template <int IDX0>")
     text.append(sig)
     text.append("    unsigned ra[4], rb[4];")
+    if stores:
+        text.append("    unsigned stt;")
     text.append('    asm volatile("' + body + '"\n        "' + lines[-1] + '"')
     text.append("        : " + ", ".join(outs))
     text.append("        : " + ", ".join(ins))
     text.append('        : "memory", "scc");')
-    text.append("    (void)ra; (void)rb;")
+    text.append("    (void)ra; (void)rb;" + (" (void)stt;" if stores else ""))
     text.append("}")
     return "\n".join(text) + "\n"
 
@@ -172,6 +194,7 @@ def main():
     ap.add_argument("--d1-every", type=int, default=2)
     ap.add_argument("--d2-every", type=int, default=1)
     ap.add_argument("--name", default="gemm_ktile")
+    ap.add_argument("--no-stores", action="store_true", help="omit the variants with store slots")
     ap.add_argument("--dma-flags", default="", help="cache policy bits of the LDS-DMA instructions: nt | sc0 | sc1 | sc0 sc1")
     ap.add_argument("--strip", default="", help="comma list of dma,lds,bar: timing experiments only (wrong results)")
     ap.add_argument("--out", default=None)
@@ -182,6 +205,20 @@ def main():
             "// instruction stream: 64 v_mfma_f32_32x32x16_f16, the 32 fragment reads of the next k-steps, the wave's 16 LDS-DMA pieces of the\n"
             "// K-tiles ahead, one barrier. See the generator's docstring for the schedule and gemm.hip for the operands.\n")
     text = head + build(first=False, **kw) + "\n" + build(first=True, **kw)
+    if not a.no_stores:
+        # instances that also issue `stores` parked output rows of the previous tile: row index / feature-pair of parked row idx
+        text += ("\n// Deferred epilogue: of a tile's 32 output rows per lane (block b = (token tile i = b >> 1, feature pair P = b & 1), rr < 4: token row\n"
+                 "// 32 i + 8 rr (+ lane >> 3) of the wave, byte column 128 P (64 P for SwiGLU outputs) (+ lane & 7 pieces)) the first\n"
+                 "// W4_NOW are stored by the epilogue itself, the other W4_NPARK are parked in registers (index idx = 4 b + rr - W4_NOW) and\n"
+                 "// issued by the K-tile instances of the next tile. (All 32 parked: 128 + 88 registers of operands leave the compiler ~25 -\n"
+                 "// it spilled, and every reload in front of an instance is an s_waitcnt vmcnt(0).)\n"
+                 "constexpr int W4_NOW = 12, W4_NPARK = 32 - W4_NOW;\n"
+                 "constexpr int w4_store_row(int idx) { return 32 * ((idx + W4_NOW) >> 3) + 8 * (idx & 3); }\n"
+                 "constexpr int w4_store_col(int idx) { return ((idx + W4_NOW) >> 2) & 1; }\n")
+        for stores in (4, 6):
+            for wide in (True, False):
+                for first in (False, True):
+                    text += "\n" + build(first=first, stores=stores, wide=wide, **kw)
     path = a.out or os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bonito_amd", "csrc", "gemm_ktile_mfma.inc")
     with open(path, "w") as f:
         f.write(text)
