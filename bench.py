@@ -209,6 +209,8 @@ OTHER_CONFIGS = {            # BASELINE.json configs 2, 4, 5 (+ the 8-bit path o
                                                                             #  half of them ramp-up - 2.53 ms against 2.37 over 384 steps)
     "sup": ["--model", "sup", "--steps", "12", "--warmup", "3"],
     "sup_lstm": ["--model", "sup_lstm", "--steps", "8", "--warmup", "2"],
+    # config 5 on the OTHER candidate graph ("run both the @v5.0.toml graph and the @v4.3.toml graph at this shape")
+    "sup_20000": ["--model", "sup", "--chunk", "20000", "--steps", "8", "--warmup", "2"],
     "hac_quantize": ["--model", "hac", "--quantize", "--steps", "48", "--warmup", "8"],
 }
 
@@ -284,6 +286,18 @@ def main():
     local %= ndev
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    # every rank says which device it drives (stderr: visible in the driver's tail), and with one rank per GPU the ordinals must be
+    # distinct - a mis-launch (two ranks on one device, a stale visibility mask) would otherwise only show up as a bad scaling number
+    props = torch.cuda.get_device_properties(local)
+    ident = (rank, local, "%s" % getattr(props, "name", "?"), "%s" % (getattr(props, "pci_bus_id", None) or getattr(props, "uuid", "")))
+    sys.stderr.write("bench.py: rank %d/%d -> device %d of %d (%s %s) HIP_VISIBLE_DEVICES=%s ROCR_VISIBLE_DEVICES=%s\n" % (
+        rank, world, local, ndev, ident[2], ident[3], os.environ.get("HIP_VISIBLE_DEVICES"), os.environ.get("ROCR_VISIBLE_DEVICES")))
+    if world > 1 and not oversubscribed:
+        idents = [None] * world
+        dist.all_gather_object(idents, ident)
+        ordinals = sorted(i[1] for i in idents)
+        if len(set(ordinals)) != world:
+            raise SystemExit("bench.py: %d ranks on %d distinct device ordinal(s) %s - expected one rank per GPU" % (world, len(set(ordinals)), ordinals))
 
     from bonito_amd import decode
     from bonito_amd.util import limit_host_threads

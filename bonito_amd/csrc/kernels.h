@@ -93,7 +93,7 @@ int bh_k_signal_chunks(const int16_t* raw, const long* offs, const float* cal_sc
 int bh_k_lstm_wide_ok(int H);
 int bh_k_lstm_layer_wide(const void* gates_perm, const void* whh_tiles, void* h_out, int T, int N, int H, int reverse,
                          int* err_flag, hipStream_t stream, int n_rings, int* xcc_ws, int force_slow, void* ex = nullptr, int R = 0,
-                         int arm = 0);
+                         int arm = 0, int pair = 0);
 size_t bh_k_lstm_wide_ex_bytes(int N, int H);
 
 // lstm_q8.hip: 8-bit recurrent path Q8-1

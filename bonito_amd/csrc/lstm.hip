@@ -1853,6 +1853,214 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_wide_kernel(LstmWideArgs wp
     }
 }
 
+// Two rings per workgroup (round 4; lstm_layer_wgx2_kernel's pairing for the wide layers). A wide ring step is 128 MFMAs (2.0 k cycles)
+// inside 6.5 k cycles: the rest is the hand-off - publish, ~0.45 k cycles until it is visible, a poll round trip of ~1 k, the other 127
+// waves of the ring - and there is ONE wave per SIMD (all 256 accumulation registers hold W_hh), so nothing else runs meanwhile. The
+// workgroup therefore carries ring p AND ring p + n_pairs on the same register-resident weights and alternates: while ring A's h_t
+// travels (publish -> L2 -> first poll round, requested right behind the publish), the wave does ring B's whole step. Same arithmetic
+// in the same order as lstm_layer_wide_kernel<NKS, true> per ring: bit-identical (tests).
+// LDS: the h tile of a ring needs no second parity any more - between two writes of ring A's tile lies ring B's barrier, behind which
+// every wave has finished A's MFMAs - so the two tiles take the 2 x 64 KiB (H = 1024) the two parities of one ring took.
+// A launch serves 2 x 8 rings x 32 chunks = 512 chunks at H = 1024 (one pair per XCD); the engine uses it when a call carries an even
+// number of at least sixteen rings per launch group (sup LSTM-1024: `basecaller` / bench.py group two 256-chunk batches per engine call).
+template <int NKS>
+__global__ __launch_bounds__(256, 1) void lstm_layer_wide2_kernel(LstmWideArgs wp, int n_pairs) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const LstmArgs& p = wp.a;
+    constexpr int MT = 2, NB = 2, H = NKS * 32, U = 4 * MT, NSL = H / U, WPR = NSL / 4;
+    constexpr int NF = NB * NKS;                 // B fragments of a ring's h tile
+    constexpr int KQ = (NF + 3) / 4;
+    constexpr bool EXACT = NF % 4 == 0;
+    constexpr int TILE = NF * 1024;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int xcd = blockIdx.x & 7;
+    const int lwg = blockIdx.x >> 3;
+    const int rl = lwg / WPR;
+    const int pair = rl * 8 + ((p.tune & 32) ? ((xcd + (lwg - rl * WPR)) & 7) : xcd);
+    const int slice = (lwg - rl * WPR) * 4 + wave;
+    if (pair >= n_pairs) return;
+
+    char* stage = smem + 2 * TILE + wave * (NB * 16 * U * 2);   // per-wave, per column tile [16 chunks][U] output transpose (one region per
+                                                                // column tile: both tiles' values are ready before the first is read back)
+
+    half8_t whh[MT][NKS];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks)
+            whh[m][ks] = *(const half8_t*)(p.whh + ((((long)slice * MT + m) * NKS + ks) * 64 + lane) * 8);
+
+    const int c = lane & 15, q = lane >> 4;
+    const int lo = lane * 16;
+    const int dt = p.reverse ? -1 : 1;
+    const long slot_stride = (long)wp.R * TILE;
+    const long g_row = (long)p.N * 4 * H;
+
+    struct Ring {
+        int ring;
+        bool fast, dead;
+        char* hbuf;           // this ring's h tile in LDS
+        char* exr;            // its exchange ring buffer
+        const half_t* gptr;   // this lane's gate pre-activations
+        float cst[MT][NB];
+        uint4_t gq[NB], gr[NB];
+    };
+    Ring R[2];
+#pragma unroll
+    for (int w = 0; w < 2; ++w) {
+        Ring& r = R[w];
+        r.ring = pair + w * n_pairs;
+        r.dead = false;
+        r.fast = ring_store_policy(p, r.ring, slice, NSL, lane);
+        r.hbuf = smem + w * TILE;
+        r.exr = wp.ex + (long)r.ring * TILE;
+        r.gptr = wp.G + ((long)(r.ring * NB * 16 + c) * 4 * H + (slice * 4 + q) * 8);
+        const int t0 = p.reverse ? p.T - 1 : 0;
+        const int t1 = p.T > 1 ? t0 + dt : t0;
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            r.gq[nb] = *(const uint4_t*)(r.gptr + (long)t0 * g_row + (long)nb * 16 * 4 * H);
+            r.gr[nb] = *(const uint4_t*)(r.gptr + (long)t1 * g_row + (long)nb * 16 * 4 * H);
+#pragma unroll
+            for (int m = 0; m < MT; ++m) r.cst[m][nb] = 0.f;
+        }
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) asm volatile("" : "+v"(r.gq[nb]), "+v"(r.gr[nb]));
+    }
+
+    // Poll round of ring r for h of step `hstep`: my quarter of the tile (fragments wave, wave + 4, ...) by LDS-DMA straight into the
+    // ring's tile - the lane-linear image IS the fragment order. Holding the quarter in registers through the other ring's step (as
+    // the single-ring kernel does through its own) would take 2 x 64 registers that this kernel does not have.
+    auto poll = [&](Ring& r, int hstep, unsigned mask) {
+        const char* base = r.exr + (long)(hstep & 3) * slot_stride + lo;
+#pragma unroll
+        for (int kk = 0; kk < KQ; ++kk) {
+            const int f = wave + 4 * kk;
+            if ((EXACT || f < NF) && (mask & (1u << kk))) dma16_poll(base + f * 1024, r.hbuf + f * 1024);
+        }
+    };
+    // which of my fragments of ring r's tile still carry the sentinel (read back from LDS, four at a time)
+    auto pending = [&](Ring& r, unsigned mask) -> unsigned {
+        unsigned pend = 0;
+#pragma unroll
+        for (int kk = 0; kk < KQ; ++kk) {
+            const int f = wave + 4 * kk;
+            if ((EXACT || f < NF) && (mask & (1u << kk))) {
+                const uint4_t v = *(const uint4_t*)(r.hbuf + f * 1024 + lo);
+                const unsigned orv = v.x | v.y | v.z | v.w;
+                if (__any((orv & SENTINEL_MASK) != 0)) pend |= (1u << kk);
+            }
+        }
+        return pend;
+    };
+
+    // One time step of ring r. `o` is the other ring: the poll round for the h it published last (its step `ostep`) is issued behind
+    // this step's barrier - from there on nobody reads o's tile any more (every wave has finished o's MFMAs) - and travels behind
+    // this ring's MFMAs and gates; it is VALIDATED here too, in front of this ring's publish: at that point the polls are the youngest
+    // vector-memory operations of the wave, so the vmcnt(0) that proves they have landed waits for nothing else (behind the publish it
+    // would sit out the publish stores' acknowledgements: measured, 8.9 us per pair of ring steps instead of 6.5 for two single ones).
+    auto ring_step = [&](Ring& r, int step, int t, Ring& o, int ostep) {
+        const bool do_o = ostep >= 0 && ostep + 1 < p.T;
+        // ---- C. gate pre-activations: this step's are in gq; rotate and request step t+2 -----------------------------------
+        float4_t acc[MT][NB];
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            const half8_t g8 = __builtin_bit_cast(half8_t, r.gq[nb]);
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[m][nb][i] = (float)g8[i * MT + m];
+        }
+        {
+            const int t2 = (step + 2 < p.T) ? t + 2 * dt : t;
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+                r.gq[nb] = r.gr[nb];
+                r.gr[nb] = *(const uint4_t*)(r.gptr + (long)t2 * g_row + (long)nb * 16 * 4 * H);
+            }
+        }
+        __syncthreads();          // this ring's tile is complete and validated by all four waves; nobody reads the OTHER ring's tile any more
+        if (do_o && (step == 0 || (p.tune & 64))) poll(o, ostep, ~0u);
+        // ---- E. recurrent part, gates ------------------------------------------------------------------------------------------
+        if (step > 0) {
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+                // the other ring's poll round goes out behind the first column tile's MFMAs: late enough for its publishes to be visible
+                // (issued right behind the barrier, ~0.3 k cycles after them, the first round mostly came back incomplete and the
+                // re-poll - a full round trip - sat on the critical path), early enough to be back behind the second tile and the gates
+                if (nb == 1 && do_o && !(p.tune & 64)) poll(o, ostep, ~0u);
+                const char* hb = r.hbuf + (nb * NKS) * 1024 + lo;
+                half8_t b_cur = *(const half8_t*)hb, b_nxt = b_cur;
+#pragma unroll
+                for (int ks = 0; ks < NKS; ++ks) {
+                    if (ks + 1 < NKS) b_nxt = *(const half8_t*)(hb + (ks + 1) * 1024);
+#pragma unroll
+                    for (int m = 0; m < MT; ++m) mfma16_av(whh[m][ks], b_cur, acc[m][nb]);
+                    b_cur = b_nxt;
+                }
+            }
+            asm volatile("s_nop 15\n\ts_nop 7" : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[1][0]), "+v"(acc[1][1]));
+        }
+        unsigned short hv[NB][MT];
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+                hv[nb][m] = __builtin_bit_cast(unsigned short, (half_t)lstm_cell(acc[m][nb][0], acc[m][nb][1], acc[m][nb][2], acc[m][nb][3], r.cst[m][nb]));
+        // ---- B(o). my quarter of the OTHER ring's next tile: landed? complete? (re-poll what still carries the sentinel) ----------
+        if (do_o) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            unsigned spins = o.dead ? p.max_spins : 0u;
+            unsigned pend = pending(o, ~0u);
+            while (pend != 0) {
+                if (++spins > p.max_spins) {
+                    if (lane == 0 && !o.dead) atomicExch(p.err, 1);
+                    o.dead = true;
+                    break;
+                }
+                if (!(p.tune & 1)) __builtin_amdgcn_s_sleep(1);
+                poll(o, ostep, pend);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                pend = pending(o, pend);
+            }
+        }
+        // ---- publish h_t ---------------------------------------------------------------------------------------------------------
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            char* stg = stage + nb * (16 * U * 2);
+            u16_alias_t* sg = (u16_alias_t*)stg + c * U + q * MT;
+#pragma unroll
+            for (int m = 0; m < MT; ++m) sg[m] = hv[nb][m];
+            if (lane < 32) {                    // 16 chunks x 2 parts of 4 units: 8-byte stores
+                const int cc = lane >> 1, part = lane & 1;
+                const unsigned long long packed = *(const u64_alias_t*)((half_t*)stg + cc * U + part * 4);
+                unsigned long long* dst =
+                    (unsigned long long*)(p.h + ((long)t * p.N + (r.ring * NB + nb) * 16 + cc) * H + slice * U + part * 4);
+                const int u0 = slice * U + part * 4;
+                const int my_byte = (((nb * NKS + (u0 >> 5)) * 64 + ((u0 >> 3) & 3) * 16 + cc) << 4) + (u0 & 7) * 2;
+                // the re-arm store of the previous step must be complete before anything newer is published (lstm_layer_wgx_kernel)
+                if (nb == 0) __builtin_amdgcn_s_waitcnt(0x0F70);
+                unsigned long long* xd = (unsigned long long*)(r.exr + (long)(step & 3) * slot_stride + my_byte);
+                if (r.fast) *xd = packed;
+                else __hip_atomic_store(xd, packed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (step >= 2 && step + 2 < p.T) {
+                    unsigned long long* ra = (unsigned long long*)(r.exr + (long)((step + 2) & 3) * slot_stride + my_byte);
+                    if (r.fast) *ra = ~0ull;
+                    else __hip_atomic_store(ra, ~0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                *dst = packed;                  // the layer output proper
+            }
+        }
+    };
+
+    int t = p.reverse ? p.T - 1 : 0;
+    for (int step = 0; step < p.T; ++step, t += dt) {
+        ring_step(R[0], step, t, R[1], step - 1);     // behind A's barrier: B's h of the previous step is requested
+        ring_step(R[1], step, t, R[0], step);         // behind B's barrier: A's h of this step
+    }
+}
+
 __global__ void fill_u16_kernel(uint16_t* dst, uint16_t v, size_t count) {
     size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 8;
     const size_t stride = (size_t)gridDim.x * blockDim.x * 8;
@@ -2172,7 +2380,7 @@ size_t bh_k_lstm_wide_ex_bytes(int N, int H) { return (size_t)4 * (N / 32) * 2 *
 
 // ex != nullptr: ring-buffer exchange (R = rings of the whole batch, `arm` = fill it with the sentinel first: once per layer)
 int bh_k_lstm_layer_wide(const void* gates_perm, const void* whh_tiles, void* h_out, int T, int N, int H, int reverse,
-                         int* err_flag, hipStream_t stream, int n_rings, int* xcc_ws, int force_slow, void* ex, int R, int arm) {
+                         int* err_flag, hipStream_t stream, int n_rings, int* xcc_ws, int force_slow, void* ex, int R, int arm, int pair) {
     using namespace bh;
     BH_REQUIRE(bh_k_lstm_wide_ok(H), "lstm: wide kernel does not cover H=%d", H);
     BH_REQUIRE(N % 32 == 0, "lstm: wide kernel needs the batch padded to a multiple of 32 (N=%d)", N);
@@ -2183,7 +2391,7 @@ int bh_k_lstm_layer_wide(const void* gates_perm, const void* whh_tiles, void* h_
     BH_REQUIRE(n_rings > 0 && n_rings <= N / 32, "lstm: n_rings=%d outside 1..%d", n_rings, N / 32);
     const int rl = (n_rings + 7) / 8;
     const int grid = 8 * rl * wpr;
-    BH_REQUIRE(grid <= cus, "lstm: %d workgroups must be co-resident but the device has %d CUs; split the batch", grid, cus);
+    BH_REQUIRE(pair || grid <= cus, "lstm: %d workgroups must be co-resident but the device has %d CUs; split the batch", grid, cus);
     BH_REQUIRE(xcc_ws != nullptr, "lstm: missing XCD agreement workspace");
     BH_CHECK_HIP(hipMemsetAsync(xcc_ws, 0xFF, (size_t)n_rings * nsl * sizeof(int), stream));
     LstmWideArgs a{(const half_t*)gates_perm,
@@ -2193,6 +2401,23 @@ int bh_k_lstm_layer_wide(const void* gates_perm, const void* whh_tiles, void* h_
     const int nks = H / 32;
     if (ex && arm) BH_CHECK_HIP(hipMemsetAsync(ex, 0xFF, (size_t)4 * R * 2 * nks * 1024, stream));
     const size_t lds = (size_t)2 * 2 * nks * 1024 + 4 * 16 * 8 * 2;
+    if (pair) {
+        // two rings per workgroup: n_rings is even, ring p shares its workgroups with ring p + n_rings / 2
+        BH_REQUIRE(ex != nullptr && n_rings % 2 == 0, "lstm: the paired wide kernel needs the ring-buffer exchange and an even ring count (%d)", n_rings);
+        const int n_pairs = n_rings / 2;
+        const int grid2 = 8 * ((n_pairs + 7) / 8) * wpr;
+        BH_REQUIRE(grid2 <= cus, "lstm: %d workgroups must be co-resident but the device has %d CUs; split the batch", grid2, cus);
+#define BH_LSTM_WIDE2(NKS)                                                                                               \
+    if (nks == NKS) {                                                                                                    \
+        BH_CHECK_HIP(hipFuncSetAttribute((const void*)lstm_layer_wide2_kernel<NKS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds + 1024)); \
+        hipLaunchKernelGGL((lstm_layer_wide2_kernel<NKS>), dim3(grid2), dim3(256), lds + 1024, stream, a, n_pairs);        \
+    } else
+        BH_LSTM_WIDE2(20) BH_LSTM_WIDE2(24) BH_LSTM_WIDE2(28) BH_LSTM_WIDE2(32)
+        { BH_REQUIRE(false, "lstm: wide kernel has no instance for H=%d", H); }
+#undef BH_LSTM_WIDE2
+        BH_CHECK_HIP(hipGetLastError());
+        return 0;
+    }
 #define BH_LSTM_WIDE(NKS)                                                                                               \
     if (nks == NKS && ex) {                                                                                             \
         BH_CHECK_HIP(hipFuncSetAttribute((const void*)lstm_layer_wide_kernel<NKS, true>, hipFuncAttributeMaxDynamicSharedMemorySize, \

@@ -229,3 +229,55 @@ def test_bench_call_shape_hac_2048x10000():
     assert qd < 1e-3 and (qs[rows] != oqs).mean() < 1e-3
     assert int((omv != 0).sum()) > 100
     assert d.max().item() < 2.4e-2 and d.mean().item() < 3e-3, (d.max().item(), d.mean().item())      # as at 512 x 10000 (5 x measured)
+
+
+def test_full_size_sup_v5_transformer_256x20000_rna():
+    """SURVEY 8(d) config 5 says "run both the @v5.0.toml graph and the @v4.3.toml graph at this shape" (rna004 sup: batch 256 x chunk
+    20000, beam decode, rna=True): the transformer graph of bonito/models/configs/dna_r10.4.1@v5.0.toml at 1667 tokens / 3334 CRF steps
+    per chunk - the attention ring kernel, the rotary table and the four-wave GEMM's rotary / residual / SwiGLU epilogues at a token
+    count that is not a multiple of anything - against nn_ref + crf_oracle.c on four chunks of the batch (review, round 3)."""
+    cfg = util.set_config_defaults(util.load_toml(os.path.join(GOLDEN, "configs", "dna_r10.4.1@v5.0.toml")))
+    torch.manual_seed(25)
+    model = util.load_symbol(cfg, "Model")(cfg).eval()
+    synthetic.randomise_batchnorm_(model)
+    _head_gain_(model, 4.0)
+    sc = _full_size("sup_v5_256x20000_rna", model, 256, 20000, 4.5e-2, 6e-3, rna=True)     # bounds of the 256 x 12000 test
+    assert sc.shape == (256, 3334, 4096)
+
+
+def test_every_row_of_a_2048_chunk_call_against_the_oracle():
+    """The full-size tests compare a handful of rows with the oracle and reach the rest through "variant X is bit-identical to variant
+    Y". Here EVERY chunk of a 2048-chunk engine call - all 128 rings, 64 ring pairs, every XCD position of the paired recurrent kernel -
+    is compared directly: scores vs the fp32 restatement, the Viterbi path of every chunk and the beam decode of every 8th one vs
+    oracle/crf_oracle.c on the engine's scores. Short chunks (1200 samples = 200 steps) keep the CPU oracle under a minute (review,
+    round 3)."""
+    batch, chunk = 2048, 1200
+    model = synthetic.make_model("hac", batchsize=batch, chunksize=chunk)
+    sl = model.seqdist.state_len
+    nn_ref.round_params_to_half_(model)
+    x = torch.randn(batch, 1, chunk, generator=torch.Generator().manual_seed(4)).half()
+    g = _gpu_copy(model, batch, chunk)
+    scores = g(x.cuda())
+    g._hip.check()
+    assert "lstm_layer_wgx2_kernel<12,3>" in g._hip.describe() and scores.shape == (batch, 200, 1024)
+    worst_max, worst_mean, worst_row = 0.0, 0.0, -1
+    for lo in range(0, batch, 256):
+        want = _oracle_scores(model, x[lo:lo + 256])
+        d = (scores[lo:lo + 256].cpu().float() - want).abs()
+        per_row_max = d.flatten(1).max(1).values
+        if per_row_max.max().item() > worst_max:
+            worst_max, worst_row = per_row_max.max().item(), lo + int(per_row_max.argmax())
+        worst_mean = max(worst_mean, d.flatten(1).mean(1).max().item())
+    sub = scores.cpu().numpy()
+    vm, vp = decode.viterbi(scores)
+    om, op, _ = crf_ref.viterbi(sub, sl, blank=2.0)
+    seq, qs, mv, qf = decode.beam_search(scores, return_qfloat=True)
+    rows = list(range(0, batch, 8))
+    oseq, oqs, omv, oqf = crf_ref.beam_search(sub[rows], sl)
+    qd = float(np.abs(qf.numpy()[rows] - oqf).max())
+    _record("all_rows_hac_2048x1200", max=worst_max, mean_of_worst_row=worst_mean, worst_row=worst_row, q_max=qd, bases=int((omv != 0).sum()))
+    assert np.array_equal(vp.numpy(), op) and np.array_equal(vm.numpy(), om)
+    assert np.array_equal(mv.numpy()[rows], omv) and np.array_equal(seq.numpy()[rows], oseq)
+    assert qd < 1e-3 and (qs.numpy()[rows] != oqs).mean() < 1e-3
+    assert int((omv != 0).sum()) > 100
+    assert worst_max < 2.4e-2 and worst_mean < 3e-3, (worst_max, worst_mean, worst_row)      # the bounds of the 512 x 10000 test, for every row

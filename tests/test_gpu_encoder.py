@@ -398,3 +398,29 @@ def test_paired_rings_very_short_chunks(L):
     one, layout = _encode(model.encoder, x)
     two, _ = _encode(model.encoder, x, lstm_pair=0)
     assert "wgx2" in layout and one.shape[1] == (L - 1) // 6 + 1 and torch.equal(one, two)
+
+
+@pytest.mark.parametrize("H,N,L,tune", [(1024, 512, 600, 0), (1024, 288, 300, 0), (768, 544, 300, 0), (1024, 512, 300, 32), (1024, 512, 12, 0)])
+def test_wide_paired_rings_same_bytes_as_single_rings(H, N, L, tune):
+    """Wide layers (H = 768 / 1024), calls of more than 8 rings of 32 chunks: `lstm_layer_wide2_kernel` carries two rings per workgroup on
+    one register-resident copy of W_hh and alternates between them (the hand-off of one ring passes behind the step of the other; the
+    polls land by LDS-DMA in the ring's single h tile; engine option `lstm_pair_wide`). Same arithmetic in the same order as
+    `lstm_layer_wide_kernel`: the same bytes as the default (single rings, two launches) - 16 rings (one full paired launch), 9 rings (one pair launch of 8 + a lone ring),
+    17 rings at H = 768, the rings of a pair spread over all XCDs (write-through hand-off), and two time steps only - and close to
+    the fp32 oracle; run twice with identical bytes (`_encode`)."""
+    from bonito_amd import nn as bnn, synthetic
+    torch.manual_seed(H + N)
+    cfg = synthetic.lstm_crf_encoder_config(H, 3, n_lstm=2)
+    model = bnn.from_dict(cfg)
+    synthetic.randomise_batchnorm_(model)
+    nn_ref.round_params_to_half_(model)
+    x = torch.randn(N, 1, L, generator=torch.Generator().manual_seed(N + L)).half()
+    opts = {"lstm_tune": tune} if tune else {}
+    one, layout = _encode(model, x.cuda(), lstm_pair_wide=1, **opts)      # (an option, off by default: correct but not faster, DESIGN 4c)
+    two, layout0 = _encode(model, x.cuda(), **opts)
+    assert "lstm_layer_wide2_kernel" in layout and "wide2" not in layout0
+    assert torch.equal(one, two)
+    rows = [0, 31, 32, N // 2 + 5, N - 1]
+    with torch.no_grad():
+        want = nn_ref.forward(model, x[rows].float(), expand_blanks=False).permute(1, 0, 2)
+    assert (one[rows].cpu().float() - want).abs().max().item() < TOL_MAX
