@@ -370,7 +370,7 @@ __global__ __launch_bounds__(256) void rmsnorm_residual_kernel(NormArgs p) {
     const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= p.M) return;
     const half_t* a = p.a + row * p.D;
-    const half_t* x = p.x + row * p.D;
+    const half_t* x = p.x != nullptr ? p.x + row * p.D : nullptr;     // null: `a` already holds the residual sum (fused into the producing GEMM)
     half_t* o = p.out + row * p.D;
     float z[2][8];     // D <= 1024: up to two 16-byte vectors per lane
     float ss = 0.0f;
@@ -380,10 +380,11 @@ __global__ __launch_bounds__(256) void rmsnorm_residual_kernel(NormArgs p) {
         const int idx = lane + 64 * v;
         if (idx < nv) {
             const half8_t av = *(const half8_t*)(a + idx * 8);
-            const half8_t xv = *(const half8_t*)(x + idx * 8);
+            half8_t xv = av;
+            if (x != nullptr) xv = *(const half8_t*)(x + idx * 8);
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                z[v][e] = (float)av[e] + p.alpha * (float)xv[e];
+                z[v][e] = x != nullptr ? (float)av[e] + p.alpha * (float)xv[e] : (float)av[e];
                 ss += z[v][e] * z[v][e];
             }
         }

@@ -197,6 +197,7 @@ struct bh_encoder {
     DevBuf ex16;                           // fp16 workgroup-shared kernel: exchange ring buffer (lstm_layer_wgx_kernel)
     int lstm_pair = 1;                     // batches of more rings than one launch holds: two rings per workgroup instead of two launches
     int lstm_pair_wide = 0;                // the same for the wide (H > 512) kernel: built and tested, not faster (see encoder_forward)
+    int norm_fuse = 0;                     // transformer: 1 = alpha * residual added in the out_proj / fc2 epilogues instead of the norm kernel (measured: no gain, 67.7 vs 67.4 ms per sup step - the residual read costs the GEMM epilogue what it saves the norm kernel)
     int lstm_exchange = 1;                 // 1: hand-off through the ring buffer (no sentinel fill of the output tensor), 0: through the output
     int lstm_q8 = 1;                       // 0: run quantised layers through the fp16 kernels (A/B)
     DevBuf res;                            // pending residual projection of a QuartzNet block
@@ -1026,9 +1027,15 @@ extern "C" int bh_encoder_forward(bh_encoder_t* e, const void* signal, int N, in
                         if (!rc) rc = bh_k_attention(e->t_qkv.p, e->t_a.p, (const float*)e->rot.p, N, len, d.nhead, D / d.nhead,
                                                      d.win_left, d.win_right, st);
                     }
-                    if (!rc) rc = bh_k_linear(e->t_a.p, l.w1.p, (const float*)l.b1.p, e->t_b.p, M, D, D, D, D, D, bh::ACT_NONE,
-                                              1.0f, -INFINITY, INFINITY, 0, 0, 0, 0, 0, st);
-                    if (!rc) rc = bh_k_rmsnorm_residual(e->t_b.p, cur, (const float*)l.w4.p, e->t_a.p, M, D, d.alpha, eps, st);
+                    // DeepNorm residual alpha * x fused into the projection's epilogue (fp32 accumulator + alpha * x, one rounding); the norm
+                    // kernel then reads one tensor instead of two ("norm_fuse" 1; default 0 = the separate residual read in the norm kernel)
+                    if (!rc && e->norm_fuse)
+                        rc = bh_k_linear(e->t_a.p, l.w1.p, (const float*)l.b1.p, e->t_b.p, M, D, D, D, D, D, bh::ACT_NONE,
+                                         1.0f, -INFINITY, INFINITY, 0, 0, 0, 0, 0, st, cur, D, d.alpha);
+                    else if (!rc)
+                        rc = bh_k_linear(e->t_a.p, l.w1.p, (const float*)l.b1.p, e->t_b.p, M, D, D, D, D, D, bh::ACT_NONE,
+                                         1.0f, -INFINITY, INFINITY, 0, 0, 0, 0, 0, st);
+                    if (!rc) rc = bh_k_rmsnorm_residual(e->t_b.p, e->norm_fuse ? nullptr : cur, (const float*)l.w4.p, e->t_a.p, M, D, d.alpha, eps, st);
                     if (rc) return rc;
                 }
                 void* dst = e->act[which].p;
@@ -1036,9 +1043,13 @@ extern "C" int bh_encoder_forward(bh_encoder_t* e, const void* signal, int N, in
                     ProfSpan span(e, st, BH_PROF_MLP);
                     rc = bh_k_linear(e->t_a.p, l.w2.p, nullptr, e->t_mid.p, M, 2 * F, D, D, D, F, bh::ACT_NONE, 1.0f,
                                      -INFINITY, INFINITY, 1, 0, 0, 0, 0, st);
-                    if (!rc) rc = bh_k_linear(e->t_mid.p, l.w3.p, nullptr, e->t_b.p, M, D, F, F, F, D, bh::ACT_NONE, 1.0f,
-                                              -INFINITY, INFINITY, 0, 0, 0, 0, 0, st);
-                    if (!rc) rc = bh_k_rmsnorm_residual(e->t_b.p, e->t_a.p, (const float*)l.w5.p, dst, M, D, d.alpha, eps, st);
+                    if (!rc && e->norm_fuse)
+                        rc = bh_k_linear(e->t_mid.p, l.w3.p, nullptr, e->t_b.p, M, D, F, F, F, D, bh::ACT_NONE, 1.0f,
+                                         -INFINITY, INFINITY, 0, 0, 0, 0, 0, st, e->t_a.p, D, d.alpha);
+                    else if (!rc)
+                        rc = bh_k_linear(e->t_mid.p, l.w3.p, nullptr, e->t_b.p, M, D, F, F, F, D, bh::ACT_NONE, 1.0f,
+                                         -INFINITY, INFINITY, 0, 0, 0, 0, 0, st);
+                    if (!rc) rc = bh_k_rmsnorm_residual(e->t_b.p, e->norm_fuse ? nullptr : e->t_a.p, (const float*)l.w5.p, dst, M, D, d.alpha, eps, st);
                     if (rc) return rc;
                 }
                 cur = dst; which = (which + 1) % e->n_act;
@@ -1314,6 +1325,7 @@ extern "C" int bh_encoder_set_option(bh_encoder_t* e, const char* name, int valu
     if (!strcmp(name, "lstm_exchange")) { e->lstm_exchange = value; return 0; }
     if (!strcmp(name, "lstm_pair")) { e->lstm_pair = value; return 0; }
     if (!strcmp(name, "lstm_pair_wide")) { e->lstm_pair_wide = value; return 0; }
+    if (!strcmp(name, "norm_fuse")) { e->norm_fuse = value; return 0; }
     if (!strcmp(name, "gemm_v1")) { bh_k_linear_force_v1(value); return 0; }   // process-wide A/B switch
     if (!strcmp(name, "lstm_tune")) { e->lstm_force_slow = (e->lstm_force_slow & 1) | (value << 8); return 0; }
     BH_REQUIRE(false, "encoder_set_option: unknown option '%s'", name);

@@ -26,8 +26,9 @@ struct GemmArgs {
     const half_t* X;   // [M][ldx]
     const half_t* W;   // [N][ldw]
     const float* bias; // [N] or null
-    const half_t* res; // optional residual [M][ldres], added before the activation
+    const half_t* res; // optional residual [M][ldres]: res_scale * res is added before the activation
     int ldres;
+    float res_scale = 1.0f;
     half_t* out;       // rows remapped, see below; [.][ldo]
     int M, N, K;
     int ldx, ldw, ldo;
@@ -102,13 +103,13 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, float4_t (&acc)
         if (p.res != nullptr) {
             const half_t* rp = p.res + (long)m * p.ldres + fbase;
             if (ALIGNED || full) {
-                v0 += __builtin_convertvector(*(const half8_t*)rp, float8_t);
-                v1 += __builtin_convertvector(*(const half8_t*)(rp + 8), float8_t);
+                v0 += p.res_scale * __builtin_convertvector(*(const half8_t*)rp, float8_t);
+                v1 += p.res_scale * __builtin_convertvector(*(const half8_t*)(rp + 8), float8_t);
             } else {
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
-                    if (fbase + i < p.N) v0[i] += (float)rp[i];
-                    if (fbase + 8 + i < p.N) v1[i] += (float)rp[8 + i];
+                    if (fbase + i < p.N) v0[i] += p.res_scale * (float)rp[i];
+                    if (fbase + 8 + i < p.N) v1[i] += p.res_scale * (float)rp[8 + i];
                 }
             }
         }
@@ -675,7 +676,7 @@ __device__ __forceinline__ bool w4_epilogue(const GemmArgs& p, float16_t (&acc)[
                 if constexpr (has_res) {
                     const half8_t r8 = __builtin_bit_cast(half8_t, rres[rr]);
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] += (float)r8[e];
+                    for (int e = 0; e < 8; ++e) v[e] += p.res_scale * (float)r8[e];
                 }
                 if constexpr (rot) {
                     if (rot_here) {
@@ -1009,7 +1010,7 @@ void bh_k_linear_stagger(int units) { bh::g_stagger = units; }
 int bh_k_linear(const void* X, const void* W, const float* bias, void* out, int M, int N, int K,
                 int ldx, int ldw, int ldo, int act, float scale, float clamp_lo, float clamp_hi,
                 int gated, int row_div, long row_s_hi, long row_s_lo, int row_lim, hipStream_t stream,
-                const void* residual, int ldres) {
+                const void* residual, int ldres, float res_scale) {
     using namespace bh;
     BH_REQUIRE(M > 0 && N > 0 && K > 0, "linear: empty problem M=%d N=%d K=%d", M, N, K);
     BH_REQUIRE(K % 8 == 0 && ldx % 8 == 0 && ldw % 8 == 0, "linear: K/ldx/ldw must be multiples of 8 halves");
@@ -1017,7 +1018,7 @@ int bh_k_linear(const void* X, const void* W, const float* bias, void* out, int 
     BH_REQUIRE(!gated || (N % 16 == 0), "linear: gated epilogue needs N %% 16 == 0");
     GemmArgs a;
     a.X = (const half_t*)X; a.W = (const half_t*)W; a.bias = bias; a.out = (half_t*)out;
-    a.res = (const half_t*)residual; a.ldres = ldres;
+    a.res = (const half_t*)residual; a.ldres = ldres; a.res_scale = res_scale;
     a.M = M; a.N = N; a.K = K; a.ldx = ldx; a.ldw = ldw; a.ldo = ldo;
     a.scale = scale; a.clamp_lo = clamp_lo; a.clamp_hi = clamp_hi;
     a.row_div = row_div > 0 ? row_div : 1;

@@ -10,7 +10,7 @@
 int bh_k_linear(const void* X, const void* W, const float* bias, void* out, int M, int N, int K,
                 int ldx, int ldw, int ldo, int act, float scale, float clamp_lo, float clamp_hi,
                 int gated, int row_div, long row_s_hi, long row_s_lo, int row_lim, hipStream_t stream,
-                const void* residual = nullptr, int ldres = 0);
+                const void* residual = nullptr, int ldres = 0, float res_scale = 1.0f);
 
 void bh_k_linear_force_v1(int on);
 void bh_k_linear_stagger(int units);

@@ -132,6 +132,26 @@ def test_transformer_attention_paths_agree(name):
     assert (outs[1] - outs[0]).abs().max().item() < 1e-2 * rng
 
 
+@pytest.mark.parametrize("name", TF_FIXTURES)
+def test_transformer_residual_fused_into_the_projections_agrees(name):
+    """DeepNorm's alpha * x (bonito/transformer/model.py:125-128: `norm(sublayer(x), alpha * x)`) is added in the epilogue of the
+    out_proj / fc2 GEMMs (fp32 accumulator + alpha * x, one rounding) and the norm kernel reads one tensor (`norm_fuse` 1; an option - it measured no faster);
+    `norm_fuse` 0 (default) is the separate residual read in the norm kernel. Both match the reference fixture, and each other to fp16 rounding."""
+    cfg, sd, x, y = load_tf_fixture(name)
+    model = build_tf_model(cfg, sd)
+    want = ref_scores_to_koi(y)
+    rng = max(want.abs().max().item(), 1.0)
+    outs = {}
+    for fuse in (1, 0):
+        enc = HipEncoder(model.encoder, batchsize=x.shape[0], chunksize=x.shape[-1])
+        enc.set_option("norm_fuse", fuse)
+        outs[fuse] = enc(x.half().cuda()).cpu().float()
+        enc.check()
+        d = (outs[fuse] - want).abs()
+        assert d.max().item() < 2e-2 * rng and d.mean().item() < 3e-3 * rng, (fuse, d.max().item(), d.mean().item())
+    assert (outs[1] - outs[0]).abs().max().item() < 1e-2 * rng
+
+
 def test_transformer_long_chunk_ring_attention_matches_oracle():
     """T = 700 tokens (six query blocks: the ring wraps) and a batch of 3, v5.0-style window (127, 128), against the fp32
     oracle of the reference modules."""
