@@ -1301,8 +1301,10 @@ SideStream* side_stream(int S) {
     // Measured (MI355X, 512 x 1667 steps): forking shortens the decode stage 8.3 -> 6.7 ms (S=64) / 11.3 -> 9.3 ms (S=256).
     // Where the decoder is the pipeline bottleneck (fast-sized models) that is a net win (10.0 -> 9.4 ms per step); next to
     // the latency-bound LSTM of a hac-sized model the denser decode burst costs the encoder more than it saves (24.4-25.0 ->
-    // 25.3-25.5 ms per step), so auto mode forks only for S <= 64.
-    if (g_beam_fork == 0 || (g_beam_fork < 0 && S > 64)) return nullptr;
+    // 25.3-25.5 ms per step), so auto mode forks for S <= 64 - and for 1024 states, where the scan is not a wave of the beam
+    // kernel and that kernel is one wave per chunk on an otherwise idle CU (round 4, 256-chunk batches: decode 9.9 -> 7.5 ms of
+    // the transformer sup model with its step unchanged at 67.7 ms, 17.5 -> 13.5 ms of the LSTM sup model, step 112.7 -> 111.0).
+    if (g_beam_fork == 0 || (g_beam_fork < 0 && S > 64 && S < 1024)) return nullptr;
     thread_local SideStream per_dev[16];
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;

@@ -335,7 +335,7 @@ def _linear_ref(x, w, b, act, gated, scale=1.0, lo=-INF, hi=INF):
     return z.clamp(lo, hi)
 
 
-@pytest.mark.parametrize("M,N,K,gated,act", [(300, 256, 256, 0, 0), (1000 + 7, 512, 384, 0, 1), (2048, 256, 512, 1, 0), (777, 768, 1024, 0, 2),
+@pytest.mark.parametrize("M,N,K,gated,act", [(300, 256, 640, 0, 0), (1000 + 7, 512, 384, 0, 1), (2048, 256, 512, 1, 0), (777, 768, 1024, 0, 2),
                                              (40000 + 13, 1024, 384, 0, 1), (70000, 512, 512, 1, 0), (131072 + 5, 256, 2048, 0, 0)])
 def test_linear_four_wave_kernel(M, N, K, gated, act):
     """gemm_w4_kernel (256 x 256 x 64 tile on four waves, 32x32x16 MFMAs, one generated instruction stream per K-tile, outputs
@@ -369,9 +369,9 @@ def test_linear_four_wave_kernel(M, N, K, gated, act):
 
 def test_linear_four_wave_kernel_layouts_exactly():
     """X = I-like (one 1.0 per row) against an asymmetric W: every output is one W element exactly, so a permuted fragment row, a
-    wrong swizzle or a transposed store shows up as a wrong value, not as noise. K = 256, several feature and token tiles."""
+    wrong swizzle or a transposed store shows up as a wrong value, not as noise. K = 384 (the shortest K the kernel takes), several feature and token tiles."""
     from bonito_amd import decode
-    M, N, K = 1024, 512, 256
+    M, N, K = 1024, 512, 384
     x = torch.zeros(M, K)
     x[torch.arange(M), (torch.arange(M) * 7) % K] = 1.0
     w = ((torch.arange(N * K).reshape(N, K) * 37) % 2039 / 16.0).half()

@@ -215,7 +215,7 @@ def main():
                  "constexpr int W4_NOW = 12, W4_NPARK = 32 - W4_NOW;\n"
                  "constexpr int w4_store_row(int idx) { return 32 * ((idx + W4_NOW) >> 3) + 8 * (idx & 3); }\n"
                  "constexpr int w4_store_col(int idx) { return ((idx + W4_NOW) >> 2) & 1; }\n")
-        for stores in (4, 6):
+        for stores in (4,):
             for wide in (True, False):
                 for first in (False, True):
                     text += "\n" + build(first=first, stores=stores, wide=wide, **kw)
