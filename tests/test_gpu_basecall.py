@@ -574,6 +574,6 @@ def test_bench_default_mode_runs_and_reports_the_contract_fields():
     assert d["with_h2d"]["value"] > 5e7 and d["value_with_h2d"] == d["with_h2d"]["value"] and d["batches_per_engine_call"] == 4
     one = d["per_call_1"]                                        # the product path's call shape, in the same line
     assert one["value"] > 5e7 and "lstm_layer_wgx" in one["roofline"]["kernel"] and one["roofline"]["chunks_per_launch"] == 512
-    assert set(d["other_configs"]) == {"fast", "sup", "sup_lstm", "hac_quantize"}
+    assert set(d["other_configs"]) == {"fast", "sup", "sup_lstm", "sup_20000", "hac_quantize"}
     for name, leg in d["other_configs"].items():
         assert "error" not in leg and leg["value"] > 1e7, (name, leg)
