@@ -42,6 +42,30 @@ __device__ __forceinline__ float lse2_tab(float a, float b, const float* tab) {
     return m + sp;
 }
 
+// lse2_tab without control flow (same arithmetic): safe for garbage `b` as long as the result is discarded
+__device__ __forceinline__ float lse2_tab_nb(float a, float b, const float* tab) {
+    const float m = fmaxf(a, b);
+    const float d = fabsf(a - b);
+    const bool plain = !(d < BH_LSE_RANGE);          // covers m == -inf (d is NaN or +inf then)
+    const float x = d * BH_LSE_SCALE;
+    // d < RANGE: x < RANGE * SCALE = TABLE_SIZE - 2, the clamp changes nothing. Otherwise (d >= RANGE, +inf or NaN) the index only
+    // has to stay inside the table: fminf returns the bound for NaN, d is never negative
+    const int i = (int)fminf(x, (float)(BH_LSE_TABLE_SIZE - 2));
+    const float f = x - (float)i;
+    const float t0 = tab[i];
+    const float sp = __fmaf_rn(f, tab[i + 1] - t0, t0);
+    return plain ? m : m + sp;
+}
+
+// The scans call the branch-free form (round 4): with the early return every one of the 16-20 LSEs of a lane and step sat in its own
+// exec-masked branch (s_and_saveexec / s_cbranch_execz / s_or, an lgkmcnt(0) in front of each), which also kept the four independent
+// state chains of a lane from overlapping their table reads. Same operations on the same values: bit-identical rows.
+#ifndef BH_LSE_BRANCHY
+#define lse2_scan lse2_tab_nb
+#else
+#define lse2_scan lse2_tab
+#endif
+
 // wave-wide max without LDS traffic: DPP butterflies inside each row of 16 lanes, then row broadcasts;
 // the total ends up in lane 63 (classic GCN reduction, valid on the gfx9 family incl. gfx950).
 template <int CTRL, int ROW_MASK>
@@ -137,13 +161,13 @@ __global__ void crf_backward_kernel(ScanArgs p) {
 #pragma unroll
                         for (int x = 0; x < 4; ++x) {
                             const half_t m = __builtin_bit_cast(half_t, (unsigned short)(w[x] >> sh16));
-                            acc = lse2_tab(acc, (float)m + (pvx[x] - ref), tab);
+                            acc = lse2_scan(acc, (float)m + (pvx[x] - ref), tab);
                         }
                     } else {
 #pragma unroll
                         for (int x = 0; x < 4; ++x) {
                             const int s2 = sm * 4 + x;
-                            acc = lse2_tab(acc, (float)row[s2 * 4 + lead] + (prev[s2] - ref), tab);
+                            acc = lse2_scan(acc, (float)row[s2 * 4 + lead] + (prev[s2] - ref), tab);
                         }
                     }
                     buf[(cb ^ 1) * S + s] = acc;
@@ -240,7 +264,7 @@ __global__ void crf_forward_post_kernel(ScanArgs p) {
                     acc = p.blank + (prev[j] - ref);
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
-                        acc = lse2_tab(acc, (float)cur[u][r] + (prev[r * q + (j >> 2)] - ref), tab);
+                        acc = lse2_scan(acc, (float)cur[u][r] + (prev[r * q + (j >> 2)] - ref), tab);
                     buf[(cb ^ 1) * S + j] = acc;
                 }
                 A += (double)ref;
@@ -338,7 +362,7 @@ __global__ void crf_posterior_viterbi_kernel(PostVitArgs pa) {
             for (int r = 0; r < 4; ++r) {
                 const int src = r * q + (j >> 2);
                 const float ms = (float)m4[r];
-                acc = lse2_tab(acc, ms + (prev[src] - ref), tab);
+                acc = lse2_scan(acc, ms + (prev[src] - ref), tab);
                 const float e = (float)((double)prev[src] + (double)ms + off);
                 const float cand = __logf(__expf(e) + 1e-8f) + vprev[src];
                 if (cand > best) { best = cand; bk = 1 + r; }
@@ -636,20 +660,6 @@ __device__ __forceinline__ void dma16_nt(const char* g, char* lds) {      // sam
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt" ::"s"(l), "v"(g) : "memory");
 }
 
-// lse2_tab without control flow (same arithmetic): safe for garbage `b` as long as the result is discarded
-__device__ __forceinline__ float lse2_tab_nb(float a, float b, const float* tab) {
-    const float m = fmaxf(a, b);
-    const float d = fabsf(a - b);
-    const bool plain = !(d < BH_LSE_RANGE);          // covers m == -inf (d is NaN or +inf then)
-    const float x = d * BH_LSE_SCALE;
-    int i = plain ? 0 : (int)x;
-    i = min(max(i, 0), BH_LSE_TABLE_SIZE - 2);
-    const float f = x - (float)i;
-    const float t0 = tab[i];
-    const float sp = __fmaf_rn(f, tab[i + 1] - t0, t0);
-    return plain ? m : m + sp;
-}
-
 // STATE_LEN is a template parameter so that every LDS region sits at a constant offset (immediate DS offsets, no address
 // arithmetic or scalar registers spent on them); DBG compiles the per-section cycle counters in.
 // One wave per chunk, CPW chunks (waves) per workgroup: the waves share nothing but the 16 KiB lse table - each has its own
@@ -692,7 +702,7 @@ __device__ __forceinline__ void guide_step(float blank, const half_t* row, const
 #pragma unroll
         for (int x = 0; x < 4; ++x) {
             const int s2 = sm * 4 + x;
-            a = lse2_tab(a, (float)row[s2 * 4 + lead] + (prev[s2] - ref), tab);
+            a = lse2_scan(a, (float)row[s2 * 4 + lead] + (prev[s2] - ref), tab);
         }
         acc[k] = a;
     }
@@ -726,7 +736,7 @@ __device__ __forceinline__ void scan_step(const BeamArgs& p, const half_t* row, 
         const int j = active ? lane * SPL + k : 0;
         float a = p.blank + (ap[j] - ref);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) a = lse2_tab(a, (float)row[j * 4 + r] + (ap[r * q + (j >> 2)] - ref), tab);
+        for (int r = 0; r < 4; ++r) a = lse2_scan(a, (float)row[j * 4 + r] + (ap[r * q + (j >> 2)] - ref), tab);
         acc[k] = a;
     }
     if (active) {

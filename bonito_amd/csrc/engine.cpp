@@ -196,7 +196,6 @@ struct bh_encoder {
     DevBuf q_act[2], q_ex;                 // 8-bit recurrent path: int8 activations in fragment order, exchange ring buffer
     DevBuf ex16;                           // fp16 workgroup-shared kernel: exchange ring buffer (lstm_layer_wgx_kernel)
     int lstm_pair = 1;                     // batches of more rings than one launch holds: two rings per workgroup instead of two launches
-    int lstm_pair_wide = 0;                // the same for the wide (H > 512) kernel: built and tested, not faster (see encoder_forward)
     int norm_fuse = 0;                     // transformer: 1 = alpha * residual added in the out_proj / fc2 epilogues instead of the norm kernel (measured: no gain, 67.7 vs 67.4 ms per sup step - the residual read costs the GEMM epilogue what it saves the norm kernel)
     int lstm_exchange = 1;                 // 1: hand-off through the ring buffer (no sentinel fill of the output tensor), 0: through the output
     int lstm_q8 = 1;                       // 0: run quantised layers through the fp16 kernels (A/B)
@@ -731,9 +730,8 @@ extern "C" int bh_encoder_describe(const bh_encoder_t* e, char* buf, size_t n) {
                     const bool pair = e->lstm_pair && fit > 0 && Np / 16 > fit;
                     snprintf(line, sizeof(line), "%d lstm %d%s: lstm_layer_%s_kernel<%d,%d>\n", li, H, d.reverse ? " rev" : "", pair ? "wgx2" : "wgx", H / 32, U / 4);
                 }
-                else if (p.wg) snprintf(line, sizeof(line), "%d lstm %d%s: lstm_layer_wg_kernel<%d,%d>\n", li, H, d.reverse ? " rev" : "", H / 32, U / 4);
                 else if (p.fused) snprintf(line, sizeof(line), "%d lstm %d%s: lstm_layer_fused_kernel<%d>\n", li, H, d.reverse ? " rev" : "", H / 32);
-                else if (p.wide) snprintf(line, sizeof(line), "%d lstm %d%s: gemm + lstm_layer_wide_kernel<%d,%s>%s\n", li, H, d.reverse ? " rev" : "", H / 32, p.widex ? "true" : "false", p.widex && e->lstm_pair_wide ? " (lstm_layer_wide2_kernel: two rings per workgroup, for calls of more than 256 chunks)" : "");
+                else if (p.wide) snprintf(line, sizeof(line), "%d lstm %d%s: gemm + lstm_layer_wide_kernel<%d,%s>\n", li, H, d.reverse ? " rev" : "", H / 32, p.widex ? "true" : "false");
                 else if (p.reg_path) snprintf(line, sizeof(line), "%d lstm %d%s: gemm + lstm_layer_kernel<%d,false>\n", li, H, d.reverse ? " rev" : "", H / 32);
                 else snprintf(line, sizeof(line), "%d lstm %d%s: gemm + lstm_layer_kernel<%d,true> (weight streaming)\n", li, H, d.reverse ? " rev" : "", H / 32);
                 break;
@@ -858,7 +856,7 @@ extern "C" int bh_encoder_forward(bh_encoder_t* e, const void* signal, int N, in
                 int rc;
                 void* dst = e->act[which].p;
                 const LstmPath lp = lstm_path(e, l);
-                const bool reg_path = lp.reg_path, wide = lp.wide, fused = lp.fused, wg = lp.wg, cta = lp.cta;
+                const bool reg_path = lp.reg_path, wide = lp.wide, fused = lp.fused, cta = lp.cta;
                 if (lp.q8) {
                     const int R = Np / 16;
                     const size_t tile = bh_k_lstm_q8_tile_bytes(H);
@@ -920,23 +918,19 @@ extern "C" int bh_encoder_forward(bh_encoder_t* e, const void* signal, int N, in
                 ProfSpan span(e, st, BH_PROF_LSTM_REC);
                 // co-residency: one launch serves at most (CUs / (8 * H/16)) * 32 rings
                 const int nsl = H / 16;
-                const int wg_wpr = wg ? (H / bh_k_lstm_wg_units(H)) / 4 : 1;     // workgroups per ring (wg variant)
-                const int groups_fit = wg ? e->n_cus / (8 * wg_wpr) : reg_path ? e->n_cus / (8 * nsl) : e->n_cus / (8 * (nsl / 4));
+                const bool wgk = lp.wgx || cta;                                  // a workgroup-shared kernel serves the layer (else: per-wave kernels)
+                const int wg_wpr = wgk ? (H / bh_k_lstm_wg_units(H)) / 4 : 1;    // workgroups per ring
+                const int groups_fit = wgk ? e->n_cus / (8 * wg_wpr) : reg_path ? e->n_cus / (8 * nsl) : e->n_cus / (8 * (nsl / 4));
                 BH_REQUIRE(groups_fit >= 1, "encoder_forward: device has too few CUs (%d) for hidden size %d", e->n_cus, H);
                 const int wide_fit = wide ? e->n_cus / (8 * (H / 32)) : 0;          // ring groups (of 8 rings) that are co-resident
                 BH_REQUIRE(!wide || wide_fit >= 1, "encoder_forward: device has too few CUs (%d) for hidden size %d", e->n_cus, H);
-                const int rings_per_launch = wide ? wide_fit * 8 : cta ? (1 << 20) : wg ? groups_fit * 8 : reg_path ? groups_fit * 32 : groups_fit * 8;
+                const int rings_per_launch = wide ? wide_fit * 8 : cta ? (1 << 20) : wgk ? groups_fit * 8 : reg_path ? groups_fit * 32 : groups_fit * 8;
                 const int ring_chunks = wide ? 32 : 16;
                 const int n_rings = Np / ring_chunks;
                 for (int r0 = 0; r0 < n_rings;) {
                     // more rings than one launch holds: the ring-buffer kernel carries two rings per workgroup (lstm_layer_wgx2_kernel)
                     const bool pair = lp.wgx && e->lstm_pair && n_rings - r0 > rings_per_launch;
-                    // wide layers: two rings per workgroup (lstm_layer_wide2_kernel) when the call carries more rings than one launch of
-                    // single rings holds - an even number of them per launch. Option "lstm_pair_wide", OFF by default: bit-identical, but
-                    // measured slower than two launches of single rings (27.3 vs 2 x 10.9 ms per 512 chunks x 3334 steps at H = 1024)
-                    const int wide_nr = std::min(2 * rings_per_launch, n_rings - r0) & ~1;
-                    const bool pair_w = wide && lp.widex && e->lstm_pair_wide && n_rings - r0 > rings_per_launch && wide_nr >= 2;
-                    const int nr = pair_w ? wide_nr : std::min(pair ? 2 * rings_per_launch : rings_per_launch, n_rings - r0);
+                    const int nr = std::min(pair ? 2 * rings_per_launch : rings_per_launch, n_rings - r0);
                     const size_t col = (size_t)r0 * ring_chunks;
                     if (pair)
                         rc = bh_k_lstm_layer_wgx2((const char*)cur + col * H * 2, l.w4.p, (const float*)l.b0.p, l.w3.p,
@@ -945,7 +939,7 @@ extern "C" int bh_encoder_forward(bh_encoder_t* e, const void* signal, int N, in
                     else if (wide)
                         rc = bh_k_lstm_layer_wide((const char*)e->gates.p + col * 4 * H * 2, l.w3.p, (char*)dst + col * H * 2, len, Np, H,
                                                   d.reverse, e->cur_err, st, nr, (int*)e->lstm_ws.p, e->lstm_force_slow,
-                                                  lp.widex ? (char*)e->ex16.p + (size_t)r0 * 2 * (H / 32) * 1024 : nullptr, n_rings, r0 == 0, pair_w);
+                                                  lp.widex ? (char*)e->ex16.p + (size_t)r0 * 2 * (H / 32) * 1024 : nullptr, n_rings, r0 == 0);
                     else if (cta)
                         rc = bh_k_lstm_layer_cta((const char*)cur + col * H * 2, l.w4.p, (const float*)l.b0.p, l.w3.p,
                                                  (char*)dst + col * H * 2, len, Np, H, d.reverse, st, nr);
@@ -953,10 +947,6 @@ extern "C" int bh_encoder_forward(bh_encoder_t* e, const void* signal, int N, in
                         rc = bh_k_lstm_layer_wgx((const char*)cur + col * H * 2, l.w4.p, (const float*)l.b0.p, l.w3.p,
                                                  (char*)dst + col * H * 2, (char*)e->ex16.p + (size_t)r0 * (H / 32) * 1024, len, Np, H, n_rings,
                                                  d.reverse, e->cur_err, st, nr, (int*)e->lstm_ws.p, e->lstm_force_slow, r0 == 0);
-                    else if (wg)
-                        rc = bh_k_lstm_layer_wg((const char*)cur + col * H * 2, l.w4.p, (const float*)l.b0.p, l.w3.p,
-                                                (char*)dst + col * H * 2, len, Np, H, d.reverse, e->cur_err, st, nr,
-                                                (int*)e->lstm_ws.p, e->lstm_force_slow);
                     else if (fused)
                         rc = bh_k_lstm_layer_fused((const char*)cur + col * H * 2, l.w2.p, (const float*)l.b0.p, l.w1.p,
                                                    (char*)dst + col * H * 2, len, Np, H, d.reverse, e->cur_err, st, nr,
@@ -1324,7 +1314,6 @@ extern "C" int bh_encoder_set_option(bh_encoder_t* e, const char* name, int valu
     if (!strcmp(name, "lstm_q8")) { e->lstm_q8 = value; return 0; }
     if (!strcmp(name, "lstm_exchange")) { e->lstm_exchange = value; return 0; }
     if (!strcmp(name, "lstm_pair")) { e->lstm_pair = value; return 0; }
-    if (!strcmp(name, "lstm_pair_wide")) { e->lstm_pair_wide = value; return 0; }
     if (!strcmp(name, "norm_fuse")) { e->norm_fuse = value; return 0; }
     if (!strcmp(name, "gemm_v1")) { bh_k_linear_force_v1(value); return 0; }   // process-wide A/B switch
     if (!strcmp(name, "lstm_tune")) { e->lstm_force_slow = (e->lstm_force_slow & 1) | (value << 8); return 0; }

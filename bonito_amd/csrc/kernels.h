@@ -39,8 +39,6 @@ int bh_k_lstm_wg_units(int H);
 int bh_k_lstm_cta_units(int H);
 int bh_k_lstm_layer_cta(const void* x, const void* wih_tiles, const float* bias, const void* whh_tiles, void* h_out, int T, int N,
                         int H, int reverse, hipStream_t stream, int n_rings);
-int bh_k_lstm_layer_wg(const void* x, const void* wih_tiles, const float* bias, const void* whh_tiles, void* h_out, int T, int N,
-                       int H, int reverse, int* err_flag, hipStream_t stream, int n_rings, int* xcc_ws, int force_slow);
 
 // crf.hip
 int bh_k_crf_viterbi(const void* scores, int N, int T, int state_len, int layout_5s, float blank_score,
@@ -93,7 +91,7 @@ int bh_k_signal_chunks(const int16_t* raw, const long* offs, const float* cal_sc
 int bh_k_lstm_wide_ok(int H);
 int bh_k_lstm_layer_wide(const void* gates_perm, const void* whh_tiles, void* h_out, int T, int N, int H, int reverse,
                          int* err_flag, hipStream_t stream, int n_rings, int* xcc_ws, int force_slow, void* ex = nullptr, int R = 0,
-                         int arm = 0, int pair = 0);
+                         int arm = 0);
 size_t bh_k_lstm_wide_ex_bytes(int N, int H);
 
 // lstm_q8.hip: 8-bit recurrent path Q8-1

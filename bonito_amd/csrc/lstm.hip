@@ -440,7 +440,10 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_fused_kernel(LstmFusedArgs 
 }
 
 // ---------------------------------------------------------------------------------------------------
-// Workgroup-shared exchange ("wg" variant): the four waves of a workgroup are four SLICES OF THE SAME RING.
+// Workgroup-shared kernels (lstm_layer_wgx_kernel / lstm_layer_wgx2_kernel below): the four waves of a workgroup are four SLICES OF
+// THE SAME RING. (Round 1's lstm_layer_wg_kernel - this structure with the hand-off through the sentinel-filled output tensor - was
+// removed in round 4: superseded by the ring-buffer exchange since round 2; lstm_layer_fused_kernel is the bit-identity reference that
+// still exchanges through the output tensor, "lstm_exchange" 0 selects it.)
 // Every wave owns U = 4*MT hidden units (MT M-tiles whose 16 rows are 4 units x 4 gates, so a lane ends up with all
 // four gate pre-activations of MT units), holds BOTH its W_hh and W_ih fragments in registers (H=384, U=12:
 // 2*144 registers of the 512-entry unified file) and the workgroup shares h_{t-1} and x_{t+1} through LDS:
@@ -448,7 +451,7 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_fused_kernel(LstmFusedArgs 
 // fragments, one workgroup barrier per step publishes them. Compared with lstm_layer_fused_kernel this cuts the
 // L2 read traffic of the exchange and of the x stream by 4x (it was 768 waves x 12 KB x ~2.5 per step at hac
 // size, i.e. L2-bandwidth-bound polling), needs no LDS for weights and keeps all 256 CUs busy at N=512, H=384.
-// Exchange protocol (sentinel pre-fill, data-as-flag, XCD agreement, bounded spins) is unchanged.
+// XCD agreement and bounded spins as in lstm_layer_fused_kernel.
 __device__ __forceinline__ void mfma16_av(const half8_t& a_agpr, const half8_t& b, float4_t& c) {
     asm("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(c) : "a"(a_agpr), "v"(b));
 }
@@ -461,265 +464,8 @@ __device__ __forceinline__ void mfma_settle_v(float4_t (&c)[MT]) {
     else asm volatile("s_nop 15\n\ts_nop 7" : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]));
 }
 
-template <int NKS, int MT>
-__global__ __launch_bounds__(256, 1) void lstm_layer_wg_kernel(LstmFusedArgs fp) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const LstmArgs& p = fp.a;
-    constexpr int H = NKS * 32, U = 4 * MT, NSL = H / U, WPR = NSL / 4, KQ = (NKS + 3) / 4;
-    constexpr bool EXACT = NKS % 4 == 0;     // every wave owns exactly KQ k-steps
-    static_assert(H % (4 * U) == 0, "four slices per workgroup");
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int xcd = blockIdx.x & 7;
-    const int lwg = blockIdx.x >> 3;
-    const int rl = lwg / WPR;
-    // test hook ("lstm_tune" bit 5): spread the workgroups of every ring over all eight XCDs, so that the placement-independent
-    // (write-through) hand-off really crosses XCDs
-    const int ring = rl * 8 + ((p.tune & 32) ? ((xcd + (lwg - rl * WPR)) & 7) : xcd);
-    const int slice = (lwg - rl * WPR) * 4 + wave;
-    if (ring >= p.n_rings) return;                      // whole workgroup (same ring) leaves together
-
-    char* hbuf = smem;                                  // [2][NKS][64 lanes][16 B]  B fragments of h_{t-1}
-    char* xbuf = smem + 2 * NKS * 1024;                 // [2][NKS][64][16]          B fragments of x_t
-    char* stage = smem + 4 * NKS * 1024 + wave * (16 * U * 2);   // per-wave [16 chunks][U] output transpose
-
-    half8_t whh[MT][NKS], wih[MT][NKS];
-#pragma unroll
-    for (int m = 0; m < MT; ++m)
-#pragma unroll
-        for (int ks = 0; ks < NKS; ++ks) {
-            const long o = ((((long)slice * MT + m) * NKS + ks) * 64 + lane) * 8;
-            whh[m][ks] = *(const half8_t*)(p.whh + o);
-            wih[m][ks] = *(const half8_t*)(fp.wih + o);
-        }
-
-    const int c = lane & 15, q = lane >> 4;
-    const long row_bytes = (long)p.N * H * 2;
-    const unsigned voff = (unsigned)(((ring * 16 + c) * H + q * 8) * 2);
-    float cst[MT];
-    float4_t bias4[MT];
-#pragma unroll
-    for (int m = 0; m < MT; ++m) {
-        cst[m] = 0.f;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) bias4[m][i] = fp.bias[i * H + slice * U + q * MT + m];
-    }
-    bool dead = false;
-
-    const bool fast = ring_store_policy(p, ring, slice, NSL, lane);
-
-    int t = p.reverse ? p.T - 1 : 0;
-    const int dt = p.reverse ? -1 : 1;
-    const half_t* xptr = fp.x + ((long)(ring * 16 + c) * H + q * 8);
-    const long x_row = (long)p.N * H;
-    const int lo = lane * 16;
-
-    // this wave's quarter of the k-steps: ks = wave + 4*kk
-    uint4_t xq[KQ], xr[KQ], hq[KQ];     // x quarters of step+1 (landed) and step+2 (in flight), h quarter being polled
-    float4_t xacc[MT];
-
-    auto x_phase = [&](const char* xb) {
-#pragma unroll
-        for (int m = 0; m < MT; ++m) xacc[m] = bias4[m];
-        half8_t b_cur = *(const half8_t*)(xb + lo), b_nxt = b_cur;
-#pragma unroll
-        for (int ks = 0; ks < NKS; ++ks) {
-            if (ks + 1 < NKS) b_nxt = *(const half8_t*)(xb + (ks + 1) * 1024 + lo);
-#pragma unroll
-            for (int m = 0; m < MT; ++m) {
-                if (m < MT - 1) mfma16_av(wih[m][ks], b_cur, xacc[m]);
-                else mfma16_vv(wih[m][ks], b_cur, xacc[m]);
-            }
-            b_cur = b_nxt;
-        }
-        mfma_settle_v<MT>(xacc);
-    };
-
-    // ---- prologue: x_0 -> LDS -> input projection of step 0; x_1 landed, x_2 on its way -------------------------------
-    {
-        const int t1 = p.T > 1 ? t + dt : t, t2 = p.T > 2 ? t + 2 * dt : t;
-#pragma unroll
-        for (int kk = 0; kk < KQ; ++kk) {
-            const int ks = wave + 4 * kk;
-            if (EXACT || ks < NKS) {
-                *(uint4_t*)(xbuf + ks * 1024 + lo) = *(const uint4_t*)(xptr + (long)t * x_row + ks * 32);
-                xq[kk] = *(const uint4_t*)(xptr + (long)t1 * x_row + ks * 32);
-                xr[kk] = *(const uint4_t*)(xptr + (long)t2 * x_row + ks * 32);
-            }
-        }
-#pragma unroll
-        for (int kk = 0; kk < KQ; ++kk) asm volatile("" : "+v"(xq[kk]), "+v"(xr[kk]));    // landed: clean vm counter at loop entry
-    }
-    __syncthreads();
-    x_phase(xbuf);
-#pragma unroll
-    for (int kk = 0; kk < KQ; ++kk) hq[kk] = uint4_t{0, 0, 0, 0};
-
-    long long st_poll = 0, st_rounds = 0, st_first_ok = 0, st_x = 0, st_rec = 0, st_bar = 0, st_hist = 0;
-    long long st_a = 0, st_c = 0, st_mf = 0, st_gate = 0, st_store = 0;
-    const long long st_t0 = __builtin_readcyclecounter();
-    const long long st_r0 = (p.tune & 4) ? (long long)__builtin_amdgcn_s_memrealtime() : 0;     // 100 MHz
-
-    for (int step = 0; step < p.T; ++step, t += dt) {
-        const long long pct = (p.tune & 4) ? __builtin_readcyclecounter() : 0;
-        const int par = step & 1;
-        float4_t acc[MT];
-#pragma unroll
-        for (int m = 0; m < MT; ++m) acc[m] = xacc[m];
-        // ---- A. x_{t+1} quarter (in registers since the previous step) -> LDS --------------------------------------
-#pragma unroll
-        for (int kk = 0; kk < KQ; ++kk) {
-            const int ks = wave + 4 * kk;
-            if (EXACT || ks < NKS) *(uint4_t*)(xbuf + ((par ^ 1) * NKS + ks) * 1024 + lo) = xq[kk];
-        }
-        // ---- B. my quarter of h_{t-1}: round one was issued right after the previous store ------------------
-        const long long pc0 = (p.tune & 4) ? __builtin_readcyclecounter() : 0;
-        if (step > 0) {
-            const char* base = (const char*)p.h + (long)(t - dt) * row_bytes;
-            __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)row_bytes, 0x00020000);
-            unsigned spins = dead ? p.max_spins : 0u;
-            unsigned pend = 0;
-#pragma unroll
-            for (int kk = 0; kk < KQ; ++kk) {
-                const int ks = wave + 4 * kk;
-                if (EXACT || ks < NKS) {
-                    unsigned orv = hq[kk].x | hq[kk].y | hq[kk].z | hq[kk].w;
-                    if (__any((orv & SENTINEL_MASK) != 0)) pend |= (1u << kk);
-                }
-            }
-            unsigned rounds = 1;
-            while (pend != 0) {
-                if (++spins > p.max_spins) {
-                    if (lane == 0 && !dead) atomicExch(p.err, 1);
-                    dead = true;
-                    break;
-                }
-                if (!(p.tune & 1)) __builtin_amdgcn_s_sleep(1);
-#pragma unroll
-                for (int kk = 0; kk < KQ; ++kk)
-                    if (pend & (1u << kk))
-                        hq[kk] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff + (wave + 4 * kk) * 64, 0, (int)0x80000010);
-#pragma unroll
-                for (int kk = 0; kk < KQ; ++kk)
-                    if (pend & (1u << kk)) {
-                        unsigned orv = hq[kk].x | hq[kk].y | hq[kk].z | hq[kk].w;
-                        if (!__any((orv & SENTINEL_MASK) != 0)) pend &= ~(1u << kk);
-                    }
-                ++rounds;
-            }
-#pragma unroll
-            for (int kk = 0; kk < KQ; ++kk) {
-                const int ks = wave + 4 * kk;
-                if (EXACT || ks < NKS) *(uint4_t*)(hbuf + (par * NKS + ks) * 1024 + lo) = hq[kk];
-            }
-            if (p.tune & 4) {
-                st_poll += __builtin_readcyclecounter() - pc0; st_rounds += rounds; st_first_ok += (rounds == 1);
-                st_hist += 1ll << (16 * (rounds > 3 ? 3 : rounds - 1));
-            }
-        }
-        const long long pcc = (p.tune & 4) ? __builtin_readcyclecounter() : 0;
-        // ---- C. rotate the x quarters and request step t+3, in the memory-quiet phase before the barrier. Two steps of
-        //         slack: the loads are never waited for on the store -> poll -> barrier critical path, and they stay away
-        //         from the store / poll burst (issued right after the polls they cut first-round poll success from
-        //         93 % to 53 %; one step of slack with a wait before the h_t store: 41 %) ------------------------------
-        {
-            const int t3 = (step + 3 < p.T) ? t + 3 * dt : t;
-#pragma unroll
-            for (int kk = 0; kk < KQ; ++kk) {
-                const int ks = wave + 4 * kk;
-                xq[kk] = xr[kk];
-                if (EXACT || ks < NKS) xr[kk] = *(const uint4_t*)(xptr + (long)t3 * x_row + ks * 32);
-            }
-        }
-        // ---- D. publish both tiles to the workgroup ----------------------------------------------------------
-        const long long pc1 = (p.tune & 4) ? __builtin_readcyclecounter() : 0;
-        __syncthreads();
-        const long long pc2 = (p.tune & 4) ? __builtin_readcyclecounter() : 0;
-        // ---- E. recurrent part, gates, publish h_t ------------------------------------------------------------
-        if (step > 0) {
-            const char* hb = hbuf + par * NKS * 1024 + lo;
-            half8_t hb_f[NKS];                       // all B fragments up front: one LDS latency, then MFMAs back to back
-#pragma unroll
-            for (int ks = 0; ks < NKS; ++ks) hb_f[ks] = *(const half8_t*)(hb + ks * 1024);
-#pragma unroll
-            for (int ks = 0; ks < NKS; ++ks)
-#pragma unroll
-                for (int m = 0; m < MT; ++m) mfma16_av(whh[m][ks], hb_f[ks], acc[m]);
-            mfma_settle_v<MT>(acc);
-        }
-        const long long pcm = (p.tune & 4) ? __builtin_readcyclecounter() : 0;
-        half_t ho[MT];
-#pragma unroll
-        for (int m = 0; m < MT; ++m) {
-            // (timing experiment: replacing lstm_cell by a clamp saves 645 cycles per step = 13 % of the kernel)
-            const float hv = lstm_cell(acc[m][0], acc[m][1], acc[m][2], acc[m][3], cst[m]);
-            ho[m] = (half_t)hv;
-        }
-        const long long pcg = (p.tune & 4) ? __builtin_readcyclecounter() : 0;
-
-        if constexpr (MT == 4) {
-            half4_t h4 = {ho[0], ho[1], ho[2], ho[3]};
-            unsigned long long packed = __builtin_bit_cast(unsigned long long, h4);
-            unsigned long long* dst = (unsigned long long*)(p.h + ((long)t * p.N + ring * 16 + c) * H + slice * U + q * 4);
-            if (fast) *dst = packed;
-            else __hip_atomic_store(dst, packed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        } else {
-            // lane (q, c) holds units q*MT..q*MT+MT-1 of chunk c: transpose through the wave's LDS patch so that the
-            // global store is 8 bytes per lane (U/4 lanes per chunk). Measured alternative: MT direct 2-byte stores per
-            // lane without the LDS round trip are slower (hac encoder 19.2 -> 20.7 ms).
-            u16_alias_t* sg = (u16_alias_t*)stage + c * U + q * MT;
-#pragma unroll
-            for (int m = 0; m < MT; ++m) sg[m] = __builtin_bit_cast(unsigned short, ho[m]);
-            constexpr int PARTS = U / 4;
-            if (lane < 16 * PARTS) {
-                const int cc = lane / PARTS, part = lane - cc * PARTS;
-                const unsigned long long packed = *(const u64_alias_t*)((half_t*)stage + cc * U + part * 4);
-                unsigned long long* dst =
-                    (unsigned long long*)(p.h + ((long)t * p.N + ring * 16 + cc) * H + slice * U + part * 4);
-                if (fast) *dst = packed;
-                else __hip_atomic_store(dst, packed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-        }
-        // ---- F. first poll round for h_t goes out now; it is checked after the input projection -------------
-        if (step + 1 < p.T) {
-            const char* base = (const char*)p.h + (long)t * row_bytes;
-            __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)row_bytes, 0x00020000);
-#pragma unroll
-            for (int kk = 0; kk < KQ; ++kk) {
-                const int ks = wave + 4 * kk;
-                if (EXACT || ks < NKS) hq[kk] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff + ks * 64, 0, (int)0x80000010);
-            }
-        }
-        const long long pc3 = (p.tune & 4) ? __builtin_readcyclecounter() : 0;
-        // ---- G. input projection of step t+1 from the LDS tile published at D --------------------------------
-        x_phase(xbuf + (par ^ 1) * NKS * 1024);
-        if (p.tune & 4) {
-            const long long now = __builtin_readcyclecounter();
-            st_bar += pc2 - pc1; st_rec += pc3 - pc2; st_x += now - pc3;
-            st_a += pc0 - pct; st_c += pc1 - pcc; st_mf += pcm - pc2; st_gate += pcg - pcm; st_store += pc3 - pcg;
-        }
-    }
-    if ((p.tune & 4) && lane == 0) {
-        long long* st = (long long*)((char*)p.xcc_ws + (((size_t)p.n_rings * NSL * sizeof(int) + 64 + 7) & ~(size_t)7)) + ((long)ring * NSL + slice) * 16;
-        st[0] = __builtin_readcyclecounter() - st_t0;
-        st[1] = st_poll;
-        st[2] = st_rounds;
-        st[3] = st_first_ok;
-        st[4] = st_x;
-        st[5] = st_bar;
-        st[6] = st_rec;
-        st[7] = st_hist;
-        st[8] = st_a;
-        st[9] = st_c;
-        st[10] = st_mf;
-        st[11] = st_gate;
-        st[12] = st_store;
-        st[13] = (long long)__builtin_amdgcn_s_memrealtime() - st_r0;
-    }
-}
-
 // ---------------------------------------------------------------------------------------------------
-// "wgx": the workgroup-shared kernel above with the exchange and the x stream of the 8-bit kernel (lstm_q8.hip). Same
+// "wgx": the workgroup-shared structure above with the exchange and the x stream of the 8-bit kernel (lstm_q8.hip). Same
 // arithmetic, same accumulation order, same lstm_cell() -> the same bytes as every other fp16 variant (tested); what changes is
 // where the bytes travel:
 //   * the hand-off no longer goes through the layer's output tensor. h_t is published into a small RING BUFFER of four time
@@ -1655,7 +1401,8 @@ __global__ __launch_bounds__(64 * (NKS * 32 / (4 * MT)), 1) void lstm_layer_cta_
 // registers at H = 1024), a workgroup is four slices of one ring, a ring spans H/32 workgroups (32 at H = 1024 = one whole XCD),
 // and batch 256 fills 256 CUs. The input projection comes from a GEMM whose output columns are permuted so that a lane's
 // eight pre-activations (4 gates x 2 units) are one 16-byte load: G[t][n][(slice*4 + q)*8 + gate*2 + m].
-// Exchange protocol and workgroup sharing of the h tile through LDS as in lstm_layer_wg_kernel (each wave polls a quarter).
+// Workgroup sharing of the h tile through LDS as in lstm_layer_wgx_kernel (each wave polls a quarter); the exchange goes through the
+// ring buffer (RX) or, with "lstm_exchange" 0, through the sentinel-filled output tensor.
 // Replaces the weight-streaming kernel on these shapes: 139 -> 14.4 ms per layer launch at H=1024, N=256, T=3334.
 struct LstmWideArgs {
     const half_t* G;      // [T][N][4H], columns permuted as above, bias included
@@ -1853,214 +1600,11 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_wide_kernel(LstmWideArgs wp
     }
 }
 
-// Two rings per workgroup (round 4; lstm_layer_wgx2_kernel's pairing for the wide layers). A wide ring step is 128 MFMAs (2.0 k cycles)
-// inside 6.5 k cycles: the rest is the hand-off - publish, ~0.45 k cycles until it is visible, a poll round trip of ~1 k, the other 127
-// waves of the ring - and there is ONE wave per SIMD (all 256 accumulation registers hold W_hh), so nothing else runs meanwhile. The
-// workgroup therefore carries ring p AND ring p + n_pairs on the same register-resident weights and alternates: while ring A's h_t
-// travels (publish -> L2 -> first poll round, requested right behind the publish), the wave does ring B's whole step. Same arithmetic
-// in the same order as lstm_layer_wide_kernel<NKS, true> per ring: bit-identical (tests).
-// LDS: the h tile of a ring needs no second parity any more - between two writes of ring A's tile lies ring B's barrier, behind which
-// every wave has finished A's MFMAs - so the two tiles take the 2 x 64 KiB (H = 1024) the two parities of one ring took.
-// A launch serves 2 x 8 rings x 32 chunks = 512 chunks at H = 1024 (one pair per XCD); the engine uses it when a call carries an even
-// number of at least sixteen rings per launch group (sup LSTM-1024: `basecaller` / bench.py group two 256-chunk batches per engine call).
-template <int NKS>
-__global__ __launch_bounds__(256, 1) void lstm_layer_wide2_kernel(LstmWideArgs wp, int n_pairs) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const LstmArgs& p = wp.a;
-    constexpr int MT = 2, NB = 2, H = NKS * 32, U = 4 * MT, NSL = H / U, WPR = NSL / 4;
-    constexpr int NF = NB * NKS;                 // B fragments of a ring's h tile
-    constexpr int KQ = (NF + 3) / 4;
-    constexpr bool EXACT = NF % 4 == 0;
-    constexpr int TILE = NF * 1024;
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int xcd = blockIdx.x & 7;
-    const int lwg = blockIdx.x >> 3;
-    const int rl = lwg / WPR;
-    const int pair = rl * 8 + ((p.tune & 32) ? ((xcd + (lwg - rl * WPR)) & 7) : xcd);
-    const int slice = (lwg - rl * WPR) * 4 + wave;
-    if (pair >= n_pairs) return;
-
-    char* stage = smem + 2 * TILE + wave * (NB * 16 * U * 2);   // per-wave, per column tile [16 chunks][U] output transpose (one region per
-                                                                // column tile: both tiles' values are ready before the first is read back)
-
-    half8_t whh[MT][NKS];
-#pragma unroll
-    for (int m = 0; m < MT; ++m)
-#pragma unroll
-        for (int ks = 0; ks < NKS; ++ks)
-            whh[m][ks] = *(const half8_t*)(p.whh + ((((long)slice * MT + m) * NKS + ks) * 64 + lane) * 8);
-
-    const int c = lane & 15, q = lane >> 4;
-    const int lo = lane * 16;
-    const int dt = p.reverse ? -1 : 1;
-    const long slot_stride = (long)wp.R * TILE;
-    const long g_row = (long)p.N * 4 * H;
-
-    struct Ring {
-        int ring;
-        bool fast, dead;
-        char* hbuf;           // this ring's h tile in LDS
-        char* exr;            // its exchange ring buffer
-        const half_t* gptr;   // this lane's gate pre-activations
-        float cst[MT][NB];
-        uint4_t gq[NB], gr[NB];
-    };
-    Ring R[2];
-#pragma unroll
-    for (int w = 0; w < 2; ++w) {
-        Ring& r = R[w];
-        r.ring = pair + w * n_pairs;
-        r.dead = false;
-        r.fast = ring_store_policy(p, r.ring, slice, NSL, lane);
-        r.hbuf = smem + w * TILE;
-        r.exr = wp.ex + (long)r.ring * TILE;
-        r.gptr = wp.G + ((long)(r.ring * NB * 16 + c) * 4 * H + (slice * 4 + q) * 8);
-        const int t0 = p.reverse ? p.T - 1 : 0;
-        const int t1 = p.T > 1 ? t0 + dt : t0;
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb) {
-            r.gq[nb] = *(const uint4_t*)(r.gptr + (long)t0 * g_row + (long)nb * 16 * 4 * H);
-            r.gr[nb] = *(const uint4_t*)(r.gptr + (long)t1 * g_row + (long)nb * 16 * 4 * H);
-#pragma unroll
-            for (int m = 0; m < MT; ++m) r.cst[m][nb] = 0.f;
-        }
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb) asm volatile("" : "+v"(r.gq[nb]), "+v"(r.gr[nb]));
-    }
-
-    // Poll round of ring r for h of step `hstep`: my quarter of the tile (fragments wave, wave + 4, ...) by LDS-DMA straight into the
-    // ring's tile - the lane-linear image IS the fragment order. Holding the quarter in registers through the other ring's step (as
-    // the single-ring kernel does through its own) would take 2 x 64 registers that this kernel does not have.
-    auto poll = [&](Ring& r, int hstep, unsigned mask) {
-        const char* base = r.exr + (long)(hstep & 3) * slot_stride + lo;
-#pragma unroll
-        for (int kk = 0; kk < KQ; ++kk) {
-            const int f = wave + 4 * kk;
-            if ((EXACT || f < NF) && (mask & (1u << kk))) dma16_poll(base + f * 1024, r.hbuf + f * 1024);
-        }
-    };
-    // which of my fragments of ring r's tile still carry the sentinel (read back from LDS, four at a time)
-    auto pending = [&](Ring& r, unsigned mask) -> unsigned {
-        unsigned pend = 0;
-#pragma unroll
-        for (int kk = 0; kk < KQ; ++kk) {
-            const int f = wave + 4 * kk;
-            if ((EXACT || f < NF) && (mask & (1u << kk))) {
-                const uint4_t v = *(const uint4_t*)(r.hbuf + f * 1024 + lo);
-                const unsigned orv = v.x | v.y | v.z | v.w;
-                if (__any((orv & SENTINEL_MASK) != 0)) pend |= (1u << kk);
-            }
-        }
-        return pend;
-    };
-
-    // One time step of ring r. `o` is the other ring: the poll round for the h it published last (its step `ostep`) is issued behind
-    // this step's barrier - from there on nobody reads o's tile any more (every wave has finished o's MFMAs) - and travels behind
-    // this ring's MFMAs and gates; it is VALIDATED here too, in front of this ring's publish: at that point the polls are the youngest
-    // vector-memory operations of the wave, so the vmcnt(0) that proves they have landed waits for nothing else (behind the publish it
-    // would sit out the publish stores' acknowledgements: measured, 8.9 us per pair of ring steps instead of 6.5 for two single ones).
-    auto ring_step = [&](Ring& r, int step, int t, Ring& o, int ostep) {
-        const bool do_o = ostep >= 0 && ostep + 1 < p.T;
-        // ---- C. gate pre-activations: this step's are in gq; rotate and request step t+2 -----------------------------------
-        float4_t acc[MT][NB];
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb) {
-            const half8_t g8 = __builtin_bit_cast(half8_t, r.gq[nb]);
-#pragma unroll
-            for (int m = 0; m < MT; ++m)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) acc[m][nb][i] = (float)g8[i * MT + m];
-        }
-        {
-            const int t2 = (step + 2 < p.T) ? t + 2 * dt : t;
-#pragma unroll
-            for (int nb = 0; nb < NB; ++nb) {
-                r.gq[nb] = r.gr[nb];
-                r.gr[nb] = *(const uint4_t*)(r.gptr + (long)t2 * g_row + (long)nb * 16 * 4 * H);
-            }
-        }
-        __syncthreads();          // this ring's tile is complete and validated by all four waves; nobody reads the OTHER ring's tile any more
-        if (do_o && (step == 0 || (p.tune & 64))) poll(o, ostep, ~0u);
-        // ---- E. recurrent part, gates ------------------------------------------------------------------------------------------
-        if (step > 0) {
-#pragma unroll
-            for (int nb = 0; nb < NB; ++nb) {
-                // the other ring's poll round goes out behind the first column tile's MFMAs: late enough for its publishes to be visible
-                // (issued right behind the barrier, ~0.3 k cycles after them, the first round mostly came back incomplete and the
-                // re-poll - a full round trip - sat on the critical path), early enough to be back behind the second tile and the gates
-                if (nb == 1 && do_o && !(p.tune & 64)) poll(o, ostep, ~0u);
-                const char* hb = r.hbuf + (nb * NKS) * 1024 + lo;
-                half8_t b_cur = *(const half8_t*)hb, b_nxt = b_cur;
-#pragma unroll
-                for (int ks = 0; ks < NKS; ++ks) {
-                    if (ks + 1 < NKS) b_nxt = *(const half8_t*)(hb + (ks + 1) * 1024);
-#pragma unroll
-                    for (int m = 0; m < MT; ++m) mfma16_av(whh[m][ks], b_cur, acc[m][nb]);
-                    b_cur = b_nxt;
-                }
-            }
-            asm volatile("s_nop 15\n\ts_nop 7" : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[1][0]), "+v"(acc[1][1]));
-        }
-        unsigned short hv[NB][MT];
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-            for (int m = 0; m < MT; ++m)
-                hv[nb][m] = __builtin_bit_cast(unsigned short, (half_t)lstm_cell(acc[m][nb][0], acc[m][nb][1], acc[m][nb][2], acc[m][nb][3], r.cst[m][nb]));
-        // ---- B(o). my quarter of the OTHER ring's next tile: landed? complete? (re-poll what still carries the sentinel) ----------
-        if (do_o) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            unsigned spins = o.dead ? p.max_spins : 0u;
-            unsigned pend = pending(o, ~0u);
-            while (pend != 0) {
-                if (++spins > p.max_spins) {
-                    if (lane == 0 && !o.dead) atomicExch(p.err, 1);
-                    o.dead = true;
-                    break;
-                }
-                if (!(p.tune & 1)) __builtin_amdgcn_s_sleep(1);
-                poll(o, ostep, pend);
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                pend = pending(o, pend);
-            }
-        }
-        // ---- publish h_t ---------------------------------------------------------------------------------------------------------
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb) {
-            char* stg = stage + nb * (16 * U * 2);
-            u16_alias_t* sg = (u16_alias_t*)stg + c * U + q * MT;
-#pragma unroll
-            for (int m = 0; m < MT; ++m) sg[m] = hv[nb][m];
-            if (lane < 32) {                    // 16 chunks x 2 parts of 4 units: 8-byte stores
-                const int cc = lane >> 1, part = lane & 1;
-                const unsigned long long packed = *(const u64_alias_t*)((half_t*)stg + cc * U + part * 4);
-                unsigned long long* dst =
-                    (unsigned long long*)(p.h + ((long)t * p.N + (r.ring * NB + nb) * 16 + cc) * H + slice * U + part * 4);
-                const int u0 = slice * U + part * 4;
-                const int my_byte = (((nb * NKS + (u0 >> 5)) * 64 + ((u0 >> 3) & 3) * 16 + cc) << 4) + (u0 & 7) * 2;
-                // the re-arm store of the previous step must be complete before anything newer is published (lstm_layer_wgx_kernel)
-                if (nb == 0) __builtin_amdgcn_s_waitcnt(0x0F70);
-                unsigned long long* xd = (unsigned long long*)(r.exr + (long)(step & 3) * slot_stride + my_byte);
-                if (r.fast) *xd = packed;
-                else __hip_atomic_store(xd, packed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (step >= 2 && step + 2 < p.T) {
-                    unsigned long long* ra = (unsigned long long*)(r.exr + (long)((step + 2) & 3) * slot_stride + my_byte);
-                    if (r.fast) *ra = ~0ull;
-                    else __hip_atomic_store(ra, ~0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-                *dst = packed;                  // the layer output proper
-            }
-        }
-    };
-
-    int t = p.reverse ? p.T - 1 : 0;
-    for (int step = 0; step < p.T; ++step, t += dt) {
-        ring_step(R[0], step, t, R[1], step - 1);     // behind A's barrier: B's h of the previous step is requested
-        ring_step(R[1], step, t, R[0], step);         // behind B's barrier: A's h of this step
-    }
-}
-
+// (Round 4 built the pairing of lstm_layer_wgx2_kernel for this kernel as well - two rings per workgroup on one register-resident copy of
+// the weights, bit-identical in five geometries - and measured it SLOWER than two launches of single rings: 27.3 against 2 x 10.9 ms per
+// 512 chunks x 3334 steps at H = 1024. A wide ring step is already 128 MFMAs against ~1.3 k cycles of hand-off, every register holds
+// weights or accumulators, so the second ring's polls, validation and publish run one after the other in the same wave. Removed again;
+// git: 113fefb "paired wide recurrent kernel".)
 __global__ void fill_u16_kernel(uint16_t* dst, uint16_t v, size_t count) {
     size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 8;
     const size_t stride = (size_t)gridDim.x * blockDim.x * 8;
@@ -2218,44 +1762,6 @@ int bh_k_lstm_wg_units(int H) {
     return 0;
 }
 
-int bh_k_lstm_layer_wg(const void* x, const void* wih_packed, const float* bias, const void* whh_packed, void* h_out,
-                       int T, int N, int H, int reverse, int* err_flag, hipStream_t stream, int n_rings, int* xcc_ws,
-                       int force_slow) {
-    using namespace bh;
-    BH_REQUIRE(N % 16 == 0, "lstm: batch must be padded to a multiple of 16 (N=%d)", N);
-    const int U = bh_k_lstm_wg_units(H);
-    BH_REQUIRE(U != 0, "lstm: workgroup-shared kernel does not cover H=%d", H);
-    BH_REQUIRE(x != h_out, "lstm: fused layer cannot run in place");
-    int dev = 0, cus = 0;
-    BH_CHECK_HIP(hipGetDevice(&dev));
-    BH_CHECK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-    const int nsl = H / U, wpr = nsl / 4;
-    BH_REQUIRE(n_rings > 0 && n_rings <= N / 16, "lstm: n_rings=%d outside 1..%d", n_rings, N / 16);
-    const int rl = (n_rings + 7) / 8;
-    const int grid = 8 * rl * wpr;
-    BH_REQUIRE(grid <= cus, "lstm: %d workgroups must be co-resident but the device has %d CUs; split the batch", grid, cus);
-    BH_REQUIRE(xcc_ws != nullptr, "lstm: missing XCD agreement workspace");
-    BH_CHECK_HIP(hipMemsetAsync(xcc_ws, 0xFF, (size_t)n_rings * nsl * sizeof(int), stream));
-    LstmFusedArgs a{(const half_t*)x, (const half_t*)wih_packed, bias,
-                    LstmArgs{nullptr, (const half_t*)whh_packed, (half_t*)h_out, T, N, H, n_rings, reverse, err_flag, g_max_spins,
-                             xcc_ws, force_slow & 1, force_slow >> 8}};
-    const int nks = H / 32;
-    const size_t lds = (size_t)4 * nks * 1024 + 4 * 16 * U * 2;
-#define BH_LSTM_WG(NKS, MT)                                                                                      \
-    if (nks == NKS && U == 4 * MT) {                                                                             \
-        if (lds > 64 * 1024)                                                                                     \
-            BH_CHECK_HIP(hipFuncSetAttribute((const void*)lstm_layer_wg_kernel<NKS, MT>,                         \
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));            \
-        hipLaunchKernelGGL((lstm_layer_wg_kernel<NKS, MT>), dim3(grid), dim3(256), lds, stream, a);               \
-    } else
-    BH_LSTM_WG(3, 3) BH_LSTM_WG(6, 3) BH_LSTM_WG(9, 3) BH_LSTM_WG(12, 3)
-    BH_LSTM_WG(2, 4) BH_LSTM_WG(4, 4) BH_LSTM_WG(8, 4)
-    { BH_REQUIRE(false, "lstm: workgroup-shared kernel has no instance for H=%d", H); }
-#undef BH_LSTM_WG
-    BH_CHECK_HIP(hipGetLastError());
-    return 0;
-}
-
 // Ring-buffer exchange variant of the workgroup-shared kernel (lstm_layer_wgx_kernel). `ex`: 4 * R * (H/32) KiB, armed here
 // with 0xFF when `arm` is set (once per layer: launches of one layer share it, each with its ring offset applied by the caller).
 size_t bh_k_lstm_wgx_ex_bytes(int N, int H) { return (size_t)4 * (N / 16) * (H / 32) * 1024; }
@@ -2380,7 +1886,7 @@ size_t bh_k_lstm_wide_ex_bytes(int N, int H) { return (size_t)4 * (N / 32) * 2 *
 
 // ex != nullptr: ring-buffer exchange (R = rings of the whole batch, `arm` = fill it with the sentinel first: once per layer)
 int bh_k_lstm_layer_wide(const void* gates_perm, const void* whh_tiles, void* h_out, int T, int N, int H, int reverse,
-                         int* err_flag, hipStream_t stream, int n_rings, int* xcc_ws, int force_slow, void* ex, int R, int arm, int pair) {
+                         int* err_flag, hipStream_t stream, int n_rings, int* xcc_ws, int force_slow, void* ex, int R, int arm) {
     using namespace bh;
     BH_REQUIRE(bh_k_lstm_wide_ok(H), "lstm: wide kernel does not cover H=%d", H);
     BH_REQUIRE(N % 32 == 0, "lstm: wide kernel needs the batch padded to a multiple of 32 (N=%d)", N);
@@ -2391,7 +1897,7 @@ int bh_k_lstm_layer_wide(const void* gates_perm, const void* whh_tiles, void* h_
     BH_REQUIRE(n_rings > 0 && n_rings <= N / 32, "lstm: n_rings=%d outside 1..%d", n_rings, N / 32);
     const int rl = (n_rings + 7) / 8;
     const int grid = 8 * rl * wpr;
-    BH_REQUIRE(pair || grid <= cus, "lstm: %d workgroups must be co-resident but the device has %d CUs; split the batch", grid, cus);
+    BH_REQUIRE(grid <= cus, "lstm: %d workgroups must be co-resident but the device has %d CUs; split the batch", grid, cus);
     BH_REQUIRE(xcc_ws != nullptr, "lstm: missing XCD agreement workspace");
     BH_CHECK_HIP(hipMemsetAsync(xcc_ws, 0xFF, (size_t)n_rings * nsl * sizeof(int), stream));
     LstmWideArgs a{(const half_t*)gates_perm,
@@ -2401,23 +1907,6 @@ int bh_k_lstm_layer_wide(const void* gates_perm, const void* whh_tiles, void* h_
     const int nks = H / 32;
     if (ex && arm) BH_CHECK_HIP(hipMemsetAsync(ex, 0xFF, (size_t)4 * R * 2 * nks * 1024, stream));
     const size_t lds = (size_t)2 * 2 * nks * 1024 + 4 * 16 * 8 * 2;
-    if (pair) {
-        // two rings per workgroup: n_rings is even, ring p shares its workgroups with ring p + n_rings / 2
-        BH_REQUIRE(ex != nullptr && n_rings % 2 == 0, "lstm: the paired wide kernel needs the ring-buffer exchange and an even ring count (%d)", n_rings);
-        const int n_pairs = n_rings / 2;
-        const int grid2 = 8 * ((n_pairs + 7) / 8) * wpr;
-        BH_REQUIRE(grid2 <= cus, "lstm: %d workgroups must be co-resident but the device has %d CUs; split the batch", grid2, cus);
-#define BH_LSTM_WIDE2(NKS)                                                                                               \
-    if (nks == NKS) {                                                                                                    \
-        BH_CHECK_HIP(hipFuncSetAttribute((const void*)lstm_layer_wide2_kernel<NKS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds + 1024)); \
-        hipLaunchKernelGGL((lstm_layer_wide2_kernel<NKS>), dim3(grid2), dim3(256), lds + 1024, stream, a, n_pairs);        \
-    } else
-        BH_LSTM_WIDE2(20) BH_LSTM_WIDE2(24) BH_LSTM_WIDE2(28) BH_LSTM_WIDE2(32)
-        { BH_REQUIRE(false, "lstm: wide kernel has no instance for H=%d", H); }
-#undef BH_LSTM_WIDE2
-        BH_CHECK_HIP(hipGetLastError());
-        return 0;
-    }
 #define BH_LSTM_WIDE(NKS)                                                                                               \
     if (nks == NKS && ex) {                                                                                             \
         BH_CHECK_HIP(hipFuncSetAttribute((const void*)lstm_layer_wide_kernel<NKS, true>, hipFuncAttributeMaxDynamicSharedMemorySize, \

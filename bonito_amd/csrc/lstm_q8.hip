@@ -9,7 +9,8 @@
 //                every fp32 operation is rounded separately (no contraction), so `pre` is bit-identical to the oracle's
 //   cell       : the fp32 gate arithmetic of the fp16 kernels (lstm_cell), h published as fp16 and quantised from THAT value.
 //
-// Structure: the workgroup-shared exchange of lstm_layer_wg_kernel (lstm.hip) with three changes the 8-bit operands allow:
+// Structure: the workgroup-shared kernel of lstm.hip (four slices of one ring per workgroup, lstm_layer_wgx_kernel) with three changes
+// the 8-bit operands allow (this file had them first; the fp16 kernel took the ring buffer and the LDS-DMA x stream from here):
 //   * weights: W_hh and W_ih tiles of a wave are 2 * MT * (H/64) * 4 registers (144 at H = 384, U = 12 units per wave:
 //     half of the fp16 kernel's 288), MFMAs per step halve (K = 64 per instruction);
 //   * the exchange no longer goes through the layer's output tensor. Activations travel as int8 in MFMA B-fragment order

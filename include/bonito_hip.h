@@ -116,11 +116,10 @@ int bh_encoder_forward(bh_encoder_t* enc, const void* signal, int N, int L, void
 /* one text line per layer naming the kernels the engine launches for it (measurement / logging) */
 int bh_encoder_describe(const bh_encoder_t* enc, char* buf, size_t bytes);
 /* "lstm_exchange" (1 default: the workgroup-shared fp16 recurrent kernel hands h_t over through a small L2-resident ring
- * buffer and writes the output tensor separately; 0: through the sentinel-filled output tensor as in round 1).
+ * buffer and writes the output tensor separately; 0: through the sentinel-filled output tensor - the per-wave
+ * lstm_layer_fused_kernel for H <= 512, the wide kernel's older hand-off above that; same bytes, tests).
  * "lstm_pair" (1 default: a batch of more rings than one launch of that kernel holds - more than 512 chunks at H = 384 - is served
- * two rings per workgroup on one register-resident copy of the weights, lstm_layer_wgx2_kernel; 0: one launch per 32 rings).
- * "lstm_pair_wide" (0 default: the same pairing for the wide, H > 512, recurrent kernel - lstm_layer_wide2_kernel: bit-identical,
- * measured slower than two launches of single rings, kept as an option). */
+ * two rings per workgroup on one register-resident copy of the weights, lstm_layer_wgx2_kernel; 0: one launch per 32 rings). */
 /* tuning / test options (results never change): "lstm_fused" (3 default: narrowest applicable fused kernel; 2, 1, 0 = older
  * variants down to projection-by-GEMM), "lstm_force_slow" (0/1: write-through exchange), "lstm_wide" (1/0), "lstm_prefill"
  * (1 default: sentinel fill of the next recurrent layer's buffer on a side stream), "attn_ring" (1/0), "lstm_tune" (bit mask) */

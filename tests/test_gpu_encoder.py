@@ -225,7 +225,7 @@ def test_workgroup_shared_lstm_kernel_widths(H, sl):
         if fused == -2:
             enc.set_option("lstm_prefill", 0)
         if fused <= -2:
-            enc.set_option("lstm_exchange", 0)         # round-1 hand-off through the sentinel-filled output tensor
+            enc.set_option("lstm_exchange", 0)         # hand-off through the sentinel-filled output tensor (lstm_layer_fused_kernel / cta)
         outs[fused] = enc(x.cuda()).cpu().float()
         enc.check()
         assert (outs[fused] - want).abs().max().item() < TOL_MAX, fused
@@ -279,7 +279,7 @@ def test_full_size_hac_encoder_kernel_variants_bit_identical():
         enc.set_option("lstm_fused", fused)
         enc.set_option("lstm_force_slow", slow)
         enc.set_option("lstm_prefill", prefill)     # 0: sentinel fill inline instead of beside the previous layer's kernel
-        enc.set_option("lstm_exchange", exch)       # 1 (default): ring-buffer hand-off, 0: through the output tensor (round 1)
+        enc.set_option("lstm_exchange", exch)       # 1 (default): ring-buffer hand-off, 0: through the output tensor (per-wave fused kernel)
         for _ in range(2):                             # twice: the side-stream fill must also be ordered across calls
             out = enc(x)
         outs.append(out)
@@ -421,13 +421,13 @@ def test_paired_rings_very_short_chunks(L):
 
 
 @pytest.mark.parametrize("H,N,L,tune", [(1024, 512, 600, 0), (1024, 288, 300, 0), (768, 544, 300, 0), (1024, 512, 300, 32), (1024, 512, 12, 0)])
-def test_wide_paired_rings_same_bytes_as_single_rings(H, N, L, tune):
-    """Wide layers (H = 768 / 1024), calls of more than 8 rings of 32 chunks: `lstm_layer_wide2_kernel` carries two rings per workgroup on
-    one register-resident copy of W_hh and alternates between them (the hand-off of one ring passes behind the step of the other; the
-    polls land by LDS-DMA in the ring's single h tile; engine option `lstm_pair_wide`). Same arithmetic in the same order as
-    `lstm_layer_wide_kernel`: the same bytes as the default (single rings, two launches) - 16 rings (one full paired launch), 9 rings (one pair launch of 8 + a lone ring),
-    17 rings at H = 768, the rings of a pair spread over all XCDs (write-through hand-off), and two time steps only - and close to
-    the fp32 oracle; run twice with identical bytes (`_encode`)."""
+def test_wide_layers_calls_of_several_launches(H, N, L, tune):
+    """Wide layers (H = 768 / 1024), calls of more than the 8 rings of 32 chunks that one launch of `lstm_layer_wide_kernel` holds: 16
+    rings (two full launches), 9 rings (a full launch + a lone ring), 17 rings at H = 768, the workgroups of a ring spread over all XCDs
+    (write-through hand-off), and two time steps only. The launches of a layer share the exchange ring buffer (armed once, each launch
+    at its ring offset): ring-buffer hand-off == hand-off through the output tensor byte for byte, identical bytes when run twice
+    (`_encode`), close to the fp32 oracle. (Round 4 also ran these geometries through a two-rings-per-workgroup variant of the kernel:
+    bit-identical, slower, removed - DESIGN 4.)"""
     from bonito_amd import nn as bnn, synthetic
     torch.manual_seed(H + N)
     cfg = synthetic.lstm_crf_encoder_config(H, 3, n_lstm=2)
@@ -436,9 +436,9 @@ def test_wide_paired_rings_same_bytes_as_single_rings(H, N, L, tune):
     nn_ref.round_params_to_half_(model)
     x = torch.randn(N, 1, L, generator=torch.Generator().manual_seed(N + L)).half()
     opts = {"lstm_tune": tune} if tune else {}
-    one, layout = _encode(model, x.cuda(), lstm_pair_wide=1, **opts)      # (an option, off by default: correct but not faster)
-    two, layout0 = _encode(model, x.cuda(), **opts)
-    assert "lstm_layer_wide2_kernel" in layout and "wide2" not in layout0
+    one, layout = _encode(model, x.cuda(), **opts)
+    two, _ = _encode(model, x.cuda(), lstm_exchange=0, **opts)
+    assert "lstm_layer_wide_kernel<%d,true>" % (H // 32) in layout
     assert torch.equal(one, two)
     rows = [0, 31, 32, N // 2 + 5, N - 1]
     with torch.no_grad():
