@@ -1415,14 +1415,12 @@ struct LstmWideArgs {
 // protocol and its argument are stated there): a workgroup's poll of its ring tile (64 KiB at H = 1024) becomes 64 coalesced KiB
 // instead of 1024 half-line pieces of a row-major tensor, the sentinel fill of the output tensor disappears, and the output
 // tensor is written by a second plain store. Same arithmetic -> same bytes as RX = false (tested).
-template <int NKS, bool RX>
+template <int NKS, bool RX, bool STATS = false>
 __global__ __launch_bounds__(256, 1) void lstm_layer_wide_kernel(LstmWideArgs wp) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const LstmArgs& p = wp.a;
     constexpr int MT = 2, NB = 2, H = NKS * 32, U = 4 * MT, NSL = H / U, WPR = NSL / 4;
     constexpr int NF = NB * NKS;                 // B fragments of a ring's h tile
-    constexpr int KQ = (NF + 3) / 4;
-    constexpr bool EXACT = NF % 4 == 0;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int xcd = blockIdx.x & 7;
@@ -1469,7 +1467,14 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_wide_kernel(LstmWideArgs wp
     // gate pre-activations of this lane: 16 bytes per column tile
     const half_t* gptr = wp.G + ((long)(ring * NB * 16 + c) * 4 * H + (slice * 4 + q) * 8);
     const long g_row = (long)p.N * 4 * H;
-    uint4_t gq[NB], gr[NB], hq[KQ];
+    // Round 4: the two column tiles of a ring are INDEPENDENT chunks that merely share the weights, so a step is two half-steps, one
+    // per tile, each with its own poll check, barrier, 2 * NKS MFMAs, gates, publish and first poll round: while tile 0's h_t travels
+    // (publish -> L2 -> poll, ~1.5 k cycles) the wave does tile 1's half-step (~1.5 k cycles of MFMAs and gates) and vice versa. In
+    // lock step (one barrier, both tiles' MFMAs, both tiles' gates, then the hand-off of both) the round trip was exposed in every step:
+    // 6.5 k cycles per step for 2.0 k of MFMAs. Same arithmetic per cell -> the same bytes (tests).
+    constexpr int KH = (NKS + 3) / 4;            // poll pieces of a wave per tile
+    constexpr bool EXH = NKS % 4 == 0;
+    uint4_t gq[NB], gr[NB], hq[NB][KH];
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
         const int t1 = p.T > 1 ? t + dt : t;
@@ -1479,124 +1484,150 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_wide_kernel(LstmWideArgs wp
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) asm volatile("" : "+v"(gq[nb]), "+v"(gr[nb]));
 #pragma unroll
-    for (int kk = 0; kk < KQ; ++kk) hq[kk] = uint4_t{0, 0, 0, 0};
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int kk = 0; kk < KH; ++kk) hq[nb][kk] = uint4_t{0, 0, 0, 0};
 
+    // STATS ("lstm_tune" bit 2, H = 1024 with the ring-buffer exchange only): per-wave cycle stamps into the workspace tail
+    // (tools/lstm_wide_stats.py). A template parameter: as a run-time flag the ten untaken branches per step cost the product kernel 6 %.
+    constexpr bool stats = STATS;
+    long long st_poll = 0, st_bar = 0, st_mf = 0, st_gate = 0, st_rounds = 0, st_wait = 0;
+    const long long st_t0 = __builtin_readcyclecounter(), st_r0 = (long long)__builtin_amdgcn_s_memrealtime();
     for (int step = 0; step < p.T; ++step, t += dt) {
         const int par = step & 1;
-        // ---- B. my quarter of the ring's h_{t-1} tile (round one went out right after the previous store) --------
-        if (step > 0) {
-            const char* base = RX ? exr + (long)((step - 1) & 3) * slot_stride : (const char*)p.h + (long)(t - dt) * row_bytes;
-            __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, RX ? TILE : (int)row_bytes, 0x00020000);
-            unsigned spins = dead ? p.max_spins : 0u;
-            unsigned pend = 0;
-#pragma unroll
-            for (int kk = 0; kk < KQ; ++kk) {
-                const int f = wave + 4 * kk;
-                if (EXACT || f < NF) {
-                    unsigned orv = hq[kk].x | hq[kk].y | hq[kk].z | hq[kk].w;
-                    if (__any((orv & SENTINEL_MASK) != 0)) pend |= (1u << kk);
-                }
-            }
-            while (pend != 0) {
-                if (++spins > p.max_spins) {
-                    if (lane == 0 && !dead) atomicExch(p.err, 1);
-                    dead = true;
-                    break;
-                }
-                if (!(p.tune & 1)) __builtin_amdgcn_s_sleep(1);
-#pragma unroll
-                for (int kk = 0; kk < KQ; ++kk)
-                    if (pend & (1u << kk))
-                        hq[kk] = __builtin_amdgcn_raw_buffer_load_b128(rs, frag_voff(wave + 4 * kk), 0, (int)0x80000010);
-#pragma unroll
-                for (int kk = 0; kk < KQ; ++kk)
-                    if (pend & (1u << kk)) {
-                        unsigned orv = hq[kk].x | hq[kk].y | hq[kk].z | hq[kk].w;
-                        if (!__any((orv & SENTINEL_MASK) != 0)) pend &= ~(1u << kk);
-                    }
-            }
-#pragma unroll
-            for (int kk = 0; kk < KQ; ++kk) {
-                const int f = wave + 4 * kk;
-                if (EXACT || f < NF) *(uint4_t*)(hbuf + (par * NF + f) * 1024 + lo) = hq[kk];
-            }
-        }
-        // ---- C. gate pre-activations: this step's are in gq; rotate and request step t+2 (memory-quiet phase) -------
-        float4_t acc[MT][NB];
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
-            const half8_t g8 = __builtin_bit_cast(half8_t, gq[nb]);
+            const long long c0 = stats ? __builtin_readcyclecounter() : 0;
+            // ---- B. my quarter of tile nb of the ring's h_{t-1} (round one went out right after this tile's previous store) --------
+            if (step > 0) {
+                const char* base = RX ? exr + (long)((step - 1) & 3) * slot_stride : (const char*)p.h + (long)(t - dt) * row_bytes;
+                __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, RX ? TILE : (int)row_bytes, 0x00020000);
+                unsigned spins = dead ? p.max_spins : 0u;
+                unsigned pend = 0;
 #pragma unroll
-            for (int m = 0; m < MT; ++m)
+                for (int kk = 0; kk < KH; ++kk) {
+                    if (EXH || wave + 4 * kk < NKS) {
+                        unsigned orv = hq[nb][kk].x | hq[nb][kk].y | hq[nb][kk].z | hq[nb][kk].w;
+                        if (__any((orv & SENTINEL_MASK) != 0)) pend |= (1u << kk);
+                    }
+                }
+                if (stats) st_wait += __builtin_readcyclecounter() - c0;
+                while (pend != 0) {
+                    if (++spins > p.max_spins) {
+                        if (lane == 0 && !dead) atomicExch(p.err, 1);
+                        dead = true;
+                        break;
+                    }
+                    ++st_rounds;
+                    if (!(p.tune & 1)) __builtin_amdgcn_s_sleep(1);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) acc[m][nb][i] = (float)g8[i * MT + m];
-        }
-        {
-            const int t2 = (step + 2 < p.T) ? t + 2 * dt : t;
+                    for (int kk = 0; kk < KH; ++kk)
+                        if (pend & (1u << kk))
+                            hq[nb][kk] = __builtin_amdgcn_raw_buffer_load_b128(rs, frag_voff(nb * NKS + wave + 4 * kk), 0, (int)0x80000010);
 #pragma unroll
-            for (int nb = 0; nb < NB; ++nb) {
+                    for (int kk = 0; kk < KH; ++kk)
+                        if (pend & (1u << kk)) {
+                            unsigned orv = hq[nb][kk].x | hq[nb][kk].y | hq[nb][kk].z | hq[nb][kk].w;
+                            if (!__any((orv & SENTINEL_MASK) != 0)) pend &= ~(1u << kk);
+                        }
+                }
+#pragma unroll
+                for (int kk = 0; kk < KH; ++kk) {
+                    const int ks = wave + 4 * kk;
+                    if (EXH || ks < NKS) *(uint4_t*)(hbuf + (par * NF + nb * NKS + ks) * 1024 + lo) = hq[nb][kk];
+                }
+            }
+            // ---- C. gate pre-activations of tile nb: this step's are in gq; rotate and request step t+2 ------------------------------
+            float4_t acc[MT];
+            {
+                const half8_t g8 = __builtin_bit_cast(half8_t, gq[nb]);
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) acc[m][i] = (float)g8[i * MT + m];
+                const int t2 = (step + 2 < p.T) ? t + 2 * dt : t;
                 gq[nb] = gr[nb];
                 gr[nb] = *(const uint4_t*)(gptr + (long)t2 * g_row + (long)nb * 16 * 4 * H);
             }
-        }
-        __syncthreads();
-        // ---- E. recurrent part, gates, publish h_t ------------------------------------------------------------
-        if (step > 0) {
+            const long long c1 = stats ? __builtin_readcyclecounter() : 0;
+            __syncthreads();                            // tile nb of h_{t-1} is complete in LDS (and the stage buffer is free again)
+            const long long c2 = stats ? __builtin_readcyclecounter() : 0;
+            // ---- E. recurrent part of tile nb, gates, publish ------------------------------------------------------------------------
+            // The first poll round for the OTHER tile goes out from inside this tile's MFMAs, a quarter of the way in: that tile was
+            // published ~0.6 k cycles earlier by every wave of the ring at about the same time, so the round finds complete data (issued
+            // right behind the publish it sampled the L2 before the partners' stores were visible and a second, exposed round followed:
+            // 12.9 ms per launch instead of 10.2 on that box), and it has landed when that tile's next half-step checks it (1-2 % of the
+            // steps need a second round). Tile 0 polls tile 1's h_{t-1}, tile 1 polls tile 0's h_t.
+            // Same box, sup-LSTM 256 x 20000, ms per launch: lock step 11.40-11.44, this 11.04-11.11, polls an eighth of the way in
+            // 11.25-11.29. Also measured (tools/lstm_wide_stats.py, cycles per step incl. ~1.1 k of stamps; base 7290): fragment reads
+            // 2 / 4 k-steps ahead 7240 / 7260 - the loop is bound by LDS BANDWIDTH, not latency: the four waves read the same 32 KiB
+            // tile, 128 KiB per half-step at 128 B per clock = the 1024 cycles of its MFMAs; the gate prefetch behind the polls 7900; a
+            // counted vmcnt in front of the publish 7430; even / odd k-steps in separate accumulators 8280.
+            const int ob = 1 - nb;                      // (a constant after unrolling)
+            const bool want = nb == 1 ? step + 1 < p.T : step > 0;
+            auto other_polls = [&]() __attribute__((always_inline)) {
+                const int dstep = nb == 1 ? step : step - 1;
+                const char* base = RX ? exr + (long)(dstep & 3) * slot_stride : (const char*)p.h + (long)(nb == 1 ? t : t - dt) * row_bytes;
+                __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, RX ? TILE : (int)row_bytes, 0x00020000);
 #pragma unroll
-            for (int nb = 0; nb < NB; ++nb) {
+                for (int kk = 0; kk < KH; ++kk) {
+                    const int ks = wave + 4 * kk;
+                    if (EXH || ks < NKS) hq[ob][kk] = __builtin_amdgcn_raw_buffer_load_b128(rs, frag_voff(ob * NKS + ks), 0, (int)0x80000010);
+                }
+            };
+            if (step > 0) {
                 const char* hb = hbuf + (par * NF + nb * NKS) * 1024 + lo;
                 half8_t b_cur = *(const half8_t*)hb, b_nxt = b_cur;
 #pragma unroll
                 for (int ks = 0; ks < NKS; ++ks) {
                     if (ks + 1 < NKS) b_nxt = *(const half8_t*)(hb + (ks + 1) * 1024);
 #pragma unroll
-                    for (int m = 0; m < MT; ++m) mfma16_av(whh[m][ks], b_cur, acc[m][nb]);
+                    for (int m = 0; m < MT; ++m) mfma16_av(whh[m][ks], b_cur, acc[m]);
                     b_cur = b_nxt;
+                    if (ks == NKS / 4 && want) other_polls();
                 }
-            }
-            asm volatile("s_nop 15\n\ts_nop 7" : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[1][0]), "+v"(acc[1][1]));
-        }
+                asm volatile("s_nop 15\n\ts_nop 7" : "+v"(acc[0]), "+v"(acc[1]));
+            } else if (want) other_polls();
+            const long long c3 = stats ? __builtin_readcyclecounter() : 0;
+            {
+                u16_alias_t* sg = (u16_alias_t*)stage + c * U + q * MT;
 #pragma unroll
-        for (int nb = 0; nb < NB; ++nb) {
-            u16_alias_t* sg = (u16_alias_t*)stage + c * U + q * MT;
-#pragma unroll
-            for (int m = 0; m < MT; ++m)
-                sg[m] = __builtin_bit_cast(unsigned short, (half_t)lstm_cell(acc[m][nb][0], acc[m][nb][1], acc[m][nb][2], acc[m][nb][3], cst[m][nb]));
-            if (lane < 32) {                    // 16 chunks x 2 parts of 4 units: 8-byte stores
-                const int cc = lane >> 1, part = lane & 1;
-                const unsigned long long packed = *(const u64_alias_t*)((half_t*)stage + cc * U + part * 4);
-                unsigned long long* dst =
-                    (unsigned long long*)(p.h + ((long)t * p.N + (ring * NB + nb) * 16 + cc) * H + slice * U + part * 4);
-                if constexpr (RX) {
-                    const int u0 = slice * U + part * 4;
-                    const int my_byte = (((nb * NKS + (u0 >> 5)) * 64 + ((u0 >> 3) & 3) * 16 + cc) << 4) + (u0 & 7) * 2;
-                    // the re-arm store of the previous step must be complete before anything newer is published (lstm_layer_wgx_kernel)
-                    if (nb == 0) __builtin_amdgcn_s_waitcnt(0x0F70);
-                    unsigned long long* xd = (unsigned long long*)(exr + (long)(step & 3) * slot_stride + my_byte);
-                    if (fast) *xd = packed;
-                    else __hip_atomic_store(xd, packed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (step >= 2 && step + 2 < p.T) {
-                        unsigned long long* ra = (unsigned long long*)(exr + (long)((step + 2) & 3) * slot_stride + my_byte);
-                        if (fast) *ra = ~0ull;
-                        else __hip_atomic_store(ra, ~0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                for (int m = 0; m < MT; ++m)
+                    sg[m] = __builtin_bit_cast(unsigned short, (half_t)lstm_cell(acc[m][0], acc[m][1], acc[m][2], acc[m][3], cst[m][nb]));
+                if (lane < 32) {                    // 16 chunks x 2 parts of 4 units: 8-byte stores
+                    const int cc = lane >> 1, part = lane & 1;
+                    const unsigned long long packed = *(const u64_alias_t*)((half_t*)stage + cc * U + part * 4);
+                    unsigned long long* dst =
+                        (unsigned long long*)(p.h + ((long)t * p.N + (ring * NB + nb) * 16 + cc) * H + slice * U + part * 4);
+                    if constexpr (RX) {
+                        const int u0 = slice * U + part * 4;
+                        const int my_byte = (((nb * NKS + (u0 >> 5)) * 64 + ((u0 >> 3) & 3) * 16 + cc) << 4) + (u0 & 7) * 2;
+                        // the re-arm store of this tile's previous step must be complete before anything newer of it is published
+                        // (lstm_layer_wgx_kernel); what else is in flight - the other tile's polls - went out a half-step ago
+                        __builtin_amdgcn_s_waitcnt(0x0F70);
+                        unsigned long long* xd = (unsigned long long*)(exr + (long)(step & 3) * slot_stride + my_byte);
+                        if (fast) *xd = packed;
+                        else __hip_atomic_store(xd, packed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (step >= 2 && step + 2 < p.T) {
+                            unsigned long long* ra = (unsigned long long*)(exr + (long)((step + 2) & 3) * slot_stride + my_byte);
+                            if (fast) *ra = ~0ull;
+                            else __hip_atomic_store(ra, ~0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        }
+                        *dst = packed;              // the layer output proper
+                    } else {
+                        if (fast) *dst = packed;
+                        else __hip_atomic_store(dst, packed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     }
-                    *dst = packed;              // the layer output proper
-                } else {
-                    if (fast) *dst = packed;
-                    else __hip_atomic_store(dst, packed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
             }
+            if (stats) { const long long c4 = __builtin_readcyclecounter(); st_poll += c1 - c0; st_bar += c2 - c1; st_mf += c3 - c2; st_gate += c4 - c3; }
         }
-        // ---- F. first poll round for h_t ---------------------------------------------------------------------------
-        if (step + 1 < p.T) {
-            const char* base = RX ? exr + (long)(step & 3) * slot_stride : (const char*)p.h + (long)t * row_bytes;
-            __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, RX ? TILE : (int)row_bytes, 0x00020000);
-#pragma unroll
-            for (int kk = 0; kk < KQ; ++kk) {
-                const int f = wave + 4 * kk;
-                if (EXACT || f < NF) hq[kk] = __builtin_amdgcn_raw_buffer_load_b128(rs, frag_voff(f), 0, (int)0x80000010);
-            }
-        }
+    }
+    if (stats && lane == 0) {
+        long long* st = (long long*)((char*)p.xcc_ws + (((size_t)p.n_rings * NSL * sizeof(int) + 64 + 7) & ~(size_t)7)) + ((long)ring * NSL + slice) * 16;
+        st[0] = __builtin_readcyclecounter() - st_t0;
+        st[1] = st_poll; st[2] = st_bar; st[3] = st_mf; st[4] = st_gate; st[5] = st_rounds;
+        st[6] = (long long)__builtin_amdgcn_s_memrealtime() - st_r0; st[7] = st_wait;
     }
 }
 
@@ -1916,6 +1947,10 @@ int bh_k_lstm_layer_wide(const void* gates_perm, const void* whh_tiles, void* h_
         BH_CHECK_HIP(hipFuncSetAttribute((const void*)lstm_layer_wide_kernel<NKS, false>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                          (int)lds));                                                                    \
         hipLaunchKernelGGL((lstm_layer_wide_kernel<NKS, false>), dim3(grid), dim3(256), lds, stream, a);                 \
+    } else
+    if (nks == 32 && ex && ((force_slow >> 8) & 4)) {
+        BH_CHECK_HIP(hipFuncSetAttribute((const void*)lstm_layer_wide_kernel<32, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL((lstm_layer_wide_kernel<32, true, true>), dim3(grid), dim3(256), lds, stream, a);
     } else
     BH_LSTM_WIDE(20) BH_LSTM_WIDE(24) BH_LSTM_WIDE(28) BH_LSTM_WIDE(32)
     { BH_REQUIRE(false, "lstm: wide kernel has no instance for H=%d", H); }
