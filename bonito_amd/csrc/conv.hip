@@ -269,8 +269,13 @@ int bh_k_conv_first(const void* signal, const float* w, const float* bias, void*
 }
 
 int g_conv_ws = 1;      // bh_set_option("conv_ws", 0): always the generic implicit-GEMM kernel (A/B, regression tests)
+int g_conv_lds_kb = 80; // bh_set_option("conv_lds_kb", v): LDS a workgroup of conv_igemm_kernel may take for its input span; the positions per
+                        // workgroup follow, and with them how often the layer's weights are re-read from L2. 80 KiB = two workgroups per CU:
+                        // the 128-channel convolutions of the v5 sup model get 128 positions per workgroup instead of 64 (64 KiB, the
+                        // round-1 value): conv class 3.85 -> 3.25 ms per 256 x 12000 batch; 104 KiB: 3.68, 150 KiB (one workgroup per CU): 4.28
 int bh_k_conv_set_option(const char* name, int value) {
     if (name && !strcmp(name, "conv_ws")) { g_conv_ws = value; return 0; }
+    if (name && !strcmp(name, "conv_lds_kb")) { g_conv_lds_kb = value > 0 ? value : 80; return 0; }
     return 1;
 }
 
@@ -292,7 +297,7 @@ int bh_k_conv_igemm(const void* in, const void* wpk, const float* bias, void* ou
         return 0;
     }
     int pw = 64;
-    while (pw > 16 && lds_for(pw) > 64 * 1024) pw >>= 1;
+    while (pw > 16 && lds_for(pw) > (size_t)g_conv_lds_kb * 1024) pw >>= 1;
     size_t lds = lds_for(pw);
     BH_REQUIRE(lds <= 160 * 1024, "conv_igemm: input span does not fit LDS (%zu bytes)", lds);
     dim3 grid((Lout + 4 * pw - 1) / (4 * pw), N);
