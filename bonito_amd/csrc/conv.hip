@@ -82,7 +82,10 @@ struct ConvArgs {
     long os_n, os_t;
 };
 
-template <int NTT>  // position tiles (of 16) per wave
+// FS (round 4, layers with a multiple of 64 output channels): the four waves split the FEATURE tiles and each covers all 4 * NTT
+// position tiles of the workgroup, instead of splitting the positions and each walking all feature tiles: a weight fragment is then
+// fetched once per workgroup (not once per wave) and feeds 4 * NTT MFMAs instead of NTT. Same accumulation order per output.
+template <int NTT, bool FS = false>  // position tiles (of 16) per wave and feature tile
 __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     half_t* xin = (half_t*)smem;
@@ -109,20 +112,37 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
 
     const int nks = p.Kp >> 5;
     const int nft = (p.Cout + 15) >> 4;
-    int boff[NTT];
+    constexpr int NT = FS ? 4 * NTT : NTT;           // position tiles this wave covers
+    const int pbase = FS ? 0 : wave * PW;
+    int boff[NT];
 #pragma unroll
-    for (int tt = 0; tt < NTT; ++tt)
-        boff[tt] = (wave * PW + tt * 16 + r) * p.stride * p.Cin + kg * 8;
+    for (int tt = 0; tt < NT; ++tt)
+        boff[tt] = (pbase + tt * 16 + r) * p.stride * p.Cin + kg * 8;
 
-    for (int ft = 0; ft < nft; ++ft) {
-        float4_t acc[NTT];
+    for (int ft = FS ? wave : 0; ft < nft; ft += FS ? 4 : 1) {
+        float4_t acc[NT];
 #pragma unroll
-        for (int tt = 0; tt < NTT; ++tt) acc[tt] = float4_t{0.f, 0.f, 0.f, 0.f};
+        for (int tt = 0; tt < NT; ++tt) acc[tt] = float4_t{0.f, 0.f, 0.f, 0.f};
         const half_t* wrow = p.wpk + (long)(ft * 16 + r) * p.Kp + kg * 8;
-        for (int ks = 0; ks < nks; ++ks) {
+        // four k-steps per trip: their weight fragments (global, L2-resident) are requested together, so a trip waits for one round
+        // trip instead of four (one k-step per trip left 1-2 MFMAs per exposed load at 16 / 32 positions per wave)
+        int ks = 0;
+        for (; ks + 4 <= nks; ks += 4) {
+            half8_t a[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) a[u] = *(const half8_t*)(wrow + (ks + u) * 32);
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int tt = 0; tt < NT; ++tt) {
+                    half8_t b = *(const half8_t*)(xin + boff[tt] + (ks + u) * 32);
+                    acc[tt] = mfma16(a[u], b, acc[tt]);
+                }
+        }
+        for (; ks < nks; ++ks) {
             half8_t a = *(const half8_t*)(wrow + ks * 32);
 #pragma unroll
-            for (int tt = 0; tt < NTT; ++tt) {
+            for (int tt = 0; tt < NT; ++tt) {
                 half8_t b = *(const half8_t*)(xin + boff[tt] + ks * 32);
                 acc[tt] = mfma16(a, b, acc[tt]);
             }
@@ -133,8 +153,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) bv[g] = (p.bias && f + g < p.Cout) ? p.bias[f + g] : 0.0f;
 #pragma unroll
-            for (int tt = 0; tt < NTT; ++tt) {
-                int t = t0 + wave * PW + tt * 16 + r;
+            for (int tt = 0; tt < NT; ++tt) {
+                int t = t0 + pbase + tt * 16 + r;
                 if (t >= p.Lout) continue;
                 half4_t o;
 #pragma unroll
@@ -269,13 +289,15 @@ int bh_k_conv_first(const void* signal, const float* w, const float* bias, void*
 }
 
 int g_conv_ws = 1;      // bh_set_option("conv_ws", 0): always the generic implicit-GEMM kernel (A/B, regression tests)
-int g_conv_lds_kb = 80; // bh_set_option("conv_lds_kb", v): LDS a workgroup of conv_igemm_kernel may take for its input span; the positions per
-                        // workgroup follow, and with them how often the layer's weights are re-read from L2. 80 KiB = two workgroups per CU:
-                        // the 128-channel convolutions of the v5 sup model get 128 positions per workgroup instead of 64 (64 KiB, the
-                        // round-1 value): conv class 3.85 -> 3.25 ms per 256 x 12000 batch; 104 KiB: 3.68, 150 KiB (one workgroup per CU): 4.28
+int g_conv_fs = 1;      // bh_set_option("conv_fs", 0): never the feature-split instance of conv_igemm_kernel (A/B, tests)
+int g_conv_lds_kb = 64; // bh_set_option("conv_lds_kb", v): LDS a workgroup of conv_igemm_kernel may take for its input span; the positions per
+                        // workgroup follow. Measured on the v5 sup model (256 x 12000, conv class per batch): position-split instances
+                        // 3.85 ms at 64 KiB, 3.25 at 80, 3.68 at 104, 4.28 at 150 (one workgroup per CU); with four k-steps of weight
+                        // fragments per trip 2.99 at 80; feature-split instances (FS) 2.4-2.6 anywhere from 24 to 64 KiB, 2.69 at 80
 int bh_k_conv_set_option(const char* name, int value) {
     if (name && !strcmp(name, "conv_ws")) { g_conv_ws = value; return 0; }
-    if (name && !strcmp(name, "conv_lds_kb")) { g_conv_lds_kb = value > 0 ? value : 80; return 0; }
+    if (name && !strcmp(name, "conv_fs")) { g_conv_fs = value; return 0; }
+    if (name && !strcmp(name, "conv_lds_kb")) { g_conv_lds_kb = value > 0 ? value : 64; return 0; }
     return 1;
 }
 
@@ -306,7 +328,17 @@ int bh_k_conv_igemm(const void* in, const void* wpk, const float* bias, void* ou
                          : pw == 32 ? (const void*)conv_igemm_kernel<2> : (const void*)conv_igemm_kernel<1>;
         BH_CHECK_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     }
-    if (pw == 64) hipLaunchKernelGGL(conv_igemm_kernel<4>, grid, dim3(256), lds, stream, a);
+    const bool fs = g_conv_fs && Cout % 64 == 0;
+    if (fs) {
+        if (lds > 64 * 1024) {
+            const void* fn = pw == 64 ? (const void*)conv_igemm_kernel<4, true>
+                             : pw == 32 ? (const void*)conv_igemm_kernel<2, true> : (const void*)conv_igemm_kernel<1, true>;
+            BH_CHECK_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        }
+        if (pw == 64) hipLaunchKernelGGL((conv_igemm_kernel<4, true>), grid, dim3(256), lds, stream, a);
+        else if (pw == 32) hipLaunchKernelGGL((conv_igemm_kernel<2, true>), grid, dim3(256), lds, stream, a);
+        else hipLaunchKernelGGL((conv_igemm_kernel<1, true>), grid, dim3(256), lds, stream, a);
+    } else if (pw == 64) hipLaunchKernelGGL(conv_igemm_kernel<4>, grid, dim3(256), lds, stream, a);
     else if (pw == 32) hipLaunchKernelGGL(conv_igemm_kernel<2>, grid, dim3(256), lds, stream, a);
     else hipLaunchKernelGGL(conv_igemm_kernel<1>, grid, dim3(256), lds, stream, a);
     BH_CHECK_HIP(hipGetLastError());

@@ -178,6 +178,38 @@ def test_conv_weight_stationary_kernel_equals_generic(tnc, Cout):
     assert outs[0].float().abs().max().item() > 0.1
 
 
+@pytest.mark.parametrize("Cin,Cout,K,stride,L", [(64, 64, 5, 1, 1300), (64, 128, 9, 3, 2000), (128, 128, 9, 2, 1111), (128, 512, 5, 2, 900)])
+def test_conv_feature_split_instances_equal_position_split(Cin, Cout, K, stride, L):
+    """The convolutions of the v5 transformer models (multiples of 64 output channels): conv_igemm_kernel's feature-split instances
+    (four waves = four feature tiles, each covering all positions of the workgroup; default) and the position-split ones
+    ("conv_fs" 0) accumulate every output in the same order -> identical bytes, for every LDS budget (positions per workgroup 64,
+    128, 256) and a ragged last block."""
+    from bonito_amd import decode
+    g = torch.Generator().manual_seed(Cin + Cout + K)
+    N = 3
+    x = (torch.randn(N, L, Cin, generator=g) * 0.7).half().to(dev())
+    w = (torch.randn(Cout, Cin, K, generator=g) * (1.0 / (Cin * K) ** 0.5)).half().float()
+    wpk, bd = _pack_conv(w), (torch.randn(Cout, generator=g) * 0.1).to(dev())
+    Lout = (L + 2 * (K // 2) - K) // stride + 1
+    outs = []
+    try:
+        for fs, kb in ((1, 64), (0, 64), (1, 150), (1, 24)):
+            decode.set_option("conv_fs", fs)
+            decode.set_option("conv_lds_kb", kb)
+            out = torch.zeros(N * Lout * Cout, dtype=torch.float16, device=dev())
+            _lib.check(_lib.lib().bh_conv1d(_lib.ptr(x), _lib.ptr(wpk), _lib.ptr(bd), _lib.ptr(out), N, L, Cin, Cout, K, stride,
+                                            K // 2, 1, -0.5, 3.5, Lout * Cout, Cout, _lib.stream_ptr()), "conv1d")
+            torch.cuda.synchronize()
+            outs.append(out.cpu())
+    finally:
+        decode.set_option("conv_fs", 1)
+        decode.set_option("conv_lds_kb", 0)
+    assert all(torch.equal(outs[0], o) for o in outs[1:])
+    z = F.conv1d(x.cpu().float().permute(0, 2, 1), w, bd.cpu(), stride=stride, padding=K // 2)
+    want = (z * torch.sigmoid(z)).clamp(-0.5, 3.5).permute(0, 2, 1).reshape(-1)
+    assert (outs[0].float() - want).abs().max().item() < 1.5e-2
+
+
 def _lstm_ref(G, Whh, reverse):
     T, N, H4 = G.shape
     H = H4 // 4
