@@ -127,7 +127,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
         // four k-steps per trip: their weight fragments (global, L2-resident) are requested together, so a trip waits for one round
         // trip instead of four (one k-step per trip left 1-2 MFMAs per exposed load at 16 / 32 positions per wave)
         int ks = 0;
-        for (; ks + 4 <= nks; ks += 4) {
+        for (; FS && ks + 4 <= nks; ks += 4) {       // (FS instances only: the 16-channel layers of the LSTM models have 3 k-steps and measured 5-10 % slower with this loop in front of theirs)
             half8_t a[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) a[u] = *(const half8_t*)(wrow + (ks + u) * 32);
