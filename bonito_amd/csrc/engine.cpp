@@ -687,6 +687,34 @@ extern "C" int bh_encoder_output_shape(const bh_encoder_t* enc, int L, int* T, i
 }
 
 namespace {
+// Do the convolutions at layers i (raw signal in), j1, j2 form the front end conv_front3_kernel serves (conv.hip)? Clamp layers in
+// between are folded into the convolutions (fused_clamp) and skipped.
+static bool conv_front3_at(const bh_encoder* e, size_t i, size_t* j1, size_t* j2) {
+    const size_t nl = e->layers.size();
+    size_t idx[2];
+    int found = 0;
+    for (size_t j = i + 1; j < nl && found < 2; ++j) {
+        if (e->layers[j].d.kind == BH_LAYER_CLAMP) continue;
+        if (e->layers[j].d.kind != BH_LAYER_CONV) return false;
+        idx[found++] = j;
+    }
+    if (found < 2) return false;
+    const Layer &a = e->layers[i], &b = e->layers[idx[0]], &c = e->layers[idx[1]];
+    if (a.d.in_size != 1 || a.pointwise || b.pointwise || c.pointwise || b.d.add_residual || c.d.add_residual) return false;
+    // the layer behind conv3 must be the recurrent stack (time-major store), as for conv_ws_kernel's use today
+    int next_kind = 0;
+    for (size_t j = idx[1] + 1; j < nl; ++j)
+        if (e->layers[j].d.kind != BH_LAYER_CLAMP) { next_kind = e->layers[j].d.kind; break; }
+    if (next_kind != BH_LAYER_LSTM) return false;
+    if (!bh_k_conv_front3_ok(a.cout_eff, a.d.winlen, a.d.stride, b.cin_eff, b.cout_eff, b.d.winlen, b.d.stride, c.cin_eff, c.cout_eff,
+                             c.d.winlen, c.d.stride))
+        return false;
+    if (a.d.out_size != b.d.in_size || b.d.out_size != c.d.in_size || c.cout_eff != c.d.out_size) return false;
+    *j1 = idx[0];
+    *j2 = idx[1];
+    return true;
+}
+
 // which recurrence kernel serves a layer (see lstm.hip)
 struct LstmPath { bool reg_path, wide, fused, wg, cta, q8, wgx, widex; };
 static LstmPath lstm_path(const bh_encoder* e, const Layer& l) {
@@ -714,10 +742,14 @@ extern "C" int bh_encoder_describe(const bh_encoder_t* e, char* buf, size_t n) {
     for (const auto& l : e->layers) {
         const bh_layer_t& d = l.d;
         switch (d.kind) {
-            case BH_LAYER_CONV:
+            case BH_LAYER_CONV: {
+                size_t fj1 = 0, fj2 = 0;
+                const bool front = d.in_size == 1 && conv_front3_at(e, (size_t)li, &fj1, &fj2);
                 snprintf(line, sizeof(line), "%d conv %d->%d k%d s%d: %s\n", li, d.in_size, d.out_size, d.winlen, d.stride,
-                         l.pointwise ? "gemm (pointwise)" : d.in_size == 1 ? "conv_first_kernel" : "conv_igemm_kernel / conv_ws_kernel");
+                         l.pointwise ? "gemm (pointwise)" : front ? "conv_front3_kernel (this and the next two convolutions in one kernel)"
+                         : d.in_size == 1 ? "conv_first_kernel" : "conv_igemm_kernel / conv_ws_kernel");
                 break;
+            }
             case BH_LAYER_LSTM: {
                 const LstmPath p = lstm_path(e, l);
                 const int H = d.out_size, U = bh_k_lstm_wg_units(H);
@@ -823,6 +855,29 @@ extern "C" int bh_encoder_forward(bh_encoder_t* e, const void* signal, int N, in
             case BH_LAYER_CONV: {
                 BH_REQUIRE(lay == L_SIGNAL || lay == L_NLC, "encoder_forward: convolution after a time-major layer");
                 BH_REQUIRE(C == d.in_size, "encoder_forward: layer %zu expects %d channels, got %d", i, d.in_size, C);
+                size_t fj1 = 0, fj2 = 0;
+                if (lay == L_SIGNAL && conv_front3_at(e, i, &fj1, &fj2)) {
+                    // conv1 -> conv2 -> conv3 in one kernel, the 16-channel intermediates stay in LDS (conv_front3_kernel)
+                    const Layer &l2 = e->layers[fj1], &l3 = e->layers[fj2];
+                    const int len1 = conv_out_len(len, d.winlen, d.stride, d.padding);
+                    const int len2 = conv_out_len(len1, l2.d.winlen, l2.d.stride, l2.d.padding);
+                    const int len3 = conv_out_len(len2, l3.d.winlen, l3.d.stride, l3.d.padding);
+                    BH_REQUIRE(len1 > 0 && len2 > 0 && len3 > 0, "encoder_forward: chunk too short for the convolution stack");
+                    void* dst3 = e->act[which].p;
+                    int rc3 = prefill_next(fj2, which, (size_t)len3 * Np);
+                    if (rc3) return rc3;
+                    ProfSpan span(e, st, BH_PROF_CONV);
+                    auto lo_of = [](const Layer& x) { return x.fused_clamp ? x.clamp_lo : -INFINITY; };
+                    auto hi_of = [](const Layer& x) { return x.fused_clamp ? x.clamp_hi : INFINITY; };
+                    rc3 = bh_k_conv_front3(cur, Np, len, (const float*)l.w0.p, (const float*)l.b0.p, d.winlen, d.padding, d.activation, lo_of(l),
+                                           hi_of(l), l2.w0.p, (const float*)l2.b0.p, l2.d.winlen, l2.d.padding, l2.d.activation, lo_of(l2),
+                                           hi_of(l2), l3.w0.p, (const float*)l3.b0.p, l3.cout_eff, l3.d.winlen, l3.d.stride, l3.d.padding,
+                                           l3.d.activation, lo_of(l3), hi_of(l3), dst3, (long)l3.cout_eff, (long)Np * l3.cout_eff, st);
+                    if (rc3) return rc3;
+                    cur = dst3; which = (which + 1) % e->n_act; len = len3; C = l3.d.out_size; lay = L_TNC;
+                    i = fj2;                        // (the two convolutions and the clamps between them are done)
+                    break;
+                }
                 const int lout = conv_out_len(len, d.winlen, d.stride, d.padding);
                 void* dst = e->act[which].p;
                 const bool tnc = next_kind == BH_LAYER_LSTM;

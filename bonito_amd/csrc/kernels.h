@@ -76,7 +76,13 @@ size_t bh_k_posterior_viterbi_workspace(int N, int T, int state_len);
 int bh_k_posterior_viterbi(const void* scores, int N, int T, int state_len, float blank, void* workspace, int8_t* moves,
                            int8_t* path, hipStream_t stream);
 int bh_k_decode_set_option(const char* name, int value);
-int bh_k_conv_set_option(const char* name, int value);     // "conv_ws"
+int bh_k_conv_set_option(const char* name, int value);     // "conv_ws", "conv_fs", "conv_lds_kb", "conv_fuse"
+// conv1 -> conv2 -> conv3 of an LSTM model's front end in one kernel (conv_front3_kernel); _ok: does the shape qualify?
+int bh_k_conv_front3_ok(int c1_eff, int K1, int s1, int c2_in_eff, int c2_eff, int K2, int s2, int c3_in_eff, int c3_out, int K3, int s3);
+int bh_k_conv_front3(const void* signal, int N, int L0, const float* w1, const float* b1, int K1, int pad1, int act1, float lo1, float hi1,
+                     const void* w2pk, const float* b2, int K2, int pad2, int act2, float lo2, float hi2, const void* w3pk,
+                     const float* b3, int Cout3, int K3, int stride3, int pad3, int act3, float lo3, float hi3, void* out, long os_n,
+                     long os_t, hipStream_t stream);
 int bh_k_linear_qkv_rotary(const void* X, const void* W, const float* bias, void* out, int M, int D, int K, const float* cos_sin,
                            int T, float qscale, hipStream_t stream);
 int bh_k_attention_prerotated(const void* qkv, void* out, int N, int T, int nhead, int head_dim, int win_left, int win_right,

@@ -420,6 +420,28 @@ def test_paired_rings_very_short_chunks(L):
     assert "wgx2" in layout and one.shape[1] == (L - 1) // 6 + 1 and torch.equal(one, two)
 
 
+@pytest.mark.parametrize("kind,N,L", [("hac", 37, 3000), ("hac", 16, 1531), ("fast", 21, 2400), ("hac", 5, 9996), ("fast", 3, 500)])
+def test_fused_conv_front_end_equals_three_kernels(kind, N, L):
+    """conv1 -> conv2 -> conv3 of the LSTM models as ONE kernel (`conv_front3_kernel`, the 16-channel intermediates stay in LDS;
+    default) against the three separate kernels ("conv_fuse" 0): every output is computed by the same operations in the same order,
+    positions outside a layer's output are the zeros of the next layer's padding -> identical bytes at the END of the encoder (any
+    difference in the convolutions would pass through five recurrent layers), for chunk lengths that end inside a workgroup's span,
+    odd batches, a chunk shorter than one workgroup's span, and the 96-wide stack."""
+    from bonito_amd import decode, synthetic
+    model = synthetic.make_model(kind, batchsize=N, chunksize=L)
+    x = torch.randn(N, 1, L, generator=torch.Generator().manual_seed(N + L)).half().cuda()
+    try:
+        decode.set_option("conv_fuse", 0)
+        three, layout3 = _encode(model.encoder, x)
+        decode.set_option("conv_fuse", 2)            # 2: also for the 96-channel stack (default 1 fuses the 384-channel one only)
+        one, layout1 = _encode(model.encoder, x)
+    finally:
+        decode.set_option("conv_fuse", 1)
+    assert "conv_front3_kernel" in layout1 and "conv_front3_kernel" not in layout3
+    assert torch.equal(one, three)
+    assert torch.isfinite(one.float()).all() and one.float().abs().max().item() > 0.1
+
+
 @pytest.mark.parametrize("H,N,L,tune", [(1024, 512, 600, 0), (1024, 288, 300, 0), (768, 544, 300, 0), (1024, 512, 300, 32), (1024, 512, 12, 0)])
 def test_wide_layers_calls_of_several_launches(H, N, L, tune):
     """Wide layers (H = 768 / 1024), calls of more than the 8 rings of 32 chunks that one launch of `lstm_layer_wide_kernel` holds: 16
