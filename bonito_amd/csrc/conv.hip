@@ -360,7 +360,7 @@ __global__ __launch_bounds__(64 * WAVES) void conv_front3_kernel(ConvFront3Args 
                 const int u = p3_start + q0 - q.pad2 + i;
                 const float* x = sl + (q0 + i);
                 const float x0 = x[0], x1 = x[1], x2 = x[2], x3 = x[3], x4 = x[4];
-                half8_t o;
+                float av[8];
 #pragma unroll
                 for (int c = 0; c < 8; ++c) {
                     float a = w1b[c];
@@ -369,10 +369,19 @@ __global__ __launch_bounds__(64 * WAVES) void conv_front3_kernel(ConvFront3Args 
                     a = fmaf(w1r[c][2], x2, a);
                     a = fmaf(w1r[c][3], x3, a);
                     a = fmaf(w1r[c][4], x4, a);
-                    a = apply_act_rt(a, q.act1);
-                    const half_t hv = (half_t)fminf(fmaxf(a, q.lo1), q.hi1);
-                    o[c] = (u >= 0 && u < q.L1) ? hv : (half_t)0.0f;
+                    av[c] = a;
                 }
+                if (q.act1 == ACT_SWISH) {                  // (the switch of apply_act_rt once per item instead of once per channel)
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) av[c] = swishf_(av[c]);
+                } else {
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) av[c] = apply_act_rt(av[c], q.act1);
+                }
+                const bool inside = u >= 0 && u < q.L1;
+                half8_t o;
+#pragma unroll
+                for (int c = 0; c < 8; ++c) o[c] = inside ? (half_t)fminf(fmaxf(av[c], q.lo1), q.hi1) : (half_t)0.0f;
                 *(half8_t*)(a1 + i * C16 + c0t) = o;
             }
         } else
@@ -402,13 +411,20 @@ __global__ __launch_bounds__(64 * WAVES) void conv_front3_kernel(ConvFront3Args 
             for (int ks = 0; ks < 3; ++ks) acc = mfma16(a2[ks], *(const half8_t*)(xrow + ks * 32), acc);
             const int j = q0 + pt * 16 + r;                           // span row = conv2 position p3_start + j
             const int v = p3_start + j;
+            float xv[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) xv[g] = acc[g] + b2v[g];
+            if (q.act2 == ACT_SWISH) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) xv[g] = swishf_(xv[g]);
+            } else {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) xv[g] = apply_act_rt(xv[g], q.act2);
+            }
+            const bool inside = v >= 0 && v < q.L2;                                  // outside conv2's output: conv3's zero padding
             half4_t o;
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                float x = apply_act_rt(acc[g] + b2v[g], q.act2);
-                x = fminf(fmaxf(x, q.lo2), q.hi2);
-                o[g] = (v >= 0 && v < q.L2) ? (half_t)x : (half_t)0.0f;               // outside conv2's output: conv3's zero padding
-            }
+            for (int g = 0; g < 4; ++g) o[g] = inside ? (half_t)fminf(fmaxf(xv[g], q.lo2), q.hi2) : (half_t)0.0f;
             if (j < span_pos) *(half4_t*)(xin + j * C16 + kg * 4) = o;
         }
         __syncthreads();
