@@ -60,6 +60,24 @@ __global__ __launch_bounds__(256) void conv_first_kernel(ConvFirstArgs p) {
     };
     int c0 = 0;
     if (p.vec8) {   // Cout and both output strides are multiples of 8: 16-byte packed stores
+        if (p.K == 5 && p.act == ACT_SWISH) {       // every bonito model: taps unrolled, the activation switch outside the channel loop
+            const float x0 = x[0], x1 = x[1], x2 = x[2], x3 = x[3], x4 = x[4];
+            for (; c0 + 8 <= p.Cout; c0 += 8) {
+                half8_t o;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float* wr = wl + (c0 + j) * 5;
+                    float a = bl[c0 + j];
+                    a = fmaf(wr[0], x0, a);
+                    a = fmaf(wr[1], x1, a);
+                    a = fmaf(wr[2], x2, a);
+                    a = fmaf(wr[3], x3, a);
+                    a = fmaf(wr[4], x4, a);
+                    o[j] = (half_t)fminf(fmaxf(swishf_(a), p.clamp_lo), p.clamp_hi);
+                }
+                *(half8_t*)(dst + c0) = o;
+            }
+        }
         for (; c0 + 8 <= p.Cout; c0 += 8) {
             half8_t o;
 #pragma unroll
@@ -156,13 +174,19 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
             for (int tt = 0; tt < NT; ++tt) {
                 int t = t0 + pbase + tt * 16 + r;
                 if (t >= p.Lout) continue;
+                float xv[4];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) xv[g] = acc[tt][g] + bv[g];
+                if (p.act == ACT_SWISH) {                   // (the activation switch once per four outputs, not once per output)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) xv[g] = swishf_(xv[g]);
+                } else {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) xv[g] = apply_act_rt(xv[g], p.act);
+                }
                 half4_t o;
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    float x = apply_act_rt(acc[tt][g] + bv[g], p.act);
-                    x = fminf(fmaxf(x, p.clamp_lo), p.clamp_hi);
-                    o[g] = (half_t)x;
-                }
+                for (int g = 0; g < 4; ++g) o[g] = (half_t)fminf(fmaxf(xv[g], p.clamp_lo), p.clamp_hi);
                 half_t* dst = p.out + (long)n * p.os_n + (long)t * p.os_t + f;
                 if (f + 4 <= p.Cout) *(half4_t*)dst = o;
                 else
