@@ -196,7 +196,8 @@ int bh_lstm_q8_layer(const void* x, float bound, const float* w_ih, const float*
                      int reverse, int variant, void* h16_out, int8_t* hq_frag, int32_t* sums, void* stream);
 
 /* Process-wide knobs (measurement / tuning hooks, no reference counterpart).
- *   "beam_fork": -1 auto (default), 0 = run the posterior scan behind the beam kernel on the caller's stream,
+ *   "beam_fork": -1 auto (default: where the scan is a kernel of its own - up to 64 states, and 1024 states, where the beam kernel
+ *                is one wave per chunk), 0 = run the posterior scan behind the beam kernel on the caller's stream,
  *                1 = run it next to the beam kernel on an internal helper stream (joined before finalize).
  *   "beam_fuse": -1 (default) = auto: fused for <= 256 states; 1 = the forward / posterior scan runs as a second wave inside the beam kernel's workgroups and reads
  *                the score and guide rows from the blocks the beam wave stages in LDS (the score tensor is read from HBM once
@@ -207,7 +208,12 @@ int bh_lstm_q8_layer(const void* x, float bound, const float* w_ih, const float*
  *   "beam_select": 0 (default) = top-W selection by histogram + exact boundary ranking, 1 = MSB-first radix search
  *                (the same beams either way; kept for regression tests and A/B timing).
  *   "conv_ws": 1 (default) = weight-stationary kernel for the 384-channel / 19-tap convolution, 0 = generic implicit GEMM.
- *   "gemm_path": 0 auto (default), 1 = register-staged 128x128x64 kernel only, 2 = never the persistent 256x256x64 kernel.
+ *   "conv_fuse": 1 (default) = conv1 -> conv2 -> conv3 of a 384-channel LSTM stack as one kernel (intermediates in LDS), 2 = also
+ *                for the 96-channel stacks, 0 = three kernels. "conv_fs": 1 (default) = feature-split instances of the implicit-GEMM
+ *                kernel for layers with a multiple of 64 output channels, 0 = position-split. "conv_lds_kb": LDS a workgroup of that
+ *                kernel may take for its input span (default 64). All of them: identical bytes (tests).
+ *   "gemm_path": 0 auto (default), 1 = register-staged 128x128x64 kernel only, 2 = never a 256x256x64 kernel, 3 = never the
+ *                four-wave kernel (gemm_w4_kernel; the eight-wave one where it applies), 5 = the four-wave kernel for every legal shape.
  *   "lstm_q8_variant": geometry of the 8-bit recurrent kernel chosen at bh_encoder_create: 0 (default) = 12 / 16 units per wave,
  *                one workgroup per CU; 1 = 4 units per wave, three workgroups per CU; 2 = 12 units per wave compiled for two
  *                workgroups per CU, so that the recurrent kernels of two engines (two batches in flight) share every CU and each
