@@ -52,6 +52,7 @@ SIGNATURES = {
     "bh_encoder_error_flag": (_i, [_vp]),
     "bh_encoder_last_ticket": (_l, [_vp]),
     "bh_encoder_error_flag_at": (_i, [_vp, _l]),
+    "bh_encoder_ack": (_i, [_vp, _l]),
     "bh_encoder_describe": (_i, [_vp, C.c_char_p, _sz]),
     "bh_encoder_profile": (_i, [_vp, _i]),
     "bh_encoder_profile_read": (_i, [_vp, C.POINTER(C.c_float), C.POINTER(_i)]),

@@ -216,6 +216,7 @@ class _Pipeline:
             if dev_batch is None:
                 raise
             planes = self._retry_serially(dev_batch, lane)
+            self.engine(lane).ack(ticket)        # repaired: the engine-wide flag (poll / check) must not report this forward later
         if self.mode == "viterbi":
             path = planes[1]                 # plane 1 carries the path for the Viterbi decoder
             planes[0] = hip_decode.path_to_sequence(path)

@@ -419,8 +419,7 @@ int bh_k_attention(const void* qkv, void* out, const float* cos_sin, int N, int 
     do {                                                                                              \
         const size_t lds = (size_t)(7 * 16 + NT * 16) * 128 + (size_t)64 * (7 * 16 + NT * 16 + 4) * 2; \
         if (lds > 64 * 1024)                                                                          \
-            BH_CHECK_HIP(hipFuncSetAttribute((const void*)attention_kernel<NT>,                       \
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+            BH_CHECK_HIP(bh_max_lds((const void*)attention_kernel<NT>, (int)lds)); \
         hipLaunchKernelGGL(attention_kernel<NT>, grid, dim3(512), lds, stream, a);                    \
     } while (0)
     if (need <= 6) BH_ATTN(6);
@@ -443,7 +442,7 @@ int bh_k_attention_prerotated(const void* qkv, void* out, int N, int T, int nhea
     BH_REQUIRE(N > 0 && T > 0 && nhead > 0, "attention: empty problem");
     AttnRingArgs a{(const half_t*)qkv, (half_t*)out, N, T, nhead, win_left, win_right};
     const size_t lds = (size_t)RING * 128 + (size_t)64 * RVS * 2;
-    BH_CHECK_HIP(hipFuncSetAttribute((const void*)attention_ring_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    BH_CHECK_HIP(bh_max_lds((const void*)attention_ring_kernel, (int)lds));
     hipLaunchKernelGGL(attention_ring_kernel, dim3(nhead, N), dim3(512), lds, stream, a);
     BH_CHECK_HIP(hipGetLastError());
     return 0;

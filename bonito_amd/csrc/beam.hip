@@ -1243,7 +1243,7 @@ int bh_k_crf_logz(const void* scores, int N, int T, int state_len, float blank, 
         int b_threads = 0;
         size_t b_lds = 0;
         backward_geometry(S, N, sa.cpb, b_threads, b_lds);
-        if (b_lds > 64 * 1024) BH_CHECK_HIP(hipFuncSetAttribute((const void*)crf_backward_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b_lds));
+        if (b_lds > 64 * 1024) BH_CHECK_HIP(bh_max_lds((const void*)crf_backward_kernel, (int)b_lds));
         hipLaunchKernelGGL(crf_backward_kernel, dim3((N + sa.cpb - 1) / sa.cpb), dim3(b_threads), b_lds, stream, sa);
         sa.cpb = 1;
     }
@@ -1276,7 +1276,7 @@ int bh_k_posterior_viterbi(const void* scores, int N, int T, int state_len, floa
         int b_threads = 0;
         size_t b_lds = 0;
         backward_geometry(S, N, sa.cpb, b_threads, b_lds);
-        if (b_lds > 64 * 1024) BH_CHECK_HIP(hipFuncSetAttribute((const void*)crf_backward_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b_lds));
+        if (b_lds > 64 * 1024) BH_CHECK_HIP(bh_max_lds((const void*)crf_backward_kernel, (int)b_lds));
         hipLaunchKernelGGL(crf_backward_kernel, dim3((N + sa.cpb - 1) / sa.cpb), dim3(b_threads), b_lds, stream, sa);
         sa.cpb = 1;
     }
@@ -1358,7 +1358,7 @@ int bh_k_beam_search(const void* scores, int N, int T, int state_len, int beam_w
         int b_threads = 0;
         size_t b_lds = 0;
         backward_geometry(S, N, sa.cpb, b_threads, b_lds);
-        if (b_lds > 64 * 1024) BH_CHECK_HIP(hipFuncSetAttribute((const void*)crf_backward_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b_lds));
+        if (b_lds > 64 * 1024) BH_CHECK_HIP(bh_max_lds((const void*)crf_backward_kernel, (int)b_lds));
         hipLaunchKernelGGL(crf_backward_kernel, dim3((N + sa.cpb - 1) / sa.cpb), dim3(b_threads), b_lds, stream, sa);
         sa.cpb = 1;
     }
@@ -1388,7 +1388,7 @@ int bh_k_beam_search(const void* scores, int N, int T, int state_len, int beam_w
     auto launch_beam = [&](auto kern, int cpw, size_t wave_lds, size_t scan_lds = 0) -> int {
         const size_t lds_beam = (size_t)BEAM_TAB_LDS + cpw * (wave_lds + scan_lds);
         if (lds_beam > 64 * 1024)
-            BH_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_beam));
+            BH_CHECK_HIP(bh_max_lds((const void*)kern, (int)lds_beam));
         hipLaunchKernelGGL(kern, dim3((N + cpw - 1) / cpw), dim3(64 * cpw * (ckpt ? 3 : scan_lds ? 2 : 1)), lds_beam, stream, ba);
         return 0;
     };

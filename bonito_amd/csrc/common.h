@@ -66,6 +66,11 @@ __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 
 // Host-side error plumbing for the C ABI (thread-local message, int status).
 void bh_set_error(const char* fmt, ...);
+// hipFuncSetAttribute(fn, MaxDynamicSharedMemorySize, bytes), issued only when (fn, current device) has not been raised to `bytes` yet
+// (it used to run in front of every launch of the large-LDS kernels: host overhead on the hot path; engine.cpp)
+hipError_t bh_max_lds(const void* fn, int bytes);
+// compute units of the current device, cached per device (256 when the query fails)
+int bh_cu_count();
 #define BH_CHECK_HIP(expr)                                                              \
     do {                                                                                \
         hipError_t _e = (expr);                                                         \

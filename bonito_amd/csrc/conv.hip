@@ -577,14 +577,14 @@ int bh_k_conv_igemm(const void* in, const void* wpk, const float* bias, void* ou
     if (lds > 64 * 1024) {
         const void* fn = pw == 64 ? (const void*)conv_igemm_kernel<4>
                          : pw == 32 ? (const void*)conv_igemm_kernel<2> : (const void*)conv_igemm_kernel<1>;
-        BH_CHECK_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        BH_CHECK_HIP(bh_max_lds(fn, (int)lds));
     }
     const bool fs = g_conv_fs && Cout % 64 == 0;
     if (fs) {
         if (lds > 64 * 1024) {
             const void* fn = pw == 64 ? (const void*)conv_igemm_kernel<4, true>
                              : pw == 32 ? (const void*)conv_igemm_kernel<2, true> : (const void*)conv_igemm_kernel<1, true>;
-            BH_CHECK_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            BH_CHECK_HIP(bh_max_lds(fn, (int)lds));
         }
         if (pw == 64) hipLaunchKernelGGL((conv_igemm_kernel<4, true>), grid, dim3(256), lds, stream, a);
         else if (pw == 32) hipLaunchKernelGGL((conv_igemm_kernel<2, true>), grid, dim3(256), lds, stream, a);
@@ -628,10 +628,10 @@ int bh_k_conv_front3(const void* signal, int N, int L0, const float* w1, const f
     const size_t lds = ((span * 16 + 40 + 7) & ~(size_t)7) * 2 + (size_t)(256 + K2 - 1 + 6) * 16 * 2 + (span + K2 + K1 + 6) * 4 + (size_t)(16 * K1 + 16) * 4;
     const dim3 grid((L3 + 255) / 256, N);
     if (Cout3 == 384) {
-        if (lds > 64 * 1024) BH_CHECK_HIP(hipFuncSetAttribute((const void*)conv_front3_kernel<3, 10, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        if (lds > 64 * 1024) BH_CHECK_HIP(bh_max_lds((const void*)conv_front3_kernel<3, 10, 8>, (int)lds));
         hipLaunchKernelGGL((conv_front3_kernel<3, 10, 8>), grid, dim3(512), lds, stream, a);
     } else {
-        if (lds > 64 * 1024) BH_CHECK_HIP(hipFuncSetAttribute((const void*)conv_front3_kernel<1, 10, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        if (lds > 64 * 1024) BH_CHECK_HIP(bh_max_lds((const void*)conv_front3_kernel<1, 10, 6>, (int)lds));
         hipLaunchKernelGGL((conv_front3_kernel<1, 10, 6>), grid, dim3(384), lds, stream, a);
     }
     BH_CHECK_HIP(hipGetLastError());

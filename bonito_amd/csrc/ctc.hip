@@ -110,7 +110,7 @@ int bh_k_dwconv(const void* in, const float* w, void* out, int N, int Lin, int L
     const size_t lds = (size_t)((DW_T - 1) * stride + K) * DW_C * 2 + (size_t)K * DW_C * 4;
     BH_REQUIRE(lds <= 160 * 1024, "dwconv: kernel %d x stride %d does not fit LDS", K, stride);
     if (lds > 64 * 1024)
-        BH_CHECK_HIP(hipFuncSetAttribute((const void*)dwconv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        BH_CHECK_HIP(bh_max_lds((const void*)dwconv_kernel, (int)lds));
     dim3 grid((Lout + DW_T - 1) / DW_T, (C + DW_C - 1) / DW_C, N);
     hipLaunchKernelGGL(dwconv_kernel, grid, dim3(256), lds, stream, a);
     BH_CHECK_HIP(hipGetLastError());

@@ -14,6 +14,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <string>
 #include <vector>
@@ -168,6 +169,40 @@ static inline int conv_out_len(int L, int K, int stride, int pad) { return (L + 
 
 }  // namespace
 
+// ---- launch helpers shared by the kernel files (declared in common.h) ------------------------------------------------------------------
+#include <mutex>
+#include <unordered_map>
+hipError_t bh_max_lds(const void* fn, int bytes) {
+    static std::mutex mu;
+    static std::unordered_map<unsigned long long, int> raised;       // (function, device) -> bytes granted so far
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    const unsigned long long key = (unsigned long long)(uintptr_t)fn * 64ull + (unsigned)dev % 64u;
+    {
+        std::lock_guard<std::mutex> g(mu);
+        auto it = raised.find(key);
+        if (it != raised.end() && it->second >= bytes) return hipSuccess;
+    }
+    e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e == hipSuccess) {
+        std::lock_guard<std::mutex> g(mu);
+        int& have = raised[key];
+        if (have < bytes) have = bytes;
+    }
+    return e;
+}
+int bh_cu_count() {
+    static std::atomic<int> cached[64];
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    cus = cached[dev].load(std::memory_order_relaxed);
+    if (cus > 0) return cus;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) return 256;
+    cached[dev].store(cus, std::memory_order_relaxed);
+    return cus;
+}
+
 struct bh_encoder {
     int device = 0;
     int max_batch = 0, max_chunk = 0;
@@ -183,9 +218,11 @@ struct bh_encoder {
     // ("has anything timed out since the last check").
     static constexpr int ERR_SLOTS = 64;
     int* err_host = nullptr;     // pinned [ERR_SLOTS] mirror of `err`
-    long ticket = -1;            // number of the most recent forward
-    long checked = -1;           // forwards <= checked have been reported by bh_encoder_check
-    int sticky = 0;              // flags harvested from recycled slots (forwards in (checked, ticket - ERR_SLOTS])
+    // (atomics: bh_encoder_forward runs on the encoder thread of the product pipeline while bh_encoder_error_flag_at / _ack / _error_flag
+    //  run on its decode thread - ctypes releases the GIL; advisor finding, round 4)
+    std::atomic<long> ticket{-1};    // number of the most recent forward
+    std::atomic<long> checked{-1};   // forwards <= checked have been reported by bh_encoder_check
+    std::atomic<int> sticky{0};      // flags harvested from recycled slots (forwards in (checked, ticket - ERR_SLOTS])
     int* cur_err = nullptr;      // device slot of the forward being issued
     int n_act = 2;               // activation buffers in rotation: 3 when recurrent layers pre-fill their exchange sentinel
     // sentinel pre-fill of the NEXT recurrent layer's output buffer, on a side stream under the current layer's kernel
@@ -805,8 +842,8 @@ extern "C" int bh_encoder_forward(bh_encoder_t* e, const void* signal, int N, in
     {
         const long n = ++e->ticket;
         const int slot = (int)(n % bh_encoder::ERR_SLOTS);
-        if (n - bh_encoder::ERR_SLOTS > e->checked) e->sticky |= e->err_host[slot];
-        e->err_host[slot] = 0;
+        if (n - bh_encoder::ERR_SLOTS > e->checked.load()) e->sticky.fetch_or(((volatile int*)e->err_host)[slot]);
+        ((volatile int*)e->err_host)[slot] = 0;
         e->cur_err = (int*)e->err.p + slot;
         BH_CHECK_HIP(hipMemsetAsync(e->cur_err, 0, sizeof(int), st));
     }
@@ -1150,11 +1187,13 @@ extern "C" int bh_encoder_forward(bh_encoder_t* e, const void* signal, int N, in
     return 0;
 }
 
-extern "C" long bh_encoder_last_ticket(const bh_encoder_t* e) { return e ? e->ticket : -1; }
+extern "C" long bh_encoder_last_ticket(const bh_encoder_t* e) { return e ? e->ticket.load() : -1; }
 
 extern "C" int bh_encoder_error_flag_at(const bh_encoder_t* e, long ticket) {
-    if (!e || !e->err_host || ticket < 0 || ticket > e->ticket) return 0;
-    if (e->ticket - ticket >= bh_encoder::ERR_SLOTS) {
+    if (!e || !e->err_host) return 0;
+    const long cur = e->ticket.load();
+    if (ticket < 0 || ticket > cur) return 0;
+    if (cur - ticket >= bh_encoder::ERR_SLOTS) {
         bh_set_error("forward %ld is more than %d forwards old: its timeout flag has been recycled", ticket, bh_encoder::ERR_SLOTS);
         return -1;
     }
@@ -1163,13 +1202,29 @@ extern "C" int bh_encoder_error_flag_at(const bh_encoder_t* e, long ticket) {
     return flag;
 }
 
+// The caller has dealt with the timeout of forward `ticket` (re-ran the batch): drop its flag, so that it is neither harvested into the
+// engine-wide flag when the slot is recycled nor reported by bh_encoder_error_flag / bh_encoder_check (advisor finding, round 4: a
+// successful retry left poll() poisoned for the life of the engine).
+extern "C" int bh_encoder_ack(bh_encoder_t* e, long ticket) {
+    BH_REQUIRE(e && e->err_host, "encoder_ack: null engine");
+    const long cur = e->ticket.load();
+    BH_REQUIRE(ticket >= 0 && ticket <= cur, "encoder_ack: forward %ld has not been issued (last %ld)", ticket, cur);
+    if (cur - ticket >= bh_encoder::ERR_SLOTS) {
+        bh_set_error("forward %ld is more than %d forwards old: its timeout flag has been recycled", ticket, bh_encoder::ERR_SLOTS);
+        return -1;
+    }
+    ((volatile int*)e->err_host)[ticket % bh_encoder::ERR_SLOTS] = 0;
+    return 0;
+}
+
 // flags of the forwards that bh_encoder_check has not reported yet (host side only: completed forwards whose copy has landed)
 static int pending_flags(const bh_encoder_t* e) {
-    int flag = e->sticky;
-    long lo = e->checked + 1;
-    if (lo < e->ticket - bh_encoder::ERR_SLOTS + 1) lo = e->ticket - bh_encoder::ERR_SLOTS + 1;
+    int flag = e->sticky.load();
+    const long cur = e->ticket.load();
+    long lo = e->checked.load() + 1;
+    if (lo < cur - bh_encoder::ERR_SLOTS + 1) lo = cur - bh_encoder::ERR_SLOTS + 1;
     if (lo < 0) lo = 0;
-    for (long n = lo; n <= e->ticket; ++n) flag |= ((volatile const int*)e->err_host)[n % bh_encoder::ERR_SLOTS];
+    for (long n = lo; n <= cur; ++n) flag |= ((volatile const int*)e->err_host)[n % bh_encoder::ERR_SLOTS];
     return flag;
 }
 
@@ -1186,9 +1241,9 @@ extern "C" int bh_encoder_check(bh_encoder_t* e, void* stream_) {
     const int flag = pending_flags(e);
     // reported: forget everything up to the most recent forward. (A forward still in flight on ANOTHER stream than `stream_` is
     // past this check; its flag stays readable through its ticket.)
-    e->sticky = 0;
+    e->sticky.store(0);
     if (flag) bh_set_error("device-side timeout in a persistent kernel (flag=%d)", flag);
-    e->checked = e->ticket;
+    e->checked.store(e->ticket.load());
     return flag;
 }
 

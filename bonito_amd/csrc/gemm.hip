@@ -921,7 +921,7 @@ static int g_stagger = 0;    // bh_k_linear_stagger
 static int g_force_v1 = 0;   // test / A-B hook (bh_k_linear_force_v1): 1 = v1 only, 2 = never v3 / v5, 3 = never v5 (v3 where it applies), 5 = v5 whenever the shape is legal (tests: small problems)
 
 template <int ACT, bool GATED>
-static void launch(const GemmArgs& a, hipStream_t s) {
+static int launch(const GemmArgs& a, hipStream_t s) {
     int grid = a.n_ft * a.n_tt;
     // v5 (gemm_w4_kernel) / v3 when the problem has at least ~2 waves of 256 x 256 tiles over the chip and no K tail
     {
@@ -930,9 +930,7 @@ static void launch(const GemmArgs& a, hipStream_t s) {
             ((a.row_div == 1 && a.row_s_hi == 1) || a.row_div % 256 == 0) && (a.rot_cs == nullptr || a.rot_T >= 256) &&
             (long)a.ldo * 2 * (a.row_div == 1 ? 1 : a.row_s_lo) < (1l << 24) &&
             (long)a.M * a.ldx < (1l << 31) && (long)a.N * a.ldw < (1l << 31)) {
-            int dev = 0, cus = 256;
-            if (hipGetDevice(&dev) != hipSuccess ||
-                hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+            const int cus = bh_cu_count();
             GemmArgs b = a;
             b.n_ft = nf3; b.n_tt = nt3;
             int gf = g_w4_gf > 0 ? g_w4_gf : 4;
@@ -952,7 +950,7 @@ static void launch(const GemmArgs& a, hipStream_t s) {
 // slower than four rows over five - 0.879 against 0.853 ms on the hac CRF head)
 #define W4_LAUNCH(A_, G_, MODE_)                                                                                                    \
     do {                                                                                                                          \
-        (void)hipFuncSetAttribute((const void*)gemm_w4_kernel<A_, G_, 4, MODE_>, hipFuncAttributeMaxDynamicSharedMemorySize, W4_LDS); \
+        BH_CHECK_HIP(bh_max_lds((const void*)gemm_w4_kernel<A_, G_, 4, MODE_>, W4_LDS));                                          \
         hipLaunchKernelGGL((gemm_w4_kernel<A_, G_, 4, MODE_>), dim3(slots < cus ? (int)slots : cus), dim3(256), W4_LDS, s, b);      \
     } while (0)
             if constexpr (GATED) {
@@ -971,29 +969,28 @@ static void launch(const GemmArgs& a, hipStream_t s) {
                 done = false;
             }
 #undef W4_LAUNCH
-            if (done) return;
+            if (done) return 0;
         }
         if (false) {
-            return;
+            return 0;
         }
         if (a.K % BK3 == 0 && (g_force_v1 == 0 || g_force_v1 == 3) && a.N >= 256 && a.N % 16 == 0 && (long)nf3 * nt3 >= 512 &&
             (long)a.M * a.ldx < (1l << 31) && (long)a.N * a.ldw < (1l << 31)) {
-            int dev = 0, cus = 256;
-            if (hipGetDevice(&dev) != hipSuccess ||
-                hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+            const int cus = bh_cu_count();
             GemmArgs b = a;
             b.n_ft = nf3; b.n_tt = nt3;
             b.stagger = g_stagger;
             const int tiles = nf3 * nt3;
-            (void)hipFuncSetAttribute((const void*)gemm_big_kernel<ACT, GATED>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE3);
+            BH_CHECK_HIP(bh_max_lds((const void*)gemm_big_kernel<ACT, GATED>, 4 * TILE3));
             hipLaunchKernelGGL((gemm_big_kernel<ACT, GATED>), dim3(tiles < cus ? tiles : cus), dim3(512), 4 * TILE3, s, b);
-            return;
+            return 0;
         }
     }
     if (a.K % BK2 == 0 && g_force_v1 != 1)
         hipLaunchKernelGGL((gemm_glds_kernel<ACT, GATED>), dim3(grid), dim3(256), 4 * TILE2, s, a);
     else
         hipLaunchKernelGGL((gemm_kernel<ACT, GATED>), dim3(grid), dim3(256), 4 * TILE_BYTES, s, a);
+    return 0;
 }
 
 }  // namespace bh
@@ -1023,14 +1020,16 @@ int bh_k_linear(const void* X, const void* W, const float* bias, void* out, int 
 #ifdef BH_GEMM_STATS
     a.dbg = g_gemm_dbg;
 #endif
-    if (gated) { launch<ACT_NONE, true>(a, stream); }
+    int rc = 0;
+    if (gated) { rc = launch<ACT_NONE, true>(a, stream); }
     else switch (act) {
-        case ACT_NONE: launch<ACT_NONE, false>(a, stream); break;
-        case ACT_SWISH: launch<ACT_SWISH, false>(a, stream); break;
-        case ACT_TANH: launch<ACT_TANH, false>(a, stream); break;
-        case ACT_RELU: launch<ACT_RELU, false>(a, stream); break;
+        case ACT_NONE: rc = launch<ACT_NONE, false>(a, stream); break;
+        case ACT_SWISH: rc = launch<ACT_SWISH, false>(a, stream); break;
+        case ACT_TANH: rc = launch<ACT_TANH, false>(a, stream); break;
+        case ACT_RELU: rc = launch<ACT_RELU, false>(a, stream); break;
         default: BH_REQUIRE(false, "linear: unknown activation %d", act);
     }
+    if (rc) return rc;
     BH_CHECK_HIP(hipGetLastError());
     return 0;
 }
@@ -1050,7 +1049,7 @@ int bh_k_linear_qkv_rotary(const void* X, const void* W, const float* bias, void
     a.row_div = 1; a.row_s_hi = 1; a.row_s_lo = 0; a.row_lim = 0x7fffffff;
     a.n_ft = (a.N + BF - 1) / BF; a.n_tt = (M + BT - 1) / BT;
     a.rot_cs = cos_sin; a.rot_T = T; a.rot_nfeat = 2 * D; a.rot_qfeat = D; a.rot_qscale = qscale;
-    launch<ACT_NONE, false>(a, stream);
+    if (int rc = launch<ACT_NONE, false>(a, stream)) return rc;
     BH_CHECK_HIP(hipGetLastError());
     return 0;
 }

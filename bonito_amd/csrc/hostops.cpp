@@ -202,11 +202,12 @@ extern "C" long bh_host_format_read(const int8_t* const* base, const long* plane
         for (long i = 0, j = n_seq - 1; i < j; ++i, --j) { const char t = seq[i]; seq[i] = seq[j]; seq[j] = t; }
         for (long i = 0, j = n_qs - 1; i < j; ++i, --j) { const char t = qs[i]; qs[i] = qs[j]; qs[j] = t; }
     }
-    // io.format_record's conventions, quirks included (tests fuzz the two against each other): a qstring that is exactly "*" means
-    // "no qualities" (mean 0.0; '!' per base in FASTQ, '*' in SAM); an EMPTY qstring beside a sequence is written as an empty field
-    const bool qs_missing = n_qs == 1 && qs[0] == '*';
-    if (!qs_missing) for (long i = 0; i < n_qs; ++i) ++hist[(unsigned char)qs[i]];
-    const double mq = (n_qs && !qs_missing) ? mean_qscore(hist) : 0.0;
+    // io.format_record's conventions (tests fuzz the two against each other) = the reference's (bonito/io.py:431-433): the mean q-score
+    // is always computed from the q-string - a decoded "*" beside one base is Q9, not a sentinel (this path never sees the sentinel);
+    // an EMPTY q-string beside a sequence means "no qualities": mean 0.0, '!' per base in FASTQ, '*' in SAM
+    const bool no_quals = n_qs == 0;
+    for (long i = 0; i < n_qs; ++i) ++hist[(unsigned char)qs[i]];
+    const double mq = n_qs ? mean_qscore(hist) : 0.0;
     *seq_len = n_seq;
     *mean_q = mq;
     if (mq < min_qscore || n_seq == 0) return 0;
@@ -225,11 +226,11 @@ extern "C" long bh_host_format_read(const int8_t* const* base, const long* plane
     } else if (mode == 0) {
         *p++ = '@'; put(read_id, id_len); *p++ = ' '; tags(); *p++ = '\n';
         put(seq, n_seq); put("\n+\n", 3);
-        if (qs_missing) { memset(p, '!', (size_t)n_seq); p += n_seq; } else put(qs, n_qs);
+        if (no_quals) { memset(p, '!', (size_t)n_seq); p += n_seq; } else put(qs, n_qs);
         *p++ = '\n';
     } else {
         put(read_id, id_len); put("\t4\t*\t0\t0\t*\t*\t0\t0\t", 17); put(seq, n_seq); *p++ = '\t';
-        put(qs, n_qs);
+        if (no_quals) *p++ = '*'; else put(qs, n_qs);
         put("\tNM:i:0\t", 8); tags(); *p++ = '\n';
     }
     return (long)(p - out);

@@ -1768,8 +1768,7 @@ int bh_k_lstm_layer_fused(const void* x, const void* wih_packed, const float* bi
 #define BH_LSTM_CASE(NKS)                                                                                        \
     case NKS:                                                                                                    \
         if (lds > 64 * 1024)                                                                                     \
-            BH_CHECK_HIP(hipFuncSetAttribute((const void*)lstm_layer_fused_kernel<NKS>,                          \
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));            \
+            BH_CHECK_HIP(bh_max_lds((const void*)lstm_layer_fused_kernel<NKS>, (int)lds));            \
         hipLaunchKernelGGL(lstm_layer_fused_kernel<NKS>, dim3(grid), dim3(256), lds, stream, a);                 \
         break;
     switch (H / 32) {
@@ -1824,8 +1823,7 @@ int bh_k_lstm_layer_wgx(const void* x, const void* wih_packed, const float* bias
 #define BH_LSTM_WGX(NKS, MT)                                                                                     \
     if (nks == NKS && U == 4 * MT) {                                                                             \
         if (lds > 64 * 1024)                                                                                     \
-            BH_CHECK_HIP(hipFuncSetAttribute((const void*)lstm_layer_wgx_kernel<NKS, MT>,                        \
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));            \
+            BH_CHECK_HIP(bh_max_lds((const void*)lstm_layer_wgx_kernel<NKS, MT>, (int)lds));            \
         hipLaunchKernelGGL((lstm_layer_wgx_kernel<NKS, MT>), dim3(grid), dim3(256), lds, stream, a);              \
     } else
     BH_LSTM_WGX(3, 3) BH_LSTM_WGX(6, 3) BH_LSTM_WGX(9, 3) BH_LSTM_WGX(12, 3)
@@ -1864,7 +1862,7 @@ int bh_k_lstm_layer_wgx2(const void* x, const void* wih_packed, const float* bia
                   (char*)ex, R};
     const size_t lds = (size_t)8 * nks * 1024 + 4 * 16 * U * 2;
     if (nks == 12 && U == 12 && ((force_slow >> 8) & 4)) {          // lstm_tune bit 2: the instance with section stamps (tools/lstm_stats2.py)
-        BH_CHECK_HIP(hipFuncSetAttribute((const void*)lstm_layer_wgx2_kernel<12, 3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        BH_CHECK_HIP(bh_max_lds((const void*)lstm_layer_wgx2_kernel<12, 3, true>, (int)lds));
         hipLaunchKernelGGL((lstm_layer_wgx2_kernel<12, 3, true>), dim3(grid), dim3(256), lds, stream, a);
         BH_CHECK_HIP(hipGetLastError());
         return 0;
@@ -1872,8 +1870,7 @@ int bh_k_lstm_layer_wgx2(const void* x, const void* wih_packed, const float* bia
 #define BH_LSTM_WGX2(NKS, MT)                                                                                    \
     if (nks == NKS && U == 4 * MT) {                                                                             \
         if (lds > 64 * 1024)                                                                                     \
-            BH_CHECK_HIP(hipFuncSetAttribute((const void*)lstm_layer_wgx2_kernel<NKS, MT>,                       \
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));            \
+            BH_CHECK_HIP(bh_max_lds((const void*)lstm_layer_wgx2_kernel<NKS, MT>, (int)lds));            \
         hipLaunchKernelGGL((lstm_layer_wgx2_kernel<NKS, MT>), dim3(grid), dim3(256), lds, stream, a);             \
     } else
     BH_LSTM_WGX2(3, 3) BH_LSTM_WGX2(6, 3) BH_LSTM_WGX2(9, 3) BH_LSTM_WGX2(12, 3)
@@ -1940,16 +1937,14 @@ int bh_k_lstm_layer_wide(const void* gates_perm, const void* whh_tiles, void* h_
     const size_t lds = (size_t)2 * 2 * nks * 1024 + 4 * 16 * 8 * 2;
 #define BH_LSTM_WIDE(NKS)                                                                                               \
     if (nks == NKS && ex) {                                                                                             \
-        BH_CHECK_HIP(hipFuncSetAttribute((const void*)lstm_layer_wide_kernel<NKS, true>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                         (int)lds));                                                                    \
+        BH_CHECK_HIP(bh_max_lds((const void*)lstm_layer_wide_kernel<NKS, true>, (int)lds));                                                                    \
         hipLaunchKernelGGL((lstm_layer_wide_kernel<NKS, true>), dim3(grid), dim3(256), lds, stream, a);                  \
     } else if (nks == NKS) {                                                                                            \
-        BH_CHECK_HIP(hipFuncSetAttribute((const void*)lstm_layer_wide_kernel<NKS, false>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                         (int)lds));                                                                    \
+        BH_CHECK_HIP(bh_max_lds((const void*)lstm_layer_wide_kernel<NKS, false>, (int)lds));                                                                    \
         hipLaunchKernelGGL((lstm_layer_wide_kernel<NKS, false>), dim3(grid), dim3(256), lds, stream, a);                 \
     } else
     if (nks == 32 && ex && ((force_slow >> 8) & 4)) {
-        BH_CHECK_HIP(hipFuncSetAttribute((const void*)lstm_layer_wide_kernel<32, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        BH_CHECK_HIP(bh_max_lds((const void*)lstm_layer_wide_kernel<32, true, true>, (int)lds));
         hipLaunchKernelGGL((lstm_layer_wide_kernel<32, true, true>), dim3(grid), dim3(256), lds, stream, a);
     } else
     BH_LSTM_WIDE(20) BH_LSTM_WIDE(24) BH_LSTM_WIDE(28) BH_LSTM_WIDE(32)

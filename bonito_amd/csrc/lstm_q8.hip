@@ -499,8 +499,7 @@ int bh_k_lstm_layer_q8(const void* xq, const void* wih, const void* whh, const f
 #define BH_Q8_LAUNCH(NK8, MT, WPS, LAST, DBG)                                                                            \
     do {                                                                                                                 \
         if (lds > 64 * 1024)                                                                                             \
-            BH_CHECK_HIP(hipFuncSetAttribute((const void*)lstm_layer_q8_kernel<NK8, MT, WPS, LAST, DBG>,                 \
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                    \
+            BH_CHECK_HIP(bh_max_lds((const void*)lstm_layer_q8_kernel<NK8, MT, WPS, LAST, DBG>, (int)lds));                    \
         hipLaunchKernelGGL((lstm_layer_q8_kernel<NK8, MT, WPS, LAST, DBG>), dim3(grid), dim3(256), lds, stream, a);       \
     } while (0)
 #define BH_Q8(NK8, MT, WPS)                                                                                              \

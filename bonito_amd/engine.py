@@ -281,8 +281,16 @@ class HipEncoder:
         if self._handle is None or ticket is None:
             return
         rc = _lib.lib().bh_encoder_error_flag_at(self._handle, int(ticket))
+        if rc < 0:          # the slot has been recycled: more than 64 forwards were issued before this one was queried - a caller bug,
+            raise RuntimeError("bh_encoder_error_flag_at: %s" % _lib.last_error())      # not a timeout (nothing to retry)
         if rc:
             raise _lib.HipEngineError("bh_encoder_error_flag_at: %s" % _lib.last_error())
+
+    def ack(self, ticket):
+        """The timeout of forward `ticket` has been handled (the batch was re-run): drop its flag, so that `poll()` / `check()` of this
+        engine do not report a batch that was already repaired (bh_encoder_ack)."""
+        if self._handle is not None and ticket is not None:
+            _lib.check(_lib.lib().bh_encoder_ack(self._handle, int(ticket)), "bh_encoder_ack")
 
     def close(self):
         if self._handle is not None:

@@ -94,7 +94,12 @@ def format_record(read, res, mode, min_qscore=0.0):
     construction. The log entry is produced for EVERY read, before the q-score / empty-sequence filters, like the reference
     (io.py:437-442)."""
     seq, qstring = res["sequence"], res.get("qstring", "*")
-    mean_q = mean_qscore(qstring) if qstring and qstring != "*" else 0.0
+    # Reference semantics (bonito/io.py:431-433, util.py:114-121): the mean q-score is ALWAYS computed from the q-string - 9.0 for the
+    # "*" sentinel as for a real one-base read with Q9 (whose q-string IS "*"), 0.0 for an empty one. Only the formatting differs: the
+    # sentinel / an empty q-string beside a sequence mean "no qualities" ('!' per base in FASTQ, where the reference would write a
+    # malformed record; '*' in SAM). A decoded "*" beside ONE base is a quality and is written unchanged (advisor finding, round 4).
+    no_quals = len(qstring) == 0 or (qstring == "*" and len(seq) != 1)
+    mean_q = mean_qscore(qstring) if len(qstring) else 0.0
     log = (read.read_id, signal_samples(read))
     if mean_q < min_qscore or not len(seq):
         return None, None, log
@@ -102,9 +107,9 @@ def format_record(read, res, mode, min_qscore=0.0):
         text = ">%s\n%s\n" % (read.read_id, seq)
     elif mode == "fastq":
         tags = read_tags(read, res, mean_q)
-        text = "@%s %s\n%s\n+\n%s\n" % (read.read_id, "\t".join(tags), seq, qstring if qstring != "*" else "!" * len(seq))
+        text = "@%s %s\n%s\n+\n%s\n" % (read.read_id, "\t".join(tags), seq, "!" * len(seq) if no_quals else qstring)
     else:
-        text = sam_record(read.read_id, seq, qstring, tags=read_tags(read, res, mean_q)) + "\n"
+        text = sam_record(read.read_id, seq, "*" if no_quals else qstring, tags=read_tags(read, res, mean_q)) + "\n"
     return text, summary_row(read, len(seq), mean_q), log
 
 

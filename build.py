@@ -24,17 +24,20 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-u
 # lstm_q8.hip: the pre-activation of the 8-bit recurrent path is DEFINED operation by operation (oracle/lstm_q8_ref.py); with
 # contraction on, the compiler fused different multiply-add pairs in different template instances
 EXTRA_FLAGS = {"signal.hip": ["-ffp-contract=off"], "lstm_q8.hip": ["-ffp-contract=off"]}
-if os.environ.get("BH_EXTRA_GEMM_FLAGS"):
-    EXTRA_FLAGS["gemm.hip"] = os.environ["BH_EXTRA_GEMM_FLAGS"].split()
 # Timing experiments only (e.g. BH_EXTRA_LSTM_FLAGS=-DBH_EXPT_SHARE: wrong results on purpose). Such a build NEVER writes the product
 # library: objects go to build/obj_expt, the result is bonito_amd/libbonito_hip_expt.so, and bonito_amd/_lib.py loads that file only
 # when BONITO_HIP_LIB names it (a stray environment variable used to produce a silently wrong libbonito_hip.so; review, round 3).
-EXPERIMENT = bool(os.environ.get("BH_EXTRA_LSTM_FLAGS"))
+# BH_EXTRA_GEMM_FLAGS (e.g. -DBH_GEMM_STATS: another GemmArgs layout + cycle stamps) is treated the same way (advisor, round 4: it used
+# to rebuild gemm.hip into the product object directory, and unsetting it did not rebuild - staleness is checked by mtime only).
+EXPERIMENT = bool(os.environ.get("BH_EXTRA_LSTM_FLAGS") or os.environ.get("BH_EXTRA_GEMM_FLAGS"))
 if EXPERIMENT:
-    EXTRA_FLAGS["lstm.hip"] = os.environ["BH_EXTRA_LSTM_FLAGS"].split()
+    if os.environ.get("BH_EXTRA_LSTM_FLAGS"):
+        EXTRA_FLAGS["lstm.hip"] = os.environ["BH_EXTRA_LSTM_FLAGS"].split()
+    if os.environ.get("BH_EXTRA_GEMM_FLAGS"):
+        EXTRA_FLAGS["gemm.hip"] = os.environ["BH_EXTRA_GEMM_FLAGS"].split()
     OBJ = os.path.join(ROOT, "build", "obj_expt")
     LIB = os.path.join(ROOT, "bonito_amd", "libbonito_hip_expt.so")
-    sys.stderr.write("build.py: BH_EXTRA_LSTM_FLAGS is set -> experimental library %s (the product library is not touched)\n" % LIB)
+    sys.stderr.write("build.py: BH_EXTRA_LSTM_FLAGS / BH_EXTRA_GEMM_FLAGS set -> experimental library %s (the product library is not touched)\n" % LIB)
 
 
 def _newer(dst, srcs):

@@ -140,6 +140,10 @@ int bh_encoder_check(bh_encoder_t* enc, void* stream);
 int bh_encoder_error_flag(const bh_encoder_t* enc);
 long bh_encoder_last_ticket(const bh_encoder_t* enc);
 int bh_encoder_error_flag_at(const bh_encoder_t* enc, long ticket);
+/* The caller has handled the timeout of forward `ticket` (it re-ran the batch): forget that flag - it is then reported neither by
+ * bh_encoder_error_flag / bh_encoder_check nor when its slot is recycled. 0, or -1 for a ticket whose slot has been recycled already.
+ * bh_encoder_forward may run on one host thread while the four flag queries run on another (all flag state is atomic). */
+int bh_encoder_ack(bh_encoder_t* enc, long ticket);
 
 /* Per-kernel-class timing with HIP events recorded on the forward's stream (measurement only).
  * After enabling, every bh_encoder_forward appends spans; profile_read synchronises on them and returns

@@ -336,8 +336,9 @@ def test_fused_record_formatter_writes_the_bytes_of_the_python_path(mode, revers
 
 @pytest.mark.parametrize("mode", ["fastq", "sam", "fasta"])
 def test_fused_record_formatter_edge_cases_follow_format_record(mode):
-    """Advisor findings (round 3) on `bh_host_format_read` vs `io.format_record`: a qstring that is exactly "*" means "no qualities"
-    (mean 0.0; '!' per base in FASTQ), an EMPTY qstring beside a sequence is written as an empty field, a read may span more than
+    """Advisor findings (rounds 3 and 4) on `bh_host_format_read` vs `io.format_record`: a decoded qstring "*" beside ONE base is a real
+    quality (Q9: mean 9.0, written unchanged - the reference's semantics, bonito/io.py:431-433), an EMPTY qstring beside a sequence
+    means "no qualities" ('!' per base in FASTQ, '*' in SAM, mean 0.0), a read may span more than
     64 engine calls (tiny batches / `--per-call 1` / ultra-long reads), and a non-ASCII read id is carried through as UTF-8."""
     import importlib
     from bonito_amd import io as bio
@@ -371,6 +372,15 @@ def test_fused_record_formatter_edge_cases_follow_format_record(mode):
             want = [bio.format_record(read, bc.fmt_planes(stride, bc.stitch_planes(planes, read.signal_len, chunksize, overlap, stride), False), mode, min_q)]
             got = list(bc.records_from_planes(iter([(keys, planes)]), chunksize, overlap, stride, mode, min_q))
             assert got == want, (read.read_id, min_q)
+            if read.read_id == "star":           # Q9 passes a threshold of 5 and is written as what it is
+                assert got[0][0] is not None and (mode == "fasta" or "*" in got[0][0]) and abs(got[0][1][-1] - 9.0) < 1e-6
+            if read.read_id == "noqual":
+                if min_q > 0:
+                    assert got[0][0] is None
+                elif mode == "fastq":
+                    assert got[0][0].endswith("ACG\n+\n!!!\n")
+                elif mode == "sam":
+                    assert "\tACG\t*\tNM:i:0" in got[0][0]
 
     # one read of 150 chunks delivered as 150 engine calls of one chunk each (> 64 pieces)
     rng = np.random.default_rng(5)
