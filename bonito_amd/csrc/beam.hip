@@ -85,8 +85,6 @@ struct ScanArgs {
     float* P;              // [N][T][4]   (forward only)
     int nt;                // stream scores / guide with the non-temporal cache policy (they are read once; keeps the L2 for the
                            // recurrent kernels' exchange buffers when the decoder runs beside the next batch's encoder)
-    int ckpt;              // backward scan: write only the guide rows t % ckpt == 0 (and t == T); 0 = every row. The fused
-                           // beam kernel recomputes the rows in between from the staged scores (beam_kernel, CKPT)
     int cpb;               // backward scan: chunks per workgroup (backward_geometry)
 };
 
@@ -182,10 +180,8 @@ __global__ void crf_backward_kernel(ScanArgs p) {
                 __syncthreads();
                 if (active) {
                     const float* now = buf + cb * S;
-                    if (p.ckpt == 0 || t % p.ckpt == 0) {
-                        if (p.nt) __builtin_nontemporal_store(now[s] - now[0], bn + (long)t * S + s);
-                        else bn[(long)t * S + s] = now[s] - now[0];
-                    }
+                    if (p.nt) __builtin_nontemporal_store(now[s] - now[0], bn + (long)t * S + s);
+                    else bn[(long)t * S + s] = now[s] - now[0];
                 }
             }
         }
@@ -430,10 +426,13 @@ struct BeamArgs {
     int nt;                // non-temporal staging of scores / guide
 };
 
-constexpr int BTB = 2;     // steps per staged block; two blocks are resident (the next one streams in under the current one). Two steps
-                           // (9 k cycles of beam work) hide the DMA latency as well as four did and take 12 KiB less LDS per chunk at 256
-                           // states: measured on MI355X, hac: decode stage 4.35 -> 3.65 ms per batch, bench step with one batch per engine
-                           // call 19.7 -> 17.9 ms (more decode workgroups find room beside the recurrent kernel)
+#ifndef BH_BTB
+#define BH_BTB 1
+#endif
+constexpr int BTB = BH_BTB;     // steps per staged block; two blocks are resident (the next one streams in under the current one). Round 2 went
+                           // from four to two (12 KiB less LDS per chunk at 256 states, decode 4.35 -> 3.65 ms per hac batch), round 5 to ONE:
+                           // a step of a chunk is ~5 k cycles, enough to hide the DMA of the next row, and at 14.1 KiB per chunk eight
+                           // chunks share a CU (g_beam_cpw): 12.97 -> 8.72 ms per 2048-chunk call. -DBH_BTB=n builds other depths (expt)
 constexpr int MAXW = 32;
 
 __device__ __forceinline__ unsigned bs_hash0(int s) { return ((unsigned)s + 1u) * 2654435761u; }
@@ -675,48 +674,6 @@ constexpr int BEAM_TAB_LDS = (BH_LSE_TABLE_SIZE + 2) * 4;
 // LDS of one fused scan wave: alpha~ ping-pong [2][S]
 template <int STATE_LEN>
 __host__ __device__ constexpr int scan_wave_lds() { return 2 * (1 << (2 * STATE_LEN)) * 4 + 64; }
-// ... with the checkpointed guide: + third score buffer [BTB][4S] halves + checkpoint rows [2][S] + raw backward chain [2][S]
-template <int STATE_LEN>
-__host__ __device__ constexpr int scan_wave_lds_ckpt() {
-    return scan_wave_lds<STATE_LEN>() + 4 * 4 * (1 << (2 * STATE_LEN)) * 2 + 4 * (1 << (2 * STATE_LEN)) * 4;
-}
-
-// One step of the backward (guide) recurrence of crf_backward_kernel by ONE wave: out[s] = normalised beta~_t, raw_out = the
-// unnormalised values the next (earlier) step chains on. Same operations in the same order as crf_backward_kernel, so the
-// recomputed rows are bit-identical to the ones that kernel would have stored (prev = a stored, normalised row: prev[0] == 0,
-// and (prev[s] - 0) is the stored value; prev = the raw row of the previous recomputed step: exactly the kernel's chain).
-template <int STATE_LEN>
-__device__ __forceinline__ void guide_step(float blank, const half_t* row, const float* prev, float* raw_out, float* out,
-                                           const float* tab, int lane) {
-    constexpr int S = 1 << (2 * STATE_LEN);
-    constexpr int SPL = S >= 64 ? S / 64 : 1;
-    const bool active = S >= 64 || lane < S;
-    const float ref = prev[0];
-    float acc[SPL];
-#pragma unroll
-    for (int k = 0; k < SPL; ++k) {
-        const int st = active ? lane * SPL + k : 0;
-        const int lead = st >> (2 * (STATE_LEN - 1));
-        const int sm = st & ((S >> 2) - 1);
-        float a = blank + (prev[st] - ref);
-#pragma unroll
-        for (int x = 0; x < 4; ++x) {
-            const int s2 = sm * 4 + x;
-            a = lse2_scan(a, (float)row[s2 * 4 + lead] + (prev[s2] - ref), tab);
-        }
-        acc[k] = a;
-    }
-    if (active) {
-#pragma unroll
-        for (int k = 0; k < SPL; ++k) raw_out[lane * SPL + k] = acc[k];
-    }
-    const float n0 = raw_out[0];
-    if (active) {
-#pragma unroll
-        for (int k = 0; k < SPL; ++k) out[lane * SPL + k] = acc[k] - n0;
-    }
-}
-
 // The forward / posterior scan of crf_forward_post_kernel as ONE wave beside the beam wave of the same chunk (FUSE): it reads
 // the score rows and guide rows from the LDS blocks the beam wave stages anyway, so the score tensor and the guide are read
 // from HBM once for both (2.63 GB of 7.9 GB per hac batch gone, one kernel and its launch gone). Lane l owns the states
@@ -773,25 +730,19 @@ __device__ __forceinline__ void scan_step(const BeamArgs& p, const half_t* row, 
     }
 }
 
-// CKPT (with FUSE): the guide is not read row by row. The backward scan stores only every BTB-th row (the row behind each staged
-// block); the scan wave recomputes the rows of block k+1 backwards from that checkpoint and the block's staged scores while the
-// beam wave works on block k (three score buffers, two guide buffers, two checkpoint rows). Guide traffic: 1/BTB of a write and
-// of a read instead of one each.
-template <int STATE_LEN, int CPW, bool DBG, bool FUSE = false, bool CKPT = false>
-__global__ __launch_bounds__(64 * CPW * (CKPT ? 3 : FUSE ? 2 : 1)) __attribute__((amdgpu_waves_per_eu(1, 8))) void beam_kernel(BeamArgs p) {
-    static_assert(!CKPT || FUSE, "the checkpointed guide needs the scan wave");
+template <int STATE_LEN, int CPW, bool DBG, bool FUSE = false>
+__global__ __launch_bounds__(64 * CPW * (FUSE ? 2 : 1)) __attribute__((amdgpu_waves_per_eu(1, 8))) void beam_kernel(BeamArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int S = 1 << (2 * STATE_LEN);
     constexpr int sh = 2 * (STATE_LEN - 1);
-    constexpr int NTHR = 64 * CPW * (CKPT ? 3 : FUSE ? 2 : 1);
+    constexpr int NTHR = 64 * CPW * (FUSE ? 2 : 1);
     static_assert(NBK == HBINS, "the selection histogram reuses the bucket fill counters");
     static_assert(beam_wave_lds<STATE_LEN>() % 16 == 0 && BEAM_TAB_LDS % 16 == 0, "LDS regions must stay 16-byte aligned");
     const int T = p.T, W = p.W;
     const int lane = threadIdx.x & 63;
     const int wave_all = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const bool guide_role = CKPT && wave_all >= 2 * CPW;         // third wave of a chunk: recomputes the guide rows of the next block
-    const bool scan_role = FUSE && wave_all >= CPW;              // (the guide wave shares the scan wave's LDS carve and helpers)
-    const int wave = guide_role ? wave_all - 2 * CPW : scan_role ? wave_all - CPW : wave_all;      // chunk slot inside the workgroup
+    const bool scan_role = FUSE && wave_all >= CPW;
+    const int wave = scan_role ? wave_all - CPW : wave_all;      // chunk slot inside the workgroup
     const int n = blockIdx.x * CPW + wave;
     // LDS carve
     float* tab = (float*)smem;                           // lse table (shared by the waves)
@@ -801,12 +752,8 @@ __global__ __launch_bounds__(64 * CPW * (CKPT ? 3 : FUSE ? 2 : 1)) __attribute__
     char* mine = smem + BEAM_TAB_LDS + wave * beam_wave_lds<STATE_LEN>();
     half_t* st_sc = (half_t*)mine;                       // [2][BTB][4S]
     float* st_b = (float*)(st_sc + 2 * BTB * 4 * S);     // [2][BTB][S]
-    constexpr int SCAN_LDS = CKPT ? scan_wave_lds_ckpt<STATE_LEN>() : scan_wave_lds<STATE_LEN>();
+    constexpr int SCAN_LDS = scan_wave_lds<STATE_LEN>();
     char* scan_mem = smem + BEAM_TAB_LDS + CPW * beam_wave_lds<STATE_LEN>() + wave * SCAN_LDS;
-    half_t* sc3 = (half_t*)(scan_mem + scan_wave_lds<STATE_LEN>());       // CKPT: third score buffer [BTB][4S]
-    float* ck = (float*)(sc3 + BTB * 4 * S);                             // CKPT: checkpoint rows [2][S]
-    float* braw = ck + 2 * S;                                            // CKPT: raw backward chain [2][S]
-    auto sc_buf = [&](int i) -> half_t* { return i < 2 ? st_sc + i * BTB * 4 * S : sc3; };
     if (scan_role) {
         // ---- forward / posterior scan over the blocks the beam wave stages ---------------------------------------------
         float* al = (float*)scan_mem;
@@ -818,39 +765,11 @@ __global__ __launch_bounds__(64 * CPW * (CKPT ? 3 : FUSE ? 2 : 1)) __attribute__
         float* Pn = p.P + (long)n * T * 4;
         double A = 0.0;
         int cb = 0;
-        // CKPT: guide rows tb0+1 .. tb0+nsteps of the block starting at tb0 -> st_b[gi]: the last one is the checkpoint (zeros
-        // at t == T), the others are recomputed backwards from it with the block's score rows
-        auto make_guide = [&](int tb0, int blk) {
-            const int nsteps = min(BTB, T - tb0);
-            float* g = st_b + (blk & 1) * BTB * S;
-            const half_t* bsc = sc_buf(blk % 3);
-            const float* c = ck + (blk & 1) * S;
-            const bool last = tb0 + nsteps == T;
-            if (S >= 64 || lane < S)
-                for (int k = 0; k < SPLz; ++k) g[(nsteps - 1) * S + lane * SPLz + k] = last ? 0.0f : c[lane * SPLz + k];
-            const float* prev = g + (nsteps - 1) * S;
-            for (int r = nsteps - 2, cbk = 0; r >= 0; --r, cbk ^= 1) {
-                guide_step<STATE_LEN>(p.blank, bsc + (r + 1) * 4 * S, prev, braw + cbk * S, g + r * S, tab, lane);
-                prev = braw + cbk * S;
-            }
-        };
-        if (CKPT) {
-            __syncthreads();                        // P1: blocks 0 and 1 (scores + checkpoints) have landed
-            if (guide_role && T > 0) make_guide(0, 0);
-            __syncthreads();                        // P2: the guide of block 0 is ready
-        }
-        if (guide_role) {                           // one block ahead of the beam and scan waves, one barrier per block like them
-            for (int tb0 = 0, blk = 0; tb0 < T; tb0 += BTB, ++blk) {
-                __syncthreads();
-                if (tb0 + BTB < T) make_guide(tb0 + BTB, blk + 1);
-            }
-            return;
-        }
         for (int tb0 = 0, blk = 0; tb0 < T; tb0 += BTB, ++blk) {
             const int nsteps = min(BTB, T - tb0);
             const double Bmine = lane < nsteps ? Bn[tb0 + lane] : 0.0;       // one fp64 per step, fetched once per block
             __syncthreads();                                                   // block `blk` has landed (beam wave waited for its DMA)
-            const half_t* blk_sc = CKPT ? sc_buf(blk % 3) : st_sc + (blk & 1) * BTB * 4 * S;
+            const half_t* blk_sc = st_sc + (blk & 1) * BTB * 4 * S;
             const float* blk_b = st_b + (blk & 1) * BTB * S;
             for (int u = 0; u < nsteps; ++u) {
                 const unsigned long long bb = (unsigned long long)__double_as_longlong(Bmine);
@@ -955,33 +874,20 @@ __global__ __launch_bounds__(64 * CPW * (CKPT ? 3 : FUSE ? 2 : 1)) __attribute__
         dma_rows((const char*)(sc + (long)tb0 * 4 * S), (char*)(st_sc + which * BTB * 4 * S), nsteps * S / 2);     // 4S halves per step
         dma_rows((const char*)(bn + (long)(tb0 + 1) * S), (char*)(st_b + which * BTB * S), nsteps * S / 4);         // S floats per step
     };
-    // CKPT: score rows of block `blk` into score buffer blk % 3, its checkpoint row beta~_{tb0+nsteps} into ck[blk & 1]
-    auto stage_ck = [&](int tb0, int blk) {
-        const int nsteps = min(BTB, T - tb0);
-        dma_rows((const char*)(sc + (long)tb0 * 4 * S), (char*)sc_buf(blk % 3), nsteps * S / 2);
-        if (tb0 + nsteps < T) dma_rows((const char*)(bn + (long)(tb0 + nsteps) * S), (char*)(ck + (blk & 1) * S), S / 4);
-    };
-    if (CKPT) {
-        if (T > 0) stage_ck(0, 0);
-        if (T > BTB) stage_ck(BTB, 1);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();                            // P1
-        __syncthreads();                            // P2: the scan wave has made the guide rows of block 0
-    } else if (T > 0) stage(0, 0);
+    if (T > 0) stage(0, 0);
     for (int tb0 = 0, blk = 0; tb0 < T; tb0 += BTB, ++blk) {
         const int nsteps = min(BTB, T - tb0);
         {
             long long ts0 = 0;
             if (DBG) ts0 = __builtin_readcyclecounter();
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this block has landed (CKPT: the next one and its checkpoint)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this block has landed
             // unfused: wave-private buffers, no barrier. Fused: one workgroup barrier per block publishes the landed block to
             // the scan wave and proves that it is done with the block before last, whose buffer the next DMA overwrites
             if (FUSE) __syncthreads();
             if (DBG) dsec[5] += __builtin_readcyclecounter() - ts0;
-            if (CKPT) { if (tb0 + 2 * BTB < T) stage_ck(tb0 + 2 * BTB, blk + 2); }
-            else if (tb0 + BTB < T) stage(tb0 + BTB, (blk + 1) & 1);  // (everything read from that buffer was consumed a block ago)
+            if (tb0 + BTB < T) stage(tb0 + BTB, (blk + 1) & 1);  // (everything read from that buffer was consumed a block ago)
         }
-        const half_t* blk_sc = CKPT ? sc_buf(blk % 3) : st_sc + (blk & 1) * BTB * 4 * S;
+        const half_t* blk_sc = st_sc + (blk & 1) * BTB * 4 * S;
         const float* blk_b = st_b + (blk & 1) * BTB * S;
         for (int u = 0; u < nsteps; ++u) {
             const half_t* row = blk_sc + u * 4 * S;
@@ -1236,7 +1142,7 @@ int bh_k_crf_logz(const void* scores, int N, int T, int state_len, float blank, 
     char* w = (char*)workspace;
     float* beta = (float*)w;   w += align((size_t)N * (T + 1) * S * sizeof(float));
     double* Bcum = (double*)w;
-    ScanArgs sa{(const half_t*)scores, N, T, S, state_len, blank, beta, Bcum, logz_out, nullptr, g_decode_nt, 0, 1};
+    ScanArgs sa{(const half_t*)scores, N, T, S, state_len, blank, beta, Bcum, logz_out, nullptr, g_decode_nt, 1};
     const int threads = S < 64 ? 64 : S;
     const size_t lds_scan = (size_t)(BH_LSE_TABLE_SIZE + 2 + 2 * S + 2 * 16 * 16 + 8) * sizeof(float) + (size_t)2 * 4 * S * 2;
     {
@@ -1269,7 +1175,7 @@ int bh_k_posterior_viterbi(const void* scores, int N, int T, int state_len, floa
     double* Bcum = (double*)w; w += align((size_t)N * (T + 1) * sizeof(double));
     double* logZ = (double*)w;
     uint8_t* bp = (uint8_t*)workspace + bh_k_beam_workspace(N, T, state_len);
-    ScanArgs sa{(const half_t*)scores, N, T, S, state_len, blank, beta, Bcum, logZ, nullptr, g_decode_nt, 0, 1};
+    ScanArgs sa{(const half_t*)scores, N, T, S, state_len, blank, beta, Bcum, logZ, nullptr, g_decode_nt, 1};
     const int threads = S < 64 ? 64 : S;
     const size_t lds_scan = (size_t)(BH_LSE_TABLE_SIZE + 2 + 2 * S + 2 * 16 * 16 + 8) * sizeof(float) + (size_t)2 * 4 * S * 2;
     {
@@ -1294,16 +1200,17 @@ namespace {
 struct SideStream { hipStream_t stream = nullptr; hipEvent_t fork = nullptr, join = nullptr; };
 int g_beam_select = 0;     // 0 histogram top-W selection, 1 radix search (A/B and regression tests)
 int g_beam_fork = -1;      // -1 auto (fork for small state spaces), 0 never, 1 always; bh_set_option("beam_fork", v)
-int g_beam_ckpt = 0;       // with the fused scan: 1 = guide checkpointed every BTB steps and recomputed by a third wave per chunk. Cuts the
-                           // guide's HBM traffic to a quarter (decode stage 5.26 -> 3.94 GB per hac batch) but costs more than it saves
-                           // next to the encoder: decode 5.7 -> 6.1 ms, bench step 19.6 -> 20.7 ms (fp16), 14.8 -> 15.2 (8-bit, two
-                           // lanes); with the recomputation on the scan wave itself 23.4 ms. Off by default.
-int g_beam_cpw = 1;        // chunks per workgroup of the fused beam kernel at 256 states ("beam_cpw": 1, 2, 3). The 16 KiB lse table is shared
-                           // by the chunks of a workgroup: three chunks make two 78 KiB workgroups = six chunks per CU where one per
-                           // workgroup (37 KiB) gives four. Measured in round 3 (hac, 2048-chunk calls): decode 3.71 / 3.56 / 3.63 ms
-                           // per batch for 1 / 2 / 3, the bench step unchanged - with four chunks per CU the kernel is already bound by
-                           // the instructions the beam and scan waves issue (~5.5 k SIMD cycles per chunk and time step), not by the
-                           // latency of one wave's LDS round trips. Left at 1.
+int g_beam_cpw = 0;        // chunks per workgroup of the fused beam kernel at 256 states ("beam_cpw": 0 = automatic, 1, 2, 4). The decode
+                           // kernels are chains of dependent LDS round trips, ballots and scalar branches - ~5.5 k cycles per time step
+                           // of a chunk whatever else runs - so what counts is how many chunks a CU works on AT ONCE, and whether the
+                           // call fits ONE round of resident workgroups. The 16 KiB lse table is shared by the chunks of a workgroup
+                           // and a chunk's own LDS is 14.1 KiB (one-step staging blocks, BTB = 1): one chunk per workgroup = five
+                           // chunks per CU, two = six, four = eight (two workgroups of 72.5 KiB). Round 5, MI355X, 2048 x 1667 steps
+                           // at 256 states, decode stage alone: 12.97 ms (BTB 2, one per workgroup: four per CU, two rounds) ->
+                           // 12.00 (BTB 1, five per CU) -> 8.72 ms (BTB 1, four per workgroup: eight per CU, one round). Round 3 had
+                           // tried two and three per workgroup with BTB 2 (3.71 / 3.56 / 3.63 ms per batch) and read the flat result
+                           // as "instruction bound": those geometries still needed two rounds. Automatic = the smallest of 1 / 2 / 4
+                           // that lets the call's chunks be resident together.
 int g_beam_fuse = -1;      // forward / posterior scan as a second wave of the beam kernel's workgroups: -1 auto (<= 256 states: one
                            // scan wave keeps up with the beam wave; at 1024 states its 16 states per lane make the beam wave wait:
                            // sup-LSTM 256 x 3334 decode 18 -> 36 ms), 0 never (own kernel), 1 always
@@ -1350,8 +1257,7 @@ int bh_k_beam_search(const void* scores, int N, int T, int state_len, int beam_w
     long long* dbg = getenv("BH_BEAM_DEBUG") ? (long long*)w : nullptr;
 
     const bool fuse = g_beam_fuse > 0 || (g_beam_fuse < 0 && S <= 256);
-    const bool ckpt = fuse && g_beam_ckpt != 0 && S <= 256;       // (three score buffers of 1024 states do not fit the LDS)
-    ScanArgs sa{(const half_t*)scores, N, T, S, state_len, blank, beta, Bcum, logZ, P, g_decode_nt, ckpt ? BTB : 0, 1};
+    ScanArgs sa{(const half_t*)scores, N, T, S, state_len, blank, beta, Bcum, logZ, P, g_decode_nt, 1};
     const int threads = S < 64 ? 64 : S;
     const size_t lds_scan = (size_t)(BH_LSE_TABLE_SIZE + 2 + 2 * S + 2 * 16 * 16 + 8) * sizeof(float) + (size_t)2 * 4 * S * 2;
     {
@@ -1389,26 +1295,19 @@ int bh_k_beam_search(const void* scores, int N, int T, int state_len, int beam_w
         const size_t lds_beam = (size_t)BEAM_TAB_LDS + cpw * (wave_lds + scan_lds);
         if (lds_beam > 64 * 1024)
             BH_CHECK_HIP(bh_max_lds((const void*)kern, (int)lds_beam));
-        hipLaunchKernelGGL(kern, dim3((N + cpw - 1) / cpw), dim3(64 * cpw * (ckpt ? 3 : scan_lds ? 2 : 1)), lds_beam, stream, ba);
+        hipLaunchKernelGGL(kern, dim3((N + cpw - 1) / cpw), dim3(64 * cpw * (scan_lds ? 2 : 1)), lds_beam, stream, ba);
         return 0;
     };
     int lrc = -2;
-    if (ckpt) {
-        switch (state_len * 2 + (dbg ? 1 : 0)) {
-            case 2: lrc = launch_beam(beam_kernel<1, 4, false, true, true>, 4, beam_wave_lds<1>(), scan_wave_lds_ckpt<1>()); break;
-            case 3: lrc = launch_beam(beam_kernel<1, 4, true, true, true>, 4, beam_wave_lds<1>(), scan_wave_lds_ckpt<1>()); break;
-            case 4: lrc = launch_beam(beam_kernel<2, 4, false, true, true>, 4, beam_wave_lds<2>(), scan_wave_lds_ckpt<2>()); break;
-            case 5: lrc = launch_beam(beam_kernel<2, 4, true, true, true>, 4, beam_wave_lds<2>(), scan_wave_lds_ckpt<2>()); break;
-            case 6: lrc = launch_beam(beam_kernel<3, 4, false, true, true>, 4, beam_wave_lds<3>(), scan_wave_lds_ckpt<3>()); break;
-            case 7: lrc = launch_beam(beam_kernel<3, 4, true, true, true>, 4, beam_wave_lds<3>(), scan_wave_lds_ckpt<3>()); break;
-            case 8: lrc = launch_beam(beam_kernel<4, 1, false, true, true>, 1, beam_wave_lds<4>(), scan_wave_lds_ckpt<4>()); break;
-            case 9: lrc = launch_beam(beam_kernel<4, 1, true, true, true>, 1, beam_wave_lds<4>(), scan_wave_lds_ckpt<4>()); break;
-            case 10: lrc = launch_beam(beam_kernel<5, 1, false, true, true>, 1, beam_wave_lds<5>(), scan_wave_lds_ckpt<5>()); break;
-            case 11: lrc = launch_beam(beam_kernel<5, 1, true, true, true>, 1, beam_wave_lds<5>(), scan_wave_lds_ckpt<5>()); break;
-        }
-    } else if (fuse && state_len == 4 && !dbg && g_beam_cpw == 3) {
-        lrc = launch_beam(beam_kernel<4, 3, false, true>, 3, beam_wave_lds<4>(), scan_wave_lds<4>());
-    } else if (fuse && state_len == 4 && !dbg && g_beam_cpw == 2) {
+    int cpw4 = g_beam_cpw;           // chunks per workgroup at 256 states
+    if (fuse && state_len == 4 && cpw4 <= 0) {
+        const long cus = bh_cu_count();
+        cpw4 = (long)N <= 5 * cus ? 1 : (long)N <= 6 * cus ? 2 : 4;
+    }
+    if (false) {
+    } else if (fuse && state_len == 4 && !dbg && cpw4 == 4) {
+        lrc = launch_beam(beam_kernel<4, 4, false, true>, 4, beam_wave_lds<4>(), scan_wave_lds<4>());
+    } else if (fuse && state_len == 4 && !dbg && cpw4 == 2) {
         lrc = launch_beam(beam_kernel<4, 2, false, true>, 2, beam_wave_lds<4>(), scan_wave_lds<4>());
     } else if (fuse) {
         switch (state_len * 2 + (dbg ? 1 : 0)) {
@@ -1450,6 +1349,5 @@ int bh_k_decode_set_option(const char* name, int value) {
     if (name && !strcmp(name, "beam_fuse")) { g_beam_fuse = value; return 0; }
     if (name && !strcmp(name, "beam_cpw")) { g_beam_cpw = value; return 0; }
     if (name && !strcmp(name, "decode_nt")) { g_decode_nt = value; return 0; }
-    if (name && !strcmp(name, "beam_ckpt")) { g_beam_ckpt = value; return 0; }
     return 1;     // not a decoder option
 }

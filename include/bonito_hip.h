@@ -206,9 +206,9 @@ int bh_lstm_q8_layer(const void* x, float bound, const float* w_ih, const float*
  *   "beam_fuse": -1 (default) = auto: fused for <= 256 states; 1 = the forward / posterior scan runs as a second wave inside the beam kernel's workgroups and reads
  *                the score and guide rows from the blocks the beam wave stages in LDS (the score tensor is read from HBM once
  *                for both); 0 = separate crf_forward_post_kernel as in round 1 (then "beam_fork" applies).
- *   "beam_ckpt": 1 = with the fused scan, the backward scan stores only every 4th guide row and a third wave per chunk
- *                recomputes the rows in between from the staged scores (bit-identical rows; a quarter of the guide traffic, but
- *                5 % slower end to end on MI355X); 0 (default) = every row stored and read.
+ *   "beam_cpw": chunks per workgroup of the fused beam kernel at 256 states: 0 (default) = the smallest of 1 / 2 / 4 that lets all
+ *                chunks of the call be resident at once (5 / 6 / 8 chunks per CU; the kernels are latency chains, so chunks in
+ *                flight per CU are what counts: 2048 x 1667 steps 12.0 -> 8.7 ms on MI355X); 1, 2, 4 force a geometry. Same bytes.
  *   "beam_select": 0 (default) = top-W selection by histogram + exact boundary ranking, 1 = MSB-first radix search
  *                (the same beams either way; kept for regression tests and A/B timing).
  *   "conv_ws": 1 (default) = weight-stationary kernel for the 384-channel / 19-tap convolution, 0 = generic implicit GEMM.

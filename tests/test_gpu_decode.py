@@ -261,23 +261,23 @@ def test_hip_decoders_match_reference_ctc_crf_fixture():
 
 @pytest.mark.parametrize("state_len", [1, 2, 3, 4, 5])
 def test_fused_and_separate_posterior_scan_agree(state_len):
-    """bh_set_option("beam_fuse" / "beam_ckpt"): the forward / posterior scan as a second wave of the beam kernel's workgroups
-    with the guide checkpointed every 4 steps and recomputed by a third wave ("beam_ckpt" 1), the same with every
-    guide row stored (default for <= 256 states), or the round-1 arrangement (own kernel) -- same sequences and moves bit for bit, q-scores to summation
-    order. T = 203 / 61 are not multiples of the block length (partial last block), T = 4, 5, 1 exercise the prologue."""
+    """bh_set_option("beam_fuse" / "beam_cpw"): the forward / posterior scan as a second wave of the beam kernel's workgroups (default for
+    <= 256 states) with one, two or four chunks per workgroup (256 states: the automatic choice depends on the call's size), or the
+    round-1 arrangement (own kernel) -- same sequences and moves bit for bit, q-scores to summation order. T = 203 / 61 / 5 / 1 exercise the
+    prologue and the last block."""
     rng = np.random.default_rng(300 + state_len)
     for N, T in ([(5, 61), (2, 5)] if state_len == 5 else [(11, 203), (3, 4), (3, 5), (2, 1), (4, 8)]):
         sc = torch.from_numpy(_peaky_scores(rng, N, T, state_len)).cuda()
         outs = []
         try:
-            for fuse, ckpt in ((1, 1), (1, 0), (0, 0)):
+            for fuse, cpw in ((1, 4), (1, 2), (1, 1), (0, 0)):
                 decode.set_option("beam_fuse", fuse)
-                decode.set_option("beam_ckpt", ckpt)
+                decode.set_option("beam_cpw", cpw)
                 outs.append(decode.beam_search(sc, return_qfloat=True))
         finally:
             decode.set_option("beam_fuse", -1)
-            decode.set_option("beam_ckpt", 0)
-        for o in outs[:2]:
-            assert torch.equal(o[0], outs[2][0]) and torch.equal(o[2], outs[2][2]), (N, T)
-            assert (o[3] - outs[2][3]).abs().max().item() < 1e-4
-            assert (o[1] != outs[2][1]).float().mean().item() < 1e-3
+            decode.set_option("beam_cpw", 0)
+        for o in outs[:3]:
+            assert torch.equal(o[0], outs[3][0]) and torch.equal(o[2], outs[3][2]), (N, T)
+            assert (o[3] - outs[3][3]).abs().max().item() < 1e-4
+            assert (o[1] != outs[3][1]).float().mean().item() < 1e-3

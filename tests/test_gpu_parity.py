@@ -56,13 +56,17 @@ def _floors(res, **floors):
 # floors: 1 - 2 x (1 - identity measured on MI355X), figures of the first measured run behind each line
 def test_end_to_end_identity_fast_512x10000():
     res = _run("fast", synthetic.make_model("fast", batchsize=512, chunksize=10000), 512, 10000, 8)
-    _floors(res, viterbi_path_identity=0.98, viterbi_seq_identity=0.98, beam_seq_identity=0.98, moves_identity=0.98)
+    # measured (round 5): Viterbi path 1.0 (8 of 8 chunks bit-identical), beam sequence 1.0, beam MOVE TABLE 0.9507 - the sequences agree
+    # base for base, the step at which a base is emitted does not always: BS-1 folds a move into the stay that spells the same sequence and
+    # follows the higher of the two, and a random-weight head leaves those two within the fp16 error of each other
+    _floors(res, viterbi_path_identity=0.998, viterbi_seq_identity=0.998, beam_seq_identity=0.998, moves_identity=0.90)
     assert res["scores_max_abs"] < 2.1e-2
 
 
 def test_end_to_end_identity_hac_512x10000():
     res = _run("hac", synthetic.make_model("hac", batchsize=512, chunksize=10000), 512, 10000, 8)
-    _floors(res, viterbi_path_identity=0.98, viterbi_seq_identity=0.98, beam_seq_identity=0.98, moves_identity=0.98)
+    # measured (round 5, the bench line's `parity`): Viterbi path 1.0, beam sequence 1.0, beam move table 0.9613
+    _floors(res, viterbi_path_identity=0.998, viterbi_seq_identity=0.998, beam_seq_identity=0.998, moves_identity=0.92)
     assert res["scores_max_abs"] < 2.4e-2
 
 
