@@ -3,8 +3,8 @@
 // Algorithm "BS-1" is defined in DESIGN.md and restated on the CPU in oracle/crf_oracle.c; this file
 // implements exactly that definition:
 //
-//   K1 crf_backward_kernel      beta~[N][T+1][S], B[N][T+1] (double), logZ[N]   (Log semiring, table lse2)
-//   K2 crf_forward_post_kernel  class posteriors P[N][T][4]
+//   K1 bs2_backward_kernel      the guide b[N][T+1][S] in the LINEAR domain (deterministic exp, round 5: "BS-2" below)
+//   K2 scan wave of K3 / bs2_forward_post_kernel   class posteriors P[N][T][4] (linear domain)
 //   K3 beam_kernel              beam of <=32 (state, sequence-hash) elements; back-pointers bp[N][T][32]
 //   K4 beam_finalize_kernel     traceback, sequence / moves / q-string
 //
@@ -207,103 +207,6 @@ static void backward_geometry(int S, int N, int& cpb, int& threads, size_t& lds)
     lds = (size_t)((BH_LSE_TABLE_SIZE * 4 + 15) & ~15) + (size_t)cpb * 24 * S + 64;
 }
 
-// PB: prefetch the guide offsets B_t with the scores (8 more registers per SU; at 1024 threads per workgroup that crosses the
-// 64-register line below which two workgroups share a CU, so the 1024-state instantiation reads B_t inside the step).
-template <bool PB>
-__global__ void crf_forward_post_kernel(ScanArgs p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* tab = (float*)smem;
-    float* buf = tab + BH_LSE_TABLE_SIZE + 2;   // [2][S]
-    float* part = buf + 2 * p.S;                // [2][4 classes][16 waves] class partial sums (16-byte aligned: S % 4 == 0)
-    const int S = p.S, T = p.T, q = S >> 2;
-    const int n = blockIdx.x, j = threadIdx.x;
-    const bool active = j < S;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
-    for (int i = threadIdx.x; i < BH_LSE_TABLE_SIZE; i += blockDim.x) tab[i] = g_lse_tab[i];
-    if (active) buf[j] = 0.0f;
-    const half_t* sc = p.scores + (long)n * T * 4 * S + j * 4;
-    const float* bn = p.beta + (long)n * (T + 1) * S;
-    const double* Bn = p.Bcum + (long)n * (T + 1);
-    const double lz = p.logZ[n];
-    float* Pn = p.P + (long)n * T * 4;
-    __syncthreads();
-
-    // everything a step needs from global memory is requested SU steps ahead: the score quad, the guide value and the
-    // running guide offset B_t (one fp64 per step; read inside the step it put an L2 round trip on the critical path)
-    half4_t cur[SU], nxt[SU];
-    float bcur[SU], bnxt[SU];
-    double Bcur[PB ? SU : 1], Bnxt[PB ? SU : 1];
-    auto load = [&](half4_t (&dst)[SU], float (&bd)[SU], double (&Bd)[PB ? SU : 1], int t0) {
-#pragma unroll
-        for (int u = 0; u < SU; ++u) {
-            int t = t0 + u;
-            if (active && t < T) {
-                dst[u] = *(const half4_t*)(sc + (long)t * 4 * S);
-                bd[u] = bn[(long)(t + 1) * S + j];
-                if (PB) Bd[u] = Bn[t];
-            }
-        }
-    };
-    double A = 0.0;
-    int cb = 0;
-    load(cur, bcur, Bcur, 0);
-    for (int t0 = 0; t0 < T; t0 += SU) {
-        load(nxt, bnxt, Bnxt, t0 + SU);
-#pragma unroll
-        for (int u = 0; u < SU; ++u) {
-            const int t = t0 + u;
-            if (t < T) {
-                const float* prev = buf + cb * S;
-                const float ref = prev[0];
-                float acc = 0.0f;
-                if (active) {
-                    acc = p.blank + (prev[j] - ref);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        acc = lse2_scan(acc, (float)cur[u][r] + (prev[r * q + (j >> 2)] - ref), tab);
-                    buf[(cb ^ 1) * S + j] = acc;
-                }
-                A += (double)ref;
-                cb ^= 1;
-                __syncthreads();
-                // boundary u = t+1: p[s] = exp(alpha~ + beta~ - (logZ - A_u - raw[0] - B_t))
-                const float* now = buf + cb * S;
-                const float now0 = now[0];
-                float pv = 0.0f;
-                if (active) {
-                    const double norm = lz - (A + (double)now0) - (PB ? Bcur[u] : Bn[t]);
-                    pv = __expf((float)((double)(acc - now0) + (double)bcur[u] - norm));
-                }
-                // class sums: lanes with equal (lane & 3) are one class. Inside a row of 16 lanes two DPP rotations add the
-                // four lanes of a class, two shuffles add the four rows; the per-wave totals go to LDS class-major so that
-                // the four finishing threads read their waves' values as 16-byte vectors.
-                pv += dpp_f<0x124, 0xF>(pv);     // row_ror:4
-                pv += dpp_f<0x128, 0xF>(pv);     // row_ror:8
-                pv += __shfl_xor(pv, 16);
-                pv += __shfl_xor(pv, 32);
-                float* slot = part + (t & 1) * 64;            // [4 classes][16 waves]
-                if (lane < 4) slot[lane * 16 + wave] = pv;
-                __syncthreads();
-                if (threadIdx.x < 4) {
-                    const float* mine = slot + threadIdx.x * 16;
-                    float tot = 0.0f;
-                    if (nwaves >= 4) {
-                        for (int w = 0; w < nwaves; w += 4) {
-                            const float4_t v = *(const float4_t*)(mine + w);
-                            tot += (v.x + v.y) + (v.z + v.w);
-                        }
-                    } else {
-                        for (int w = 0; w < nwaves; ++w) tot += mine[w];
-                    }
-                    Pn[(long)t * 4 + threadIdx.x] = tot;
-                }
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < SU; ++u) { cur[u] = nxt[u]; bcur[u] = bnxt[u]; if (PB) Bcur[u] = Bnxt[u]; }
-    }
-}
-
 // ------------------------------------------------------------------------------------------------
 // Posterior decoding = SeqdistModel.decode_batch (/root/reference bonito/crf/model.py:196-199):
 //     post = posteriors(scores) + 1e-8 ; path = viterbi(log post)
@@ -411,7 +314,7 @@ __global__ void crf_posterior_viterbi_kernel(PostVitArgs pa) {
 // ------------------------------------------------------------------------------------------------
 struct BeamArgs {
     const half_t* scores;  // [N][T][4S]
-    const float* beta;     // [N][T+1][S]
+    const float* beta;     // [N][T+1][S] the LINEAR guide b of bs2_backward_kernel
     int N, T, S, state_len, W;
     float blank, cut;      // cut = log(beam_cut)
     uint8_t* bp;           // [N][T][32]  parent | move << 5 | base << 6
@@ -419,10 +322,7 @@ struct BeamArgs {
     long long* dbg;        // optional [N][8] per-section cycle counters (BH_BEAM_DEBUG)
     float inv_bin;         // 256 / cut: selection histogram bins per unit of key; 0 puts every key into one bin, which
                            // turns the selection into the plain radix search (bh_set_option("beam_select", 1))
-    // fused forward / posterior scan (FUSE instantiations): what crf_forward_post_kernel reads and writes
-    const double* Bcum;    // [N][T+1]
-    const double* logZ;    // [N]
-    float* P;              // [N][T][4]
+    float* P;              // [N][T][4] class posteriors, written by the fused scan wave (FUSE instantiations)
     int nt;                // non-temporal staging of scores / guide
 };
 
@@ -513,6 +413,8 @@ __device__ __forceinline__ float wave_max_f32(float v) {
     v = fmaxf(v, dpp_f<0x143, 0xC>(v));    // row_bcast31 into rows 2 and 3 -> lane 63 holds the total
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
+
+__device__ __forceinline__ float wave_max_pos(float v) { return wave_max_f32(v); }
 
 template <int CTRL>
 __device__ __forceinline__ int dpp_i0(int v) {       // DPP move; lanes whose source falls outside the row read 0
@@ -659,6 +561,227 @@ __device__ __forceinline__ void dma16_nt(const char* g, char* lds) {      // sam
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt" ::"s"(l), "v"(g) : "memory");
 }
 
+// =================================================================================================================================
+// BS-2 (round 5): the guide and the posterior scan in the LINEAR domain.
+//
+// The table-lse2 scans of rounds 1-4 were chains: four dependent lse2 per state and step, each with two dependent LDS table reads at
+// random addresses (SQ counters of round 5: the backward scan waited 51 % of its wave cycles, its LDS bank-conflict cycles were 2.6 x
+// the cycles its LDS instructions were active). In the linear domain a step is five multiply-adds per state on exponentials that do not
+// depend on the recurrence, no table, no chain. What the search needs - guide rows that are bit-identical on the GPU and in the CPU
+// oracle - is kept by evaluating the exponential (and the logarithm the beam wave takes of the guide values it ranks with) with plain
+// IEEE operations only: polynomials by fmaf and integer arithmetic on the exponent bits (include/bh_bs2.h, oracle/crf_oracle.c
+// oracle_bs2_exp / oracle_bs2_log / oracle_bs2_backward: the same operations in the same order). Packed fp32 instructions
+// (v_pk_fma_f32, two IEEE fmas per lane) carry the polynomial.
+//
+// State <-> lane mapping of the backward scan: lane m owns the four states {m + lead * S/4}, i.e. the four k-mers that differ in their
+// LEADING base. Their successors are the same four states 4m .. 4m+3, and the 16 transition scores they need are the 32 contiguous
+// bytes row[16m .. 16m+15] - every byte a lane reads is used, reads are linear across the wave (no bank conflicts), and a half needs no
+// extraction beyond the conversion. (With one state per thread, as before, a thread picked one half out of every eight bytes.)
+// =================================================================================================================================
+#include "../../include/bh_bs2.h"
+typedef float float2_t __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ float2_t fma2(float2_t a, float2_t b, float2_t c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ float2_t splat2(float v) { return float2_t{v, v}; }
+
+// e^x for two values: oracle_bs2_exp, operation for operation (v_med3_f32, v_pk_fma_f32, v_pk_add_f32, v_lshl_add_u32)
+__device__ __forceinline__ float2_t bs2_exp2(float2_t x) {
+    x.x = __builtin_amdgcn_fmed3f(x.x, -BH_BS2_XMAX, BH_BS2_XMAX);
+    x.y = __builtin_amdgcn_fmed3f(x.y, -BH_BS2_XMAX, BH_BS2_XMAX);
+    const float2_t t = fma2(x, splat2(BH_BS2_LOG2E), splat2(BH_BS2_MAGIC));
+    const float2_t n = t - splat2(BH_BS2_MAGIC);
+    const float2_t f = fma2(x, splat2(BH_BS2_LOG2E), -n);
+    float2_t p = splat2(BH_BS2_E5);
+    p = fma2(p, f, splat2(BH_BS2_E4));
+    p = fma2(p, f, splat2(BH_BS2_E3));
+    p = fma2(p, f, splat2(BH_BS2_E2));
+    p = fma2(p, f, splat2(BH_BS2_E1));
+    p = fma2(p, f, splat2(BH_BS2_E0));
+    // 2^n by adding n to the exponent field: n sits in the low mantissa bits of t, and the low nine bits of the magic constant are zero,
+    // so (bits(t) << 23) IS n << 23 (mod 2^32)
+    float2_t r;
+    r.x = __uint_as_float(__float_as_uint(p.x) + (__float_as_uint(t.x) << 23));
+    r.y = __uint_as_float(__float_as_uint(p.y) + (__float_as_uint(t.y) << 23));
+    return r;
+}
+__device__ __forceinline__ float bs2_exp1(float x) { return bs2_exp2(float2_t{x, x}).x; }
+
+// ln v of a positive normal fp32: oracle_bs2_log, operation for operation
+__device__ __forceinline__ float bs2_log(float v) {
+    const unsigned u = __float_as_uint(v);
+    int e = (int)(u >> 23) - 127;
+    float m = __uint_as_float((u & 0x007fffffu) | 0x3f800000u);
+    const bool hi = m > BH_BS2_SQRT2;
+    m = hi ? m * 0.5f : m;
+    e = hi ? e + 1 : e;
+    const float z = m - 1.0f;
+    float q = BH_BS2_L7;
+    q = __fmaf_rn(q, z, BH_BS2_L6);
+    q = __fmaf_rn(q, z, BH_BS2_L5);
+    q = __fmaf_rn(q, z, BH_BS2_L4);
+    q = __fmaf_rn(q, z, BH_BS2_L3);
+    q = __fmaf_rn(q, z, BH_BS2_L2);
+    q = __fmaf_rn(q, z, BH_BS2_L1);
+    q = __fmaf_rn(q, z, BH_BS2_L0);
+    return __fmaf_rn((float)e, BH_BS2_LN2, __fmul_rn(z, q));
+}
+
+struct Bs2Args {
+    const half_t* scores;  // [N][T][4S]
+    float* b;              // [N][T+1][S] the linear-domain guide, every row scaled by a power of two (maximum in [1, 2))
+    int N, T;
+    float blank;
+    int nt;
+};
+
+constexpr int BS2_R = 4;       // score rows per staged block of the backward scan (two blocks resident)
+
+template <int STATE_LEN>
+struct Bs2Geo {
+    static constexpr int S = 1 << (2 * STATE_LEN), Q = S / 4;
+    static constexpr int TPC = Q < 64 ? 64 : Q;          // threads per chunk: one lane per group of four states
+    static constexpr int WPC = TPC / 64;                 // waves per chunk (4 at 1024 states, else 1)
+    static constexpr int CPB = 256 / TPC;                // chunks per workgroup of 256 threads
+    static constexpr int ROW = 4 * S * 2;                // bytes of a score row
+    static constexpr int CHUNK_LDS = 2 * BS2_R * ROW + 2 * S * 4 + 64;      // staged rows, b ping-pong, wave maxima
+};
+
+template <int STATE_LEN>
+__global__ __launch_bounds__(256) void bs2_backward_kernel(Bs2Args p) {
+    using G = Bs2Geo<STATE_LEN>;
+    constexpr int S = G::S, Q = G::Q, WPC = G::WPC;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int T = p.T;
+    const int slot = threadIdx.x / G::TPC, m_raw = threadIdx.x - slot * G::TPC;
+    const int lane = threadIdx.x & 63, wv = m_raw >> 6;
+    const int n = blockIdx.x * G::CPB + slot;
+    const bool live = n < p.N;
+    const int nn = live ? n : p.N - 1;                    // (a slot beyond the batch keeps the barriers company and stores nothing)
+    const bool act = m_raw < Q;
+    const int m = act ? m_raw : Q - 1;
+    char* mine = smem + (size_t)slot * G::CHUNK_LDS;
+    half_t* rows = (half_t*)mine;                         // [2][BS2_R][4S]
+    float* pb = (float*)(mine + 2 * BS2_R * G::ROW);      // [2][S]
+    float* mxs = pb + 2 * S;                              // [2][4] per-wave maxima (WPC > 1)
+    const half_t* sc = p.scores + (long)nn * T * 4 * S;
+    float* bn = p.b + (long)nn * (T + 1) * S;
+    const float eb = bs2_exp1(p.blank);
+
+    // step u = 0 .. T-1 handles row t = T-1-u; block k = steps k*R .. k*R+R-1 in buffer k & 1, slot r = u - k*R
+    auto stage = [&](int k) {
+        const int u0 = k * BS2_R, nr = min(BS2_R, T - u0);
+        char* dst = (char*)(rows + (size_t)(k & 1) * BS2_R * 4 * S);
+        constexpr int n16 = S / 2;                        // 16-byte pieces per row
+        for (int r = 0; r < nr; ++r) {
+            const char* src = (const char*)(sc + (long)(T - 1 - (u0 + r)) * 4 * S);
+#pragma unroll
+            for (int i0 = 0; i0 < n16; i0 += G::TPC) {
+                const int piece = i0 + wv * 64 + lane;     // this wave's 1 KiB of the row: pieces [i0 + 64 wv, +64)
+                if (i0 + wv * 64 < n16 && piece < n16) {
+                    if (p.nt) dma16_nt(src + (long)piece * 16, dst + (size_t)r * G::ROW + (size_t)(i0 + wv * 64) * 16);
+                    else dma16(src + (long)piece * 16, dst + (size_t)r * G::ROW + (size_t)(i0 + wv * 64) * 16);
+                }
+            }
+        }
+    };
+    // b_T = 1 (its maximum is 1: scale 2^0)
+    if (act) {
+#pragma unroll
+        for (int l = 0; l < 4; ++l) pb[m + l * Q] = 1.0f;
+    }
+    if (WPC > 1 && m_raw < 4) mxs[m_raw] = 1.0f;
+    if (WPC == 1 && act && live) {
+#pragma unroll
+        for (int l = 0; l < 4; ++l) bn[(long)T * S + m + l * Q] = 1.0f;
+    }
+    if (T > 0) stage(0);
+    int cur = 0;
+    const int nblk = (T + BS2_R - 1) / BS2_R;
+    for (int k = 0; k < nblk; ++k) {
+        const int u0 = k * BS2_R, nr = min(BS2_R, T - u0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // block k has landed
+        if (WPC > 1) __syncthreads();                               // ... for every wave of the chunk, and block k-1 is consumed
+        if (k + 1 < nblk) stage(k + 1);
+        const half_t* blk = rows + (size_t)(k & 1) * BS2_R * 4 * S;
+        for (int r = 0; r < nr; ++r) {
+            const int t = T - 1 - (u0 + r);
+            const float* prev = pb + cur * S;
+            const uint4_t w0 = *(const uint4_t*)(blk + (size_t)r * 4 * S + 16 * m);
+            const uint4_t w1 = *(const uint4_t*)(blk + (size_t)r * 4 * S + 16 * m + 8);
+            float4_t succ = *(const float4_t*)(prev + 4 * m);
+            float own[4];
+#pragma unroll
+            for (int l = 0; l < 4; ++l) own[l] = prev[m + l * Q];
+            if (WPC > 1) {
+                // the previous step left its values unscaled: its row maximum is known only behind the barrier
+                const float4_t mv = *(const float4_t*)(mxs + cur * 4);
+                const float mx = fmaxf(fmaxf(mv.x, mv.y), fmaxf(mv.z, mv.w));
+                const unsigned eb23 = ((__float_as_uint(mx) >> 23) - 127u) << 23;
+#pragma unroll
+                for (int l = 0; l < 4; ++l) own[l] = __uint_as_float(__float_as_uint(own[l]) - eb23);
+#pragma unroll
+                for (int x = 0; x < 4; ++x) succ[x] = __uint_as_float(__float_as_uint(succ[x]) - eb23);
+                if (act && live) {                                  // ... which makes them row t+1 of the guide
+#pragma unroll
+                    for (int l = 0; l < 4; ++l) {
+                        if (p.nt) __builtin_nontemporal_store(own[l], bn + (long)(t + 1) * S + m + l * Q);
+                        else bn[(long)(t + 1) * S + m + l * Q] = own[l];
+                    }
+                }
+            }
+            // the lane's 16 scores: word j of (w0, w1) holds successor x = j / 2, leads 2 (j & 1) and 2 (j & 1) + 1
+            const unsigned w[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+            float2_t acc01, acc23;                                  // raw[lead 0, 1], raw[lead 2, 3]
+            acc01 = fma2(splat2(eb), float2_t{own[0], own[1]}, splat2(BH_BS2_TINY));
+            acc23 = fma2(splat2(eb), float2_t{own[2], own[3]}, splat2(BH_BS2_TINY));
+#pragma unroll
+            for (int x = 0; x < 4; ++x) {
+                const half2_t h01 = __builtin_bit_cast(half2_t, w[2 * x]), h23 = __builtin_bit_cast(half2_t, w[2 * x + 1]);
+                const float2_t e01 = bs2_exp2(float2_t{(float)h01.x, (float)h01.y});
+                const float2_t e23 = bs2_exp2(float2_t{(float)h23.x, (float)h23.y});
+                acc01 = fma2(e01, splat2(succ[x]), acc01);
+                acc23 = fma2(e23, splat2(succ[x]), acc23);
+            }
+            float raw[4] = {acc01.x, acc01.y, acc23.x, acc23.y};
+            float mx = act ? fmaxf(fmaxf(raw[0], raw[1]), fmaxf(raw[2], raw[3])) : 0.0f;
+            mx = wave_max_pos(mx);
+            float* nextb = pb + (cur ^ 1) * S;
+            if (WPC > 1) {
+                if (lane == 0) mxs[(cur ^ 1) * 4 + wv] = mx;
+                if (act) {
+#pragma unroll
+                    for (int l = 0; l < 4; ++l) nextb[m + l * Q] = raw[l];
+                }
+                __syncthreads();
+            } else {
+                const unsigned eb23 = ((__float_as_uint(mx) >> 23) - 127u) << 23;
+#pragma unroll
+                for (int l = 0; l < 4; ++l) raw[l] = __uint_as_float(__float_as_uint(raw[l]) - eb23);
+                if (act) {
+#pragma unroll
+                    for (int l = 0; l < 4; ++l) nextb[m + l * Q] = raw[l];
+                    if (live) {
+#pragma unroll
+                        for (int l = 0; l < 4; ++l) {
+                            if (p.nt) __builtin_nontemporal_store(raw[l], bn + (long)t * S + m + l * Q);
+                            else bn[(long)t * S + m + l * Q] = raw[l];
+                        }
+                    }
+                }
+            }
+            cur ^= 1;
+        }
+    }
+    if (WPC > 1 && act && live) {          // row 0: scale and store what the last step left
+        const float* prev = pb + cur * S;
+        const float4_t mv = *(const float4_t*)(mxs + cur * 4);
+        const float mx = fmaxf(fmaxf(mv.x, mv.y), fmaxf(mv.z, mv.w));
+        const unsigned eb23 = ((__float_as_uint(mx) >> 23) - 127u) << 23;
+#pragma unroll
+        for (int l = 0; l < 4; ++l) bn[m + l * Q] = __uint_as_float(__float_as_uint(prev[m + l * Q]) - eb23);
+    }
+}
+
 // STATE_LEN is a template parameter so that every LDS region sits at a constant offset (immediate DS offsets, no address
 // arithmetic or scalar registers spent on them); DBG compiles the per-section cycle counters in.
 // One wave per chunk, CPW chunks (waves) per workgroup: the waves share nothing but the 16 KiB lse table - each has its own
@@ -674,59 +797,192 @@ constexpr int BEAM_TAB_LDS = (BH_LSE_TABLE_SIZE + 2) * 4;
 // LDS of one fused scan wave: alpha~ ping-pong [2][S]
 template <int STATE_LEN>
 __host__ __device__ constexpr int scan_wave_lds() { return 2 * (1 << (2 * STATE_LEN)) * 4 + 64; }
-// The forward / posterior scan of crf_forward_post_kernel as ONE wave beside the beam wave of the same chunk (FUSE): it reads
-// the score rows and guide rows from the LDS blocks the beam wave stages anyway, so the score tensor and the guide are read
-// from HBM once for both (2.63 GB of 7.9 GB per hac batch gone, one kernel and its launch gone). Lane l owns the states
-// [l * SPL, (l + 1) * SPL), SPL = S / 64: alpha~ lives in a private LDS ping-pong (one wave: LDS operations complete in issue
-// order, no barrier inside a step), every state runs exactly the recurrence of crf_forward_post_kernel (same operations in the
-// same order -> the same alpha~), only the order of the fp32 class sums differs (q-scores are a tolerance-level output).
+// wave-wide sum; the total ends up in lane 63 and is broadcast from there
+__device__ __forceinline__ float wave_sum_f32(float v) {
+    v += dpp_f<0xB1, 0xF>(v);      // quad_perm [1,0,3,2]
+    v += dpp_f<0x4E, 0xF>(v);      // quad_perm [2,3,0,1]
+    v += dpp_f<0x124, 0xF>(v);     // row_ror:4
+    v += dpp_f<0x128, 0xF>(v);     // row_ror:8   -> every lane holds its row's sum
+    const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 15));
+    const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 31));
+    const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 47));
+    const float r4 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+    return (r1 + r2) + (r3 + r4);
+}
+
+// One step of the forward / posterior scan in the LINEAR domain (BS-2) for the lane's four states j = 4m .. 4m+3 (classes 0 .. 3):
+//     a'[j] = e^blank a[j] + sum_r e^{score[j][r]} a[r S/4 + m]            (the four states share their four predecessors)
+//     pv[j] = a'[j] b_{t+1}[j]                                              (b = the guide row, linear)
+// Returns a' (unscaled) in anew and the lane's class products in pv. Nothing here feeds the search - the class posteriors are a
+// tolerance-level output (q-scores within 1e-3 of an fp64 scan) - so the exponentials are the hardware's (v_exp_f32).
 template <int STATE_LEN>
-__device__ __forceinline__ void scan_step(const BeamArgs& p, const half_t* row, const float* bnext, float* ap, float* an, const float* tab,
-                                          int lane, double& A, double lz, double Bt, float* Pt) {
-    constexpr int S = 1 << (2 * STATE_LEN);
-    constexpr int SPL = S >= 64 ? S / 64 : 1, q = S >> 2;
-    const bool active = S >= 64 || lane < S;
-    const float ref = ap[0];
-    float acc[SPL];
+__device__ __forceinline__ void scan_lin_lane(float ebl, const half_t* row, const float* ap, float4_t bnext4, int m, float (&anew)[4],
+                                              float (&pv)[4]) {
+    constexpr int S = 1 << (2 * STATE_LEN), Q = S / 4;
+    const uint4_t w0 = *(const uint4_t*)(row + 16 * m), w1 = *(const uint4_t*)(row + 16 * m + 8);
+    const float4_t own = *(const float4_t*)(ap + 4 * m);
+    float pr[4];
 #pragma unroll
-    for (int k = 0; k < SPL; ++k) {
-        const int j = active ? lane * SPL + k : 0;
-        float a = p.blank + (ap[j] - ref);
+    for (int r = 0; r < 4; ++r) pr[r] = ap[r * Q + m];
+    const unsigned w[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
 #pragma unroll
-        for (int r = 0; r < 4; ++r) a = lse2_scan(a, (float)row[j * 4 + r] + (ap[r * q + (j >> 2)] - ref), tab);
-        acc[k] = a;
+    for (int k = 0; k < 4; ++k) {
+        const half2_t h01 = __builtin_bit_cast(half2_t, w[2 * k]), h23 = __builtin_bit_cast(half2_t, w[2 * k + 1]);
+        float a = __fmaf_rn(ebl, own[k], BH_BS2_TINY);      // (the floor keeps every value a normal number: the rescaling below is exact)
+        a = __fmaf_rn(__expf((float)h01.x), pr[0], a);
+        a = __fmaf_rn(__expf((float)h01.y), pr[1], a);
+        a = __fmaf_rn(__expf((float)h23.x), pr[2], a);
+        a = __fmaf_rn(__expf((float)h23.y), pr[3], a);
+        anew[k] = a;
+        pv[k] = a * bnext4[k];
     }
-    if (active) {
+}
+
+// The forward / posterior scan as ONE wave beside the beam wave of the same chunk (FUSE, <= 256 states): it reads the score rows and the
+// guide rows from the LDS blocks the beam wave stages anyway, so the score tensor and the guide are read from HBM once for both. Lane m
+// < S/4 owns the states 4m .. 4m+3; alpha lives in a private LDS ping-pong (one wave: LDS operations complete in issue order, no
+// barrier inside a step), rescaled every step by the power of two of its maximum.
+template <int STATE_LEN>
+__device__ __forceinline__ void scan_step(float ebl, const half_t* row, const float* bnext, float* ap, float* an, int lane, float* Pt) {
+    constexpr int S = 1 << (2 * STATE_LEN), Q = S / 4;
+    const bool act = lane < Q;
+    const int m = act ? lane : Q - 1;
+    float anew[4], pv[4];
+    scan_lin_lane<STATE_LEN>(ebl, row, ap, *(const float4_t*)(bnext + 4 * m), m, anew, pv);
+    float mx = act ? fmaxf(fmaxf(anew[0], anew[1]), fmaxf(anew[2], anew[3])) : 0.0f;
+    mx = wave_max_f32(mx);
+    const unsigned e23 = ((__float_as_uint(mx) >> 23) - 127u) << 23;
+    if (act) {
+        float4_t o;
 #pragma unroll
-        for (int k = 0; k < SPL; ++k) an[lane * SPL + k] = acc[k];
+        for (int k = 0; k < 4; ++k) o[k] = __uint_as_float(__float_as_uint(anew[k]) - e23);
+        *(float4_t*)(an + 4 * m) = o;
     }
-    A += (double)ref;
-    const float now0 = an[0];
-    const double norm = lz - (A + (double)now0) - Bt;
-    float cls[4] = {0.f, 0.f, 0.f, 0.f};
+    float cls[4];
 #pragma unroll
-    for (int k = 0; k < SPL; ++k) {
-        const int j = active ? lane * SPL + k : 0;
-        const float pv = active ? __expf((float)((double)(acc[k] - now0) + (double)bnext[j] - norm)) : 0.0f;
-        if (SPL >= 4) cls[k & 3] += pv;         // a lane's states cover the four classes evenly
-        else cls[0] = pv;                       // SPL == 1: the class is lane & 3
-    }
-    if (SPL >= 4) {
-#pragma unroll
-        for (int x = 0; x < 4; ++x) {
-            float v = cls[x];
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
-            cls[x] = v;
+    for (int k = 0; k < 4; ++k) cls[k] = wave_sum_f32(act ? pv[k] : 0.0f);
+    const float inv = 1.0f / ((cls[0] + cls[1]) + (cls[2] + cls[3]));
+    if (lane < 4) Pt[lane] = (lane == 0 ? cls[0] : lane == 1 ? cls[1] : lane == 2 ? cls[2] : cls[3]) * inv;
+}
+
+// The same scan as a kernel of its own: 1024 states (four waves per chunk, one barrier per step; "beam_fork" runs it beside the beam
+// kernel on a helper stream) and the "beam_fuse" 0 arrangement of the smaller state spaces. Score rows and guide rows arrive by LDS-DMA
+// in blocks of BS2_FR steps, two blocks resident.
+struct Bs2FwdArgs {
+    const half_t* scores;  // [N][T][4S]
+    const float* b;        // [N][T+1][S] linear guide
+    float* P;              // [N][T][4]
+    int N, T;
+    float blank;
+    int nt;
+};
+constexpr int BS2_FR = 2;
+template <int STATE_LEN>
+struct Bs2FwdGeo {
+    static constexpr int S = 1 << (2 * STATE_LEN), Q = S / 4;
+    static constexpr int TPC = Q < 64 ? 64 : Q, WPC = TPC / 64, CPB = 256 / TPC;
+    static constexpr int ROW = 4 * S * 2, GROW = S * 4;
+    static constexpr int CHUNK_LDS = 2 * BS2_FR * (ROW + GROW) + 2 * S * 4 + 2 * 4 * 4 + 2 * 4 * 4 * 4;     // rows, alpha ping-pong, maxima, class sums
+};
+
+template <int STATE_LEN>
+__global__ __launch_bounds__(256) void bs2_forward_post_kernel(Bs2FwdArgs p) {
+    using G = Bs2FwdGeo<STATE_LEN>;
+    constexpr int S = G::S, Q = G::Q, WPC = G::WPC;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int T = p.T;
+    const int slot = threadIdx.x / G::TPC, m_raw = threadIdx.x - slot * G::TPC;
+    const int lane = threadIdx.x & 63, wv = m_raw >> 6;
+    const int n = blockIdx.x * G::CPB + slot;
+    const bool live = n < p.N;
+    const int nn = live ? n : p.N - 1;
+    const bool act = m_raw < Q;
+    const int m = act ? m_raw : Q - 1;
+    char* mine = smem + (size_t)slot * G::CHUNK_LDS;
+    half_t* rows = (half_t*)mine;                                   // [2][FR][4S]
+    float* grows = (float*)(mine + 2 * BS2_FR * G::ROW);            // [2][FR][S]
+    float* al = grows + 2 * BS2_FR * S;                             // [2][S]
+    float* mxs = al + 2 * S;                                        // [2][4]
+    float* part = mxs + 8;                                          // [2][4 waves][4 classes]
+    const half_t* sc = p.scores + (long)nn * T * 4 * S;
+    const float* bn = p.b + (long)nn * (T + 1) * S;
+    float* Pn = p.P + (long)nn * T * 4;
+    const float ebl = __expf(p.blank);
+    auto dma_row = [&](const char* src, char* dst, int n16) {
+        for (int i0 = 0; i0 < n16; i0 += G::TPC) {
+            const int piece = i0 + wv * 64 + lane;
+            if (i0 + wv * 64 < n16 && piece < n16) {
+                if (p.nt) dma16_nt(src + (long)piece * 16, dst + (size_t)(i0 + wv * 64) * 16);
+                else dma16(src + (long)piece * 16, dst + (size_t)(i0 + wv * 64) * 16);
+            }
         }
-        if (lane < 4) Pt[lane] = lane == 0 ? cls[0] : lane == 1 ? cls[1] : lane == 2 ? cls[2] : cls[3];
-    } else {
-        float v = cls[0];
-        v += dpp_f<0x124, 0xF>(v);     // row_ror:4
-        v += dpp_f<0x128, 0xF>(v);     // row_ror:8
-        v += __shfl_xor(v, 16);
-        v += __shfl_xor(v, 32);
-        if (lane < 4) Pt[lane] = v;
+    };
+    auto stage = [&](int k) {
+        const int t0 = k * BS2_FR, nr = min(BS2_FR, T - t0);
+        for (int r = 0; r < nr; ++r) {
+            dma_row((const char*)(sc + (long)(t0 + r) * 4 * S), (char*)(rows + (size_t)((k & 1) * BS2_FR + r) * 4 * S), S / 2);
+            dma_row((const char*)(bn + (long)(t0 + r + 1) * S), (char*)(grows + (size_t)((k & 1) * BS2_FR + r) * S), S / 4);
+        }
+    };
+    if (act) *(float4_t*)(al + 4 * m) = float4_t{1.0f, 1.0f, 1.0f, 1.0f};
+    if (m_raw < 4) mxs[m_raw] = 1.0f;
+    if (T > 0) stage(0);
+    int cur = 0;
+    const int nblk = (T + BS2_FR - 1) / BS2_FR;
+    for (int k = 0; k < nblk; ++k) {
+        const int t0 = k * BS2_FR, nr = min(BS2_FR, T - t0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (WPC > 1) __syncthreads();
+        if (k + 1 < nblk) stage(k + 1);
+        for (int r = 0; r < nr; ++r) {
+            const int t = t0 + r;
+            const half_t* row = rows + (size_t)((k & 1) * BS2_FR + r) * 4 * S;
+            const float4_t bnext4 = *(const float4_t*)(grows + (size_t)((k & 1) * BS2_FR + r) * S + 4 * m);
+            float anew[4], pv[4];
+            scan_lin_lane<STATE_LEN>(ebl, row, al + cur * S, bnext4, m, anew, pv);
+            float mx = act ? fmaxf(fmaxf(anew[0], anew[1]), fmaxf(anew[2], anew[3])) : 0.0f;
+            mx = wave_max_f32(mx);
+            float cls[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) cls[c] = wave_sum_f32(act ? pv[c] : 0.0f);
+            float* an = al + (cur ^ 1) * S;
+            if (WPC > 1) {
+                // per-wave maxima and class sums meet behind the barrier; the NEXT step rescales what it reads. The rescaling of the
+                // values this step read is folded in here: every wave of the chunk derives the same power of two from mxs[cur].
+                const float4_t mv = *(const float4_t*)(mxs + cur * 4);
+                const float pmx = fmaxf(fmaxf(mv.x, mv.y), fmaxf(mv.z, mv.w));
+                const unsigned pe23 = ((__float_as_uint(pmx) >> 23) - 127u) << 23;      // scale of the row this step read
+                if (act) {
+                    float4_t o;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) o[c] = __uint_as_float(__float_as_uint(anew[c]) - pe23);
+                    *(float4_t*)(an + 4 * m) = o;
+                }
+                if (lane == 0) {
+                    mxs[(cur ^ 1) * 4 + wv] = __uint_as_float(__float_as_uint(mx) - pe23);
+                    *(float4_t*)(part + ((cur ^ 1) * 4 + wv) * 4) = float4_t{cls[0], cls[1], cls[2], cls[3]};
+                }
+                __syncthreads();
+                if (m_raw < 4 && live) {
+                    const float* pp = part + (cur ^ 1) * 16;
+                    float c4[4], tot = 0.0f;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) { c4[c] = (pp[c] + pp[4 + c]) + (pp[8 + c] + pp[12 + c]); tot += c4[c]; }
+                    Pn[(long)t * 4 + m_raw] = (m_raw == 0 ? c4[0] : m_raw == 1 ? c4[1] : m_raw == 2 ? c4[2] : c4[3]) / tot;
+                }
+            } else {
+                const unsigned e23 = ((__float_as_uint(mx) >> 23) - 127u) << 23;
+                if (act) {
+                    float4_t o;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) o[c] = __uint_as_float(__float_as_uint(anew[c]) - e23);
+                    *(float4_t*)(an + 4 * m) = o;
+                }
+                const float inv = 1.0f / ((cls[0] + cls[1]) + (cls[2] + cls[3]));
+                if (lane < 4 && live) Pn[(long)t * 4 + lane] = (lane == 0 ? cls[0] : lane == 1 ? cls[1] : lane == 2 ? cls[2] : cls[3]) * inv;
+            }
+            cur ^= 1;
+        }
     }
 }
 
@@ -755,29 +1011,19 @@ __global__ __launch_bounds__(64 * CPW * (FUSE ? 2 : 1)) __attribute__((amdgpu_wa
     constexpr int SCAN_LDS = scan_wave_lds<STATE_LEN>();
     char* scan_mem = smem + BEAM_TAB_LDS + CPW * beam_wave_lds<STATE_LEN>() + wave * SCAN_LDS;
     if (scan_role) {
-        // ---- forward / posterior scan over the blocks the beam wave stages ---------------------------------------------
+        // ---- forward / posterior scan (linear domain) over the blocks the beam wave stages ---------------------------------
         float* al = (float*)scan_mem;
-        constexpr int SPLz = S >= 64 ? S / 64 : 1;
-        if (S >= 64 || lane < S)
-            for (int k = 0; k < SPLz; ++k) al[lane * SPLz + k] = 0.0f;
-        const double* Bn = p.Bcum + (long)n * (T + 1);
-        const double lz = p.logZ[n];
+        if (lane < S / 4) *(float4_t*)(al + 4 * lane) = float4_t{1.0f, 1.0f, 1.0f, 1.0f};       // alpha_0 = 1
+        const float ebl = __expf(p.blank);
         float* Pn = p.P + (long)n * T * 4;
-        double A = 0.0;
         int cb = 0;
         for (int tb0 = 0, blk = 0; tb0 < T; tb0 += BTB, ++blk) {
             const int nsteps = min(BTB, T - tb0);
-            const double Bmine = lane < nsteps ? Bn[tb0 + lane] : 0.0;       // one fp64 per step, fetched once per block
             __syncthreads();                                                   // block `blk` has landed (beam wave waited for its DMA)
             const half_t* blk_sc = st_sc + (blk & 1) * BTB * 4 * S;
             const float* blk_b = st_b + (blk & 1) * BTB * S;
             for (int u = 0; u < nsteps; ++u) {
-                const unsigned long long bb = (unsigned long long)__double_as_longlong(Bmine);
-                const unsigned lo32 = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)bb, u);
-                const unsigned hi32 = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(bb >> 32), u);
-                const double Bt = __longlong_as_double((long long)(((unsigned long long)hi32 << 32) | lo32));
-                scan_step<STATE_LEN>(p, blk_sc + u * 4 * S, blk_b + u * S, al + cb * S, al + (cb ^ 1) * S, tab, lane, A, lz, Bt,
-                                     Pn + (long)(tb0 + u) * 4);
+                scan_step<STATE_LEN>(ebl, blk_sc + u * 4 * S, blk_b + u * S, al + cb * S, al + (cb ^ 1) * S, lane, Pn + (long)(tb0 + u) * 4);
                 cb ^= 1;
             }
         }
@@ -918,7 +1164,7 @@ __global__ __launch_bounds__(64 * CPW * (FUSE ? 2 : 1)) __attribute__((amdgpu_wa
                 cinfo[i] = cj[i] == 0 ? ce[i] : (ce[i] | (1 << 5) | (x << 6));
                 const int bk = (int)(ch[i] & (NBK - 1));
                 mv[i] = (float)row[s2 * 4 + (es >> sh)];
-                bg[i] = b1[cst[i]];
+                bg[i] = b1[cst[i]];               // linear guide value; its logarithm is taken once the loads have landed
                 ent0[i] = *(const uint4_t*)(tb.ent + bk * BKE);
             }
             const int n_ov = tb.ov_cnt[0];
@@ -964,7 +1210,7 @@ __global__ __launch_bounds__(64 * CPW * (FUSE ? 2 : 1)) __attribute__((amdgpu_wa
             float best = -INFINITY;
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
-                key[i] = cs[i] + bg[i];                  // -inf for absent / folded candidates
+                key[i] = cs[i] + bs2_log(bg[i]);         // -inf for absent / folded candidates (the guide value is always a positive normal)
                 best = fmaxf(best, key[i]);
             }
             best = wave_max_f32(best);
@@ -1249,30 +1495,37 @@ int bh_k_beam_search(const void* scores, int N, int T, int state_len, int beam_w
     auto align = [](size_t x) { return (x + 255) / 256 * 256; };
     char* w = (char*)workspace;
     float* beta = (float*)w;   w += align((size_t)N * (T + 1) * S * sizeof(float));
-    double* Bcum = (double*)w; w += align((size_t)N * (T + 1) * sizeof(double));
-    double* logZ = (double*)w; w += align((size_t)N * sizeof(double));
+    w += align((size_t)N * (T + 1) * sizeof(double));      // (B_t and logZ of the Log-semiring scans: bh_crf_logz / posterior Viterbi share
+    w += align((size_t)N * sizeof(double));                //  this workspace layout; the beam search no longer needs them)
     float* P = (float*)w;      w += align((size_t)N * T * 4 * sizeof(float));
     uint8_t* bp = (uint8_t*)w; w += align((size_t)N * T * 32);
     int* fin = (int*)w;         w += align((size_t)N * sizeof(int));
     long long* dbg = getenv("BH_BEAM_DEBUG") ? (long long*)w : nullptr;
 
-    const bool fuse = g_beam_fuse > 0 || (g_beam_fuse < 0 && S <= 256);
-    ScanArgs sa{(const half_t*)scores, N, T, S, state_len, blank, beta, Bcum, logZ, P, g_decode_nt, 1};
-    const int threads = S < 64 ? 64 : S;
-    const size_t lds_scan = (size_t)(BH_LSE_TABLE_SIZE + 2 + 2 * S + 2 * 16 * 16 + 8) * sizeof(float) + (size_t)2 * 4 * S * 2;
+    const bool fuse = g_beam_fuse != 0 && S <= 256;      // (the scan wave owns four states per lane: up to 256 states)
+    // ---- guide: linear-domain backward scan (BS-2) -------------------------------------------------------------------------------
     {
-        int b_threads = 0;
-        size_t b_lds = 0;
-        backward_geometry(S, N, sa.cpb, b_threads, b_lds);
-        if (b_lds > 64 * 1024) BH_CHECK_HIP(bh_max_lds((const void*)crf_backward_kernel, (int)b_lds));
-        hipLaunchKernelGGL(crf_backward_kernel, dim3((N + sa.cpb - 1) / sa.cpb), dim3(b_threads), b_lds, stream, sa);
-        sa.cpb = 1;
+        Bs2Args a2{(const half_t*)scores, beta, N, T, blank, g_decode_nt};
+        auto launch_bwd = [&](auto kern, int cpb, size_t chunk_lds) -> int {
+            const size_t lds = (size_t)cpb * chunk_lds;
+            if (lds > 64 * 1024) BH_CHECK_HIP(bh_max_lds((const void*)kern, (int)lds));
+            hipLaunchKernelGGL(kern, dim3((N + cpb - 1) / cpb), dim3(256), lds, stream, a2);
+            return 0;
+        };
+        int rc = -2;
+        switch (state_len) {
+            case 1: rc = launch_bwd(bs2_backward_kernel<1>, Bs2Geo<1>::CPB, Bs2Geo<1>::CHUNK_LDS); break;
+            case 2: rc = launch_bwd(bs2_backward_kernel<2>, Bs2Geo<2>::CPB, Bs2Geo<2>::CHUNK_LDS); break;
+            case 3: rc = launch_bwd(bs2_backward_kernel<3>, Bs2Geo<3>::CPB, Bs2Geo<3>::CHUNK_LDS); break;
+            case 4: rc = launch_bwd(bs2_backward_kernel<4>, Bs2Geo<4>::CPB, Bs2Geo<4>::CHUNK_LDS); break;
+            case 5: rc = launch_bwd(bs2_backward_kernel<5>, Bs2Geo<5>::CPB, Bs2Geo<5>::CHUNK_LDS); break;
+        }
+        if (rc) return rc;
     }
-    // The forward/posterior scan and the beam kernel both depend only on the backward scan and both are latency chains over T
-    // (one workgroup / one wave per chunk): run them side by side - the posterior scan on a per-device helper stream forked
-    // from and joined back into the caller's stream with events.
-    // Default: the forward / posterior scan runs as a second wave inside the beam kernel's workgroups (FUSE), sharing the staged
-    // score / guide blocks. "beam_fuse" 0 restores the separate crf_forward_post_kernel (optionally forked onto a helper stream).
+    // The forward / posterior scan and the beam kernel both depend only on the backward scan. Default for <= 256 states: the scan runs as
+    // a second wave inside the beam kernel's workgroups (FUSE), sharing the staged score / guide blocks. Otherwise ("beam_fuse" 0, 1024
+    // states) it is a kernel of its own, and with "beam_fork" it runs BESIDE the beam kernel on a per-device helper stream, forked from
+    // and joined back into the caller's stream with events.
     SideStream* side = fuse ? nullptr : side_stream(S);
     const bool fork = side != nullptr;
     if (fork) {
@@ -1280,14 +1533,27 @@ int bh_k_beam_search(const void* scores, int N, int T, int state_len, int beam_w
         BH_CHECK_HIP(hipStreamWaitEvent(side->stream, side->fork, 0));
     }
     if (!fuse) {
-        if (S <= 256)
-            hipLaunchKernelGGL(crf_forward_post_kernel<true>, dim3(N), dim3(threads), lds_scan, fork ? side->stream : stream, sa);
-        else
-            hipLaunchKernelGGL(crf_forward_post_kernel<false>, dim3(N), dim3(threads), lds_scan, fork ? side->stream : stream, sa);
+        Bs2FwdArgs f2{(const half_t*)scores, beta, P, N, T, blank, g_decode_nt};
+        hipStream_t fs = fork ? side->stream : stream;
+        auto launch_fwd = [&](auto kern, int cpb, size_t chunk_lds) -> int {
+            const size_t lds = (size_t)cpb * chunk_lds;
+            if (lds > 64 * 1024) BH_CHECK_HIP(bh_max_lds((const void*)kern, (int)lds));
+            hipLaunchKernelGGL(kern, dim3((N + cpb - 1) / cpb), dim3(256), lds, fs, f2);
+            return 0;
+        };
+        int rc = -2;
+        switch (state_len) {
+            case 1: rc = launch_fwd(bs2_forward_post_kernel<1>, Bs2FwdGeo<1>::CPB, Bs2FwdGeo<1>::CHUNK_LDS); break;
+            case 2: rc = launch_fwd(bs2_forward_post_kernel<2>, Bs2FwdGeo<2>::CPB, Bs2FwdGeo<2>::CHUNK_LDS); break;
+            case 3: rc = launch_fwd(bs2_forward_post_kernel<3>, Bs2FwdGeo<3>::CPB, Bs2FwdGeo<3>::CHUNK_LDS); break;
+            case 4: rc = launch_fwd(bs2_forward_post_kernel<4>, Bs2FwdGeo<4>::CPB, Bs2FwdGeo<4>::CHUNK_LDS); break;
+            case 5: rc = launch_fwd(bs2_forward_post_kernel<5>, Bs2FwdGeo<5>::CPB, Bs2FwdGeo<5>::CHUNK_LDS); break;
+        }
+        if (rc) return rc;
     }
     if (fork) BH_CHECK_HIP(hipEventRecord(side->join, side->stream));
     BeamArgs ba{(const half_t*)scores, beta, N, T, S, state_len, beam_width, blank, logf(beam_cut), bp, fin, dbg,
-                g_beam_select ? 0.0f : 256.0f / fmaxf(logf(beam_cut), 1e-6f), Bcum, logZ, P, g_decode_nt};
+                g_beam_select ? 0.0f : 256.0f / fmaxf(logf(beam_cut), 1e-6f), P, g_decode_nt};
     // Chunks (waves) per workgroup, measured on MI355X next to the encoder of the same model: four for the narrow state
     // spaces (fast-sized models, three lanes: 1.20e9 -> 1.26e9 samples/s); one for 256 states - two waves per workgroup
     // there cost the hac pipeline 6 % (the 78 KiB workgroups find room beside the recurrent layer's workgroups later).
@@ -1319,8 +1585,6 @@ int bh_k_beam_search(const void* scores, int N, int T, int state_len, int beam_w
             case 7: lrc = launch_beam(beam_kernel<3, 4, true, true>, 4, beam_wave_lds<3>(), scan_wave_lds<3>()); break;
             case 8: lrc = launch_beam(beam_kernel<4, 1, false, true>, 1, beam_wave_lds<4>(), scan_wave_lds<4>()); break;
             case 9: lrc = launch_beam(beam_kernel<4, 1, true, true>, 1, beam_wave_lds<4>(), scan_wave_lds<4>()); break;
-            case 10: lrc = launch_beam(beam_kernel<5, 1, false, true>, 1, beam_wave_lds<5>(), scan_wave_lds<5>()); break;
-            case 11: lrc = launch_beam(beam_kernel<5, 1, true, true>, 1, beam_wave_lds<5>(), scan_wave_lds<5>()); break;
         }
     } else
     switch (state_len * 2 + (dbg ? 1 : 0)) {

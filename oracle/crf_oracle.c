@@ -138,29 +138,34 @@ int oracle_crf_logz(const uint16_t* scores, int N, int T, int state_len, int lay
 }
 
 /* =================================================================================================
- * Beam-search decode ("BS-1").  koi.decode.beam_search (ont-koi==0.5.4, requirements.txt:19; call site
- * bonito/crf/basecall.py:36-40) is a closed third-party dependency: its exact merging / q-score rules are
- * NOT available in /root/reference, so the algorithm below is OUR definition (DESIGN.md "Beam search
- * BS-1"), PARITY UNPINNED against koi; the HIP kernels (bonito_amd/csrc/beam.hip) implement exactly
- * this and are tested against it bit for bit (sequence, moves) / within 1e-3 (q-scores).
+ * Beam-search decode ("BS-2"; round 5, BS-1 = the same search with a Log-semiring table-lse2 guide).  koi.decode.beam_search
+ * (ont-koi==0.5.4, requirements.txt:19; call site bonito/crf/basecall.py:36-40) is a closed third-party dependency: its exact
+ * merging / q-score rules are NOT available in /root/reference, so the algorithm below is OUR definition (DESIGN.md "Beam search
+ * BS-2"), PARITY UNPINNED against koi; the HIP kernels (bonito_amd/csrc/beam.hip) implement exactly this and are tested
+ * against it bit for bit (sequence, moves) / within 1e-3 (q-scores).
  *
  * Scores: fp16 koi layout [N][T][4S]; entry s'*4 + r = move INTO state s' having dropped base r; stay
  * (blank) score is the scalar `blank`.
  *
- *  1. backward guide (Log semiring, deterministic table lse2), normalised by state 0 each step:
- *        raw_T[s] = 0
- *        raw_t[s] = lse2(...lse2(blank + b[s], m_0 + b[s'_0])..., m_3 + b[s'_3]),  b = raw_{t+1} - raw_{t+1}[0]
- *        s'_x = ((s << 2) | x) & (S-1),  m_x = score[t][s'_x*4 + (s >> 2(k-1))]
- *        beta~_t[s] = raw_t[s] - raw_t[0]          stored for t = 0..T          ([T+1][S] fp32)
- *        B_t = sum_{u > t} raw_u[0]   (double)  so that  beta_t[s] = beta~_t[s] + raw_t[0] + B_t
- *  2. forward scan, same normalisation: alpha~_u, A_u; class posteriors
- *        P_u[x] = sum_{s & 3 == x} exp(alpha~_u[s] + beta~_u[s] - (logZ - A_u - B_u)),  u = 1..T
+ *  1. backward guide in the LINEAR domain (oracle_bs2_backward): E = bs2_exp(score) - a deterministic fp32 exponential (polynomial +
+ *     exponent bits, include/bh_bs2.h) - and
+ *        b_T[s] = 1
+ *        raw_t[s] = fma(E_3, b[s'_3], fma(E_2, b[s'_2], fma(E_1, b[s'_1], fma(E_0, b[s'_0], fma(e^blank, b[s], 2^-60))))),  b = b_{t+1}
+ *        s'_x = ((s << 2) | x) & (S-1),  E_x = bs2_exp(score[t][s'_x*4 + (s >> 2(k-1))])
+ *        b_t[s] = raw_t[s] * 2^-e,  e = exponent of max_s raw_t[s]      (an exact scaling: the row's maximum lands in [1, 2))
+ *     stored for t = 0..T ([T+1][S] fp32). Only ratios inside a row matter to the search, so no offsets are kept.
+ *  2. class posteriors P_u[x] = sum_{s & 3 == x} alpha_u[s] beta_u[s] / sum_s alpha_u[s] beta_u[s], u = 1..T: here in fp64 with libm
+ *     (oracle_crf_posteriors_f64 - the TRUE posteriors of the model; the HIP kernels run a linear-domain fp32 scan and are held to
+ *     1e-3 on the q-scores derived from them).
  *  3. beam search over (state, sequence hash): stay / 4 moves per element, merge a move into the stay
- *     that spells the same sequence (lse2), rank by score + beta~_{t+1}[state], cut at best - log(beam_cut),
+ *     that spells the same sequence (table lse2), rank by score + bs2_log(b_{t+1}[state]), cut at best - log(beam_cut),
  *     keep `beam_width` (ties: lower candidate index), slots in candidate-index order.
  *  4. traceback from the best final element; per emitted base x with dwell u = t+1..t':
  *        err = mean_u sum_{y != x} P_u[y];  q = -10 log10(max(err, 1e-10)) * scale + offset, clamped to [1, 50]
  *        qstring = 33 + floor(q + 0.5) at the emitting step.
+ *
+ *  oracle_crf_backward / oracle_crf_forward_post below are the Log-semiring (table lse2) scans of round 1-4: they still define
+ *  bh_crf_logz and the posterior-Viterbi decoder (D1), whose kernels are unchanged.
  * ================================================================================================= */
 #include "../include/bh_lse_table.h"
 static const float LSE_TAB[BH_LSE_TABLE_SIZE] = {BH_LSE_TABLE_VALUES};
@@ -254,6 +259,130 @@ int oracle_crf_forward_post(const uint16_t* scores, int N, int T, int state_len,
     return 0;
 }
 
+/* ---- BS-2: deterministic exp / log (include/bh_bs2.h) and the linear-domain guide scan -------------------------------------------- */
+#include "../include/bh_bs2.h"
+static inline uint32_t f2u(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+static inline float u2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+
+float oracle_bs2_exp(float x) {
+    x = fminf(fmaxf(x, -BH_BS2_XMAX), BH_BS2_XMAX);
+    const float t = fmaf(x, BH_BS2_LOG2E, BH_BS2_MAGIC);
+    const float n = t - BH_BS2_MAGIC;
+    const float f = fmaf(x, BH_BS2_LOG2E, -n);
+    float p = BH_BS2_E5;
+    p = fmaf(p, f, BH_BS2_E4);
+    p = fmaf(p, f, BH_BS2_E3);
+    p = fmaf(p, f, BH_BS2_E2);
+    p = fmaf(p, f, BH_BS2_E1);
+    p = fmaf(p, f, BH_BS2_E0);
+    return u2f(f2u(p) + ((f2u(t) - (uint32_t)BH_BS2_MAGIC_BITS) << 23));
+}
+
+/* ln v for a positive NORMAL fp32 */
+float oracle_bs2_log(float v) {
+    const uint32_t u = f2u(v);
+    int e = (int)(u >> 23) - 127;
+    float m = u2f((u & 0x007fffffu) | 0x3f800000u);
+    if (m > BH_BS2_SQRT2) { m = m * 0.5f; e += 1; }
+    const float z = m - 1.0f;
+    float q = BH_BS2_L7;
+    q = fmaf(q, z, BH_BS2_L6);
+    q = fmaf(q, z, BH_BS2_L5);
+    q = fmaf(q, z, BH_BS2_L4);
+    q = fmaf(q, z, BH_BS2_L3);
+    q = fmaf(q, z, BH_BS2_L2);
+    q = fmaf(q, z, BH_BS2_L1);
+    q = fmaf(q, z, BH_BS2_L0);
+    return fmaf((float)e, BH_BS2_LN2, z * q);
+}
+
+/* b [N][T+1][S] fp32: the linear-domain guide, every row scaled (exactly, by a power of two) so that its maximum lies in [1, 2) */
+int oracle_bs2_backward(const uint16_t* scores, int N, int T, int state_len, float blank, float* b) {
+    const int S = ipow4(state_len), sh = 2 * (state_len - 1);
+    float* raw = (float*)malloc(sizeof(float) * S);
+    if (!raw) return -1;
+    const float eb = oracle_bs2_exp(blank);
+    for (int n = 0; n < N; ++n) {
+        float* bn = b + (size_t)n * (T + 1) * S;
+        for (int s = 0; s < S; ++s) bn[(size_t)T * S + s] = 1.0f;
+        for (int t = T - 1; t >= 0; --t) {
+            const uint16_t* sc = scores + ((size_t)n * T + t) * 4 * S;
+            const float* prev = bn + (size_t)(t + 1) * S;
+            float mx = 0.0f;
+            for (int s = 0; s < S; ++s) {
+                float acc = fmaf(eb, prev[s], BH_BS2_TINY);
+                const int lead = s >> sh;
+                for (int x = 0; x < 4; ++x) {
+                    const int s2 = ((s << 2) | x) & (S - 1);
+                    acc = fmaf(oracle_bs2_exp(h2f(sc[s2 * 4 + lead])), prev[s2], acc);
+                }
+                raw[s] = acc;
+                if (acc > mx) mx = acc;
+            }
+            const uint32_t eb23 = ((f2u(mx) >> 23) - 127u) << 23;          /* exponent of the maximum, in place */
+            for (int s = 0; s < S; ++s) bn[(size_t)t * S + s] = u2f(f2u(raw[s]) - eb23);
+        }
+    }
+    free(raw);
+    return 0;
+}
+
+/* TRUE class posteriors P [N][T][4] (boundary u = t+1 stored at index t): forward and backward in fp64, log domain, libm. */
+int oracle_crf_posteriors_f64(const uint16_t* scores, int N, int T, int state_len, float blank, float* P) {
+    const int S = ipow4(state_len), sh = 2 * (state_len - 1), q = S / 4;
+    double* beta = (double*)malloc(sizeof(double) * (size_t)(T + 1) * S);
+    double* al = (double*)malloc(sizeof(double) * S);
+    double* nx = (double*)malloc(sizeof(double) * S);
+    if (!beta || !al || !nx) { free(beta); free(al); free(nx); return -1; }
+    for (int n = 0; n < N; ++n) {
+        for (int s = 0; s < S; ++s) beta[(size_t)T * S + s] = 0.0;
+        for (int t = T - 1; t >= 0; --t) {
+            const uint16_t* sc = scores + ((size_t)n * T + t) * 4 * S;
+            const double* prev = beta + (size_t)(t + 1) * S;
+            double* cur = beta + (size_t)t * S;
+            for (int s = 0; s < S; ++s) {
+                const int lead = s >> sh;
+                double v[5], m;
+                v[0] = (double)blank + prev[s];
+                m = v[0];
+                for (int x = 0; x < 4; ++x) {
+                    const int s2 = ((s << 2) | x) & (S - 1);
+                    v[1 + x] = (double)h2f(sc[s2 * 4 + lead]) + prev[s2];
+                    if (v[1 + x] > m) m = v[1 + x];
+                }
+                double sum = 0.0;
+                for (int k = 0; k < 5; ++k) sum += exp(v[k] - m);
+                cur[s] = m + log(sum);
+            }
+        }
+        for (int s = 0; s < S; ++s) al[s] = 0.0;
+        for (int t = 0; t < T; ++t) {
+            const uint16_t* sc = scores + ((size_t)n * T + t) * 4 * S;
+            for (int j = 0; j < S; ++j) {
+                double v[5], m;
+                v[0] = (double)blank + al[j];
+                m = v[0];
+                for (int r = 0; r < 4; ++r) {
+                    v[1 + r] = (double)h2f(sc[j * 4 + r]) + al[r * q + (j >> 2)];
+                    if (v[1 + r] > m) m = v[1 + r];
+                }
+                double sum = 0.0;
+                for (int k = 0; k < 5; ++k) sum += exp(v[k] - m);
+                nx[j] = m + log(sum);
+            }
+            double* tmp = al; al = nx; nx = tmp;
+            const double* bu = beta + (size_t)(t + 1) * S;
+            double mx = -INFINITY;
+            for (int s = 0; s < S; ++s) if (al[s] + bu[s] > mx) mx = al[s] + bu[s];
+            double cls[4] = {0, 0, 0, 0}, tot = 0.0;
+            for (int s = 0; s < S; ++s) { const double pv = exp(al[s] + bu[s] - mx); cls[s & 3] += pv; tot += pv; }
+            for (int x = 0; x < 4; ++x) P[((size_t)n * T + t) * 4 + x] = (float)(cls[x] / tot);
+        }
+    }
+    free(beta); free(al); free(nx);
+    return 0;
+}
+
 static inline uint32_t bs_hash0(int s) { return ((uint32_t)s + 1u) * 2654435761u; }
 static inline uint32_t bs_mix(uint32_t h, int x) {
     h = (h ^ ((uint32_t)x + 1u)) * 16777619u;
@@ -276,20 +405,19 @@ int oracle_beam_search(const uint16_t* scores, int N, int T, int state_len, int 
     const int S = ipow4(state_len), sh = 2 * (state_len - 1);
     if (beam_width < 1 || beam_width > BS_MAXW) return -2;
     const int W = beam_width;
-    float* beta = (float*)malloc(sizeof(float) * (size_t)N * (T + 1) * S);
-    double* Bcum = (double*)malloc(sizeof(double) * (size_t)N * (T + 1));
-    double* logZ = (double*)malloc(sizeof(double) * N);
+    float* beta = (float*)malloc(sizeof(float) * (size_t)N * (T + 1) * S);        /* the linear-domain guide b */
     float* P = (float*)malloc(sizeof(float) * (size_t)N * T * 4);
     uint8_t* bp = (uint8_t*)malloc((size_t)T * BS_MAXW);
-    if (!beta || !Bcum || !logZ || !P || !bp) { free(beta); free(Bcum); free(logZ); free(P); free(bp); return -1; }
-    oracle_crf_backward(scores, N, T, state_len, blank, beta, Bcum, logZ);
-    oracle_crf_forward_post(scores, N, T, state_len, blank, beta, Bcum, logZ, P);
+    if (!beta || !P || !bp) { free(beta); free(P); free(bp); return -1; }
+    if (oracle_bs2_backward(scores, N, T, state_len, blank, beta) || oracle_crf_posteriors_f64(scores, N, T, state_len, blank, P)) {
+        free(beta); free(P); free(bp); return -1;
+    }
     const float cut = logf(beam_cut);
     for (int n = 0; n < N; ++n) {
         const float* bn = beta + (size_t)n * (T + 1) * S;
         bs_elem beam[BS_MAXW];
         int nb = 0;
-        /* init: top-W states by beta~_0 (ties: lower state), slots in state order */
+        /* init: top-W states by b_0 (ties: lower state), slots in state order */
         {
             char* used = (char*)calloc(S, 1);
             int take = W < S ? W : S;
@@ -341,7 +469,7 @@ int oracle_beam_search(const uint16_t* scores, int N, int T, int state_len, int 
                 }
             float best = -INFINITY;
             for (int c = 0; c < nc; ++c) {
-                c_key[c] = c_alive[c] ? c_score[c] + b1[c_state[c]] : -INFINITY;
+                c_key[c] = c_alive[c] ? c_score[c] + oracle_bs2_log(b1[c_state[c]]) : -INFINITY;
                 if (c_key[c] > best) best = c_key[c];
             }
             const float thr = best - cut;
@@ -371,7 +499,7 @@ int oracle_beam_search(const uint16_t* scores, int N, int T, int state_len, int 
                 }
             (void)nsel;
         }
-        /* best final element (beta~_T = 0 -> key = score); ties: lower slot */
+        /* best final element (b_T = 1 -> key = score); ties: lower slot */
         int r = 0;
         for (int e = 1; e < nb; ++e) if (bs_ukey(beam[e].score) > bs_ukey(beam[r].score)) r = e;
         int8_t* sq = sequence + (size_t)n * T;
@@ -405,7 +533,7 @@ int oracle_beam_search(const uint16_t* scores, int N, int T, int state_len, int 
             qs[t] = (int8_t)(33 + (int)floorf(qv + 0.5f));
         }
     }
-    free(beta); free(Bcum); free(logZ); free(P); free(bp);
+    free(beta); free(P); free(bp);
     return 0;
 }
 

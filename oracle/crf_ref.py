@@ -242,3 +242,38 @@ def posterior_viterbi_autograd(scores_4s, state_len, blank=2.0):
     torch.logsumexp(alpha, dim=-1).sum().backward()
     post = x.grad + 1e-8
     return viterbi_autograd(post.log().numpy(), state_len).T
+
+
+def bs2_exp(x):
+    f = _lib().oracle_bs2_exp
+    f.restype, f.argtypes = C.c_float, [C.c_float]
+    return float(f(float(x)))
+
+
+def bs2_log(v):
+    f = _lib().oracle_bs2_log
+    f.restype, f.argtypes = C.c_float, [C.c_float]
+    return float(f(float(v)))
+
+
+def bs2_backward(scores, state_len, blank=2.0):
+    """-> b [N,T+1,S] f32: the linear-domain guide of BS-2 (every row scaled by a power of two so that its maximum lies in [1, 2))."""
+    a, bits = _as_half_bits(scores)
+    N, T, _ = a.shape
+    S = 4 ** state_len
+    b = np.zeros((N, T + 1, S), np.float32)
+    rc = _lib().oracle_bs2_backward(bits.ctypes.data_as(C.c_void_p), N, T, int(state_len), C.c_float(blank), b.ctypes.data_as(C.c_void_p))
+    if rc:
+        raise RuntimeError("oracle_bs2_backward failed")
+    return b
+
+
+def posteriors_f64(scores, state_len, blank=2.0):
+    """-> P [N,T,4] f32: the model's true class posteriors at the boundaries u = 1..T (fp64 forward / backward, libm)."""
+    a, bits = _as_half_bits(scores)
+    N, T, _ = a.shape
+    P = np.zeros((N, T, 4), np.float32)
+    rc = _lib().oracle_crf_posteriors_f64(bits.ctypes.data_as(C.c_void_p), N, T, int(state_len), C.c_float(blank), P.ctypes.data_as(C.c_void_p))
+    if rc:
+        raise RuntimeError("oracle_crf_posteriors_f64 failed")
+    return P
