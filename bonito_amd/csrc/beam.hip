@@ -326,13 +326,20 @@ struct BeamArgs {
     int nt;                // non-temporal staging of scores / guide
 };
 
-#ifndef BH_BTB
-#define BH_BTB 1
+// Steps per staged block of the beam kernel; two blocks are resident (the next one streams in under the current one). Round 2 went from four
+// to two (12 KiB less LDS per chunk at 256 states, decode 4.35 -> 3.65 ms per hac batch); round 5: ONE at 256 states and above - a step of
+// a chunk is ~5 k cycles, enough to hide the DMA of the next row, and at 14.1 KiB per chunk eight chunks share a CU (g_beam_cpw): 12.97 ->
+// 8.72 ms per 2048-chunk call. Below 256 states it stays two: there the four beam waves of a workgroup and their shared scan wave meet at
+// one barrier per block, and a barrier per step costs the fast-sized models' pipeline 12 % (2.35 -> 2.65 ms per batch, measured).
+// -DBH_BTB=n forces a depth (experiments).
+template <int STATE_LEN>
+__host__ __device__ constexpr int beam_btb() {
+#ifdef BH_BTB
+    return BH_BTB;
+#else
+    return STATE_LEN >= 4 ? 1 : 2;
 #endif
-constexpr int BTB = BH_BTB;     // steps per staged block; two blocks are resident (the next one streams in under the current one). Round 2 went
-                           // from four to two (12 KiB less LDS per chunk at 256 states, decode 4.35 -> 3.65 ms per hac batch), round 5 to ONE:
-                           // a step of a chunk is ~5 k cycles, enough to hide the DMA of the next row, and at 14.1 KiB per chunk eight
-                           // chunks share a CU (g_beam_cpw): 12.97 -> 8.72 ms per 2048-chunk call. -DBH_BTB=n builds other depths (expt)
+}
 constexpr int MAXW = 32;
 
 __device__ __forceinline__ unsigned bs_hash0(int s) { return ((unsigned)s + 1u) * 2654435761u; }
@@ -606,24 +613,18 @@ __device__ __forceinline__ float2_t bs2_exp2(float2_t x) {
 }
 __device__ __forceinline__ float bs2_exp1(float x) { return bs2_exp2(float2_t{x, x}).x; }
 
-// ln v of a positive normal fp32: oracle_bs2_log, operation for operation
+// ln v of a positive normal fp32: oracle_bs2_log, operation for operation (eleven instructions)
 __device__ __forceinline__ float bs2_log(float v) {
     const unsigned u = __float_as_uint(v);
-    int e = (int)(u >> 23) - 127;
-    float m = __uint_as_float((u & 0x007fffffu) | 0x3f800000u);
-    const bool hi = m > BH_BS2_SQRT2;
-    m = hi ? m * 0.5f : m;
-    e = hi ? e + 1 : e;
-    const float z = m - 1.0f;
-    float q = BH_BS2_L7;
-    q = __fmaf_rn(q, z, BH_BS2_L6);
-    q = __fmaf_rn(q, z, BH_BS2_L5);
+    const float ef = (float)(int)(u >> 23);
+    const float z = __uint_as_float((u & 0x007fffffu) | 0x3f800000u) - 1.0f;
+    float q = BH_BS2_L5;
     q = __fmaf_rn(q, z, BH_BS2_L4);
     q = __fmaf_rn(q, z, BH_BS2_L3);
     q = __fmaf_rn(q, z, BH_BS2_L2);
     q = __fmaf_rn(q, z, BH_BS2_L1);
     q = __fmaf_rn(q, z, BH_BS2_L0);
-    return __fmaf_rn((float)e, BH_BS2_LN2, __fmul_rn(z, q));
+    return __fmaf_rn(ef, BH_BS2_LN2, __fmaf_rn(z, q, BH_BS2_LOGC));
 }
 
 struct Bs2Args {
@@ -636,61 +637,109 @@ struct Bs2Args {
 
 constexpr int BS2_R = 4;       // score rows per staged block of the backward scan (two blocks resident)
 
+// max / sum over the GL lanes of a lane group (GL = 64: the wave, 16: a DPP row, 4: a quad, 1: the lane itself); every lane of the group
+// ends up with the result
+template <int GL>
+__device__ __forceinline__ float group_max(float v) {
+    if constexpr (GL >= 4) {
+        v = fmaxf(v, dpp_f<0xB1, 0xF>(v));     // quad_perm [1,0,3,2]
+        v = fmaxf(v, dpp_f<0x4E, 0xF>(v));     // quad_perm [2,3,0,1]
+    }
+    if constexpr (GL >= 16) {
+        v = fmaxf(v, dpp_f<0x124, 0xF>(v));    // row_ror:4
+        v = fmaxf(v, dpp_f<0x128, 0xF>(v));    // row_ror:8
+    }
+    if constexpr (GL == 64) {
+        v = fmaxf(v, dpp_f<0x142, 0xA>(v));    // row_bcast15 into rows 1 and 3
+        v = fmaxf(v, dpp_f<0x143, 0xC>(v));    // row_bcast31 into rows 2 and 3 -> lane 63 holds the total
+        v = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+    }
+    return v;
+}
+template <int GL>
+__device__ __forceinline__ float group_sum(float v) {
+    if constexpr (GL >= 4) {
+        v += dpp_f<0xB1, 0xF>(v);
+        v += dpp_f<0x4E, 0xF>(v);
+    }
+    if constexpr (GL >= 16) {
+        v += dpp_f<0x124, 0xF>(v);
+        v += dpp_f<0x128, 0xF>(v);
+    }
+    if constexpr (GL == 64) {
+        const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 15));
+        const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 31));
+        const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 47));
+        const float r4 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+        v = (r1 + r2) + (r3 + r4);
+    }
+    return v;
+}
+
+// Geometry of the backward scan. A chunk needs Q = S/4 lanes. Up to 256 states that is at most one wave, and for the small state spaces
+// SEVERAL CHUNKS SHARE A WAVE (16 / 4 / 1 lanes each at 64 / 16 / 4 states): the instruction stream of a step then serves 4 / 16 / 64
+// chunks - with one chunk per wave a 64-state scan cost as many instructions as a 256-state one. At 1024 states a chunk is four waves
+// and one barrier per step. A "unit" is what runs in lockstep: the chunks of one wave, or the waves of one chunk.
 template <int STATE_LEN>
 struct Bs2Geo {
     static constexpr int S = 1 << (2 * STATE_LEN), Q = S / 4;
-    static constexpr int TPC = Q < 64 ? 64 : Q;          // threads per chunk: one lane per group of four states
-    static constexpr int WPC = TPC / 64;                 // waves per chunk (4 at 1024 states, else 1)
-    static constexpr int CPB = 256 / TPC;                // chunks per workgroup of 256 threads
+    static constexpr int GL = Q < 64 ? Q : 64;           // lanes per chunk inside a wave
+    static constexpr int CPWV = 64 / GL;                 // chunks per wave
+    static constexpr int WPC = Q <= 64 ? 1 : Q / 64;     // waves per chunk
+    static constexpr int UT = WPC * 64;                  // threads per unit
+    static constexpr int UPB = CPWV > 1 ? 1 : 256 / UT;  // units per workgroup: 256 threads, but ONE wave where a wave already holds several chunks
+                                                         // (fast-sized models run three batch lanes: small workgroups find room beside the encoder)
+    static constexpr int CPB = UPB * CPWV;               // chunks per workgroup
     static constexpr int ROW = 4 * S * 2;                // bytes of a score row
-    static constexpr int CHUNK_LDS = 2 * BS2_R * ROW + 2 * S * 4 + 64;      // staged rows, b ping-pong, wave maxima
+    static constexpr int PP = CPWV * S / 2;              // 16-byte pieces of one row of every chunk of a unit (128, or 512 at 1024 states)
+    static constexpr int UNIT_LDS = 2 * BS2_R * CPWV * ROW + CPWV * 2 * S * 4 + 64;      // staged rows, b ping-pong per chunk, wave maxima
 };
 
 template <int STATE_LEN>
 __global__ __launch_bounds__(256) void bs2_backward_kernel(Bs2Args p) {
     using G = Bs2Geo<STATE_LEN>;
-    constexpr int S = G::S, Q = G::Q, WPC = G::WPC;
+    constexpr int S = G::S, Q = G::Q, WPC = G::WPC, GL = G::GL, CPWV = G::CPWV;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int T = p.T;
-    const int slot = threadIdx.x / G::TPC, m_raw = threadIdx.x - slot * G::TPC;
-    const int lane = threadIdx.x & 63, wv = m_raw >> 6;
-    const int n = blockIdx.x * G::CPB + slot;
+    const int unit = threadIdx.x / G::UT, tu = threadIdx.x - unit * G::UT;
+    const int lane = threadIdx.x & 63, wv = tu >> 6;
+    const int c = WPC == 1 ? lane / GL : 0;               // chunk inside the wave
+    const int m = WPC == 1 ? lane - c * GL : tu;          // the lane owns the states m + lead * Q
+    const int n0 = (blockIdx.x * G::UPB + unit) * CPWV;   // first chunk of the unit
+    const int n = n0 + c;
     const bool live = n < p.N;
-    const int nn = live ? n : p.N - 1;                    // (a slot beyond the batch keeps the barriers company and stores nothing)
-    const bool act = m_raw < Q;
-    const int m = act ? m_raw : Q - 1;
-    char* mine = smem + (size_t)slot * G::CHUNK_LDS;
-    half_t* rows = (half_t*)mine;                         // [2][BS2_R][4S]
-    float* pb = (float*)(mine + 2 * BS2_R * G::ROW);      // [2][S]
-    float* mxs = pb + 2 * S;                              // [2][4] per-wave maxima (WPC > 1)
-    const half_t* sc = p.scores + (long)nn * T * 4 * S;
+    const int nn = live ? n : p.N - 1;                    // (a slot beyond the batch repeats the last chunk's reads and stores nothing)
+    char* mine = smem + (size_t)unit * G::UNIT_LDS;
+    half_t* rows = (half_t*)mine;                         // [2][BS2_R][CPWV][4S]
+    float* pb = (float*)(mine + 2 * BS2_R * CPWV * G::ROW) + (size_t)c * 2 * S;      // this chunk's [2][S]
+    float* mxs = (float*)(mine + 2 * BS2_R * CPWV * G::ROW) + (size_t)CPWV * 2 * S;  // [2][4] per-wave maxima (WPC > 1)
     float* bn = p.b + (long)nn * (T + 1) * S;
     const float eb = bs2_exp1(p.blank);
 
-    // step u = 0 .. T-1 handles row t = T-1-u; block k = steps k*R .. k*R+R-1 in buffer k & 1, slot r = u - k*R
+    // step u = 0 .. T-1 handles row t = T-1-u; block k = steps k*R .. k*R+R-1 in buffer k & 1, slot r = u - k*R.
+    // One row of all chunks of the unit is PP 16-byte pieces, laid out [chunk][piece] = in piece order: lane l of a DMA moves piece
+    // q = i0 + 64 wv + l, which belongs to chunk q / (S/2).
     auto stage = [&](int k) {
         const int u0 = k * BS2_R, nr = min(BS2_R, T - u0);
-        char* dst = (char*)(rows + (size_t)(k & 1) * BS2_R * 4 * S);
-        constexpr int n16 = S / 2;                        // 16-byte pieces per row
         for (int r = 0; r < nr; ++r) {
-            const char* src = (const char*)(sc + (long)(T - 1 - (u0 + r)) * 4 * S);
+            char* dst = (char*)(rows + (size_t)((k & 1) * BS2_R + r) * CPWV * 4 * S);
+            const long trow = (long)(T - 1 - (u0 + r)) * 4 * S;
 #pragma unroll
-            for (int i0 = 0; i0 < n16; i0 += G::TPC) {
-                const int piece = i0 + wv * 64 + lane;     // this wave's 1 KiB of the row: pieces [i0 + 64 wv, +64)
-                if (i0 + wv * 64 < n16 && piece < n16) {
-                    if (p.nt) dma16_nt(src + (long)piece * 16, dst + (size_t)r * G::ROW + (size_t)(i0 + wv * 64) * 16);
-                    else dma16(src + (long)piece * 16, dst + (size_t)r * G::ROW + (size_t)(i0 + wv * 64) * 16);
-                }
+            for (int i0 = 0; i0 < G::PP; i0 += G::UT) {
+                const int q = i0 + wv * 64 + lane;
+                const int qc = q / (S / 2), qp = q - qc * (S / 2);
+                const int qn = min(n0 + qc, p.N - 1);
+                const char* src = (const char*)(p.scores + (long)qn * T * 4 * S + trow) + (long)qp * 16;
+                if (p.nt) dma16_nt(src, dst + (size_t)(i0 + wv * 64) * 16);
+                else dma16(src, dst + (size_t)(i0 + wv * 64) * 16);
             }
         }
     };
     // b_T = 1 (its maximum is 1: scale 2^0)
-    if (act) {
 #pragma unroll
-        for (int l = 0; l < 4; ++l) pb[m + l * Q] = 1.0f;
-    }
-    if (WPC > 1 && m_raw < 4) mxs[m_raw] = 1.0f;
-    if (WPC == 1 && act && live) {
+    for (int l = 0; l < 4; ++l) pb[m + l * Q] = 1.0f;
+    if (WPC > 1 && tu < 4) mxs[tu] = 1.0f;
+    if (WPC == 1 && live) {
 #pragma unroll
         for (int l = 0; l < 4; ++l) bn[(long)T * S + m + l * Q] = 1.0f;
     }
@@ -702,12 +751,12 @@ __global__ __launch_bounds__(256) void bs2_backward_kernel(Bs2Args p) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // block k has landed
         if (WPC > 1) __syncthreads();                               // ... for every wave of the chunk, and block k-1 is consumed
         if (k + 1 < nblk) stage(k + 1);
-        const half_t* blk = rows + (size_t)(k & 1) * BS2_R * 4 * S;
         for (int r = 0; r < nr; ++r) {
             const int t = T - 1 - (u0 + r);
             const float* prev = pb + cur * S;
-            const uint4_t w0 = *(const uint4_t*)(blk + (size_t)r * 4 * S + 16 * m);
-            const uint4_t w1 = *(const uint4_t*)(blk + (size_t)r * 4 * S + 16 * m + 8);
+            const half_t* row = rows + ((size_t)((k & 1) * BS2_R + r) * CPWV + c) * 4 * S;
+            const uint4_t w0 = *(const uint4_t*)(row + 16 * m);
+            const uint4_t w1 = *(const uint4_t*)(row + 16 * m + 8);
             float4_t succ = *(const float4_t*)(prev + 4 * m);
             float own[4];
 #pragma unroll
@@ -721,7 +770,7 @@ __global__ __launch_bounds__(256) void bs2_backward_kernel(Bs2Args p) {
                 for (int l = 0; l < 4; ++l) own[l] = __uint_as_float(__float_as_uint(own[l]) - eb23);
 #pragma unroll
                 for (int x = 0; x < 4; ++x) succ[x] = __uint_as_float(__float_as_uint(succ[x]) - eb23);
-                if (act && live) {                                  // ... which makes them row t+1 of the guide
+                if (live) {                                         // ... which makes them row t+1 of the guide
 #pragma unroll
                     for (int l = 0; l < 4; ++l) {
                         if (p.nt) __builtin_nontemporal_store(own[l], bn + (long)(t + 1) * S + m + l * Q);
@@ -743,36 +792,31 @@ __global__ __launch_bounds__(256) void bs2_backward_kernel(Bs2Args p) {
                 acc23 = fma2(e23, splat2(succ[x]), acc23);
             }
             float raw[4] = {acc01.x, acc01.y, acc23.x, acc23.y};
-            float mx = act ? fmaxf(fmaxf(raw[0], raw[1]), fmaxf(raw[2], raw[3])) : 0.0f;
-            mx = wave_max_pos(mx);
+            const float mx = group_max<GL>(fmaxf(fmaxf(raw[0], raw[1]), fmaxf(raw[2], raw[3])));
             float* nextb = pb + (cur ^ 1) * S;
             if (WPC > 1) {
                 if (lane == 0) mxs[(cur ^ 1) * 4 + wv] = mx;
-                if (act) {
 #pragma unroll
-                    for (int l = 0; l < 4; ++l) nextb[m + l * Q] = raw[l];
-                }
+                for (int l = 0; l < 4; ++l) nextb[m + l * Q] = raw[l];
                 __syncthreads();
             } else {
                 const unsigned eb23 = ((__float_as_uint(mx) >> 23) - 127u) << 23;
 #pragma unroll
                 for (int l = 0; l < 4; ++l) raw[l] = __uint_as_float(__float_as_uint(raw[l]) - eb23);
-                if (act) {
 #pragma unroll
-                    for (int l = 0; l < 4; ++l) nextb[m + l * Q] = raw[l];
-                    if (live) {
+                for (int l = 0; l < 4; ++l) nextb[m + l * Q] = raw[l];
+                if (live) {
 #pragma unroll
-                        for (int l = 0; l < 4; ++l) {
-                            if (p.nt) __builtin_nontemporal_store(raw[l], bn + (long)t * S + m + l * Q);
-                            else bn[(long)t * S + m + l * Q] = raw[l];
-                        }
+                    for (int l = 0; l < 4; ++l) {
+                        if (p.nt) __builtin_nontemporal_store(raw[l], bn + (long)t * S + m + l * Q);
+                        else bn[(long)t * S + m + l * Q] = raw[l];
                     }
                 }
             }
             cur ^= 1;
         }
     }
-    if (WPC > 1 && act && live) {          // row 0: scale and store what the last step left
+    if (WPC > 1 && live) {          // row 0: scale and store what the last step left
         const float* prev = pb + cur * S;
         const float4_t mv = *(const float4_t*)(mxs + cur * 4);
         const float mx = fmaxf(fmaxf(mv.x, mv.y), fmaxf(mv.z, mv.w));
@@ -789,7 +833,7 @@ __global__ __launch_bounds__(256) void bs2_backward_kernel(Bs2Args p) {
 // keeps the LDS footprint per chunk low enough for several decode kernels and a recurrent layer to be co-resident.)
 template <int STATE_LEN>
 __host__ __device__ constexpr int beam_wave_lds() {
-    constexpr int S = 1 << (2 * STATE_LEN);
+    constexpr int S = 1 << (2 * STATE_LEN), BTB = beam_btb<STATE_LEN>();
     return 2 * (BTB * 4 * S * 2 + BTB * S * 4) + NBK * BKE * 8 + MAXW * (16 + 8 + 8) + (NBK + 4) * 4 + BTB * MAXW;
 }
 constexpr int BEAM_TAB_LDS = (BH_LSE_TABLE_SIZE + 2) * 4;
@@ -841,16 +885,15 @@ __device__ __forceinline__ void scan_lin_lane(float ebl, const half_t* row, cons
 // The forward / posterior scan as ONE wave beside the beam wave of the same chunk (FUSE, <= 256 states): it reads the score rows and the
 // guide rows from the LDS blocks the beam wave stages anyway, so the score tensor and the guide are read from HBM once for both. Lane m
 // < S/4 owns the states 4m .. 4m+3; alpha lives in a private LDS ping-pong (one wave: LDS operations complete in issue order, no
-// barrier inside a step), rescaled every step by the power of two of its maximum.
+// barrier inside a step), rescaled every step by the power of two of its maximum. Below 256 states ONE scan wave serves all chunks of the
+// workgroup (16 / 4 / 1 lanes each, group_max / group_sum over the lanes of a chunk): a 64-state step costs the instructions of a
+// 256-state one, so four chunks share them.
 template <int STATE_LEN>
-__device__ __forceinline__ void scan_step(float ebl, const half_t* row, const float* bnext, float* ap, float* an, int lane, float* Pt) {
-    constexpr int S = 1 << (2 * STATE_LEN), Q = S / 4;
-    const bool act = lane < Q;
-    const int m = act ? lane : Q - 1;
+__device__ __forceinline__ void scan_step(float ebl, const half_t* row, const float* bnext, float* ap, float* an, int m, bool act, float* Pt) {
+    constexpr int S = 1 << (2 * STATE_LEN), Q = S / 4, GL = Q < 64 ? Q : 64;
     float anew[4], pv[4];
     scan_lin_lane<STATE_LEN>(ebl, row, ap, *(const float4_t*)(bnext + 4 * m), m, anew, pv);
-    float mx = act ? fmaxf(fmaxf(anew[0], anew[1]), fmaxf(anew[2], anew[3])) : 0.0f;
-    mx = wave_max_f32(mx);
+    const float mx = group_max<GL>(fmaxf(fmaxf(anew[0], anew[1]), fmaxf(anew[2], anew[3])));
     const unsigned e23 = ((__float_as_uint(mx) >> 23) - 127u) << 23;
     if (act) {
         float4_t o;
@@ -860,9 +903,13 @@ __device__ __forceinline__ void scan_step(float ebl, const half_t* row, const fl
     }
     float cls[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) cls[k] = wave_sum_f32(act ? pv[k] : 0.0f);
+    for (int k = 0; k < 4; ++k) cls[k] = group_sum<GL>(pv[k]);
     const float inv = 1.0f / ((cls[0] + cls[1]) + (cls[2] + cls[3]));
-    if (lane < 4) Pt[lane] = (lane == 0 ? cls[0] : lane == 1 ? cls[1] : lane == 2 ? cls[2] : cls[3]) * inv;
+    if (GL == 1) {
+        if (act) *(float4_t*)Pt = float4_t{cls[0] * inv, cls[1] * inv, cls[2] * inv, cls[3] * inv};
+    } else if (act && m < 4) {
+        Pt[m] = (m == 0 ? cls[0] : m == 1 ? cls[1] : m == 2 ? cls[2] : cls[3]) * inv;
+    }
 }
 
 // The same scan as a kernel of its own: 1024 states (four waves per chunk, one barrier per step; "beam_fork" runs it beside the beam
@@ -986,25 +1033,36 @@ __global__ __launch_bounds__(256) void bs2_forward_post_kernel(Bs2FwdArgs p) {
     }
 }
 
+// scan waves of a fused workgroup: one per chunk at 256 states, one for all chunks below
+template <int STATE_LEN, int CPW, bool FUSE>
+__host__ __device__ constexpr int beam_scan_waves() { return !FUSE ? 0 : (1 << (2 * STATE_LEN)) / 4 >= 64 ? CPW : 1; }
+
 template <int STATE_LEN, int CPW, bool DBG, bool FUSE = false>
-__global__ __launch_bounds__(64 * CPW * (FUSE ? 2 : 1)) __attribute__((amdgpu_waves_per_eu(1, 8))) void beam_kernel(BeamArgs p) {
+__global__ __launch_bounds__(64 * (CPW + beam_scan_waves<STATE_LEN, CPW, FUSE>())) __attribute__((amdgpu_waves_per_eu(1, 8))) void beam_kernel(BeamArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int S = 1 << (2 * STATE_LEN);
     constexpr int sh = 2 * (STATE_LEN - 1);
-    constexpr int NTHR = 64 * CPW * (FUSE ? 2 : 1);
+    constexpr int BTB = beam_btb<STATE_LEN>();
+    constexpr int QS = S / 4, GLS = QS < 64 ? QS : 64;       // scan wave: lanes per chunk
+    constexpr int NTHR = 64 * (CPW + beam_scan_waves<STATE_LEN, CPW, FUSE>());
+    static_assert(!FUSE || QS >= 64 || CPW * QS <= 64, "one scan wave must hold the chunks of the workgroup");
     static_assert(NBK == HBINS, "the selection histogram reuses the bucket fill counters");
     static_assert(beam_wave_lds<STATE_LEN>() % 16 == 0 && BEAM_TAB_LDS % 16 == 0, "LDS regions must stay 16-byte aligned");
     const int T = p.T, W = p.W;
     const int lane = threadIdx.x & 63;
     const int wave_all = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const bool scan_role = FUSE && wave_all >= CPW;
-    const int wave = scan_role ? wave_all - CPW : wave_all;      // chunk slot inside the workgroup
+    // chunk slot inside the workgroup: the wave's own for a beam wave (and for a scan wave at 256 states), per lane group in the shared
+    // scan wave of the smaller state spaces
+    const int slot_raw = !scan_role ? wave_all : QS >= 64 ? wave_all - CPW : lane / GLS;
+    const bool slot_ok = slot_raw < CPW && blockIdx.x * CPW + slot_raw < p.N;
+    const int wave = slot_ok ? slot_raw : 0;
     const int n = blockIdx.x * CPW + wave;
     // LDS carve
     float* tab = (float*)smem;                           // lse table (shared by the waves)
     for (int i = threadIdx.x; i < BH_LSE_TABLE_SIZE; i += NTHR) tab[i] = g_lse_tab[i];
     __syncthreads();
-    if (n >= p.N) return;
+    if (!slot_ok && (!scan_role || QS >= 64)) return;        // (a shared scan wave stays: its other lane groups have chunks)
     char* mine = smem + BEAM_TAB_LDS + wave * beam_wave_lds<STATE_LEN>();
     half_t* st_sc = (half_t*)mine;                       // [2][BTB][4S]
     float* st_b = (float*)(st_sc + 2 * BTB * 4 * S);     // [2][BTB][S]
@@ -1013,7 +1071,8 @@ __global__ __launch_bounds__(64 * CPW * (FUSE ? 2 : 1)) __attribute__((amdgpu_wa
     if (scan_role) {
         // ---- forward / posterior scan (linear domain) over the blocks the beam wave stages ---------------------------------
         float* al = (float*)scan_mem;
-        if (lane < S / 4) *(float4_t*)(al + 4 * lane) = float4_t{1.0f, 1.0f, 1.0f, 1.0f};       // alpha_0 = 1
+        const int sm = QS >= 64 ? lane : lane - (lane / GLS) * GLS;          // the lane owns the states 4 sm .. 4 sm + 3 of its chunk
+        if (slot_ok) *(float4_t*)(al + 4 * sm) = float4_t{1.0f, 1.0f, 1.0f, 1.0f};       // alpha_0 = 1
         const float ebl = __expf(p.blank);
         float* Pn = p.P + (long)n * T * 4;
         int cb = 0;
@@ -1023,7 +1082,7 @@ __global__ __launch_bounds__(64 * CPW * (FUSE ? 2 : 1)) __attribute__((amdgpu_wa
             const half_t* blk_sc = st_sc + (blk & 1) * BTB * 4 * S;
             const float* blk_b = st_b + (blk & 1) * BTB * S;
             for (int u = 0; u < nsteps; ++u) {
-                scan_step<STATE_LEN>(ebl, blk_sc + u * 4 * S, blk_b + u * S, al + cb * S, al + (cb ^ 1) * S, lane, Pn + (long)(tb0 + u) * 4);
+                scan_step<STATE_LEN>(ebl, blk_sc + u * 4 * S, blk_b + u * S, al + cb * S, al + (cb ^ 1) * S, sm, slot_ok, Pn + (long)(tb0 + u) * 4);
                 cb ^= 1;
             }
         }
@@ -1506,19 +1565,18 @@ int bh_k_beam_search(const void* scores, int N, int T, int state_len, int beam_w
     // ---- guide: linear-domain backward scan (BS-2) -------------------------------------------------------------------------------
     {
         Bs2Args a2{(const half_t*)scores, beta, N, T, blank, g_decode_nt};
-        auto launch_bwd = [&](auto kern, int cpb, size_t chunk_lds) -> int {
-            const size_t lds = (size_t)cpb * chunk_lds;
+        auto launch_bwd = [&](auto kern, int cpb, size_t lds, int threads) -> int {
             if (lds > 64 * 1024) BH_CHECK_HIP(bh_max_lds((const void*)kern, (int)lds));
-            hipLaunchKernelGGL(kern, dim3((N + cpb - 1) / cpb), dim3(256), lds, stream, a2);
+            hipLaunchKernelGGL(kern, dim3((N + cpb - 1) / cpb), dim3(threads), lds, stream, a2);
             return 0;
         };
         int rc = -2;
         switch (state_len) {
-            case 1: rc = launch_bwd(bs2_backward_kernel<1>, Bs2Geo<1>::CPB, Bs2Geo<1>::CHUNK_LDS); break;
-            case 2: rc = launch_bwd(bs2_backward_kernel<2>, Bs2Geo<2>::CPB, Bs2Geo<2>::CHUNK_LDS); break;
-            case 3: rc = launch_bwd(bs2_backward_kernel<3>, Bs2Geo<3>::CPB, Bs2Geo<3>::CHUNK_LDS); break;
-            case 4: rc = launch_bwd(bs2_backward_kernel<4>, Bs2Geo<4>::CPB, Bs2Geo<4>::CHUNK_LDS); break;
-            case 5: rc = launch_bwd(bs2_backward_kernel<5>, Bs2Geo<5>::CPB, Bs2Geo<5>::CHUNK_LDS); break;
+            case 1: rc = launch_bwd(bs2_backward_kernel<1>, Bs2Geo<1>::CPB, (size_t)Bs2Geo<1>::UPB * Bs2Geo<1>::UNIT_LDS, Bs2Geo<1>::UPB * Bs2Geo<1>::UT); break;
+            case 2: rc = launch_bwd(bs2_backward_kernel<2>, Bs2Geo<2>::CPB, (size_t)Bs2Geo<2>::UPB * Bs2Geo<2>::UNIT_LDS, Bs2Geo<2>::UPB * Bs2Geo<2>::UT); break;
+            case 3: rc = launch_bwd(bs2_backward_kernel<3>, Bs2Geo<3>::CPB, (size_t)Bs2Geo<3>::UPB * Bs2Geo<3>::UNIT_LDS, Bs2Geo<3>::UPB * Bs2Geo<3>::UT); break;
+            case 4: rc = launch_bwd(bs2_backward_kernel<4>, Bs2Geo<4>::CPB, (size_t)Bs2Geo<4>::UPB * Bs2Geo<4>::UNIT_LDS, Bs2Geo<4>::UPB * Bs2Geo<4>::UT); break;
+            case 5: rc = launch_bwd(bs2_backward_kernel<5>, Bs2Geo<5>::CPB, (size_t)Bs2Geo<5>::UPB * Bs2Geo<5>::UNIT_LDS, Bs2Geo<5>::UPB * Bs2Geo<5>::UT); break;
         }
         if (rc) return rc;
     }
@@ -1561,7 +1619,7 @@ int bh_k_beam_search(const void* scores, int N, int T, int state_len, int beam_w
         const size_t lds_beam = (size_t)BEAM_TAB_LDS + cpw * (wave_lds + scan_lds);
         if (lds_beam > 64 * 1024)
             BH_CHECK_HIP(bh_max_lds((const void*)kern, (int)lds_beam));
-        hipLaunchKernelGGL(kern, dim3((N + cpw - 1) / cpw), dim3(64 * cpw * (scan_lds ? 2 : 1)), lds_beam, stream, ba);
+        hipLaunchKernelGGL(kern, dim3((N + cpw - 1) / cpw), dim3(64 * (cpw + (!scan_lds ? 0 : S >= 256 ? cpw : 1))), lds_beam, stream, ba);
         return 0;
     };
     int lrc = -2;

@@ -278,22 +278,18 @@ float oracle_bs2_exp(float x) {
     return u2f(f2u(p) + ((f2u(t) - (uint32_t)BH_BS2_MAGIC_BITS) << 23));
 }
 
-/* ln v for a positive NORMAL fp32 */
+/* ln v for a positive NORMAL fp32 (absolute error ~1e-5: include/bh_bs2.h) */
 float oracle_bs2_log(float v) {
     const uint32_t u = f2u(v);
-    int e = (int)(u >> 23) - 127;
-    float m = u2f((u & 0x007fffffu) | 0x3f800000u);
-    if (m > BH_BS2_SQRT2) { m = m * 0.5f; e += 1; }
-    const float z = m - 1.0f;
-    float q = BH_BS2_L7;
-    q = fmaf(q, z, BH_BS2_L6);
-    q = fmaf(q, z, BH_BS2_L5);
+    const float ef = (float)(int)(u >> 23);                         /* biased exponent field; the bias sits in BH_BS2_LOGC */
+    const float z = u2f((u & 0x007fffffu) | 0x3f800000u) - 1.0f;    /* mantissa - 1 in [0, 1) */
+    float q = BH_BS2_L5;
     q = fmaf(q, z, BH_BS2_L4);
     q = fmaf(q, z, BH_BS2_L3);
     q = fmaf(q, z, BH_BS2_L2);
     q = fmaf(q, z, BH_BS2_L1);
     q = fmaf(q, z, BH_BS2_L0);
-    return fmaf((float)e, BH_BS2_LN2, z * q);
+    return fmaf(ef, BH_BS2_LN2, fmaf(z, q, BH_BS2_LOGC));
 }
 
 /* b [N][T+1][S] fp32: the linear-domain guide, every row scaled (exactly, by a power of two) so that its maximum lies in [1, 2) */
