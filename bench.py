@@ -88,6 +88,9 @@ def parse(argv=None):
                          "decode kernels of 2048 chunks pack the CUs better); 1 = one batch per call (lstm_layer_wgx_kernel). Needs "
                          "--steps divisible by it, otherwise the largest divisor among 4, 2, 1 is used.")
     ap.add_argument("--warmup-seconds", type=float, default=1.5, help="the warm-up also lasts at least this long")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="plumbing check without a device (tests/test_bench_cpu.py): ranks, rendezvous (gloo), barrier, MAX-reduce and the JSON "
+                         "contract of an N-rank launch, with a sleep in place of the hot path; the line says \"data\": \"dry-run\" and is not a measurement")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-side-legs", action="store_true", help="skip per_call_1 and other_configs (child runs use this)")
     ap.add_argument("--no-h2d-leg", action="store_true", help="skip the second timed region (H2D inside the step)")
@@ -392,6 +395,46 @@ def spawn_ranks(n):
     return 1 if any(rcs) else 0
 
 
+def dry_run(a, json_out):
+    """`--dry-run`: everything of an N-rank launch that is not device work - the environment contract of the launcher (RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_*), the rendezvous, the barriers that bracket the timed region, the MAX-reduce of the elapsed time, rank 0's one
+    JSON line. The hot path is a sleep; the line is marked and is not a measurement."""
+    import torch.distributed as dist
+    from bonito_amd import parallel
+    rank, world, local = parallel.init("gloo")
+    if world != a.gpus:
+        raise SystemExit("bench.py: --gpus %d but the launcher started %d rank(s)" % (a.gpus, world))
+    sys.stderr.write("bench.py: dry run, rank %d/%d (local %d)\n" % (rank, world, local))
+    step_s = 2e-3
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(a.warmup):
+        time.sleep(step_s)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        time.sleep(step_s)
+    barrier()
+    elapsed = parallel.max_over_ranks(time.perf_counter() - t0, device="cpu")
+    if rank == 0:
+        samples = a.batch * a.chunk * a.steps * world
+        json_out.write(json.dumps({
+            "metric": "signal samples/sec/GPU (chunk=10000, batch=512) + read accuracy vs ref", "value": samples / elapsed,
+            "unit": "samples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * elapsed / a.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "dry-run",
+            "config": {"workload": "DRY RUN: a %.0f ms sleep per step in place of the hot path - plumbing only" % (1e3 * step_s),
+                       "parallelism": "replicas x%d (shard-by-read, no collective)" % world},
+            "per_gpu": samples / elapsed / world, "roofline": None, "cpu_baseline": None, "dry_run": True}) + "\n")
+        json_out.flush()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0
+
+
 def main():
     a = parse()
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -404,6 +447,8 @@ def main():
     import torch
     import torch.distributed as dist
     from bonito_amd import parallel
+    if a.dry_run:
+        return dry_run(a, json_out)
     assert torch.cuda.is_available(), "bench.py needs a HIP device; there is no CPU fallback"
     ndev = torch.cuda.device_count()
     # one process per GPU; RCCL only for barrier + MAX-reduce. More ranks than GPUs (a 1-GPU test box running `--gpus 2`):

@@ -83,24 +83,32 @@ def launch(args, argv):
         env["PYTHONPATH"] = pkg_root + (os.pathsep + env["PYTHONPATH"] if env.get("PYTHONPATH") else "")
         procs.append(subprocess.Popen([sys.executable, "-m", "bonito_amd", "basecaller", *child_argv], env=env,
                                       stdout=None if rank == 0 else subprocess.DEVNULL))
-    # a worker that dies would leave the others waiting for it in the record merge: poll, and take the rest down with it
+    # A worker other than rank 0 that dies does not take the run down: rank 0 keeps the records it had received from it and basecalls
+    # the rest of that worker's shard itself (parallel.ordered_records, `rescue`), the other workers carry on. Rank 0 is the writer:
+    # if IT fails, the rest is taken down with it.
     import time
     rcs = [None] * len(procs)
     while any(rc is None for rc in rcs):
         for i, pr in enumerate(procs):
             if rcs[i] is None:
                 rcs[i] = pr.poll()
-        if any(rc not in (None, 0) for rc in rcs):
+                if rcs[i] not in (None, 0) and i != 0:
+                    sys.stderr.write("> warning: worker rank %d (device %s) exited with code %d: rank 0 takes over its reads\n"
+                                     % (i, devices[i], rcs[i]))
+        if rcs[0] not in (None, 0):
             for i, pr in enumerate(procs):
                 if rcs[i] is None:
                     pr.terminate()
                     rcs[i] = pr.wait()
             break
         time.sleep(0.05)
+    if rcs[0] != 0:
+        sys.stderr.write("> error: the writing worker (rank 0) failed with code %s\n" % rcs[0])
+        return 1
     bad = [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
     if bad:
-        sys.stderr.write("> error: worker(s) failed: %s\n" % ", ".join("rank %d rc %d" % b for b in bad))
-        return 1
+        sys.stderr.write("> warning: completed WITHOUT %s; every read was basecalled and written\n"
+                         % ", ".join("rank %d (rc %d)" % b for b in bad))
     return 0
 
 
@@ -155,38 +163,58 @@ def main(args, argv=None):
                   do_trim=not args.no_trim) if args.device_ingest else None    # int16 reads: pA scaling, normalisation, trim, chunking on the GPU
     import importlib
     records_fn = getattr(importlib.import_module(basecall.__module__), "basecall_records", None)
-    if records_fn is not None:
-        # CRF family: stitching, string compaction and the record text of a read are ONE library call (crf/basecall.py
-        # records_from_planes); the triples are what io.format_record makes of basecall()'s results, byte for byte
-        records = records_fn(model, reads, mode, reverse=args.revcomp, rna=args.rna, batchsize=bc["batchsize"],
-                             chunksize=bc["chunksize"], overlap=bc["overlap"], lanes=args.lanes, per_call=args.per_call,
-                             min_qscore=args.min_qscore, raw=raw_kw)
-    else:
-        if args.device_ingest:
-            raise SystemExit("> error: --device-ingest needs a CRF model")
+    if records_fn is None and args.device_ingest:
+        raise SystemExit("> error: --device-ingest needs a CRF model")
+
+    def make_records(mdl, rds):
+        if records_fn is not None:
+            # CRF family: stitching, string compaction and the record text of a read are ONE library call (crf/basecall.py
+            # records_from_planes); the triples are what io.format_record makes of basecall()'s results, byte for byte
+            return records_fn(mdl, rds, mode, reverse=args.revcomp, rna=args.rna, batchsize=bc["batchsize"],
+                              chunksize=bc["chunksize"], overlap=bc["overlap"], lanes=args.lanes, per_call=args.per_call,
+                              min_qscore=args.min_qscore, raw=raw_kw)
         names = basecall.__code__.co_varnames
         kw = {"lanes": args.lanes} if args.lanes > 1 and "lanes" in names else {}
-        results = basecall(model, reads, reverse=args.revcomp, rna=args.rna, batchsize=bc["batchsize"],
+        results = basecall(mdl, rds, reverse=args.revcomp, rna=args.rna, batchsize=bc["batchsize"],
                            chunksize=bc["chunksize"], overlap=bc["overlap"], **kw)
-        records = parallel.format_stream(results, mode, args.min_qscore)
+        return parallel.format_stream(results, mode, args.min_qscore)
+
+    records = make_records(model, reads)
+    fault = os.environ.get("BONITO_AMD_FAULT_INJECT", "")          # "rank:count" - that worker dies after `count` records (tests of the
+    if fault and world > 1 and int(fault.split(":")[0]) == rank:    # failure-detection path: tests/test_gpu_basecall.py); never set in production
+        def dying(recs, count=int(fault.split(":")[1])):
+            for k, rec in enumerate(recs):
+                if k == count:
+                    os._exit(7)
+                yield rec
+        records = dying(records)
     t0 = perf_counter()
+    lost_ranks = []
     if world > 1:
-        # every rank formats its own records; rank 0 merges the streams in input order and is the only writer
-        records = parallel.ordered_records(records, rank, world)
+        def rescue(r, k):
+            """Rank r is gone after k records: the rest of ITS shard, from this process - a second engine (own workspace) on this
+            rank's GPU, fed by the same reader shard the dead worker had (records are idempotent and keyed by their index)."""
+            import itertools
+            sys.stderr.write("> warning: rank %d is gone after %d records; rank 0 basecalls the rest of its reads\n" % (r, k))
+            lost_ranks.append(r)
+            m2 = util.load_model(args.model_directory, args.device, weights=args.weights if args.weights > 0 else None,
+                                 chunksize=args.chunksize, overlap=args.overlap, batchsize=args.batchsize,
+                                 quantize=args.quantize, use_koi=True).apply(fuse_bn_)
+            theirs = reader.get_reads(read_ids=read_ids, skip=args.skip, do_trim=not args.no_trim,
+                                      scaling_strategy=model.config.get("scaling"),
+                                      norm_params=model.config.get("standardisation") if pa else model.config.get("normalisation"),
+                                      n_max=args.max_reads or None, raw=args.device_ingest, rank=r, world=world)
+            return make_records(m2, itertools.islice(theirs, k, None))
+
+        # every rank formats its own records; rank 0 merges the streams in input order and is the only writer. The streams end with a
+        # closing message from rank 0 (no barrier: it would wait for a worker that died)
+        records = parallel.ordered_records(records, rank, world, rescue=rescue)
         if rank != 0:
-            import torch.distributed as dist
-            dist.barrier(group=parallel.host_group())
-            dist.destroy_process_group()
             return 0
     writer = Writer(mode, records, fd=out, summary_path=None if args.no_summary else args.summary, preformatted=True)
     writer.start()
     writer.join()
     duration = perf_counter() - t0
-    if world > 1:
-        import torch.distributed as dist
-        if writer.error is None:
-            dist.barrier(group=parallel.host_group())
-            dist.destroy_process_group()
     if writer.error is not None:
         raise writer.error
     num_samples = sum(n for _, n in writer.log)
@@ -194,7 +222,8 @@ def main(args, argv=None):
     sys.stderr.write("> duration: %s\n" % timedelta(seconds=np.round(duration)))
     sys.stderr.write("> samples per second %.1E\n" % (num_samples / max(duration, 1e-9)))
     if world > 1:
-        sys.stderr.write("> devices: %d (one process per GPU, reads sharded round-robin)\n" % world)
+        sys.stderr.write("> devices: %d (one process per GPU, reads sharded round-robin)%s\n"
+                         % (world, "; lost on the way: rank(s) %s" % sorted(set(lost_ranks)) if lost_ranks else ""))
     sys.stderr.write("> done\n")
     return 0
 

@@ -16,6 +16,8 @@ Read chunks are independent (/root/reference bonito/crf/basecall.py:70-72) and t
   waits once that window is full), nothing is held until the end.
   The reference gets its ordering from a single process (bonito/io.py:400-469 consumes one iterator); this is the same
   contract across processes.
+* A rank that dies does not take the run down (round 5): rank 0 keeps what it received from it and produces the rest of that rank's
+  shard itself (`ordered_records(..., rescue=)`); the launcher lets the survivors finish.
 * The only collectives are barriers / a MAX-reduce for timing (bench.py). Nothing per batch.
 """
 import io
@@ -122,7 +124,10 @@ class _Prefetch:
             yield item
 
 
-def ordered_records(local_records, rank=None, world=None, batch=64, group=None, window=32):
+_BYE = "__bonito_amd_bye__"
+
+
+def ordered_records(local_records, rank=None, world=None, batch=64, group=None, window=32, rescue=None, on_rank_lost=None):
     """Merge the per-rank record streams into global input order on rank 0.
 
     `local_records`: this rank's records in ITS order; its k-th record is global record ``rank + k * world`` (what
@@ -130,13 +135,20 @@ def ordered_records(local_records, rank=None, world=None, batch=64, group=None, 
 
     Rank 0: returns a generator over ALL records in global order (record i is pulled from rank i % world's stream; the
     stream of a rank is a sequence of messages of up to `batch` records, the last one flagged). Other ranks: the call
-    sends this rank's records to rank 0 as they are produced and returns an empty iterator when done.
+    sends this rank's records to rank 0 as they are produced, waits for rank 0's closing message and returns an empty iterator.
 
     Back-pressure without stalling the GPUs: on every rank the records are produced by a thread of their own into a queue of at
     most `window` messages (`window * batch` records), so a rank whose send is waiting for rank 0 - because an EARLIER record of a
     slower rank is still missing - keeps basecalling until that window is full, and rank 0's own pipeline keeps running while
     its writer waits for another rank. Nothing is ever held beyond the windows (a run with one rank ten times slower than the
-    others finishes with the same bytes, tests/test_parallel.py)."""
+    others finishes with the same bytes, tests/test_parallel.py).
+
+    A rank that DIES (round 5; SURVEY 5 "failure detection": re-queue on another replica): records are idempotent and keyed by their
+    index, so when rank 0 can no longer receive from rank r it keeps what it has received and takes the rest of r's stream from
+    ``rescue(r, k)`` - an iterator over rank r's records from its k-th on, produced by rank 0's own pipeline (the CLI builds it from
+    the same reader shard and the same model) - instead of taking the run down. `on_rank_lost(r, k, exc)` is told. Without `rescue` the
+    failure propagates as before. The streams end with a closing message from rank 0 to every rank that is still there (no
+    collective: a barrier would wait for the dead)."""
     if rank is None or world is None:
         rank, world, _ = env_rank_world()
     if world == 1:
@@ -155,12 +167,32 @@ def ordered_records(local_records, rank=None, world=None, batch=64, group=None, 
     if rank != 0:
         for msg in _Prefetch(messages(local_records), window):
             _send_obj(msg, 0, group)
+        bye = _recv_obj(0, group)                 # rank 0 has everything (raises if rank 0 is gone)
+        assert bye == _BYE, "unexpected closing message %r" % (bye,)
         return iter(())
 
     def merged():
         local = iter(_Prefetch(local_records, window * batch))
         bufs = [[] for _ in range(world)]        # records received from rank r and not yet emitted
         done = [False] * world
+        got = [0] * world                        # records received from rank r so far
+        lost = [None] * world                    # rank r died: the iterator that stands in for the rest of its stream
+
+        def receive(src):
+            """next message of rank src -> bufs / done; a dead peer switches the stream over to the rescue iterator"""
+            try:
+                recs, last = _recv_obj(src, group)
+            except Exception as exc:             # gloo: connection closed / reset by peer, timeout
+                if rescue is None:
+                    raise
+                if on_rank_lost is not None:
+                    on_rank_lost(src, got[src], exc)
+                lost[src] = iter(rescue(src, got[src]))
+                return
+            bufs[src] = recs
+            got[src] += len(recs)
+            done[src] = last
+
         i = 0
         while True:
             src = i % world
@@ -170,21 +202,31 @@ def ordered_records(local_records, rank=None, world=None, batch=64, group=None, 
                 except StopIteration:
                     break
             else:
-                while not bufs[src] and not done[src]:
-                    recs, last = _recv_obj(src, group)
-                    bufs[src] = recs
-                    done[src] = last
-                if not bufs[src]:
-                    break                        # rank src is exhausted: indices are dense, so nothing follows i
-                yield bufs[src].pop(0)
+                while not bufs[src] and not done[src] and lost[src] is None:
+                    receive(src)
+                if bufs[src]:
+                    yield bufs[src].pop(0)
+                elif lost[src] is not None:
+                    try:
+                        yield next(lost[src])
+                    except StopIteration:
+                        break                    # rank src's shard is exhausted: indices are dense, so nothing follows i
+                else:
+                    break                        # rank src is exhausted
             i += 1
         for r in range(1, world):                # drain the final (possibly empty) messages so no sender is left blocked
-            while not done[r]:
-                recs, last = _recv_obj(r, group)
-                assert not recs or last, "rank %d holds records beyond the end of the stream" % r
-                assert not recs, "rank %d holds records beyond the end of the stream" % r
-                done[r] = last
+            while not done[r] and lost[r] is None:
+                receive(r)
+                assert not bufs[r], "rank %d holds records beyond the end of the stream" % r
+            if lost[r] is not None:
+                assert next(lost[r], None) is None, "rank %d's shard holds records beyond the end of the stream" % r
         assert not any(bufs), "records left over after the merge"
+        for r in range(1, world):
+            if lost[r] is None:
+                try:
+                    _send_obj(_BYE, r, group)
+                except Exception:                # it died after its last message: nothing left to tell it
+                    pass
 
     return merged()
 

@@ -80,3 +80,32 @@ def test_experimental_lstm_flags_never_write_the_product_library(tmp_path):
     r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=env, capture_output=True, text=True)
     lib, obj, flags = r.stdout.strip().split("\n")
     assert lib.endswith("bonito_amd/libbonito_hip.so") and obj.endswith("build/obj") and flags == "None"
+
+
+@pytest.mark.parametrize("launcher", ["self", "torchrun"])
+def test_eight_rank_launch_plumbing_dry_run(launcher):
+    """The driver's 8-GPU run must not fail on plumbing: `bench.py --gpus 8` (its own spawner) and the driver's
+    `python -m torch.distributed.run --nproc-per-node 8 ... bench.py --gpus 8` both rendezvous, barrier, MAX-reduce and print ONE JSON
+    line with n_gpus 8 and the contract's keys. `--dry-run` puts a sleep in place of the hot path (no device here); everything else is
+    the code the real run executes up to the device assertion."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    tail = [os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "6", "--warmup", "2", "--dry-run"]
+    cmd = [sys.executable] + tail if launcher == "self" else [
+        sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+        "--master-port", str(port)] + tail
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=dict(env, OMP_NUM_THREADS="1"))
+    assert r.returncode == 0, r.stderr[-1500:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-500:]
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 8 and j["steps"] == 6 and j["warmup"] == 2 and j["scaling"] == "weak" and j["dry_run"] is True
+    for key in ("metric", "value", "unit", "ms_per_step", "higher_is_better", "vs_baseline", "dtype", "data", "config"):
+        assert key in j
+    assert j["data"] == "dry-run" and j["value"] > 0 and j["ms_per_step"] >= 2.0
+    # whole-job aggregate: eight ranks' samples over the slowest rank's time
+    assert abs(j["value"] - 8 * 512 * 10000 * 6 / (j["ms_per_step"] * 6e-3)) / j["value"] < 1e-6

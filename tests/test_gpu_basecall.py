@@ -1,5 +1,6 @@
 """End-to-end basecall pipeline on the GPU (chunk -> batch -> HIP encoder -> HIP beam search -> stitch)
 against an independent serial restatement that decodes the same HIP scores with the CPU oracle (-m gpu)."""
+import os
 import numpy as np
 import pytest
 import torch
@@ -307,6 +308,31 @@ def test_cli_multi_process_devices_equals_single_device(tmp_path):
         outs.append(("\n".join(l for l in r.stdout.split("\n") if not l.startswith("@PG")), summ.read_text()))
     assert outs[0] == outs[1] and len(outs[0][0].strip().split("\n")) == 36
     assert outs[2] == outs[3] and outs[2][0].startswith("@HD")
+
+
+def test_cli_worker_death_is_absorbed_by_rank_0(tmp_path):
+    """`--devices 0,0,0` with worker rank 1 killed after its second record (BONITO_AMD_FAULT_INJECT): the launcher lets the others
+    finish, rank 0 basecalls the rest of the dead worker's shard on a second engine, and the output is the one-process output (SURVEY 5
+    "failure detection": re-queue on another replica; reference seam bonito/multiprocessing.py:27-33)."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    mdir, rdir = tmp_path / "model", tmp_path / "reads"
+    mdir.mkdir(); rdir.mkdir()
+    _write_model_dir(mdir, fixture="lstm96_sl3")
+    rng = np.random.default_rng(9)
+    for i in range(14):
+        np.save(rdir / ("read%02d.npy" % i), (rng.standard_normal(int(rng.integers(700, 9000))) * 12 + 90).astype(np.float32))
+    outs = []
+    for extra, env in (([], {}), (["--devices", "0,0,0"], {"BONITO_AMD_FAULT_INJECT": "1:2"})):
+        summ = tmp_path / ("summary%d.tsv" % len(outs))
+        r = subprocess.run([sys.executable, "-m", "bonito_amd", "basecaller", str(mdir), str(rdir), "--summary", str(summ),
+                            "--batchsize", "8"] + extra, capture_output=True, text=True, cwd=ROOT, timeout=600, env=dict(os.environ, **env))
+        assert r.returncode == 0, r.stderr[-2000:]
+        assert "completed reads: 14" in r.stderr
+        outs.append((r.stdout, summ.read_text(), r.stderr))
+    assert outs[0][:2] == outs[1][:2] and len(outs[0][0].strip().split("\n")) == 56
+    assert "rank 1 is gone after" in outs[1][2] and "completed WITHOUT rank 1" in outs[1][2]
 
 
 def test_exchange_timeout_surfaces_as_an_exception_never_as_output():

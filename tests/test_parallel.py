@@ -231,3 +231,56 @@ def test_child_device_mask_follows_the_parent_masks():
     for env in ({"HIP_VISIBLE_DEVICES": "4,6"}, {"ROCR_VISIBLE_DEVICES": "2,3"}):
         with pytest.raises(SystemExit):
             child_device_mask(2, env)
+
+
+def _dying_worker(rank, world, port, rdir, mode, victim, after, q):
+    """Rank `victim` dies (os._exit, no goodbye) after producing `after` records; rank 0 re-does the rest of its shard (rescue)."""
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    parallel.init("gloo")
+    rd = reader.Reader(rdir)
+
+    def records_of(r, skip=0):
+        import itertools
+        reads = itertools.islice(rd.get_reads(rank=r, world=world), skip, None)
+        for k, rec in enumerate(parallel.format_stream(fake_basecall(None, reads), mode, 7.0)):
+            if rank == victim and r == rank and skip + k == after:
+                os._exit(3)
+            yield rec
+
+    lost = []
+    records = parallel.ordered_records(records_of(rank), rank, world, batch=2, window=2, rescue=lambda r, k: records_of(r, k),
+                                       on_rank_lost=lambda r, k, exc: lost.append((r, k)))
+    out = None
+    if rank == 0:
+        out = _run_writer(records, mode, True, os.path.join(rdir, "summary_dying.tsv"))
+    else:
+        assert list(records) == []
+    q.put((rank, out, lost))
+
+
+@pytest.mark.parametrize("world,victim,after", [(3, 1, 3), (3, 2, 0), (2, 1, 5)])
+def test_a_rank_that_dies_is_replaced_by_rank_0_and_the_output_is_unchanged(tmp_path, world, victim, after):
+    """SURVEY 5 "failure detection" (re-queue on another replica): a worker is killed in the middle of its stream; rank 0 keeps the
+    records it had received from it, produces the rest of that rank's shard itself and writes the same bytes as a one-rank run; the
+    surviving ranks finish normally (closing message instead of a barrier that would wait for the dead)."""
+    rdir = str(tmp_path)
+    make_reads_dir(rdir)
+    mode = "fastq"
+    want = _run_writer(fake_basecall(None, reader.Reader(rdir).get_reads()), mode, False, os.path.join(rdir, "summary_1.tsv"))
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_dying_worker, args=(r, world, port, rdir, mode, victim, after, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    outs = {}
+    for _ in range(world - 1):                                # the victim never reports
+        rank, out, lost = q.get(timeout=180)
+        outs[rank] = (out, lost)
+    for r, p in enumerate(procs):
+        p.join(timeout=60)
+        assert p.exitcode == (3 if r == victim else 0), (r, p.exitcode)
+    text, summary, log = outs[0][0]
+    assert text == want[0] and summary == want[1] and log == want[2]
+    (lost_rank, k), = outs[0][1]
+    assert lost_rank == victim and k <= after                 # what had arrived is kept; the rest was re-done from record k on
