@@ -112,6 +112,10 @@ def parse(argv=None):
             a.per_call = 2
         elif a.model == "fast" and not a.quantize and a.lanes == 3 and not lanes_given:
             a.per_call = 4
+        elif a.model in ("sup", "sup_lstm") and a.lanes == 1:
+            # 1024 states: the decode is one wave per chunk (a latency chain), two 256-chunk batches decode in the time of one
+            # (round 5: sup 64.1 -> 62.8 ms per batch, sup_lstm 101.3 -> 97.5); what crf/basecall.py batches_per_call picks
+            a.per_call = 2
         else:
             a.per_call = 1
     while a.steps % a.per_call:                       # exactly --steps batches are timed: fall back to a divisor

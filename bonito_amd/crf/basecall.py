@@ -274,6 +274,23 @@ def auto_lanes(model, quantize=False):
 
 
 def batches_per_call(model, batchsize, quantize=False, chunksize=None, lanes=1):
+    """`_batches_per_call_encoder` (what the recurrent kernels want), and for the 1024-state models at least calls of 512 chunks: their
+    decode is ONE wave per chunk on a CU of its own - a latency chain - so two 256-chunk batches decode in the time of one (round 5,
+    bench.py --per-call 2: decode 6.4 -> 4.1 ms per batch of the v5 transformer, 11.3 -> 7.1 of the 1024-wide LSTM; steps 64.1 -> 62.8 and
+    101.3 -> 97.5 ms); bounded by 16 GiB of scores per call."""
+    n = _batches_per_call_encoder(model, batchsize, quantize, chunksize, lanes)
+    seqdist = getattr(model, "seqdist", None)
+    if n == 1 and seqdist is not None and int(getattr(seqdist, "state_len", 0)) >= 5 and int(batchsize) <= 256:
+        want = max(1, 512 // max(1, int(batchsize)))
+        if chunksize:
+            stride = max(1, int(getattr(model, "stride", 1) or 1))
+            per_chunk = (int(chunksize) // stride + 1) * (4 ** (int(seqdist.state_len) + 1)) * 2
+            want = min(want, max(1, (16 << 30) // max(1, per_chunk * int(batchsize))))
+        n = max(1, min(2, want))
+    return n
+
+
+def _batches_per_call_encoder(model, batchsize, quantize=False, chunksize=None, lanes=1):
     """How many `batchsize`-chunk batches one ENGINE call should carry. The reference hands koi one batch per forward
     (crf/basecall.py:70-72) and `batchsize` keeps that meaning for the caller: chunks are independent, so results do not depend on
     how they are grouped (tests). For the 192...512-wide fp16 recurrent layers the engine's kernel carries two rings of 16 chunks

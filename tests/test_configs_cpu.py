@@ -85,4 +85,9 @@ def test_engine_call_size_policy():
     fast = synthetic.make_model("fast", batchsize=16, chunksize=1200)
     assert batches_per_call(fast, 512, chunksize=10000) == 1 and batches_per_call(fast, 512, chunksize=10000, lanes=3) == 4
     assert batches_per_call(synthetic.make_model("sup_lstm", batchsize=16, chunksize=1200), 512, chunksize=10000) == 1
-    assert batches_per_call(synthetic.make_transformer_model(batchsize=16, chunksize=1200), 256, chunksize=12000) == 1
+    # 1024-state models (round 5): calls of 512 chunks - their decode is one wave per chunk, two batches decode in the time of one -
+    # bounded by 16 GiB of scores per call
+    sup = synthetic.make_transformer_model(batchsize=16, chunksize=1200)
+    assert [batches_per_call(sup, b, chunksize=12000) for b in (128, 256, 512)] == [2, 2, 1]
+    assert batches_per_call(sup, 256, chunksize=20000) == 2 and batches_per_call(sup, 256, chunksize=80000) == 1
+    assert batches_per_call(synthetic.make_model("sup_lstm", batchsize=16, chunksize=1200), 256, chunksize=20000) == 2
