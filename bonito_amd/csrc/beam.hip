@@ -856,12 +856,11 @@ __device__ __forceinline__ float wave_sum_f32(float v) {
 
 // One step of the forward / posterior scan in the LINEAR domain (BS-2) for the lane's four states j = 4m .. 4m+3 (classes 0 .. 3):
 //     a'[j] = e^blank a[j] + sum_r e^{score[j][r]} a[r S/4 + m]            (the four states share their four predecessors)
-//     pv[j] = a'[j] b_{t+1}[j]                                              (b = the guide row, linear)
-// Returns a' (unscaled) in anew and the lane's class products in pv. Nothing here feeds the search - the class posteriors are a
+// and the class products pv[j] = a'[j] b_{t+1}[j] (b = the guide row, linear) are formed by the caller from the RESCALED a' (with every
+// score at the cap a row grows by 2^62: products of unscaled values would leave the fp32 range). Nothing here feeds the search - the class posteriors are a
 // tolerance-level output (q-scores within 1e-3 of an fp64 scan) - so the exponentials are the hardware's (v_exp_f32).
 template <int STATE_LEN>
-__device__ __forceinline__ void scan_lin_lane(float ebl, const half_t* row, const float* ap, float4_t bnext4, int m, float (&anew)[4],
-                                              float (&pv)[4]) {
+__device__ __forceinline__ void scan_lin_lane(float ebl, const half_t* row, const float* ap, int m, float (&anew)[4]) {
     constexpr int S = 1 << (2 * STATE_LEN), Q = S / 4;
     const uint4_t w0 = *(const uint4_t*)(row + 16 * m), w1 = *(const uint4_t*)(row + 16 * m + 8);
     const float4_t own = *(const float4_t*)(ap + 4 * m);
@@ -871,14 +870,17 @@ __device__ __forceinline__ void scan_lin_lane(float ebl, const half_t* row, cons
     const unsigned w[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        const half2_t h01 = __builtin_bit_cast(half2_t, w[2 * k]), h23 = __builtin_bit_cast(half2_t, w[2 * k + 1]);
+        // scores above BH_BS2_XMAX are capped like the guide's (v_pk_min_f16: the exponential must not overflow; far below -XMAX it
+        // underflows to zero, which is what the oracle's clamp to -XMAX amounts to at fp32 resolution)
+        const half2_t cap = {(half_t)BH_BS2_XMAX, (half_t)BH_BS2_XMAX};
+        const half2_t h01 = __builtin_elementwise_min(__builtin_bit_cast(half2_t, w[2 * k]), cap);
+        const half2_t h23 = __builtin_elementwise_min(__builtin_bit_cast(half2_t, w[2 * k + 1]), cap);
         float a = __fmaf_rn(ebl, own[k], BH_BS2_TINY);      // (the floor keeps every value a normal number: the rescaling below is exact)
         a = __fmaf_rn(__expf((float)h01.x), pr[0], a);
         a = __fmaf_rn(__expf((float)h01.y), pr[1], a);
         a = __fmaf_rn(__expf((float)h23.x), pr[2], a);
         a = __fmaf_rn(__expf((float)h23.y), pr[3], a);
         anew[k] = a;
-        pv[k] = a * bnext4[k];
     }
 }
 
@@ -891,19 +893,18 @@ __device__ __forceinline__ void scan_lin_lane(float ebl, const half_t* row, cons
 template <int STATE_LEN>
 __device__ __forceinline__ void scan_step(float ebl, const half_t* row, const float* bnext, float* ap, float* an, int m, bool act, float* Pt) {
     constexpr int S = 1 << (2 * STATE_LEN), Q = S / 4, GL = Q < 64 ? Q : 64;
-    float anew[4], pv[4];
-    scan_lin_lane<STATE_LEN>(ebl, row, ap, *(const float4_t*)(bnext + 4 * m), m, anew, pv);
+    float anew[4];
+    scan_lin_lane<STATE_LEN>(ebl, row, ap, m, anew);
+    const float4_t bnext4 = *(const float4_t*)(bnext + 4 * m);
     const float mx = group_max<GL>(fmaxf(fmaxf(anew[0], anew[1]), fmaxf(anew[2], anew[3])));
     const unsigned e23 = ((__float_as_uint(mx) >> 23) - 127u) << 23;
-    if (act) {
-        float4_t o;
+    float4_t o;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) o[k] = __uint_as_float(__float_as_uint(anew[k]) - e23);
-        *(float4_t*)(an + 4 * m) = o;
-    }
+    for (int k = 0; k < 4; ++k) o[k] = __uint_as_float(__float_as_uint(anew[k]) - e23);
+    if (act) *(float4_t*)(an + 4 * m) = o;
     float cls[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) cls[k] = group_sum<GL>(pv[k]);
+    for (int k = 0; k < 4; ++k) cls[k] = group_sum<GL>(o[k] * bnext4[k]);
     const float inv = 1.0f / ((cls[0] + cls[1]) + (cls[2] + cls[3]));
     if (GL == 1) {
         if (act) *(float4_t*)Pt = float4_t{cls[0] * inv, cls[1] * inv, cls[2] * inv, cls[3] * inv};
@@ -954,7 +955,7 @@ __global__ __launch_bounds__(256) void bs2_forward_post_kernel(Bs2FwdArgs p) {
     const half_t* sc = p.scores + (long)nn * T * 4 * S;
     const float* bn = p.b + (long)nn * (T + 1) * S;
     float* Pn = p.P + (long)nn * T * 4;
-    const float ebl = __expf(p.blank);
+    const float ebl = __expf(__builtin_amdgcn_fmed3f(p.blank, -BH_BS2_XMAX, BH_BS2_XMAX));
     auto dma_row = [&](const char* src, char* dst, int n16) {
         for (int i0 = 0; i0 < n16; i0 += G::TPC) {
             const int piece = i0 + wv * 64 + lane;
@@ -985,28 +986,31 @@ __global__ __launch_bounds__(256) void bs2_forward_post_kernel(Bs2FwdArgs p) {
             const int t = t0 + r;
             const half_t* row = rows + (size_t)((k & 1) * BS2_FR + r) * 4 * S;
             const float4_t bnext4 = *(const float4_t*)(grows + (size_t)((k & 1) * BS2_FR + r) * S + 4 * m);
-            float anew[4], pv[4];
-            scan_lin_lane<STATE_LEN>(ebl, row, al + cur * S, bnext4, m, anew, pv);
+            float anew[4];
+            scan_lin_lane<STATE_LEN>(ebl, row, al + cur * S, m, anew);
             float mx = act ? fmaxf(fmaxf(anew[0], anew[1]), fmaxf(anew[2], anew[3])) : 0.0f;
             mx = wave_max_f32(mx);
+            // rescale: by this row's own maximum where one wave holds the chunk, by the maximum of the row this step READ where four do
+            // (this row's is known only behind the barrier; rows then stay within [g, 2g), g = the growth of a step <= 2^62)
+            unsigned sc23;
+            if (WPC > 1) {
+                const float4_t mv = *(const float4_t*)(mxs + cur * 4);
+                sc23 = ((__float_as_uint(fmaxf(fmaxf(mv.x, mv.y), fmaxf(mv.z, mv.w))) >> 23) - 127u) << 23;
+            } else {
+                sc23 = ((__float_as_uint(mx) >> 23) - 127u) << 23;
+            }
+            float4_t o;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) o[c] = __uint_as_float(__float_as_uint(anew[c]) - sc23);
             float cls[4];
 #pragma unroll
-            for (int c = 0; c < 4; ++c) cls[c] = wave_sum_f32(act ? pv[c] : 0.0f);
+            for (int c = 0; c < 4; ++c) cls[c] = wave_sum_f32(act ? o[c] * bnext4[c] : 0.0f);
             float* an = al + (cur ^ 1) * S;
             if (WPC > 1) {
-                // per-wave maxima and class sums meet behind the barrier; the NEXT step rescales what it reads. The rescaling of the
-                // values this step read is folded in here: every wave of the chunk derives the same power of two from mxs[cur].
-                const float4_t mv = *(const float4_t*)(mxs + cur * 4);
-                const float pmx = fmaxf(fmaxf(mv.x, mv.y), fmaxf(mv.z, mv.w));
-                const unsigned pe23 = ((__float_as_uint(pmx) >> 23) - 127u) << 23;      // scale of the row this step read
-                if (act) {
-                    float4_t o;
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) o[c] = __uint_as_float(__float_as_uint(anew[c]) - pe23);
-                    *(float4_t*)(an + 4 * m) = o;
-                }
+                // per-wave maxima (in the scale of the stored row) and class sums meet behind the barrier
+                if (act) *(float4_t*)(an + 4 * m) = o;
                 if (lane == 0) {
-                    mxs[(cur ^ 1) * 4 + wv] = __uint_as_float(__float_as_uint(mx) - pe23);
+                    mxs[(cur ^ 1) * 4 + wv] = __uint_as_float(__float_as_uint(mx) - sc23);
                     *(float4_t*)(part + ((cur ^ 1) * 4 + wv) * 4) = float4_t{cls[0], cls[1], cls[2], cls[3]};
                 }
                 __syncthreads();
@@ -1018,13 +1022,7 @@ __global__ __launch_bounds__(256) void bs2_forward_post_kernel(Bs2FwdArgs p) {
                     Pn[(long)t * 4 + m_raw] = (m_raw == 0 ? c4[0] : m_raw == 1 ? c4[1] : m_raw == 2 ? c4[2] : c4[3]) / tot;
                 }
             } else {
-                const unsigned e23 = ((__float_as_uint(mx) >> 23) - 127u) << 23;
-                if (act) {
-                    float4_t o;
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) o[c] = __uint_as_float(__float_as_uint(anew[c]) - e23);
-                    *(float4_t*)(an + 4 * m) = o;
-                }
+                if (act) *(float4_t*)(an + 4 * m) = o;
                 const float inv = 1.0f / ((cls[0] + cls[1]) + (cls[2] + cls[3]));
                 if (lane < 4 && live) Pn[(long)t * 4 + lane] = (lane == 0 ? cls[0] : lane == 1 ? cls[1] : lane == 2 ? cls[2] : cls[3]) * inv;
             }
@@ -1073,7 +1071,7 @@ __global__ __launch_bounds__(64 * (CPW + beam_scan_waves<STATE_LEN, CPW, FUSE>()
         float* al = (float*)scan_mem;
         const int sm = QS >= 64 ? lane : lane - (lane / GLS) * GLS;          // the lane owns the states 4 sm .. 4 sm + 3 of its chunk
         if (slot_ok) *(float4_t*)(al + 4 * sm) = float4_t{1.0f, 1.0f, 1.0f, 1.0f};       // alpha_0 = 1
-        const float ebl = __expf(p.blank);
+        const float ebl = __expf(__builtin_amdgcn_fmed3f(p.blank, -BH_BS2_XMAX, BH_BS2_XMAX));
         float* Pn = p.P + (long)n * T * 4;
         int cb = 0;
         for (int tb0 = 0, blk = 0; tb0 < T; tb0 += BTB, ++blk) {

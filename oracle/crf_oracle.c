@@ -323,9 +323,12 @@ int oracle_bs2_backward(const uint16_t* scores, int N, int T, int state_len, flo
     return 0;
 }
 
-/* TRUE class posteriors P [N][T][4] (boundary u = t+1 stored at index t): forward and backward in fp64, log domain, libm. */
-int oracle_crf_posteriors_f64(const uint16_t* scores, int N, int T, int state_len, float blank, float* P) {
+/* TRUE class posteriors P [N][T][4] (boundary u = t+1 stored at index t): forward and backward in fp64, log domain, libm. Scores (and
+ * the blank score) are clamped to [-XMAX, XMAX] like the guide's: that is part of BS-2's definition; a trained head stays within +-5. */
+static inline double clampx(float x) { return (double)fminf(fmaxf(x, -BH_BS2_XMAX), BH_BS2_XMAX); }
+int oracle_crf_posteriors_f64(const uint16_t* scores, int N, int T, int state_len, float blank_in, float* P) {
     const int S = ipow4(state_len), sh = 2 * (state_len - 1), q = S / 4;
+    const double blank = clampx(blank_in);
     double* beta = (double*)malloc(sizeof(double) * (size_t)(T + 1) * S);
     double* al = (double*)malloc(sizeof(double) * S);
     double* nx = (double*)malloc(sizeof(double) * S);
@@ -339,11 +342,11 @@ int oracle_crf_posteriors_f64(const uint16_t* scores, int N, int T, int state_le
             for (int s = 0; s < S; ++s) {
                 const int lead = s >> sh;
                 double v[5], m;
-                v[0] = (double)blank + prev[s];
+                v[0] = blank + prev[s];
                 m = v[0];
                 for (int x = 0; x < 4; ++x) {
                     const int s2 = ((s << 2) | x) & (S - 1);
-                    v[1 + x] = (double)h2f(sc[s2 * 4 + lead]) + prev[s2];
+                    v[1 + x] = clampx(h2f(sc[s2 * 4 + lead])) + prev[s2];
                     if (v[1 + x] > m) m = v[1 + x];
                 }
                 double sum = 0.0;
@@ -356,10 +359,10 @@ int oracle_crf_posteriors_f64(const uint16_t* scores, int N, int T, int state_le
             const uint16_t* sc = scores + ((size_t)n * T + t) * 4 * S;
             for (int j = 0; j < S; ++j) {
                 double v[5], m;
-                v[0] = (double)blank + al[j];
+                v[0] = blank + al[j];
                 m = v[0];
                 for (int r = 0; r < 4; ++r) {
-                    v[1 + r] = (double)h2f(sc[j * 4 + r]) + al[r * q + (j >> 2)];
+                    v[1 + r] = clampx(h2f(sc[j * 4 + r])) + al[r * q + (j >> 2)];
                     if (v[1 + r] > m) m = v[1 + r];
                 }
                 double sum = 0.0;

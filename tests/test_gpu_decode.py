@@ -119,6 +119,30 @@ def test_beam_search_random_scores_and_params(kind):
         assert np.abs(qf.numpy() - oqf).max() < 1e-3
 
 
+@pytest.mark.parametrize("state_len", [2, 4, 5])
+def test_beam_search_out_of_range_scores_stay_bit_exact(state_len):
+    """BS-2's guide lives in the linear domain: scores far outside the +-5 a trained head emits - up to the fp16 maximum, and a blank
+    score of +-30 - must neither overflow nor diverge from the oracle (the exponential clamps its argument to +-40 on both sides, every
+    recurrence sum carries a 2^-60 floor, the rescaling is exact): sequence and moves stay bit-identical. The q-scores come from an fp32
+    scan: with weights spread over e^+-40 a posterior mass of 2e-5 carries the fp32 resolution of the total (1e-7 absolute), i.e. the
+    ERROR PROBABILITIES agree to a few 1e-6 absolute and q to 0.05 up there (within +-5, the range of a trained head, q agrees to 1e-3: the tests
+    above)."""
+    rng = np.random.default_rng(900 + state_len)
+    N, T = (3, 40) if state_len == 5 else (6, 90)
+    S = 4 ** state_len
+    sc = (rng.normal(0, 30, (N, T, 4 * S))).astype(np.float16)
+    sc[rng.random(sc.shape) < 0.01] = np.float16(65504)
+    sc[rng.random(sc.shape) < 0.01] = np.float16(-65504)
+    sc[0, :, :] = np.float16(-60000)                     # a chunk in which every move is (numerically) impossible
+    sc[1, : T // 2, :] = np.float16(60000)               # ... and one in which every move saturates
+    for blank in (2.0, -30.0, 30.0):
+        seq, qs, mv, qf = decode.beam_search(torch.from_numpy(sc).cuda(), blank_score=blank, return_qfloat=True)
+        oseq, oqs, omv, oqf = crf_ref.beam_search(sc, state_len, blank=blank)
+        assert np.array_equal(mv.numpy(), omv) and np.array_equal(seq.numpy(), oseq), (state_len, blank)
+        assert np.isfinite(qf.numpy()).all() and np.abs(qf.numpy() - oqf).max() < 0.05
+        assert np.abs(10.0 ** (-qf.numpy() / 10.0) - 10.0 ** (-oqf / 10.0))[omv != 0].max() < 5e-6
+
+
 def test_beam_search_close_to_viterbi_on_confident_scores():
     rng = np.random.default_rng(5)
     sc = _peaky_scores(rng, 6, 300, 3, sharp=4.0)
