@@ -238,7 +238,8 @@ int bh_crf_posterior_viterbi(const void* scores, int N, int T, int state_len, fl
  * [N][T][4^(state_len+1)] (koi layout).  Outputs are DEVICE int8 [N][T], zero where nothing is emitted:
  * sequence = ASCII base at emitting steps, qstring = 33 + round(q), moves in {0,1}; qfloat (optional,
  * device fp32 [N][T]) receives the un-rounded q.  workspace: bh_beam_search_workspace(N, T, state_len) bytes.
- * Algorithm "BS-1": DESIGN.md; bit-exact against oracle/crf_oracle.c for sequence and moves.
+ * Algorithm "BS-2" (round 5: the guide and the posterior scan in the linear domain, a deterministic exponential shared with the oracle;
+ * DESIGN.md 5); bit-exact against oracle/crf_oracle.c for sequence and moves, q within 1e-3 of its fp64 posteriors.
  * Limits: 1 <= state_len <= 5, 1 <= beam_width <= 32, beam_cut >= 1, T < 131072 steps per chunk. */
 size_t bh_beam_search_workspace(int N, int T, int state_len);
 int bh_beam_search(const void* scores, int N, int T, int state_len, int beam_width, float beam_cut,

@@ -133,7 +133,7 @@ def viterbi_bruteforce(scores_tnc_5s, state_len):
 
 
 def beam_search(scores, state_len, beam_width=32, beam_cut=100.0, blank=2.0, scale=1.0, offset=0.0):
-    """BS-1 decode of koi-layout scores [N,T,4S] (float16). Returns (sequence, qstring, moves, qfloat)."""
+    """BS-2 decode (linear-domain guide, fp64 posteriors; BS-1 = the table-lse2 guide of rounds 1-4) of koi-layout scores [N,T,4S] (float16). Returns (sequence, qstring, moves, qfloat)."""
     a, bits = _as_half_bits(scores)
     N, T, _ = a.shape
     seq = np.zeros((N, T), np.int8)
