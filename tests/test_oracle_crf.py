@@ -200,3 +200,53 @@ def test_oracle_matches_reference_ctc_crf_executed_with_stubbed_koi():
         assert np.abs(crf_ref.logz(x, sl) - z["logz%d" % sl]).max() < 1e-4
         pm, pp = crf_ref.posterior_viterbi(x, sl)
         assert [alphabet[p[p != 0]].tobytes().decode() for p in pp] == json.loads(str(z["post_str%d" % sl]))
+
+
+def test_bs2_deterministic_exp_and_log_accuracy_and_range():
+    """The two elementary functions of the linear-domain guide (include/bh_bs2.h): accuracy against libm, the clamp, and that the
+    exponential never leaves the normal fp32 range (the bit-exact contract with the GPU rests on normal operands only)."""
+    xs = np.concatenate([np.linspace(-45, 45, 4001), np.float16(np.linspace(-5, 5, 2001)).astype(np.float64), [65504.0, -65504.0]])
+    e = np.array([crf_ref.bs2_exp(x) for x in xs], np.float64)
+    ref = np.exp(np.clip(xs, -40.0, 40.0))
+    assert np.abs(e / ref - 1.0).max() < 3e-6 and np.abs(e / ref - 1.0)[np.abs(xs) <= 5].max() < 1e-6     # (log2e in fp32 times 58 at the clamp)
+    assert e.min() > 1e-18 and e.max() < 3e17 and (e >= 2.0 ** -126).all()
+    assert crf_ref.bs2_exp(0.0) == np.float32(1.0000001192092896)               # the polynomial's constant term, not exactly 1
+    vs = np.exp(np.random.default_rng(0).uniform(-85, 2, 4000)).astype(np.float32)
+    lg = np.array([crf_ref.bs2_log(v) for v in vs], np.float64)
+    assert np.abs(lg - np.log(vs.astype(np.float64))).max() < 2e-5
+    assert all(crf_ref.bs2_log(a) <= crf_ref.bs2_log(b) for a, b in zip(np.sort(vs)[:-1:50], np.sort(vs)[1::50]))   # monotone where it ranks
+
+
+@pytest.mark.parametrize("state_len", [1, 2, 3, 4])
+def test_bs2_guide_equals_the_log_semiring_guide_and_rows_are_normalised(state_len):
+    """oracle_bs2_backward (BS-2, linear domain) against the table-lse2 scan of rounds 1-4: ln b_t[s] - ln b_t[0] == beta~_t[s] to 1e-5;
+    every row's maximum lies in [1, 2) (an exact power-of-two scaling), nothing underflows; and the fp64 posteriors agree with the
+    fp32 table scan's to 1e-5 and sum to one."""
+    rng = np.random.default_rng(10 + state_len)
+    S = 4 ** state_len
+    sc = rng.normal(0, 2.5, (3, 120, 4 * S)).clip(-5, 5).astype(np.float16)
+    b = crf_ref.bs2_backward(sc, state_len)
+    beta, B, lz = crf_ref.backward(sc, state_len)
+    g = np.log(b.astype(np.float64))
+    assert np.abs((g - g[:, :, :1]) - beta).max() < 2e-5
+    mx = b.max(axis=2)
+    assert (mx >= 1.0).all() and (mx < 2.0).all() and b.min() > 1e-30
+    assert (b[:, -1, :] == 1.0).all()
+    P = crf_ref.posteriors_f64(sc, state_len)
+    assert np.abs(P.sum(-1) - 1.0).max() < 1e-6
+    assert np.abs(P - crf_ref.forward_post(sc, state_len, beta, B, lz)).max() < 2e-5
+
+
+def test_bs2_out_of_range_scores_are_clamped_not_overflowed():
+    rng = np.random.default_rng(4)
+    sc = rng.normal(0, 40, (2, 50, 64)).astype(np.float16)
+    sc[0, 10:20] = np.float16(65504)
+    sc[1, :25] = np.float16(-65504)
+    for blank in (2.0, 60.0, -60.0):
+        b = crf_ref.bs2_backward(sc, 2, blank=blank)
+        assert np.isfinite(b).all() and (b > 0).all() and b.min() >= 2.0 ** -126
+        seq, qs, mv, qf = crf_ref.beam_search(sc, 2, blank=blank)
+        assert np.isfinite(qf).all()
+    # the all-saturated block is symmetric: uniform class posteriors
+    P = crf_ref.posteriors_f64(sc, 2)
+    assert np.abs(P[0, 11:18] - 0.25).max() < 1e-6
