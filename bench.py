@@ -103,13 +103,13 @@ def parse(argv=None):
     a.lanes = a.lanes or (3 if a.model == "fast" else 2 if a.quantize and a.model == "hac" else 1)
     if not a.per_call:
         # measured on MI355X (profiles/r02_bench_lines.jsonl): hac fp16 - four batches per call, one lane (paired recurrent kernel);
-        # hac --quantize - two lanes (8-bit kernels compiled for two workgroups per CU) x two batches per call: 14.6 -> 13.7 ms;
+        # hac --quantize - two lanes (8-bit kernels compiled for two workgroups per CU) x four batches per call (two until round 5);
         # fast - three lanes x four batches per call (the ring-in-a-workgroup kernel of one 512-chunk batch fills an eighth of the
         # chip): 3.57 -> 2.51 ms per batch
         if a.model == "hac" and not a.quantize and a.lanes == 1:
             a.per_call = 4
         elif a.model == "hac" and a.quantize and a.lanes == 2 and not lanes_given:
-            a.per_call = 2
+            a.per_call = 4          # (round 5: 2048-chunk calls give the decode stage eight chunks per CU: 12.28 -> 11.63 ms; 2 before)
         elif a.model == "fast" and not a.quantize and a.lanes == 3 and not lanes_given:
             a.per_call = 4
         elif a.model in ("sup", "sup_lstm") and a.lanes == 1:

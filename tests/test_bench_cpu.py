@@ -51,8 +51,8 @@ def test_batches_per_engine_call(bench, monkeypatch):
     assert parsed("--steps", "7").per_call == 1                      # exactly K steps: an odd K runs one batch per call
     assert parsed("--steps", "50").per_call == 2 and parsed("--steps", "20").per_call == 4
     assert parsed("--per-call", "1").call_batch == 512
-    q = parsed("--quantize")                                         # 8-bit path: two lanes x two batches per call
-    assert (q.lanes, q.per_call) == (2, 2) and parsed("--quantize", "--lanes", "1").per_call == 1
+    q = parsed("--quantize")                                         # 8-bit path: two lanes x four batches per call
+    assert (q.lanes, q.per_call) == (2, 4) and parsed("--quantize", "--lanes", "1").per_call == 1
     f = parsed("--model", "fast")                                    # three lanes x four batches per call
     assert (f.lanes, f.per_call, f.call_batch) == (3, 4, 2048) and parsed("--model", "fast", "--lanes", "1").per_call == 1
     assert parsed("--lanes", "2").per_call == 1

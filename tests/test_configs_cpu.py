@@ -79,7 +79,7 @@ def test_engine_call_size_policy():
     assert auto_lanes(synthetic.make_model("sup_lstm", batchsize=16, chunksize=1200), True) == 1
     assert auto_lanes(synthetic.make_transformer_model(batchsize=16, chunksize=1200)) == 1
     assert [batches_per_call(hac, b) for b in (128, 256, 512, 1024, 2048, 4096)] == [8, 8, 4, 2, 1, 1]
-    assert batches_per_call(hac, 512, quantize=True) == 1 and batches_per_call(hac, 512, quantize=True, lanes=2) == 2
+    assert batches_per_call(hac, 512, quantize=True) == 1 and batches_per_call(hac, 512, quantize=True, lanes=2) == 4
     assert batches_per_call(hac, 256, quantize=True, lanes=2) == 4 and batches_per_call(hac, 2048, quantize=True, lanes=2) == 1
     assert [batches_per_call(hac, 512, chunksize=c) for c in (4000, 10000, 20000, 40000)] == [4, 4, 2, 1]
     fast = synthetic.make_model("fast", batchsize=16, chunksize=1200)
