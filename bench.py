@@ -104,14 +104,14 @@ def parse(argv=None):
     if not a.per_call:
         # measured on MI355X (profiles/r02_bench_lines.jsonl): hac fp16 - four batches per call, one lane (paired recurrent kernel);
         # hac --quantize - two lanes (8-bit kernels compiled for two workgroups per CU) x four batches per call (two until round 5);
-        # fast - three lanes x four batches per call (the ring-in-a-workgroup kernel of one 512-chunk batch fills an eighth of the
-        # chip): 3.57 -> 2.51 ms per batch
+        # fast - three lanes x eight batches per call (the ring-in-a-workgroup kernel of one 512-chunk batch fills an eighth of the
+        # chip): 3.57 -> 2.51 ms per batch with four, 2.28 with eight
         if a.model == "hac" and not a.quantize and a.lanes == 1:
             a.per_call = 4
         elif a.model == "hac" and a.quantize and a.lanes == 2 and not lanes_given:
             a.per_call = 4          # (round 5: 2048-chunk calls give the decode stage eight chunks per CU: 12.28 -> 11.63 ms; 2 before)
         elif a.model == "fast" and not a.quantize and a.lanes == 3 and not lanes_given:
-            a.per_call = 4
+            a.per_call = 8          # (4096 chunks = 256 rings = one ring-in-a-workgroup per CU; round 5: 2.37 -> 2.28 ms, four before)
         elif a.model in ("sup", "sup_lstm") and a.lanes == 1:
             # 1024 states: the decode is one wave per chunk (a latency chain), two 256-chunk batches decode in the time of one
             # (round 5: sup 64.1 -> 62.8 ms per batch, sup_lstm 101.3 -> 97.5); what crf/basecall.py batches_per_call picks
@@ -341,7 +341,7 @@ def e2e_leg(name, hard_timeout=150.0):
 
 
 OTHER_CONFIGS = {            # BASELINE.json configs 2, 4, 5 (+ the 8-bit path of config 3); the headline itself is config 3
-    "fast": ["--model", "fast", "--steps", "384", "--warmup", "48"],        # (three lanes x four batches per call: 96 steps were 8 calls per lane,
+    "fast": ["--model", "fast", "--steps", "384", "--warmup", "48"],        # (three lanes x eight batches per call = 16 calls per lane; 96 steps were
                                                                             #  half of them ramp-up - 2.53 ms against 2.37 over 384 steps)
     "sup": ["--model", "sup", "--steps", "12", "--warmup", "3"],
     "sup_lstm": ["--model", "sup_lstm", "--steps", "8", "--warmup", "2"],

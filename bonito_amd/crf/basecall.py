@@ -299,11 +299,11 @@ def _batches_per_call_encoder(model, batchsize, quantize=False, chunksize=None, 
     across call boundaries (hac, batches of 512: 14.9 ms per batch in calls of 1024 chunks, 13.96 in calls of 2048 - bench.py
     --per-call 2 / 4 on one box): calls of up to 2048 chunks there, as long as the score tensor of a call stays below 8 GiB; the
     8-bit path with its two lanes: calls of 2048 chunks as well (round 5: the decode stage then has eight chunks per CU, bench.py
-    --quantize 12.28 -> 11.63 ms per batch; round 2 had settled on 1024-chunk calls, 14.6 -> 13.7); the narrow (64 / 96 / 128 wide) models with their three lanes: calls of 2048 chunks; one batch per call everywhere else."""
+    --quantize 12.28 -> 11.63 ms per batch; round 2 had settled on 1024-chunk calls, 14.6 -> 13.7); the narrow (64 / 96 / 128 wide) models with their three lanes: calls of 4096 chunks (round 5: 2.37 -> 2.28 ms per batch; 2048 before); one batch per call everywhere else."""
     sizes = lstm_widths(model)
     q8 = bool(quantize) and any(q8_covers(h) for h in sizes)
     if sizes and all(h in (64, 96, 128) for h in sizes) and not q8:   # ring-in-a-workgroup kernels: a 512-chunk batch fills an eighth of the chip
-        return max(1, min(4, 2048 // max(1, int(batchsize)))) if lanes >= 2 else 1
+        return max(1, min(8, 4096 // max(1, int(batchsize)))) if lanes >= 2 else 1      # (4096 chunks = 256 rings = one workgroup per CU)
     if quantize:
         if lanes >= 2 and max_lanes(model, True) == 2:
             return max(1, min(4, 2048 // max(1, int(batchsize))))

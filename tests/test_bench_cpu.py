@@ -53,8 +53,8 @@ def test_batches_per_engine_call(bench, monkeypatch):
     assert parsed("--per-call", "1").call_batch == 512
     q = parsed("--quantize")                                         # 8-bit path: two lanes x four batches per call
     assert (q.lanes, q.per_call) == (2, 4) and parsed("--quantize", "--lanes", "1").per_call == 1
-    f = parsed("--model", "fast")                                    # three lanes x four batches per call
-    assert (f.lanes, f.per_call, f.call_batch) == (3, 4, 2048) and parsed("--model", "fast", "--lanes", "1").per_call == 1
+    f = parsed("--model", "fast")                                    # three lanes x eight batches per call
+    assert (f.lanes, f.per_call, f.call_batch) == (3, 8, 4096) and parsed("--model", "fast", "--lanes", "1").per_call == 1
     assert parsed("--lanes", "2").per_call == 1
     # 1024-state models: two 256-chunk batches per call (their decode is one wave per chunk; two batches decode in the time of one)
     assert parsed("--model", "sup").per_call == 2 and parsed("--model", "sup_lstm").call_batch == 512

@@ -83,7 +83,7 @@ def test_engine_call_size_policy():
     assert batches_per_call(hac, 256, quantize=True, lanes=2) == 4 and batches_per_call(hac, 2048, quantize=True, lanes=2) == 1
     assert [batches_per_call(hac, 512, chunksize=c) for c in (4000, 10000, 20000, 40000)] == [4, 4, 2, 1]
     fast = synthetic.make_model("fast", batchsize=16, chunksize=1200)
-    assert batches_per_call(fast, 512, chunksize=10000) == 1 and batches_per_call(fast, 512, chunksize=10000, lanes=3) == 4
+    assert batches_per_call(fast, 512, chunksize=10000) == 1 and batches_per_call(fast, 512, chunksize=10000, lanes=3) == 8
     assert batches_per_call(synthetic.make_model("sup_lstm", batchsize=16, chunksize=1200), 512, chunksize=10000) == 1
     # 1024-state models (round 5): calls of 512 chunks - their decode is one wave per chunk, two batches decode in the time of one -
     # bounded by 16 GiB of scores per call
