@@ -466,7 +466,7 @@ def test_batches_per_engine_call_do_not_change_the_calls():
     assert batches_per_call(model, 512, chunksize=40000) == 1
     assert batches_per_call(model, 512, quantize=True) == 1 and max_lanes(model) == 1 and max_lanes(model, True) == 2
     fast = synthetic.make_model("fast", batchsize=64, chunksize=2400)
-    assert batches_per_call(fast, 512) == 1 and batches_per_call(fast, 512, lanes=3) == 4 and max_lanes(fast) > 8
+    assert batches_per_call(fast, 512) == 1 and batches_per_call(fast, 512, lanes=3) == 8 and max_lanes(fast) > 8
     rng = np.random.default_rng(6)
     reads = _reads(rng, [6000 + 500 * (i % 7) for i in range(150)])
     outs = [[(r.read_id, res["sequence"], res["qstring"], res["moves"].tobytes())

@@ -9,3 +9,7 @@ timeout 900 python bench.py > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_
 timeout 600 python bench.py --steps 20 --warmup 5 > gpurun_out/${TAG}_bench_driver_flags.json 2> gpurun_out/${TAG}_bench_driver_flags.err; tail -n1 gpurun_out/${TAG}_bench_driver_flags.json | cut -c1-300
 PS_ARGS="--batch 1024" timeout 900 bash tools/prof_round.sh $TAG > gpurun_out/${TAG}_prof.log 2>&1; sed -n 1,30p gpurun_out/${TAG}_prof.log | cut -c1-170
 timeout 600 bash tools/prof_decode.sh $TAG > gpurun_out/${TAG}_prof_decode.log 2>&1; head -5 gpurun_out/${TAG}_prof_decode.log
+# the N > 1 launch paths on this one-GPU box (ranks share the device, the two collectives go over gloo): bench.py's own spawner and the
+# driver's launcher line
+timeout 600 python bench.py --gpus 2 --steps 8 --warmup 4 > gpurun_out/${TAG}_bench_gpus2_self.json 2> gpurun_out/${TAG}_bench_gpus2_self.err; tail -n1 gpurun_out/${TAG}_bench_gpus2_self.json | cut -c1-260
+timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --steps 8 --warmup 4 > gpurun_out/${TAG}_bench_gpus2_torchrun.json 2> gpurun_out/${TAG}_bench_gpus2_torchrun.err; tail -n1 gpurun_out/${TAG}_bench_gpus2_torchrun.json | cut -c1-260
