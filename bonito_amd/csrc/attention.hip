@@ -201,7 +201,7 @@ __global__ __launch_bounds__(512) void attention_ring_kernel(AttnRingArgs p) {
     constexpr int NT = 18;
     char* kl = smem;                              // [RING][128 B] swizzled by slot & 7
     half_t* vt = (half_t*)(smem + RING * 128);    // [64][RVS]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int D = p.H * HD;
     const int h = blockIdx.x, n = blockIdx.y;
     const half_t* base = p.qkv + (long)n * p.T * 3 * D;
@@ -270,12 +270,17 @@ __global__ __launch_bounds__(512) void attention_ring_kernel(AttnRingArgs p) {
 
         const int rel0 = wave * 16;               // this wave's first key tile, relative to jb
         float4_t s[NT];
+        // ring row of this lane's key in tile kt: (jb + rel0 + 16 kt + (lane & 15)) & 511. Every term but the lane's is a multiple of 16,
+        // so the swizzle (slot & 7) is the lane's own constant and the tile's offset is wave-uniform (round 5: two lane-constant base
+        // pointers + a scalar offset per tile instead of re-deriving both addresses on the vector ALU)
+        const int tile0 = __builtin_amdgcn_readfirstlane((jb + rel0) >> 4);          // wave-uniform ring tile of this wave's first keys
+        const char* kl_lane0 = kl + ((lane & 15) << 7) + ((g ^ (lane & 7)) << 4);
+        const char* kl_lane1 = kl + ((lane & 15) << 7) + (((g + 4) ^ (lane & 7)) << 4);
 #pragma unroll
         for (int kt = 0; kt < NT; ++kt) {
-            const int slot = (jb + rel0 + kt * 16 + (lane & 15)) & (RING - 1);
-            const char* rp = kl + slot * 128;
-            const half8_t a0 = *(const half8_t*)(rp + ((g ^ (slot & 7)) << 4));
-            const half8_t a1 = *(const half8_t*)(rp + (((g + 4) ^ (slot & 7)) << 4));
+            const int toff = ((tile0 + kt) & (RING / 16 - 1)) << 11;                   // scalar: 16 rows of 128 bytes per tile
+            const half8_t a0 = *(const half8_t*)(kl_lane0 + toff);
+            const half8_t a1 = *(const half8_t*)(kl_lane1 + toff);
             float4_t acc = {0.f, 0.f, 0.f, 0.f};
             acc = mfma16(a0, qf[0], acc);
             acc = mfma16(a1, qf[1], acc);
@@ -297,22 +302,28 @@ __global__ __launch_bounds__(512) void attention_ring_kernel(AttnRingArgs p) {
                     s[kt][e] = (rel >= lo && rel <= hi) ? s[kt][e] : -INFINITY;
                 }
             }
-            m = fmaxf(m, fmaxf(fmaxf(s[kt][0], s[kt][1]), fmaxf(s[kt][2], s[kt][3])));
+            m = fmaxf(fmaxf(m, s[kt][0]), s[kt][1]);          // two v_max3_f32 per tile
+            m = fmaxf(fmaxf(m, s[kt][2]), s[kt][3]);
         }
         m = fmaxf(m, __shfl_xor(m, 16));
         m = fmaxf(m, __shfl_xor(m, 32));
         const float msafe = (m == -INFINITY) ? 0.0f : m;
         // scores are in log2 units (the Wqkv epilogue folded log2(e) into the scale of q): p = 2^(s - m), one v_exp each.
-        // P stays unnormalised (<= 1) on its way through the PV product; O is divided by the row sum at the end.
-        float sum = 0.0f;
+        // P stays unnormalised (<= 1) on its way through the PV product; O is divided by the row sum at the end. The subtraction
+        // and the row sum run two values per instruction (v_pk_add_f32).
+        typedef float f2_t __attribute__((ext_vector_type(2)));
+        const f2_t m2 = {msafe, msafe};
+        f2_t sum2 = {0.0f, 0.0f};
 #pragma unroll
-        for (int kt = 0; kt < NT; ++kt)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float pv = __builtin_amdgcn_exp2f(s[kt][e] - msafe);
-                s[kt][e] = pv;
-                sum += pv;
-            }
+        for (int kt = 0; kt < NT; ++kt) {
+            f2_t a = f2_t{s[kt][0], s[kt][1]} - m2, b = f2_t{s[kt][2], s[kt][3]} - m2;
+            a.x = __builtin_amdgcn_exp2f(a.x); a.y = __builtin_amdgcn_exp2f(a.y);
+            b.x = __builtin_amdgcn_exp2f(b.x); b.y = __builtin_amdgcn_exp2f(b.y);
+            s[kt][0] = a.x; s[kt][1] = a.y; s[kt][2] = b.x; s[kt][3] = b.y;
+            sum2 += a;
+            sum2 += b;
+        }
+        float sum = sum2.x + sum2.y;
         sum += __shfl_xor(sum, 16);
         sum += __shfl_xor(sum, 32);
         const float inv = sum > 0.0f ? 1.0f / sum : 0.0f;
@@ -320,18 +331,19 @@ __global__ __launch_bounds__(512) void attention_ring_kernel(AttnRingArgs p) {
         float4_t o[4];
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) o[mt] = float4_t{0.f, 0.f, 0.f, 0.f};
+        // V^T fragment reads: row (d index) mt * 16 + (lane & 15), columns slot .. slot + 3 and slot + 16 .. + 19; slot = the wave-uniform
+        // tile start + 4 g, so a read is a lane-constant base + a scalar offset (+ an immediate for mt)
+        const half_t* vlane = vt + (lane & 15) * RVS + g * 4;
 #pragma unroll
         for (int c = 0; c < NT / 2; ++c) {
             const float8_t pf = {s[2 * c][0], s[2 * c][1], s[2 * c][2], s[2 * c][3],
                                  s[2 * c + 1][0], s[2 * c + 1][1], s[2 * c + 1][2], s[2 * c + 1][3]};
             const half8_t pb = __builtin_convertvector(pf, half8_t);
-            const int slot = (jb + rel0 + c * 32 + g * 4) & (RING - 1);        // 4 consecutive keys, then +16
-            const int slot2 = (slot + 16) & (RING - 1);
+            const int u0 = ((tile0 + 2 * c) & (RING / 16 - 1)) << 4, u1 = ((tile0 + 2 * c + 1) & (RING / 16 - 1)) << 4;      // scalar
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt) {
-                const half_t* vp = vt + (mt * 16 + (lane & 15)) * RVS;
-                const half4_t va = *(const half4_t*)(vp + slot);
-                const half4_t vb = *(const half4_t*)(vp + slot2);
+                const half4_t va = *(const half4_t*)(vlane + mt * 16 * RVS + u0);
+                const half4_t vb = *(const half4_t*)(vlane + mt * 16 * RVS + u1);
                 half8_t af;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { af[e] = va[e]; af[4 + e] = vb[e]; }
