@@ -247,6 +247,23 @@ def test_beam_fork_option_does_not_change_results():
         decode.set_option("no_such_option", 1)
 
 
+@pytest.mark.parametrize("state_len", [3, 4, 5])
+def test_non_temporal_staging_option_does_not_change_results(state_len):
+    """bh_set_option("decode_nt", 1): scores and guide rows staged with the non-temporal cache policy (LDS-DMA `nt`, non-temporal guide
+    stores) in the backward scan, the beam kernel and the stand-alone posterior scan - the same bytes."""
+    rng = np.random.default_rng(500 + state_len)
+    N, T = (3, 70) if state_len == 5 else (9, 160)
+    sc = torch.from_numpy(_peaky_scores(rng, N, T, state_len)).cuda()
+    try:
+        base = [x.clone() for x in decode.beam_search(sc, return_qfloat=True)]
+        decode.set_option("decode_nt", 1)
+        nt = [x.clone() for x in decode.beam_search(sc, return_qfloat=True)]
+    finally:
+        decode.set_option("decode_nt", 0)
+    for a, b in zip(base, nt):
+        assert torch.equal(a, b)
+
+
 @pytest.mark.parametrize("kind", ["normal", "ties", "zeros"])
 def test_beam_selection_variants_agree_with_oracle(kind):
     # top-W selection by histogram + exact boundary ranking (default) or by radix search (bh_set_option "beam_select"):
