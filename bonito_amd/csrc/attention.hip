@@ -460,25 +460,6 @@ int bh_k_attention_prerotated(const void* qkv, void* out, int N, int T, int nhea
     return 0;
 }
 
-// row scale of the folded norm: r[m] = rsqrt(sum_p part[p][m] / D + eps) (the partial sums come out of the producing GEMM's epilogue in a
-// fixed order: deterministic)
-namespace bh {
-__global__ void norm_finish_kernel(const float* part, int pieces, long M, float inv_d, float eps, float* r) {
-    const long m = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (m >= M) return;
-    float ss = 0.0f;
-    for (int p = 0; p < pieces; ++p) ss += part[(long)p * M + m];
-    r[m] = rsqrtf(ss * inv_d + eps);
-}
-}  // namespace bh
-
-int bh_k_norm_finish(const float* part, int pieces, long M, int D, float eps, float* r, hipStream_t stream) {
-    BH_REQUIRE(part != nullptr && r != nullptr && pieces > 0 && M > 0 && D > 0, "norm_finish: bad arguments");
-    hipLaunchKernelGGL(bh::norm_finish_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, stream, part, pieces, M, 1.0f / (float)D, eps, r);
-    BH_CHECK_HIP(hipGetLastError());
-    return 0;
-}
-
 int bh_k_rmsnorm_residual(const void* a, const void* x, const float* w, void* out, long M, int D, float alpha,
                           float eps, hipStream_t stream) {
     using namespace bh;

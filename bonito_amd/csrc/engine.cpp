@@ -141,9 +141,6 @@ static int upload_f32(DevBuf& b, const float* w, size_t n) { return upload(b, w,
 struct Layer {
     bh_layer_t d;        // descriptor (host pointers are not kept)
     DevBuf w0, w1, w2, w3, w4, w5, b0, b1;
-    // transformer layer, folded RMSNorm (round 5): Wqkv with the PREVIOUS layer's norm2 gain folded into its input columns (absent for the
-    // first layer of a stack), fc1 with this layer's norm1 gain folded in - the projections then read the un-normalised activations
-    DevBuf w0f, w2f;
     bool fused_clamp = false;   // a following CLAMP was folded into this layer
     float clamp_lo = -INFINITY, clamp_hi = INFINITY;
     // convolution: channel counts as laid out in memory. Channel-minor activations between two
@@ -241,10 +238,6 @@ struct bh_encoder {
     int lstm_q8 = 1;                       // 0: run quantised layers through the fp16 kernels (A/B)
     DevBuf res;                            // pending residual projection of a QuartzNet block
     DevBuf t_qkv, t_mid, t_a, t_b, rot;   // transformer workspace + rotary cos/sin table [Tmax][32][2]
-    DevBuf nf_part, nf_r[2];              // folded RMSNorm: partial sums of squares [D/64][M], row scales [M] (two in rotation)
-    int norm_fold = 1;                    // transformer: 1 (default) = RMSNorm folded into the projections where gemm_w4_kernel serves all four of a
-                                          // layer's GEMMs (no norm kernel: the out_proj / fc2 epilogues add the scaled residual and emit the row
-                                          // statistics, Wqkv / fc1 read the un-normalised tensor through folded weights and a row scale), 0 = norm kernels
     int rot_len = 0;
     int out_features = 0;
     int lstm_force_slow = 0;
@@ -272,7 +265,6 @@ struct bh_encoder {
         q_act[0].release(); q_act[1].release(); q_ex.release(); ex16.release();
         act[0].release(); act[1].release(); act[2].release(); gates.release(); sig.release(); err.release(); lstm_ws.release();
         res.release(); t_qkv.release(); t_mid.release(); t_a.release(); t_b.release(); rot.release();
-        nf_part.release(); nf_r[0].release(); nf_r[1].release();
     }
 };
 
@@ -549,23 +541,6 @@ extern "C" int bh_encoder_create(const bh_layer_t* layers, int n_layers, int dev
                 if (!rc) rc = upload_f16(L.w3, d.w3, (size_t)D * F);
                 if (!rc) rc = upload_f32(L.w4, d.w4, D);
                 if (!rc) rc = upload_f32(L.w5, d.w5, D);
-                if (!rc) {   // folded RMSNorm: fc1 (interleaved rows) with this layer's norm1 gain on its input columns
-                    std::vector<float> wf((size_t)2 * F * D);
-                    for (int j = 0; j < F; ++j)
-                        for (int k = 0; k < D; ++k) {
-                            wf[(size_t)(2 * j) * D + k] = d.w2[(size_t)j * D + k] * d.w4[k];
-                            wf[(size_t)(2 * j + 1) * D + k] = d.w2[(size_t)(F + j) * D + k] * d.w4[k];
-                        }
-                    rc = upload_f16(L.w2f, wf.data(), wf.size());
-                }
-                if (!rc && i > 0 && layers[i - 1].kind == BH_LAYER_TRANSFORMER && layers[i - 1].in_size == D && layers[i - 1].w5) {
-                    // ... Wqkv with the previous layer's norm2 gain
-                    std::vector<float> wf((size_t)3 * D * D);
-                    const float* g = layers[i - 1].w5;
-                    for (size_t n = 0; n < (size_t)3 * D; ++n)
-                        for (int k = 0; k < D; ++k) wf[n * D + k] = d.w0[n * D + k] * g[k];
-                    rc = upload_f16(L.w0f, wf.data(), wf.size());
-                }
                 break;
             }
             case BH_LAYER_DWCONV: {
@@ -699,8 +674,6 @@ extern "C" int bh_encoder_create(const bh_layer_t* layers, int n_layers, int dev
         if (m_qkv) {
             if (e->t_qkv.alloc(m_qkv + 256) || e->t_mid.alloc(m_mid + 256) || e->t_a.alloc(m_d + 256) || e->t_b.alloc(m_d + 256))
                 return fail(-1);
-            // folded RMSNorm: [D / 64][M] partial sums (fp32) = m_d / 2 / 64 * 4 * ... sized by the widest layer: M * D / 64 floats = m_d / 32 bytes
-            if (e->nf_part.alloc(m_d / 32 + 256) || e->nf_r[0].alloc(m_d / 256 + 256) || e->nf_r[1].alloc(m_d / 256 + 256)) return fail(-1);
             // rotary table: angle = t * 10000^(-i/32), fp32 like flash_attn.layers.rotary
             std::vector<float> cs((size_t)tmax * 32 * 2);
             if (bh_rotary_table(tmax, 64, cs.data())) return fail(-2);
@@ -883,9 +856,6 @@ extern "C" int bh_encoder_forward(bh_encoder_t* e, const void* signal, int N, in
     const void* cur_q = nullptr;     // output of a Q8-1 layer feeding the next one (int8, fragment order)
     int qi = 0;
     const void* cur = e->sig.p;
-    // folded RMSNorm (transformer stacks): `cur` is an UN-normalised tensor z with a pending row scale and gain, x = pend_r[token] * pend_w o z
-    const float* pend_r = nullptr;
-    const float* pend_w = nullptr;
     Layout lay = L_SIGNAL;
     int len = L, C = 1, which = 0;
     bool res_ready = false;
@@ -1123,58 +1093,6 @@ extern "C" int bh_encoder_forward(bh_encoder_t* e, const void* signal, int N, in
                 const int M = N * len;            // batch-major: padded chunks sit behind the valid rows
                 const float eps = d.eps > 0.0f ? d.eps : 1e-5f;
                 int rc;
-                const bool ring_attn = e->attn_ring && d.win_left <= 128 && d.win_left + d.win_right <= 256;
-                // RMSNorm folded into the projections (round 5): the layer's two norm kernels (2 x 0.13 ms of HBM traffic per layer at 256 x
-                // 1000 tokens) disappear - out_proj / fc2 add alpha * (r * w o z) in their epilogues and emit sums of squares per row, a
-                // [M]-sized kernel turns those into the next row scale, Wqkv / fc1 multiply by it behind weights that carry the gain.
-                // Where gemm_w4_kernel serves all four GEMMs (the folded epilogues exist there only) and the ring attention path runs.
-                const bool fold = e->norm_fold && ring_attn && !e->norm_fuse && D % 64 == 0 && len >= 256 && l.w2f.p != nullptr && (pend_r == nullptr || l.w0f.p != nullptr) &&
-                                  bh_k_linear_w4_applies(M, 3 * D, D) && bh_k_linear_w4_applies(M, D, D) && bh_k_linear_w4_applies(M, 2 * F, D) &&
-                                  bh_k_linear_w4_applies(M, D, F) && (size_t)M * (D / 64) * 4 <= e->nf_part.bytes && (size_t)M * 4 <= e->nf_r[0].bytes;
-                if (fold) {
-                    void* dstf = e->act[which].p;
-                    float* part = (float*)e->nf_part.p;
-                    float* r1 = (float*)e->nf_r[0].p;
-                    float* r2 = (float*)e->nf_r[1].p;
-                    {
-                        ProfSpan span(e, st, BH_PROF_ATTENTION);
-                        rc = bh_k_linear_qkv_rotary(cur, pend_r ? l.w0f.p : l.w0.p, (const float*)l.b0.p, e->t_qkv.p, M, D, D, (const float*)e->rot.p,
-                                                    len, 0.125f * 1.4426950408889634f, st, pend_r);
-                        if (!rc) rc = bh_k_attention_prerotated(e->t_qkv.p, e->t_a.p, N, len, d.nhead, D / d.nhead, d.win_left, d.win_right, st);
-                        // z1 = out_proj(a) + alpha * x,  x = cur (plain) or pend_r * pend_w o cur; row statistics of z1
-                        const BhNormFold nf1{nullptr, pend_r, pend_w, part};
-                        if (!rc) rc = bh_k_linear_nf(e->t_a.p, l.w1.p, (const float*)l.b1.p, e->t_b.p, M, D, D, D, D, D, bh::ACT_NONE, 1.0f, -INFINITY,
-                                                     INFINITY, 0, 0, 0, 0, 0, st, cur, D, d.alpha, &nf1);
-                        if (!rc) rc = bh_k_norm_finish(part, D / 64, M, D, eps, r1, st);
-                        if (rc) return rc;
-                    }
-                    {
-                        ProfSpan span(e, st, BH_PROF_MLP);
-                        const BhNormFold nf2{r1, nullptr, nullptr, nullptr};
-                        rc = bh_k_linear_nf(e->t_b.p, l.w2f.p, nullptr, e->t_mid.p, M, 2 * F, D, D, D, F, bh::ACT_NONE, 1.0f, -INFINITY, INFINITY, 1, 0,
-                                            0, 0, 0, st, nullptr, 0, 1.0f, &nf2);
-                        // z2 = fc2(mid) + alpha * r1 * w_norm1 o z1; row statistics of z2
-                        const BhNormFold nf3{nullptr, r1, (const float*)l.w4.p, part};
-                        if (!rc) rc = bh_k_linear_nf(e->t_mid.p, l.w3.p, nullptr, dstf, M, D, F, F, F, D, bh::ACT_NONE, 1.0f, -INFINITY, INFINITY, 0, 0,
-                                                     0, 0, 0, st, e->t_b.p, D, d.alpha, &nf3);
-                        if (!rc) rc = bh_k_norm_finish(part, D / 64, M, D, eps, r2, st);
-                        if (rc) return rc;
-                    }
-                    cur = dstf; which = (which + 1) % e->n_act;
-                    pend_r = r2; pend_w = (const float*)l.w5.p;
-                    // the last layer of the stack hands a NORMALISED tensor on (one norm kernel per stack instead of two per layer)
-                    const bool more = i + 1 < e->layers.size() && e->layers[i + 1].d.kind == BH_LAYER_TRANSFORMER && e->layers[i + 1].d.in_size == D;
-                    if (!more) {
-                        ProfSpan span(e, st, BH_PROF_MLP);
-                        void* dn = e->act[which].p;
-                        rc = bh_k_rmsnorm_residual(cur, nullptr, pend_w, dn, M, D, d.alpha, eps, st);
-                        if (rc) return rc;
-                        cur = dn; which = (which + 1) % e->n_act;
-                        pend_r = nullptr; pend_w = nullptr;
-                    }
-                    break;
-                }
-                BH_REQUIRE(pend_r == nullptr, "encoder_forward: layer %zu would need the normalised tensor of a folded layer", i);
                 {
                     ProfSpan span(e, st, BH_PROF_ATTENTION);
                     // default: rotary + softmax scale in the Wqkv epilogue, persistent ring-buffer attention kernel; the
@@ -1507,7 +1425,6 @@ extern "C" int bh_encoder_set_option(bh_encoder_t* e, const char* name, int valu
     if (!strcmp(name, "lstm_exchange")) { e->lstm_exchange = value; return 0; }
     if (!strcmp(name, "lstm_pair")) { e->lstm_pair = value; return 0; }
     if (!strcmp(name, "norm_fuse")) { e->norm_fuse = value; return 0; }
-    if (!strcmp(name, "norm_fold")) { e->norm_fold = value; return 0; }
     if (!strcmp(name, "gemm_v1")) { bh_k_linear_force_v1(value); return 0; }   // process-wide A/B switch
     if (!strcmp(name, "lstm_tune")) { e->lstm_force_slow = (e->lstm_force_slow & 1) | (value << 8); return 0; }
     BH_REQUIRE(false, "encoder_set_option: unknown option '%s'", name);

@@ -45,12 +45,6 @@ struct GemmArgs {
     int rot_T = 1, rot_nfeat = 0, rot_qfeat = 0;
     float rot_qscale = 1.0f;
     int w4_gf = 4;     // gemm_w4_kernel: feature tiles per block of its work order (1, 2, 4, 8, 16 or 32; see the kernel)
-    // folded RMSNorm (gemm_w4_kernel only; round 5, DESIGN.md 3a "the norm folded into the projections"): the transformer's activations
-    // are kept UN-normalised (z) with a per-token scale r and the norm's gain w folded into the next projection's weights:
-    const float* rs_in = nullptr;    // [M]  the product is multiplied by rs_in[token] before bias / rotary / SwiGLU (x = r * (w o z) fed as z)
-    const float* res_rs = nullptr;   // [M]  the residual tensor is an un-normalised z too: residual = res_scale * res_rs[token] * res_w[feature] * res
-    const float* res_w = nullptr;    // [N]
-    float* sq_part = nullptr;        // [N / 64][M] sums of squares of the output rows over 64-feature pieces (the next norm's statistics)
 #ifdef BH_GEMM_STATS
     unsigned long long* dbg = nullptr;   // tools/gemm_lab.hip: cycle stamps of workgroup 0 (K loops, epilogues, total, real-time ticks, tiles)
 #endif
@@ -598,9 +592,7 @@ struct W4Store {
 };
 
 // MODE (compile time, so that the block loop is straight-line code the compiler can software-pipeline; with run-time flags every
-// `if` inside it was a join with full s_waitcnt's: 9.5 k cycles per tile whatever the stores did): 1 = residual, 2 = rotary, 4 = scale / clamp,
-// 8 = row scale of the input (rs_in), 16 = the residual carries a row scale and a feature gain (res_rs, res_w), 32 = sums of squares of the
-// output rows (sq_part) - the three pieces of the folded RMSNorm
+// `if` inside it was a join with full s_waitcnt's: 9.5 k cycles per tile whatever the stores did): 1 = residual, 2 = rotary, 4 = scale / clamp
 template <int ACT, bool GATED, int MODE, typename PARK>
 __device__ __forceinline__ bool w4_epilogue(const GemmArgs& p, float16_t (&acc)[4][4], int f0, int t0, int wa, int wb, int lane, char* scratch,
                                             PARK (&park)[W4_NPARK], W4Store& st) {
@@ -625,8 +617,6 @@ __device__ __forceinline__ bool w4_epilogue(const GemmArgs& p, float16_t (&acc)[
         st.rowb = (unsigned)__builtin_amdgcn_readfirstlane(rowbytes);
     }
     constexpr bool has_res = (MODE & 1) != 0;
-    constexpr bool rs_in = (MODE & 8) != 0, res_nrm = (MODE & 16) != 0, sq_out = (MODE & 32) != 0;
-    static_assert(!res_nrm || has_res, "a normed residual is a residual");
     const __amdgpu_buffer_rsrc_t rrsrc = __builtin_amdgcn_make_buffer_rsrc(
         (void*)(has_res ? p.res + (long)tw * p.ldres + fw : p.out), 0, 0x7ffffff0, 0x00020000);
     const int resbytes = p.ldres * 2;
@@ -676,57 +666,17 @@ __device__ __forceinline__ bool w4_epilogue(const GemmArgs& p, float16_t (&acc)[
                         rres[rr] = __builtin_amdgcn_raw_buffer_load_b128(rrsrc, rvoff + P * 128, (32 * i + 8 * rr) * resbytes, 0);
                 }
             }
-            // row scales of the lane's four tokens of this block (clamped inside M for the rows a ragged tile does not store)
-            float rsv[4] = {1.0f, 1.0f, 1.0f, 1.0f}, rrv[4] = {1.0f, 1.0f, 1.0f, 1.0f};
-            float wq[8];                        // res_nrm: the gain of the lane's eight features of this feature pair (reloaded per block:
-            if constexpr (rs_in || res_nrm) {   // sixteen more live registers through the whole epilogue spilled)
-#pragma unroll
-                for (int rr = 0; rr < 4; ++rr) {
-                    const int tok = min(tw + 32 * i + 8 * rr + tl, p.M - 1);
-                    if constexpr (rs_in) rsv[rr] = p.rs_in[tok];
-                    if constexpr (res_nrm) rrv[rr] = p.res_scale * p.res_rs[tok];
-                }
-                if constexpr (res_nrm) {
-                    const float4_t w0 = *(const float4_t*)(p.res_w + fw + P * 64 + 8 * q), w1 = *(const float4_t*)(p.res_w + fw + P * 64 + 8 * q + 4);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) { wq[e] = w0[e]; wq[4 + e] = w1[e]; }
-                }
-            }
             if (b + 1 < 8) write_block(acc[(b + 1) >> 1][2 * ((b + 1) & 1)], acc[(b + 1) >> 1][2 * ((b + 1) & 1) + 1]);
             const bool rot_here = rot && fw + P * 64 < p.rot_nfeat;
             const float rqs = fw + P * 64 < p.rot_qfeat ? p.rot_qscale : 1.0f;
 #pragma unroll
             for (int rr = 0; rr < 4; ++rr) {
-                float v[8];
-                if constexpr (rs_in) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) { v[e] = __fmaf_rn(lo[rr][e], rsv[rr], bq[P][e]); v[4 + e] = __fmaf_rn(hi[rr][e], rsv[rr], bq[P][4 + e]); }
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) { v[e] = lo[rr][e] + bq[P][e]; v[4 + e] = hi[rr][e] + bq[P][4 + e]; }
-                }
+                float v[8] = {lo[rr][0] + bq[P][0], lo[rr][1] + bq[P][1], lo[rr][2] + bq[P][2], lo[rr][3] + bq[P][3],
+                              hi[rr][0] + bq[P][4], hi[rr][1] + bq[P][5], hi[rr][2] + bq[P][6], hi[rr][3] + bq[P][7]};
                 if constexpr (has_res) {
                     const half8_t r8 = __builtin_bit_cast(half8_t, rres[rr]);
-                    if constexpr (res_nrm) {
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) v[e] = __fmaf_rn(rrv[rr] * wq[e], (float)r8[e], v[e]);
-                    } else {
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) v[e] += p.res_scale * (float)r8[e];
-                    }
-                }
-                if constexpr (sq_out) {
-                    // sum of squares of the lane's eight outputs (the values that are rounded to fp16 below), then over the eight lanes
-                    // q = 0 .. 7 that hold the token's other features of this 64-feature piece: xor 1, xor 2 inside the quad, then lane
-                    // q = 0 adds lane q = 4 (row_shl:4 delivers lane + 4); lane q = 0 stores
-                    float ss = 0.0f;
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) ss = __fmaf_rn(v[e], v[e], ss);
-                    ss += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, ss), 0xB1, 0xF, 0xF, true));
-                    ss += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, ss), 0x4E, 0xF, 0xF, true));
-                    ss += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, ss), 0x104, 0xF, 0xF, true));      // row_shl:4: lane <- lane + 4
-                    const int tok = tw + 32 * i + 8 * rr + tl;
-                    if (q == 0 && tok < p.M) p.sq_part[(long)((fw >> 6) + P) * p.M + tok] = ss;
+                    for (int e = 0; e < 8; ++e) v[e] += p.res_scale * (float)r8[e];
                 }
                 if constexpr (rot) {
                     if (rot_here) {
@@ -994,8 +944,7 @@ static int launch(const GemmArgs& a, hipStream_t s) {
             // epilogue modes are compile-time (w4_epilogue): the combinations the engine uses are instantiated, anything else falls through
             // to the eight-wave kernel below
             const bool plain = a.scale == 1.0f && a.clamp_lo == -INFINITY && a.clamp_hi == INFINITY;
-            const int mode = (a.res != nullptr ? 1 : 0) | (a.rot_cs != nullptr ? 2 : 0) | (plain ? 0 : 4) | (a.rs_in != nullptr ? 8 : 0) |
-                             (a.res_rs != nullptr ? 16 : 0) | (a.sq_part != nullptr ? 32 : 0);
+            const int mode = (a.res != nullptr ? 1 : 0) | (a.rot_cs != nullptr ? 2 : 0) | (plain ? 0 : 4);
             bool done = true;
 // four parked rows per K-tile instance on every K (K = 384, six instances: six rows per instance over four of them measured 3 %
 // slower than four rows over five - 0.879 against 0.853 ms on the hac CRF head)
@@ -1005,17 +954,12 @@ static int launch(const GemmArgs& a, hipStream_t s) {
         hipLaunchKernelGGL((gemm_w4_kernel<A_, G_, 4, MODE_>), dim3(slots < cus ? (int)slots : cus), dim3(256), W4_LDS, s, b);      \
     } while (0)
             if constexpr (GATED) {
-                if (mode == 0) W4_LAUNCH(ACT_NONE, true, 0);
-                else if (mode == 8) W4_LAUNCH(ACT_NONE, true, 8);                  // fc1 on an un-normalised input (folded RMSNorm)
-                else done = false;
+                if (mode == 0) W4_LAUNCH(ACT_NONE, true, 0); else done = false;
             } else if constexpr (ACT == ACT_NONE) {
                 if (mode == 0) W4_LAUNCH(ACT_NONE, false, 0);
                 else if (mode == 1) W4_LAUNCH(ACT_NONE, false, 1);
                 else if (mode == 2) W4_LAUNCH(ACT_NONE, false, 2);
                 else if (mode == 4) W4_LAUNCH(ACT_NONE, false, 4);
-                else if (mode == 10) W4_LAUNCH(ACT_NONE, false, 10);               // Wqkv + rotary on an un-normalised input
-                else if (mode == 33) W4_LAUNCH(ACT_NONE, false, 33);               // out_proj / fc2: plain residual + the row statistics
-                else if (mode == 49) W4_LAUNCH(ACT_NONE, false, 49);               // ... with an un-normalised residual (row scale, gain)
                 else done = false;
             } else if constexpr (ACT == ACT_TANH) {
                 if (mode == 4) W4_LAUNCH(ACT_TANH, false, 4); else if (mode == 0) W4_LAUNCH(ACT_TANH, false, 0); else done = false;
@@ -1026,10 +970,6 @@ static int launch(const GemmArgs& a, hipStream_t s) {
             }
 #undef W4_LAUNCH
             if (done) return 0;
-        }
-        if (a.rs_in != nullptr || a.res_rs != nullptr || a.sq_part != nullptr) {
-            bh_set_error("linear: the folded-norm epilogues exist in gemm_w4_kernel only (M=%d N=%d K=%d is not served by it: ask bh_k_linear_w4_applies first)", a.M, a.N, a.K);
-            return -2;
         }
         if (false) {
             return 0;
@@ -1058,27 +998,10 @@ static int launch(const GemmArgs& a, hipStream_t s) {
 void bh_k_linear_force_v1(int on) { bh::g_force_v1 = on; }
 void bh_k_linear_stagger(int units) { bh::g_stagger = units; }
 
-// Whether gemm_w4_kernel serves a plain (identity row map) linear layer of this shape: the engine folds the transformer's RMSNorm into the
-// projections only where all four of a layer's GEMMs are (the folded epilogues exist in that kernel only).
-int bh_k_linear_w4_applies(int M, int N, int K) {
-    using namespace bh;
-    const int nf3 = (N + BF3 - 1) / BF3, nt3 = (M + BT3 - 1) / BT3;
-    return K % 128 == 0 && K >= 384 && (g_force_v1 == 0 || g_force_v1 == 5) && N % 256 == 0 && ((long)nf3 * nt3 >= 512 || g_force_v1 == 5) &&
-           (long)M * K < (1l << 31) && (long)N * K < (1l << 31);
-}
-
 int bh_k_linear(const void* X, const void* W, const float* bias, void* out, int M, int N, int K,
                 int ldx, int ldw, int ldo, int act, float scale, float clamp_lo, float clamp_hi,
                 int gated, int row_div, long row_s_hi, long row_s_lo, int row_lim, hipStream_t stream,
                 const void* residual, int ldres, float res_scale) {
-    return bh_k_linear_nf(X, W, bias, out, M, N, K, ldx, ldw, ldo, act, scale, clamp_lo, clamp_hi, gated, row_div, row_s_hi, row_s_lo, row_lim,
-                          stream, residual, ldres, res_scale, nullptr);
-}
-
-int bh_k_linear_nf(const void* X, const void* W, const float* bias, void* out, int M, int N, int K,
-                   int ldx, int ldw, int ldo, int act, float scale, float clamp_lo, float clamp_hi,
-                   int gated, int row_div, long row_s_hi, long row_s_lo, int row_lim, hipStream_t stream,
-                   const void* residual, int ldres, float res_scale, const BhNormFold* nf) {
     using namespace bh;
     BH_REQUIRE(M > 0 && N > 0 && K > 0, "linear: empty problem M=%d N=%d K=%d", M, N, K);
     BH_REQUIRE(K % 8 == 0 && ldx % 8 == 0 && ldw % 8 == 0, "linear: K/ldx/ldw must be multiples of 8 halves");
@@ -1087,11 +1010,6 @@ int bh_k_linear_nf(const void* X, const void* W, const float* bias, void* out, i
     GemmArgs a;
     a.X = (const half_t*)X; a.W = (const half_t*)W; a.bias = bias; a.out = (half_t*)out;
     a.res = (const half_t*)residual; a.ldres = ldres; a.res_scale = res_scale;
-    if (nf != nullptr) {
-        BH_REQUIRE(N % 64 == 0, "linear: the folded-norm epilogues need N %% 64 == 0");
-        BH_REQUIRE((nf->res_rs == nullptr) == (nf->res_w == nullptr) && (nf->res_rs == nullptr || residual != nullptr), "linear: res_rs / res_w come with a residual");
-        a.rs_in = nf->rs_in; a.res_rs = nf->res_rs; a.res_w = nf->res_w; a.sq_part = nf->sq_part;
-    }
     a.M = M; a.N = N; a.K = K; a.ldx = ldx; a.ldw = ldw; a.ldo = ldo;
     a.scale = scale; a.clamp_lo = clamp_lo; a.clamp_hi = clamp_hi;
     a.row_div = row_div > 0 ? row_div : 1;
@@ -1119,7 +1037,7 @@ int bh_k_linear_nf(const void* X, const void* W, const float* bias, void* out, i
 // Packed Wqkv projection with the rotary embedding (and the softmax scale of q) applied in the epilogue:
 // out[m][0:D) = rot(q) * qscale, out[m][D:2D) = rot(k), out[m][2D:3D) = v; position of row m is m % T. cos_sin: [>=T][32][2].
 int bh_k_linear_qkv_rotary(const void* X, const void* W, const float* bias, void* out, int M, int D, int K, const float* cos_sin,
-                           int T, float qscale, hipStream_t stream, const float* rs_in) {
+                           int T, float qscale, hipStream_t stream) {
     using namespace bh;
     BH_REQUIRE(M > 0 && D > 0 && K > 0 && T > 0 && cos_sin != nullptr, "linear_qkv_rotary: bad arguments");
     BH_REQUIRE(D % 64 == 0 && K % 8 == 0, "linear_qkv_rotary: d_model must be a multiple of 64 (heads of 64), K of 8");
@@ -1131,7 +1049,6 @@ int bh_k_linear_qkv_rotary(const void* X, const void* W, const float* bias, void
     a.row_div = 1; a.row_s_hi = 1; a.row_s_lo = 0; a.row_lim = 0x7fffffff;
     a.n_ft = (a.N + BF - 1) / BF; a.n_tt = (M + BT - 1) / BT;
     a.rot_cs = cos_sin; a.rot_T = T; a.rot_nfeat = 2 * D; a.rot_qfeat = D; a.rot_qscale = qscale;
-    a.rs_in = rs_in;
     if (int rc = launch<ACT_NONE, false>(a, stream)) return rc;
     BH_CHECK_HIP(hipGetLastError());
     return 0;

@@ -11,21 +11,6 @@ int bh_k_linear(const void* X, const void* W, const float* bias, void* out, int 
                 int ldx, int ldw, int ldo, int act, float scale, float clamp_lo, float clamp_hi,
                 int gated, int row_div, long row_s_hi, long row_s_lo, int row_lim, hipStream_t stream,
                 const void* residual = nullptr, int ldres = 0, float res_scale = 1.0f);
-// The transformer's RMSNorm folded into the projections (round 5): activations stay un-normalised (z) with a per-token scale r, the gain
-// of the norm is folded into the next projection's weights by the engine. gemm_w4_kernel only (bh_k_linear_w4_applies).
-struct BhNormFold {
-    const float* rs_in;    // [M] or null: the product is multiplied by rs_in[token] before bias / rotary / SwiGLU
-    const float* res_rs;   // [M] or null: the residual is an un-normalised tensor: residual = res_scale * res_rs[token] * res_w[feature] * res
-    const float* res_w;    // [N] (with res_rs)
-    float* sq_part;        // [N / 64][M] or null: sums of squares of the output rows, per 64-feature piece
-};
-int bh_k_linear_nf(const void* X, const void* W, const float* bias, void* out, int M, int N, int K,
-                   int ldx, int ldw, int ldo, int act, float scale, float clamp_lo, float clamp_hi,
-                   int gated, int row_div, long row_s_hi, long row_s_lo, int row_lim, hipStream_t stream,
-                   const void* residual, int ldres, float res_scale, const BhNormFold* nf);
-int bh_k_linear_w4_applies(int M, int N, int K);
-// r[m] = rsqrt(sum_p part[p][m] / D + eps): the row scale of the folded norm from the partial sums of the producing GEMM
-int bh_k_norm_finish(const float* part, int pieces, long M, int D, float eps, float* r, hipStream_t stream);
 
 void bh_k_linear_force_v1(int on);
 void bh_k_linear_stagger(int units);
@@ -99,7 +84,7 @@ int bh_k_conv_front3(const void* signal, int N, int L0, const float* w1, const f
                      const float* b3, int Cout3, int K3, int stride3, int pad3, int act3, float lo3, float hi3, void* out, long os_n,
                      long os_t, hipStream_t stream);
 int bh_k_linear_qkv_rotary(const void* X, const void* W, const float* bias, void* out, int M, int D, int K, const float* cos_sin,
-                           int T, float qscale, hipStream_t stream, const float* rs_in = nullptr);
+                           int T, float qscale, hipStream_t stream);
 int bh_k_attention_prerotated(const void* qkv, void* out, int N, int T, int nhead, int head_dim, int win_left, int win_right,
                               hipStream_t stream);
 // signal.hip

@@ -466,46 +466,3 @@ def test_wide_layers_calls_of_several_launches(H, N, L, tune):
     with torch.no_grad():
         want = nn_ref.forward(model, x[rows].float(), expand_blanks=False).permute(1, 0, 2)
     assert (one[rows].cpu().float() - want).abs().max().item() < TOL_MAX
-
-
-@pytest.mark.parametrize("batch,chunk", [(5, 7200), (2, 12000)])
-def test_transformer_rmsnorm_folded_into_the_projections_agrees(batch, chunk):
-    """`norm_fold` 1 (default where gemm_w4_kernel serves a layer's four GEMMs): no RMSNorm kernel inside the stack - out_proj / fc2 add
-    alpha * (r * w o z) in their epilogues and emit the rows' sums of squares, Wqkv / fc1 read the un-normalised tensor through weights
-    that carry the norm's gain and a per-token scale (bonito/transformer/model.py:110-111,125-128) - against `norm_fold` 0 (norm
-    kernels) and the fp32 oracle, on a d = 512 / 8 heads / d_ff 2048 stack small enough for the oracle. "gemm_path" 5 sends these small
-    problems to gemm_w4_kernel (ragged last tiles: the predicated instance of the epilogue)."""
-    from bonito_amd import decode, synthetic
-    torch.manual_seed(13)
-    cfg = synthetic.transformer_model_config(d_model=512, nhead=8, dim_ff=2048, depth=3, window=(127, 128), state_len=3,
-                                             batchsize=batch, chunksize=chunk)
-    from bonito_amd.transformer import Model
-    model = Model(cfg).eval()
-    with torch.no_grad():                      # non-trivial gains, so that a gain folded into the wrong weights shows
-        for name, p in model.named_parameters():
-            if name.endswith("norm1.weight") or name.endswith("norm2.weight"):
-                p.copy_(1.0 + 0.3 * torch.randn(p.shape))
-    nn_ref.round_params_to_half_(model.encoder)
-    x = torch.randn(batch, 1, chunk).half()
-    outs = {}
-    try:
-        decode.set_option("gemm_path", 5)
-        for fold in (1, 0):
-            enc = HipEncoder(model.encoder, batchsize=batch, chunksize=chunk)
-            enc.set_option("norm_fold", fold)
-            outs[fold] = enc(x.cuda()).cpu().float()
-            enc.check()
-            if fold:
-                again = enc(x.cuda()).cpu().float()
-                assert torch.equal(again, outs[1])            # deterministic: the row statistics are summed in a fixed order
-    finally:
-        decode.set_option("gemm_path", 0)
-    with torch.no_grad():
-        want = nn_ref.forward(model.encoder, x.float(), expand_blanks=False)
-    if want.shape != outs[1].shape:
-        want = want.permute(1, 0, 2)
-    rng = max(want.abs().max().item(), 1.0)
-    for fold in (1, 0):
-        d = (outs[fold] - want).abs()
-        assert d.max().item() < 2e-2 * rng and d.mean().item() < 3e-3 * rng, (fold, d.max().item(), d.mean().item(), rng)
-    assert (outs[1] - outs[0]).abs().max().item() < 1e-2 * rng
