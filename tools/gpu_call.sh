@@ -1,13 +1,12 @@
 #!/bin/bash
 # One parameterised GPU-box script (replaces the per-session gpu_call*.sh files): runs the named steps in order, every output under gpurun_out/.
 #   usage (on the box, via gpurun): bash tools/gpu_call.sh <tag> step [step ...]
-#   steps: stream (instruction-stream micro-benchmark)  stats2 (section cycles of the paired recurrent kernel)  tests (pytest -m gpu)
+#   steps: stats2 (section cycles of the paired recurrent kernel)  tests (pytest -m gpu)
 #          smoke  bench (default bench.py)  prof (tools/prof_round.sh <tag>)  q8tests  e2e
 cd ${GRAFT_REPO_ROOT:-/root/repo}; mkdir -p gpurun_out
 TAG=$1; shift
 for step in "$@"; do
   case $step in
-    stream) timeout 300 build/streambench/stream_bench 2000 > gpurun_out/${TAG}_stream.log 2>&1; cat gpurun_out/${TAG}_stream.log | cut -c1-220 ;;
     stats2) timeout 300 python tools/lstm_stats2.py 1024 > gpurun_out/${TAG}_stats2.log 2>&1; tail -n 12 gpurun_out/${TAG}_stats2.log ;;
     tests)  timeout 1500 python -m pytest tests -m gpu -x -q > gpurun_out/${TAG}_pytest.log 2>&1; tail -n 5 gpurun_out/${TAG}_pytest.log ;;
     lstmtests) timeout 900 python -m pytest tests/test_gpu_encoder.py tests/test_gpu_configs.py -m gpu -x -q > gpurun_out/${TAG}_pytest_lstm.log 2>&1; tail -n 5 gpurun_out/${TAG}_pytest_lstm.log ;;
