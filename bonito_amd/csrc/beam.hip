@@ -1446,8 +1446,6 @@ int bh_k_crf_logz(const void* scores, int N, int T, int state_len, float blank, 
     float* beta = (float*)w;   w += align((size_t)N * (T + 1) * S * sizeof(float));
     double* Bcum = (double*)w;
     ScanArgs sa{(const half_t*)scores, N, T, S, state_len, blank, beta, Bcum, logz_out, nullptr, g_decode_nt, 1};
-    const int threads = S < 64 ? 64 : S;
-    const size_t lds_scan = (size_t)(BH_LSE_TABLE_SIZE + 2 + 2 * S + 2 * 16 * 16 + 8) * sizeof(float) + (size_t)2 * 4 * S * 2;
     {
         int b_threads = 0;
         size_t b_lds = 0;
@@ -1480,7 +1478,6 @@ int bh_k_posterior_viterbi(const void* scores, int N, int T, int state_len, floa
     uint8_t* bp = (uint8_t*)workspace + bh_k_beam_workspace(N, T, state_len);
     ScanArgs sa{(const half_t*)scores, N, T, S, state_len, blank, beta, Bcum, logZ, nullptr, g_decode_nt, 1};
     const int threads = S < 64 ? 64 : S;
-    const size_t lds_scan = (size_t)(BH_LSE_TABLE_SIZE + 2 + 2 * S + 2 * 16 * 16 + 8) * sizeof(float) + (size_t)2 * 4 * S * 2;
     {
         int b_threads = 0;
         size_t b_lds = 0;
