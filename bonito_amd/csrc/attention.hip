@@ -196,7 +196,13 @@ struct AttnRingArgs {
     int wl, wr;
 };
 
-__global__ __launch_bounds__(512) void attention_ring_kernel(AttnRingArgs p) {
+// WAVES = waves per workgroup = query tiles of 16 per block (8: blocks of 128 queries, the geometry of rounds 2-4; 12: blocks of 192 - the
+// live rows of a block, 272 + 16 WAVES = 464, still fit the 512-row ring, so the same 130 KiB of LDS carry 12 waves per CU instead of 8:
+// the kernel WAITS (two waves per SIMD, 49 % of the wave cycles), it does not issue - round 5)
+template <int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void attention_ring_kernel(AttnRingArgs p) {
+    constexpr int RQB = 16 * WAVES, NTHR = 64 * WAVES;
+    static_assert(272 + RQB <= RING && RQB % 16 == 0, "the block's live rows must fit the ring");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NT = 18;
     char* kl = smem;                              // [RING][128 B] swizzled by slot & 7
@@ -234,17 +240,17 @@ __global__ __launch_bounds__(512) void attention_ring_kernel(AttnRingArgs p) {
         }
     };
 
-    // ---- prologue: rows -128 .. 271 (200 pairs x 8 chunks) -------------------------------------------------------------
-    for (int t = tid; t < 200 * 8; t += 512) {
+    // ---- prologue: rows -128 .. RQB + 143 ((136 + RQB / 2) pairs x 8 chunks) ------------------------------------------------
+    for (int t = tid; t < (136 + RQB / 2) * 8; t += NTHR) {
         uint4_t kv[2], vv[2];
         load_pair(-128, t >> 3, t & 7, kv, vv);
         store_pair(-128, t >> 3, t & 7, kv, vv);
     }
-    const int nblk = (p.T + QB - 1) / QB;
+    const int nblk = (p.T + RQB - 1) / RQB;
     // this wave's 16 queries of a block as B fragments (already rotated and scaled); the next block's are requested one
     // block ahead together with its new key/value rows
     auto load_q = [&](int blk, half8_t (&q)[2]) {
-        const int qi = blk * QB + wave * 16 + (lane & 15);
+        const int qi = blk * RQB + wave * 16 + (lane & 15);
         q[0] = half8_t{0, 0, 0, 0, 0, 0, 0, 0};
         q[1] = q[0];
         if (qi < p.T) {
@@ -256,16 +262,16 @@ __global__ __launch_bounds__(512) void attention_ring_kernel(AttnRingArgs p) {
     half8_t qn[2];
     load_q(0, qn);
     for (int b = 0; b < nblk; ++b) {
-        const int i0 = b * QB;
+        const int i0 = b * RQB;
         const int jb = i0 - 128;
         const int qi = i0 + wave * 16 + (lane & 15);
         half8_t qf[2] = {qn[0], qn[1]};
         if (b + 1 < nblk) load_q(b + 1, qn);
-        // the 128 rows the NEXT block adds (128(b+1)+144 .. +271): requested now, stored after this block's compute
+        // the RQB rows the NEXT block adds (i0 + RQB + 144 ..): requested now, stored after this block's compute
         uint4_t nk[2], nv[2];
-        const int nfirst = i0 + QB + 144;
+        const int nfirst = i0 + RQB + 144;
         const bool more = b + 1 < nblk;
-        if (more) load_pair(nfirst, tid >> 3, tid & 7, nk, nv);        // 64 pairs x 8 chunks = 512 tasks
+        if (more) load_pair(nfirst, tid >> 3, tid & 7, nk, nv);        // RQB / 2 pairs x 8 chunks = one task per thread
         __syncthreads();                          // ring rows of this block are in place
 
         const int rel0 = wave * 16;               // this wave's first key tile, relative to jb
@@ -291,7 +297,7 @@ __global__ __launch_bounds__(512) void attention_ring_kernel(AttnRingArgs p) {
         // the wave's keys, query q of the wave sees q+1-(128-wl) .. q+128+wr): the 15 interior tiles skip the mask.
         const int kfirst = jb + rel0 + g * 4;
         const int lo = max(qi - p.wl, 0) - kfirst, hi = min(qi + p.wr, p.T - 1) - kfirst;
-        const bool edge = jb < 0 || jb + 400 > p.T || p.wl != 127 || p.wr != 128;       // block-uniform
+        const bool edge = jb < 0 || jb + 272 + RQB > p.T || p.wl != 127 || p.wr != 128;       // block-uniform
         float m = -INFINITY;
 #pragma unroll
         for (int kt = 0; kt < NT; ++kt) {
@@ -445,6 +451,8 @@ int bh_k_attention(const void* qkv, void* out, const float* cos_sin, int N, int 
 }
 
 // q (already rotated and scaled) | k (already rotated) | v  ->  attention output; see attention_ring_kernel.
+int g_attn_waves = 0;      // bh_set_option("attn_waves", 0 | 8 | 12): 0 = automatic
+
 int bh_k_attention_prerotated(const void* qkv, void* out, int N, int T, int nhead, int head_dim, int win_left, int win_right,
                               hipStream_t stream) {
     using namespace bh;
@@ -454,8 +462,15 @@ int bh_k_attention_prerotated(const void* qkv, void* out, int N, int T, int nhea
     BH_REQUIRE(N > 0 && T > 0 && nhead > 0, "attention: empty problem");
     AttnRingArgs a{(const half_t*)qkv, (half_t*)out, N, T, nhead, win_left, win_right};
     const size_t lds = (size_t)RING * 128 + (size_t)64 * RVS * 2;
-    BH_CHECK_HIP(bh_max_lds((const void*)attention_ring_kernel, (int)lds));
-    hipLaunchKernelGGL(attention_ring_kernel, dim3(nhead, N), dim3(512), lds, stream, a);
+    // twelve waves (blocks of 192 queries) where the chunk is long enough to fill them; "attn_waves" 8 / 12 forces a geometry
+    const int waves = g_attn_waves == 8 || g_attn_waves == 12 ? g_attn_waves : (T >= 384 ? 12 : 8);
+    if (waves == 12) {
+        BH_CHECK_HIP(bh_max_lds((const void*)attention_ring_kernel<12>, (int)lds));
+        hipLaunchKernelGGL(attention_ring_kernel<12>, dim3(nhead, N), dim3(768), lds, stream, a);
+    } else {
+        BH_CHECK_HIP(bh_max_lds((const void*)attention_ring_kernel<8>, (int)lds));
+        hipLaunchKernelGGL(attention_ring_kernel<8>, dim3(nhead, N), dim3(512), lds, stream, a);
+    }
     BH_CHECK_HIP(hipGetLastError());
     return 0;
 }

@@ -1469,6 +1469,7 @@ extern "C" int bh_set_option(const char* name, int value) {
     if (bh_k_conv_set_option(name, value) == 0) return 0;
     if (bh_k_lstm_set_option(name, value) == 0) return 0;
     if (!strcmp(name, "gemm_path")) { bh_k_linear_force_v1(value); return 0; }
+    if (!strcmp(name, "attn_waves")) { extern int g_attn_waves; g_attn_waves = value; return 0; }
     if (!strcmp(name, "gemm_stagger")) { bh_k_linear_stagger(value); return 0; }
     if (!strcmp(name, "lstm_q8_variant")) { g_q8_variant = value; return 0; }
     BH_REQUIRE(false, "set_option: unknown option '%s'", name);

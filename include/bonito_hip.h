@@ -209,6 +209,7 @@ int bh_lstm_q8_layer(const void* x, float bound, const float* w_ih, const float*
  *   "beam_cpw": chunks per workgroup of the fused beam kernel at 256 states: 0 (default) = the smallest of 1 / 2 / 4 that lets all
  *                chunks of the call be resident at once (5 / 6 / 8 chunks per CU; the kernels are latency chains, so chunks in
  *                flight per CU are what counts: 2048 x 1667 steps 12.0 -> 8.7 ms on MI355X); 1, 2, 4 force a geometry. Same bytes.
+ *   "attn_waves": 0 (default) = automatic, 8 / 12 = waves per workgroup of the ring attention kernel (query blocks of 128 / 192; same results).
  *   "beam_select": 0 (default) = top-W selection by histogram + exact boundary ranking, 1 = MSB-first radix search
  *                (the same beams either way; kept for regression tests and A/B timing).
  *   "conv_ws": 1 (default) = weight-stationary kernel for the 384-channel / 19-tap convolution, 0 = generic implicit GEMM.
