@@ -177,6 +177,19 @@ def test_transformer_long_chunk_ring_attention_matches_oracle():
     for ring in (1, 0):
         assert outs[ring].shape == want.shape
         assert (outs[ring] - want).abs().max().item() < 2e-2 * rng, ring
+    # the ring kernel's two geometries (round 5: twelve waves = query blocks of 192 is the automatic choice from 384 tokens on; eight =
+    # blocks of 128): a query sees the same key tiles in the same order either way - identical bytes
+    from bonito_amd import decode
+    geo = {}
+    try:
+        for waves in (8, 12):
+            decode.set_option("attn_waves", waves)
+            enc = HipEncoder(model.encoder, batchsize=3, chunksize=8400)
+            geo[waves] = enc(x.cuda()).cpu()
+            enc.check()
+    finally:
+        decode.set_option("attn_waves", 0)
+    assert torch.equal(geo[8], geo[12]) and torch.equal(geo[12].float(), outs[1])
 
 
 def test_fused_and_unfused_lstm_paths_agree():
