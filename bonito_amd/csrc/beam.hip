@@ -1101,14 +1101,14 @@ __global__ __launch_bounds__(64 * (CPW + beam_scan_waves<STATE_LEN, CPW, FUSE>()
     uint8_t* bpn = p.bp + (long)n * T * MAXW;
 
     long long dsec[6] = {0, 0, 0, 0, 0, 0};
-    // candidate decomposition is time-invariant: c = lane + 64*i = e*5 + j
-    int ce[3], cj[3], cer[3];
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        const int c = lane + 64 * i;
-        ce[i] = c / 5; cj[i] = c - ce[i] * 5;
-        cer[i] = ce[i] < MAXW ? ce[i] : 0;             // in-range element index for unconditional reads
-    }
+    // The lane's three candidate slots (time-invariant; round 5): slot 0 = the STAY of element `lane` (lanes < 32), slots 1 and 2 = the
+    // MOVES 4 e + x = lane and 64 + lane (elements lane >> 2 and 16 + (lane >> 2), base x = lane & 3). Candidate order - ties, slots of the
+    // new beam - is (slot, lane): the stays by element, then the moves by (element, base), as in oracle_beam_search. A merge then costs
+    // ONE lse2 per lane (slot 0) and the hash lookup TWO slots; with the candidates interleaved as c = 5 e + j (rounds 1-4) every slot of
+    // every lane ran both.
+    const int ce[3] = {lane & (MAXW - 1), lane >> 2, 16 + (lane >> 2)};
+    const int mx = lane & 3;
+    const bool stay_lane = lane < MAXW;
 
     // ---- init: top-W states by beta~_0 (ties: lower state), slots in state order ------------------
     int nb;
@@ -1200,48 +1200,52 @@ __global__ __launch_bounds__(64 * (CPW + beam_scan_waves<STATE_LEN, CPW, FUSE>()
             long long tc0 = 0;
             if (DBG) tc0 = __builtin_readcyclecounter();
             // ---- (b) candidates; a move that spells the same sequence as a stay is folded into it ---
-            // Every LDS level is issued for all three candidates before it is consumed, and nothing is conditional on
-            // loaded data: level 1 = parent element, level 2 = transition score + guide + hash bucket.
+            // Every LDS level is issued for all slots before it is consumed, and nothing is conditional on loaded data:
+            // level 1 = parent element, level 2 = transition score + guide + hash bucket (moves), guide (stay).
             // A candidate that does not exist (beyond the beam) or was folded into a stay carries score -inf.
             float cs[3];
             unsigned ch[3];
             int cst[3], cinfo[3];
             uint4_t el[3];
 #pragma unroll
-            for (int i = 0; i < 3; ++i) el[i] = b_elem[cer[i]];
+            for (int i = 0; i < 3; ++i) el[i] = b_elem[ce[i]];
             float mv[3], bg[3];
             uint4_t ent0[3];
+            {   // slot 0: the stay
+                const int es = (int)(el[0].x & (unsigned)(S - 1));      // (stale slots beyond the beam stay in range)
+                cst[0] = es; ch[0] = el[0].y; cinfo[0] = ce[0];
+                bg[0] = b1[es];
+            }
 #pragma unroll
-            for (int i = 0; i < 3; ++i) {
-                const int es = (int)(el[i].x & (unsigned)(S - 1));      // (stale slots beyond the beam stay in range)
-                const int x = cj[i] > 0 ? cj[i] - 1 : 0;
-                const int s2 = ((es << 2) | x) & (S - 1);
-                cst[i] = cj[i] == 0 ? es : s2;
-                ch[i] = cj[i] == 0 ? el[i].y : bs_mix(el[i].y, x);
-                cinfo[i] = cj[i] == 0 ? ce[i] : (ce[i] | (1 << 5) | (x << 6));
-                const int bk = (int)(ch[i] & (NBK - 1));
+            for (int i = 1; i < 3; ++i) {
+                const int es = (int)(el[i].x & (unsigned)(S - 1));
+                const int s2 = ((es << 2) | mx) & (S - 1);
+                cst[i] = s2;
+                ch[i] = bs_mix(el[i].y, mx);
+                cinfo[i] = ce[i] | (1 << 5) | (mx << 6);
                 mv[i] = (float)row[s2 * 4 + (es >> sh)];
-                bg[i] = b1[cst[i]];               // linear guide value; its logarithm is taken once the loads have landed
-                ent0[i] = *(const uint4_t*)(tb.ent + bk * BKE);
+                bg[i] = b1[s2];
+                ent0[i] = *(const uint4_t*)(tb.ent + (int)(ch[i] & (NBK - 1)) * BKE);
             }
             const int n_ov = tb.ov_cnt[0];
+            cs[0] = (stay_lane && ce[0] < nb) ? __uint_as_float(el[0].z) + p.blank : -INFINITY;
             unsigned dhit[3];
 #pragma unroll
-            for (int i = 0; i < 3; ++i) {
-                cs[i] = ce[i] < nb ? __uint_as_float(el[i].z) + (cj[i] == 0 ? p.blank : mv[i]) : -INFINITY;
+            for (int i = 1; i < 3; ++i) {
+                cs[i] = ce[i] < nb ? __uint_as_float(el[i].z) + mv[i] : -INFINITY;
                 dhit[i] = bucket_match(ent0[i], ch[i], tag | ((unsigned)cst[i] << 5));
             }
-            if (n_ov > 0) {                              // rare: some bucket held more than four elements
+            if (n_ov > 0) {                              // rare: some bucket held more than two elements
                 for (int k = 0; k < n_ov; ++k) {
                     const uint2_t e = tb.ov[k];
 #pragma unroll
-                    for (int i = 0; i < 3; ++i)
+                    for (int i = 1; i < 3; ++i)
                         dhit[i] = min(dhit[i], e.x == ch[i] ? e.y - (tag | ((unsigned)cst[i] << 5)) : 32u);
                 }
             }
 #pragma unroll
-            for (int i = 0; i < 3; ++i)
-                if (cj[i] != 0 && ce[i] < nb && dhit[i] < 32u) {
+            for (int i = 1; i < 3; ++i)
+                if (ce[i] < nb && dhit[i] < 32u) {
                     m_pair[dhit[i]] = uint2_t{__float_as_uint(cs[i]), (unsigned)cinfo[i]};
                     cs[i] = -INFINITY;
                 }
@@ -1250,17 +1254,12 @@ __global__ __launch_bounds__(64 * (CPW + beam_scan_waves<STATE_LEN, CPW, FUSE>()
             if (lane < 4) tb.ov_cnt[lane] = 0;
             if (DBG) { const long long t1 = __builtin_readcyclecounter(); dsec[0] += t1 - tc0; tc0 = t1; }
             {   // (no barriers inside a step: one wave per workgroup, and LDS operations complete in issue order)
-                uint2_t mp[3];
-#pragma unroll
-                for (int i = 0; i < 3; ++i) mp[i] = m_pair[cer[i]];
-#pragma unroll
-                for (int i = 0; i < 3; ++i) {
-                    const bool merged = cj[i] == 0 && ce[i] < nb && (int)mp[i].y >= 0;
-                    const float ms = __uint_as_float(mp[i].x);
-                    const float lse = lse2_tab_nb(cs[i], ms, tab);
-                    if (merged && ms > cs[i]) cinfo[i] = (int)mp[i].y;
-                    if (merged) cs[i] = lse;
-                }
+                const uint2_t mp = m_pair[ce[0]];
+                const bool merged = stay_lane && ce[0] < nb && (int)mp.y >= 0;
+                const float ms = __uint_as_float(mp.x);
+                const float lse = lse2_tab_nb(cs[0], ms, tab);
+                if (merged && ms > cs[0]) cinfo[0] = (int)mp.y;
+                if (merged) cs[0] = lse;
             }
             // ---- (c) keys, cut ---------------------------------------------------------------------
             float key[3];

@@ -157,8 +157,8 @@ int oracle_crf_logz(const uint16_t* scores, int N, int T, int state_len, int lay
  *  2. class posteriors P_u[x] = sum_{s & 3 == x} alpha_u[s] beta_u[s] / sum_s alpha_u[s] beta_u[s], u = 1..T: here in fp64 with libm
  *     (oracle_crf_posteriors_f64 - the TRUE posteriors of the model; the HIP kernels run a linear-domain fp32 scan and are held to
  *     1e-3 on the q-scores derived from them).
- *  3. beam search over (state, sequence hash): stay / 4 moves per element, merge a move into the stay
- *     that spells the same sequence (table lse2), rank by score + bs2_log(b_{t+1}[state]), cut at best - log(beam_cut),
+ *  3. beam search over (state, sequence hash): stay / 4 moves per element (candidate order: the stays by element, then the moves by
+ *     element and base), merge a move into the stay that spells the same sequence (table lse2), rank by score + bs2_log(b_{t+1}[state]), cut at best - log(beam_cut),
  *     keep `beam_width` (ties: lower candidate index), slots in candidate-index order.
  *  4. traceback from the best final element; per emitted base x with dwell u = t+1..t':
  *        err = mean_u sum_{y != x} P_u[y];  q = -10 log10(max(err, 1e-10)) * scale + offset, clamped to [1, 50]
@@ -433,34 +433,37 @@ int oracle_beam_search(const uint16_t* scores, int N, int T, int state_len, int 
         for (int t = 0; t < T; ++t) {
             const uint16_t* sc = scores + ((size_t)n * T + t) * 4 * S;
             const float* b1 = bn + (size_t)(t + 1) * S;
-            /* candidates: index c = e*5 + j */
+            /* candidates in THIS order (it decides ties and the slots of the new beam): the stays, c = e, then the moves, c = 32 + 4 e + x
+               (round 5: the kernels keep the stays of all elements in one lane set and the 128 moves in two - a merge costs one lse2 per
+               lane instead of three; rounds 1-4 interleaved them as c = 5 e + j) */
             int c_state[BS_MAXW * 5];
             uint32_t c_hash[BS_MAXW * 5];
             float c_score[BS_MAXW * 5], c_key[BS_MAXW * 5];
             uint8_t c_info[BS_MAXW * 5];   /* parent | move<<5 | base<<6 */
             char c_alive[BS_MAXW * 5];
-            const int nc = nb * 5;
+            const int nc = BS_MAXW * 5;
+            memset(c_alive, 0, sizeof(c_alive));
+            for (int c = 0; c < nc; ++c) { c_state[c] = 0; c_hash[c] = 0; c_score[c] = -INFINITY; c_info[c] = 0; }
             for (int e = 0; e < nb; ++e) {
                 const int s = beam[e].state, lead = s >> sh;
-                c_state[e * 5] = s; c_hash[e * 5] = beam[e].hash; c_score[e * 5] = beam[e].score + blank;
-                c_info[e * 5] = (uint8_t)e; c_alive[e * 5] = 1;
+                c_state[e] = s; c_hash[e] = beam[e].hash; c_score[e] = beam[e].score + blank;
+                c_info[e] = (uint8_t)e; c_alive[e] = 1;
                 for (int x = 0; x < 4; ++x) {
-                    const int c = e * 5 + 1 + x, s2 = ((s << 2) | x) & (S - 1);
+                    const int c = BS_MAXW + e * 4 + x, s2 = ((s << 2) | x) & (S - 1);
                     c_state[c] = s2; c_hash[c] = bs_mix(beam[e].hash, x);
                     c_score[c] = beam[e].score + h2f(sc[s2 * 4 + lead]);
                     c_info[c] = (uint8_t)(e | (1 << 5) | (x << 6)); c_alive[c] = 1;
                 }
             }
-            /* merge a move into the stay that spells the same sequence */
+            /* merge a move into the stay that spells the same sequence (the first such stay) */
             for (int e = 0; e < nb; ++e)
                 for (int x = 0; x < 4; ++x) {
-                    const int c = e * 5 + 1 + x;
+                    const int c = BS_MAXW + e * 4 + x;
                     for (int d = 0; d < nb; ++d) {
-                        const int cs = d * 5;
-                        if (c_hash[cs] == c_hash[c] && c_state[cs] == c_state[c]) {
+                        if (c_hash[d] == c_hash[c] && c_state[d] == c_state[c]) {
                             const float stay_sc = beam[d].score + blank;   /* un-merged stay score */
-                            if (c_score[c] > stay_sc) c_info[cs] = c_info[c];
-                            c_score[cs] = oracle_lse2(stay_sc, c_score[c]);
+                            if (c_score[c] > stay_sc) c_info[d] = c_info[c];
+                            c_score[d] = oracle_lse2(stay_sc, c_score[c]);
                             c_alive[c] = 0;
                             break;
                         }
