@@ -1150,13 +1150,7 @@ __global__ __launch_bounds__(64 * (CPW + beam_scan_waves<STATE_LEN, CPW, FUSE>()
             const unsigned long long tm = __ballot(take);
             if (take) {          // step tag 0
                 const int slot = before + popc64(tm & lanemask_lt(lane));
-                const unsigned h = bs_hash0(s);
-                b_elem[slot] = uint4_t{(unsigned)s, h, 0u /* score 0.0f */, 0u};
-                const int bk = (int)(h & (NBK - 1));
-                const int pos = atomicAdd(&tb.cnt[bk], 1);
-                const uint2_t e{h, ((unsigned)s << 5) | (unsigned)slot};
-                if (pos < BKE) tb.ent[bk * BKE + pos] = e;
-                else tb.ov[atomicAdd(tb.ov_cnt, 1)] = e;
+                b_elem[slot] = uint4_t{(unsigned)s, bs_hash0(s), 0u /* score 0.0f */, 0u};      // (the hash table is built at the head of every step)
             }
             tie_before += popc64(eq);
             before += popc64(tm);
@@ -1196,7 +1190,6 @@ __global__ __launch_bounds__(64 * (CPW + beam_scan_waves<STATE_LEN, CPW, FUSE>()
             const half_t* row = blk_sc + u * 4 * S;
             const float* b1 = blk_b + u * S;
             const unsigned tag = ((unsigned)(tb0 + u) & TAG_MASK) << 15;            // of the table built for this step
-            const unsigned tag_next = ((unsigned)(tb0 + u + 1) & TAG_MASK) << 15;
             long long tc0 = 0;
             if (DBG) tc0 = __builtin_readcyclecounter();
             // ---- (b) candidates; a move that spells the same sequence as a stay is folded into it ---
@@ -1215,6 +1208,16 @@ __global__ __launch_bounds__(64 * (CPW + beam_scan_waves<STATE_LEN, CPW, FUSE>()
                 const int es = (int)(el[0].x & (unsigned)(S - 1));      // (stale slots beyond the beam stay in range)
                 cst[0] = es; ch[0] = el[0].y; cinfo[0] = ce[0];
                 bg[0] = b1[es];
+                // ... which is what the moves look up: the beam's elements enter this step's hash table here, ONE LDS atomic per element
+                // (round 5; rounds 2-4 inserted the selected candidates at the end of the previous step from three divergent blocks with
+                // an atomic each). One wave: the bucket reads below are issued behind these writes and LDS operations complete in order.
+                if (stay_lane && ce[0] < nb) {
+                    const int bk = (int)(ch[0] & (NBK - 1));
+                    const int pos = atomicAdd(&tb.cnt[bk], 1);
+                    const uint2_t e{ch[0], tag | ((unsigned)es << 5) | (unsigned)lane};
+                    if (pos < BKE) tb.ent[bk * BKE + pos] = e;
+                    else tb.ov[atomicAdd(tb.ov_cnt, 1)] = e;
+                }
             }
 #pragma unroll
             for (int i = 1; i < 3; ++i) {
@@ -1295,25 +1298,14 @@ __global__ __launch_bounds__(64 * (CPW + beam_scan_waves<STATE_LEN, CPW, FUSE>()
                     }
                 }
             }
-            // new beam + its hash table (atomics of the three candidates in flight together)
-            int pos[3];
-#pragma unroll
-            for (int i = 0; i < 3; ++i) {
-                pos[i] = 0;
-                if (sel[i]) {
-                    b_elem[slot[i]] = uint4_t{(unsigned)cst[i], ch[i], __float_as_uint(cs[i] - shift), 0u};
-                    st_bp[u * MAXW + slot[i]] = (uint8_t)cinfo[i];
-                    pos[i] = atomicAdd(&tb.cnt[ch[i] & (NBK - 1)], 1);
-                }
-            }
-            if (lane < MAXW) m_pair[lane] = uint2_t{0u, 0xffffffffu};
+            // the new beam (its elements enter the hash table at the head of the next step)
 #pragma unroll
             for (int i = 0; i < 3; ++i)
                 if (sel[i]) {
-                    const uint2_t e{ch[i], tag_next | ((unsigned)cst[i] << 5) | (unsigned)slot[i]};
-                    if (pos[i] < BKE) tb.ent[(ch[i] & (NBK - 1)) * BKE + pos[i]] = e;
-                    else tb.ov[atomicAdd(tb.ov_cnt, 1)] = e;
+                    b_elem[slot[i]] = uint4_t{(unsigned)cst[i], ch[i], __float_as_uint(cs[i] - shift), 0u};
+                    st_bp[u * MAXW + slot[i]] = (uint8_t)cinfo[i];
                 }
+            if (lane < MAXW) m_pair[lane] = uint2_t{0u, 0xffffffffu};
             nb = nnew;
             if (DBG) { const long long t1 = __builtin_readcyclecounter(); dsec[3] += t1 - tc0; dsec[4] += nb; }
         }
