@@ -132,6 +132,29 @@ def viterbi_bruteforce(scores_tnc_5s, state_len):
     return best, paths
 
 
+def map_sequence_bruteforce(scores_t4s, state_len, blank=2.0):
+    """EXACT sequence posterior of a tiny problem: {sequence: ln sum of exp(path score) over every path spelling it} for koi-layout
+    scores [T, 4S] (fp64 arithmetic, unpruned prefix search: every (sequence, state) pair is kept). The target a beam search
+    approximates - independent of BS-1 / BS-2 / the guide; used by tests only (cost ~ 5^T)."""
+    x = np.asarray(scores_t4s, dtype=np.float64)
+    T, S = x.shape[0], 4 ** state_len
+    cur = {("", s): 0.0 for s in range(S)}
+    for t in range(T):
+        new = {}
+        for (seq, s), lp in cur.items():
+            cands = [((seq, s), lp + blank)]
+            for b in range(4):
+                ns = ((s << 2) | b) & (S - 1)
+                cands.append(((seq + "ACGT"[b], ns), lp + x[t, ns * 4 + s // (S // 4)]))
+            for k, v in cands:
+                new[k] = np.logaddexp(new[k], v) if k in new else v
+        cur = new
+    total = {}
+    for (seq, _), lp in cur.items():
+        total[seq] = np.logaddexp(total[seq], lp) if seq in total else lp
+    return total
+
+
 def beam_search(scores, state_len, beam_width=32, beam_cut=100.0, blank=2.0, scale=1.0, offset=0.0):
     """BS-2 decode (linear-domain guide, fp64 posteriors; BS-1 = the table-lse2 guide of rounds 1-4) of koi-layout scores [N,T,4S] (float16). Returns (sequence, qstring, moves, qfloat)."""
     a, bits = _as_half_bits(scores)

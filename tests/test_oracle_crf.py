@@ -122,6 +122,52 @@ def test_wide_beam_recovers_planted_sequence():
     assert np.median(qf[mv == 1]) > 20
 
 
+def _beam_vs_exact_map(cases, make):
+    misses, worst = 0, 0.0
+    for sl, T, seed in cases:
+        x = make(sl, T, seed)
+        total = crf_ref.map_sequence_bruteforce(x[0], sl)
+        best = max(total, key=total.get)
+        seq, _, mv, _ = crf_ref.beam_search(x, sl)
+        got = "".join(chr(c) for c in seq[0] if c)
+        assert got in total and len(got) == int(mv.sum())
+        if got != best:
+            misses += 1
+            worst = max(worst, total[best] - total[got])
+    return misses, worst
+
+
+def test_beam_search_finds_the_exact_map_sequence_on_peaked_scores_and_stays_close_on_flat_ones():
+    """The beam search is the builder's own definition (koi is a closed wheel), so it is pinned to what ANY beam search approximates: the
+    sequence with the largest total path probability, computed exactly by an unpruned prefix search in fp64 (tiny T only). Scores with
+    a planted path (what a trained head emits): the beam's sequence IS the exact MAP sequence in every case. Flat random scores (the
+    hardest input: thousands of sequences within a nat of each other, 5461-87381 distinct sequences against a beam of 32): the MAP in
+    29 of 36 cases (asserted: at least 75 %) and never more than one nat below it (measured worst: 0.78)."""
+    def peaked(sl, T, seed):
+        rng = np.random.default_rng(5000 * sl + 10 * T + seed)
+        S = 4 ** sl
+        x = np.clip(rng.standard_normal((1, T, 4 * S)) * 1.5, -5, 5)
+        st = int(rng.integers(S))
+        for t in range(T):
+            if rng.random() < 0.5:
+                ns = ((st << 2) | int(rng.integers(4))) & (S - 1)
+                x[0, t, ns * 4 + st // (S // 4)] += 6.0
+                st = ns
+            else:
+                x[0, t] -= 3.0
+        return np.clip(x, -5, 5).astype(np.float16)
+
+    def flat(sl, T, seed):
+        rng = np.random.default_rng(1000 * sl + 10 * T + seed)
+        return np.clip(rng.standard_normal((1, T, 4 * 4 ** sl)) * 2.5, -5, 5).astype(np.float16)
+
+    misses, _ = _beam_vs_exact_map([(sl, T, seed) for sl, T in ((1, 8), (2, 7)) for seed in range(12)], peaked)
+    assert misses == 0
+    cases = [(sl, T, seed) for sl, T in ((1, 6), (1, 8), (2, 6)) for seed in range(12)]
+    misses, worst = _beam_vs_exact_map(cases, flat)
+    assert misses <= 0.25 * len(cases) and worst < 1.0, (misses, worst)
+
+
 def test_reverse_complement_matches_reference_fixture():
     import os
     from conftest import GOLDEN
