@@ -534,7 +534,7 @@ __device__ __forceinline__ int hist_select(const float (&key)[3], const unsigned
 }
 
 // Stay elements keyed by sequence hash: NBK buckets of BKE entries (hash, step tag << 15 | state << 5 | slot), filled
-// with one LDS atomic per element as the beam is written; a move candidate reads its whole bucket with one 16-byte load
+// with one LDS atomic per element at the head of the step (by the lane that owns the element's stay); a move candidate reads its whole bucket with one 16-byte load
 // and compares in registers - one LDS round trip and no divergent probe loop. Entries of earlier steps carry another
 // tag and never match, so nothing is cleared but the bucket fill counters. A third element in a bucket (a few percent
 // of the steps) goes to an overflow list that every lookup then scans. Ties between equal (hash, state) stays resolve to the lowest slot, like
