@@ -13,6 +13,8 @@ model = model.half().cuda()
 sig = torch.randn(256, 1, chunk, device="cuda").half()
 model(sig)
 enc = model._hip
+if extra:
+    enc.set_option("lstm_tune", extra)      # the timed passes run with the extra bits too (e.g. 128: round-4 poll order)
 print([ln for ln in enc.describe().splitlines() if "lstm" in ln][0])
 enc.profile(True)
 for _ in range(3):
