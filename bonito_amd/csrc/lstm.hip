@@ -1560,9 +1560,12 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_wide_kernel(LstmWideArgs wp
             // steps need a second round). Tile 0 polls tile 1's h_{t-1}, tile 1 polls tile 0's h_t.
             // Same box, sup-LSTM 256 x 20000, ms per launch: lock step 11.40-11.44, this 11.04-11.11, polls an eighth of the way in
             // 11.25-11.29. Also measured (tools/lstm_wide_stats.py, cycles per step incl. ~1.1 k of stamps; base 7290): fragment reads
-            // 2 / 4 k-steps ahead 7240 / 7260 - the loop is bound by LDS BANDWIDTH, not latency: the four waves read the same 32 KiB
-            // tile, 128 KiB per half-step at 128 B per clock = the 1024 cycles of its MFMAs; the gate prefetch behind the polls 7900; a
-            // counted vmcnt in front of the publish 7430; even / odd k-steps in separate accumulators 8280.
+            // 2 / 4 k-steps ahead 7240 / 7260; the gate prefetch behind the polls 7900; a counted vmcnt in front of the publish 7430; even /
+            // odd k-steps in separate accumulators 8280. Round 5 (profiles/r05_lstm_wide_elimination.txt): NOT LDS bandwidth, as round 4
+            // read it - without any fragment read the section loses 260 cycles per step; the 64 MFMAs of a half-step are 1056 cycles in any
+            // order (the s_nop hipcc puts between them is free), the eight poll loads cost ~900 cycles of blocked issue (~116 for quiet
+            // data) and the two add wherever the polls are placed (burst, one every 1-3 k-steps, reads 6-10 ahead, own quarter from the
+            // poll registers, rotated per workgroup: all within 3 %). With no MFMAs at all the layer keeps 81 % of its time.
             const int ob = 1 - nb;                      // (a constant after unrolling)
             const bool want = nb == 1 ? step + 1 < p.T : step > 0;
             auto other_polls = [&]() __attribute__((always_inline)) {
