@@ -106,6 +106,25 @@ def test_beam_search_matches_oracle(state_len):
     assert set(np.unique(seq.numpy())) <= {0, 65, 67, 71, 84}
 
 
+@pytest.mark.parametrize("state_len", [1, 2, 3, 4, 5])
+def test_beam_search_edge_shapes_match_oracle(state_len):
+    """Ragged ends of the launch geometry: one and two time steps (shorter than a staging block), one chunk, and chunk counts on both sides
+    of what a wave / a workgroup packs (64 / 16 / 4 chunks per wave below 256 states, four chunks per workgroup above) - bit-exact sequence
+    and moves, q within tolerance, both decoders."""
+    rng = np.random.default_rng(900 + state_len)
+    S = 4 ** state_len
+    shapes = [(1, 1), (1, 2), (2, 3), (5, 5), (17, 9), (65, 4)] if state_len < 5 else [(1, 1), (1, 2), (3, 5), (5, 9)]
+    for N, T in shapes:
+        sc = np.clip(rng.standard_normal((N, T, 4 * S)) * 2.0, -5, 5).astype(np.float16)
+        seq, qs, mv, qf = decode.beam_search(torch.from_numpy(sc).cuda(), return_qfloat=True)
+        oseq, oqs, omv, oqf = crf_ref.beam_search(sc, state_len)
+        assert np.array_equal(mv.numpy(), omv) and np.array_equal(seq.numpy(), oseq), (N, T)
+        assert np.abs(qf.numpy() - oqf).max() < 1e-3, (N, T)
+        m, pth = decode.viterbi(torch.from_numpy(sc).cuda())
+        om, op, _ = crf_ref.viterbi(sc, state_len)
+        assert np.array_equal(pth.numpy(), op) and np.array_equal(m.numpy(), om), (N, T)
+
+
 @pytest.mark.parametrize("kind", ["normal", "ties"])
 def test_beam_search_random_scores_and_params(kind):
     rng = np.random.default_rng(77)
