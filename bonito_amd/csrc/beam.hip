@@ -1657,5 +1657,6 @@ int bh_k_decode_set_option(const char* name, int value) {
     if (name && !strcmp(name, "beam_fuse")) { g_beam_fuse = value; return 0; }
     if (name && !strcmp(name, "beam_cpw")) { g_beam_cpw = value; return 0; }
     if (name && !strcmp(name, "decode_nt")) { g_decode_nt = value; return 0; }
+    if (name && !strcmp(name, "viterbi_quad")) { bh::g_viterbi_quad = value; return 0; }
     return 1;     // not a decoder option
 }

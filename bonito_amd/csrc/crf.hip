@@ -11,9 +11,19 @@
 //   move_t = (k_t != 0), path_t = move_t ? 1 + (j_t & 3) : 0.
 // fp32 left-fold of fp16 inputs with exactly one addend per step => bit-identical to the CPU oracle.
 //
-// One workgroup per chunk, one thread per state; alpha ping-pongs in LDS (one barrier per step);
-// score loads are register-prefetched U steps ahead so the serial alpha chain never waits on HBM;
-// 3-bit back-pointers go to a [N][T][S] byte workspace and are chased back in LDS-staged blocks.
+// Round 1 kernel (`crf_viterbi_kernel`; kept for the reference's [T][N][5S] layout, for S < 64 and for unaligned strides): one workgroup
+// per chunk, one thread per state; alpha ping-pongs in LDS (one barrier per step); score loads are register-prefetched U steps ahead so
+// the serial alpha chain never waits on HBM; 3-bit back-pointers go to a [N][T][S] byte workspace and are chased back in LDS-staged blocks.
+//
+// Round 5 kernel (`crf_viterbi_quad_kernel`, koi layout, S >= 64): the lane <-> state mapping of the BS-2 forward scan (beam.hip). Thread i
+// of a chunk owns the FOUR states 4i .. 4i+3: they share their four predecessors r S/4 + i, and the 16 transition scores they need are
+// the 32 contiguous bytes row[16 i .. 16 i + 15] - every byte a lane loads is used, the four stay terms come from the lane's own registers,
+// and a step is two LDS reads of two floats (stride S/4: ds_read2st64_b32 at 256 states), sixteen adds and compares, one 16-byte LDS
+// write. 256 states = ONE WAVE per chunk: no barrier at all (a wave's LDS operations complete in order), four chunks per workgroup;
+// 64 states = four chunks per wave; 1024 states = four waves per chunk, one barrier per step. Back-pointers: the four 3-bit values of a
+// thread as one 16-bit word, [N][T][S/4] (half the bytes of round 1's). Same arithmetic, same tie rules -> the same bytes as the round-1
+// kernel and the CPU oracle (tests/test_gpu_decode.py). Per call on MI355X (tools/decode_bench.py ... viterbi): 2048 x 1667 x 1024 (hac) 3.50 -> 1.62 ms
+// (7.9 GB of scores and back-pointers = 4.9 TB/s), 2048 x 1667 x 256 (fast) 2.70 -> 0.98, 512 x 2000 x 4096 (sup) 4.48 -> 2.18.
 #include <algorithm>
 
 #include "common.h"
@@ -33,6 +43,7 @@ struct VitArgs {
 };
 
 constexpr int VU = 8;  // prefetch depth (time steps)
+int g_viterbi_quad = 1;       // "viterbi_quad": 1 = four states per thread (round 5), 0 = the round-1 kernel everywhere
 
 template <bool L5S>
 __global__ void crf_viterbi_kernel(VitArgs p) {
@@ -149,6 +160,135 @@ __global__ void crf_viterbi_kernel(VitArgs p) {
     }
 }
 
+template <int SL>
+struct VitQuadGeo {
+    static constexpr int S = 1 << (2 * SL), Q = S / 4;              // Q threads per chunk, four states each
+    static constexpr int CPB = Q >= 256 ? 1 : 256 / Q;              // chunks per workgroup of 256 threads
+    static constexpr bool BARRIER = Q > 64;                         // a chunk spans several waves
+    static constexpr int TB = 64;                                   // traceback block (time steps)
+    static constexpr int ALPHA = (BARRIER ? 2 : 1) * S * 4;         // bytes per chunk
+    static constexpr int STAGE = TB * Q * 2;                        // back-pointer block, bytes per chunk
+    static constexpr int PER_CHUNK = ALPHA + STAGE + 2 * TB + 16;   // + the block's moves / path + final state
+    static constexpr int LDS = CPB * PER_CHUNK;
+};
+
+constexpr int VQU = 4;  // prefetch depth (time steps)
+
+template <int SL>
+__global__ __launch_bounds__(256) void crf_viterbi_quad_kernel(VitArgs p) {
+    using G = VitQuadGeo<SL>;
+    constexpr int S = G::S, Q = G::Q;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int c = threadIdx.x / Q, i = threadIdx.x % Q;
+    const int n_raw = blockIdx.x * G::CPB + c;
+    const bool valid = n_raw < p.N;                                 // a ragged last workgroup computes chunk N-1 again and stores nothing
+    const int n = valid ? n_raw : p.N - 1;
+    char* base = smem + c * G::PER_CHUNK;
+    float* al = (float*)base;                                       // [1 or 2][S]
+    unsigned short* stage = (unsigned short*)(base + G::ALPHA);     // [TB][Q]
+    int8_t* res_m = (int8_t*)(base + G::ALPHA + G::STAGE);
+    int8_t* res_p = res_m + G::TB;
+    int* s_state = (int*)(res_p + G::TB);
+    const half_t* sc = p.scores + (long)n * p.s_n + 16 * i;
+    unsigned short* bp = (unsigned short*)p.bp + (long)n * p.T * Q;
+
+    float own[4] = {0.f, 0.f, 0.f, 0.f};
+    *(float4_t*)(al + 4 * i) = float4_t{0.f, 0.f, 0.f, 0.f};
+    if (G::BARRIER) __syncthreads();
+
+    uint4_t cur[VQU][2], nxt[VQU][2];
+    auto load = [&](uint4_t (&dst)[VQU][2], int t0) {
+#pragma unroll
+        for (int u = 0; u < VQU; ++u) {
+            const int t = min(t0 + u, p.T - 1);                     // (rows beyond the end are never used)
+            const uint4_t* s = (const uint4_t*)(sc + (long)t * p.s_t);
+            dst[u][0] = s[0];
+            dst[u][1] = s[1];
+        }
+    };
+    int cb = 0;
+    load(cur, 0);
+    for (int t0 = 0; t0 < p.T; t0 += VQU) {
+        load(nxt, t0 + VQU);
+#pragma unroll
+        for (int u = 0; u < VQU; ++u) {
+            const int t = t0 + u;
+            if (t < p.T) {                                          // uniform across the workgroup
+                const float* a = al + (G::BARRIER ? cb * S : 0);
+                float pa[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) pa[r] = a[r * Q + i];
+                const half8_t h0 = __builtin_bit_cast(half8_t, cur[u][0]), h1 = __builtin_bit_cast(half8_t, cur[u][1]);
+                unsigned kk = 0;
+                float nw[4];
+#pragma unroll
+                for (int x = 0; x < 4; ++x) {
+                    float best = own[x] + p.blank;
+                    unsigned k = 0;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int e = 4 * x + r;
+                        const float cand = pa[r] + (float)(e < 8 ? h0[e] : h1[e - 8]);
+                        if (cand > best) { best = cand; k = 1 + r; }
+                    }
+                    nw[x] = best;
+                    kk |= k << (3 * x);
+                }
+#pragma unroll
+                for (int x = 0; x < 4; ++x) own[x] = nw[x];
+                // (one wave per chunk: every lane's predecessor reads above were issued before this write; LDS operations of a wave complete in order)
+                *(float4_t*)(al + (G::BARRIER ? (cb ^ 1) * S : 0) + 4 * i) = float4_t{nw[0], nw[1], nw[2], nw[3]};
+                if (valid) bp[(long)t * Q + i] = (unsigned short)kk;
+                if (G::BARRIER) { cb ^= 1; __syncthreads(); }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < VQU; ++u) { cur[u][0] = nxt[u][0]; cur[u][1] = nxt[u][1]; }
+    }
+
+    // ---- final state: argmax_j alpha_T[j], lowest j on ties (one thread per chunk scans the S values in LDS) ----
+    __syncthreads();
+    if (i == 0) {
+        const float* a = al + (G::BARRIER ? cb * S : 0);
+        float best = a[0];
+        int bj = 0;
+        for (int j = 1; j < S; ++j)
+            if (a[j] > best) { best = a[j]; bj = j; }
+        *s_state = bj;
+        if (p.best && valid) p.best[n] = best;
+    }
+    __threadfence();   // back-pointer stores of this workgroup -> visible to its own later loads
+    __syncthreads();
+
+    // ---- traceback in LDS-staged blocks of TB steps: the chunk's threads copy, its first thread chases ----
+    int8_t* mo = p.moves + (long)n * p.T;
+    int8_t* pa_out = p.path + (long)n * p.T;
+    for (int thi = p.T; thi > 0; thi -= G::TB) {
+        const int tlo = max(0, thi - G::TB);
+        const int n16 = (thi - tlo) * Q / 8;                        // 16-byte pieces (Q % 8 == 0)
+        const uint4_t* src = (const uint4_t*)(bp + (long)tlo * Q);
+        for (int e = i; e < n16; e += Q) ((uint4_t*)stage)[e] = src[e];
+        __syncthreads();
+        if (i == 0) {
+            int st = *s_state;
+            for (int t = thi - 1; t >= tlo; --t) {
+                const int k = (stage[(t - tlo) * Q + (st >> 2)] >> (3 * (st & 3))) & 7;
+                res_m[t - tlo] = (int8_t)(k != 0);
+                res_p[t - tlo] = (int8_t)(k != 0 ? 1 + (st & 3) : 0);
+                if (k != 0) st = (k - 1) * Q + (st >> 2);
+            }
+            *s_state = st;
+        }
+        __syncthreads();
+        if (valid)
+            for (int e = i; e < thi - tlo; e += Q) {
+                mo[tlo + e] = res_m[e];
+                pa_out[tlo + e] = res_p[e];
+            }
+        __syncthreads();
+    }
+}
+
 }  // namespace bh
 
 int bh_k_crf_viterbi(const void* scores, int N, int T, int state_len, int layout_5s, float blank_score,
@@ -162,6 +302,19 @@ int bh_k_crf_viterbi(const void* scores, int N, int T, int state_len, int layout
     for (int i = 0; i < state_len; ++i) S *= 4;
     BH_REQUIRE(layout_5s || (s_t % 4 == 0 && s_n % 4 == 0), "viterbi: 4S layout needs strides %% 4 == 0");
     VitArgs a{(const half_t*)scores, N, T, S, blank_score, s_n, s_t, (uint8_t*)bp_ws, moves, path, best_score};
+    // koi layout, 64 states and more, rows 16-byte aligned: four states per thread (round 5); "viterbi_quad" 0 = the round-1 kernel
+    if (!layout_5s && state_len >= 3 && g_viterbi_quad && s_t % 8 == 0 && s_n % 8 == 0 && ((uintptr_t)scores & 15) == 0) {
+#define BH_VIT_QUAD(SL)                                                                                                        \
+    {                                                                                                                          \
+        using G = VitQuadGeo<SL>;                                                                                              \
+        BH_CHECK_HIP(bh_max_lds((const void*)crf_viterbi_quad_kernel<SL>, G::LDS));                                            \
+        hipLaunchKernelGGL(crf_viterbi_quad_kernel<SL>, dim3((N + G::CPB - 1) / G::CPB), dim3(256), G::LDS, stream, a);        \
+    }
+        if (state_len == 3) BH_VIT_QUAD(3) else if (state_len == 4) BH_VIT_QUAD(4) else BH_VIT_QUAD(5)
+#undef BH_VIT_QUAD
+        BH_CHECK_HIP(hipGetLastError());
+        return 0;
+    }
     int threads = S < 64 ? 64 : S;
     int TB = (32 * 1024) / S; if (TB > 512) TB = 512; if (TB < 1) TB = 1;
     size_t lds = 16 + (size_t)2 * S * sizeof(float) + (size_t)TB * S + 2 * TB + 16;

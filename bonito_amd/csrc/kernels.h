@@ -76,6 +76,7 @@ size_t bh_k_posterior_viterbi_workspace(int N, int T, int state_len);
 int bh_k_posterior_viterbi(const void* scores, int N, int T, int state_len, float blank, void* workspace, int8_t* moves,
                            int8_t* path, hipStream_t stream);
 int bh_k_decode_set_option(const char* name, int value);
+namespace bh { extern int g_viterbi_quad; }       // crf.hip ("viterbi_quad")
 int bh_k_conv_set_option(const char* name, int value);     // "conv_ws", "conv_fs", "conv_lds_kb", "conv_fuse"
 // conv1 -> conv2 -> conv3 of an LSTM model's front end in one kernel (conv_front3_kernel); _ok: does the shape qualify?
 int bh_k_conv_front3_ok(int c1_eff, int K1, int s1, int c2_in_eff, int c2_eff, int K2, int s2, int c3_in_eff, int c3_out, int K3, int s3);

@@ -41,6 +41,53 @@ def test_viterbi_expanded_layout_exact(state_len):
     assert np.array_equal(path.numpy(), op) and np.array_equal(moves.numpy(), om)
 
 
+@pytest.mark.parametrize("state_len", [3, 4, 5])
+def test_viterbi_quad_kernel_equals_the_round_1_kernel(state_len):
+    """Round 5: `crf_viterbi_quad_kernel` (four states per thread, one wave per 256-state chunk, 16-bit back-pointer words) against the
+    round-1 kernel (`viterbi_quad` 0: one thread per state) and the C oracle - moves, path and best score, with tie-heavy scores, a chunk
+    count that leaves the last workgroup ragged (16 / 4 / 1 chunks per workgroup), a step count that is no multiple of the prefetch
+    depth or of the traceback block; then through the C ABI with padded rows (row stride 2 C: still the new kernel) and with a base
+    pointer 8 bytes off a 16-byte boundary (falls back to the round-1 kernel): the same bytes."""
+    import ctypes as C
+    from bonito_amd import _lib
+    S = 4 ** state_len
+    Cc = 4 * S
+    N, T = {3: 37, 4: 13, 5: 3}[state_len], 131
+    rng = np.random.default_rng(300 + state_len)
+    sc = _scores(rng, N, T, Cc, "ties")
+    dev = torch.from_numpy(sc).cuda()
+    m1, p1, b1 = decode.viterbi(dev, return_score=True)
+    decode.set_option("viterbi_quad", 0)
+    try:
+        m0, p0, b0 = decode.viterbi(dev, return_score=True)
+    finally:
+        decode.set_option("viterbi_quad", 1)
+    assert torch.equal(m1, m0) and torch.equal(p1, p0) and torch.equal(b1, b0)
+    om, op, ob = crf_ref.viterbi(sc, state_len)
+    assert np.array_equal(p1.numpy(), op) and np.array_equal(m1.numpy(), om) and np.array_equal(b1.numpy(), ob)
+
+    lib = _lib.lib()
+
+    def run(ptr, s_n, s_t):
+        ws = torch.empty(lib.bh_crf_viterbi_workspace(N, T, state_len), dtype=torch.uint8, device="cuda")
+        mo = torch.empty((N, T), dtype=torch.int8, device="cuda")
+        pa = torch.empty((N, T), dtype=torch.int8, device="cuda")
+        be = torch.empty((N,), dtype=torch.float32, device="cuda")
+        _lib.check(lib.bh_crf_viterbi(ptr, N, T, state_len, 0, 2.0, s_n, s_t, _lib.ptr(ws), _lib.ptr(mo), _lib.ptr(pa), _lib.ptr(be),
+                                      _lib.stream_ptr("cuda:0")), "bh_crf_viterbi")
+        torch.cuda.synchronize()
+        return mo.cpu(), pa.cpu(), be.cpu()
+
+    padded = torch.full((N, T, 2 * Cc), 9.0, dtype=torch.float16, device="cuda")
+    padded[:, :, :Cc] = dev
+    mp, pp, bpad = run(_lib.ptr(padded), T * 2 * Cc, 2 * Cc)
+    assert torch.equal(mp, m1) and torch.equal(pp, p1) and torch.equal(bpad, b1)
+    flat = torch.zeros(N * T * Cc + 8, dtype=torch.float16, device="cuda")
+    flat[4:4 + N * T * Cc] = dev.reshape(-1)
+    mu, pu, bu = run(C.c_void_p(flat.data_ptr() + 8), T * Cc, Cc)
+    assert torch.equal(mu, m1) and torch.equal(pu, p1) and torch.equal(bu, b1)
+
+
 def test_viterbi_edge_shapes():
     rng = np.random.default_rng(4)
     for N, T in [(1, 1), (1, 7), (3, 8), (2, 9), (1, 513)]:

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Decode stage alone (bh_beam_search on resident scores, no D2H): milliseconds per call for a few option settings.
-    python tools/decode_bench.py [N T C] [name=value ...]      e.g.  2048 1667 1024 beam_cpw=4"""
+"""Decode stage alone (bh_beam_search - or, with the word `viterbi`, bh_crf_viterbi - on resident scores, no D2H): milliseconds per call for
+a few option settings.
+    python tools/decode_bench.py [N T C] [viterbi] [name=value ...]      e.g.  2048 1667 1024 beam_cpw=4 / 2048 1667 1024 viterbi viterbi_quad=0"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -15,7 +16,13 @@ sl = decode.state_len_of(C)
 lib = _lib.lib()
 ws = torch.empty(lib.bh_beam_search_workspace(N, T, sl), dtype=torch.uint8, device="cuda")
 out = torch.empty((3, N, T), dtype=torch.int8, device="cuda")
+VITERBI = "viterbi" in sys.argv[1:]
+vws = torch.empty(lib.bh_crf_viterbi_workspace(N, T, sl), dtype=torch.uint8, device="cuda") if VITERBI else None
 def run():
+    if VITERBI:
+        _lib.check(lib.bh_crf_viterbi(_lib.ptr(sc), N, T, sl, 0, 2.0, T * C, C, _lib.ptr(vws), _lib.ptr(out[0]), _lib.ptr(out[1]), None,
+                                      _lib.stream_ptr("cuda:0")), "bh_crf_viterbi")
+        return
     _lib.check(lib.bh_beam_search(_lib.ptr(sc), N, T, sl, 32, 100.0, 2.0, 1.0, 0.0, _lib.ptr(ws), _lib.ptr(out[0]), _lib.ptr(out[1]),
                                   _lib.ptr(out[2]), None, _lib.stream_ptr("cuda:0")), "bh_beam_search")
 def timed(tag):
