@@ -1,6 +1,6 @@
 #!/bin/bash
 # Decode stage alone under rocprofv3: kernel trace (per-kernel time) + SQ counter passes of tools/decode_bench.py.
-#   usage: bash tools/prof_decode.sh <tag> [N T C]     outputs: gpurun_out/prof_<tag>/decode_{kernel_stats.csv,sq_counters.txt}
+#   usage: bash tools/prof_decode.sh <tag> [N T C] [viterbi]     (FETCH_SIZE / WRITE_SIZE: KiB per dispatch, own passes)     outputs: gpurun_out/prof_<tag>/decode_{kernel_stats.csv,sq_counters.txt}
 TAG=${1:-r05}
 shift
 ARGS=${@:-2048 1667 1024}
@@ -13,7 +13,7 @@ python $R/tools/rocprof_summary.py $(find $OUT/trace -name "*.db" | head -1) $OU
 rm -rf $OUT/trace
 : > $OUT/decode_sq_counters.txt
 i=0
-for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM" "SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_SCA SQ_WAIT_INST_LDS" "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VALU_TRANS SQ_INSTS_BRANCH"; do
+for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM" "SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_SCA SQ_WAIT_INST_LDS" "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VALU_TRANS SQ_INSTS_BRANCH" "FETCH_SIZE" "WRITE_SIZE"; do
   i=$((i+1))
   BH_DECODE_BENCH_REPS=1 rocprofv3 --kernel-trace --pmc $set -d $OUT/sq$i -o sq -- python $R/tools/decode_bench.py $ARGS > $OUT/sq$i.log 2>&1
   db=$(find $OUT/sq$i -name "*.db" | head -1)
