@@ -33,6 +33,7 @@ The JSON line also carries
 import argparse
 import json
 import os
+import re
 import statistics
 import sys
 import time
@@ -146,7 +147,8 @@ def pmc_traffic(kernel, a, launch_chunks=None):
     except (OSError, ValueError):
         return None, None
     base = (kernel or "").split("<")[0]
-    ent = table.get(kernel or "") or table.get(base)
+    named = re.search(r"(lstm_layer_\w+_kernel)", kernel or "")          # "gemm + lstm_layer_wide_kernel<32,true>" -> the recurrent kernel
+    ent = table.get(kernel or "") or table.get(base) or (table.get(named.group(1)) if named else None)
     if not ent or ent.get("workload") != "%s %dx%d" % (a.model, launch_chunks or a.call_batch, a.chunk):
         return None, None
     return ent["bytes_per_launch"], ent.get("source")
@@ -678,6 +680,8 @@ def main():
                 per_span = -(-(call_batch // 16) // 64)
             elif rec and "lstm_layer_wgx_kernel" in rec[0]:
                 per_span = -(-(call_batch // 16) // 32)
+            elif rec and "lstm_layer_wide_kernel<32" in rec[0]:
+                per_span = -(-call_batch // 256)          # 1024-wide layers: eight rings of 32 chunks (one per XCD) per launch
         flops_per_launch /= per_span
         avg_ms /= per_span
         launch_chunks = call_batch // per_span
