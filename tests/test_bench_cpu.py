@@ -67,6 +67,23 @@ def test_pmc_traffic_table_names_the_roofline_kernel(bench):
     assert entry["bytes_per_launch"] > 1e9 and os.path.exists(os.path.join(ROOT, entry["source"]))
 
 
+def test_pmc_traffic_lookup_by_workload_and_kernel_name(bench):
+    """`roofline.traffic` comes from the committed PMC passes and only for the workload they were taken on: the kernel name as the engine
+    describes it (template arguments, a "gemm + " prefix for layers with a separate input projection), the chunks of ONE launch."""
+    import types
+    hac = types.SimpleNamespace(model="hac", call_batch=2048, chunk=10000)
+    got, src = bench.pmc_traffic("lstm_layer_wgx2_kernel<12,3>", hac, 1024)
+    assert got and 2.5e9 < got < 2.8e9 and src.startswith("profiles/")
+    assert bench.pmc_traffic("lstm_layer_wgx2_kernel<12,3>", hac, 2048) == (None, None)          # another launch size: no measurement
+    fast = types.SimpleNamespace(model="fast", call_batch=4096, chunk=10000)
+    got, _ = bench.pmc_traffic("lstm_layer_cta_kernel<3,3>", fast)
+    assert got and 2.5e9 < got < 2.8e9
+    wide = types.SimpleNamespace(model="sup_lstm", call_batch=512, chunk=20000)
+    got, _ = bench.pmc_traffic("gemm + lstm_layer_wide_kernel<32,true>", wide, 256)
+    assert got and 8.5e9 < got < 9.5e9
+    assert bench.pmc_traffic("attention_ring_kernel<12>", wide, 256) == (None, None)
+
+
 def test_experimental_lstm_flags_never_write_the_product_library(tmp_path):
     """`BH_EXTRA_LSTM_FLAGS` builds (timing experiments, wrong results on purpose) go to libbonito_hip_expt.so / build/obj_expt; a
     stray environment variable must not be able to replace bonito_amd/libbonito_hip.so (review, round 3)."""
