@@ -1359,7 +1359,16 @@ __global__ __launch_bounds__(64) void beam_finalize_kernel(FinArgs p) {
         const int tlo = max(0, thi - FTB);
         const int nbytes = (thi - tlo) * MAXW;
         const uint4_t* src = (const uint4_t*)(bp + (long)tlo * MAXW);
-        for (int i = lane; i < nbytes / 16; i += 64) ((uint4_t*)st)[i] = src[i];
+        {   // all loads of the block first, then the LDS writes (one load + wait + write per iteration cost 8 round trips per block)
+            constexpr int PER = FTB * MAXW / 16 / 64;
+            uint4_t tmp[PER];
+#pragma unroll
+            for (int k = 0; k < PER; ++k)
+                if (lane + 64 * k < nbytes / 16) tmp[k] = src[lane + 64 * k];
+#pragma unroll
+            for (int k = 0; k < PER; ++k)
+                if (lane + 64 * k < nbytes / 16) ((uint4_t*)st)[lane + 64 * k] = tmp[k];
+        }
         __syncthreads();
         if (lane == 0) {
             int r = s_r;
@@ -1367,7 +1376,7 @@ __global__ __launch_bounds__(64) void beam_finalize_kernel(FinArgs p) {
                 const int info = st[(t - tlo) * MAXW + r];
                 const int is_move = (info >> 5) & 1;
                 res_m[t - tlo] = (int8_t)is_move;
-                res_s[t - tlo] = is_move ? (int8_t)("ACGT"[info >> 6]) : (int8_t)0;
+                res_s[t - tlo] = is_move ? (int8_t)((0x54474341u >> (8 * (info >> 6))) & 0xffu) : (int8_t)0;      // "ACGT"[x] without a load in the chase
                 r = info & 31;
             }
             s_r = r;
