@@ -84,6 +84,27 @@ def test_pmc_traffic_lookup_by_workload_and_kernel_name(bench):
     assert bench.pmc_traffic("attention_ring_kernel<12>", wide, 256) == (None, None)
 
 
+def test_rocprof_summary_reports_median_and_roofline_leg_average(tmp_path):
+    """tools/rocprof_summary.py on a synthetic rocpd database: AverageNs over every launch, MedianNs, and Last30AverageNs = the launches of
+    bench.py's roofline leg (run one kernel at a time behind the timed regions) - the figure `roofline.avg_launch_ms` must agree with."""
+    import csv
+    import sqlite3
+    import subprocess
+    db = str(tmp_path / "t.db")
+    con = sqlite3.connect(db)
+    con.execute("create table kernels (name, start, end, vgpr_count, accum_vgpr_count, sgpr_count, lds_size, grid_x, workgroup_x)")
+    for i in range(100):                 # 70 launches of the pipelined region (some stretched by overlap), then 30 clean ones
+        dur = 3600 if i >= 70 else (7900 if i % 7 == 0 else 3500)
+        con.execute("insert into kernels values ('k', ?, ?, 252, 0, 112, 99840, 65536, 256)", (i * 10000, i * 10000 + dur))
+    con.commit()
+    con.close()
+    out = str(tmp_path / "t.csv")
+    subprocess.run([sys.executable, os.path.join(ROOT, "tools", "rocprof_summary.py"), db, out], check=True, capture_output=True)
+    row = list(csv.DictReader(open(out)))[0]
+    assert int(row["Calls"]) == 100 and int(row["MedianNs"]) == 3500 and float(row["Last30AverageNs"]) == 3600.0
+    assert float(row["AverageNs"]) > 3900 and int(row["MaxNs"]) == 7900
+
+
 def test_experimental_lstm_flags_never_write_the_product_library(tmp_path):
     """`BH_EXTRA_LSTM_FLAGS` builds (timing experiments, wrong results on purpose) go to libbonito_hip_expt.so / build/obj_expt; a
     stray environment variable must not be able to replace bonito_amd/libbonito_hip.so (review, round 3)."""
