@@ -539,6 +539,232 @@ int oracle_beam_search(const uint16_t* scores, int N, int T, int state_len, int 
     return 0;
 }
 
+/* ---- BS-1 (the beam search of rounds 1-4), kept as a QUALITY REFERENCE for BS-2 only (tests/test_oracle_crf.py, bench.py `parity`):
+ * the same search with the Log-semiring table-lse2 guide (oracle_crf_backward) and the candidate order c = 5 e + j. Sequence and moves
+ * only. The product decoder is BS-2; this function exists so that a redefinition of the decoder cannot quietly cost sequence quality
+ * (review, round 5): oracle_seq_logprob_f64 below scores both answers with the model's exact path sum. */
+int oracle_beam_search_bs1(const uint16_t* scores, int N, int T, int state_len, int beam_width, float beam_cut,
+                           float blank, int8_t* sequence, int8_t* moves) {
+    const int S = ipow4(state_len), sh = 2 * (state_len - 1);
+    if (beam_width < 1 || beam_width > BS_MAXW) return -2;
+    const int W = beam_width;
+    float* beta = (float*)malloc(sizeof(float) * (size_t)N * (T + 1) * S);
+    double* Bcum = (double*)malloc(sizeof(double) * (size_t)N * (T + 1));
+    double* logZ = (double*)malloc(sizeof(double) * N);
+    uint8_t* bp = (uint8_t*)malloc((size_t)T * BS_MAXW);
+    if (!beta || !Bcum || !logZ || !bp) { free(beta); free(Bcum); free(logZ); free(bp); return -1; }
+    oracle_crf_backward(scores, N, T, state_len, blank, beta, Bcum, logZ);
+    const float cut = logf(beam_cut);
+    for (int n = 0; n < N; ++n) {
+        const float* bn = beta + (size_t)n * (T + 1) * S;
+        bs_elem beam[BS_MAXW];
+        int nb = 0;
+        {
+            char* used = (char*)calloc(S, 1);
+            int take = W < S ? W : S;
+            for (int k = 0; k < take; ++k) {
+                int bi = -1;
+                for (int s = 0; s < S; ++s)
+                    if (!used[s] && (bi < 0 || bs_ukey(bn[s]) > bs_ukey(bn[bi]))) bi = s;
+                used[bi] = 1;
+            }
+            for (int s = 0; s < S; ++s)
+                if (used[s]) { beam[nb].state = s; beam[nb].hash = bs_hash0(s); beam[nb].score = 0.0f; ++nb; }
+            free(used);
+        }
+        for (int t = 0; t < T; ++t) {
+            const uint16_t* sc = scores + ((size_t)n * T + t) * 4 * S;
+            const float* b1 = bn + (size_t)(t + 1) * S;
+            int c_state[BS_MAXW * 5];
+            uint32_t c_hash[BS_MAXW * 5];
+            float c_score[BS_MAXW * 5], c_key[BS_MAXW * 5];
+            uint8_t c_info[BS_MAXW * 5];
+            char c_alive[BS_MAXW * 5];
+            const int nc = nb * 5;
+            for (int e = 0; e < nb; ++e) {
+                const int s = beam[e].state, lead = s >> sh;
+                c_state[e * 5] = s; c_hash[e * 5] = beam[e].hash; c_score[e * 5] = beam[e].score + blank;
+                c_info[e * 5] = (uint8_t)e; c_alive[e * 5] = 1;
+                for (int x = 0; x < 4; ++x) {
+                    const int c = e * 5 + 1 + x, s2 = ((s << 2) | x) & (S - 1);
+                    c_state[c] = s2; c_hash[c] = bs_mix(beam[e].hash, x);
+                    c_score[c] = beam[e].score + h2f(sc[s2 * 4 + lead]);
+                    c_info[c] = (uint8_t)(e | (1 << 5) | (x << 6)); c_alive[c] = 1;
+                }
+            }
+            for (int e = 0; e < nb; ++e)
+                for (int x = 0; x < 4; ++x) {
+                    const int c = e * 5 + 1 + x;
+                    for (int d = 0; d < nb; ++d) {
+                        const int cs = d * 5;
+                        if (c_hash[cs] == c_hash[c] && c_state[cs] == c_state[c]) {
+                            const float stay_sc = beam[d].score + blank;
+                            if (c_score[c] > stay_sc) c_info[cs] = c_info[c];
+                            c_score[cs] = oracle_lse2(stay_sc, c_score[c]);
+                            c_alive[c] = 0;
+                            break;
+                        }
+                    }
+                }
+            float best = -INFINITY;
+            for (int c = 0; c < nc; ++c) {
+                c_key[c] = c_alive[c] ? c_score[c] + b1[c_state[c]] : -INFINITY;
+                if (c_key[c] > best) best = c_key[c];
+            }
+            const float thr = best - cut;
+            for (int c = 0; c < nc; ++c) if (c_alive[c] && c_key[c] < thr) { c_alive[c] = 0; c_key[c] = -INFINITY; }
+            char sel[BS_MAXW * 5];
+            memset(sel, 0, sizeof(sel));
+            for (int k = 0; k < W; ++k) {
+                int bi = -1;
+                for (int c = 0; c < nc; ++c)
+                    if (c_alive[c] && !sel[c] && (bi < 0 || bs_ukey(c_key[c]) > bs_ukey(c_key[bi]))) bi = c;
+                if (bi < 0) break;
+                sel[bi] = 1;
+            }
+            int bestc = -1;
+            for (int c = 0; c < nc; ++c)
+                if (sel[c] && (bestc < 0 || bs_ukey(c_key[c]) > bs_ukey(c_key[bestc]))) bestc = c;
+            const float shift = c_score[bestc];
+            nb = 0;
+            for (int c = 0; c < nc; ++c)
+                if (sel[c]) {
+                    beam[nb].state = c_state[c]; beam[nb].hash = c_hash[c]; beam[nb].score = c_score[c] - shift;
+                    bp[(size_t)t * BS_MAXW + nb] = c_info[c];
+                    ++nb;
+                }
+        }
+        int r = 0;
+        for (int e = 1; e < nb; ++e) if (bs_ukey(beam[e].score) > bs_ukey(beam[r].score)) r = e;
+        int8_t* sq = sequence + (size_t)n * T;
+        int8_t* mv = moves + (size_t)n * T;
+        for (int t = T - 1; t >= 0; --t) {
+            const uint8_t info = bp[(size_t)t * BS_MAXW + r];
+            const int is_move = (info >> 5) & 1;
+            mv[t] = (int8_t)is_move;
+            sq[t] = is_move ? (int8_t)"ACGT"[info >> 6] : 0;
+            r = info & 31;
+        }
+    }
+    free(beta); free(Bcum); free(logZ); free(bp);
+    return 0;
+}
+
+/* ---- The model's EXACT log-probability of a called sequence, fp64, independent of every decoder here.
+ * The CTC-CRF of bonito/crf/model.py:30-108 in the koi layout: alpha_0[s] = 0 for every k-mer state s; per step a path either stays
+ * (score `blank`) or moves from s to s' = ((s << 2) | x) & (S-1) emitting base x (score sc[t][4 s' + (s >> 2(k-1))]).
+ *     logp = ln  sum over start states and over every alignment that emits exactly seq[0..len)  of exp(path score)
+ *     logz = ln  sum over ALL paths                                                              (CTC_CRF.logZ, crf/model.py:47-52)
+ * so logp - logz is ln P(sequence | scores), the quantity a sequence-level beam search maximises. After i >= k emissions the state is
+ * the last k bases of the prefix; before that, the unfilled leading digits are those of the start state: level i < k keeps a dense
+ * [S] row (only states whose low i digits spell seq[0..i) are ever finite), level i >= k one scalar. Cost T (len + k S).
+ * seq: base indices 0..3. Scores are used as they are (no clamp): for heads within +-5 that is the model itself. */
+static inline double lse2_f64(double a, double b) {
+    if (a == -INFINITY) return b;
+    if (b == -INFINITY) return a;
+    const double m = a > b ? a : b;
+    return m + log(exp(a - m) + exp(b - m));
+}
+int oracle_seq_logprob_f64(const uint16_t* scores, int T, int state_len, float blank_in, const int8_t* seq, int len,
+                           double* logp, double* logz) {
+    const int S = ipow4(state_len), sh = 2 * (state_len - 1), k = state_len, q = S / 4;
+    const double blank = (double)blank_in;
+    if (len < 0 || len > T) { *logp = -INFINITY; }
+    /* logZ */
+    double* al = (double*)malloc(sizeof(double) * S);
+    double* nx = (double*)malloc(sizeof(double) * S);
+    /* dense levels 0 .. k-1 ([k][S]), scalar levels k .. len */
+    double* dense = (double*)malloc(sizeof(double) * (size_t)(k > 0 ? k : 1) * S);
+    double* tail = (double*)malloc(sizeof(double) * (size_t)(len + 1));
+    int* st = (int*)malloc(sizeof(int) * (size_t)(len + 1));      /* state after i >= k emissions */
+    if (!al || !nx || !dense || !tail || !st) { free(al); free(nx); free(dense); free(tail); free(st); return -1; }
+    for (int s = 0; s < S; ++s) al[s] = 0.0;
+    for (int t = 0; t < T; ++t) {
+        const uint16_t* sc = scores + (size_t)t * 4 * S;
+        for (int j = 0; j < S; ++j) {
+            double v[5], m;
+            v[0] = blank + al[j];
+            m = v[0];
+            for (int r = 0; r < 4; ++r) {
+                v[1 + r] = (double)h2f(sc[j * 4 + r]) + al[r * q + (j >> 2)];
+                if (v[1 + r] > m) m = v[1 + r];
+            }
+            double sum = 0.0;
+            for (int c = 0; c < 5; ++c) sum += exp(v[c] - m);
+            nx[j] = m + log(sum);
+        }
+        double* tmp = al; al = nx; nx = tmp;
+    }
+    {
+        double m = -INFINITY, sum = 0.0;
+        for (int s = 0; s < S; ++s) if (al[s] > m) m = al[s];
+        for (int s = 0; s < S; ++s) sum += exp(al[s] - m);
+        *logz = m + log(sum);
+    }
+    if (len < 0 || len > T) { free(al); free(nx); free(dense); free(tail); free(st); return 0; }
+    /* the sequence's own forward pass */
+    for (int i = 0; i < k; ++i)
+        for (int s = 0; s < S; ++s) dense[(size_t)i * S + s] = (i == 0) ? 0.0 : -INFINITY;
+    for (int i = 0; i <= len; ++i) tail[i] = -INFINITY;
+    {
+        int cur = 0;
+        for (int i = 1; i <= len; ++i) {
+            cur = ((cur << 2) | seq[i - 1]) & (S - 1);
+            st[i] = cur;          /* meaningful for i >= k */
+        }
+        st[0] = 0;
+    }
+    for (int t = 0; t < T; ++t) {
+        const uint16_t* sc = scores + (size_t)t * 4 * S;
+        const int hi = len < t + 1 ? len : t + 1;
+        for (int i = hi; i >= 0; --i) {           /* descending: level i reads the OLD level i - 1 */
+            if (i >= k) {
+                double stay = tail[i] + blank, mv = -INFINITY;
+                if (i >= 1) {
+                    const int s2 = st[i];
+                    if (i - 1 >= k) {
+                        const int sp = st[i - 1];
+                        mv = tail[i - 1] + (double)h2f(sc[s2 * 4 + (sp >> sh)]);
+                    } else {                        /* i - 1 == k - 1: the four predecessors differ in their leading digit */
+                        const double* dp = dense + (size_t)(i - 1) * S;
+                        for (int r = 0; r < 4; ++r) {
+                            const int sp = r * q + (s2 >> 2);
+                            mv = lse2_f64(mv, dp[sp] + (double)h2f(sc[s2 * 4 + r]));
+                        }
+                    }
+                }
+                tail[i] = lse2_f64(stay, mv);
+            } else {
+                double* di = dense + (size_t)i * S;
+                if (i == 0) {
+                    for (int s = 0; s < S; ++s) di[s] += blank;
+                } else {
+                    const double* dp = dense + (size_t)(i - 1) * S;
+                    const int x = seq[i - 1];
+                    for (int s2 = 0; s2 < S; ++s2) {
+                        double v = di[s2] + blank;
+                        if ((s2 & 3) == x)
+                            for (int r = 0; r < 4; ++r) {
+                                const int sp = r * q + (s2 >> 2);
+                                v = lse2_f64(v, dp[sp] + (double)h2f(sc[s2 * 4 + r]));
+                            }
+                        di[s2] = v;
+                    }
+                }
+            }
+        }
+    }
+    if (len >= k) *logp = tail[len];
+    else {
+        double acc = -INFINITY;
+        const double* dl = dense + (size_t)len * S;
+        for (int s = 0; s < S; ++s) acc = lse2_f64(acc, dl[s]);
+        *logp = acc;
+    }
+    free(al); free(nx); free(dense); free(tail); free(st);
+    return 0;
+}
+
 /* =================================================================================================
  * CTC prefix beam search ("PB-1").  Replaces fast_ctc_decode.beam_search(probs, alphabet, beam_size=5,
  * beam_cut_threshold=1e-3) (bonito/ctc/model.py:44; Rust crate, un-pinned in requirements.txt:3, absent

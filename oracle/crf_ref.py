@@ -172,6 +172,44 @@ def beam_search(scores, state_len, beam_width=32, beam_cut=100.0, blank=2.0, sca
     return seq, qs, mv, qf
 
 
+def beam_search_bs1(scores, state_len, beam_width=32, beam_cut=100.0, blank=2.0):
+    """BS-1 (the decoder of rounds 1-4: Log-semiring table-lse2 guide, candidate order 5 e + j), kept ONLY as the quality reference the
+    product decoder BS-2 is guarded against. Returns (sequence, moves) [N,T] int8."""
+    a, bits = _as_half_bits(scores)
+    N, T, _ = a.shape
+    seq = np.zeros((N, T), np.int8)
+    mv = np.zeros((N, T), np.int8)
+    rc = _lib().oracle_beam_search_bs1(bits.ctypes.data_as(C.c_void_p), N, T, int(state_len), int(beam_width), C.c_float(beam_cut),
+                                       C.c_float(blank), seq.ctypes.data_as(C.c_void_p), mv.ctypes.data_as(C.c_void_p))
+    if rc:
+        raise RuntimeError("oracle_beam_search_bs1 failed (%d)" % rc)
+    return seq, mv
+
+
+def seq_logprob(scores_t4s, state_len, seq, blank=2.0):
+    """(ln sum over every alignment of `seq` of exp(path score), logZ) of ONE chunk's koi-layout scores [T,4S] in fp64 - the model's exact
+    sequence likelihood (crf/model.py:30-108 semantics), independent of any decoder. `seq`: bytes / str over ACGT, or an int8 plane of a
+    decoder (zeros = nothing emitted). ln P(seq | scores) = the difference of the two."""
+    a, bits = _as_half_bits(scores_t4s)
+    T = a.shape[0]
+    if isinstance(seq, str):
+        seq = seq.encode()
+    raw = np.frombuffer(seq, np.uint8) if isinstance(seq, (bytes, bytearray)) else np.asarray(seq).astype(np.uint8)
+    raw = raw[raw != 0]
+    lut = np.full(256, -1, np.int8)
+    for i, ch in enumerate(b"ACGT"):
+        lut[ch] = i
+    idx = np.ascontiguousarray(lut[raw])
+    if (idx < 0).any():
+        raise ValueError("sequence holds bytes outside ACGT")
+    lp, lz = C.c_double(), C.c_double()
+    rc = _lib().oracle_seq_logprob_f64(bits.ctypes.data_as(C.c_void_p), int(T), int(state_len), C.c_float(blank),
+                                       idx.ctypes.data_as(C.c_void_p), int(len(idx)), C.byref(lp), C.byref(lz))
+    if rc:
+        raise RuntimeError("oracle_seq_logprob_f64 failed")
+    return lp.value, lz.value
+
+
 def backward(scores, state_len, blank=2.0):
     """-> (beta~ [N,T+1,S] f32, Bcum [N,T+1] f64, logZ [N] f64)"""
     a, bits = _as_half_bits(scores)

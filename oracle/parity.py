@@ -64,12 +64,26 @@ def _bases(plane):
     return [row[row != 0] for row in np.asarray(plane)]
 
 
-def oracle_outputs(model, x, blank=2.0, decoders=("viterbi", "beam"), timers=None, forward=None):
+def _sliced(fn, sc, threads):
+    """fn(scores slice) -> tuple of arrays with the chunk axis first, over `threads` slices of the chunks in parallel (the C oracle is
+    single-threaded per call and ctypes drops the interpreter lock), concatenated back in order."""
+    n = sc.shape[0]
+    threads = max(1, min(int(threads), n))
+    if threads == 1:
+        return fn(sc)
+    from concurrent.futures import ThreadPoolExecutor
+    cuts = np.linspace(0, n, threads + 1).astype(int)
+    with ThreadPoolExecutor(threads) as ex:
+        parts = list(ex.map(lambda i: fn(sc[cuts[i]:cuts[i + 1]]), range(threads)))
+    return tuple(np.concatenate([p[k] for p in parts]) for k in range(len(parts[0])))
+
+
+def oracle_outputs(model, x, blank=2.0, decoders=("viterbi", "beam"), timers=None, fp16=False, threads=1):
     """The CPU path on chunks x [n,1,L] (torch CPU, values already fp16-representable): nn_ref.forward in fp32 on `model` (whose
     parameters the caller has rounded to fp16 with nn_ref.round_params_to_half_), scores rounded to fp16 in the engine's [n,T,4S]
-    layout, then the C decoders. `timers`: optional dict that receives the seconds of each stage. `forward`: optional callable
-    x [n,1,L] -> scores [T,n,4S] standing in for nn_ref.forward (bench.py: the reference's own bonito/nn.py encoder where /root/reference
-    exists, i.e. never on the GPU box)."""
+    layout, then the C decoders (`threads` slices of the chunks in parallel). `timers`: optional dict that receives the seconds of
+    each stage. `fp16`: nn_ref's fp16-STORAGE mode (every value rounded where the engine stores fp16) instead of the fp32 CPU path -
+    the second oracle of the end-to-end comparison (what is left against it is summation order + the hardware exponential)."""
     import time
 
     import torch
@@ -77,18 +91,18 @@ def oracle_outputs(model, x, blank=2.0, decoders=("viterbi", "beam"), timers=Non
     sl = model.seqdist.state_len
     t0 = time.perf_counter()
     with torch.no_grad():
-        y = forward(x.float()) if forward is not None else nn_ref.forward(model.encoder, x.float(), expand_blanks=False)
+        y = nn_ref.forward(model.encoder, x.float(), expand_blanks=False, fp16=fp16)
     sc = y.permute(1, 0, 2).contiguous().half().numpy()
     t1 = time.perf_counter()
     out = {"scores": sc, "state_len": np.int32(sl)}
     t2 = t1
     if "viterbi" in decoders:
-        mv, path, best = crf_ref.viterbi(sc, sl, blank=blank)
+        mv, path, best = _sliced(lambda z: crf_ref.viterbi(z, sl, blank=blank), sc, threads)
         out.update(vit_moves=mv, vit_path=path, vit_score=best)
         t2 = time.perf_counter()
     t3 = t2
     if "beam" in decoders:
-        seq, qs, bmv, qf = crf_ref.beam_search(sc, sl, blank=blank)
+        seq, qs, bmv, qf = _sliced(lambda z: crf_ref.beam_search(z, sl, blank=blank), sc, threads)
         out.update(beam_seq=seq, beam_qs=qs, beam_moves=bmv, beam_qf=qf)
         t3 = time.perf_counter()
     if timers is not None:
@@ -96,6 +110,35 @@ def oracle_outputs(model, x, blank=2.0, decoders=("viterbi", "beam"), timers=Non
         timers["viterbi"] = timers.get("viterbi", 0.0) + (t2 - t1)
         timers["beam"] = timers.get("beam", 0.0) + (t3 - t2)
     return out
+
+
+def bs2_vs_bs1(scores, state_len, bs2_seq, blank=2.0, threads=1):
+    """QUALITY GUARD of the product decoder's definition (review, round 5: BS-1 -> BS-2 was a redefinition made for kernel speed, and
+    bit-exactness against an oracle that moves with the kernel says nothing about what the change cost). On every chunk of koi-layout
+    fp16 `scores` [n,T,4S]: the BS-1 answer (crf_ref.beam_search_bs1, the decoder of rounds 1-4) and the given BS-2 answer `bs2_seq`
+    (int8 plane [n,T]) are BOTH scored with the model's exact sequence log-probability in fp64 (crf_ref.seq_logprob: sum over every
+    alignment and start state, independent of any decoder). Returns a JSON-ready dict; `dlogp` = ln P(BS-2 sequence) - ln P(BS-1
+    sequence) per chunk: >= 0 means the redefinition found an equally or more probable sequence."""
+    from oracle import crf_ref
+    sc = np.asarray(scores)
+    s1, _ = _sliced(lambda z: crf_ref.beam_search_bs1(z, state_len, blank=blank), sc, threads)
+
+    def lp(args):
+        i, plane = args
+        a, lz = crf_ref.seq_logprob(sc[i], state_len, plane, blank=blank)
+        return a - lz
+
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max(1, int(threads))) as ex:
+        l2 = np.array(list(ex.map(lp, [(i, np.asarray(bs2_seq)[i]) for i in range(sc.shape[0])])))
+        l1 = np.array(list(ex.map(lp, [(i, s1[i]) for i in range(sc.shape[0])])))
+    d = l2 - l1
+    same = int(sum(np.array_equal(a[a != 0], b[b != 0]) for a, b in zip(np.asarray(bs2_seq), s1)))
+    return {"chunks": int(sc.shape[0]), "steps_per_chunk": int(sc.shape[1]), "sequences_identical": same,
+            "dlogp_mean": float(d.mean()), "dlogp_min": float(d.min()), "dlogp_max": float(d.max()),
+            "bs2_better": int((d > 1e-9).sum()), "bs2_worse": int((d < -1e-9).sum()),
+            "logp_bs2_mean": float(l2.mean()), "logp_bs1_mean": float(l1.mean()),
+            "definition": "ln P(seq | scores) in fp64 by the exact path sum (oracle_seq_logprob_f64), BS-2's sequence minus BS-1's, per chunk"}
 
 
 def compare(hip, ora):

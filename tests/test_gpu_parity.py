@@ -9,6 +9,10 @@ identity measured on MI355X with at most twice its error rate allowed (figures b
 gpurun_out/parity_e2e_<name>.json, the bench line carries the same object as `parity`).
 
 The oracle's chunks ride at the head of a FULL engine call (512 / 256 chunks), so the kernels compared are the ones the bench times.
+
+Round 6: 64 chunks for fast / hac (8 before); every comparison is made against TWO CPU oracles - the fp32 path and nn_ref's fp16-storage mode
+(values rounded where the engine stores fp16) - so that precision is told apart from summation order; BASELINE configs 5 (256 x 20000, both
+candidate graphs) and 1 (CTC, 16 x 4000) have their own rows; the BS-2-against-BS-1 quality guard runs on every sample.
 """
 import copy
 import json
@@ -33,9 +37,12 @@ def _record(name, res):
 
 
 def _run(name, model, batch, chunk, n, quantize=False):
+    """-> (HIP vs the fp32 CPU path, HIP vs the fp16-storage oracle, the two oracles against each other) on the same n chunks."""
     nn_ref.round_params_to_half_(model)
     xo = torch.randn(n, 1, chunk, generator=torch.Generator().manual_seed(25)).half()
-    ora = parity.oracle_outputs(model, xo)
+    threads = min(16, n)
+    ora = parity.oracle_outputs(model, xo, threads=threads)
+    ora16 = parity.oracle_outputs(model, xo, threads=threads, fp16=True)
     g = copy.deepcopy(model)
     g.use_koi(batchsize=batch, chunksize=chunk, quantize=quantize)
     g = g.half().to("cuda")
@@ -43,9 +50,14 @@ def _run(name, model, batch, chunk, n, quantize=False):
     x[:n] = xo
     hip = parity.hip_outputs(g, x.cuda(), n)
     res = parity.compare(hip, ora)
-    _record(name, res)
+    res16 = parity.compare(hip, ora16)
+    between = parity.compare(ora16, ora)
+    guard = parity.bs2_vs_bs1(ora["scores"], int(ora["state_len"]), ora["beam_seq"], threads=threads)
+    _record(name, dict(res, vs_fp16_storage_oracle=res16, fp16_storage_oracle_vs_fp32_oracle=between, bs2_vs_bs1=guard))
     assert res["beam_alignment_columns"] > 100 * n and res["viterbi_alignment_columns"] > 100 * n      # the synthetic head does emit bases
-    return res
+    # the decoder's redefinition (BS-1 -> BS-2) costs no sequence probability on these scores (exact fp64 path sums)
+    assert guard["dlogp_mean"] > -0.05 and guard["dlogp_min"] > -1.0, guard
+    return res, res16, between
 
 
 def _floors(res, **floors):
@@ -53,36 +65,70 @@ def _floors(res, **floors):
     assert not bad, "identity below its floor (measured, floor): %r -- all figures: %r" % (bad, res)
 
 
+def _precision_not_order(res, res16, between):
+    """What separates the engine from the fp32 CPU path is fp16 STORAGE, not its arithmetic: the fp16-storage oracle (a CPU program) sits as
+    far from the fp32 path as the engine does, and the engine is CLOSER to it than to the fp32 path."""
+    assert res16["scores_mean_abs"] < res["scores_mean_abs"], (res16["scores_mean_abs"], res["scores_mean_abs"])
+    assert between["scores_mean_abs"] > 0.5 * res["scores_mean_abs"], (between["scores_mean_abs"], res["scores_mean_abs"])
+
+
 # floors: 1 - 2 x (1 - identity measured on MI355X), figures of the first measured run behind each line
 def test_end_to_end_identity_fast_512x10000():
-    res = _run("fast", synthetic.make_model("fast", batchsize=512, chunksize=10000), 512, 10000, 8)
-    # measured (round 5): Viterbi path 1.0 (8 of 8 chunks bit-identical), beam sequence 1.0, beam MOVE TABLE 0.9507 - the sequences agree
-    # base for base, the step at which a base is emitted does not always: BS-1 folds a move into the stay that spells the same sequence and
+    res, res16, between = _run("fast", synthetic.make_model("fast", batchsize=512, chunksize=10000), 512, 10000, 64)
+    # measured (round 5, 8 chunks): Viterbi path 1.0 (8 of 8 chunks bit-identical), beam sequence 1.0, beam MOVE TABLE 0.9507 - the sequences agree
+    # base for base, the step at which a base is emitted does not always: the search folds a move into the stay that spells the same sequence and
     # follows the higher of the two, and a random-weight head leaves those two within the fp16 error of each other
     _floors(res, viterbi_path_identity=0.998, viterbi_seq_identity=0.998, beam_seq_identity=0.998, moves_identity=0.90)
     assert res["scores_max_abs"] < 2.1e-2
+    _precision_not_order(res, res16, between)
 
 
 def test_end_to_end_identity_hac_512x10000():
-    res = _run("hac", synthetic.make_model("hac", batchsize=512, chunksize=10000), 512, 10000, 8)
-    # measured (round 5, the bench line's `parity`): Viterbi path 1.0, beam sequence 1.0, beam move table 0.9613
+    res, res16, between = _run("hac", synthetic.make_model("hac", batchsize=512, chunksize=10000), 512, 10000, 64)
+    # measured (round 5, 8 chunks; the bench line's `parity`): Viterbi path 1.0, beam sequence 1.0, beam move table 0.9613
     _floors(res, viterbi_path_identity=0.998, viterbi_seq_identity=0.998, beam_seq_identity=0.998, moves_identity=0.92)
     assert res["scores_max_abs"] < 2.4e-2
+    _precision_not_order(res, res16, between)
 
 
 def test_end_to_end_identity_hac_quantize_512x10000():
     """The 8-bit recurrence (Q8-1) against the fp32 CPU path: a different arithmetic, so a lower identity - stated, not hidden."""
-    res = _run("hac_q8", synthetic.make_model("hac", batchsize=512, chunksize=10000), 512, 10000, 8, quantize=True)
-    # measured (round 5): scores max |d| 0.148 - and still Viterbi path 1.0, beam sequence 1.0; beam move table 0.831, 43 % of the bases
+    res, _, _ = _run("hac_q8", synthetic.make_model("hac", batchsize=512, chunksize=10000), 512, 10000, 32, quantize=True)
+    # measured (round 5, 8 chunks): scores max |d| 0.148 - and still Viterbi path 1.0, beam sequence 1.0; beam move table 0.831, 43 % of the bases
     # emitted at the same step (the synthetic head saturates its tanh * 5 scores: WHICH base is robust, WHEN it is emitted is not)
     _floors(res, viterbi_path_identity=0.998, viterbi_seq_identity=0.998, beam_seq_identity=0.998, moves_identity=0.66)
 
 
 def test_end_to_end_identity_sup_v5_transformer_256x12000():
     model = synthetic.make_transformer_model(head_gain=4.0, batchsize=256, chunksize=12000)
-    res = _run("sup_v5", model, 256, 12000, 2)
-    # measured (round 5): everything 1.0 (both chunks bit-identical in path, sequence and moves) at a score error of 0.047 on a range of 27
+    res, _, _ = _run("sup_v5", model, 256, 12000, 4)
+    # measured (round 5, 2 chunks): everything 1.0 (both chunks bit-identical in path, sequence and moves) at a score error of 0.047 on a range of 27
     _floors(res, viterbi_path_identity=0.995, viterbi_seq_identity=0.995, beam_seq_identity=0.995, moves_identity=0.99)
+
+
+# BASELINE config 5 (rna004 sup, 256 x 20000, 1024 states; architecture unknown offline -> BOTH candidate graphs, SURVEY 8d). `rna=True` only
+# reverses the called strings on the host (crf/basecall.py `fmt`, reference bonito/crf/basecall.py:48-55): test_gpu_configs.py holds that.
+def test_end_to_end_identity_config5_transformer_graph_256x20000():
+    model = synthetic.make_transformer_model(head_gain=4.0, batchsize=256, chunksize=20000)
+    res, _, _ = _run("config5_v5_graph", model, 256, 20000, 2)
+    _floors(res, viterbi_path_identity=0.995, viterbi_seq_identity=0.995, beam_seq_identity=0.995, moves_identity=0.98)
+
+
+def test_end_to_end_identity_config5_lstm1024_graph_256x20000():
+    res, res16, between = _run("config5_v43_graph", synthetic.make_model("sup_lstm", batchsize=256, chunksize=20000), 256, 20000, 2)
+    _floors(res, viterbi_path_identity=0.995, viterbi_seq_identity=0.995, beam_seq_identity=0.995, moves_identity=0.90)
+    _precision_not_order(res, res16, between)
+
+
+def test_end_to_end_identity_config1_ctc_16x4000():
+    """BASELINE config 1 (dna_r9.4.1 QuartzNet CTC, 16 chunks x 4000, greedy + prefix beam 5) through the product pipeline against the fp32
+    CPU path: bench.py's `config1_ctc` leg, asserted."""
+    import bench
+    r = bench.config1_worker()
+    _record("config1_ctc", r)
+    assert r["greedy_alignment_columns"] > 16 * 50 and r["beam5_alignment_columns"] > 16 * 50
+    assert r["greedy_seq_identity"] > 0.97 and r["beam5_seq_identity"] > 0.97, r
+    assert r["logp_max_abs"] < 5e-2, r
 
 
 def test_identity_metrics_are_one_for_the_oracle_against_itself_and_drop_for_a_planted_error():
