@@ -1093,22 +1093,32 @@ extern "C" int bh_encoder_forward(bh_encoder_t* e, const void* signal, int N, in
                 const int M = N * len;            // batch-major: padded chunks sit behind the valid rows
                 const float eps = d.eps > 0.0f ? d.eps : 1e-5f;
                 int rc;
+                // profile spans (measurement only): the attention kernel and fc1 each get a span of their own - ONE launch per span, so that a
+                // roofline can name a kernel - the projections and norms around them share the two older classes
+                // default: rotary + softmax scale in the Wqkv epilogue, persistent ring-buffer attention kernel; the
+                // block-per-workgroup kernel (rotation applied while staging) serves wider windows and "attn_ring" = 0
+                const bool ring = e->attn_ring && d.win_left <= 128 && d.win_left + d.win_right <= 256;
                 {
                     ProfSpan span(e, st, BH_PROF_ATTENTION);
-                    // default: rotary + softmax scale in the Wqkv epilogue, persistent ring-buffer attention kernel; the
-                    // block-per-workgroup kernel (rotation applied while staging) serves wider windows and "attn_ring" = 0
-                    const bool ring = e->attn_ring && d.win_left <= 128 && d.win_left + d.win_right <= 256;
-                    if (ring) {
+                    if (ring)
                         rc = bh_k_linear_qkv_rotary(cur, l.w0.p, (const float*)l.b0.p, e->t_qkv.p, M, D, D, (const float*)e->rot.p,
                                                     len, 0.125f * 1.4426950408889634f, st);     // scores in log2 units
-                        if (!rc) rc = bh_k_attention_prerotated(e->t_qkv.p, e->t_a.p, N, len, d.nhead, D / d.nhead, d.win_left,
-                                                                d.win_right, st);
-                    } else {
+                    else
                         rc = bh_k_linear(cur, l.w0.p, (const float*)l.b0.p, e->t_qkv.p, M, 3 * D, D, D, D, 3 * D, bh::ACT_NONE,
                                          1.0f, -INFINITY, INFINITY, 0, 0, 0, 0, 0, st);
-                        if (!rc) rc = bh_k_attention(e->t_qkv.p, e->t_a.p, (const float*)e->rot.p, N, len, d.nhead, D / d.nhead,
-                                                     d.win_left, d.win_right, st);
-                    }
+                    if (rc) return rc;
+                }
+                {
+                    ProfSpan span(e, st, BH_PROF_ATTENTION_CORE);
+                    if (ring)
+                        rc = bh_k_attention_prerotated(e->t_qkv.p, e->t_a.p, N, len, d.nhead, D / d.nhead, d.win_left, d.win_right, st);
+                    else
+                        rc = bh_k_attention(e->t_qkv.p, e->t_a.p, (const float*)e->rot.p, N, len, d.nhead, D / d.nhead,
+                                            d.win_left, d.win_right, st);
+                    if (rc) return rc;
+                }
+                {
+                    ProfSpan span(e, st, BH_PROF_ATTENTION);
                     // DeepNorm residual alpha * x fused into the projection's epilogue (fp32 accumulator + alpha * x, one rounding); the norm
                     // kernel then reads one tensor instead of two ("norm_fuse" 1; default 0 = the separate residual read in the norm kernel)
                     if (!rc && e->norm_fuse)
@@ -1122,10 +1132,14 @@ extern "C" int bh_encoder_forward(bh_encoder_t* e, const void* signal, int N, in
                 }
                 void* dst = e->act[which].p;
                 {
-                    ProfSpan span(e, st, BH_PROF_MLP);
+                    ProfSpan span(e, st, BH_PROF_MLP_FC1);
                     rc = bh_k_linear(e->t_a.p, l.w2.p, nullptr, e->t_mid.p, M, 2 * F, D, D, D, F, bh::ACT_NONE, 1.0f,
                                      -INFINITY, INFINITY, 1, 0, 0, 0, 0, st);
-                    if (!rc && e->norm_fuse)
+                    if (rc) return rc;
+                }
+                {
+                    ProfSpan span(e, st, BH_PROF_MLP);
+                    if (e->norm_fuse)
                         rc = bh_k_linear(e->t_mid.p, l.w3.p, nullptr, e->t_b.p, M, D, F, F, F, D, bh::ACT_NONE, 1.0f,
                                          -INFINITY, INFINITY, 0, 0, 0, 0, 0, st, e->t_a.p, D, d.alpha);
                     else if (!rc)

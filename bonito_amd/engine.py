@@ -236,15 +236,16 @@ class HipEncoder:
         self.last_ticket = int(_lib.lib().bh_encoder_last_ticket(self._handle))
         return scores
 
-    PROF_CLASSES = ("conv", "lstm_gemm", "fill", "lstm_rec", "crf_linear", "attention", "mlp", "other")
+    # "attention" = the projections + norm around the attention kernel, "mlp" = fc2 + norm; "mlp_fc1" and "attention_core" hold ONE kernel each
+    PROF_CLASSES = ("conv", "lstm_gemm", "fill", "lstm_rec", "crf_linear", "attention", "mlp", "other", "mlp_fc1", "attention_core")
 
     def profile(self, enable=True):
         _lib.check(_lib.lib().bh_encoder_profile(self._handle, int(bool(enable))), "bh_encoder_profile")
 
     def profile_read(self):
         """-> {class: (milliseconds, spans)} accumulated since the last read (HIP events on the forward stream)."""
-        ms = (C.c_float * 8)()
-        n = (C.c_int * 8)()
+        ms = (C.c_float * len(self.PROF_CLASSES))()
+        n = (C.c_int * len(self.PROF_CLASSES))()
         _lib.check(_lib.lib().bh_encoder_profile_read(self._handle, ms, n), "bh_encoder_profile_read")
         return {k: (float(ms[i]), int(n[i])) for i, k in enumerate(self.PROF_CLASSES)}
 

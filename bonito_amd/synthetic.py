@@ -86,9 +86,10 @@ def transformer_flops_per_chunk(d_model=512, dim_ff=2048, depth=18, window=(127,
     T = (l4 + 4 - 5) // 2 + 1
     D, F, W = d_model, dim_ff, window[0] + window[1] + 1
     conv = 2 * (c1 * 5 * L + c1 * c2 * 5 * L + c2 * c3 * 9 * l3 + c3 * c4 * 9 * l4 + c4 * D * 5 * T)
-    attn = 2 * T * D * 3 * D + 2 * 2 * T * W * D + 2 * T * D * D
-    mlp = 2 * T * D * 2 * F + 2 * T * F * D
-    parts = {"conv": conv, "attention": depth * attn, "mlp": depth * mlp, "other": 2 * T * D * 2 * D,
+    # keys follow the engine's profile classes (include/bonito_hip.h BH_PROF_*): "attention" = Wqkv + out_proj, "attention_core" = the
+    # windowed QK^T + PV of the attention kernel, "mlp_fc1" = fc1 (+ SwiGLU), "mlp" = fc2
+    parts = {"conv": conv, "attention": depth * (2 * T * D * 3 * D + 2 * T * D * D), "attention_core": depth * 2 * 2 * T * W * D,
+             "mlp_fc1": depth * 2 * T * D * 2 * F, "mlp": depth * 2 * T * F * D, "other": 2 * T * D * 2 * D,
              "crf_linear": 2 * (2 * T) * D * 4 ** (state_len + 1)}
     parts["total"] = sum(parts.values())
     return parts

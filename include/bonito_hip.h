@@ -149,7 +149,9 @@ int bh_encoder_ack(bh_encoder_t* enc, long ticket);
  * After enabling, every bh_encoder_forward appends spans; profile_read synchronises on them and returns
  * accumulated milliseconds and span counts per class, then clears. */
 enum { BH_PROF_CONV = 0, BH_PROF_LSTM_GEMM = 1, BH_PROF_FILL = 2, BH_PROF_LSTM_REC = 3, BH_PROF_CRF_LINEAR = 4,
-       BH_PROF_ATTENTION = 5, BH_PROF_MLP = 6, BH_PROF_OTHER = 7, BH_PROF_CLASSES = 8 };
+       BH_PROF_ATTENTION = 5 /* Wqkv + rotary, out_proj, the first residual norm */, BH_PROF_MLP = 6 /* fc2 + the second residual norm */,
+       BH_PROF_OTHER = 7, BH_PROF_MLP_FC1 = 8 /* fc1 + SwiGLU alone: one launch per span */,
+       BH_PROF_ATTENTION_CORE = 9 /* the attention kernel alone: one launch per span */, BH_PROF_CLASSES = 10 };
 int bh_encoder_profile(bh_encoder_t* enc, int enable);
 int bh_encoder_profile_read(bh_encoder_t* enc, float* ms /*[BH_PROF_CLASSES]*/, int* spans /*[BH_PROF_CLASSES]*/);
 

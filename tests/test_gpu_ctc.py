@@ -115,3 +115,24 @@ def test_prefix_beam_search_matches_oracle():
             assert seq == oseq and path == opath, (bs, thr, len(seq), len(oseq))
     s, p = ctc_decode.beam_search(reads[2], alphabet)
     assert len(s) == len(p) and all(a < b for a, b in zip(p, p[1:]))
+
+
+def test_grouped_decode_equals_one_launch_per_read():
+    """Round 6: `basecall` decodes up to 64 stitched reads per launch (one lane per read) instead of one launch per read; the per-read path
+    (`decode`, the reference's call pattern) must give the same dictionaries."""
+    from functools import partial
+    from bonito_amd.ctc import basecall as mod
+    import importlib
+    bc = importlib.import_module("bonito_amd.ctc.basecall")
+    model, _, _ = _gpu_model()
+    rng = np.random.default_rng(9)
+    items = []
+    for i, T in enumerate((5, 1334, 400, 1, 77)):
+        lp = torch.log_softmax(torch.from_numpy(rng.standard_normal((T, 5)).astype(np.float32) * 3), -1)
+        items.append((Read("r%d" % i, None), {"scores": lp}))
+    for beamsize, qscores in ((1, False), (5, False), (5, True)):
+        grouped = list(bc.decode_grouped(model, iter(items), beamsize=beamsize, qscores=qscores, group=3))
+        single = [(r, bc.decode(v, model.decode, beamsize=beamsize, qscores=qscores, stride=model.stride)) for r, v in items]
+        assert [r.read_id for r, _ in grouped] == [r.read_id for r, _ in single]
+        for (_, a), (_, b) in zip(grouped, single):
+            assert a == b, (beamsize, qscores, a, b)

@@ -5,7 +5,7 @@
 
 reads pmc_rd.txt / pmc_wr.txt (tools/pmc_summary.py output of the separate `--pmc FETCH_SIZE` and `--pmc WRITE_SIZE` passes), writes
 profiles/<tag>_pmc_hbm_bytes.txt (both lists under one header) and, for every recurrent kernel found, the entry of
-profiles/pmc_traffic.json that bench.py copies into roofline.traffic: bytes per launch = 1024 * (2 * FETCH_SIZE + WRITE_SIZE) - the
+profiles/pmc_traffic.json that bench.py copies into roofline.traffic (key "<kernel>|<workload>"): bytes per launch = 1024 * (2 * FETCH_SIZE + WRITE_SIZE) - the
 counters are KiB per dispatch, and on gfx950 FETCH_SIZE reports half the bytes of 16-byte coalesced streams (MI355X_MICROARCH.md, HBM)."""
 import json
 import os
@@ -41,13 +41,18 @@ def main():
     table = json.load(open(table_path))
     fetch = {r[0]: r[3] for r in rd}
     write = {r[0]: r[3] for r in wr}
+    # the kernels a bench roofline can name: the recurrent kernels, fc1 (+ SwiGLU) of the transformer, the attention kernel
+    wanted = (r"(lstm_layer_\w+_kernel)", r"(gemm_w4_kernel)<0, true, 4, 0>", r"(attention_ring_kernel)")
     for name in fetch:
-        m = re.search(r"(lstm_layer_\w+_kernel)", name)
+        m = None
+        for pat in wanted:
+            m = m or re.search(pat, name)
         if not m or name not in write:
             continue
-        table[m.group(1)] = {"workload": workload, "bytes_per_launch": int(round(1024 * (2 * fetch[name] + write[name]), -6)),
-                             "source": "profiles/%s_pmc_hbm_bytes.txt" % tag}
-        print(m.group(1), table[m.group(1)])
+        ent = {"workload": workload, "bytes_per_launch": int(round(1024 * (2 * fetch[name] + write[name]), -6)),
+               "kernel": name, "source": "profiles/%s_pmc_hbm_bytes.txt" % tag}
+        table["%s|%s" % (m.group(1), workload)] = ent
+        print(m.group(1), ent)
     with open(table_path, "w") as fh:
         json.dump(table, fh, indent=1)
         fh.write("\n")

@@ -21,7 +21,11 @@ ap.add_argument("--steps", type=int, default=3)
 ap.add_argument("--batch", type=int, default=512)
 ap.add_argument("--chunk", type=int, default=10000)
 ap.add_argument("--quantize", action="store_true")
+ap.add_argument("--set", action="append", default=[], metavar="NAME=VALUE", help="library option (bh_set_option), e.g. lstm_q8_variant=2")
 a = ap.parse_args()
+for kv in a.set:
+    k, _, v = kv.partition("=")
+    decode.set_option(k, int(v))
 if a.model == "sup":
     a.batch, a.chunk = (256, 12000) if (a.batch, a.chunk) == (512, 10000) else (a.batch, a.chunk)
     model = synthetic.make_transformer_model(head_gain=4.0, batchsize=a.batch, chunksize=a.chunk)
