@@ -162,7 +162,7 @@ def pmc_traffic(kernel, a, launch_chunks=None):
             table = json.load(fh)
     except (OSError, ValueError):
         return None, None
-    workload = "%s%s %dx%d" % (a.model, " quantize" if a.quantize else "", launch_chunks or a.call_batch, a.chunk)
+    workload = "%s%s %dx%d" % (a.model, " quantize" if getattr(a, "quantize", False) else "", launch_chunks or a.call_batch, a.chunk)
     base = (kernel or "").split("<")[0].split(" ")[0]
     named = re.search(r"(lstm_layer_\w+_kernel)", kernel or "")          # "gemm + lstm_layer_wide_kernel<32,true>" -> the recurrent kernel
     for key in ([named.group(1)] if named else []) + [base]:
