@@ -519,7 +519,7 @@ def dry_run(a, json_out):
     JSON line. The hot path is a sleep; the line is marked and is not a measurement."""
     import torch.distributed as dist
     from bonito_amd import parallel
-    rank, world, local = parallel.init("gloo")
+    rank, world, local = parallel.init("gloo", timeout=600.0)
     if world != a.gpus:
         raise SystemExit("bench.py: --gpus %d but the launcher started %d rank(s)" % (a.gpus, world))
     sys.stderr.write("bench.py: dry run, rank %d/%d (local %d)\n" % (rank, world, local))
@@ -572,7 +572,8 @@ def main():
     # one process per GPU; RCCL only for barrier + MAX-reduce. More ranks than GPUs (a 1-GPU test box running `--gpus 2`):
     # ranks share devices and the two collectives go over gloo, since RCCL refuses two ranks on one device.
     oversubscribed = int(os.environ.get("WORLD_SIZE", "1")) > ndev
-    rank, world, local = parallel.init("gloo" if oversubscribed else "nccl")
+    # (the side legs of rank 0 - roofline spans, CPU oracle - run between two barriers: a generous bound on the default group)
+    rank, world, local = parallel.init("gloo" if oversubscribed else "nccl", timeout=3600.0)
     if world != a.gpus:
         raise SystemExit("bench.py: --gpus %d but the launcher started %d rank(s)" % (a.gpus, world))
     local %= ndev

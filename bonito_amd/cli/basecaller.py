@@ -74,41 +74,68 @@ def launch(args, argv):
         elif not tok.startswith(("--devices=", "--device=")):
             child_argv.append(tok)
     procs = []
+    import tempfile
+    ready_dir = tempfile.mkdtemp(prefix="bonito_amd_")
+    ready = os.path.join(ready_dir, "rendezvous_done")
     for rank, dev in enumerate(devices):
         dev = child_device_mask(dev, os.environ)
         env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(len(devices)), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(port), HIP_VISIBLE_DEVICES=str(dev), BONITO_AMD_SPAWNED="1")
+                   MASTER_PORT=str(port), HIP_VISIBLE_DEVICES=str(dev), BONITO_AMD_SPAWNED="1", BONITO_AMD_READY_FILE=ready)
         env.pop("CUDA_VISIBLE_DEVICES", None)
         pkg_root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
         env["PYTHONPATH"] = pkg_root + (os.pathsep + env["PYTHONPATH"] if env.get("PYTHONPATH") else "")
         procs.append(subprocess.Popen([sys.executable, "-m", "bonito_amd", "basecaller", *child_argv], env=env,
                                       stdout=None if rank == 0 else subprocess.DEVNULL))
-    # A worker other than rank 0 that dies does not take the run down: rank 0 keeps the records it had received from it and basecalls
-    # the rest of that worker's shard itself (parallel.ordered_records, `rescue`), the other workers carry on. Rank 0 is the writer:
-    # if IT fails, the rest is taken down with it.
+    # Two phases (advisor, round 5). BEFORE rank 0 reports that every rank has joined (parallel.rendezvous_done): a worker that exits -
+    # out of memory, a bad device, an import error - can only leave the others waiting in the rendezvous, so everything is taken down
+    # at once. AFTER: a worker other than rank 0 that dies does not take the run down - rank 0 keeps the records it had received from
+    # it and basecalls the rest of that worker's shard itself (parallel.ordered_records, `rescue`), the other workers carry on. Rank 0
+    # is the writer: if IT fails, the rest is taken down with it. Exit code: 0 = complete, every rank alive to the end; 3 = complete
+    # (every read basecalled and written) but a worker was lost on the way - a scheduler can tell; 1 = failed.
+    import shutil
     import time
-    rcs = [None] * len(procs)
-    while any(rc is None for rc in rcs):
+
+    def take_down(rcs):
         for i, pr in enumerate(procs):
             if rcs[i] is None:
-                rcs[i] = pr.poll()
-                if rcs[i] not in (None, 0) and i != 0:
-                    sys.stderr.write("> warning: worker rank %d (device %s) exited with code %d: rank 0 takes over its reads\n"
-                                     % (i, devices[i], rcs[i]))
-        if rcs[0] not in (None, 0):
+                pr.terminate()
+        for i, pr in enumerate(procs):
+            if rcs[i] is None:
+                try:
+                    rcs[i] = pr.wait(timeout=10)
+                except Exception:
+                    pr.kill()
+                    rcs[i] = pr.wait()
+
+    rcs = [None] * len(procs)
+    try:
+        while any(rc is None for rc in rcs):
+            joined = os.path.exists(ready)
             for i, pr in enumerate(procs):
                 if rcs[i] is None:
-                    pr.terminate()
-                    rcs[i] = pr.wait()
-            break
-        time.sleep(0.05)
+                    rcs[i] = pr.poll()
+                    if rcs[i] not in (None, 0) and i != 0 and joined:
+                        sys.stderr.write("> warning: worker rank %d (device %s) exited with code %d: rank 0 takes over its reads\n"
+                                         % (i, devices[i], rcs[i]))
+            early = [(i, rc) for i, rc in enumerate(rcs) if rc not in (None, 0)] if not joined else []
+            if early:
+                sys.stderr.write("> error: worker rank %d exited with code %d before every rank had joined: stopping all workers\n" % early[0])
+                take_down(rcs)
+                return 1
+            if rcs[0] not in (None, 0):
+                take_down(rcs)
+                break
+            time.sleep(0.05)
+    finally:
+        shutil.rmtree(ready_dir, ignore_errors=True)
     if rcs[0] != 0:
         sys.stderr.write("> error: the writing worker (rank 0) failed with code %s\n" % rcs[0])
         return 1
     bad = [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
     if bad:
-        sys.stderr.write("> warning: completed WITHOUT %s; every read was basecalled and written\n"
+        sys.stderr.write("> warning: completed WITHOUT %s; every read was basecalled and written (exit code 3)\n"
                          % ", ".join("rank %d (rc %d)" % b for b in bad))
+        return 3
     return 0
 
 
@@ -130,7 +157,9 @@ def main(args, argv=None):
         # one process per GPU: spawned by `launch` (sees one device) or by torchrun (device = LOCAL_RANK)
         if not os.environ.get("BONITO_AMD_SPAWNED") and args.device == "cuda":
             args.device = "cuda:%d" % local
+        _fault_hook_early(rank)
         parallel.init("gloo")              # host objects only: there is no device collective on this path
+        parallel.host_group()              # every rank joins here (bounded by the rendezvous timeout); rank 0 then tells the launcher
     util.init(args.seed, args.device)
     util.limit_host_threads(8)       # host work is small copies; never out-spin a container's CPU quota
     log = sys.stderr.write if rank == 0 else (lambda _msg: None)
@@ -180,14 +209,7 @@ def main(args, argv=None):
         return parallel.format_stream(results, mode, args.min_qscore)
 
     records = make_records(model, reads)
-    fault = os.environ.get("BONITO_AMD_FAULT_INJECT", "")          # "rank:count" - that worker dies after `count` records (tests of the
-    if fault and world > 1 and int(fault.split(":")[0]) == rank:    # failure-detection path: tests/test_gpu_basecall.py); never set in production
-        def dying(recs, count=int(fault.split(":")[1])):
-            for k, rec in enumerate(recs):
-                if k == count:
-                    os._exit(7)
-                yield rec
-        records = dying(records)
+    records = _fault_hook(records, rank, world)
     t0 = perf_counter()
     lost_ranks = []
     if world > 1:
@@ -204,12 +226,23 @@ def main(args, argv=None):
                                       scaling_strategy=model.config.get("scaling"),
                                       norm_params=model.config.get("standardisation") if pa else model.config.get("normalisation"),
                                       n_max=args.max_reads or None, raw=args.device_ingest, rank=r, world=world)
-            return make_records(m2, itertools.islice(theirs, k, None))
+            try:
+                yield from make_records(m2, itertools.islice(theirs, k, None))
+            finally:
+                # the stand-in engine (its workspace, its share of the score tensors) goes when its shard is done: two resident engines for
+                # the rest of the run could exhaust rank 0's memory, and rank 0 is the only writer (advisor, round 5)
+                eng = getattr(m2, "_hip", None)
+                if eng is not None:
+                    eng.close()
+                del m2
+                import torch
+                torch.cuda.empty_cache()
 
         # every rank formats its own records; rank 0 merges the streams in input order and is the only writer. The streams end with a
         # closing message from rank 0 (no barrier: it would wait for a worker that died)
         records = parallel.ordered_records(records, rank, world, rescue=rescue)
         if rank != 0:
+            parallel.shutdown()
             return 0
     writer = Writer(mode, records, fd=out, summary_path=None if args.no_summary else args.summary, preformatted=True)
     writer.start()
@@ -225,7 +258,48 @@ def main(args, argv=None):
         sys.stderr.write("> devices: %d (one process per GPU, reads sharded round-robin)%s\n"
                          % (world, "; lost on the way: rank(s) %s" % sorted(set(lost_ranks)) if lost_ranks else ""))
     sys.stderr.write("> done\n")
+    if world > 1:
+        parallel.shutdown()
     return 0
+
+
+def _fault_hook(records, rank, world):
+    """TEST HOOK of the failure-detection path (tests/test_gpu_basecall.py): with BONITO_AMD_TEST_HOOKS=1 AND BONITO_AMD_FAULT_INJECT=
+    "<rank>:<count>" that worker exits hard after `count` records. Without the first variable the second is ignored; a malformed value
+    is an error at start-up (not a crash in every worker half-way), and an armed hook says so on stderr (advisor, round 5)."""
+    fault = os.environ.get("BONITO_AMD_FAULT_INJECT", "")
+    if not fault:
+        return records
+    if os.environ.get("BONITO_AMD_TEST_HOOKS") != "1":
+        sys.stderr.write("> warning: BONITO_AMD_FAULT_INJECT is set but BONITO_AMD_TEST_HOOKS is not 1: ignored\n")
+        return records
+    if fault.endswith(":early"):
+        return records                     # handled before the rendezvous (_fault_hook_early)
+    try:
+        victim, count = (int(tok) for tok in fault.split(":"))
+        if victim < 0 or count < 0:
+            raise ValueError
+    except ValueError:
+        raise SystemExit("> error: BONITO_AMD_FAULT_INJECT must be <rank>:<records> or <rank>:early, got %r" % fault)
+    if world < 2 or victim != rank:
+        return records
+    sys.stderr.write("> WARNING: TEST HOOK ARMED - rank %d will exit hard after %d records (BONITO_AMD_FAULT_INJECT)\n" % (rank, count))
+
+    def dying(recs):
+        for k, rec in enumerate(recs):
+            if k == count:
+                os._exit(7)
+            yield rec
+    return dying(records)
+
+
+def _fault_hook_early(rank):
+    """TEST HOOK: BONITO_AMD_FAULT_INJECT="<rank>:early" (with BONITO_AMD_TEST_HOOKS=1) - that worker exits BEFORE joining the rendezvous,
+    the case in which the launcher must stop everything at once (tests/test_cli_cpu.py)."""
+    fault = os.environ.get("BONITO_AMD_FAULT_INJECT", "")
+    if os.environ.get("BONITO_AMD_TEST_HOOKS") == "1" and fault.endswith(":early") and fault.split(":")[0] == str(rank):
+        sys.stderr.write("> WARNING: TEST HOOK ARMED - rank %d exits before the rendezvous (BONITO_AMD_FAULT_INJECT)\n" % rank)
+        os._exit(9)
 
 
 def argparser():

@@ -32,19 +32,39 @@ def env_rank_world():
     return int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("LOCAL_RANK", "0"))
 
 
-def init(backend=None):
-    """Initialise torch.distributed from the torchrun environment (no-op for a single process)."""
+RENDEZVOUS_TIMEOUT_S = 180.0        # store rendezvous + the collectives that build the groups; BONITO_AMD_RENDEZVOUS_TIMEOUT overrides
+STREAM_TIMEOUT_S = 7 * 24 * 3600.0    # point-to-point record streams: a rank legitimately waits as long as the run lasts
+
+
+def init(backend=None, timeout=None):
+    """Initialise torch.distributed from the torchrun environment (no-op for a single process). The default group gets a SHORT timeout
+    (advisor, round 5: a worker that dies before or during the rendezvous - out of memory, a bad device, an import error - used to
+    leave the others in `init_process_group` for gloo's default of 30 minutes); the record streams run on `host_group()`, whose
+    point-to-point operations may wait as long as the run lasts."""
+    import datetime
     rank, world, local = env_rank_world()
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if timeout is None:
+            timeout = float(os.environ.get("BONITO_AMD_RENDEZVOUS_TIMEOUT", RENDEZVOUS_TIMEOUT_S))
+        td = datetime.timedelta(seconds=timeout)
         if backend == "nccl":
             torch.cuda.set_device(local)
-            dist.init_process_group(backend, device_id=torch.device("cuda", local))
+            dist.init_process_group(backend, device_id=torch.device("cuda", local), timeout=td)
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, timeout=td)
     return rank, world, local
+
+
+def rendezvous_done():
+    """Tell the launcher (cli/basecaller.py `launch`) that every rank has joined: from here on a lost worker is absorbed by rank 0; before,
+    the launcher takes the run down. The file named by BONITO_AMD_READY_FILE is created by rank 0 once the host group exists."""
+    path = os.environ.get("BONITO_AMD_READY_FILE")
+    if path and env_rank_world()[0] == 0:
+        with open(path, "w") as fh:
+            fh.write("ready\n")
 
 
 def shard(items, rank, world):
@@ -85,11 +105,38 @@ _HOST_GROUP = None
 
 
 def host_group():
-    """A gloo group for host objects (the default group may be RCCL, which only moves device tensors)."""
+    """A gloo group for host objects (the default group may be RCCL, which only moves device tensors), with a timeout that does not
+    bound the run: a worker that has finished its shard waits for rank 0's closing message for as long as the slowest rank needs.
+    Creating it is a collective of every rank (bounded by the default group's short timeout)."""
     global _HOST_GROUP
     if _HOST_GROUP is None:
-        _HOST_GROUP = dist.new_group(backend="gloo") if dist.get_backend() != "gloo" else dist.group.WORLD
+        import datetime
+        _HOST_GROUP = dist.new_group(backend="gloo", timeout=datetime.timedelta(seconds=STREAM_TIMEOUT_S))
+        rendezvous_done()
     return _HOST_GROUP
+
+
+def shutdown():
+    """Normal exit path of a multi-process run: drop the groups (advisor, round 5: the CLI no longer did)."""
+    global _HOST_GROUP
+    _HOST_GROUP = None
+    if dist.is_available() and dist.is_initialized():
+        try:
+            dist.destroy_process_group()
+        except Exception:          # a peer that died has left a half-open pair behind: nothing to clean up on its side
+            pass
+
+
+_PEER_GONE = ("closed by peer", "reset by peer", "connection closed", "broken pipe", "socket closed", "connection refused",
+              "peer closed", "connection reset")
+
+
+def peer_is_gone(exc):
+    """Is this gloo failure a DEAD peer (connection closed / reset) rather than a live one that is slow, a timeout or a corrupt message?
+    Only the former may be rescued: a stalled-but-alive rank keeps sending into its stream, and a duplicate producer for its shard
+    would leave it blocked for ever (advisor, round 5)."""
+    text = str(exc).lower()
+    return isinstance(exc, (RuntimeError, ConnectionError, OSError)) and any(tok in text for tok in _PEER_GONE)
 
 
 class _Prefetch:
@@ -182,12 +229,16 @@ def ordered_records(local_records, rank=None, world=None, batch=64, group=None, 
             """next message of rank src -> bufs / done; a dead peer switches the stream over to the rescue iterator"""
             try:
                 recs, last = _recv_obj(src, group)
-            except Exception as exc:             # gloo: connection closed / reset by peer, timeout
-                if rescue is None:
+            except Exception as exc:
+                # only a peer whose connection is CLOSED / RESET is dead; a timeout or a garbled message of a live rank is an error
+                if rescue is None or not peer_is_gone(exc):
                     raise
                 if on_rank_lost is not None:
                     on_rank_lost(src, got[src], exc)
-                lost[src] = iter(rescue(src, got[src]))
+
+                def lazily(r=src, k=got[src]):          # the stand-in producer (a second model on rank 0's GPU in the CLI) is built on
+                    yield from rescue(r, k)             # the first record asked of it - a rank that died BEHIND its last record costs nothing
+                lost[src] = lazily()
                 return
             bufs[src] = recs
             got[src] += len(recs)

@@ -80,3 +80,46 @@ def test_npy_reader(tmp_path):
     with pytest.raises(FileNotFoundError):
         reader.Reader(str(tmp_path / "nope"))
 
+
+
+def test_launcher_stops_everything_when_a_worker_dies_before_the_rendezvous(tmp_path):
+    """Advisor, round 5: a worker that exits before every rank has joined (out of memory, a bad device, an import error) used to leave
+    the others in `init_process_group` for gloo's default of 30 minutes, and the launcher returned 0 with workers missing. Now the
+    launcher takes the run down at once and fails. (No GPU is touched: the hook fires, and the launcher reacts, before any model load.)"""
+    import subprocess
+    import sys
+    import time
+    from conftest import ROOT
+    env = dict(os.environ, BONITO_AMD_TEST_HOOKS="1", BONITO_AMD_FAULT_INJECT="1:early", BONITO_AMD_RENDEZVOUS_TIMEOUT="120")
+    t0 = time.time()
+    r = subprocess.run([sys.executable, "-m", "bonito_amd", "basecaller", str(tmp_path / "no_model"), str(tmp_path), "--devices", "0,0,0"],
+                       capture_output=True, text=True, cwd=ROOT, timeout=110, env=env)
+    assert r.returncode == 1, (r.returncode, r.stderr[-1500:])
+    assert "before every rank had joined" in r.stderr and "TEST HOOK ARMED" in r.stderr
+    assert time.time() - t0 < 100          # not the rendezvous timeout, let alone gloo's 30 minutes
+
+
+def test_fault_hook_is_inert_without_the_test_switch_and_rejects_malformed_values(monkeypatch):
+    from bonito_amd.cli import basecaller as cli
+    recs = [1, 2, 3]
+    monkeypatch.setenv("BONITO_AMD_FAULT_INJECT", "0:1")
+    monkeypatch.delenv("BONITO_AMD_TEST_HOOKS", raising=False)
+    assert list(cli._fault_hook(iter(recs), 0, 2)) == recs          # set but not armed: ignored
+    monkeypatch.setenv("BONITO_AMD_TEST_HOOKS", "1")
+    monkeypatch.setenv("BONITO_AMD_FAULT_INJECT", "zero:one")
+    with pytest.raises(SystemExit):
+        cli._fault_hook(iter(recs), 0, 2)
+    monkeypatch.setenv("BONITO_AMD_FAULT_INJECT", "1:2")
+    assert list(cli._fault_hook(iter(recs), 0, 2)) == recs          # another rank's fault
+
+
+def test_only_a_closed_connection_counts_as_a_dead_peer():
+    """parallel.ordered_records rescues a rank's shard only when gloo reports its connection closed / reset; a timeout or a garbled
+    message of a live rank is an error that propagates (advisor, round 5)."""
+    from bonito_amd import parallel
+    assert parallel.peer_is_gone(RuntimeError("[/pytorch/third_party/gloo/gloo/transport/tcp/pair.cc:534] Connection closed by peer [127.0.0.1]:4242"))
+    assert parallel.peer_is_gone(RuntimeError("Read error [127.0.0.1]:1234: Connection reset by peer"))
+    assert not parallel.peer_is_gone(RuntimeError("Timed out waiting 1800000ms for recv operation to complete"))
+    assert not parallel.peer_is_gone(ValueError("connection closed by peer"))          # not a transport error type
+    import pickle
+    assert not parallel.peer_is_gone(pickle.UnpicklingError("invalid load key"))

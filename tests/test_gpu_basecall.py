@@ -324,11 +324,12 @@ def test_cli_worker_death_is_absorbed_by_rank_0(tmp_path):
     for i in range(14):
         np.save(rdir / ("read%02d.npy" % i), (rng.standard_normal(int(rng.integers(700, 9000))) * 12 + 90).astype(np.float32))
     outs = []
-    for extra, env in (([], {}), (["--devices", "0,0,0"], {"BONITO_AMD_FAULT_INJECT": "1:2"})):
+    for extra, env in (([], {}), (["--devices", "0,0,0"], {"BONITO_AMD_FAULT_INJECT": "1:2", "BONITO_AMD_TEST_HOOKS": "1"})):
         summ = tmp_path / ("summary%d.tsv" % len(outs))
         r = subprocess.run([sys.executable, "-m", "bonito_amd", "basecaller", str(mdir), str(rdir), "--summary", str(summ),
                             "--batchsize", "8"] + extra, capture_output=True, text=True, cwd=ROOT, timeout=600, env=dict(os.environ, **env))
-        assert r.returncode == 0, r.stderr[-2000:]
+        # 0 = complete; 3 = complete, every read written, but a worker was lost on the way (a scheduler can tell the two apart)
+        assert r.returncode == (3 if env else 0), r.stderr[-2000:]
         assert "completed reads: 14" in r.stderr
         outs.append((r.stdout, summ.read_text(), r.stderr))
     assert outs[0][:2] == outs[1][:2] and len(outs[0][0].strip().split("\n")) == 56
