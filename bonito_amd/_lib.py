@@ -86,6 +86,7 @@ SIGNATURES = {
     "bh_host_format_read": (_l, [_vp, _vp, _vp, _vp, _i, _l, _l, _i, _i, _i, _i, _i, _i, C.c_double, C.c_char_p, C.c_char_p, _l, _l,
                                  _vp, _l, _vp, _vp]),
     "bh_host_mean_qscore": (C.c_double, [C.c_char_p, _l]),
+    "bh_host_svb16_decode": (_l, [_vp, _l, _l, _vp]),
     "bh_lstm_workspace": (_sz, [_i, _i]),
     "bh_lstm_layer": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _vp]),
     "bh_lstm_q8_layer": (_i, [_vp, _f, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),

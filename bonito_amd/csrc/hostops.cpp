@@ -235,3 +235,30 @@ extern "C" long bh_host_format_read(const int8_t* const* base, const long* plane
     }
     return (long)(p - out);
 }
+
+// ---- pod5 signal codec (bonito_amd/pod5.py) ------------------------------------------------------------------------------------------
+// The inner layer of ONT's VBZ signal compression as published with the pod5 format (the outer layer, zstd, is undone by the caller):
+// streamvbyte for 16-bit values ("svb16") over the zig-zag code of the first differences. `count` values: ceil(count / 8) key bytes (bit
+// i % 8 of byte i / 8 says whether value i takes one byte or two), then the data bytes, little-endian. value -> delta = (v >> 1) ^ -(v & 1),
+// sample_i = sample_{i-1} + delta (16-bit wrap-around, sample_{-1} = 0). Returns the bytes consumed, or -1 when the input is too short.
+// Replaces pod5's compiled decoder on the path /root/reference bonito/pod5.py:52 (`read.signal`); the wheel is absent here: FORMAT UNPINNED.
+extern "C" long bh_host_svb16_decode(const uint8_t* in, long n_in, long count, int16_t* out) {
+    if (!in || !out || count < 0 || n_in < 0) return -1;
+    const long nkeys = (count + 7) / 8;
+    if (n_in < nkeys) return -1;
+    const uint8_t* keys = in;
+    const uint8_t* data = in + nkeys;
+    const uint8_t* end = in + n_in;
+    uint16_t prev = 0;
+    for (long i = 0; i < count; ++i) {
+        const int two = (keys[i >> 3] >> (i & 7)) & 1;
+        if (data + 1 + two > end) return -1;
+        uint16_t v = data[0];
+        if (two) v |= (uint16_t)data[1] << 8;
+        data += 1 + two;
+        const uint16_t delta = (uint16_t)((v >> 1) ^ (uint16_t)(0u - (v & 1u)));
+        prev = (uint16_t)(prev + delta);
+        out[i] = (int16_t)prev;
+    }
+    return (long)(data - in);
+}

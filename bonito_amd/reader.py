@@ -4,10 +4,11 @@ Signal ingest for the basecaller: `Read` objects with a normalised float32 `.sig
 bonito/pod5.py:52-67: scale to pA, normalise, trim the start).
 
 Formats: the pod5 / fast5 readers of the reference need the `pod5` / `ont_fast5_api` wheels, which are not
-installable here (no network). `Reader` therefore accepts
+installable here (no network). `Reader` accepts
   * a directory of ``*.npy`` files -- one read each: float32 (already in pA or normalised) or int16 raw ADC
     with an optional ``<name>.json`` side-car {"offset":..., "scale":..., "read_id":...};
-  * ``*.pod5`` files when the `pod5` module is importable (same calls as bonito/pod5.py:113-124).
+  * ``*.pod5`` files through bonito_amd/pod5.py (round 6: the container, its Arrow tables and the VBZ signal codec read
+    without the wheel; same per-read flow as bonito/pod5.py:52-67,113-124; format unpinned - no reference .pod5 exists here).
 """
 import json
 import os
@@ -105,8 +106,8 @@ class RawRead:
 
 
 class Reader:
-    """Yields `Read`s from a directory (``*.npy``; ``*.pod5`` when the pod5 module is available); with ``raw=True`` int16
-    reads are yielded as `RawRead`s for the device ingest instead of being normalised here."""
+    """Yields `Read`s from a directory (``*.npy`` and ``*.pod5``); with ``raw=True`` int16 reads are yielded as `RawRead`s for the
+    device ingest instead of being normalised here."""
 
     def __init__(self, directory, recursive=False):
         pattern = "**/*" if recursive else "*"
@@ -152,10 +153,7 @@ class Reader:
             if stop():
                 return
         if self.pod5:
-            try:
-                import pod5
-            except ImportError as exc:
-                raise RuntimeError("reading .pod5 needs the `pod5` package, which is not installed") from exc
+            from bonito_amd import pod5          # the container / Arrow / VBZ reader of this package (the `pod5` wheel is not needed)
             for path in self.pod5:
                 with pod5.Reader(path) as fh:
                     for rec in fh.reads():
@@ -164,11 +162,13 @@ class Reader:
                             continue
                         index += 1
                         if index % world == rank:
-                            cal = rec.calibration
-                            yield Read(rid, rec.signal, filename=os.path.basename(path), run_id=rec.run_info.acquisition_id,
-                                       channel=rec.pore.channel, mux=rec.pore.well,
-                                       start=rec.start_sample / rec.run_info.sample_rate, sample_rate=rec.run_info.sample_rate,
-                                       scaling=cal.scale, offset=cal.offset, do_trim=do_trim, scaling_strategy=scaling_strategy,
-                                       norm_params=norm_params)
+                            cal, rate = rec.calibration, float(rec.run_info.sample_rate or 5000.0)
+                            common = dict(filename=os.path.basename(path), run_id=rec.run_info.acquisition_id, channel=rec.pore.channel,
+                                          mux=rec.pore.well, start=rec.start_sample / rate, sample_rate=rate, scaling=cal.scale, offset=cal.offset)
+                            if raw:          # int16 ADC samples straight to the device ingest (bh_signal_chunks)
+                                yield RawRead(rid, rec.signal, **common)
+                            else:
+                                yield Read(rid, rec.signal, do_trim=do_trim, scaling_strategy=scaling_strategy, norm_params=norm_params,
+                                           **common)
                         if stop():
                             return

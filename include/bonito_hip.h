@@ -317,6 +317,10 @@ long bh_host_format_read(const int8_t* const* base, const long* plane_stride, co
                          char* out, long out_cap, long* seq_len, double* mean_q);
 /* Mean q-score of a phred string, averaged in error-probability space (bonito/util.py mean_qscore_from_qstring). */
 double bh_host_mean_qscore(const char* qstring, long n);
+/* pod5 signal codec, inner layer (bonito_amd/pod5.py; replaces the pod5 wheel behind /root/reference bonito/pod5.py:52 `read.signal`):
+ * streamvbyte-16 over the zig-zag code of the first differences -> `count` int16 samples. `in` is the zstd-DEcompressed block.
+ * Returns the bytes consumed, -1 when the input is too short. Host code, no device involved. */
+long bh_host_svb16_decode(const uint8_t* in, long n_in, long count, int16_t* out);
 /* one LSTM layer over gates_in = x W_ih^T + b (fp16 [T][N][4H], torch gate order); h_out fp16 [T][N][H].
  * N % 16 == 0.  workspace: bh_lstm_workspace(N, H) device bytes.  err_flag: device int, set non-zero on a
  * device-side timeout.  flags bit 0: force the placement-independent write-through exchange policy;
