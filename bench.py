@@ -327,7 +327,15 @@ def e2e_worker(name="hac", reads=20000, mean_len=100000, batchsize=512):
     done, nreads, dt = once(lens)
     assert done == int(lens.sum()), (done, int(lens.sum()))
     aff = len(os.sched_getaffinity(0))
+    # what the DEVICE computed for those reads: every read is cut into chunks of 9996 samples that overlap by 498, plus one stub chunk
+    # where the length does not fit (util.chunk) - 9-10 % more chunk-samples than read samples at these lengths. `value` counts read
+    # samples (the reference CLI's definition); the figure to hold against the bench's `value` (chunk-samples/s) is this one
+    step = 9996 - 498
+    n_chunks = int(sum((int(n) - 498 + step - 1) // step if n >= 9996 else 1 for n in lens))
     return {"value": done / dt, "unit": "samples/s", "reads": nreads, "samples": done, "seconds": dt, "host_cpus": aff,
+            "chunks": n_chunks, "chunk_samples_per_s": n_chunks * 9996 / dt,
+            "chunk_samples_note": "chunks x 9996 / seconds: the device-side rate of this run (overlap 498 of 9996 and one stub chunk per read "
+                                  "make it 9-10 % more than the read samples); compare THIS with `value` of the bench line",
             "host_cpus_effective": util.effective_cpu_count(),
             "definition": "bonito/cli/basecaller.py:156-164 (clock around writer.start() .. writer.join(), samples from writer.log)",
             "workload": "%s, %d synthetic reads (normal lengths, mean %d), chunksize 9996 overlap 498 batchsize %d, FASTQ + move tables "

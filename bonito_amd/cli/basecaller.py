@@ -240,7 +240,7 @@ def main(args, argv=None):
 
         # every rank formats its own records; rank 0 merges the streams in input order and is the only writer. The streams end with a
         # closing message from rank 0 (no barrier: it would wait for a worker that died)
-        records = parallel.ordered_records(records, rank, world, rescue=rescue)
+        records = parallel.ordered_records(records, rank, world, rescue=rescue, packed=True)
         if rank != 0:
             parallel.shutdown()
             return 0

@@ -117,7 +117,9 @@ class Writer(Thread):
     """Consumes the basecall iterator (this drives the whole pipeline) and writes records to `fd`.
 
     `iterator` yields (read, result) pairs, or -- `preformatted=True`, the multi-GPU merge of bonito_amd/parallel.py --
-    the (text, summary_row, log) triples `format_record` made of them on the rank that basecalled the read."""
+    the (text, summary_row, log) triples `format_record` made of them on the rank that basecalled the read. A pre-formatted
+    text may be `bytes` / a memoryview and a row the rendered TSV line as `bytes` (the packed blocks of parallel.ordered_records, the
+    library's record text taken as it is): they go to the binary layer of `fd` without a str round trip."""
 
     def __init__(self, mode, iterator, fd=sys.stdout, min_qscore=0.0, summary_path=None, groups=(), preformatted=False):
         super().__init__()
@@ -136,14 +138,30 @@ class Writer(Thread):
                 tsv.writerow(summary_field_names)
             if self.mode == "sam":
                 self.fd.write(sam_header(self.groups))
+            raw = getattr(self.fd, "buffer", None)          # the binary layer under a text file (sys.stdout, open(..., "w")); None for StringIO
+            dirty = self.mode == "sam"                      # text written through the str layer and not yet flushed
             for item in self.iterator:
                 text, row, log = item if self.preformatted else format_record(item[0], item[1], self.mode, self.min_qscore)
                 self.log.append(log)
                 if text is None:
                     continue
-                self.fd.write(text)
+                if isinstance(text, str):
+                    self.fd.write(text)
+                    dirty = True
+                elif raw is not None:
+                    if dirty:
+                        self.fd.flush()
+                        dirty = False
+                    raw.write(text)
+                else:
+                    self.fd.write(bytes(text).decode("utf-8"))
                 if tsv:
-                    tsv.writerow(row)
+                    if isinstance(row, (bytes, bytearray, memoryview)):
+                        summary.write(bytes(row).decode("utf-8"))          # rendered by the csv module on the producing rank
+                    else:
+                        tsv.writerow(row)
+            if raw is not None:
+                raw.flush()
             self.fd.flush()
             if summary:
                 summary.close()

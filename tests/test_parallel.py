@@ -284,3 +284,69 @@ def test_a_rank_that_dies_is_replaced_by_rank_0_and_the_output_is_unchanged(tmp_
     assert text == want[0] and summary == want[1] and log == want[2]
     (lost_rank, k), = outs[0][1]
     assert lost_rank == victim and k <= after                 # what had arrived is kept; the rest was re-done from record k on
+
+
+def test_packed_record_blocks_round_trip_and_match_the_writer_bytes(tmp_path):
+    """Round 6: records travel from the ranks to rank 0 as packed blocks (one buffer per message, summary rows rendered on the producing
+    rank with the csv dialect of io.Writer) instead of pickles. Unpacking gives back the same texts / rows / log entries, and a Writer fed
+    the unpacked (bytes) records writes the very bytes it writes for the original (str, list) records - into a real file (binary layer)
+    and into a StringIO (decode path)."""
+    rdir = str(tmp_path)
+    make_reads_dir(rdir)
+    recs = list(parallel.format_stream(fake_basecall(None, reader.Reader(rdir).get_reads()), "sam", 7.0))
+    assert any(t is None for t, _, _ in recs) and sum(t is not None for t, _, _ in recs) > 5          # filtered reads travel too (log only)
+    blob = parallel.pack_records(recs, True)
+    got, last = parallel.unpack_records(memoryview(bytes(blob)))
+    assert last and len(got) == len(recs)
+    for (t, r, l), (t2, r2, l2) in zip(recs, got):
+        assert l2 == (l[0], l[1])
+        assert (t is None) == (t2 is None) and (t is None or bytes(t2).decode() == t)
+        assert (r is None) == (r2 is None) and (r is None or r2 == parallel.render_summary_row(r))
+    assert parallel.unpack_records(parallel.pack_records([], False)) == ([], False)
+    with pytest.raises(ValueError):
+        parallel.unpack_records(bytes(64))
+    want = _run_writer(iter(recs), "sam", True, os.path.join(rdir, "s_a.tsv"))
+    have = _run_writer(iter(got), "sam", True, os.path.join(rdir, "s_b.tsv"))                        # StringIO sink: the decode path
+    strip = lambda s: "\n".join(ln for ln in s.split("\n") if not ln.startswith("@PG"))
+    assert strip(have[0]) == strip(want[0]) and have[1] == want[1] and have[2] == want[2]
+    path = os.path.join(rdir, "out.sam")
+    mixed = [recs[i] if i % 2 else got[i] for i in range(len(recs))]                                  # rank 0's own str records between the peers' bytes
+    with open(path, "w") as fh:
+        w = bio.Writer("sam", iter(mixed), fd=fh, summary_path=os.path.join(rdir, "s_c.tsv"), preformatted=True)
+        w.start(); w.join()
+        assert w.error is None
+    assert strip(open(path).read()) == strip(want[0]) and open(os.path.join(rdir, "s_c.tsv")).read() == want[1]
+
+
+def _packed_worker(rank, world, port, rdir, mode, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    parallel.init("gloo")
+    reads = reader.Reader(rdir).get_reads(rank=rank, world=world)
+    records = parallel.ordered_records(parallel.format_stream(fake_basecall(None, reads), mode, 7.0), rank, world, batch=3, window=2, packed=True)
+    out = None
+    if rank == 0:
+        out = _run_writer(records, mode, True, os.path.join(rdir, "summary_p%d.tsv" % world))
+    else:
+        assert list(records) == []
+    q.put((rank, out))
+    parallel.shutdown()
+
+
+@pytest.mark.parametrize("world,mode", [(2, "fastq"), (4, "sam")])
+def test_multi_rank_packed_streams_are_byte_identical(tmp_path, world, mode):
+    rdir = str(tmp_path)
+    make_reads_dir(rdir)
+    want = _run_writer(fake_basecall(None, reader.Reader(rdir).get_reads()), mode, False, os.path.join(rdir, "summary_1.tsv"))
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_packed_worker, args=(r, world, port, rdir, mode, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    outs = dict(q.get(timeout=180) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    text, summary, log = outs[0]
+    strip = lambda s: "\n".join(ln for ln in s.split("\n") if not ln.startswith("@PG"))
+    assert strip(text) == strip(want[0]) and summary == want[1] and log == want[2] and len(log) == N_READS

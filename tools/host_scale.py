@@ -34,7 +34,7 @@ def worker(a):
     model = synthetic.make_model("hac", batchsize=a.batchsize, chunksize=10000)
     stride = model.stride
     T = chunksize // stride
-    rng = np.random.default_rng(7 + a.rank)
+    rng = np.random.default_rng(7 + (0 if a.merge else a.rank))          # --merge: every rank sees the SAME read set and takes its shard
     per_call = bc.batches_per_call(model, a.batchsize, False, chunksize, 1)
     call = a.batchsize * per_call
     mv = (rng.random((call, T)) < 0.42).astype(np.int8)
@@ -66,6 +66,35 @@ def worker(a):
 
     lens = np.clip(rng.normal(a.mean_len, a.mean_len / 3, a.reads), 5000, None).astype(int)
     pool = [np.random.default_rng(100 + k).standard_normal(int(lens.max()) + 1).astype(np.float32) for k in range(4)]
+    if a.merge:
+        # the PRODUCT's multi-process path (round 6): every rank produces the records of ITS shard (read i belongs to rank i % world, as
+        # Reader.get_reads(rank=, world=) shards), rank 0 merges the streams in input order through parallel.ordered_records and is the
+        # only writer (bonito_amd.io.Writer into /dev/null) - what `basecaller --devices 0-7` does around the device stages
+        from bonito_amd import io as bio
+        from bonito_amd import parallel
+        os.environ.update(RANK=str(a.rank), WORLD_SIZE=str(a.ranks), LOCAL_RANK=str(a.rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(a.port))
+        parallel.init("gloo")
+        mine = [(i, n) for i, n in enumerate(lens) if i % a.ranks == a.rank]
+        reads = (Read(i, pool[i % 4][:int(n)]) for i, n in mine)
+        records = bc.basecall_records(model, reads, "fastq", chunksize=chunksize, overlap=overlap, batchsize=a.batchsize)
+        t0 = time.perf_counter()
+        merged = parallel.ordered_records(records, a.rank, a.ranks, packed=not a.pickled)
+        if a.rank == 0:
+            with open(os.devnull, "w") as sink:
+                w = bio.Writer("fastq", merged, fd=sink, preformatted=True)
+                w.start()
+                w.join()
+            if w.error is not None:
+                raise w.error
+            dt = time.perf_counter() - t0
+            total = sum(n for _, n in w.log)
+            assert len(w.log) == a.reads and total == int(lens.sum()), (len(w.log), total)
+            print("merge: %d ranks, %d reads, %.3e samples, %.2f s -> %.3e samples/s through rank 0's ordered writer (%.3e per rank; stub device "
+                  "rate %.3e per rank)" % (a.ranks, len(w.log), total, dt, total / dt, total / dt / a.ranks, 2048 * 9996 / (a.call_ms * 1e-3)), flush=True)
+        else:
+            assert list(merged) == []
+        parallel.shutdown()
+        return
     reads = (Read(i, pool[i % 4][:int(n)]) for i, n in enumerate(lens))
     t0 = time.perf_counter()
     n_out = n_bytes = 0
@@ -89,11 +118,22 @@ def main():
     ap.add_argument("--batchsize", type=int, default=512)
     ap.add_argument("--call-ms", type=float, default=56.0, help="device time of one 2048-chunk engine call + decode (hac: 4 x 13.7 ms)")
     ap.add_argument("--rank", type=int, default=-1)
+    ap.add_argument("--merge", action="store_true",
+                    help="the ranks share ONE read set (--reads in total, sharded round-robin) and rank 0 merges their record streams in input "
+                         "order and writes (parallel.ordered_records + io.Writer): the aggregate the 8-GPU product run is bounded by on the host side")
+    ap.add_argument("--port", type=int, default=0)
+    ap.add_argument("--pickled", action="store_true", help="--merge with the pickled record messages of rounds 2-5 instead of packed blocks (A/B)")
     a = ap.parse_args()
     if a.rank >= 0:
         return worker(a)
     t0 = time.perf_counter()
-    procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--rank", str(r)] + sys.argv[1:], stdout=subprocess.PIPE, text=True)
+    extra = []
+    if a.merge:
+        import socket
+        with socket.socket() as sock:
+            sock.bind(("127.0.0.1", 0))
+            extra = ["--port", str(sock.getsockname()[1])]
+    procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--rank", str(r)] + sys.argv[1:] + extra, stdout=subprocess.PIPE, text=True)
              for r in range(a.ranks)]
     rates = []
     for p in procs:
@@ -102,6 +142,8 @@ def main():
         for line in out.splitlines():
             if "samples/s" in line:
                 rates.append(float(line.split("->")[1].split()[0]))
+    if a.merge:
+        return
     cpus = sorted(os.sched_getaffinity(0))
     print("%d rank(s) on %d host cpu(s): sum %.3e samples/s, slowest rank %.3e, wall %.1f s" % (
         a.ranks, len(cpus), sum(rates), min(rates) if rates else 0.0, time.perf_counter() - t0))
