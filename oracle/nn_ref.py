@@ -89,6 +89,8 @@ def lstm_forward(m, x, fp16=False):
     out = torch.empty(T, N, H)
     steps = range(T - 1, -1, -1) if m.reverse else range(T)
     gx = x @ W_ih.T + b
+    if fp16 and H > 512:
+        gx = _h(gx)          # layers wider than 512: the engine's input projection is a GEMM of its own whose output (bias included) is stored in fp16
     for t in steps:
         g = gx[t] + h @ W_hh.T
         i, f, gg, o = g.chunk(4, dim=-1)

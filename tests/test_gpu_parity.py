@@ -123,7 +123,9 @@ def test_end_to_end_identity_config5_lstm1024_graph_256x20000():
     # measured (round 6): paths and sequences identical, beam move table 0.844 (2 chunks) / 0.878 (4 chunks, the bench line): with 1024 states
     # and a random-weight head many alignments of the same sequence score within the fp16 error of each other
     _floors(res, viterbi_path_identity=0.995, viterbi_seq_identity=0.995, beam_seq_identity=0.995, moves_identity=0.72)
-    _precision_not_order(res, res16, between)
+    # (no `_precision_not_order` here: at 1024 hidden units the accumulation order of a 2048-long dot product weighs as much as the fp16
+    # storage - engine vs fp32 path 5.4e-4 mean, engine vs fp16-storage oracle 5.6e-4, the two oracles 5.1e-4 apart: all the same size)
+    assert res16["scores_mean_abs"] < 2 * res["scores_mean_abs"] and between["scores_mean_abs"] > 0.3 * res["scores_mean_abs"]
 
 
 def test_end_to_end_identity_config1_ctc_16x4000():
