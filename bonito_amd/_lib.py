@@ -79,6 +79,7 @@ SIGNATURES = {
     "bh_dwconv1d": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "bh_rotary_table": (_i, [_i, _i, _vp]),
     "bh_attention": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "bh_attention_prerotated": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "bh_rmsnorm_residual": (_i, [_vp, _vp, _vp, _vp, _l, _i, _f, _f, _vp]),
     "bh_lstm_pack_whh": (_i, [_vp, _i, _vp]),
     "bh_host_compact": (_l, [_vp, _l, _vp]),

@@ -14,6 +14,8 @@
 //   two cross-lane steps, and the normalised probabilities ARE the B fragment of O^T = V^T P^T -- no LDS
 //   round trip for P (the contraction order over keys is permuted identically in A and B).
 //   The whole visible key range is in registers (<= NT tiles), so the softmax is exact, not online.
+#include <type_traits>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -194,6 +196,7 @@ struct AttnRingArgs {
     half_t* out;         // [N*T][D]
     int N, T, H;
     int wl, wr;
+    int cpw;             // round-6 kernel: chunks per workgroup (its stream), pitch = T rounded up to 16
 };
 
 // WAVES = waves per workgroup = query tiles of 16 per block (8: blocks of 128 queries, the geometry of rounds 2-4; 12: blocks of 192 - the
@@ -372,6 +375,290 @@ __global__ __launch_bounds__(64 * WAVES) void attention_ring_kernel(AttnRingArgs
 }
 
 // ---------------------------------------------------------------------------------------------------
+// Round 6 rebuild of the ring kernel (review: 0.12 of the MFMA peak, 8.6 vector instructions per MFMA, waves waiting 49 % of their cycles).
+// Same ring, same S^T = K Q^T / O^T = V^T P^T formulation, same arithmetic per visible (query, key) pair; what changed:
+//  * every key tile of a wave is classified ONCE per block with scalar arithmetic - EMPTY (no query of the wave sees any of its keys:
+//    before the chunk, behind it, or outside the window), FULL (every query sees all 16 keys) or PARTIAL. Empty tiles cost nothing at all
+//    (no fragment reads, no MFMAs, no exponentials, their PV pair is skipped when both halves are empty), full tiles are never masked;
+//    only partial tiles pay the per-element compare (3 of 18 away from the chunk ends - the old kernel masked ALL tiles of every block
+//    that touched a chunk end: 3 of the 6 blocks at T = 1000). Waves whose 16 queries all lie behind the chunk skip the block's arithmetic.
+//  * V^T rows are 4 banks apart (row stride RING + 8 halves) and PERMUTED (vrow_of below): PV fragment reads and the transposing stores
+//    of the staging tasks are both conflict free (stride RING + 4, natural order: two-way conflicts on every fragment read, eight-way on
+//    every store). The staging tasks keep their coalesced (row pair, 16-byte piece) mapping.
+//  * ONE stream per workgroup (see STREAM below): no per-(chunk, head) prologue, no idle waves at a chunk's end.
+//  * the exponentials of a tile pair sit in front of that pair's PV MFMAs instead of in one block ahead of all of them.
+// EXPT (timing experiments only, wrong results on purpose; 0 in the product): bit 0 no exponentials, bit 1 no PV MFMAs, bit 2 no QK^T
+// MFMAs, bit 3 no staging after the prologue, bit 4 no barriers inside the block loop.
+constexpr int RVS2 = RING + 8;
+
+template <int WAVES, int EXPT>
+__global__ __launch_bounds__(64 * WAVES) void attention_ring2_kernel(AttnRingArgs p) {
+    constexpr int RQB = 16 * WAVES, NTHR = 64 * WAVES;
+    static_assert(272 + RQB <= RING && RQB % 16 == 0, "the block's live rows must fit the ring");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NT = 18;
+    char* kl = smem;                              // [RING][128 B] swizzled by slot & 7
+    half_t* vt = (half_t*)(smem + RING * 128);    // [64][RVS2]
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int D = p.H * HD;
+    const int g = lane >> 4;
+    // STREAM: this workgroup owns head h of the chunks [c0, c0 + nc) and treats them as ONE sequence of virtual rows, chunk i at rows
+    // [i P, i P + T), P = T rounded up to 16. The ring never restarts: the prologue is paid once per workgroup instead of once per
+    // (chunk, head) - 119 KB fetched with nothing to compute beside it, sixteen times per CU at 512 chunks - and the last block of a
+    // chunk carries the first queries of the next one instead of idle waves (1000 tokens = 5.2 blocks of 192). A query never sees rows of
+    // a neighbouring chunk: its visible range is clipped to [0, T) in CHUNK coordinates, and whatever the ring holds outside it is masked
+    // or skipped like any other invisible key. Eight consecutive workgroups (one per XCD) walk the eight heads of the same chunks at the
+    // same time, as before: a token's 3 KiB row is read by all of them while it is hot.
+    const int h = blockIdx.x;
+    const int c0 = blockIdx.y * p.cpw;
+    const int nc = min(p.cpw, p.N - c0);
+    const int P = (p.T + 15) & ~15;
+    const long L = (long)nc * P;                  // virtual rows of this workgroup's stream
+    const half_t* hb = p.qkv + h * HD;            // + (chunk * T + t) * 3 D [+ D | 2 D]
+
+    // virtual row (chunk index ci, local row t) + d rows further on -> chunk index and local row; d >= 0
+    auto advance = [&](int& ci, int& t, int d) {
+        t += d;
+        while (t >= P) { t -= P; ++ci; }
+    };
+    auto row_ptr = [&](int ci, int t) { return hb + ((long)(c0 + ci) * p.T + t) * 3 * D; };
+
+    // K task: 16-byte piece c of the key-row pair at (ci, t), (ci, t + 1) [t even: a pair never straddles a chunk]: eight consecutive lanes
+    // fetch one whole row (coalesced) and write eight distinct 16-byte slots of it (conflict free)
+    auto load_k = [&](bool live, int ci, int t, int c, uint4_t (&kv)[2]) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            kv[u] = uint4_t{0, 0, 0, 0};
+            if (live && ci < nc && t + u < p.T) kv[u] = *(const uint4_t*)(row_ptr(ci, t + u) + D + c * 8);
+        }
+    };
+    auto store_k = [&](int vrow, int c, const uint4_t (&kv)[2]) {
+        const int slot = vrow & (RING - 1);          // even; the pair never straddles the wrap
+#pragma unroll
+        for (int u = 0; u < 2; ++u) *(uint4_t*)(kl + (slot + u) * 128 + ((c ^ ((slot + u) & 7)) << 4)) = kv[u];
+    };
+    // V task: the same (pair, piece) mapping - a first version of this kernel walked consecutive pairs across the lanes to spread the
+    // transposing stores over the banks, and its sixteen-byte loads from 64 different rows per instruction cost 12 % of the kernel
+    // (0.78 -> 0.69 ms per 512 chunks back on the coalesced mapping, same box). The bank spread comes from the LAYOUT instead: feature d
+    // of V^T lives in row vrow_of(d) = (d & ~7) | ((d & 7) ^ (d >> 3)), rows RVS2 halves = 260 dwords = 4 banks apart. The eight stores
+    // of a task (rows 8 c + (e ^ c), eight lanes c = 0 .. 7 per pair) then fall on banks 4 (e ^ c) + pair: 32 distinct per half-wave;
+    // a PV fragment read (16 lanes i of an M tile: rows 16 mt + 8 (i >> 3) + ((i & 7) ^ (2 mt + (i >> 3)))) on 16 distinct groups of 4.
+    auto load_v = [&](bool live, int ci, int t, int c, uint4_t (&vv)[2]) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            vv[u] = uint4_t{0, 0, 0, 0};
+            if (live && ci < nc && t + u < p.T) vv[u] = *(const uint4_t*)(row_ptr(ci, t + u) + 2 * D + c * 8);
+        }
+    };
+    auto store_v = [&](int vrow, int c, const uint4_t (&vv)[2]) {
+        const int slot = vrow & (RING - 1);
+        const half8_t v0 = __builtin_bit_cast(half8_t, vv[0]), v1 = __builtin_bit_cast(half8_t, vv[1]);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const half2_t pr = {v0[e], v1[e]};
+            *(half2_t*)(vt + (c * 8 + (e ^ c)) * RVS2 + slot) = pr;          // row vrow_of(d = 8 c + e), see below
+        }
+    };
+
+    // ---- prologue (once per workgroup): virtual rows -128 .. RQB + 143 ((136 + RQB / 2) pairs x 8 pieces); rows < 0 are zeros --------
+    constexpr int PRO = 136 + RQB / 2;
+    for (int t = tid; t < PRO * 8; t += NTHR) {
+        uint4_t kv[2], vv[2];
+        {
+            const int vrow = -128 + 2 * (t >> 3);
+            int ci = 0, tt = 0;
+            if (vrow >= 0) advance(ci, tt, vrow);
+            load_k(vrow >= 0, ci, tt, t & 7, kv);
+            store_k(vrow, t & 7, kv);
+        }
+        {
+            const int vrow = -128 + 2 * (t >> 3);
+            int ci = 0, tt = 0;
+            if (vrow >= 0) advance(ci, tt, vrow);
+            load_v(vrow >= 0, ci, tt, t & 7, vv);
+            store_v(vrow, t & 7, vv);
+        }
+    }
+    const int nblk = (int)((L + RQB - 1) / RQB);
+    // this wave's 16 queries of block `blk` start at virtual row blk RQB + 16 wave = (chunk index qc, local row qt): all 16 in one chunk (P % 16 == 0)
+    auto load_q = [&](int qc, int qt, half8_t (&q)[2]) {
+        const int t = qt + (lane & 15);
+        q[0] = half8_t{0, 0, 0, 0, 0, 0, 0, 0};
+        q[1] = q[0];
+        if (qc < nc && t < p.T) {
+            const half_t* qp = row_ptr(qc, t);
+            q[0] = *(const half8_t*)(qp + g * 8);
+            q[1] = *(const half8_t*)(qp + 32 + g * 8);
+        }
+    };
+    half8_t qn[2];
+    int nqc = 0, nqt = 0;                         // (chunk index, local row) of this wave's first query in the NEXT block to run
+    advance(nqc, nqt, wave * 16);
+    load_q(nqc, nqt, qn);
+    int sc = 0, st = 0;                           // (chunk index, local row) of virtual row RQB + 144: the first row the next block adds
+    advance(sc, st, RQB + 144);
+    const char* kl_lane0 = kl + ((lane & 15) << 7) + ((g ^ (lane & 7)) << 4);
+    const char* kl_lane1 = kl + ((lane & 15) << 7) + (((g + 4) ^ (lane & 7)) << 4);
+    // V^T fragment rows of this lane for the four M tiles (feature d = 16 mt + (lane & 15) in its permuted row), + its column group
+    const half_t* vlane[4];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+        const int i = lane & 15;
+        vlane[mt] = vt + (16 * mt + 8 * (i >> 3) + ((i & 7) ^ ((2 * mt + (i >> 3)) & 7))) * RVS2 + g * 4;
+    }
+    for (int b = 0; b < nblk; ++b) {
+        const int v0 = __builtin_amdgcn_readfirstlane(b * RQB + wave * 16);          // virtual row of this wave's first query
+        const int qc = __builtin_amdgcn_readfirstlane(nqc), qi0 = __builtin_amdgcn_readfirstlane(nqt);      // its chunk and local row
+        const int qi = qi0 + (lane & 15);
+        const int n = c0 + qc;
+        half8_t qf[2] = {qn[0], qn[1]};
+        const bool more = b + 1 < nblk && !(EXPT & 8);
+        uint4_t nk[2], nv[2];
+        const int nfirst = b * RQB + RQB + 144;
+        // the global loads of the NEXT block (its queries, the RQB key / value rows it adds): requested now, consumed after this block
+        auto issue_next = [&]() {
+            if (b + 1 < nblk) {
+                advance(nqc, nqt, RQB);
+                nqc = __builtin_amdgcn_readfirstlane(nqc);          // (wave-uniform by construction: keep them on the scalar side)
+                nqt = __builtin_amdgcn_readfirstlane(nqt);
+                load_q(nqc, nqt, qn);
+            }
+            if (more) {
+                int ci = sc, tt = st;
+                advance(ci, tt, 2 * (tid >> 3));
+                load_k(true, ci, tt, tid & 7, nk);
+                load_v(true, ci, tt, tid & 7, nv);
+                advance(sc, st, RQB);
+                sc = __builtin_amdgcn_readfirstlane(sc);
+                st = __builtin_amdgcn_readfirstlane(st);
+            }
+        };
+        constexpr bool LATE = (EXPT & 32) != 0;      // (experiment) request them behind the QK^T phase instead of in front of the barrier
+        if (!LATE) issue_next();
+        if (!(EXPT & 16)) __syncthreads();        // ring rows of this block are in place
+
+        if (qc < nc && qi0 < p.T) {               // (wave-uniform) a wave behind the end of the stream has nothing to compute
+            const int kbase = qi0 - 128;          // local key of row 0 of this wave's tile 0; tile kt = keys kbase + 16 kt .. + 15
+            // keys seen by ANY query of the wave [ulo, uhi] and by EVERY query [ilo, ihi] (queries behind the chunk included: never stored)
+            const int ulo = max(qi0 - p.wl, 0), uhi = min(qi0 + 15 + p.wr, p.T - 1);
+            const int ilo = max(qi0 + 15 - p.wl, 0), ihi = min(qi0 + p.wr, p.T - 1);
+            const int k_first = max((ulo - kbase) >> 4, 0), k_last = min((uhi - kbase) >> 4, NT - 1);
+            const int f_first = max((ilo - kbase + 15) >> 4, 0), f_last = min((ihi - kbase - 15) >> 4, NT - 1);
+            const unsigned ne = k_first <= k_last ? ((2u << k_last) - 1u) & ~((1u << k_first) - 1u) : 0u;                 // non-empty tiles
+            const unsigned full = f_first <= f_last ? ((2u << f_last) - 1u) & ~((1u << f_first) - 1u) & ne : 0u;         // never masked
+            const int tile0 = __builtin_amdgcn_readfirstlane((v0 - 128) >> 4);      // ring tile of tile 0: VIRTUAL rows index the ring
+            const int kfirst = kbase + g * 4;     // this lane's first key of tile 0
+            const int lo = max(qi - p.wl, 0) - kfirst, hi = min(qi + p.wr, p.T - 1) - kfirst;
+            // The pattern of a wave away from the chunk ends under the reference's window (127, 128): its 16 queries see 271 keys = tiles
+            // 0 .. 16 (tile 17 is beyond every query's right edge), of which only the first and the last are partial. That case - 46 of the 63
+            // working wave-blocks of a 1000-token chunk - runs as straight-line code with compile-time tile predicates (the scheduler can
+            // then run fragment reads ahead of the MFMAs and MFMAs ahead of the vector work); every other case takes the same code with the
+            // predicates read from the two scalar masks (a branch per tile).
+            constexpr unsigned NE_STD = 0x1FFFFu, FULL_STD = 0x0FFFEu;
+            auto compute = [&](auto fast_tag) {
+                constexpr bool FAST = decltype(fast_tag)::value;
+                float4_t s[NT];
+                float m = -INFINITY;
+#pragma unroll
+                for (int kt = 0; kt < NT; ++kt) {
+                    if (FAST ? ((NE_STD >> kt) & 1u) != 0 : ((ne >> kt) & 1u) != 0) {
+                        float4_t acc = {0.f, 0.f, 0.f, 0.f};
+                        if (!(EXPT & 4)) {
+                            // (measured and dropped: requesting the fragments four tiles ahead through a rotating register buffer - 0.700 against
+                            //  0.690 ms per 512 chunks: the phase does not wait for its LDS reads)
+                            const int toff = ((tile0 + kt) & (RING / 16 - 1)) << 11;
+                            const half8_t a0 = *(const half8_t*)(kl_lane0 + toff);
+                            const half8_t a1 = *(const half8_t*)(kl_lane1 + toff);
+                            acc = mfma16(a0, qf[0], acc);
+                            acc = mfma16(a1, qf[1], acc);
+                        }
+                        if (FAST ? ((FULL_STD >> kt) & 1u) == 0 : ((full >> kt) & 1u) == 0) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const int rel = kt * 16 + e;
+                                acc[e] = (rel >= lo && rel <= hi) ? acc[e] : -INFINITY;
+                            }
+                        }
+                        s[kt] = acc;
+                        m = fmaxf(fmaxf(m, acc[0]), acc[1]);
+                        m = fmaxf(fmaxf(m, acc[2]), acc[3]);
+                    }
+                }
+                if (LATE) issue_next();
+                m = fmaxf(m, __shfl_xor(m, 16));
+                m = fmaxf(m, __shfl_xor(m, 32));
+                const float msafe = (m == -INFINITY) ? 0.0f : m;
+                typedef float f2_t __attribute__((ext_vector_type(2)));
+                const f2_t m2 = {msafe, msafe};
+                f2_t sum2 = {0.0f, 0.0f};
+                float4_t o[4];
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) o[mt] = float4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int c = 0; c < NT / 2; ++c) {
+                    if (FAST ? ((NE_STD >> (2 * c)) & 3u) != 0 : ((ne >> (2 * c)) & 3u) != 0) {
+                        float4_t pr[2];
+#pragma unroll
+                        for (int u = 0; u < 2; ++u) {
+                            const int kt = 2 * c + u;
+                            if (FAST ? ((NE_STD >> kt) & 1u) != 0 : ((ne >> kt) & 1u) != 0) {
+                                f2_t a = f2_t{s[kt][0], s[kt][1]} - m2, bb = f2_t{s[kt][2], s[kt][3]} - m2;
+                                if (!(EXPT & 1)) {
+                                    a.x = __builtin_amdgcn_exp2f(a.x); a.y = __builtin_amdgcn_exp2f(a.y);
+                                    bb.x = __builtin_amdgcn_exp2f(bb.x); bb.y = __builtin_amdgcn_exp2f(bb.y);
+                                }
+                                sum2 += a;
+                                sum2 += bb;
+                                pr[u] = float4_t{a.x, a.y, bb.x, bb.y};
+                            } else {
+                                pr[u] = float4_t{0.f, 0.f, 0.f, 0.f};
+                            }
+                        }
+                        const float8_t pf = {pr[0][0], pr[0][1], pr[0][2], pr[0][3], pr[1][0], pr[1][1], pr[1][2], pr[1][3]};
+                        const half8_t pb = __builtin_convertvector(pf, half8_t);
+                        if (!(EXPT & 2)) {
+                            const int u0 = ((tile0 + 2 * c) & (RING / 16 - 1)) << 4, u1 = ((tile0 + 2 * c + 1) & (RING / 16 - 1)) << 4;
+#pragma unroll
+                            for (int mt = 0; mt < 4; ++mt) {
+                                const half4_t va = *(const half4_t*)(vlane[mt] + u0);
+                                const half4_t vb = *(const half4_t*)(vlane[mt] + u1);
+                                const half8_t af = __builtin_shufflevector(va, vb, 0, 1, 2, 3, 4, 5, 6, 7);
+                                o[mt] = mfma16(af, pb, o[mt]);
+                            }
+                        } else {
+                            o[c & 3][0] += (float)pb[0] + (float)pb[5];
+                        }
+                    }
+                }
+                float sum = sum2.x + sum2.y;
+                sum += __shfl_xor(sum, 16);
+                sum += __shfl_xor(sum, 32);
+                const float inv = sum > 0.0f ? 1.0f / sum : 0.0f;
+                if (qi < p.T) {
+                    half_t* op = p.out + ((long)n * p.T + qi) * D + h * HD + g * 4;
+#pragma unroll
+                    for (int mt = 0; mt < 4; ++mt) {
+                        half4_t ov;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) ov[e] = (half_t)(o[mt][e] * inv);
+                        *(half4_t*)(op + mt * 16) = ov;
+                    }
+                }
+            };
+            if (ne == NE_STD && full == FULL_STD) compute(std::true_type{});
+            else compute(std::false_type{});
+        } else if (LATE) {
+            issue_next();
+        }
+        if (!(EXPT & 16)) __syncthreads();        // everybody is done with the rows the next block overwrites
+        if (more) {
+            store_k(nfirst + 2 * (tid >> 3), tid & 7, nk);
+            store_v(nfirst + 2 * (tid >> 3), tid & 7, nv);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // out[m][:] = rmsnorm(a[m][:] + alpha * x[m][:]) * w     (fp32 statistics, eps inside the sqrt)
 struct NormArgs {
     const half_t* a;
@@ -452,6 +739,8 @@ int bh_k_attention(const void* qkv, void* out, const float* cos_sin, int N, int 
 
 // q (already rotated and scaled) | k (already rotated) | v  ->  attention output; see attention_ring_kernel.
 int g_attn_waves = 0;      // bh_set_option("attn_waves", 0 | 8 | 12): 0 = automatic
+int g_attn_version = 2;    // bh_set_option("attn_version", 1 | 2): 1 = the ring kernel of rounds 2-5, 2 = its round-6 rebuild (default)
+int g_attn_expt = 0;       // bh_set_option("attn_expt", bits): timing experiments of the round-6 kernel (wrong results on purpose; 0 in the product)
 
 int bh_k_attention_prerotated(const void* qkv, void* out, int N, int T, int nhead, int head_dim, int win_left, int win_right,
                               hipStream_t stream) {
@@ -460,17 +749,48 @@ int bh_k_attention_prerotated(const void* qkv, void* out, int N, int T, int nhea
     BH_REQUIRE(win_left >= 0 && win_right >= 0 && win_left <= 128 && win_left + win_right <= 256,
                "attention (ring): window (%d, %d) outside the supported range", win_left, win_right);
     BH_REQUIRE(N > 0 && T > 0 && nhead > 0, "attention: empty problem");
-    AttnRingArgs a{(const half_t*)qkv, (half_t*)out, N, T, nhead, win_left, win_right};
-    const size_t lds = (size_t)RING * 128 + (size_t)64 * RVS * 2;
+    AttnRingArgs a{(const half_t*)qkv, (half_t*)out, N, T, nhead, win_left, win_right, 1};
     // twelve waves (blocks of 192 queries) where the chunk is long enough to fill them; "attn_waves" 8 / 12 forces a geometry
     const int waves = g_attn_waves == 8 || g_attn_waves == 12 ? g_attn_waves : (T >= 384 ? 12 : 8);
-    if (waves == 12) {
-        BH_CHECK_HIP(bh_max_lds((const void*)attention_ring_kernel<12>, (int)lds));
-        hipLaunchKernelGGL(attention_ring_kernel<12>, dim3(nhead, N), dim3(768), lds, stream, a);
-    } else {
-        BH_CHECK_HIP(bh_max_lds((const void*)attention_ring_kernel<8>, (int)lds));
-        hipLaunchKernelGGL(attention_ring_kernel<8>, dim3(nhead, N), dim3(512), lds, stream, a);
+    if (g_attn_version == 1) {
+        const size_t lds = (size_t)RING * 128 + (size_t)64 * RVS * 2;
+        if (waves == 12) {
+            BH_CHECK_HIP(bh_max_lds((const void*)attention_ring_kernel<12>, (int)lds));
+            hipLaunchKernelGGL(attention_ring_kernel<12>, dim3(nhead, N), dim3(768), lds, stream, a);
+        } else {
+            BH_CHECK_HIP(bh_max_lds((const void*)attention_ring_kernel<8>, (int)lds));
+            hipLaunchKernelGGL(attention_ring_kernel<8>, dim3(nhead, N), dim3(512), lds, stream, a);
+        }
+        BH_CHECK_HIP(hipGetLastError());
+        return 0;
     }
+    const size_t lds = (size_t)RING * 128 + (size_t)64 * RVS2 * 2;
+    // chunks per workgroup: one workgroup per CU and head-column (eight columns = the eight XCDs walk the same chunks together)
+    const int ncu = bh_cu_count() > 0 ? bh_cu_count() : 256;
+    const int cols = ncu / nhead > 0 ? ncu / nhead : 1;
+    a.cpw = (N + cols - 1) / cols;
+    const int groups = (N + a.cpw - 1) / a.cpw;
+#define BH_RING2(W, E)                                                                                          \
+    do {                                                                                                        \
+        BH_CHECK_HIP(bh_max_lds((const void*)attention_ring2_kernel<W, E>, (int)lds));                          \
+        hipLaunchKernelGGL((attention_ring2_kernel<W, E>), dim3(nhead, groups), dim3(64 * W), lds, stream, a);   \
+    } while (0)
+    if (waves == 8) BH_RING2(8, 0);
+    else if (g_attn_expt == 0) BH_RING2(12, 0);
+#ifdef BH_ATTN_EXPT
+    else if (g_attn_expt == 1) BH_RING2(12, 1);
+    else if (g_attn_expt == 2) BH_RING2(12, 2);
+    else if (g_attn_expt == 4) BH_RING2(12, 4);
+    else if (g_attn_expt == 7) BH_RING2(12, 7);
+    else if (g_attn_expt == 8) BH_RING2(12, 8);
+    else if (g_attn_expt == 16) BH_RING2(12, 16);
+    else if (g_attn_expt == 24) BH_RING2(12, 24);
+    else if (g_attn_expt == 31) BH_RING2(12, 31);
+    else if (g_attn_expt == 32) BH_RING2(12, 32);
+
+#endif
+    else BH_REQUIRE(false, "attention: timing experiment %d is not compiled into this library (BH_ATTN_EXPT)", g_attn_expt);
+#undef BH_RING2
     BH_CHECK_HIP(hipGetLastError());
     return 0;
 }

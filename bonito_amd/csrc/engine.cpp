@@ -1325,6 +1325,11 @@ extern "C" int bh_attention(const void* qkv, void* out, const float* cos_sin, in
     BH_REQUIRE(qkv && out && cos_sin, "attention: null pointer");
     return bh_k_attention(qkv, out, cos_sin, N, T, nhead, head_dim, win_left, win_right, (hipStream_t)stream);
 }
+extern "C" int bh_attention_prerotated(const void* qkv, void* out, int N, int T, int nhead, int head_dim, int win_left, int win_right,
+                                       void* stream) {
+    BH_REQUIRE(qkv && out, "attention_prerotated: null pointer");
+    return bh_k_attention_prerotated(qkv, out, N, T, nhead, head_dim, win_left, win_right, (hipStream_t)stream);
+}
 extern "C" int bh_rmsnorm_residual(const void* a, const void* x, const float* w, void* out, long M, int D, float alpha,
                                    float eps, void* stream) {
     BH_REQUIRE(a && x && w && out && M > 0, "rmsnorm_residual: bad arguments");
@@ -1484,6 +1489,8 @@ extern "C" int bh_set_option(const char* name, int value) {
     if (bh_k_lstm_set_option(name, value) == 0) return 0;
     if (!strcmp(name, "gemm_path")) { bh_k_linear_force_v1(value); return 0; }
     if (!strcmp(name, "attn_waves")) { extern int g_attn_waves; g_attn_waves = value; return 0; }
+    if (!strcmp(name, "attn_version")) { extern int g_attn_version; g_attn_version = value == 1 ? 1 : 2; return 0; }
+    if (!strcmp(name, "attn_expt")) { extern int g_attn_expt; g_attn_expt = value; return 0; }
     if (!strcmp(name, "gemm_stagger")) { bh_k_linear_stagger(value); return 0; }
     if (!strcmp(name, "lstm_q8_variant")) { g_q8_variant = value; return 0; }
     BH_REQUIRE(false, "set_option: unknown option '%s'", name);

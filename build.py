@@ -29,7 +29,8 @@ EXTRA_FLAGS = {"signal.hip": ["-ffp-contract=off"], "lstm_q8.hip": ["-ffp-contra
 # when BONITO_HIP_LIB names it (a stray environment variable used to produce a silently wrong libbonito_hip.so; review, round 3).
 # BH_EXTRA_GEMM_FLAGS (e.g. -DBH_GEMM_STATS: another GemmArgs layout + cycle stamps) is treated the same way (advisor, round 4: it used
 # to rebuild gemm.hip into the product object directory, and unsetting it did not rebuild - staleness is checked by mtime only).
-EXPERIMENT = bool(os.environ.get("BH_EXTRA_LSTM_FLAGS") or os.environ.get("BH_EXTRA_GEMM_FLAGS") or os.environ.get("BH_EXTRA_BEAM_FLAGS"))
+EXPERIMENT = bool(os.environ.get("BH_EXTRA_LSTM_FLAGS") or os.environ.get("BH_EXTRA_GEMM_FLAGS") or os.environ.get("BH_EXTRA_BEAM_FLAGS")
+                  or os.environ.get("BH_EXTRA_ATTN_FLAGS"))
 if EXPERIMENT:
     if os.environ.get("BH_EXTRA_LSTM_FLAGS"):
         EXTRA_FLAGS["lstm.hip"] = os.environ["BH_EXTRA_LSTM_FLAGS"].split()
@@ -37,9 +38,11 @@ if EXPERIMENT:
         EXTRA_FLAGS["gemm.hip"] = os.environ["BH_EXTRA_GEMM_FLAGS"].split()
     if os.environ.get("BH_EXTRA_BEAM_FLAGS"):
         EXTRA_FLAGS["beam.hip"] = os.environ["BH_EXTRA_BEAM_FLAGS"].split()
+    if os.environ.get("BH_EXTRA_ATTN_FLAGS"):          # e.g. -DBH_ATTN_EXPT: the elimination variants of attention_ring2_kernel (tools/attn_bench.py)
+        EXTRA_FLAGS["attention.hip"] = os.environ["BH_EXTRA_ATTN_FLAGS"].split()
     OBJ = os.path.join(ROOT, "build", "obj_expt")
     LIB = os.path.join(ROOT, "bonito_amd", "libbonito_hip_expt.so")
-    sys.stderr.write("build.py: BH_EXTRA_LSTM_FLAGS / BH_EXTRA_GEMM_FLAGS / BH_EXTRA_BEAM_FLAGS set -> experimental library %s (the product library is not touched)\n" % LIB)
+    sys.stderr.write("build.py: BH_EXTRA_LSTM_FLAGS / BH_EXTRA_GEMM_FLAGS / BH_EXTRA_BEAM_FLAGS / BH_EXTRA_ATTN_FLAGS set -> experimental library %s (the product library is not touched)\n" % LIB)
 
 
 def _newer(dst, srcs):

@@ -291,6 +291,10 @@ int bh_rotary_table(int T, int dim, float* out);
  * cos_sin = device copy of bh_rotary_table(T, head_dim). head_dim must be 64. */
 int bh_attention(const void* qkv, void* out, const float* cos_sin, int N, int T, int nhead, int head_dim,
                  int win_left, int win_right, void* stream);
+/* The same windowed attention on packed qkv whose q and k ALREADY carry the rotary embedding and whose q is scaled by log2(e) / sqrt(head_dim)
+ * (what the engine's Wqkv epilogue writes): the persistent ring-buffer kernel the engine runs for windows with left <= 128 and
+ * left + right <= 256 (flash_attn_qkvpacked_func proper, bonito/transformer/model.py:60; softmax in base 2 on pre-scaled scores). */
+int bh_attention_prerotated(const void* qkv, void* out, int N, int T, int nhead, int head_dim, int win_left, int win_right, void* stream);
 /* out = rmsnorm(a + alpha * x) * w (fp32 statistics): RMSNorm(x, residual) of bonito/transformer/model.py:110-111,125-128 */
 int bh_rmsnorm_residual(const void* a, const void* x, const float* w, void* out, long M, int D, float alpha,
                         float eps, void* stream);

@@ -304,6 +304,44 @@ def test_attention_matches_sdpa_restatement(T, H, win):
     assert d.max().item() < 8e-3, d.max().item()
 
 
+@pytest.mark.parametrize("N,T,H,win", [(2, 1000, 8, (127, 128)), (70, 333, 8, (127, 128)), (45, 200, 2, (40, 17)), (3, 17, 1, (127, 128)),
+                                       (33, 1000, 8, (128, 128)), (130, 400, 8, (0, 0)), (9, 1667, 8, (127, 128)), (65, 96, 4, (127, 128))])
+def test_ring_attention_on_prerotated_qkv_matches_a_device_restatement(N, T, H, win):
+    """bh_attention_prerotated = the persistent ring kernel the engine runs (round 6: ONE stream per workgroup - with more chunks than the
+    device has workgroup columns (256 CUs / heads) a workgroup walks several chunks back to back through one ring, tiles are classified
+    empty / full / partial per wave, V^T rows are permuted). Every output row against softmax(base-2 scores in the window) V computed by
+    torch on the device; both kernel versions (`attn_version` 1 = rounds 2-5, 2 = round 6) and both wave counts. The shapes put chunk
+    boundaries inside blocks of 192 / 128 queries (T = 333, 200, 96, 17), use other windows than the fast path's, and more chunks than
+    columns (N = 70, 130 at 8 heads -> 3 and 5 chunks per workgroup)."""
+    from bonito_amd import decode
+    D = 64 * H
+    g = torch.Generator(device=dev()).manual_seed(N * T + H)
+    qkv = (torch.randn(N * T, 3 * D, generator=g, device=dev()) * 0.7).half()
+    x = qkv.float().view(N, T, 3, H, 64)
+    q, k, v = (x[:, :, i].permute(0, 2, 1, 3) for i in range(3))
+    i = torch.arange(T, device=dev())[:, None]
+    j = torch.arange(T, device=dev())[None, :]
+    mask = (j >= i - win[0]) & (j <= i + win[1])
+    want = torch.empty((N, T, D), device=dev())
+    for lo in range(0, N, 16):                            # in slabs: the [N, H, T, T] score tensor of the big shapes would not fit
+        sc = (q[lo:lo + 16] @ k[lo:lo + 16].transpose(-1, -2)) * 0.6931471805599453          # q carries log2(e) / sqrt(d)
+        sc = sc.masked_fill(~mask, float("-inf"))
+        want[lo:lo + 16] = (torch.softmax(sc, -1) @ v[lo:lo + 16]).permute(0, 2, 1, 3).reshape(-1, T, D)
+    try:
+        for version, waves in ((2, 0), (2, 8), (2, 12), (1, 0)):
+            decode.set_option("attn_version", version)
+            decode.set_option("attn_waves", waves)
+            out = torch.full((N * T, D), float("nan"), dtype=torch.float16, device=dev())
+            _lib.check(_lib.lib().bh_attention_prerotated(_lib.ptr(qkv), _lib.ptr(out), N, T, H, 64, win[0], win[1], _lib.stream_ptr()),
+                       "attention_prerotated")
+            torch.cuda.synchronize()
+            d = (out.float().view(N, T, D) - want).abs()
+            assert not torch.isnan(d).any() and d.max().item() < 4e-3, (version, waves, d.max().item())
+    finally:
+        decode.set_option("attn_version", 2)
+        decode.set_option("attn_waves", 0)
+
+
 def test_rotary_table_matches_flash_attn_convention():
     tab = _rot_table(50)
     inv = 1.0 / (10000 ** (torch.arange(0, 64, 2).float() / 64))
