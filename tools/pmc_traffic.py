@@ -39,20 +39,28 @@ def main():
             fh.write(r[4] + "\n")
     table_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     table = json.load(open(table_path))
-    fetch = {r[0]: r[3] for r in rd}
-    write = {r[0]: r[3] for r in wr}
-    # the kernels a bench roofline can name: the recurrent kernels, fc1 (+ SwiGLU) of the transformer, the attention kernel
-    wanted = (r"(lstm_layer_\w+_kernel)", r"(gemm_w4_kernel)<0, true, 4, 0>", r"(attention_ring_kernel)")
+    fetch = {r[0]: (r[2], r[3]) for r in rd}
+    write = {r[0]: (r[2], r[3]) for r in wr}
+    # the kernels a bench roofline can name: the recurrent kernels, fc1 (+ SwiGLU) of the transformer, the attention kernel. Several template
+    # instances of one kernel (the last 8-bit recurrent layer also writes fp16 rows) are averaged over their launches.
+    wanted = (r"(lstm_layer_\w+_kernel)", r"(gemm_w4_kernel)<0, true, 4, 0>", r"(attention_ring2?_kernel)")
+    acc = {}
     for name in fetch:
         m = None
         for pat in wanted:
             m = m or re.search(pat, name)
         if not m or name not in write:
             continue
-        ent = {"workload": workload, "bytes_per_launch": int(round(1024 * (2 * fetch[name] + write[name]), -6)),
-               "kernel": name, "source": "profiles/%s_pmc_hbm_bytes.txt" % tag}
-        table["%s|%s" % (m.group(1), workload)] = ent
-        print(m.group(1), ent)
+        n = fetch[name][0]
+        ent = acc.setdefault(m.group(1), {"n": 0, "bytes": 0.0, "kernels": []})
+        ent["n"] += n
+        ent["bytes"] += n * 1024 * (2 * fetch[name][1] + write[name][1])
+        ent["kernels"].append(name)
+    for key, ent in acc.items():
+        out_ent = {"workload": workload, "bytes_per_launch": int(round(ent["bytes"] / ent["n"], -6)), "launches": ent["n"],
+                   "kernel": "; ".join(ent["kernels"]), "source": "profiles/%s_pmc_hbm_bytes.txt" % tag}
+        table["%s|%s" % (key, workload)] = out_ent
+        print(key, out_ent)
     with open(table_path, "w") as fh:
         json.dump(table, fh, indent=1)
         fh.write("\n")
