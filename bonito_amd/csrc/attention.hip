@@ -382,9 +382,9 @@ __global__ __launch_bounds__(64 * WAVES) void attention_ring_kernel(AttnRingArgs
 //    (no fragment reads, no MFMAs, no exponentials, their PV pair is skipped when both halves are empty), full tiles are never masked;
 //    only partial tiles pay the per-element compare (3 of 18 away from the chunk ends - the old kernel masked ALL tiles of every block
 //    that touched a chunk end: 3 of the 6 blocks at T = 1000). Waves whose 16 queries all lie behind the chunk skip the block's arithmetic.
-//  * V^T rows are 4 banks apart (row stride RING + 8 halves) and PERMUTED (vrow_of below): PV fragment reads and the transposing stores
-//    of the staging tasks are both conflict free (stride RING + 4, natural order: two-way conflicts on every fragment read, eight-way on
-//    every store). The staging tasks keep their coalesced (row pair, 16-byte piece) mapping.
+//  * V^T rows are 4 banks apart (row stride RING + 8 halves): the 16 rows x 2 column groups a ds_read_b64 half-wave touches fall on 32
+//    distinct bank pairs (stride RING + 4: two-way conflicts on every PV fragment read). The staging tasks keep their coalesced (row pair,
+//    16-byte piece) mapping (their transposing stores conflict eight ways - measured not to matter, see the V task below).
 //  * ONE stream per workgroup (see STREAM below): no per-(chunk, head) prologue, no idle waves at a chunk's end.
 //  * the exponentials of a tile pair sit in front of that pair's PV MFMAs instead of in one block ahead of all of them.
 // EXPT (timing experiments only, wrong results on purpose; 0 in the product): bit 0 no exponentials, bit 1 no PV MFMAs, bit 2 no QK^T
@@ -437,12 +437,10 @@ __global__ __launch_bounds__(64 * WAVES) void attention_ring2_kernel(AttnRingArg
 #pragma unroll
         for (int u = 0; u < 2; ++u) *(uint4_t*)(kl + (slot + u) * 128 + ((c ^ ((slot + u) & 7)) << 4)) = kv[u];
     };
-    // V task: the same (pair, piece) mapping - a first version of this kernel walked consecutive pairs across the lanes to spread the
-    // transposing stores over the banks, and its sixteen-byte loads from 64 different rows per instruction cost 12 % of the kernel
-    // (0.78 -> 0.69 ms per 512 chunks back on the coalesced mapping, same box). The bank spread comes from the LAYOUT instead: feature d
-    // of V^T lives in row vrow_of(d) = (d & ~7) | ((d & 7) ^ (d >> 3)), rows RVS2 halves = 260 dwords = 4 banks apart. The eight stores
-    // of a task (rows 8 c + (e ^ c), eight lanes c = 0 .. 7 per pair) then fall on banks 4 (e ^ c) + pair: 32 distinct per half-wave;
-    // a PV fragment read (16 lanes i of an M tile: rows 16 mt + 8 (i >> 3) + ((i & 7) ^ (2 mt + (i >> 3)))) on 16 distinct groups of 4.
+    // V task: the same (pair, piece) mapping. Measured on the way and dropped: (i) consecutive lanes on consecutive pairs (conflict-free
+    // transposing stores, but sixteen-byte loads from 64 different rows per instruction: 0.78 against 0.69 ms per 512 chunks); (ii) V^T
+    // rows permuted so that the coalesced tasks' stores are conflict free as well (the same 0.69: the stores' eight-way conflicts do not
+    // show, and the permutation costs the fragment reads their shared base - one address add per M tile instead of one per key-tile pair).
     auto load_v = [&](bool live, int ci, int t, int c, uint4_t (&vv)[2]) {
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
@@ -456,7 +454,7 @@ __global__ __launch_bounds__(64 * WAVES) void attention_ring2_kernel(AttnRingArg
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const half2_t pr = {v0[e], v1[e]};
-            *(half2_t*)(vt + (c * 8 + (e ^ c)) * RVS2 + slot) = pr;          // row vrow_of(d = 8 c + e), see below
+            *(half2_t*)(vt + (c * 8 + e) * RVS2 + slot) = pr;
         }
     };
 
@@ -499,13 +497,7 @@ __global__ __launch_bounds__(64 * WAVES) void attention_ring2_kernel(AttnRingArg
     advance(sc, st, RQB + 144);
     const char* kl_lane0 = kl + ((lane & 15) << 7) + ((g ^ (lane & 7)) << 4);
     const char* kl_lane1 = kl + ((lane & 15) << 7) + (((g + 4) ^ (lane & 7)) << 4);
-    // V^T fragment rows of this lane for the four M tiles (feature d = 16 mt + (lane & 15) in its permuted row), + its column group
-    const half_t* vlane[4];
-#pragma unroll
-    for (int mt = 0; mt < 4; ++mt) {
-        const int i = lane & 15;
-        vlane[mt] = vt + (16 * mt + 8 * (i >> 3) + ((i & 7) ^ ((2 * mt + (i >> 3)) & 7))) * RVS2 + g * 4;
-    }
+    const half_t* vlane = vt + (lane & 15) * RVS2 + g * 4;      // V^T fragment base of this lane: feature row lane & 15 (+ 16 mt: an immediate), column group g
     for (int b = 0; b < nblk; ++b) {
         const int v0 = __builtin_amdgcn_readfirstlane(b * RQB + wave * 16);          // virtual row of this wave's first query
         const int qc = __builtin_amdgcn_readfirstlane(nqc), qi0 = __builtin_amdgcn_readfirstlane(nqt);      // its chunk and local row
@@ -620,8 +612,8 @@ __global__ __launch_bounds__(64 * WAVES) void attention_ring2_kernel(AttnRingArg
                             const int u0 = ((tile0 + 2 * c) & (RING / 16 - 1)) << 4, u1 = ((tile0 + 2 * c + 1) & (RING / 16 - 1)) << 4;
 #pragma unroll
                             for (int mt = 0; mt < 4; ++mt) {
-                                const half4_t va = *(const half4_t*)(vlane[mt] + u0);
-                                const half4_t vb = *(const half4_t*)(vlane[mt] + u1);
+                                const half4_t va = *(const half4_t*)(vlane + mt * 16 * RVS2 + u0);
+                                const half4_t vb = *(const half4_t*)(vlane + mt * 16 * RVS2 + u1);
                                 const half8_t af = __builtin_shufflevector(va, vb, 0, 1, 2, 3, 4, 5, 6, 7);
                                 o[mt] = mfma16(af, pb, o[mt]);
                             }
