@@ -242,6 +242,23 @@ extern "C" long bh_host_format_read(const int8_t* const* base, const long* plane
 // i % 8 of byte i / 8 says whether value i takes one byte or two), then the data bytes, little-endian. value -> delta = (v >> 1) ^ -(v & 1),
 // sample_i = sample_{i-1} + delta (16-bit wrap-around, sample_{-1} = 0). Returns the bytes consumed, or -1 when the input is too short.
 // Replaces pod5's compiled decoder on the path /root/reference bonito/pod5.py:52 (`read.signal`); the wheel is absent here: FORMAT UNPINNED.
+namespace {
+// per key byte: the offsets of its eight values inside the group's data bytes, and the group's length - breaks the pointer chase of the
+// byte-at-a-time loop (eight independent loads per key byte; the running sum of the deltas is the only serial chain left)
+struct Svb16Tab {
+    uint8_t off[256][8];
+    uint8_t len[256];
+    Svb16Tab() {
+        for (int kb = 0; kb < 256; ++kb) {
+            int o = 0;
+            for (int j = 0; j < 8; ++j) { off[kb][j] = (uint8_t)o; o += 1 + ((kb >> j) & 1); }
+            len[kb] = (uint8_t)o;
+        }
+    }
+};
+const Svb16Tab g_svb16;
+}  // namespace
+
 extern "C" long bh_host_svb16_decode(const uint8_t* in, long n_in, long count, int16_t* out) {
     if (!in || !out || count < 0 || n_in < 0) return -1;
     const long nkeys = (count + 7) / 8;
@@ -250,7 +267,25 @@ extern "C" long bh_host_svb16_decode(const uint8_t* in, long n_in, long count, i
     const uint8_t* data = in + nkeys;
     const uint8_t* end = in + n_in;
     uint16_t prev = 0;
-    for (long i = 0; i < count; ++i) {
+    long i = 0;
+    // whole groups of eight while at least 16 data bytes remain (a group reads at most 16): table-driven, no pointer chase
+    for (; i + 8 <= count && data + 16 <= end; i += 8) {
+        const unsigned kb = keys[i >> 3];
+        const uint8_t* o = g_svb16.off[kb];
+        uint16_t v[8];
+        for (int j = 0; j < 8; ++j) {
+            const uint8_t* p = data + o[j];
+            const uint16_t two = (uint16_t)((kb >> j) & 1u);
+            v[j] = (uint16_t)(p[0] | (uint16_t)((p[1] & (uint8_t)(0u - two)) << 8));
+        }
+        data += g_svb16.len[kb];
+        for (int j = 0; j < 8; ++j) {
+            const uint16_t delta = (uint16_t)((v[j] >> 1) ^ (uint16_t)(0u - (v[j] & 1u)));
+            prev = (uint16_t)(prev + delta);
+            out[i + j] = (int16_t)prev;
+        }
+    }
+    for (; i < count; ++i) {                       // the tail (and inputs too short for the wide path): byte by byte, bounds checked
         const int two = (keys[i >> 3] >> (i & 7)) & 1;
         if (data + 1 + two > end) return -1;
         uint16_t v = data[0];

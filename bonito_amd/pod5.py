@@ -86,26 +86,30 @@ def parse_footer(buf):
 
 
 # ---- the signal codec --------------------------------------------------------------------------------------------------------------------
-def vbz_decode(block, count):
-    """One VBZ-compressed signal block -> int16[count]: zstd (pyarrow's binding), then streamvbyte-16 / zig-zag / first differences in the
-    host library (one pass, no interpreter loop; the library call drops the interpreter lock)."""
+def vbz_decode(block, count, out=None):
+    """One VBZ-compressed signal block -> int16[count] (written into `out` when given): zstd, then streamvbyte-16 / zig-zag / first
+    differences in the host library (a table-driven loop, 1 ns per sample; both library calls drop the interpreter lock)."""
     import ctypes as C
 
     import pyarrow as pa
 
     from bonito_amd import _lib
     count = int(count)
-    out = np.empty(count, np.int16)
+    if out is None:
+        out = np.empty(count, np.int16)
     if count == 0:
         return out
-    # an svb16 block of `count` values is at most ceil(count / 8) + 2 count bytes. libzstd itself (this image ships libzstd.so.1) needs no
-    # size up front; pyarrow's binding does, and gets the frame header's content size
+    # an svb16 block of `count` values is at most ceil(count / 8) + 2 count bytes (+ 16 so that the decoder's wide path may over-read).
+    # libzstd itself (this image ships libzstd.so.1) needs no size up front; pyarrow's binding does, and gets the frame header's content size
     bound = (count + 7) // 8 + 2 * count
-    raw = _zstd_decompress(bytes(block), bound)
+    raw, n = _zstd_decompress(block, bound + 16)
     if raw is None:
-        raw = pa.Codec("zstd").decompress(block, decompressed_size=_zstd_content_size(block, bound), asbytes=True)
-    src = np.frombuffer(raw, np.uint8)
-    used = _lib.lib().bh_host_svb16_decode(src.ctypes.data_as(C.c_void_p), len(src), count, out.ctypes.data_as(C.c_void_p))
+        data = pa.Codec("zstd").decompress(block, decompressed_size=_zstd_content_size(block, bound), asbytes=True)
+        src = np.frombuffer(data, np.uint8)
+        ptr, n = src.ctypes.data_as(C.c_void_p), len(src)
+    else:
+        ptr = C.cast(raw, C.c_void_p)
+    used = _lib.lib().bh_host_svb16_decode(ptr, n, count, out.ctypes.data_as(C.c_void_p))
     if used < 0:
         raise Pod5FormatError("VBZ block too short for %d samples" % count)
     return out
@@ -127,12 +131,15 @@ def _zstd_content_size(block, bound):
 
 
 _ZSTD = None
+_ZSTD_BUF = {}          # per thread: a reusable output buffer (grown on demand)
 
 
 def _zstd_decompress(data, bound):
-    """libzstd through ctypes where the shared object is on the box (this image: libzstd.so.1): no size needed up front."""
+    """libzstd through ctypes where the shared object is on the box (this image: libzstd.so.1): no size needed up front. Returns (a
+    ctypes buffer that stays valid until this thread's next call, bytes decompressed) or (None, 0) when the library is not there."""
     import ctypes as C
     import ctypes.util
+    import threading
     global _ZSTD
     if _ZSTD is None:
         name = ctypes.util.find_library("zstd")
@@ -146,12 +153,16 @@ def _zstd_decompress(data, bound):
             lib.ZSTD_isError.argtypes = [C.c_size_t]
             _ZSTD = lib
     if not _ZSTD:
-        return None
-    dst = C.create_string_buffer(bound)
-    n = _ZSTD.ZSTD_decompress(dst, bound, data, len(data))
+        return None, 0
+    tid = threading.get_ident()
+    dst = _ZSTD_BUF.get(tid)
+    if dst is None or len(dst) < bound:
+        dst = _ZSTD_BUF[tid] = C.create_string_buffer(max(bound, 1 << 18))
+    src = np.frombuffer(data, np.uint8)          # zero-copy view of the arrow buffer / bytes
+    n = _ZSTD.ZSTD_decompress(dst, len(dst), src.ctypes.data_as(C.c_void_p), len(src))
     if _ZSTD.ZSTD_isError(n):
         raise Pod5FormatError("zstd: corrupt signal block")
-    return dst.raw[:n]
+    return dst, int(n)
 
 
 def svb16_decode_numpy(raw, count):
@@ -270,7 +281,7 @@ class Reader:
             if isinstance(col, pa.ExtensionArray):
                 col = col.storage
             if pa.types.is_large_binary(col.type) or pa.types.is_binary(col.type):
-                out[pos:pos + n] = vbz_decode(col[k].as_buffer(), n)
+                vbz_decode(col[k].as_buffer(), n, out=out[pos:pos + n])
             else:                                               # uncompressed: list<int16>
                 out[pos:pos + n] = np.asarray(col[k].values.to_numpy(zero_copy_only=False), np.int16)[:n]
             pos += n
@@ -348,3 +359,4 @@ class Pod5Read:
     @property
     def signal_pa(self):
         return self.calibration.scale * (self.signal.astype(np.float32) + self.calibration.offset)
+
