@@ -98,7 +98,7 @@ def parse(argv=None):
                     help="timed regions per leg, each of exactly --steps steps; the median region is reported (default: as many as "
                          "give >= 16 engine calls per leg, between 1 and 5)")
     ap.add_argument("--parity-chunks", type=int, default=-1,
-                    help="chunks of the CPU-oracle sample (cpu_baseline + parity); default 64 for hac / fast, 2 for the sup models; 0 = none")
+                    help="chunks of the CPU-oracle sample (cpu_baseline + parity); default 128 for hac / fast, 2 for the sup models; 0 = none")
     ap.add_argument("--dry-run", action="store_true",
                     help="plumbing check without a device (tests/test_bench_cpu.py): ranks, rendezvous (gloo), barrier, MAX-reduce and the JSON "
                          "contract of an N-rank launch, with a sleep in place of the hot path; the line says \"data\": \"dry-run\" and is not a measurement")
@@ -224,7 +224,9 @@ def cpu_baseline_worker(name, chunk, decoder="beam", n=None, keep=None, extras=T
 
 
 def parity_chunks(name):
-    return 2 if name in ("sup", "sup_lstm") else 64
+    """Chunks of the CPU-oracle sample (cpu_baseline + parity) of a headline run: 128 x 10000 samples of hac are ~10 s of the GPU box's 16-core
+    quota for the timed fp32 pass (+ as much again, untimed, for the fp16-storage oracle and the decoder guard)."""
+    return 2 if name in ("sup", "sup_lstm") else 128
 
 
 def parity_input(n, chunk):
