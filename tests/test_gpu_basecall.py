@@ -594,7 +594,7 @@ def test_bench_default_mode_runs_and_reports_the_contract_fields():
     roof = d["roofline"]
     assert roof["kernel"] == "lstm_layer_wgx2_kernel<12,3>" and roof["bound"] == "mfma" and 0.1 < roof["frac"] < 1.0
     with open(os.path.join(root, "profiles", "pmc_traffic.json")) as fh:
-        pmc = json.load(fh)["lstm_layer_wgx2_kernel"]
+        pmc = json.load(fh)["lstm_layer_wgx2_kernel|hac 1024x10000"]          # round 6: keyed by kernel AND workload
     assert roof["flops_per_launch"] == pytest.approx(4.027e12, rel=1e-3) and roof["traffic"] == pmc["bytes_per_launch"]
     assert 2.6e9 < roof["traffic"] < 2.8e9 and roof["traffic_source"] == pmc["source"]      # 2.62 GB algorithmic
     assert d["with_h2d"]["value"] > 5e7 and d["value_with_h2d"] == d["with_h2d"]["value"] and d["batches_per_engine_call"] == 4
