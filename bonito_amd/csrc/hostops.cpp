@@ -269,7 +269,7 @@ extern "C" long bh_host_svb16_decode(const uint8_t* in, long n_in, long count, i
     uint16_t prev = 0;
     long i = 0;
     // whole groups of eight while at least 16 data bytes remain (a group reads at most 16): table-driven, no pointer chase
-    for (; i + 8 <= count && data + 16 <= end; i += 8) {
+    for (; i + 8 <= count && end - data >= 16; i += 8) {
         const unsigned kb = keys[i >> 3];
         const uint8_t* o = g_svb16.off[kb];
         uint16_t v[8];
