@@ -537,6 +537,18 @@ __global__ __launch_bounds__(512, 1) void gemm_big_kernel(GemmArgs p) {
 #define BH_GEMM_KTILE_INC "gemm_ktile_mfma.inc"      // (tools/gemm_lab.hip builds the kernel around other variants of the stream)
 #endif
 #include BH_GEMM_KTILE_INC
+// The same K-tile on v_mfma_f32_16x16x32_f16 (round 6, gemm_w4_kernel<..., T16 = true>; tools/gen_gemmstep.py --tile16). Under the board's
+// power cap the small tile is the cheaper instruction: a hand-scheduled 128 x 128 wave tile fed from LDS runs 1775 TFLOP/s on it against 1556
+// on 32x32x16 (tools/gen_tile_probe.py, profiles/r06_mfma_tile_energy_lds.txt). What changes around the stream: the accumulators are 64
+// float4 (acc[i][j]: token tile i, feature tile j; lane (g = l >> 4, col = l & 15) holds features 16 j + 4 g .. + 3 of token 16 i + col), the W
+// rows are staged in NATURAL order (a lane's four accumulator registers are four consecutive features by themselves), fragment reads take
+// rows l & 15 of a 16-row tile (immediate offset 2048 per tile) and chunk 4 s + (l >> 4) of slab s under the same XOR swizzle (every 16-lane
+// group of the ds_read_b128 still touches sixteen distinct slots), and the epilogue writes its transposition scratch from that layout - the
+// scratch image, and everything behind it, is the same.
+#ifndef BH_GEMM_KTILE16_INC
+#define BH_GEMM_KTILE16_INC "gemm_ktile16_mfma.inc"
+#endif
+#include BH_GEMM_KTILE16_INC
 
 constexpr int W4_OP = 32768, W4_BRING = 3 * W4_OP, W4_LDS = 5 * W4_OP;     // A ring: three 32 KiB stages, B ring: two
 
@@ -545,6 +557,7 @@ __device__ __forceinline__ void w4_dma(unsigned m0v, unsigned voff, const char* 
 }
 
 // per-lane byte offsets of this wave's eight DMA pieces of each operand for the output tile (f0, t0): va = X (tokens, MFMA A), vb = W (features, B)
+template <bool T16 = false>
 __device__ __forceinline__ void w4_offsets(const GemmArgs& p, int f0, int t0, int wave, int lane, unsigned (&va)[8], unsigned (&vb)[8]) {
     const int lr = lane >> 3, slot = lane & 7;
 #pragma unroll
@@ -555,7 +568,8 @@ __device__ __forceinline__ void w4_offsets(const GemmArgs& p, int f0, int t0, in
         // feature 128 (R >> 7) + 64 (j >> 1) + 32 ((rho >> 2) & 1) + 16 (j & 1) + 4 (rho >> 3) + (rho & 3): accumulator register r of lane
         // half h is tile row (r & 3) + 8 (r >> 2) + 4 h, so the lane holds the 32 CONSECUTIVE features 32 h + 16 (j & 1) + r of the pair
         const int rho = R & 31, j = (R >> 5) & 3;
-        const int feat = f0 + (R >> 7) * 128 + (j >> 1) * 64 + 32 * ((rho >> 2) & 1) + 16 * (j & 1) + 4 * (rho >> 3) + (rho & 3);
+        // (T16: natural order - see the note at the include of the 16x16x32 stream)
+        const int feat = T16 ? f0 + R : f0 + (R >> 7) * 128 + (j >> 1) * 64 + 32 * ((rho >> 2) & 1) + 16 * (j & 1) + 4 * (rho >> 3) + (rho & 3);
         va[n] = (unsigned)min(t0 + R, p.M - 1) * (unsigned)(p.ldx * 2) + chunk * 16;
         vb[n] = (unsigned)min(feat, p.N - 1) * (unsigned)(p.ldw * 2) + chunk * 16;
     }
@@ -593,9 +607,12 @@ struct W4Store {
 
 // MODE (compile time, so that the block loop is straight-line code the compiler can software-pipeline; with run-time flags every
 // `if` inside it was a join with full s_waitcnt's: 9.5 k cycles per tile whatever the stores did): 1 = residual, 2 = rotary, 4 = scale / clamp
-template <int ACT, bool GATED, int MODE, typename PARK>
-__device__ __forceinline__ bool w4_epilogue(const GemmArgs& p, float16_t (&acc)[4][4], int f0, int t0, int wa, int wb, int lane, char* scratch,
-                                            PARK (&park)[W4_NPARK], W4Store& st) {
+template <int ACT, bool GATED, int MODE, typename ACC, typename PARK, int NP>
+__device__ __forceinline__ bool w4_epilogue(const GemmArgs& p, ACC& acc, int f0, int t0, int wa, int wb, int lane, char* scratch,
+                                            PARK (&park)[NP], W4Store& st) {
+    constexpr bool T16 = std::is_same_v<ACC, float4_t[8][8]>;       // the accumulator layout of the 16x16x32 stream
+    constexpr int NOW = 32 - NP;                                    // rows stored here; the other NP are parked (W4_NPARK / W4_NPARK16)
+    static_assert(NP == (T16 ? W4_NPARK16 : W4_NPARK) && NOW % 4 == 0, "parked rows: the split the K-tile streams were generated for");
     asm volatile("" : "+v"(lane));      // opaque: the lane constants below are recomputed per tile instead of living in registers through the K loop
     const int h = lane >> 5, col = lane & 31;
     const int tl = lane >> 3, q = lane & 7;
@@ -635,18 +652,32 @@ __device__ __forceinline__ bool w4_epilogue(const GemmArgs& p, float16_t (&acc)[
     const float* const cs0 = p.rot_cs + (q & 3) * 16;
     char* const wrow = scratch + col * 256;
     const int wx = col & 15;
-    auto write_block = [&](const float16_t& a0, const float16_t& a1) {          // the lane's 32 features of one token: tiles j = 2 P, 2 P + 1
+    auto write_block = [&](int b) {           // block b = (32 tokens i = b >> 1, feature pair P = b & 1) into the scratch
+        if constexpr (T16) {
+            // lane (g = l >> 4, c16 = l & 15): piece 4 jj + g (features 16 jj + 4 g .. + 3 of the pair) of token 16 tt + c16; an 8-lane group of
+            // the ds_write_b128 is eight tokens x one piece = eight positions piece ^ token: conflict free like the 32x32 layout's
+            const int g = lane >> 4, c16 = lane & 15;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const float4_t v0 = {a0[4 * c], a0[4 * c + 1], a0[4 * c + 2], a0[4 * c + 3]};
-            const float4_t v1 = {a1[4 * c], a1[4 * c + 1], a1[4 * c + 2], a1[4 * c + 3]};
-            *(float4_t*)(wrow + (((8 * h + c) ^ wx) << 4)) = v0;
-            *(float4_t*)(wrow + (((8 * h + 4 + c) ^ wx) << 4)) = v1;
+            for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj)
+                    *(float4_t*)(scratch + (16 * tt + c16) * 256 + (((4 * jj + g) ^ c16) << 4)) = acc[2 * (b >> 1) + tt][4 * (b & 1) + jj];
+        } else {
+            // the lane's 32 features of one token: tiles j = 2 P, 2 P + 1
+            const float16_t& a0 = acc[b >> 1][2 * (b & 1)];
+            const float16_t& a1 = acc[b >> 1][2 * (b & 1) + 1];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const float4_t v0 = {a0[4 * c], a0[4 * c + 1], a0[4 * c + 2], a0[4 * c + 3]};
+                const float4_t v1 = {a1[4 * c], a1[4 * c + 1], a1[4 * c + 2], a1[4 * c + 3]};
+                *(float4_t*)(wrow + (((8 * h + c) ^ wx) << 4)) = v0;
+                *(float4_t*)(wrow + (((8 * h + 4 + c) ^ wx) << 4)) = v1;
+            }
         }
     };
     auto blocks = [&](auto masked) {
         constexpr bool MASKED = decltype(masked)::value;
-        write_block(acc[0][0], acc[0][1]);
+        write_block(0);
 #pragma unroll
         for (int b = 0; b < 8; ++b) {
             const int i = b >> 1, P = b & 1;                // token tile, feature pair
@@ -666,7 +697,7 @@ __device__ __forceinline__ bool w4_epilogue(const GemmArgs& p, float16_t (&acc)[
                         rres[rr] = __builtin_amdgcn_raw_buffer_load_b128(rrsrc, rvoff + P * 128, (32 * i + 8 * rr) * resbytes, 0);
                 }
             }
-            if (b + 1 < 8) write_block(acc[(b + 1) >> 1][2 * ((b + 1) & 1)], acc[(b + 1) >> 1][2 * ((b + 1) & 1) + 1]);
+            if (b + 1 < 8) write_block(b + 1);
             const bool rot_here = rot && fw + P * 64 < p.rot_nfeat;
             const float rqs = fw + P * 64 < p.rot_qfeat ? p.rot_qscale : 1.0f;
 #pragma unroll
@@ -705,8 +736,8 @@ __device__ __forceinline__ bool w4_epilogue(const GemmArgs& p, float16_t (&acc)[
 #pragma unroll
                     for (int k = 0; k < 4; ++k) y[k] = v[2 * k] * swishf_(v[2 * k + 1]);
                     const uint2_t o2 = __builtin_bit_cast(uint2_t, __builtin_convertvector(y, half4_t));
-                    if constexpr (!MASKED) { if (4 * b + rr >= W4_NOW) park[4 * b + rr - W4_NOW] = o2; }
-                    if ((!MASKED && 4 * b + rr < W4_NOW) || (MASKED && live)) __builtin_amdgcn_raw_buffer_store_b64(o2, orsrc, vo + P * 64 + (32 * i + 8 * rr) * rowbytes, 0, 0);
+                    if constexpr (!MASKED) { if (4 * b + rr >= NOW) park[4 * b + rr - NOW] = o2; }
+                    if ((!MASKED && 4 * b + rr < NOW) || (MASKED && live)) __builtin_amdgcn_raw_buffer_store_b64(o2, orsrc, vo + P * 64 + (32 * i + 8 * rr) * rowbytes, 0, 0);
                 } else {
                     float8_t f8;
 #pragma unroll
@@ -716,8 +747,8 @@ __device__ __forceinline__ bool w4_epilogue(const GemmArgs& p, float16_t (&acc)[
                         for (int e = 0; e < 8; ++e) f8[e] = fminf(fmaxf(f8[e] * p.scale, p.clamp_lo), p.clamp_hi);
                     }
                     const uint4_t o4 = __builtin_bit_cast(uint4_t, __builtin_convertvector(f8, half8_t));
-                    if constexpr (!MASKED) { if (4 * b + rr >= W4_NOW) park[4 * b + rr - W4_NOW] = o4; }
-                    if ((!MASKED && 4 * b + rr < W4_NOW) || (MASKED && live)) __builtin_amdgcn_raw_buffer_store_b128(o4, orsrc, vo + P * 128 + (32 * i + 8 * rr) * rowbytes, 0, 0);
+                    if constexpr (!MASKED) { if (4 * b + rr >= NOW) park[4 * b + rr - NOW] = o4; }
+                    if ((!MASKED && 4 * b + rr < NOW) || (MASKED && live)) __builtin_amdgcn_raw_buffer_store_b128(o4, orsrc, vo + P * 128 + (32 * i + 8 * rr) * rowbytes, 0, 0);
                 }
             }
         }
@@ -728,14 +759,15 @@ __device__ __forceinline__ bool w4_epilogue(const GemmArgs& p, float16_t (&acc)[
 }
 
 // the parked rows of a tile that no K loop follows
-template <bool GATED, typename PARK>
-__device__ __forceinline__ void w4_store_parked(const PARK (&park)[W4_NPARK], const W4Store& st) {
+template <bool GATED, bool T16, typename PARK, int NP>
+__device__ __forceinline__ void w4_store_parked(const PARK (&park)[NP], const W4Store& st) {
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
         (void*)(((unsigned long long)st.srd[1] << 32) | st.srd[0]), 0, 0x7ffffff0, 0x00020000);
 #pragma unroll
-    for (int idx = 0; idx < W4_NPARK; ++idx) {
-        if constexpr (GATED) __builtin_amdgcn_raw_buffer_store_b64(park[idx], rsrc, st.voff + w4_store_col(idx) * 64 + w4_store_row(idx) * st.rowb, 0, 0);
-        else __builtin_amdgcn_raw_buffer_store_b128(park[idx], rsrc, st.voff + w4_store_col(idx) * 128 + w4_store_row(idx) * st.rowb, 0, 0);
+    for (int idx = 0; idx < NP; ++idx) {
+        const int row = T16 ? w4_store_row16(idx) : w4_store_row(idx), col = T16 ? w4_store_col16(idx) : w4_store_col(idx);
+        if constexpr (GATED) __builtin_amdgcn_raw_buffer_store_b64(park[idx], rsrc, st.voff + col * 64 + row * st.rowb, 0, 0);
+        else __builtin_amdgcn_raw_buffer_store_b128(park[idx], rsrc, st.voff + col * 128 + row * st.rowb, 0, 0);
     }
 }
 
@@ -743,7 +775,7 @@ __device__ __forceinline__ void w4_store_parked(const PARK (&park)[W4_NPARK], co
 template <int IDX0, int S, bool WIDE, bool FIRST, typename PARK>
 __device__ __forceinline__ void w4_inst_st(float16_t (&acc)[4][4], half8_t (&fa)[2][4], half8_t (&fb)[2][4], const unsigned (&rab)[4],
                                            const unsigned (&rbb)[4], unsigned sa, unsigned sb, unsigned san, unsigned sbn, const unsigned (&vd1)[8],
-                                           const unsigned (&vd2)[8], const char* sd1, const char* sd2, unsigned md1, unsigned md2,
+                                           const unsigned (&vd2)[8], const char* sd1, const char* sd2, unsigned md1, unsigned md2, unsigned,
                                            const PARK (&park)[W4_NPARK], const W4Store& st) {
     if constexpr (S == 4 && WIDE && !FIRST) gemm_ktile_st4w<IDX0>(acc, fa, fb, rab, rbb, sa, sb, san, sbn, vd1, vd2, sd1, sd2, md1, md2, park, st.srd, st.voff, st.rowb);
     else if constexpr (S == 4 && WIDE && FIRST) gemm_ktile_first_st4w<IDX0>(acc, fa, fb, rab, rbb, sa, sb, san, sbn, vd1, vd2, sd1, sd2, md1, md2, park, st.srd, st.voff, st.rowb);
@@ -752,7 +784,45 @@ __device__ __forceinline__ void w4_inst_st(float16_t (&acc)[4][4], half8_t (&fa)
     else static_assert(S == 4, "tools/gen_gemmstep.py emits the four-stores-per-instance variants only");
 }
 
-template <int ACT, bool GATED, int S, int MODE>       // S: parked output rows per K-tile instance; MODE: w4_epilogue
+template <int IDX0, int S, bool WIDE, bool FIRST, typename PARK>
+__device__ __forceinline__ void w4_inst_st(float4_t (&acc)[8][8], half8_t (&fa)[8], half8_t (&fb)[2][8], const unsigned (&rab)[2],
+                                           const unsigned (&rbb)[2], unsigned sa, unsigned sb, unsigned san, unsigned sbn, const unsigned (&vd1)[8],
+                                           const unsigned (&vd2)[8], const char* sd1, const char* sd2, unsigned md1, unsigned md2, unsigned wv,
+                                           const PARK (&park)[W4_NPARK16], const W4Store& st) {
+    if constexpr (S == 4 && WIDE && !FIRST) gemm_ktile16_st4w<IDX0>(acc, fa, fb, rab, rbb, sa, sb, san, sbn, vd1, vd2, sd1, sd2, md1, md2, wv, park, st.srd, st.voff, st.rowb);
+    else if constexpr (S == 4 && WIDE && FIRST) gemm_ktile16_first_st4w<IDX0>(acc, fa, fb, rab, rbb, sa, sb, san, sbn, vd1, vd2, sd1, sd2, md1, md2, wv, park, st.srd, st.voff, st.rowb);
+    else if constexpr (S == 4 && !WIDE && !FIRST) gemm_ktile16_st4n<IDX0>(acc, fa, fb, rab, rbb, sa, sb, san, sbn, vd1, vd2, sd1, sd2, md1, md2, wv, park, st.srd, st.voff, st.rowb);
+    else if constexpr (S == 4 && !WIDE && FIRST) gemm_ktile16_first_st4n<IDX0>(acc, fa, fb, rab, rbb, sa, sb, san, sbn, vd1, vd2, sd1, sd2, md1, md2, wv, park, st.srd, st.voff, st.rowb);
+    else static_assert(S == 4, "tools/gen_gemmstep.py emits the four-stores-per-instance variants only");
+}
+
+// MFMA result -> vector ALU: the streams end on an MFMA and pad nothing (16 wait states in front of the epilogue's first accumulator read)
+__device__ __forceinline__ void w4_settle(float16_t (&acc)[4][4]) {
+    asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3"
+                 : "+a"(acc[0][0]), "+a"(acc[0][1]), "+a"(acc[0][2]), "+a"(acc[0][3]), "+a"(acc[1][0]), "+a"(acc[1][1]), "+a"(acc[1][2]),
+                   "+a"(acc[1][3]), "+a"(acc[2][0]), "+a"(acc[2][1]), "+a"(acc[2][2]), "+a"(acc[2][3]), "+a"(acc[3][0]), "+a"(acc[3][1]),
+                   "+a"(acc[3][2]), "+a"(acc[3][3]));
+}
+__device__ __forceinline__ void w4_settle(float4_t (&acc)[8][8]) {
+#define W4_ROW(i) "+a"(acc[i][0]), "+a"(acc[i][1]), "+a"(acc[i][2]), "+a"(acc[i][3]), "+a"(acc[i][4]), "+a"(acc[i][5]), "+a"(acc[i][6]), "+a"(acc[i][7])
+    asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" : W4_ROW(0), W4_ROW(1), W4_ROW(2), W4_ROW(3), W4_ROW(4), W4_ROW(5), W4_ROW(6), W4_ROW(7));
+#undef W4_ROW
+}
+__device__ __forceinline__ void w4_ktile(float16_t (&acc)[4][4], half8_t (&fa)[2][4], half8_t (&fb)[2][4], const unsigned (&rab)[4], const unsigned (&rbb)[4],
+                                         unsigned sa, unsigned sb, unsigned san, unsigned sbn, const unsigned (&vd1)[8], const unsigned (&vd2)[8],
+                                         const char* sd1, const char* sd2, unsigned md1, unsigned md2, unsigned, bool first) {
+    if (first) gemm_ktile_first(acc, fa, fb, rab, rbb, sa, sb, san, sbn, vd1, vd2, sd1, sd2, md1, md2);
+    else gemm_ktile(acc, fa, fb, rab, rbb, sa, sb, san, sbn, vd1, vd2, sd1, sd2, md1, md2);
+}
+__device__ __forceinline__ void w4_ktile(float4_t (&acc)[8][8], half8_t (&fa)[8], half8_t (&fb)[2][8], const unsigned (&rab)[2], const unsigned (&rbb)[2],
+                                         unsigned sa, unsigned sb, unsigned san, unsigned sbn, const unsigned (&vd1)[8], const unsigned (&vd2)[8],
+                                         const char* sd1, const char* sd2, unsigned md1, unsigned md2, unsigned wv, bool first) {
+    if (first) gemm_ktile16_first(acc, fa, fb, rab, rbb, sa, sb, san, sbn, vd1, vd2, sd1, sd2, md1, md2, wv);
+    else gemm_ktile16(acc, fa, fb, rab, rbb, sa, sb, san, sbn, vd1, vd2, sd1, sd2, md1, md2, wv);
+}
+
+// S: parked output rows per K-tile instance; MODE: w4_epilogue; T16: the K-tile stream on 16x16x32 MFMAs (gemm_ktile16_mfma.inc)
+template <int ACT, bool GATED, int S, int MODE, bool T16 = false>
 __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];   // [stage][X tile 32K | W tile 32K] x 2 (addressed by offset only)
     const int tid = threadIdx.x;
@@ -763,8 +833,17 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(GemmArgs p) {
 
     // fragment read addresses: rows l & 31 of tile i (immediate offset i * 4096), chunk (2 ks + (l >> 5)) ^ ((row >> 1) & 7); the stage
     // offsets (A ring: three stages from LDS 0, B ring: two from W4_BRING) are scalars added inside the stream
-    unsigned rab[4], rbb[4];
-    {
+    // (T16: rows l & 15 of tile i (immediate offset i * 2048), chunk 4 s + (l >> 4) of slab s)
+    unsigned rab[T16 ? 2 : 4], rbb[T16 ? 2 : 4];
+    if constexpr (T16) {
+        const int row = lane & 15, kg = lane >> 4, g = (row >> 1) & 7;
+#pragma unroll
+        for (int sl = 0; sl < 2; ++sl) {
+            const unsigned off = (unsigned)(row * 128 + (((4 * sl + kg) ^ g) << 4));
+            rab[sl] = wa * 16384 + off;
+            rbb[sl] = wb * 16384 + off;
+        }
+    } else {
         const int row = lane & 31, hh = lane >> 5, g = (row >> 1) & 7;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
@@ -815,7 +894,7 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(GemmArgs p) {
         while (__builtin_readcyclecounter() < until) __builtin_amdgcn_s_sleep(32);
     }
     unsigned va[8], vb[8];
-    w4_offsets(p, f0, t0, wave, lane, va, vb);
+    w4_offsets<T16>(p, f0, t0, wave, lane, va, vb);
 
     // prologue: K-tiles 0 and 1 of both operands; fragments of k-step 0 of K-tile 0
     unsigned a0 = 0, a1 = W4_OP, a2 = 2 * W4_OP;             // A stage offsets of K-tiles G, G + 1, G + 2 (rotating)
@@ -829,7 +908,20 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(GemmArgs p) {
 #pragma unroll
     for (int n = 0; n < 8; ++n) w4_dma(b1 + wdma + n * 1024, vb[n], Bb + 128);
     asm volatile("s_waitcnt vmcnt(16)\n\ts_barrier" ::: "memory");
-    half8_t fa[2][4], fb[2][4];
+    // fragment registers: 32x32x16 - double buffered by k-step, [parity][tile]; 16x16x32 - X: one ring of eight tiles, W: [slab][tile]
+    std::conditional_t<T16, half8_t[8], half8_t[2][4]> fa;
+    std::conditional_t<T16, half8_t[2][8], half8_t[2][4]> fb;
+    if constexpr (T16) {
+        // what an instance expects in place: X tiles 0, 1 and the eight W tiles of slab 0
+        asm volatile("ds_read_b128 %0, %10 offset:0\n\tds_read_b128 %1, %10 offset:2048\n\t"
+                     "ds_read_b128 %2, %11 offset:0\n\tds_read_b128 %3, %11 offset:2048\n\tds_read_b128 %4, %11 offset:4096\n\tds_read_b128 %5, %11 offset:6144\n\t"
+                     "ds_read_b128 %6, %11 offset:8192\n\tds_read_b128 %7, %11 offset:10240\n\tds_read_b128 %8, %11 offset:12288\n\tds_read_b128 %9, %11 offset:14336\n\t"
+                     "s_waitcnt lgkmcnt(0)"
+                     : "=&v"(fa[0]), "=&v"(fa[1]), "=&v"(fb[0][0]), "=&v"(fb[0][1]), "=&v"(fb[0][2]), "=&v"(fb[0][3]), "=&v"(fb[0][4]), "=&v"(fb[0][5]),
+                       "=&v"(fb[0][6]), "=&v"(fb[0][7])
+                     : "v"(rab[0] + a0), "v"(rbb[0] + b0)
+                     : "memory");
+    } else {
     asm volatile("ds_read_b128 %0, %8 offset:0\n\tds_read_b128 %1, %8 offset:4096\n\tds_read_b128 %2, %8 offset:8192\n\tds_read_b128 %3, %8 offset:12288\n\t"
                  "ds_read_b128 %4, %9 offset:0\n\tds_read_b128 %5, %9 offset:4096\n\tds_read_b128 %6, %9 offset:8192\n\tds_read_b128 %7, %9 offset:12288\n\t"
                  "s_waitcnt lgkmcnt(0)"
@@ -837,14 +929,16 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(GemmArgs p) {
                    "=&v"(fb[0][0]), "=&v"(fb[0][1]), "=&v"(fb[0][2]), "=&v"(fb[0][3])
                  : "v"(rab[0] + a0), "v"(rbb[0] + b0)
                  : "memory");
+    }
 
 #ifdef BH_GEMM_STATS
     unsigned long long st_loop = 0, st_epi = 0, st_tiles = 0;
     const unsigned long long st_t0 = __builtin_readcyclecounter(), st_r0 = __builtin_amdgcn_s_memrealtime();
 #endif
     using park_t = std::conditional_t<GATED, uint2_t, uint4_t>;
-    constexpr int NST = (W4_NPARK + S - 1) / S;              // K-tile instances that carry parked rows (nk >= NST: the launcher)
-    park_t park[W4_NPARK];
+    constexpr int NPARK = T16 ? W4_NPARK16 : W4_NPARK;
+    constexpr int NST = (NPARK + S - 1) / S;                 // K-tile instances that carry parked rows (nk >= NST: the launcher)
+    park_t park[NPARK];
     W4Store pst;
     bool parked = false;
     const char* dA = Ab + 256;                               // DMA cursor: K-tile k + 2 of the instance of K-tile k ...
@@ -857,14 +951,14 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(GemmArgs p) {
         int tf0 = 0, tt0 = 0;
         const int next = next_valid(work + gridDim.x, tf0, tt0);
         if (next < slots) { nf0 = tf0; nt0 = tt0; }         // (no next tile: the run-ahead DMAs re-fetch this one, nobody reads them)
-        float16_t acc[4][4];
+        std::conditional_t<T16, float4_t[8][8], float16_t[4][4]> acc;
         // instance of K-tile k: reads A stage a0 / B stage b0 (k-step 0 of K-tile k + 1 from a1 / b1), D1 = A of K-tile k + 2 into A stage
         // a2, D2 = B of K-tile k + 2 into B stage b0. In the last two instances the DMA cursor is in the NEXT output tile: va / vb are
         // overwritten with its offsets in front of instance nk - 2 (nothing of this tile is fetched any more).
 #define W4_ROTATE() do { const unsigned ta = a0; a0 = a1; a1 = a2; a2 = ta; const unsigned tb = b0; b0 = b1; b1 = tb; dA += 128; dB += 128; } while (0)
 #define W4_CURSOR(k) do { if ((k) == nk - 2) { int lc = lane; asm volatile("" : "+v"(lc)); /* (opaque: nothing of it is hoisted and kept live) */ \
-                                               w4_offsets(p, nf0, nt0, wave, lc, va, vb); dA = Ab; dB = Bb; } } while (0)
-#define W4_ARGS acc, fa, fb, rab, rbb, a0, b0, a1, b1, va, vb, dA, dB, a2 + wdma, b0 + wdma
+                                               w4_offsets<T16>(p, nf0, nt0, wave, lc, va, vb); dA = Ab; dB = Bb; } } while (0)
+#define W4_ARGS acc, fa, fb, rab, rbb, a0, b0, a1, b1, va, vb, dA, dB, a2 + wdma, b0 + wdma, (unsigned)wave
         if (parked) {
             // the first NST instances also issue the previous tile's parked rows
 #define W4_ST(T) if constexpr ((T) < NST) { W4_CURSOR(T); w4_inst_st<(T) * S, S, !GATED, (T) == 0>(W4_ARGS, park, pst); W4_ROTATE(); }
@@ -872,15 +966,15 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(GemmArgs p) {
 #undef W4_ST
             for (int k = NST; k < nk; ++k) {
                 W4_CURSOR(k);
-                gemm_ktile(W4_ARGS);
+                w4_ktile(W4_ARGS, false);
                 W4_ROTATE();
             }
         } else {
-            gemm_ktile_first(W4_ARGS);
+            w4_ktile(W4_ARGS, true);
             W4_ROTATE();
             for (int k = 1; k < nk; ++k) {
                 W4_CURSOR(k);
-                gemm_ktile(W4_ARGS);
+                w4_ktile(W4_ARGS, false);
                 W4_ROTATE();
             }
         }
@@ -890,11 +984,7 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(GemmArgs p) {
 #ifdef BH_GEMM_STATS
         const unsigned long long st_b = __builtin_readcyclecounter();
 #endif
-        // MFMA result -> vector ALU: the stream ends on an MFMA and pads nothing
-        asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3"
-                     : "+a"(acc[0][0]), "+a"(acc[0][1]), "+a"(acc[0][2]), "+a"(acc[0][3]), "+a"(acc[1][0]), "+a"(acc[1][1]), "+a"(acc[1][2]),
-                       "+a"(acc[1][3]), "+a"(acc[2][0]), "+a"(acc[2][1]), "+a"(acc[2][2]), "+a"(acc[2][3]), "+a"(acc[3][0]), "+a"(acc[3][1]),
-                       "+a"(acc[3][2]), "+a"(acc[3][3]));
+        w4_settle(acc);
         // (a2: the A stage the last K-tile has just vacated - the next instance's D1 target - serves as the transposition scratch)
         parked = w4_epilogue<ACT, GATED, MODE>(p, acc, f0, t0, wa, wb, lane, smem + a2 + wdma, park, pst);
 #ifdef BH_GEMM_STATS
@@ -903,7 +993,7 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(GemmArgs p) {
         if (next >= slots) break;
         work = next; f0 = nf0; t0 = nt0;
     }
-    if (parked) w4_store_parked<GATED>(park, pst);
+    if (parked) w4_store_parked<GATED, T16>(park, pst);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the run-ahead DMAs of the tile that does not exist
 #ifdef BH_GEMM_STATS
     if (p.dbg != nullptr && tid == 0 && (blockIdx.x == 0 || blockIdx.x == 133)) {
@@ -918,6 +1008,9 @@ unsigned long long* g_gemm_dbg = nullptr;
 #endif
 int g_w4_gf = 0;             // experiments: feature tiles per block of gemm_w4_kernel's work order (0 = default)
 static int g_stagger = 0;    // bh_k_linear_stagger
+// bh_k_linear_tile16 ("gemm_tile16"): gemm_w4_kernel's K-tile stream on 16x16x32 MFMAs (1, default since round 6: 5-9 % faster on every
+// shape of tools/gemm_bench.py, sup 60.4 -> 59.2 ms per batch - profiles/r06_gemm_tile16.txt) or on 32x32x16 (0: rounds 4-5)
+static int g_w4_t16 = 1;
 static int g_force_v1 = 0;   // test / A-B hook (bh_k_linear_force_v1): 1 = v1 only, 2 = never v3 / v5, 3 = never v5 (v3 where it applies), 5 = v5 whenever the shape is legal (tests: small problems)
 
 template <int ACT, bool GATED>
@@ -948,11 +1041,12 @@ static int launch(const GemmArgs& a, hipStream_t s) {
             bool done = true;
 // four parked rows per K-tile instance on every K (K = 384, six instances: six rows per instance over four of them measured 3 %
 // slower than four rows over five - 0.879 against 0.853 ms on the hac CRF head)
-#define W4_LAUNCH(A_, G_, MODE_)                                                                                                    \
+#define W4_LAUNCH_T(A_, G_, MODE_, T16_)                                                                                            \
     do {                                                                                                                          \
-        BH_CHECK_HIP(bh_max_lds((const void*)gemm_w4_kernel<A_, G_, 4, MODE_>, W4_LDS));                                          \
-        hipLaunchKernelGGL((gemm_w4_kernel<A_, G_, 4, MODE_>), dim3(slots < cus ? (int)slots : cus), dim3(256), W4_LDS, s, b);      \
+        BH_CHECK_HIP(bh_max_lds((const void*)gemm_w4_kernel<A_, G_, 4, MODE_, T16_>, W4_LDS));                                    \
+        hipLaunchKernelGGL((gemm_w4_kernel<A_, G_, 4, MODE_, T16_>), dim3(slots < cus ? (int)slots : cus), dim3(256), W4_LDS, s, b); \
     } while (0)
+#define W4_LAUNCH(A_, G_, MODE_) do { if (g_w4_t16) W4_LAUNCH_T(A_, G_, MODE_, true); else W4_LAUNCH_T(A_, G_, MODE_, false); } while (0)
             if constexpr (GATED) {
                 if (mode == 0) W4_LAUNCH(ACT_NONE, true, 0); else done = false;
             } else if constexpr (ACT == ACT_NONE) {
@@ -969,6 +1063,7 @@ static int launch(const GemmArgs& a, hipStream_t s) {
                 done = false;
             }
 #undef W4_LAUNCH
+#undef W4_LAUNCH_T
             if (done) return 0;
         }
         if (false) {
@@ -997,6 +1092,7 @@ static int launch(const GemmArgs& a, hipStream_t s) {
 
 void bh_k_linear_force_v1(int on) { bh::g_force_v1 = on; }
 void bh_k_linear_stagger(int units) { bh::g_stagger = units; }
+void bh_k_linear_tile16(int on) { bh::g_w4_t16 = on ? 1 : 0; }
 
 int bh_k_linear(const void* X, const void* W, const float* bias, void* out, int M, int N, int K,
                 int ldx, int ldw, int ldo, int act, float scale, float clamp_lo, float clamp_hi,

@@ -14,6 +14,7 @@ int bh_k_linear(const void* X, const void* W, const float* bias, void* out, int 
 
 void bh_k_linear_force_v1(int on);
 void bh_k_linear_stagger(int units);
+void bh_k_linear_tile16(int on);   // gemm_w4_kernel on 16x16x32 MFMAs (1) or 32x32x16 (0)
 
 // conv.hip
 int bh_k_conv_first(const void* signal, const float* w, const float* bias, void* out, int N, int Lin,

@@ -76,6 +76,18 @@ def test_generated_gemm_stream_matches_its_generator(tmp_path):
     body = committed.split("__device__ __forceinline__ void gemm_ktile(")[1].split("__device__ __forceinline__ void")[0]
     assert body.count("v_mfma_f32_32x32x16_f16") == 64 and body.count("ds_read_b128") == 32
     assert body.count("global_load_lds_dwordx4") == 16 and body.count("s_barrier") == 1
+    # the same K-tile on 16x16x32 MFMAs (--tile16): 128 MFMAs, the same reads / pieces / barrier; every function one asm statement
+    out16 = tmp_path / "gemm_ktile16_mfma.inc"
+    subprocess.run([sys.executable, os.path.join(root, "tools", "gen_gemmstep.py"), "--tile16", "--out", str(out16)], check=True, capture_output=True)
+    committed = open(os.path.join(root, "bonito_amd", "csrc", "gemm_ktile16_mfma.inc")).read()
+    assert out16.read_text() == committed
+    body = committed.split("__device__ __forceinline__ void gemm_ktile16(")[1].split("__device__ __forceinline__ void")[0]
+    assert body.count("v_mfma_f32_16x16x32_f16") == 128 and body.count("ds_read_b128") == 32
+    assert body.count("global_load_lds_dwordx4") == 16 and body.count("s_barrier") == 1 and body.count("asm volatile(") == 1
+    # nothing of K-tile g is read behind the barrier, nothing of K-tile g + 1 in front of it
+    front, behind = body.split("s_barrier")
+    assert front.count("ds_read_b128") == 22 and behind.count("ds_read_b128") == 10
+    assert front.index("%[san]") > front.rindex("%[ra0] offset") and "%[san]" not in behind       # the next K-tile's address replaces ra0 behind its last use
 
 
 @pytest.mark.parametrize("preset,name", [("plain", "ringstep3_mfma.inc"), ("paired", "ringstep3p_mfma.inc"), ("unrolled", "ringstep3u_mfma.inc"),

@@ -192,6 +192,48 @@ def test_transformer_long_chunk_ring_attention_matches_oracle():
     assert torch.equal(geo[8], geo[12]) and torch.equal(geo[12].float(), outs[1])
 
 
+@pytest.mark.parametrize("tile16", [0, 1])
+def test_transformer_layers_on_the_four_wave_gemm_match_oracle(tile16):
+    """Every linear layer of a v5-width transformer (d_model 512: Wqkv with the rotary epilogue, out_proj / fc2 with and without the fused
+    residual, the SwiGLU fc1, the CRF head with scale) forced onto gemm_w4_kernel ("gemm_path" 5: any legal shape; small calls take the
+    eight-wave kernels otherwise) - on its 32x32x16 K-tile stream and on the 16x16x32 one ("gemm_tile16") - against the fp32 oracle of
+    the reference modules; 2 x 300 tokens: ragged token tiles, one rotary wrap inside a tile."""
+    from bonito_amd import decode, synthetic
+    from bonito_amd.transformer import Model
+    torch.manual_seed(12)
+    cfg = synthetic.transformer_model_config(d_model=512, nhead=8, dim_ff=2048, depth=2, window=(127, 128), state_len=3,
+                                             batchsize=2, chunksize=1800)
+    model = Model(cfg).eval()
+    nn_ref.round_params_to_half_(model.encoder)
+    x = torch.randn(2, 1, 1800).half()
+    with torch.no_grad():
+        want = nn_ref.forward(model.encoder, x.float(), expand_blanks=False)
+    outs = {}
+    try:
+        decode.set_option("gemm_tile16", tile16)
+        decode.set_option("gemm_path", 5)
+        for fuse in (0, 1):
+            enc = HipEncoder(model.encoder, batchsize=2, chunksize=1800)
+            enc.set_option("norm_fuse", fuse)
+            outs[fuse] = enc(x.cuda()).cpu().float()
+            enc.check()
+        decode.set_option("gemm_path", 2)
+        enc = HipEncoder(model.encoder, batchsize=2, chunksize=1800)
+        outs["small"] = enc(x.cuda()).cpu().float()
+        enc.check()
+    finally:
+        decode.set_option("gemm_path", 0)
+        decode.set_option("gemm_tile16", 1)              # the library's default
+    if want.shape != outs[0].shape:
+        want = want.permute(1, 0, 2)
+    rng = max(want.abs().max().item(), 1.0)
+    for key, got in outs.items():
+        assert got.shape == want.shape
+        d = (got - want).abs()
+        assert d.max().item() < 2e-2 * rng and d.mean().item() < 3e-3 * rng, (key, d.max().item(), d.mean().item(), rng)
+    assert (outs[0] - outs["small"]).abs().max().item() < 1e-2 * rng
+
+
 def test_fused_and_unfused_lstm_paths_agree():
     """The ring-in-a-workgroup kernel (3, narrow layers only), the workgroup-shared fused kernel (2), the per-wave fused kernel (1) and the GEMM + recurrence pair (0) are four
     implementations of the same layer: all must match the reference fixture; 0 differs from the fused ones only by

@@ -395,6 +395,9 @@ def test_linear_persistent_big_tile_kernel(M, N, K, gated):
     assert (big[-3000:].float() - want).abs().max().item() < 3e-2 + 3e-3 * want.abs().max().item()
 
 
+TILE16_DEFAULT = 1        # the library's default MFMA shape of the four-wave GEMM ("gemm_tile16")
+
+
 def _linear_ref(x, w, b, act, gated, scale=1.0, lo=-INF, hi=INF):
     z = x.float() @ w.float().T
     if b is not None:
@@ -405,21 +408,24 @@ def _linear_ref(x, w, b, act, gated, scale=1.0, lo=-INF, hi=INF):
     return z.clamp(lo, hi)
 
 
+@pytest.mark.parametrize("tile16", [0, 1])
 @pytest.mark.parametrize("M,N,K,gated,act", [(300, 256, 640, 0, 0), (1000 + 7, 512, 384, 0, 1), (2048, 256, 512, 1, 0), (777, 768, 1024, 0, 2),
                                              (40000 + 13, 1024, 384, 0, 1), (70000, 512, 512, 1, 0), (131072 + 5, 256, 2048, 0, 0)])
-def test_linear_four_wave_kernel(M, N, K, gated, act):
+def test_linear_four_wave_kernel(M, N, K, gated, act, tile16):
     """gemm_w4_kernel (256 x 256 x 64 tile on four waves, 32x32x16 MFMAs, one generated instruction stream per K-tile, outputs
     through an LDS scratch into full-line stores) serves K % 128 == 0, N % 256 == 0 problems of >= 512 tiles ("gemm_path" 5: any
     legal shape). EVERY output row against the fp32 restatement on the device (it accumulates K in another order than the
     16x16x32 kernels, so the bar is the tolerance of test_linear_plain, not bit equality with them), closeness to the 128-tile
     kernel, and identical bytes when run twice; shortest (4) and long (32) K-tile streams, one workgroup walking several output
-    tiles, ragged last token tile, SwiGLU / swish / tanh epilogues with bias."""
+    tiles, ragged last token tile, SwiGLU / swish / tanh epilogues with bias. `tile16`: the same kernel around the 16x16x32 K-tile
+    stream ("gemm_tile16": 64 float4 accumulators, W rows staged in natural order, another scratch write in the epilogue)."""
     from bonito_amd import decode
     g = torch.Generator().manual_seed(M + K)
     x = (torch.randn(M, K, generator=g) * 0.5).half().to(dev())
     w = (torch.randn(N, K, generator=g) * 0.2).half().to(dev())
     b = torch.randn(N, generator=g).to(dev())
     try:
+        decode.set_option("gemm_tile16", tile16)
         decode.set_option("gemm_path", 5)
         got = _linear(x, w, b, act=act, gated=gated)
         again = _linear(x, w, b, act=act, gated=gated)
@@ -427,6 +433,7 @@ def test_linear_four_wave_kernel(M, N, K, gated, act):
         small = _linear(x, w, b, act=act, gated=gated)
     finally:
         decode.set_option("gemm_path", 0)
+        decode.set_option("gemm_tile16", TILE16_DEFAULT)
     assert torch.equal(got, again)
     worst = 0.0
     for lo_ in range(0, M, 16384):                     # fp32 restatement on the device, every row
@@ -437,7 +444,8 @@ def test_linear_four_wave_kernel(M, N, K, gated, act):
     assert (got.float() - small.float()).abs().max().item() < 2e-2 + 2e-3 * small.float().abs().max().item()
 
 
-def test_linear_four_wave_kernel_layouts_exactly():
+@pytest.mark.parametrize("tile16", [0, 1])
+def test_linear_four_wave_kernel_layouts_exactly(tile16):
     """X = I-like (one 1.0 per row) against an asymmetric W: every output is one W element exactly, so a permuted fragment row, a
     wrong swizzle or a transposed store shows up as a wrong value, not as noise. K = 384 (the shortest K the kernel takes), several feature and token tiles."""
     from bonito_amd import decode
@@ -447,14 +455,17 @@ def test_linear_four_wave_kernel_layouts_exactly():
     w = ((torch.arange(N * K).reshape(N, K) * 37) % 2039 / 16.0).half()
     want = w.float()[:, (torch.arange(M) * 7) % K].T.contiguous().half()
     try:
+        decode.set_option("gemm_tile16", tile16)
         decode.set_option("gemm_path", 5)
         got = _linear(x.half().to(dev()), w.to(dev())).cpu()
     finally:
         decode.set_option("gemm_path", 0)
+        decode.set_option("gemm_tile16", TILE16_DEFAULT)
     assert torch.equal(got, want)
 
 
-def test_linear_four_wave_kernel_row_remap_scale_clamp():
+@pytest.mark.parametrize("tile16", [0, 1])
+def test_linear_four_wave_kernel_row_remap_scale_clamp(tile16):
     """The CRF head's call shape on the four-wave kernel: (t, n)-major rows -> [N][T][C] with the padded batch rows dropped, tanh,
     scale 5, clamp."""
     from bonito_amd import decode
@@ -465,8 +476,10 @@ def test_linear_four_wave_kernel_row_remap_scale_clamp():
     z = torch.tanh(x.float() @ w.float().T) * 5.0
     want = z.clamp(-4.5, 4.5).view(T, Np, Cc)[:, :Nv].permute(1, 0, 2).reshape(Nv * T, Cc)
     try:
+        decode.set_option("gemm_tile16", tile16)
         decode.set_option("gemm_path", 5)
         got = _linear(x.to(dev()), w.to(dev()), act=2, scale=5.0, lo=-4.5, hi=4.5, row=(Np, 1, T, Nv), out_rows=Nv * T).cpu().float()
     finally:
         decode.set_option("gemm_path", 0)
+        decode.set_option("gemm_tile16", TILE16_DEFAULT)
     assert (got - want).abs().max().item() < 2e-2

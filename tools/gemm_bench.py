@@ -18,8 +18,9 @@ for M, N, K, gated in shapes:
     ncol = N // 2 if gated else N
     out = torch.empty((M, ncol), dtype=torch.float16, device=dev)
     res = {}
-    for path in (0, 3, 2):
-        decode.set_option("gemm_path", path)
+    for path in (0, 32, 3, 2):
+        decode.set_option("gemm_path", 0 if path == 32 else path)
+        decode.set_option("gemm_tile16", 0 if path == 32 else 1)      # 32: the four-wave kernel on its 32x32x16 stream (rounds 4-5)
         def run():
             _lib.check(lib.bh_linear(_lib.ptr(x), _lib.ptr(w), None, _lib.ptr(out), M, N, K, K, K, ncol, 0, 1.0, -INF, INF,
                                      gated, 0, 0, 0, 0, _lib.stream_ptr()), "bh_linear")
@@ -31,7 +32,7 @@ for M, N, K, gated in shapes:
         e1.record(); torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / 40
         res[path] = (ms, 2.0 * M * N * K / ms / 1e9)
-    decode.set_option("gemm_path", 0); decode.set_option("gemm_stagger", 0)
+    decode.set_option("gemm_path", 0); decode.set_option("gemm_stagger", 0); decode.set_option("gemm_tile16", 1)
     # yardstick: the vendor library behind torch.matmul (hipBLASLt / rocBLAS), plain GEMM without the fused epilogue
     full = torch.empty((M, N), dtype=torch.float16, device=dev)
     for _ in range(15): torch.matmul(x, w.t(), out=full)
@@ -43,6 +44,6 @@ for M, N, K, gated in shapes:
     lib_ms = e0.elapsed_time(e1) / 40
     del full
     lib_tf = 2.0 * M * N * K / lib_ms / 1e9
-    print("M=%d N=%d K=%d gated=%d: auto %.3f ms %.0f TF/s (%.2f x lib) | 8-wave 256-tile %.3f ms %.0f TF/s | 128-tile %.3f ms %.0f TF/s | torch.matmul %.3f ms %.0f TF/s" % (
-        M, N, K, gated, res[0][0], res[0][1], res[0][1] / lib_tf, res[3][0], res[3][1], res[2][0], res[2][1], lib_ms, lib_tf), flush=True)
+    print("M=%d N=%d K=%d gated=%d: auto %.3f ms %.0f TF/s (%.2f x lib) | 32x32x16 stream %.3f ms %.0f TF/s | 8-wave 256-tile %.3f ms %.0f TF/s | 128-tile %.3f ms %.0f TF/s | torch.matmul %.3f ms %.0f TF/s" % (
+        M, N, K, gated, res[0][0], res[0][1], res[0][1] / lib_tf, res[32][0], res[32][1], res[3][0], res[3][1], res[2][0], res[2][1], lib_ms, lib_tf), flush=True)
     del x, w, out

@@ -13,6 +13,14 @@ void bh_set_error(const char* fmt, ...) {
     va_list ap; va_start(ap, fmt); vfprintf(stderr, fmt, ap); va_end(ap); fputc('\n', stderr);
 }
 
+// (the library's helpers of engine.cpp, restated for the stand-alone binary)
+hipError_t bh_max_lds(const void* fn, int bytes) { return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes); }
+int bh_cu_count() {
+    static int n = 0;
+    if (!n) { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, 0) != hipSuccess) return 256; n = prop.multiProcessorCount; }
+    return n;
+}
+
 __global__ void fill_kernel(bh::half_t* p, size_t n, float scale, unsigned seed) {
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         unsigned h = (unsigned)i * 2654435761u + seed;
@@ -34,6 +42,7 @@ int main(int argc, char** argv) {
     bh_k_linear_force_v1(path);
     if (getenv("LAB_GF")) bh::g_w4_gf = atoi(getenv("LAB_GF"));
     if (getenv("LAB_STAGGER")) bh_k_linear_stagger(atoi(getenv("LAB_STAGGER")));
+    if (getenv("LAB_T16")) bh_k_linear_tile16(atoi(getenv("LAB_T16")));        // gemm_w4_kernel around the 16x16x32 K-tile stream
     const int reps = getenv("LAB_REPS") ? atoi(getenv("LAB_REPS")) : 40, warm = getenv("LAB_WARM") ? atoi(getenv("LAB_WARM")) : 25;
     unsigned long long* dbg = nullptr;
     hipMalloc((void**)&dbg, 16 * 8);

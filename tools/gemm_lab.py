@@ -26,6 +26,19 @@ VARIANTS = {
     "epi_nolds": ["--strip", "dma,lds,bar", "-DBH_EPI_NOLDS"],
     "epi_valu": ["--strip", "dma,lds,bar", "-DBH_EPI_NOLDS", "-DBH_EPI_NOSTORE"],
     "epi_ldsonly": ["--strip", "dma,lds,bar", "-DBH_EPI_LDSONLY"],
+    # round 6: the K-tile on 16x16x32 MFMAs (gen_gemmstep.py --tile16; run the binaries with LAB_T16=1). t16_nowN: rows the epilogue stores itself
+    "t16_base": ["--tile16"],
+    "t16_b74": ["--tile16", "--barrier-at", "74"],
+    "t16_b86": ["--tile16", "--barrier-at", "86"],
+    "t16_r2": ["--tile16", "--read-every", "2"],
+    "t16_d2fast": ["--tile16", "--d2-every16", "2"],
+    "t16_now12": ["--tile16", "--now16", "12"],
+    "t16_now16": ["--tile16", "--now16", "16"],
+    "t16_now24": ["--tile16", "--now16", "24"],
+    "t16_s16": ["--tile16", "--stagger", "16"],
+    "t16_mfma": ["--tile16", "--strip", "dma,lds,bar"],
+    "t16_nodma": ["--tile16", "--strip", "dma"],
+    "t16_nolds": ["--tile16", "--strip", "lds"],
 }
 
 
@@ -35,8 +48,9 @@ def build(name, opts):
     opts = [o for o in opts if not o.startswith("-D")]
     subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen_gemmstep.py"), "--out", inc] + opts, check=True, stdout=subprocess.DEVNULL)
     exe = os.path.join(OUT, "lab_%s" % name)
+    which = "BH_GEMM_KTILE16_INC" if "--tile16" in opts else "BH_GEMM_KTILE_INC"
     cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-I" + os.path.join(ROOT, "include"),
-           "-I" + os.path.join(ROOT, "bonito_amd", "csrc"), '-DBH_GEMM_KTILE_INC="%s"' % inc, "-Wno-unused-function"] + defs + [
+           "-I" + os.path.join(ROOT, "bonito_amd", "csrc"), '-D%s="%s"' % (which, inc), "-Wno-unused-function"] + defs + [
            os.path.join(ROOT, "tools", "gemm_lab.hip"), "-o", exe]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode:
