@@ -863,7 +863,7 @@ def main():
         names = sorted({ln.split(": ", 1)[1] for ln in layout.splitlines() if kind in ln and ": " in ln})
         kernel = "; ".join(names)
         if cls == "mlp_fc1":
-            kernel = "gemm_w4_kernel<0, true, 4, 0> (fc1 + SwiGLU epilogue, 512 -> 2 x 2048)"
+            kernel = "gemm_w4_kernel<0, true, 4, 0, true> (fc1 + SwiGLU epilogue, 512 -> 2 x 2048; 16x16x32 K-tile stream)"
         elif cls == "attention_core":
             kernel = "attention_ring_kernel"
         lstm_kernel = kernel if cls == "lstm_rec" else None

@@ -1492,6 +1492,8 @@ extern "C" int bh_set_option(const char* name, int value) {
     if (!strcmp(name, "attn_version")) { extern int g_attn_version; g_attn_version = value == 1 ? 1 : 2; return 0; }
     if (!strcmp(name, "attn_expt")) { extern int g_attn_expt; g_attn_expt = value; return 0; }
     if (!strcmp(name, "gemm_stagger")) { bh_k_linear_stagger(value); return 0; }
+    if (!strcmp(name, "gemm_order")) { bh_k_linear_order(value); return 0; }
+    if (!strcmp(name, "gemm_gf")) { bh_k_linear_gf(value); return 0; }
     if (!strcmp(name, "gemm_tile16")) { bh_k_linear_tile16(value); return 0; }     // process-wide A/B switch: the four-wave GEMM's MFMA shape
     if (!strcmp(name, "lstm_q8_variant")) { g_q8_variant = value; return 0; }
     BH_REQUIRE(false, "set_option: unknown option '%s'", name);

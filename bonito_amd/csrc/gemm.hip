@@ -45,6 +45,7 @@ struct GemmArgs {
     int rot_T = 1, rot_nfeat = 0, rot_qfeat = 0;
     float rot_qscale = 1.0f;
     int w4_gf = 4;     // gemm_w4_kernel: feature tiles per block of its work order (1, 2, 4, 8, 16 or 32; see the kernel)
+    int w4_order = 0;  // gemm_w4_kernel: 0 = token blocks fastest inside an XCD's share, 1 = feature groups fastest (see the kernel)
 #ifdef BH_GEMM_STATS
     unsigned long long* dbg = nullptr;   // tools/gemm_lab.hip: cycle stamps of workgroup 0 (K loops, epilogues, total, real-time ticks, tiles)
 #endif
@@ -509,8 +510,8 @@ __global__ __launch_bounds__(512, 1) void gemm_big_kernel(GemmArgs p) {
 // 32 x 32 x 16 MFMAs halve the operand reads again.)
 
 // ---------------------------------------------------------------------------------------------------
-// v5 ("w4", round 4): the same 256 x 256 x 64 workgroup tile on FOUR waves - one per SIMD, each owning a 128 x 128 wave tile on
-// v_mfma_f32_32x32x16_f16 (256 accumulator registers) - with the whole K-tile as ONE generated instruction stream
+// v5 ("w4", round 4; round 6 added the 16x16x32 stream below, now the default): the same 256 x 256 x 64 workgroup tile on FOUR waves - one per
+// SIMD, each owning a 128 x 128 wave tile on v_mfma_f32_32x32x16_f16 (256 accumulator registers) - with the whole K-tile as ONE generated instruction stream
 // (tools/gen_gemmstep.py -> gemm_ktile_mfma.inc): 64 MFMAs with the 32 fragment reads of the next k-steps, the wave's 16 LDS-DMA
 // pieces of the K-tiles ahead and one barrier issued from inside the stream. What that changes against v3 (8 waves, 64 x 128
 // wave tiles on 16 x 16 x 32, compiler-scheduled, everything of a K-tile - wait, barrier, DMA issue, fragment reads, MFMAs - one
@@ -858,8 +859,9 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(GemmArgs p) {
 
     // Work order (persistent kernel, block b on XCD b % 8 - observed dispatch, for speed only). XCD x owns the token tiles
     // [tlo, tlo + NT); inside its share the order is: blocks of GF feature tiles x GT token tiles (GF * GT = 32 = one sweep of the
-    // XCD's CUs: 32 workgroups share GF W tiles and GT X tiles, GF + GT L2 fills per K-tile instead of 32 + 32 / n_ft), token
-    // blocks fastest, so the GF W tiles stay in the XCD's L2 while the X tiles stream past once per group of GF feature tiles.
+    // XCD's CUs: 32 workgroups share GF W tiles and GT X tiles, GF + GT L2 fills per K-tile instead of 32 + 32 / n_ft), then
+    // (w4_order 1, round 6) feature groups fastest: the GT X tiles stay in the XCD's L2 while the W groups come round - or (w4_order 0)
+    // token blocks fastest, so the GF W tiles stay in the XCD's L2 while the X tiles stream past once per group of GF feature tiles.
     // (Feature tiles fastest over ALL of them, as gemm_big_kernel walks, puts n_ft W tiles - 4 MiB at N = 4096, K = 512: the whole
     // L2 - in competition with the X stream: 2800-3600 cycles per K-tile at N = 4096 against 2250 at N = 512.) Slots that fall
     // outside the problem (ragged edges of the blocking) are skipped: every tile is visited exactly once for any grid.
@@ -871,7 +873,7 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(GemmArgs p) {
         const int xcd = w & 7, loc = w >> 3;
         const int NT = tq + (xcd < tr ? 1 : 0), tlo = xcd * tq + min(xcd, tr);
         const int blk = loc >> 5, within = loc & 31;
-        const int fg = blk / nbt, tg = blk - fg * nbt;
+        const int fg = p.w4_order ? blk % nfg : blk / nbt, tg = p.w4_order ? blk / nfg : blk - fg * nbt;
         const int tf = fg * GF + within % GF, tt = tg * GT + within / GF;
         f0 = tf * 256;
         t0 = (tlo + tt) * 256;
@@ -1007,6 +1009,12 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(GemmArgs p) {
 unsigned long long* g_gemm_dbg = nullptr;
 #endif
 int g_w4_gf = 0;             // experiments: feature tiles per block of gemm_w4_kernel's work order (0 = default)
+// bh_k_linear_order ("gemm_order"): GemmArgs::w4_order. 1 (default since round 6): an XCD finishes ALL feature groups of a block of token tiles
+// before it moves on - the block's X tiles (GT x 256 KiB at K = 512) are fetched from HBM once and re-read from L2, the W tiles (4 MiB at
+// N = 4096: Infinity-Cache resident) come round once per token block. 0 (rounds 4-5): token blocks fastest - X streamed from HBM once per
+// feature group (fc1: four times; PMC 5.25 GB against 2.62 algorithmic). Lab, tools/gemm_lab_order.sh: +4 % where there is more than one
+// feature group (Wqkv, fc1, the N = 4096 input projections), nothing elsewhere (profiles/r06_gemm_tile16.txt)
+int g_w4_order = 1;
 static int g_stagger = 0;    // bh_k_linear_stagger
 // bh_k_linear_tile16 ("gemm_tile16"): gemm_w4_kernel's K-tile stream on 16x16x32 MFMAs (1, default since round 6: 5-9 % faster on every
 // shape of tools/gemm_bench.py, sup 60.4 -> 59.2 ms per batch - profiles/r06_gemm_tile16.txt) or on 32x32x16 (0: rounds 4-5)
@@ -1029,6 +1037,7 @@ static int launch(const GemmArgs& a, hipStream_t s) {
             int gf = g_w4_gf > 0 ? g_w4_gf : 4;
             while (gf > 1 && (gf > nf3 || (g_w4_gf <= 0 && nf3 % gf != 0))) gf >>= 1;      // (a group that does not divide n_ft leaves slots empty: 6 tiles in groups of 4 wasted a quarter)
             b.w4_gf = gf;
+            b.w4_order = g_w4_order;
             // "gemm_stagger" n > 0: phase groups n x 256 cycles apart (measured: no gain for this kernel - its epilogue is bound by the CU's
             // store path, not by a chip-wide burst - and the last groups finish up to 7 n x 256 cycles late); default off
             b.stagger = g_stagger > 0 ? g_stagger * 256 : 0;
@@ -1093,6 +1102,8 @@ static int launch(const GemmArgs& a, hipStream_t s) {
 void bh_k_linear_force_v1(int on) { bh::g_force_v1 = on; }
 void bh_k_linear_stagger(int units) { bh::g_stagger = units; }
 void bh_k_linear_tile16(int on) { bh::g_w4_t16 = on ? 1 : 0; }
+void bh_k_linear_order(int order) { bh::g_w4_order = order ? 1 : 0; }
+void bh_k_linear_gf(int gf) { bh::g_w4_gf = gf; }
 
 int bh_k_linear(const void* X, const void* W, const float* bias, void* out, int M, int N, int K,
                 int ldx, int ldw, int ldo, int act, float scale, float clamp_lo, float clamp_hi,

@@ -14,6 +14,8 @@ int bh_k_linear(const void* X, const void* W, const float* bias, void* out, int 
 
 void bh_k_linear_force_v1(int on);
 void bh_k_linear_stagger(int units);
+void bh_k_linear_order(int order);  // gemm_w4_kernel's work order inside an XCD: 0 token blocks fastest, 1 feature groups fastest
+void bh_k_linear_gf(int gf);        // ... feature tiles per block (0 = automatic)
 void bh_k_linear_tile16(int on);   // gemm_w4_kernel on 16x16x32 MFMAs (1) or 32x32x16 (0)
 
 // conv.hip

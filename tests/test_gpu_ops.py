@@ -412,7 +412,7 @@ def _linear_ref(x, w, b, act, gated, scale=1.0, lo=-INF, hi=INF):
 @pytest.mark.parametrize("M,N,K,gated,act", [(300, 256, 640, 0, 0), (1000 + 7, 512, 384, 0, 1), (2048, 256, 512, 1, 0), (777, 768, 1024, 0, 2),
                                              (40000 + 13, 1024, 384, 0, 1), (70000, 512, 512, 1, 0), (131072 + 5, 256, 2048, 0, 0)])
 def test_linear_four_wave_kernel(M, N, K, gated, act, tile16):
-    """gemm_w4_kernel (256 x 256 x 64 tile on four waves, 32x32x16 MFMAs, one generated instruction stream per K-tile, outputs
+    """gemm_w4_kernel (256 x 256 x 64 tile on four waves, 32x32x16 or 16x16x32 MFMAs, one generated instruction stream per K-tile, outputs
     through an LDS scratch into full-line stores) serves K % 128 == 0, N % 256 == 0 problems of >= 512 tiles ("gemm_path" 5: any
     legal shape). EVERY output row against the fp32 restatement on the device (it accumulates K in another order than the
     16x16x32 kernels, so the bar is the tolerance of test_linear_plain, not bit equality with them), closeness to the 128-tile

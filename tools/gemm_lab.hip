@@ -42,6 +42,7 @@ int main(int argc, char** argv) {
     bh_k_linear_force_v1(path);
     if (getenv("LAB_GF")) bh::g_w4_gf = atoi(getenv("LAB_GF"));
     if (getenv("LAB_STAGGER")) bh_k_linear_stagger(atoi(getenv("LAB_STAGGER")));
+    if (getenv("LAB_ORDER")) bh_k_linear_order(atoi(getenv("LAB_ORDER")));
     if (getenv("LAB_T16")) bh_k_linear_tile16(atoi(getenv("LAB_T16")));        // gemm_w4_kernel around the 16x16x32 K-tile stream
     const int reps = getenv("LAB_REPS") ? atoi(getenv("LAB_REPS")) : 40, warm = getenv("LAB_WARM") ? atoi(getenv("LAB_WARM")) : 25;
     unsigned long long* dbg = nullptr;

@@ -29,6 +29,8 @@ The stream ends with lgkmcnt(0): the compiler may touch the fragment registers b
 MFMA -> vector-ALU hazard at its end: gemm_w4_kernel puts 16 wait states in front of the epilogue's first accumulator read.
 
 usage: gen_gemmstep.py [--wait-at n] [--read-at n] [--d1-every n] [--out path] [--name fn]
+       gen_gemmstep.py --tile16 [--barrier-at n] [--read-every n] [--d2-every16 n] [--now16 n] [--stagger c] [--out path]
+           -> gemm_ktile16_mfma.inc: the same K-tile on v_mfma_f32_16x16x32_f16 (build16(); the library's default since round 6)
 """
 import argparse
 import os

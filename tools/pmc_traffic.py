@@ -43,7 +43,7 @@ def main():
     write = {r[0]: (r[2], r[3]) for r in wr}
     # the kernels a bench roofline can name: the recurrent kernels, fc1 (+ SwiGLU) of the transformer, the attention kernel. Several template
     # instances of one kernel (the last 8-bit recurrent layer also writes fp16 rows) are averaged over their launches.
-    wanted = (r"(lstm_layer_\w+_kernel)", r"(gemm_w4_kernel)<0, true, 4, 0>", r"(attention_ring2?_kernel)")
+    wanted = (r"(lstm_layer_\w+_kernel)", r"(gemm_w4_kernel)<0, true, 4, 0(?:, true)?>", r"(attention_ring2?_kernel)")
     acc = {}
     for name in fetch:
         m = None
