@@ -608,6 +608,17 @@ struct W4Store {
 
 // MODE (compile time, so that the block loop is straight-line code the compiler can software-pipeline; with run-time flags every
 // `if` inside it was a join with full s_waitcnt's: 9.5 k cycles per tile whatever the stores did): 1 = residual, 2 = rotary, 4 = scale / clamp
+// four accumulation registers -> vector registers. The reads sit inside a volatile statement on purpose: as plain copies they are common to the
+// full-tile and the ragged-tile instance of the epilogue, and the compiler hoists ALL of a tile's reads in front of that branch (256 live
+// registers, every parked row spilled - seen with an epilogue that read the accumulators through plain copies, round 6)
+__device__ __forceinline__ float4_t w4_acc_read(const float4_t& a) {
+    float x0, x1, x2, x3;
+    asm volatile("v_accvgpr_read_b32 %0, %4\n\tv_accvgpr_read_b32 %1, %5\n\tv_accvgpr_read_b32 %2, %6\n\tv_accvgpr_read_b32 %3, %7"
+                 : "=v"(x0), "=v"(x1), "=v"(x2), "=v"(x3)
+                 : "a"(a[0]), "a"(a[1]), "a"(a[2]), "a"(a[3]));
+    return float4_t{x0, x1, x2, x3};
+}
+
 template <int ACT, bool GATED, int MODE, typename ACC, typename PARK, int NP>
 __device__ __forceinline__ bool w4_epilogue(const GemmArgs& p, ACC& acc, int f0, int t0, int wa, int wb, int lane, char* scratch,
                                             PARK (&park)[NP], W4Store& st) {
@@ -650,6 +661,7 @@ __device__ __forceinline__ bool w4_epilogue(const GemmArgs& p, ACC& acc, int f0,
     constexpr bool rot = !GATED && (MODE & 2) != 0;
     const float rsgn = q < 4 ? -1.0f : 1.0f;
     const int pos0 = rot ? (tw + tl) % p.rot_T : 0;                              // position of the lane's first row (rot_T >= 256: one wrap at most)
+    const int pos16 = rot && T16 ? (tw + (lane & 15)) % p.rot_T : 0;            // T16: of the lane's token in token tile 0 of the accumulator layout
     const float* const cs0 = p.rot_cs + (q & 3) * 16;
     char* const wrow = scratch + col * 256;
     const int wx = col & 15;
@@ -658,11 +670,49 @@ __device__ __forceinline__ bool w4_epilogue(const GemmArgs& p, ACC& acc, int f0,
             // lane (g = l >> 4, c16 = l & 15): piece 4 jj + g (features 16 jj + 4 g .. + 3 of the pair) of token 16 tt + c16; an 8-lane group of
             // the ds_write_b128 is eight tokens x one piece = eight positions piece ^ token: conflict free like the 32x32 layout's
             const int g = lane >> 4, c16 = lane & 15;
+            bool rotb = false;
+            if constexpr (rot) rotb = fw + (b & 1) * 64 < p.rot_nfeat;       // (wave uniform) this 64-feature pair is one rotated head
+            if (rotb) {
+                // Rotary embedding in the ACCUMULATOR layout (round 6): the partner of dim d, d +- 32, is the same lane's tile jj +- 2 - no
+                // cross-lane traffic - and a lane's cos / sin (dims 4 g .. + 3 and 16 + 4 g .. + 3 of its token) serve the whole head: 8
+                // table loads per block where the transposed layout needed 16 loads and 32 ds_bpermute per block (the Wqkv GEMM ran at
+                // 690 TFLOP/s against 950 for the same shape without the rotation). Bias (added BEFORE the rotation) moves here too.
+                const int P = b & 1;
+                const float rqs = fw + P * 64 < p.rot_qfeat ? p.rot_qscale : 1.0f;
+                float4_t bj[4];
 #pragma unroll
-            for (int tt = 0; tt < 2; ++tt)
+                for (int jj = 0; jj < 4; ++jj) {
+                    bj[jj] = float4_t{0.f, 0.f, 0.f, 0.f};
+                    if (p.bias != nullptr) bj[jj] = *(const float4_t*)(p.bias + fw + 64 * P + 16 * jj + 4 * g);
+                }
 #pragma unroll
-                for (int jj = 0; jj < 4; ++jj)
-                    *(float4_t*)(scratch + (16 * tt + c16) * 256 + (((4 * jj + g) ^ c16) << 4)) = acc[2 * (b >> 1) + tt][4 * (b & 1) + jj];
+                for (int tt = 0; tt < 2; ++tt) {
+                    const int i = 2 * (b >> 1) + tt;
+                    int pos = pos16 + 16 * i;
+                    pos = pos >= p.rot_T ? pos - p.rot_T : pos;
+                    const float* cs = p.rot_cs + (long)pos * 64 + 8 * g;          // (cos, sin) of dims 4 g .. 4 g + 3; + 32 floats: dims 16 + 4 g ..
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) {
+                        const float4_t ca = *(const float4_t*)(cs + 32 * t), cb = *(const float4_t*)(cs + 32 * t + 4);
+                        const float cc[4] = {ca[0] * rqs, ca[2] * rqs, cb[0] * rqs, cb[2] * rqs}, ss[4] = {ca[1] * rqs, ca[3] * rqs, cb[1] * rqs, cb[3] * rqs};
+                        const float4_t lo = w4_acc_read(acc[i][4 * P + t]) + bj[t], hi = w4_acc_read(acc[i][4 * P + 2 + t]) + bj[2 + t];
+                        float4_t lo2, hi2;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            lo2[r] = lo[r] * cc[r] - hi[r] * ss[r];
+                            hi2[r] = hi[r] * cc[r] + lo[r] * ss[r];
+                        }
+                        *(float4_t*)(scratch + (16 * tt + c16) * 256 + (((4 * t + g) ^ c16) << 4)) = lo2;
+                        *(float4_t*)(scratch + (16 * tt + c16) * 256 + (((4 * (t + 2) + g) ^ c16) << 4)) = hi2;
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj)
+                        *(float4_t*)(scratch + (16 * tt + c16) * 256 + (((4 * jj + g) ^ c16) << 4)) = acc[2 * (b >> 1) + tt][4 * (b & 1) + jj];
+            }
         } else {
             // the lane's 32 features of one token: tiles j = 2 P, 2 P + 1
             const float16_t& a0 = acc[b >> 1][2 * (b & 1)];
@@ -701,16 +751,24 @@ __device__ __forceinline__ bool w4_epilogue(const GemmArgs& p, ACC& acc, int f0,
             if (b + 1 < 8) write_block(b + 1);
             const bool rot_here = rot && fw + P * 64 < p.rot_nfeat;
             const float rqs = fw + P * 64 < p.rot_qfeat ? p.rot_qscale : 1.0f;
+            // (T16: a rotated block arrives rotated, bias included - write_block)
+            const float bsel = (rot && T16 && rot_here) ? 0.0f : 1.0f;
 #pragma unroll
             for (int rr = 0; rr < 4; ++rr) {
-                float v[8] = {lo[rr][0] + bq[P][0], lo[rr][1] + bq[P][1], lo[rr][2] + bq[P][2], lo[rr][3] + bq[P][3],
-                              hi[rr][0] + bq[P][4], hi[rr][1] + bq[P][5], hi[rr][2] + bq[P][6], hi[rr][3] + bq[P][7]};
+                float v[8];
+                if constexpr (rot && T16) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { v[e] = fmaf(bq[P][e], bsel, lo[rr][e]); v[4 + e] = fmaf(bq[P][4 + e], bsel, hi[rr][e]); }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { v[e] = lo[rr][e] + bq[P][e]; v[4 + e] = hi[rr][e] + bq[P][4 + e]; }
+                }
                 if constexpr (has_res) {
                     const half8_t r8 = __builtin_bit_cast(half8_t, rres[rr]);
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] += p.res_scale * (float)r8[e];
                 }
-                if constexpr (rot) {
+                if constexpr (rot && !T16) {
                     if (rot_here) {
                         // rotary embedding of the packed Wqkv projection (see gemm_epilogue): the 64-feature pair is one head, lanes q < 4
                         // hold its first half, q >= 4 the second; the partner of dim d is dim d +- 32 = lane ^ 4, same index
