@@ -611,6 +611,29 @@ struct W4Store {
 // four accumulation registers -> vector registers. The reads sit inside a volatile statement on purpose: as plain copies they are common to the
 // full-tile and the ragged-tile instance of the epilogue, and the compiler hoists ALL of a tile's reads in front of that branch (256 live
 // registers, every parked row spilled - seen with an epilogue that read the accumulators through plain copies, round 6)
+// ... and a token tile's whole row of eight quads in ONE statement: the statements are scheduling boundaries, and an epilogue that reads quad by
+// quad runs its ~20-instruction dependent chain (exp -> add -> rcp -> mul -> mul -> cvt) one quad at a time, at the vector ALU's latency
+// (SwiGLU: 9.3 k cycles per tile that way)
+__device__ __forceinline__ void w4_acc_read8(const float4_t (&a)[8], float4_t (&x)[8]) {
+    float f[32];
+    asm volatile("v_accvgpr_read_b32 %0, %32\n\tv_accvgpr_read_b32 %1, %33\n\tv_accvgpr_read_b32 %2, %34\n\tv_accvgpr_read_b32 %3, %35\n\t"
+                 "v_accvgpr_read_b32 %4, %36\n\tv_accvgpr_read_b32 %5, %37\n\tv_accvgpr_read_b32 %6, %38\n\tv_accvgpr_read_b32 %7, %39\n\t"
+                 "v_accvgpr_read_b32 %8, %40\n\tv_accvgpr_read_b32 %9, %41\n\tv_accvgpr_read_b32 %10, %42\n\tv_accvgpr_read_b32 %11, %43\n\t"
+                 "v_accvgpr_read_b32 %12, %44\n\tv_accvgpr_read_b32 %13, %45\n\tv_accvgpr_read_b32 %14, %46\n\tv_accvgpr_read_b32 %15, %47\n\t"
+                 "v_accvgpr_read_b32 %16, %48\n\tv_accvgpr_read_b32 %17, %49\n\tv_accvgpr_read_b32 %18, %50\n\tv_accvgpr_read_b32 %19, %51\n\t"
+                 "v_accvgpr_read_b32 %20, %52\n\tv_accvgpr_read_b32 %21, %53\n\tv_accvgpr_read_b32 %22, %54\n\tv_accvgpr_read_b32 %23, %55\n\t"
+                 "v_accvgpr_read_b32 %24, %56\n\tv_accvgpr_read_b32 %25, %57\n\tv_accvgpr_read_b32 %26, %58\n\tv_accvgpr_read_b32 %27, %59\n\t"
+                 "v_accvgpr_read_b32 %28, %60\n\tv_accvgpr_read_b32 %29, %61\n\tv_accvgpr_read_b32 %30, %62\n\tv_accvgpr_read_b32 %31, %63"
+                 : "=v"(f[0]), "=v"(f[1]), "=v"(f[2]), "=v"(f[3]), "=v"(f[4]), "=v"(f[5]), "=v"(f[6]), "=v"(f[7]), "=v"(f[8]), "=v"(f[9]), "=v"(f[10]),
+                   "=v"(f[11]), "=v"(f[12]), "=v"(f[13]), "=v"(f[14]), "=v"(f[15]), "=v"(f[16]), "=v"(f[17]), "=v"(f[18]), "=v"(f[19]), "=v"(f[20]),
+                   "=v"(f[21]), "=v"(f[22]), "=v"(f[23]), "=v"(f[24]), "=v"(f[25]), "=v"(f[26]), "=v"(f[27]), "=v"(f[28]), "=v"(f[29]), "=v"(f[30]), "=v"(f[31])
+                 : "a"(a[0][0]), "a"(a[0][1]), "a"(a[0][2]), "a"(a[0][3]), "a"(a[1][0]), "a"(a[1][1]), "a"(a[1][2]), "a"(a[1][3]), "a"(a[2][0]), "a"(a[2][1]),
+                   "a"(a[2][2]), "a"(a[2][3]), "a"(a[3][0]), "a"(a[3][1]), "a"(a[3][2]), "a"(a[3][3]), "a"(a[4][0]), "a"(a[4][1]), "a"(a[4][2]), "a"(a[4][3]),
+                   "a"(a[5][0]), "a"(a[5][1]), "a"(a[5][2]), "a"(a[5][3]), "a"(a[6][0]), "a"(a[6][1]), "a"(a[6][2]), "a"(a[6][3]), "a"(a[7][0]), "a"(a[7][1]),
+                   "a"(a[7][2]), "a"(a[7][3]));
+#pragma unroll
+    for (int j = 0; j < 8; ++j) x[j] = float4_t{f[4 * j], f[4 * j + 1], f[4 * j + 2], f[4 * j + 3]};
+}
 __device__ __forceinline__ float4_t w4_acc_read(const float4_t& a) {
     float x0, x1, x2, x3;
     asm volatile("v_accvgpr_read_b32 %0, %4\n\tv_accvgpr_read_b32 %1, %5\n\tv_accvgpr_read_b32 %2, %6\n\tv_accvgpr_read_b32 %3, %7"
@@ -817,16 +840,124 @@ __device__ __forceinline__ bool w4_epilogue(const GemmArgs& p, ACC& acc, int f0,
     return false;
 }
 
+// SwiGLU epilogue of one wave around the 16x16x32 stream (round 6). The accumulator layout holds a lane's FOUR consecutive features of a token: the
+// (y, gate) pairs are lane-local, so the activation runs BEFORE the transposition and what crosses the LDS is the final fp16 - 2 halves per
+// accumulator quad, 16 KiB per wave tile each way where w4_epilogue moves 64 KiB of fp32 each way - and a token's 64 outputs are exactly one
+// 128-byte line: 16 stores of 8 rows x 128 bytes per lane and tile instead of 32 stores of 8 rows x 64 bytes.
+// Block blk = 32 tokens (token tiles 2 blk, 2 blk + 1) x the wave's 64 outputs = 4 KiB of the scratch (double buffered: 8 KiB). Lane (g = l >> 4,
+// c = l & 15) writes outputs 8 j + 2 g, + 1 of token r = 16 tt + c as one dword at r * 128 + 16 (j ^ ((r >> 1) & 7)) + 4 g - the sixteen tokens
+// x four g of a ds_write_b32 fall on 64 different banks - and lane (tl = l >> 3, q = l & 7) reads the 16 bytes of piece q of row tl + 8 rr.
+// Unit u = 4 blk + rr (token row 32 blk + 8 rr of the wave): u < W4_NOWG is stored here, the rest parked (gemm_ktile16_st4g).
+template <typename PARK>
+__device__ __forceinline__ bool w4_epilogue16g(const GemmArgs& p, float4_t (&acc)[8][8], int f0, int t0, int wa, int wb, int lane, char* scratch,
+                                               PARK (&park)[W4_NPARKG], W4Store& st) {
+    asm volatile("" : "+v"(lane));
+    const int g = lane >> 4, c16 = lane & 15;
+    const int tl = lane >> 3, q = lane & 7;
+    const int fw = f0 + wb * 128, tw = t0 + wa * 128;
+    const bool ident = p.row_div == 1 && p.row_s_hi == 1;
+    const int hi_u = ident ? 0 : t0 / p.row_div;
+    const int mlim = ident ? p.M : min(p.M, hi_u * p.row_div + p.row_lim);
+    const long o0 = ident ? (long)tw : (long)hi_u * p.row_s_hi + (long)(tw - hi_u * p.row_div) * p.row_s_lo;
+    const int rowbytes = (ident ? 1 : (int)p.row_s_lo) * p.ldo * 2;
+    half_t* const obase = p.out + o0 * p.ldo + (fw >> 1);
+    const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc((void*)obase, 0, 0x7ffffff0, 0x00020000);
+    const int ovoff = tl * rowbytes + 16 * q;
+    {
+        const unsigned long long ob = (unsigned long long)obase;
+        st.srd = uint4_t{(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)ob),
+                         (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)(ob >> 32) & 0xffffu)), 0x7ffffff0u, 0x00020000u};
+        st.voff = (unsigned)ovoff;
+        st.rowb = (unsigned)__builtin_amdgcn_readfirstlane(rowbytes);
+    }
+    float4_t bj[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        bj[j] = float4_t{0.f, 0.f, 0.f, 0.f};
+        if (p.bias != nullptr) bj[j] = *(const float4_t*)(p.bias + fw + 16 * j + 4 * g);
+    }
+    auto write_block = [&](int blk, auto with_bias) {
+        char* const base = scratch + (blk & 1) * 4096;
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+            const int r = 16 * tt + c16, sw = (c16 >> 1) & 7;
+            float4_t row[8];
+            w4_acc_read8(acc[2 * blk + tt], row);
+            // W rows interleaved on the host: feature 2 k = y_k, 2 k + 1 = gate_k. Stage by stage over the row's sixteen outputs (independent
+            // instructions back to back: the chain's latency is paid once per stage, not once per output)
+            float yv[16], gv[16], ev[16];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float4_t a = row[j];
+                if constexpr (decltype(with_bias)::value) a += bj[j];
+                yv[2 * j] = a[0]; gv[2 * j] = a[1]; yv[2 * j + 1] = a[2]; gv[2 * j + 1] = a[3];
+            }
+#pragma unroll
+            for (int k = 0; k < 16; ++k) ev[k] = gv[k] * -1.4426950408889634f;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) ev[k] = __builtin_amdgcn_exp2f(ev[k]);
+#pragma unroll
+            for (int k = 0; k < 16; ++k) ev[k] = 1.0f + ev[k];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) ev[k] = __builtin_amdgcn_rcpf(ev[k]);
+#pragma unroll
+            for (int k = 0; k < 16; ++k) yv[k] = yv[k] * (gv[k] * ev[k]);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                typedef float float2_t __attribute__((ext_vector_type(2)));
+                const float2_t y = {yv[2 * j], yv[2 * j + 1]};
+                *(unsigned*)(base + r * 128 + ((j ^ sw) << 4) + 4 * g) = __builtin_bit_cast(unsigned, __builtin_convertvector(y, half2_t));
+            }
+        }
+    };
+    // (the epilogue is bound by its vector instructions - ~25 per accumulator quad, one wave per SIMD; bonito's GatedMlp has no bias, and its 256
+    // additions of zero per lane and tile were 16 % of them: the full-tile instance exists with and without, the ragged one with)
+    auto blocks = [&](auto masked, auto with_bias) {
+        constexpr bool MASKED = decltype(masked)::value;
+        write_block(0, with_bias);
+#pragma unroll
+        for (int blk = 0; blk < 4; ++blk) {
+            uint4_t o[4];
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                const int row = tl + 8 * rr;
+                o[rr] = *(const uint4_t*)(scratch + (blk & 1) * 4096 + row * 128 + ((q ^ ((row >> 1) & 7)) << 4));
+            }
+            if (blk + 1 < 4) write_block(blk + 1, with_bias);
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                const int u = 4 * blk + rr;
+                const bool live = !MASKED || tw + 32 * blk + 8 * rr + tl < mlim;
+                if constexpr (!MASKED) { if (u >= W4_NOWG) park[u - W4_NOWG] = o[rr]; }
+                if ((!MASKED && u < W4_NOWG) || (MASKED && live)) __builtin_amdgcn_raw_buffer_store_b128(o[rr], orsrc, ovoff + (32 * blk + 8 * rr) * rowbytes, 0, 0);
+            }
+        }
+    };
+    if (tw + 128 <= mlim) {
+        if (p.bias != nullptr) blocks(std::false_type{}, std::true_type{});
+        else blocks(std::false_type{}, std::false_type{});
+        return true;
+    }
+    blocks(std::true_type{}, std::true_type{});
+    return false;
+}
+
 // the parked rows of a tile that no K loop follows
 template <bool GATED, bool T16, typename PARK, int NP>
 __device__ __forceinline__ void w4_store_parked(const PARK (&park)[NP], const W4Store& st) {
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
         (void*)(((unsigned long long)st.srd[1] << 32) | st.srd[0]), 0, 0x7ffffff0, 0x00020000);
+    if constexpr (GATED && T16) {               // w4_epilogue16g: whole 128-byte rows
+#pragma unroll
+        for (int idx = 0; idx < NP; ++idx) __builtin_amdgcn_raw_buffer_store_b128(park[idx], rsrc, st.voff + w4_store_rowg(idx) * st.rowb, 0, 0);
+        return;
+    } else {
 #pragma unroll
     for (int idx = 0; idx < NP; ++idx) {
         const int row = T16 ? w4_store_row16(idx) : w4_store_row(idx), col = T16 ? w4_store_col16(idx) : w4_store_col(idx);
         if constexpr (GATED) __builtin_amdgcn_raw_buffer_store_b64(park[idx], rsrc, st.voff + col * 64 + row * st.rowb, 0, 0);
         else __builtin_amdgcn_raw_buffer_store_b128(park[idx], rsrc, st.voff + col * 128 + row * st.rowb, 0, 0);
+    }
     }
 }
 
@@ -835,7 +966,7 @@ template <int IDX0, int S, bool WIDE, bool FIRST, typename PARK>
 __device__ __forceinline__ void w4_inst_st(float16_t (&acc)[4][4], half8_t (&fa)[2][4], half8_t (&fb)[2][4], const unsigned (&rab)[4],
                                            const unsigned (&rbb)[4], unsigned sa, unsigned sb, unsigned san, unsigned sbn, const unsigned (&vd1)[8],
                                            const unsigned (&vd2)[8], const char* sd1, const char* sd2, unsigned md1, unsigned md2, unsigned,
-                                           const PARK (&park)[W4_NPARK], const W4Store& st) {
+                                           const PARK (&park)[W4_NPARK], const W4Store& st, std::false_type) {
     if constexpr (S == 4 && WIDE && !FIRST) gemm_ktile_st4w<IDX0>(acc, fa, fb, rab, rbb, sa, sb, san, sbn, vd1, vd2, sd1, sd2, md1, md2, park, st.srd, st.voff, st.rowb);
     else if constexpr (S == 4 && WIDE && FIRST) gemm_ktile_first_st4w<IDX0>(acc, fa, fb, rab, rbb, sa, sb, san, sbn, vd1, vd2, sd1, sd2, md1, md2, park, st.srd, st.voff, st.rowb);
     else if constexpr (S == 4 && !WIDE && !FIRST) gemm_ktile_st4n<IDX0>(acc, fa, fb, rab, rbb, sa, sb, san, sbn, vd1, vd2, sd1, sd2, md1, md2, park, st.srd, st.voff, st.rowb);
@@ -843,11 +974,20 @@ __device__ __forceinline__ void w4_inst_st(float16_t (&acc)[4][4], half8_t (&fa)
     else static_assert(S == 4, "tools/gen_gemmstep.py emits the four-stores-per-instance variants only");
 }
 
+template <int IDX0, int S, bool WIDE, bool FIRST>
+__device__ __forceinline__ void w4_inst_st(float4_t (&acc)[8][8], half8_t (&fa)[8], half8_t (&fb)[2][8], const unsigned (&rab)[2],
+                                           const unsigned (&rbb)[2], unsigned sa, unsigned sb, unsigned san, unsigned sbn, const unsigned (&vd1)[8],
+                                           const unsigned (&vd2)[8], const char* sd1, const char* sd2, unsigned md1, unsigned md2, unsigned wv,
+                                           const uint4_t (&park)[W4_NPARKG], const W4Store& st, std::true_type /* SwiGLU rows: w4_epilogue16g */) {
+    static_assert(S == 4, "tools/gen_gemmstep.py emits the four-stores-per-instance variants only");
+    if constexpr (!FIRST) gemm_ktile16_st4g<IDX0>(acc, fa, fb, rab, rbb, sa, sb, san, sbn, vd1, vd2, sd1, sd2, md1, md2, wv, park, st.srd, st.voff, st.rowb);
+    else gemm_ktile16_first_st4g<IDX0>(acc, fa, fb, rab, rbb, sa, sb, san, sbn, vd1, vd2, sd1, sd2, md1, md2, wv, park, st.srd, st.voff, st.rowb);
+}
 template <int IDX0, int S, bool WIDE, bool FIRST, typename PARK>
 __device__ __forceinline__ void w4_inst_st(float4_t (&acc)[8][8], half8_t (&fa)[8], half8_t (&fb)[2][8], const unsigned (&rab)[2],
                                            const unsigned (&rbb)[2], unsigned sa, unsigned sb, unsigned san, unsigned sbn, const unsigned (&vd1)[8],
                                            const unsigned (&vd2)[8], const char* sd1, const char* sd2, unsigned md1, unsigned md2, unsigned wv,
-                                           const PARK (&park)[W4_NPARK16], const W4Store& st) {
+                                           const PARK (&park)[W4_NPARK16], const W4Store& st, std::false_type) {
     if constexpr (S == 4 && WIDE && !FIRST) gemm_ktile16_st4w<IDX0>(acc, fa, fb, rab, rbb, sa, sb, san, sbn, vd1, vd2, sd1, sd2, md1, md2, wv, park, st.srd, st.voff, st.rowb);
     else if constexpr (S == 4 && WIDE && FIRST) gemm_ktile16_first_st4w<IDX0>(acc, fa, fb, rab, rbb, sa, sb, san, sbn, vd1, vd2, sd1, sd2, md1, md2, wv, park, st.srd, st.voff, st.rowb);
     else if constexpr (S == 4 && !WIDE && !FIRST) gemm_ktile16_st4n<IDX0>(acc, fa, fb, rab, rbb, sa, sb, san, sbn, vd1, vd2, sd1, sd2, md1, md2, wv, park, st.srd, st.voff, st.rowb);
@@ -995,8 +1135,9 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(GemmArgs p) {
     unsigned long long st_loop = 0, st_epi = 0, st_tiles = 0;
     const unsigned long long st_t0 = __builtin_readcyclecounter(), st_r0 = __builtin_amdgcn_s_memrealtime();
 #endif
-    using park_t = std::conditional_t<GATED, uint2_t, uint4_t>;
-    constexpr int NPARK = T16 ? W4_NPARK16 : W4_NPARK;
+    constexpr bool G16 = GATED && T16;                       // SwiGLU outputs in whole 128-byte rows (w4_epilogue16g)
+    using park_t = std::conditional_t<GATED && !T16, uint2_t, uint4_t>;
+    constexpr int NPARK = G16 ? W4_NPARKG : T16 ? W4_NPARK16 : W4_NPARK;
     constexpr int NST = (NPARK + S - 1) / S;                 // K-tile instances that carry parked rows (nk >= NST: the launcher)
     park_t park[NPARK];
     W4Store pst;
@@ -1021,7 +1162,7 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(GemmArgs p) {
 #define W4_ARGS acc, fa, fb, rab, rbb, a0, b0, a1, b1, va, vb, dA, dB, a2 + wdma, b0 + wdma, (unsigned)wave
         if (parked) {
             // the first NST instances also issue the previous tile's parked rows
-#define W4_ST(T) if constexpr ((T) < NST) { W4_CURSOR(T); w4_inst_st<(T) * S, S, !GATED, (T) == 0>(W4_ARGS, park, pst); W4_ROTATE(); }
+#define W4_ST(T) if constexpr ((T) < NST) { W4_CURSOR(T); w4_inst_st<(T) * S, S, !GATED, (T) == 0>(W4_ARGS, park, pst, std::bool_constant<G16>{}); W4_ROTATE(); }
             W4_ST(0) W4_ST(1) W4_ST(2) W4_ST(3) W4_ST(4) W4_ST(5) W4_ST(6) W4_ST(7)
 #undef W4_ST
             for (int k = NST; k < nk; ++k) {
@@ -1046,7 +1187,8 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(GemmArgs p) {
 #endif
         w4_settle(acc);
         // (a2: the A stage the last K-tile has just vacated - the next instance's D1 target - serves as the transposition scratch)
-        parked = w4_epilogue<ACT, GATED, MODE>(p, acc, f0, t0, wa, wb, lane, smem + a2 + wdma, park, pst);
+        if constexpr (G16) parked = w4_epilogue16g(p, acc, f0, t0, wa, wb, lane, smem + a2 + wdma, park, pst);
+        else parked = w4_epilogue<ACT, GATED, MODE>(p, acc, f0, t0, wa, wb, lane, smem + a2 + wdma, park, pst);
 #ifdef BH_GEMM_STATS
         st_loop += st_b - st_a; st_epi += __builtin_readcyclecounter() - st_b; ++st_tiles;
 #endif

@@ -35,6 +35,9 @@ VARIANTS = {
     "t16_now12": ["--tile16", "--now16", "12"],
     "t16_now16": ["--tile16", "--now16", "16"],
     "t16_now24": ["--tile16", "--now16", "24"],
+    "t16_nowg0": ["--tile16", "--nowg", "0"],
+    "t16_nowg4": ["--tile16", "--nowg", "4"],
+    "t16_nowg12": ["--tile16", "--nowg", "12"],
     "t16_s16": ["--tile16", "--stagger", "16"],
     "t16_mfma": ["--tile16", "--strip", "dma,lds,bar"],
     "t16_nodma": ["--tile16", "--strip", "dma"],

@@ -189,7 +189,7 @@ def build(wait_at=2, read_at=1, d1_at=0, d1_every=2, d2_every=1, first=False, na
 
 
 def build16(barrier_at=78, read_every=3, d1_at=0, d1_every=4, d2_every=4, first=False, name="gemm_ktile16", strip=(), dma_flags="", stores=0, wide=True,
-            st_at=1, st_every=4, stagger=0):
+            st_at=1, st_every=4, stagger=0, swiglu=False):
     """The same K-tile on v_mfma_f32_16x16x32_f16 (round 6: under the board's power cap a hand-scheduled LDS-fed 128 x 128 wave tile runs 14 %
     faster on the small tile - tools/gen_tile_probe.py, profiles/r06_mfma_tile_energy_lds.txt).
 
@@ -310,6 +310,11 @@ def build16(barrier_at=78, read_every=3, d1_at=0, d1_every=4, d2_every=4, first=
     if stores:
         outs.append('[stt] "=&s"(stt)')
         for n in range(stores):
+            if swiglu:      # gemm.hip, w4_epilogue16g: 16 whole 128-byte output rows per lane and tile, no column offset
+                ins.append('[pk%d] "v"(park[(IDX0 + %d) %% W4_NPARKG])' % (n, n))
+                ins.append('[k%d] "n"(w4_store_rowg((IDX0 + %d) %% W4_NPARKG))' % (n, n))
+                ins.append('[o%d] "n"(0)' % n)
+                continue
             ins.append('[pk%d] "v"(park[(IDX0 + %d) %% W4_NPARK16])' % (n, n))
             ins.append('[k%d] "n"(w4_store_row16((IDX0 + %d) %% W4_NPARK16))' % (n, n))
             ins.append('[o%d] "n"(w4_store_col16((IDX0 + %d) %% W4_NPARK16) * %d)' % (n, n, 128 if wide else 64))
@@ -319,11 +324,11 @@ def build16(barrier_at=78, read_every=3, d1_at=0, d1_every=4, d2_every=4, first=
     text = []
     text.append("// %s<%s>: barrier_at=%d read_every=%d d1_at=%d d1_every=%d d2_every=%d stagger=%d stores=%d%s : %s" % (
         name, "FIRST" if first else "", barrier_at, read_every, d1_at, d1_every, d2_every, stagger, stores, ("" if not stores else (" x16B" if wide else " x8B")), stat))
-    fname = name + ("_first" if first else "") + (("_st%d%s" % (stores, "w" if wide else "n")) if stores else "")
+    fname = name + ("_first" if first else "") + (("_st%d%s" % (stores, "g" if swiglu else "w" if wide else "n")) if stores else "")
     sig = ("__device__ __forceinline__ void %s(float4_t (&acc)[8][8], half8_t (&fa)[8], half8_t (&fb)[2][8], "
            "const unsigned (&rab)[2], const unsigned (&rbb)[2], unsigned sa, unsigned sb, unsigned san, unsigned sbn, const unsigned (&vd1)[8], "
            "const unsigned (&vd2)[8], const char* sd1, const char* sd2, unsigned md1, unsigned md2, unsigned wv%s) {" % (
-               fname, (", const %s (&park)[W4_NPARK16], uint4_t srd, unsigned stv, unsigned rowb" % ("uint4_t" if wide else "uint2_t")) if stores else ""))
+               fname, (", const %s (&park)[%s], uint4_t srd, unsigned stv, unsigned rowb" % ("uint4_t" if wide else "uint2_t", "W4_NPARKG" if swiglu else "W4_NPARK16")) if stores else ""))
     if stores:
         text.append("template <int IDX0>")
     text.append(sig)
@@ -358,6 +363,7 @@ def main():
     ap.add_argument("--st-every", type=int, default=4)
     ap.add_argument("--stagger", type=int, default=0, help="--tile16: cycles by which wave w leaves the K-tile's barrier late (times w)")
     ap.add_argument("--d2-every16", type=int, default=4, help="--tile16: MFMAs between the DMA pieces behind the barrier")
+    ap.add_argument("--nowg", type=int, default=8, help="--tile16: of the 16 stores of a SwiGLU tile, those the epilogue issues itself")
     ap.add_argument("--now16", type=int, default=20, help="--tile16: output rows (of 32 per lane) the epilogue stores itself; the rest is parked")
     a = ap.parse_args()
     if a.tile16:
@@ -372,11 +378,18 @@ def main():
                 "#ifndef W4_NOW16_VALUE\n#define W4_NOW16_VALUE %d\n#endif\n"
                 "constexpr int W4_NOW16 = W4_NOW16_VALUE, W4_NPARK16 = 32 - W4_NOW16;\n"
                 "constexpr int w4_store_row16(int idx) { return 32 * ((idx + W4_NOW16) >> 3) + 8 * (idx & 3); }\n"
-                "constexpr int w4_store_col16(int idx) { return ((idx + W4_NOW16) >> 2) & 1; }\n" % a.now16)
+                "constexpr int w4_store_col16(int idx) { return ((idx + W4_NOW16) >> 2) & 1; }\n"
+                "// SwiGLU outputs (w4_epilogue16g): a tile is 16 stores per lane (unit u = 4 blk + rr: token row 32 blk + 8 rr of the wave, the whole\n"
+                "// 128-byte output row); the first W4_NOWG go out in the epilogue, the others are parked.\n"
+                "#ifndef W4_NOWG_VALUE\n#define W4_NOWG_VALUE %d\n#endif\n"
+                "constexpr int W4_NOWG = W4_NOWG_VALUE, W4_NPARKG = 16 - W4_NOWG;\n"
+                "constexpr int w4_store_rowg(int idx) { return 32 * ((idx + W4_NOWG) >> 2) + 8 * ((idx + W4_NOWG) & 3); }\n" % (a.now16, a.nowg))
         text += build16(first=False, **kw) + "\n" + build16(first=True, **kw)
         for wide in (True, False):
             for first in (False, True):
                 text += "\n" + build16(first=first, stores=4, wide=wide, st_at=a.st_at, st_every=a.st_every, **kw)
+        for first in (False, True):
+            text += "\n" + build16(first=first, stores=4, wide=True, swiglu=True, st_at=a.st_at, st_every=a.st_every, **kw)
         path = a.out or os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bonito_amd", "csrc", "gemm_ktile16_mfma.inc")
         with open(path, "w") as f:
             f.write(text)
