@@ -608,12 +608,11 @@ struct W4Store {
 
 // MODE (compile time, so that the block loop is straight-line code the compiler can software-pipeline; with run-time flags every
 // `if` inside it was a join with full s_waitcnt's: 9.5 k cycles per tile whatever the stores did): 1 = residual, 2 = rotary, 4 = scale / clamp
-// four accumulation registers -> vector registers. The reads sit inside a volatile statement on purpose: as plain copies they are common to the
-// full-tile and the ragged-tile instance of the epilogue, and the compiler hoists ALL of a tile's reads in front of that branch (256 live
-// registers, every parked row spilled - seen with an epilogue that read the accumulators through plain copies, round 6)
-// ... and a token tile's whole row of eight quads in ONE statement: the statements are scheduling boundaries, and an epilogue that reads quad by
-// quad runs its ~20-instruction dependent chain (exp -> add -> rcp -> mul -> mul -> cvt) one quad at a time, at the vector ALU's latency
-// (SwiGLU: 9.3 k cycles per tile that way)
+// ... and a token tile's whole row of eight quads. Why statements, and why several quads per statement: (i) as plain copies the reads are common
+// to the full-tile and the ragged-tile instance of an epilogue, and the compiler hoists ALL of a tile's reads in front of that branch (256 live
+// registers, every parked row spilled); (ii) the statements are scheduling boundaries, and an epilogue that reads quad by quad runs its
+// ~20-instruction dependent chain (exp -> add -> rcp -> mul -> mul -> cvt) one quad at a time, at the vector ALU's latency (SwiGLU: 9.3 k
+// cycles per tile that way, 7.6 k with a row per statement and the math written stage by stage)
 __device__ __forceinline__ void w4_acc_read8(const float4_t (&a)[8], float4_t (&x)[8]) {
     float f[32];
     asm volatile("v_accvgpr_read_b32 %0, %32\n\tv_accvgpr_read_b32 %1, %33\n\tv_accvgpr_read_b32 %2, %34\n\tv_accvgpr_read_b32 %3, %35\n\t"
@@ -634,14 +633,24 @@ __device__ __forceinline__ void w4_acc_read8(const float4_t (&a)[8], float4_t (&
 #pragma unroll
     for (int j = 0; j < 8; ++j) x[j] = float4_t{f[4 * j], f[4 * j + 1], f[4 * j + 2], f[4 * j + 3]};
 }
-__device__ __forceinline__ float4_t w4_acc_read(const float4_t& a) {
-    float x0, x1, x2, x3;
-    asm volatile("v_accvgpr_read_b32 %0, %4\n\tv_accvgpr_read_b32 %1, %5\n\tv_accvgpr_read_b32 %2, %6\n\tv_accvgpr_read_b32 %3, %7"
-                 : "=v"(x0), "=v"(x1), "=v"(x2), "=v"(x3)
-                 : "a"(a[0]), "a"(a[1]), "a"(a[2]), "a"(a[3]));
-    return float4_t{x0, x1, x2, x3};
+// accumulation registers -> vector registers: four quads a[j0 .. j0 + 3] in one volatile statement ...
+__device__ __forceinline__ void w4_acc_read4(const float4_t (&a)[8], int j0, float4_t (&x)[4]) {
+    float f[16];
+    asm volatile("v_accvgpr_read_b32 %0, %16\n\tv_accvgpr_read_b32 %1, %17\n\tv_accvgpr_read_b32 %2, %18\n\tv_accvgpr_read_b32 %3, %19\n\t"
+                 "v_accvgpr_read_b32 %4, %20\n\tv_accvgpr_read_b32 %5, %21\n\tv_accvgpr_read_b32 %6, %22\n\tv_accvgpr_read_b32 %7, %23\n\t"
+                 "v_accvgpr_read_b32 %8, %24\n\tv_accvgpr_read_b32 %9, %25\n\tv_accvgpr_read_b32 %10, %26\n\tv_accvgpr_read_b32 %11, %27\n\t"
+                 "v_accvgpr_read_b32 %12, %28\n\tv_accvgpr_read_b32 %13, %29\n\tv_accvgpr_read_b32 %14, %30\n\tv_accvgpr_read_b32 %15, %31"
+                 : "=v"(f[0]), "=v"(f[1]), "=v"(f[2]), "=v"(f[3]), "=v"(f[4]), "=v"(f[5]), "=v"(f[6]), "=v"(f[7]), "=v"(f[8]), "=v"(f[9]), "=v"(f[10]),
+                   "=v"(f[11]), "=v"(f[12]), "=v"(f[13]), "=v"(f[14]), "=v"(f[15])
+                 : "a"(a[j0][0]), "a"(a[j0][1]), "a"(a[j0][2]), "a"(a[j0][3]), "a"(a[j0 + 1][0]), "a"(a[j0 + 1][1]), "a"(a[j0 + 1][2]), "a"(a[j0 + 1][3]),
+                   "a"(a[j0 + 2][0]), "a"(a[j0 + 2][1]), "a"(a[j0 + 2][2]), "a"(a[j0 + 2][3]), "a"(a[j0 + 3][0]), "a"(a[j0 + 3][1]), "a"(a[j0 + 3][2]),
+                   "a"(a[j0 + 3][3]));
+#pragma unroll
+    for (int j = 0; j < 4; ++j) x[j] = float4_t{f[4 * j], f[4 * j + 1], f[4 * j + 2], f[4 * j + 3]};
 }
 
+// (The 16x16x32 stream uses this function for the fused residual only - MODE 1, ACC = float4_t[8][8]: its accumulators go straight from the
+// AGPRs into the same scratch image; every other epilogue of that stream works in the accumulator layout: w4_epilogue16p / w4_epilogue16g.)
 template <int ACT, bool GATED, int MODE, typename ACC, typename PARK, int NP>
 __device__ __forceinline__ bool w4_epilogue(const GemmArgs& p, ACC& acc, int f0, int t0, int wa, int wb, int lane, char* scratch,
                                             PARK (&park)[NP], W4Store& st) {
@@ -684,7 +693,6 @@ __device__ __forceinline__ bool w4_epilogue(const GemmArgs& p, ACC& acc, int f0,
     constexpr bool rot = !GATED && (MODE & 2) != 0;
     const float rsgn = q < 4 ? -1.0f : 1.0f;
     const int pos0 = rot ? (tw + tl) % p.rot_T : 0;                              // position of the lane's first row (rot_T >= 256: one wrap at most)
-    const int pos16 = rot && T16 ? (tw + (lane & 15)) % p.rot_T : 0;            // T16: of the lane's token in token tile 0 of the accumulator layout
     const float* const cs0 = p.rot_cs + (q & 3) * 16;
     char* const wrow = scratch + col * 256;
     const int wx = col & 15;
@@ -693,49 +701,11 @@ __device__ __forceinline__ bool w4_epilogue(const GemmArgs& p, ACC& acc, int f0,
             // lane (g = l >> 4, c16 = l & 15): piece 4 jj + g (features 16 jj + 4 g .. + 3 of the pair) of token 16 tt + c16; an 8-lane group of
             // the ds_write_b128 is eight tokens x one piece = eight positions piece ^ token: conflict free like the 32x32 layout's
             const int g = lane >> 4, c16 = lane & 15;
-            bool rotb = false;
-            if constexpr (rot) rotb = fw + (b & 1) * 64 < p.rot_nfeat;       // (wave uniform) this 64-feature pair is one rotated head
-            if (rotb) {
-                // Rotary embedding in the ACCUMULATOR layout (round 6): the partner of dim d, d +- 32, is the same lane's tile jj +- 2 - no
-                // cross-lane traffic - and a lane's cos / sin (dims 4 g .. + 3 and 16 + 4 g .. + 3 of its token) serve the whole head: 8
-                // table loads per block where the transposed layout needed 16 loads and 32 ds_bpermute per block (the Wqkv GEMM ran at
-                // 690 TFLOP/s against 950 for the same shape without the rotation). Bias (added BEFORE the rotation) moves here too.
-                const int P = b & 1;
-                const float rqs = fw + P * 64 < p.rot_qfeat ? p.rot_qscale : 1.0f;
-                float4_t bj[4];
 #pragma unroll
-                for (int jj = 0; jj < 4; ++jj) {
-                    bj[jj] = float4_t{0.f, 0.f, 0.f, 0.f};
-                    if (p.bias != nullptr) bj[jj] = *(const float4_t*)(p.bias + fw + 64 * P + 16 * jj + 4 * g);
-                }
+            for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
-                for (int tt = 0; tt < 2; ++tt) {
-                    const int i = 2 * (b >> 1) + tt;
-                    int pos = pos16 + 16 * i;
-                    pos = pos >= p.rot_T ? pos - p.rot_T : pos;
-                    const float* cs = p.rot_cs + (long)pos * 64 + 8 * g;          // (cos, sin) of dims 4 g .. 4 g + 3; + 32 floats: dims 16 + 4 g ..
-#pragma unroll
-                    for (int t = 0; t < 2; ++t) {
-                        const float4_t ca = *(const float4_t*)(cs + 32 * t), cb = *(const float4_t*)(cs + 32 * t + 4);
-                        const float cc[4] = {ca[0] * rqs, ca[2] * rqs, cb[0] * rqs, cb[2] * rqs}, ss[4] = {ca[1] * rqs, ca[3] * rqs, cb[1] * rqs, cb[3] * rqs};
-                        const float4_t lo = w4_acc_read(acc[i][4 * P + t]) + bj[t], hi = w4_acc_read(acc[i][4 * P + 2 + t]) + bj[2 + t];
-                        float4_t lo2, hi2;
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            lo2[r] = lo[r] * cc[r] - hi[r] * ss[r];
-                            hi2[r] = hi[r] * cc[r] + lo[r] * ss[r];
-                        }
-                        *(float4_t*)(scratch + (16 * tt + c16) * 256 + (((4 * t + g) ^ c16) << 4)) = lo2;
-                        *(float4_t*)(scratch + (16 * tt + c16) * 256 + (((4 * (t + 2) + g) ^ c16) << 4)) = hi2;
-                    }
-                }
-            } else {
-#pragma unroll
-                for (int tt = 0; tt < 2; ++tt)
-#pragma unroll
-                    for (int jj = 0; jj < 4; ++jj)
-                        *(float4_t*)(scratch + (16 * tt + c16) * 256 + (((4 * jj + g) ^ c16) << 4)) = acc[2 * (b >> 1) + tt][4 * (b & 1) + jj];
-            }
+                for (int jj = 0; jj < 4; ++jj)
+                    *(float4_t*)(scratch + (16 * tt + c16) * 256 + (((4 * jj + g) ^ c16) << 4)) = acc[2 * (b >> 1) + tt][4 * (b & 1) + jj];
         } else {
             // the lane's 32 features of one token: tiles j = 2 P, 2 P + 1
             const float16_t& a0 = acc[b >> 1][2 * (b & 1)];
@@ -774,24 +744,17 @@ __device__ __forceinline__ bool w4_epilogue(const GemmArgs& p, ACC& acc, int f0,
             if (b + 1 < 8) write_block(b + 1);
             const bool rot_here = rot && fw + P * 64 < p.rot_nfeat;
             const float rqs = fw + P * 64 < p.rot_qfeat ? p.rot_qscale : 1.0f;
-            // (T16: a rotated block arrives rotated, bias included - write_block)
-            const float bsel = (rot && T16 && rot_here) ? 0.0f : 1.0f;
 #pragma unroll
             for (int rr = 0; rr < 4; ++rr) {
                 float v[8];
-                if constexpr (rot && T16) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) { v[e] = fmaf(bq[P][e], bsel, lo[rr][e]); v[4 + e] = fmaf(bq[P][4 + e], bsel, hi[rr][e]); }
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) { v[e] = lo[rr][e] + bq[P][e]; v[4 + e] = hi[rr][e] + bq[P][4 + e]; }
-                }
+                for (int e = 0; e < 4; ++e) { v[e] = lo[rr][e] + bq[P][e]; v[4 + e] = hi[rr][e] + bq[P][4 + e]; }
                 if constexpr (has_res) {
                     const half8_t r8 = __builtin_bit_cast(half8_t, rres[rr]);
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] += p.res_scale * (float)r8[e];
                 }
-                if constexpr (rot && !T16) {
+                if constexpr (rot) {
                     if (rot_here) {
                         // rotary embedding of the packed Wqkv projection (see gemm_epilogue): the 64-feature pair is one head, lanes q < 4
                         // hold its first half, q >= 4 the second; the partner of dim d is dim d +- 32 = lane ^ 4, same index
@@ -930,6 +893,136 @@ __device__ __forceinline__ bool w4_epilogue16g(const GemmArgs& p, float4_t (&acc
                 const bool live = !MASKED || tw + 32 * blk + 8 * rr + tl < mlim;
                 if constexpr (!MASKED) { if (u >= W4_NOWG) park[u - W4_NOWG] = o[rr]; }
                 if ((!MASKED && u < W4_NOWG) || (MASKED && live)) __builtin_amdgcn_raw_buffer_store_b128(o[rr], orsrc, ovoff + (32 * blk + 8 * rr) * rowbytes, 0, 0);
+            }
+        }
+    };
+    if (tw + 128 <= mlim) {
+        if (p.bias != nullptr) blocks(std::false_type{}, std::true_type{});
+        else blocks(std::false_type{}, std::false_type{});
+        return true;
+    }
+    blocks(std::true_type{}, std::true_type{});
+    return false;
+}
+
+// The same idea for the other epilogues of the 16x16x32 stream (ACT x MODE 0 / 2 / 4; the fused residual, MODE 1, stays on w4_epilogue): bias,
+// rotary (lane-local partner, see w4_epilogue's note), activation, scale / clamp and the ONE rounding to fp16 happen in the accumulator
+// layout, stage by stage over the eight quads of a block; 8 bytes per quad cross the LDS (32 KiB per wave tile each way instead of 64 KiB),
+// and the units are w4_epilogue's (block b = 32 tokens x feature pair P, rr: row 32 i + 8 rr, 128 bytes at byte column 128 P), so the
+// parked rows and gemm_ktile16_st4w do not change. Block b = 4 KiB of the scratch, double buffered. Lane (g, c) writes the four halves of
+// quad (tt, jj) at r * 128 + 16 ((2 jj + (g >> 1)) ^ ((r >> 1) & 7)) + 8 (g & 1), r = 16 tt + c: the 64 lanes of a ds_write_b64 fall on 64
+// different 8-byte slots.
+template <int ACT, int MODE, typename PARK>
+__device__ __forceinline__ bool w4_epilogue16p(const GemmArgs& p, float4_t (&acc)[8][8], int f0, int t0, int wa, int wb, int lane, char* scratch,
+                                               PARK (&park)[W4_NPARK16], W4Store& st) {
+    static_assert((MODE & 1) == 0, "the fused residual is read in the store layout: w4_epilogue");
+    asm volatile("" : "+v"(lane));
+    const int g = lane >> 4, c16 = lane & 15;
+    const int tl = lane >> 3, q = lane & 7;
+    const int fw = f0 + wb * 128, tw = t0 + wa * 128;
+    const bool ident = p.row_div == 1 && p.row_s_hi == 1;
+    constexpr bool plain = (MODE & 4) == 0;
+    constexpr bool rot = (MODE & 2) != 0;
+    const int hi_u = ident ? 0 : t0 / p.row_div;
+    const int mlim = ident ? p.M : min(p.M, hi_u * p.row_div + p.row_lim);
+    const long o0 = ident ? (long)tw : (long)hi_u * p.row_s_hi + (long)(tw - hi_u * p.row_div) * p.row_s_lo;
+    const int rowbytes = (ident ? 1 : (int)p.row_s_lo) * p.ldo * 2;
+    half_t* const obase = p.out + o0 * p.ldo + fw;
+    const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc((void*)obase, 0, 0x7ffffff0, 0x00020000);
+    const int ovoff = tl * rowbytes + 16 * q;
+    {
+        const unsigned long long ob = (unsigned long long)obase;
+        st.srd = uint4_t{(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)ob),
+                         (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)(ob >> 32) & 0xffffu)), 0x7ffffff0u, 0x00020000u};
+        st.voff = (unsigned)ovoff;
+        st.rowb = (unsigned)__builtin_amdgcn_readfirstlane(rowbytes);
+    }
+    float4_t bj[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        bj[j] = float4_t{0.f, 0.f, 0.f, 0.f};
+        if (p.bias != nullptr) bj[j] = *(const float4_t*)(p.bias + fw + 16 * j + 4 * g);
+    }
+    const int pos16 = rot ? (tw + c16) % p.rot_T : 0;          // position of the lane's token in token tile 0 (rot_T >= 256: one wrap at most)
+    auto write_block = [&](int b, auto with_bias) {
+        const int P = b & 1;
+        char* const base = scratch + (b & 1) * 4096;
+        float4_t x[2][4];
+        w4_acc_read4(acc[2 * (b >> 1)], 4 * P, x[0]);
+        w4_acc_read4(acc[2 * (b >> 1) + 1], 4 * P, x[1]);
+        if constexpr (decltype(with_bias)::value) {
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) x[tt][jj] += bj[4 * P + jj];
+        }
+        if constexpr (rot) {
+            if (fw + P * 64 < p.rot_nfeat) {             // (wave uniform) this 64-feature pair is one rotated head: tiles jj = t (dims < 32) and t + 2
+                const float rqs = fw + P * 64 < p.rot_qfeat ? p.rot_qscale : 1.0f;
+#pragma unroll
+                for (int tt = 0; tt < 2; ++tt) {
+                    int pos = pos16 + 16 * (2 * (b >> 1) + tt);
+                    pos = pos >= p.rot_T ? pos - p.rot_T : pos;
+                    const float* cs = p.rot_cs + (long)pos * 64 + 8 * g;          // (cos, sin) of dims 4 g .. 4 g + 3; + 32 floats: dims 16 + 4 g ..
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) {
+                        const float4_t ca = *(const float4_t*)(cs + 32 * t), cb = *(const float4_t*)(cs + 32 * t + 4);
+                        const float cc[4] = {ca[0] * rqs, ca[2] * rqs, cb[0] * rqs, cb[2] * rqs}, ss[4] = {ca[1] * rqs, ca[3] * rqs, cb[1] * rqs, cb[3] * rqs};
+                        const float4_t lo = x[tt][t], hi = x[tt][t + 2];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            x[tt][t][r] = lo[r] * cc[r] - hi[r] * ss[r];
+                            x[tt][t + 2][r] = hi[r] * cc[r] + lo[r] * ss[r];
+                        }
+                    }
+                }
+            }
+        }
+        if constexpr (ACT != ACT_NONE) {
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) x[tt][jj][r] = apply_act<ACT>(x[tt][jj][r]);
+        }
+        if constexpr (!plain) {
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) x[tt][jj][r] = fminf(fmaxf(x[tt][jj][r] * p.scale, p.clamp_lo), p.clamp_hi);
+        }
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+            const int r = 16 * tt + c16, sw = (c16 >> 1) & 7;
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj)
+                *(uint2_t*)(base + r * 128 + (((2 * jj + (g >> 1)) ^ sw) << 4) + 8 * (g & 1)) =
+                    __builtin_bit_cast(uint2_t, __builtin_convertvector(x[tt][jj], half4_t));
+        }
+    };
+    auto blocks = [&](auto masked, auto with_bias) {
+        constexpr bool MASKED = decltype(masked)::value;
+        write_block(0, with_bias);
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            const int i = b >> 1, P = b & 1;
+            uint4_t o[4];
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                const int row = tl + 8 * rr;
+                o[rr] = *(const uint4_t*)(scratch + (b & 1) * 4096 + row * 128 + ((q ^ ((row >> 1) & 7)) << 4));
+            }
+            if (b + 1 < 8) write_block(b + 1, with_bias);
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                const int u = 4 * b + rr;
+                const bool live = !MASKED || tw + 32 * i + 8 * rr + tl < mlim;
+                if constexpr (!MASKED) { if (u >= W4_NOW16) park[u - W4_NOW16] = o[rr]; }
+                if ((!MASKED && u < W4_NOW16) || (MASKED && live))
+                    __builtin_amdgcn_raw_buffer_store_b128(o[rr], orsrc, ovoff + P * 128 + (32 * i + 8 * rr) * rowbytes, 0, 0);
             }
         }
     };
@@ -1188,6 +1281,7 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(GemmArgs p) {
         w4_settle(acc);
         // (a2: the A stage the last K-tile has just vacated - the next instance's D1 target - serves as the transposition scratch)
         if constexpr (G16) parked = w4_epilogue16g(p, acc, f0, t0, wa, wb, lane, smem + a2 + wdma, park, pst);
+        else if constexpr (T16 && (MODE & 1) == 0) parked = w4_epilogue16p<ACT, MODE>(p, acc, f0, t0, wa, wb, lane, smem + a2 + wdma, park, pst);
         else parked = w4_epilogue<ACT, GATED, MODE>(p, acc, f0, t0, wa, wb, lane, smem + a2 + wdma, park, pst);
 #ifdef BH_GEMM_STATS
         st_loop += st_b - st_a; st_epi += __builtin_readcyclecounter() - st_b; ++st_tiles;
