@@ -364,7 +364,7 @@ def main():
     ap.add_argument("--stagger", type=int, default=0, help="--tile16: cycles by which wave w leaves the K-tile's barrier late (times w)")
     ap.add_argument("--d2-every16", type=int, default=4, help="--tile16: MFMAs between the DMA pieces behind the barrier")
     ap.add_argument("--nowg", type=int, default=8, help="--tile16: of the 16 stores of a SwiGLU tile, those the epilogue issues itself")
-    ap.add_argument("--now16", type=int, default=20, help="--tile16: output rows (of 32 per lane) the epilogue stores itself; the rest is parked")
+    ap.add_argument("--now16", type=int, default=24, help="--tile16: output rows (of 32 per lane) the epilogue stores itself; the rest is parked")
     a = ap.parse_args()
     if a.tile16:
         kw = dict(barrier_at=a.barrier_at, read_every=a.read_every, d1_at=a.d1_at, d1_every=2 * a.d1_every, d2_every=a.d2_every16, stagger=a.stagger,
