@@ -221,6 +221,10 @@ int bh_lstm_q8_layer(const void* x, float bound, const float* w_ih, const float*
  *                kernel may take for its input span (default 64). All of them: identical bytes (tests).
  *   "gemm_path": 0 auto (default), 1 = register-staged 128x128x64 kernel only, 2 = never a 256x256x64 kernel, 3 = never the
  *                four-wave kernel (gemm_w4_kernel; the eight-wave one where it applies), 5 = the four-wave kernel for every legal shape.
+ *   "gemm_tile16": 1 (default) = the four-wave kernel's K-tile stream on 16x16x32 MFMAs with its epilogues in the accumulator layout,
+ *                0 = the 32x32x16 stream of rounds 4-5 (results agree to fp16 rounding: another accumulation order).
+ *                "gemm_order": 1 (default) = an XCD sweeps all feature groups of a block of token tiles before it moves on, 0 = token
+ *                blocks fastest; "gemm_gf": feature tiles per block of that order (0 = automatic). Same bytes either way.
  *   "lstm_q8_variant": geometry of the 8-bit recurrent kernel chosen at bh_encoder_create: 0 (default) = 12 / 16 units per wave,
  *                one workgroup per CU; 1 = 4 units per wave, three workgroups per CU; 2 = 12 units per wave compiled for two
  *                workgroups per CU, so that the recurrent kernels of two engines (two batches in flight) share every CU and each

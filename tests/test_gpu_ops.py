@@ -444,6 +444,31 @@ def test_linear_four_wave_kernel(M, N, K, gated, act, tile16):
     assert (got.float() - small.float()).abs().max().item() < 2e-2 + 2e-3 * small.float().abs().max().item()
 
 
+def test_linear_four_wave_kernel_work_order_does_not_change_bytes():
+    """"gemm_order" (feature groups or token blocks fastest inside an XCD's share) and "gemm_gf" (feature tiles per block) only change which
+    workgroup computes which output tile when: identical bytes, ragged token edge and a feature-tile count (6) that 4 does not divide included."""
+    from bonito_amd import decode
+    g = torch.Generator().manual_seed(77)
+    M, N, K = 20000 + 9, 1536, 512
+    x = (torch.randn(M, K, generator=g) * 0.5).half().to(dev())
+    w = (torch.randn(N, K, generator=g) * 0.2).half().to(dev())
+    outs = []
+    try:
+        decode.set_option("gemm_path", 5)
+        for order, gf in ((1, 0), (0, 0), (1, 1), (0, 8), (1, 2)):
+            decode.set_option("gemm_order", order)
+            decode.set_option("gemm_gf", gf)
+            outs.append(_linear(x, w))
+    finally:
+        decode.set_option("gemm_path", 0)
+        decode.set_option("gemm_order", 1)
+        decode.set_option("gemm_gf", 0)
+    for o in outs[1:]:
+        assert torch.equal(o, outs[0])
+    want = _linear_ref(x[:4096], w, None, 0, 0)
+    assert (outs[0][:4096].float() - want).abs().max().item() < 2e-2 + 2e-3 * want.abs().max().item()
+
+
 @pytest.mark.parametrize("tile16", [0, 1])
 def test_linear_four_wave_kernel_layouts_exactly(tile16):
     """X = I-like (one 1.0 per row) against an asymmetric W: every output is one W element exactly, so a permuted fragment row, a
