@@ -30,7 +30,7 @@ EXTRA_FLAGS = {"signal.hip": ["-ffp-contract=off"], "lstm_q8.hip": ["-ffp-contra
 # BH_EXTRA_GEMM_FLAGS (e.g. -DBH_GEMM_STATS: another GemmArgs layout + cycle stamps) is treated the same way (advisor, round 4: it used
 # to rebuild gemm.hip into the product object directory, and unsetting it did not rebuild - staleness is checked by mtime only).
 EXPERIMENT = bool(os.environ.get("BH_EXTRA_LSTM_FLAGS") or os.environ.get("BH_EXTRA_GEMM_FLAGS") or os.environ.get("BH_EXTRA_BEAM_FLAGS")
-                  or os.environ.get("BH_EXTRA_ATTN_FLAGS"))
+                  or os.environ.get("BH_EXTRA_ATTN_FLAGS") or os.environ.get("BH_EXTRA_CONV_FLAGS"))
 if EXPERIMENT:
     if os.environ.get("BH_EXTRA_LSTM_FLAGS"):
         EXTRA_FLAGS["lstm.hip"] = os.environ["BH_EXTRA_LSTM_FLAGS"].split()
@@ -38,11 +38,13 @@ if EXPERIMENT:
         EXTRA_FLAGS["gemm.hip"] = os.environ["BH_EXTRA_GEMM_FLAGS"].split()
     if os.environ.get("BH_EXTRA_BEAM_FLAGS"):
         EXTRA_FLAGS["beam.hip"] = os.environ["BH_EXTRA_BEAM_FLAGS"].split()
+    if os.environ.get("BH_EXTRA_CONV_FLAGS"):          # e.g. -DBH_CONV_EXPT_NOSTORE: conv_front3_kernel without its output stores (timing only)
+        EXTRA_FLAGS["conv.hip"] = os.environ["BH_EXTRA_CONV_FLAGS"].split()
     if os.environ.get("BH_EXTRA_ATTN_FLAGS"):          # e.g. -DBH_ATTN_EXPT: the elimination variants of attention_ring2_kernel (tools/attn_bench.py)
         EXTRA_FLAGS["attention.hip"] = os.environ["BH_EXTRA_ATTN_FLAGS"].split()
     OBJ = os.path.join(ROOT, "build", "obj_expt")
     LIB = os.path.join(ROOT, "bonito_amd", "libbonito_hip_expt.so")
-    sys.stderr.write("build.py: BH_EXTRA_LSTM_FLAGS / BH_EXTRA_GEMM_FLAGS / BH_EXTRA_BEAM_FLAGS / BH_EXTRA_ATTN_FLAGS set -> experimental library %s (the product library is not touched)\n" % LIB)
+    sys.stderr.write("build.py: BH_EXTRA_LSTM_FLAGS / BH_EXTRA_GEMM_FLAGS / BH_EXTRA_BEAM_FLAGS / BH_EXTRA_ATTN_FLAGS / BH_EXTRA_CONV_FLAGS set -> experimental library %s (the product library is not touched)\n" % LIB)
 
 
 def _newer(dst, srcs):
