@@ -418,7 +418,8 @@ def test_linear_four_wave_kernel(M, N, K, gated, act, tile16):
     16x16x32 kernels, so the bar is the tolerance of test_linear_plain, not bit equality with them), closeness to the 128-tile
     kernel, and identical bytes when run twice; shortest (4) and long (32) K-tile streams, one workgroup walking several output
     tiles, ragged last token tile, SwiGLU / swish / tanh epilogues with bias. `tile16`: the same kernel around the 16x16x32 K-tile
-    stream ("gemm_tile16": 64 float4 accumulators, W rows staged in natural order, another scratch write in the epilogue)."""
+    stream ("gemm_tile16", the default: 64 float4 accumulators, W rows staged in natural order, bias / activation / SwiGLU / scale-clamp
+    applied in the accumulator layout and fp16 through the LDS scratch)."""
     from bonito_amd import decode
     g = torch.Generator().manual_seed(M + K)
     x = (torch.randn(M, K, generator=g) * 0.5).half().to(dev())
