@@ -90,6 +90,58 @@ def test_generated_gemm_stream_matches_its_generator(tmp_path):
     assert front.index("%[san]") > front.rindex("%[ra0] offset") and "%[san]" not in behind       # the next K-tile's address replaces ra0 behind its last use
 
 
+def test_tile16_gemm_stream_waits_for_every_fragment_it_uses():
+    """An independent reading of the generated 16x16x32 K-tile streams (all variants in gemm_ktile16_mfma.inc): replay the instruction
+    text with the LDS return queue (reads return in order; `s_waitcnt lgkmcnt(n)` = at most n outstanding) and check that (i) no MFMA
+    reads a fragment register whose ds_read may still be in flight, (ii) no ds_read overwrites a register while an OLDER read into the
+    same register is still in flight, (iii) every accumulator is used exactly once per 32-deep slab, by the W tile / X tile pair its name
+    says, (iv) the barrier is preceded by lgkmcnt(0) and vmcnt(8), and nothing of the next K-tile's stage (addresses made from san / sbn)
+    is read in front of it."""
+    import os
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "bonito_amd", "csrc", "gemm_ktile16_mfma.inc")).read()
+    bodies = re.findall(r"asm volatile\(\"(.*?)\"\n\s*: ", text, flags=re.S)
+    assert len(bodies) == 8                      # plain, first, and the three parked-store flavours of each
+    for body in bodies:
+        ins = [ln.strip().strip('"').replace("\\n\\t", "").strip() for ln in body.splitlines()]
+        ins = [i for i in ins if i]
+        fifo, used, next_stage_addr = [], {}, set()
+        seen_barrier = False
+        for k, i in enumerate(ins):
+            m = re.match(r"v_mfma_f32_16x16x32_f16 %\[(c\d_\d)\], %\[(fb(\d)_(\d))\], %\[(fa(\d))\], (?:%\[(c\d_\d)\]|0)$", i)
+            if m:
+                c, fb, slab, j, fa, ti = m.group(1), m.group(2), int(m.group(3)), int(m.group(4)), m.group(5), int(m.group(6))
+                assert fb not in fifo and fa not in fifo, (k, i, fifo)
+                assert c == "c%d_%d" % (ti, j) and (m.group(7) in (None, c))
+                used.setdefault(c, []).append(slab)
+                continue
+            m = re.match(r"ds_read_b128 %\[(\w+)\], %\[(\w+)\] offset:\d+$", i)
+            if m:
+                assert m.group(1) not in fifo, (k, i)
+                if m.group(2) in next_stage_addr:
+                    assert seen_barrier, (k, i)
+                fifo.append(m.group(1))
+                continue
+            m = re.match(r"s_waitcnt lgkmcnt\((\d+)\)$", i)
+            if m:
+                del fifo[:max(0, len(fifo) - int(m.group(1)))]
+                continue
+            m = re.match(r"v_add_u32_e32 %\[(\w+)\], %\[(san|sbn)\], ", i)
+            if m:
+                next_stage_addr.add(m.group(1))
+                continue
+            m = re.match(r"v_add_u32_e32 %\[(\w+)\], %\[(sa|sb)\], ", i)
+            if m:
+                next_stage_addr.discard(m.group(1))
+                continue
+            if i == "s_barrier":
+                assert not fifo and ins[k - 1] == "s_waitcnt vmcnt(8)" and ins[k - 2] == "s_waitcnt lgkmcnt(0)"
+                seen_barrier = True
+        assert seen_barrier and not fifo                              # the stream ends with lgkmcnt(0)
+        assert len(used) == 64 and all(v == [0, 1] for v in used.values())
+
+
 @pytest.mark.parametrize("preset,name", [("plain", "ringstep3_mfma.inc"), ("paired", "ringstep3p_mfma.inc"), ("unrolled", "ringstep3u_mfma.inc"),
                                          ("rec", "ringstep3r_mfma.inc")])
 def test_ring_step_streams_match_their_generator(tmp_path, preset, name):
